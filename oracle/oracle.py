@@ -1,0 +1,387 @@
+"""
+oracle/oracle.py -- TEST INFRASTRUCTURE ONLY.
+
+numpy/ctypes front-end of the C restatement (oracle/pds_oracle.c) of the reference's least-squares
+path.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
+nothing under polars_ds_extension_amd/ does.
+
+Every function takes X as an (n, p) array (converted to column-major, the layout of the reference's
+`mat_slice`, src/num_ext/linear_regression.rs:433-434) and y as (n,) or (n, k).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_LIB_PATH = _HERE / "libpds_oracle.so"
+
+SOLVERS = {"qr": 0, "svd": 1, "choleskey": 2}
+SE_TYPES = {"se": 0, "hc0": 1, "hc1": 2, "hc2": 3, "hc3": 4}
+
+
+def build(force: bool = False) -> Path:
+    """Compile the C restatement with the committed Makefile (gcc)."""
+    src_m = max((_HERE / f).stat().st_mtime for f in ("pds_oracle.c", "pds_oracle_impl.inc", "pds_oracle.h"))
+    if force or not _LIB_PATH.exists() or _LIB_PATH.stat().st_mtime < src_m:
+        subprocess.check_call(["make", "-C", str(_HERE), "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not _LIB_PATH.exists():
+            build()
+        _lib = C.CDLL(str(_LIB_PATH))
+        for name in ("orc_ln_gamma",):
+            getattr(_lib, name).restype = C.c_double
+            getattr(_lib, name).argtypes = [C.c_double]
+        _lib.orc_beta_reg.restype = C.c_double
+        _lib.orc_beta_reg.argtypes = [C.c_double, C.c_double, C.c_double, C.POINTER(C.c_int)]
+        _lib.orc_inv_beta_reg.restype = C.c_double
+        _lib.orc_inv_beta_reg.argtypes = [C.c_double] * 3
+        _lib.orc_student_t_sf.restype = C.c_double
+        _lib.orc_student_t_sf.argtypes = [C.c_double, C.c_double, C.POINTER(C.c_int)]
+        _lib.orc_student_t_ppf.restype = C.c_double
+        _lib.orc_student_t_ppf.argtypes = [C.c_double, C.c_double]
+        _lib.orc_max_threads.restype = C.c_int
+    return _lib
+
+
+def _suf(dtype) -> str:
+    dtype = np.dtype(dtype)
+    if dtype == np.float64:
+        return "_f64"
+    if dtype == np.float32:
+        return "_f32"
+    raise TypeError(f"oracle supports float64/float32, got {dtype}")
+
+
+def _real(dtype):
+    return C.c_double if np.dtype(dtype) == np.float64 else C.c_float
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _prep(X, y=None, dtype=None):
+    X = np.asarray(X)
+    if dtype is None:
+        dtype = X.dtype if X.dtype in (np.float32, np.float64) else np.float64
+    Xf = np.asfortranarray(X, dtype=dtype)
+    if Xf.ndim != 2:
+        raise ValueError("X must be 2-D")
+    if y is None:
+        return Xf, None, np.dtype(dtype)
+    yf = np.asfortranarray(np.asarray(y, dtype=dtype))
+    return Xf, yf, np.dtype(dtype)
+
+
+def max_threads() -> int:
+    return int(lib().orc_max_threads())
+
+
+# ----------------------------------------------------------------------------- special functions
+def ln_gamma(x: float) -> float:
+    return float(lib().orc_ln_gamma(float(x)))
+
+
+def beta_reg(a: float, b: float, x: float) -> float:
+    err = C.c_int(0)
+    v = lib().orc_beta_reg(float(a), float(b), float(x), C.byref(err))
+    if err.value:
+        raise ValueError("beta_reg domain error")
+    return float(v)
+
+
+def inv_beta_reg(a: float, b: float, x: float) -> float:
+    return float(lib().orc_inv_beta_reg(float(a), float(b), float(x)))
+
+
+def student_t_sf(x: float, df: float) -> float:
+    err = C.c_int(0)
+    v = lib().orc_student_t_sf(float(x), float(df), C.byref(err))
+    return float("nan") if err.value else float(v)
+
+
+def student_t_ppf(q: float, df: float) -> float:
+    return float(lib().orc_student_t_ppf(float(q), float(df)))
+
+
+# ----------------------------------------------------------------------------- moments
+def gram(X, nthreads: int = 1) -> np.ndarray:
+    Xf, _, dt = _prep(X)
+    n, p = Xf.shape
+    out = np.zeros((p, p), dtype=dt, order="F")
+    fn = getattr(lib(), "orc_gram" + _suf(dt))
+    fn(_p(Xf), C.c_int64(n), C.c_int(p), _p(out), C.c_int(nthreads))
+    return out
+
+
+def gram_cols(cols, nthreads: int = 1) -> np.ndarray:
+    """Gram matrix of a list of separately allocated columns (the Arrow layout)."""
+    dt = np.dtype(cols[0].dtype)
+    cols = [np.ascontiguousarray(c, dtype=dt) for c in cols]
+    n, p = cols[0].shape[0], len(cols)
+    ptrs = (C.c_void_p * p)(*[c.ctypes.data for c in cols])
+    out = np.zeros((p, p), dtype=dt, order="F")
+    fn = getattr(lib(), "orc_gram_cols" + _suf(dt))
+    fn(ptrs, C.c_int64(n), C.c_int(p), _p(out), C.c_int(nthreads))
+    return out
+
+
+def xty(X, y, nthreads: int = 1) -> np.ndarray:
+    Xf, yf, dt = _prep(X, y)
+    n, p = Xf.shape
+    k = 1 if yf.ndim == 1 else yf.shape[1]
+    out = np.zeros((p, k), dtype=dt, order="F")
+    fn = getattr(lib(), "orc_xty" + _suf(dt))
+    fn(_p(Xf), _p(yf), C.c_int64(n), C.c_int(p), C.c_int(k), _p(out), C.c_int(nthreads))
+    return out[:, 0] if yf.ndim == 1 else out
+
+
+# ----------------------------------------------------------------------------- batch solvers
+def solve_lr(X, y, l2_reg=0.0, add_bias=False, solver="qr", nthreads=1) -> np.ndarray:
+    """faer_solve_lr.  X must already contain the ones column when add_bias."""
+    Xf, yf, dt = _prep(X, y)
+    n, p = Xf.shape
+    k = 1 if yf.ndim == 1 else yf.shape[1]
+    beta = np.zeros((p, k), dtype=dt, order="F")
+    fn = getattr(lib(), "orc_solve_lr" + _suf(dt))
+    fn(_p(Xf), _p(yf), C.c_int64(n), C.c_int(p), C.c_int(k), _real(dt)(l2_reg), C.c_int(bool(add_bias)),
+       C.c_int(SOLVERS.get(solver, 0)), _p(beta), C.c_int(nthreads))
+    return beta[:, 0] if yf.ndim == 1 else beta
+
+
+def solve_lr_gated(X, y, l2_reg=0.0, add_bias=False, solver="qr", tol=1e-12, nthreads=1):
+    """faer_solve_lr_gated: returns None when the rank gate fires."""
+    Xf, yf, dt = _prep(X, y)
+    n, p = Xf.shape
+    k = 1 if yf.ndim == 1 else yf.shape[1]
+    beta = np.zeros((p, k), dtype=dt, order="F")
+    fn = getattr(lib(), "orc_solve_lr_gated" + _suf(dt))
+    fn.restype = C.c_int
+    ok = fn(_p(Xf), _p(yf), C.c_int64(n), C.c_int(p), C.c_int(k), _real(dt)(l2_reg), C.c_int(bool(add_bias)),
+            C.c_int(SOLVERS.get(solver, 0)), _real(dt)(tol), _p(beta), C.c_int(nthreads))
+    if not ok:
+        return None
+    return beta[:, 0] if yf.ndim == 1 else beta
+
+
+def gated_solve_gram(G, c, solver="qr", tol=1e-12):
+    """Gate + solve on a prebuilt Gram matrix (lr_solvers.rs:339-381)."""
+    G = np.asfortranarray(G)
+    dt = G.dtype
+    b = np.asfortranarray(np.array(c, dtype=dt, copy=True))
+    k = 1 if b.ndim == 1 else b.shape[1]
+    fn = getattr(lib(), "orc_gated_solve_gram" + _suf(dt))
+    fn.restype = C.c_int
+    ok = fn(_p(G), C.c_int(G.shape[0]), _p(b), C.c_int(k), C.c_int(SOLVERS.get(solver, 0)), _real(dt)(tol))
+    return b if ok else None
+
+
+def solve_gram(G, c, solver="qr"):
+    G = np.asfortranarray(G)
+    dt = G.dtype
+    b = np.asfortranarray(np.array(c, dtype=dt, copy=True))
+    k = 1 if b.ndim == 1 else b.shape[1]
+    fn = getattr(lib(), "orc_solve_xtx_xty" + _suf(dt))
+    fn(_p(G), C.c_int(G.shape[0]), _p(b), C.c_int(k), C.c_int(SOLVERS.get(solver, 0)))
+    return b
+
+
+def qr_inverse(G) -> np.ndarray:
+    G = np.asfortranarray(G)
+    dt = G.dtype
+    p = G.shape[0]
+    return solve_gram(G, np.eye(p, dtype=dt), "qr")
+
+
+def solve_lr_rcond(X, y, l2_reg=0.0, add_bias=False, rcond=0.0, nthreads=1):
+    Xf, yf, dt = _prep(X, y)
+    n, p = Xf.shape
+    beta = np.zeros(p, dtype=dt)
+    sv = np.zeros(p, dtype=dt)
+    fn = getattr(lib(), "orc_solve_lr_rcond" + _suf(dt))
+    fn.restype = C.c_int
+    rc = fn(_p(Xf), _p(yf), C.c_int64(n), C.c_int(p), _real(dt)(l2_reg), C.c_int(bool(add_bias)),
+            _real(dt)(rcond), _p(beta), _p(sv), C.c_int(nthreads))
+    if rc:
+        raise RuntimeError("SVD failed.")
+    return beta, sv
+
+
+def weighted_lr(X, y, w, solver="qr") -> np.ndarray:
+    Xf, yf, dt = _prep(X, y)
+    wf = np.ascontiguousarray(w, dtype=dt)
+    n, p = Xf.shape
+    beta = np.zeros(p, dtype=dt)
+    fn = getattr(lib(), "orc_weighted_lr" + _suf(dt))
+    fn(_p(Xf), _p(yf), _p(wf), C.c_int64(n), C.c_int(p), C.c_int(SOLVERS.get(solver, 0)), _p(beta))
+    return beta
+
+
+def coordinate_descent(X, y, l1_reg, l2_reg, add_bias=False, tol=1e-5, max_iter=200, positive=False,
+                       nthreads=1, return_info=False):
+    Xf, yf, dt = _prep(X, y)
+    n, p = Xf.shape
+    beta = np.zeros(p, dtype=dt)
+    conv = C.c_int(0)
+    fn = getattr(lib(), "orc_coordinate_descent" + _suf(dt))
+    fn.restype = C.c_int
+    it = fn(_p(Xf), _p(yf), C.c_int64(n), C.c_int(p), _real(dt)(l1_reg), _real(dt)(l2_reg), C.c_int(bool(add_bias)),
+            _real(dt)(tol), C.c_int(max_iter), C.c_int(bool(positive)), _p(beta), C.byref(conv), C.c_int(nthreads))
+    if return_info:
+        return beta, int(it), bool(conv.value)
+    return beta
+
+
+def cd_from_gram(G, c, col_sums, y_sum, m, l1_reg, l2_reg, add_bias, tol, max_iter, positive=False):
+    G = np.asfortranarray(G)
+    dt = G.dtype
+    p = G.shape[0]
+    c = np.ascontiguousarray(c, dtype=dt)
+    cs = np.ascontiguousarray(col_sums, dtype=dt)
+    beta = np.zeros(p, dtype=dt)
+    conv = C.c_int(0)
+    fn = getattr(lib(), "orc_cd_from_gram" + _suf(dt))
+    fn.restype = C.c_int
+    R = _real(dt)
+    it = fn(_p(G), _p(c), _p(cs), R(y_sum), R(m), C.c_int(p), R(l1_reg), R(l2_reg), C.c_int(bool(add_bias)), R(tol),
+            C.c_int(max_iter), C.c_int(bool(positive)), _p(beta), C.byref(conv))
+    return beta, int(it), bool(conv.value)
+
+
+def nn_lr(X, y, add_bias=False, tol=1e-5, max_iter=200, nthreads=1) -> np.ndarray:
+    Xf, yf, dt = _prep(X, y)
+    n, p = Xf.shape
+    beta = np.zeros(p, dtype=dt)
+    fn = getattr(lib(), "orc_nn_lr" + _suf(dt))
+    fn.restype = C.c_int
+    fn(_p(Xf), _p(yf), C.c_int64(n), C.c_int(p), C.c_int(bool(add_bias)), _real(dt)(tol), C.c_int(max_iter),
+       _p(beta), C.c_int(nthreads))
+    return beta
+
+
+# ----------------------------------------------------------------------------- online solvers
+def recursive_lr(X, y, start_with: int, l2_reg=0.0) -> np.ndarray:
+    """faer_recursive_lr: (n - start_with + 1, p) coefficient rows."""
+    Xf, yf, dt = _prep(X, y)
+    n, p = Xf.shape
+    out = np.zeros((n - start_with + 1, p), dtype=dt)
+    fn = getattr(lib(), "orc_recursive_lr" + _suf(dt))
+    fn(_p(Xf), _p(yf), C.c_int64(n), C.c_int(p), C.c_int64(start_with), _real(dt)(l2_reg), _p(out))
+    return out
+
+
+def rolling_lr(X, y, window: int, l2_reg=0.0) -> np.ndarray:
+    """faer_rolling_lr (sequential Woodbury): (n - window + 1, p)."""
+    Xf, yf, dt = _prep(X, y)
+    n, p = Xf.shape
+    out = np.zeros((n - window + 1, p), dtype=dt)
+    fn = getattr(lib(), "orc_rolling_lr" + _suf(dt))
+    fn(_p(Xf), _p(yf), C.c_int64(n), C.c_int(p), C.c_int64(window), _real(dt)(l2_reg), _p(out))
+    return out
+
+
+def rolling_skipping_lr(X, y, window: int, min_size: int, l2_reg=0.0):
+    """faer_rolling_skipping_lr: returns (coeffs (m,p), valid (m,) bool)."""
+    Xf, yf, dt = _prep(X, y)
+    n, p = Xf.shape
+    out = np.zeros((n - window + 1, p), dtype=dt)
+    valid = np.zeros(n - window + 1, dtype=np.uint8)
+    fn = getattr(lib(), "orc_rolling_skipping_lr" + _suf(dt))
+    fn.restype = C.c_int64
+    m = fn(_p(Xf), _p(yf), C.c_int64(n), C.c_int(p), C.c_int64(window), C.c_int64(min_size), _real(dt)(l2_reg),
+           _p(out), _p(valid))
+    return out[:m], valid[:m].astype(bool)
+
+
+# ----------------------------------------------------------------------------- reports
+def _report_out(dt, p):
+    return [np.zeros(p, dtype=dt) for _ in range(6)]
+
+
+def lin_reg_report(X, y, y_var=None, std_err="se"):
+    """pl_lin_reg_report arithmetic.  y_var defaults to var(y, ddof=1) (expr_linear.py:614-617)."""
+    Xf, yf, dt = _prep(X, y)
+    n, p = Xf.shape
+    if y_var is None:
+        y_var = float(np.var(yf.astype(np.float64), ddof=1))
+    outs = _report_out(dt, p)
+    R = _real(dt)
+    r2, adj = R(0), R(0)
+    fn = getattr(lib(), "orc_lin_reg_report" + _suf(dt))
+    fn(_p(Xf), _p(yf), C.c_int64(n), C.c_int(p), R(y_var), C.c_int(SE_TYPES[std_err]), *[_p(o) for o in outs],
+       C.byref(r2), C.byref(adj))
+    keys = ["beta", "std_err", "t", "p", "ci_lo", "ci_hi"]
+    d = dict(zip(keys, outs))
+    d["r2"], d["adj_r2"] = r2.value, adj.value
+    return d
+
+
+def wls_report(X, y, w, y_var=None):
+    Xf, yf, dt = _prep(X, y)
+    wf = np.ascontiguousarray(w, dtype=dt)
+    n, p = Xf.shape
+    if y_var is None:
+        y_var = float(np.var(yf.astype(np.float64), ddof=1))
+    outs = _report_out(dt, p)
+    R = _real(dt)
+    r2, adj = R(0), R(0)
+    fn = getattr(lib(), "orc_wls_report" + _suf(dt))
+    fn(_p(Xf), _p(yf), _p(wf), C.c_int64(n), C.c_int(p), R(y_var), *[_p(o) for o in outs], C.byref(r2), C.byref(adj))
+    keys = ["beta", "std_err", "t", "p", "ci_lo", "ci_hi"]
+    d = dict(zip(keys, outs))
+    d["r2"], d["adj_r2"] = r2.value, adj.value
+    return d
+
+
+# ----------------------------------------------------------------------------- plugin-level restatement
+def with_bias(X) -> np.ndarray:
+    """Append the ones column the way series_to_mat_for_lr does (linear_regression.rs:180-182)."""
+    X = np.asarray(X)
+    return np.column_stack([X, np.ones(X.shape[0], dtype=X.dtype)])
+
+
+def lr_methods(l1_reg: float, l2_reg: float) -> str:
+    """LRMethods::from((l1, l2)) -- src/linear/lr/mod.rs:52-64."""
+    if l1_reg > 0 and l2_reg <= 0:
+        return "l1"
+    if l1_reg <= 0 and l2_reg > 0:
+        return "l2"
+    if l1_reg > 0 and l2_reg > 0:
+        return "elastic"
+    return "normal"
+
+
+def pl_lr(X, y, *, add_bias=False, l1_reg=0.0, l2_reg=0.0, solver="qr", tol=1e-5, max_iter=200, positive=False,
+          singular_x_tol=1e-12, weights=None, f32_path=False):
+    """
+    The dispatch of pl_lr (linear_regression.rs:436-498) on null-free data.  Returns the coefficient
+    vector or None (null list) when the gate fires.  f32_path replicates the f32 twin's hard-coded
+    iteration caps (linear_regression_f32.rs:343,351,362).
+    """
+    Xb = with_bias(X) if add_bias else np.asarray(X)
+    if weights is not None:
+        return weighted_lr(Xb, y, weights, solver)
+    m = lr_methods(l1_reg, l2_reg)
+    if m in ("normal", "l2") and not positive:
+        if singular_x_tol > 0:
+            return solve_lr_gated(Xb, y, l2_reg, add_bias, solver, singular_x_tol)
+        return solve_lr(Xb, y, l2_reg, add_bias, solver)
+    if m == "normal" and positive:
+        return nn_lr(Xb, y, add_bias, tol, 200 if f32_path else max_iter)
+    cd_iter = 2000 if f32_path else max_iter
+    if m == "l2" and positive:
+        return coordinate_descent(Xb, y, 0.0, l2_reg, add_bias, tol, cd_iter, True)
+    return coordinate_descent(Xb, y, l1_reg, l2_reg, add_bias, tol, cd_iter, positive)

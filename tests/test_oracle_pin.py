@@ -1,0 +1,259 @@
+"""
+Pins the CPU oracle (oracle/pds_oracle.c) BEFORE it is trusted as the checker:
+  (1) literal reference outputs printed in the reference's examples/basics.ipynb (6 digits),
+  (2) the literal frames of the reference's own tests (tests/test_linear_exprs.py),
+  (3) numpy / scipy / scikit-learn on the reference's seeded fixtures, with the reference's tolerances.
+No GPU needed.
+"""
+import numpy as np
+import pytest
+from scipy import stats
+
+
+# ------------------------------------------------------------------ (1) notebook golden vectors
+def test_golden_pred_resid_head(orc, golden):
+    # examples/basics.ipynb cell "return_pred=True": pred = X beta with the full-frame beta.
+    g = golden["pred_head"]
+    beta = np.array(golden["lin_reg_full_frame_coeffs"])
+    X = np.c_[g["x1"], g["x2"]]
+    pred = X @ beta
+    np.testing.assert_allclose(pred, g["pred"], atol=2e-6)
+    np.testing.assert_allclose(np.array(g["y"]) - pred, g["resid"], atol=2e-6)
+
+
+def test_golden_rolling_window5(orc, golden):
+    # rolling_lin_reg(window_size=5): row 4 = OLS on rows 0..4, pred = x_4 . beta_4
+    for part in ("rolling_w5_head", "rolling_w5_tail"):
+        rowsd = golden[part]
+        X = np.array([[r["x1"], r["x2"]] for r in rowsd])
+        y = np.array([r["y"] for r in rowsd])
+        co = orc.rolling_lr(X, y, 5)
+        assert co.shape == (1, 2)
+        np.testing.assert_allclose(co[0], rowsd[4]["coeffs"], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(X[4] @ co[0], rowsd[4]["pred"], rtol=2e-5, atol=2e-6)
+        assert all(r["coeffs"] is None for r in rowsd[:4]) or part.endswith("tail")
+
+
+# ------------------------------------------------------------------ (2) literal frames of the reference tests
+def test_literal_skip_null_frame(orc):
+    # tests/test_linear_exprs.py:411-432 -- y = x1 + x2 + 3.5... wait: literal frame, row 0 has a null
+    # x1 = [None,2,3,4,5], x2 = [1,...], y = x1 + x2 ... the test pins pred [None,9.5,10.5,11.5,12.5].
+    x = np.array([[2.0, 3.0, 4.0, 5.0], [4.0, 4.0, 4.0, 4.0]]).T
+    y = np.array([9.5, 10.5, 11.5, 12.5])
+    # rank-deficient with a constant column + bias is avoided: fit y = b*x1 + c (bias) like the test
+    b = orc.pl_lr(x[:, :1], y, add_bias=True)
+    np.testing.assert_allclose(np.c_[x[:, :1], np.ones(4)] @ b, y, atol=1e-12)
+
+
+def test_linear_impute_frame(orc):
+    # tests/test_transforms.py:33-48: integer a,b ; c = a+b  => beta = [1,1]
+    a = np.array([1.0, 2.0, 3.0, 4.0, 5.0])
+    b = np.array([5.0, 1.0, 2.0, 7.0, 1.0])
+    beta = orc.pl_lr(np.c_[a, b], a + b, add_bias=False)
+    np.testing.assert_allclose(beta, [1.0, 1.0], atol=1e-12)
+
+
+# ------------------------------------------------------------------ (3) seeded fixtures / library cross-checks
+def test_single_big_fit_vs_sklearn(orc):
+    # tests/test_linear_exprs.py:1116-1142 (rng 5, N=50_000, p=6, bias): rtol 1e-8, atol 1e-10
+    from sklearn.linear_model import LinearRegression
+
+    rng = np.random.default_rng(5)
+    n, p = 50_000, 6
+    X = rng.normal(size=(n, p))
+    y = X @ rng.normal(size=p) + 1.5 + rng.normal(size=n) * 0.1
+    sk = LinearRegression().fit(X, y)
+    for solver in ("qr", "svd", "choleskey"):
+        b = orc.pl_lr(X, y, add_bias=True, solver=solver)
+        np.testing.assert_allclose(b[:-1], sk.coef_, rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(b[-1], sk.intercept_, rtol=1e-8, atol=1e-10)
+
+
+def test_bias_equals_manual_ones_column(orc):
+    # tests/test_linear_exprs.py:956-981, rtol 1e-10
+    rng = np.random.default_rng(1)
+    X = rng.normal(size=(1000, 4))
+    y = X @ [1.0, -2.0, 0.5, 3.0] + 0.7 + rng.normal(size=1000) * 0.01
+    b1 = orc.pl_lr(X, y, add_bias=True)
+    b2 = orc.pl_lr(np.c_[X, np.ones(1000)], y, add_bias=False)
+    np.testing.assert_allclose(b1, b2, rtol=1e-10)
+
+
+def test_ridge_vs_closed_form(orc):
+    rng = np.random.default_rng(11)
+    X = rng.normal(size=(2000, 5))
+    y = X @ rng.normal(size=5) + rng.normal(size=2000)
+    lam = 0.1
+    b = orc.pl_lr(X, y, l2_reg=lam, add_bias=True)
+    Xb = np.c_[X, np.ones(2000)]
+    D = np.eye(6) * lam
+    D[5, 5] = 0.0  # bias is not penalised: lr_solvers.rs:199-209
+    np.testing.assert_allclose(b, np.linalg.solve(Xb.T @ Xb + D, Xb.T @ y), rtol=1e-10)
+
+
+def test_rcond_vs_numpy_lstsq(orc):
+    # tests/test_linear_exprs.py:477-512: np.linalg.lstsq(rcond=0.3), abs 1e-10
+    rng = np.random.default_rng(123)
+    X = rng.normal(size=(5000, 3))
+    y = X @ [0.3, -0.2, 1.1] + rng.normal(size=5000) * 0.1
+    b, sv = orc.solve_lr_rcond(X, y, rcond=max(0.3, np.finfo(float).eps * 5000))
+    ref, _, _, s = np.linalg.lstsq(X, y, rcond=0.3)
+    np.testing.assert_allclose(sv, s, rtol=1e-10)
+    np.testing.assert_allclose(b, ref, atol=1e-10)
+
+
+def test_gate_collinear_and_scaled(orc):
+    # tests/test_linear_exprs.py:1184-1340 -- collinear -> null, tol=0 -> finite, well-conditioned unchanged
+    rng = np.random.default_rng(0)
+    x1 = rng.normal(size=200)
+    X = np.c_[x1, 2.0 * x1, rng.normal(size=200)]
+    y = rng.normal(size=200)
+    for dt, tol in ((np.float64, 1e-12), (np.float32, 1e-6)):
+        for solver in ("qr", "svd", "choleskey"):
+            assert orc.pl_lr(X.astype(dt), y.astype(dt), solver=solver, singular_x_tol=tol) is None
+        out = orc.pl_lr(X.astype(dt), y.astype(dt), singular_x_tol=0.0)
+        assert out is not None and out.shape == (3,)
+    Xs = rng.normal(size=(500, 7)) * 1e3  # large-scale features: raw det overflows f32, log-space does not
+    ys = Xs @ rng.normal(size=7) + rng.normal(size=500)
+    for dt, tol, rt in ((np.float64, 1e-12, 1e-9), (np.float32, 1e-6, 2e-3)):
+        b = orc.pl_lr(Xs.astype(dt), ys.astype(dt), add_bias=True, singular_x_tol=tol)
+        assert b is not None
+        ref = np.linalg.lstsq(np.c_[Xs, np.ones(500)], ys, rcond=None)[0]
+        np.testing.assert_allclose(b[:-1], ref[:-1], rtol=rt)
+
+
+def test_lasso_elastic_nnls_vs_sklearn(orc):
+    # tests/test_linear_exprs.py:557-715: abs 1e-4 / 1e-5 against sklearn
+    from sklearn.linear_model import ElasticNet, Lasso, LinearRegression
+
+    rng = np.random.default_rng(42)
+    X = rng.random(size=(5000, 3))
+    y = X @ [0.2, 0.3, -0.1] + rng.random(size=5000) * 1e-4
+    for bias in (False, True):
+        b = orc.pl_lr(X, y, l1_reg=0.01, add_bias=bias, tol=1e-7, max_iter=2000)
+        sk = Lasso(alpha=0.01, fit_intercept=bias, tol=1e-10, max_iter=10000).fit(X, y)
+        np.testing.assert_allclose(b[:3], sk.coef_, atol=1e-4)
+        if bias:
+            np.testing.assert_allclose(b[3], sk.intercept_, atol=1e-4)
+        l1, l2 = 0.01, 0.02
+        b = orc.pl_lr(X, y, l1_reg=l1, l2_reg=l2, add_bias=bias, tol=1e-7, max_iter=2000)
+        sk = ElasticNet(alpha=l1 + l2, l1_ratio=l1 / (l1 + l2), fit_intercept=bias, tol=1e-10, max_iter=10000).fit(X, y)
+        np.testing.assert_allclose(b[:3], sk.coef_, atol=1e-4)
+    b = orc.pl_lr(X, y, positive=True, add_bias=False, tol=1e-9, max_iter=5000)
+    sk = LinearRegression(positive=True, fit_intercept=False).fit(X, y)
+    np.testing.assert_allclose(b, sk.coef_, atol=1e-5)
+
+
+def test_recursive_and_rolling_vs_direct(orc):
+    # tests/test_linear_exprs.py:718-854: recursive row i-1 == lin_reg on first i rows; rolling == per window
+    rng = np.random.default_rng(3)
+    X = rng.random(size=(500, 3))
+    y = X @ [0.2, 0.3, -0.1] + rng.random(size=500) * 0.1
+    rec = orc.recursive_lr(X, y, 3)
+    for i in range(3, 30):
+        ref = np.linalg.lstsq(X[:i], y[:i], rcond=None)[0]
+        np.testing.assert_allclose(rec[i - 3], ref, atol=1e-5)
+    for w in (5, 8, 12, 15):
+        rol = orc.rolling_lr(X, y, w)
+        ref = np.array([np.linalg.lstsq(X[i - w + 1 : i + 1], y[i - w + 1 : i + 1], rcond=None)[0] for i in range(w - 1, 500)])
+        np.testing.assert_allclose(rol, ref, rtol=1e-5, atol=1e-8)
+        lam = 0.1  # ridge variant penalises every diagonal incl. a bias column
+        rolr = orc.rolling_lr(X, y, w, lam)
+        refr = np.array(
+            [np.linalg.solve(X[i - w + 1 : i + 1].T @ X[i - w + 1 : i + 1] + lam * np.eye(3), X[i - w + 1 : i + 1].T @ y[i - w + 1 : i + 1]) for i in range(w - 1, 500)]
+        )
+        np.testing.assert_allclose(rolr, refr, rtol=1e-5, atol=1e-8)
+
+
+def test_rolling_skipping_mask(orc):
+    # tests/test_linear_exprs.py:858-908: validity pattern under skip / min_valid_rows
+    rng = np.random.default_rng(9)
+    X = rng.random(size=(60, 2))
+    y = X @ [1.0, -1.0] + rng.random(size=60) * 0.01
+    X[[3, 4, 5, 20, 41], 0] = np.nan
+    w, m = 6, 4
+    co, valid = orc.rolling_skipping_lr(X, y, w, m)
+    fin = np.isfinite(X).all(axis=1) & np.isfinite(y)
+    assert len(valid) == 60 - w + 1
+    for i in range(len(valid)):
+        cnt = fin[i : i + w].sum()
+        assert valid[i] == (cnt >= m)
+        if valid[i]:
+            rows_ = np.arange(i, i + w)[fin[i : i + w]]
+            ref = np.linalg.lstsq(X[rows_], y[rows_], rcond=None)[0]
+            np.testing.assert_allclose(co[i], ref, rtol=1e-6, atol=1e-8)
+
+
+def test_report_vs_closed_forms(orc):
+    # tests/test_linear_exprs.py:169-201 (statsmodels is absent -> closed forms), :984-1028 (np.lstsq rtol 1e-10)
+    rng = np.random.default_rng(2)
+    n, p = 5000, 4
+    X = np.c_[rng.normal(size=(n, p - 1)), np.ones(n)]
+    y = X @ [0.5, -1.0, 0.0, 2.0] + rng.normal(size=n) * (0.5 + np.abs(X[:, 0]))
+    ref = np.linalg.lstsq(X, y, rcond=None)[0]
+    inv = np.linalg.inv(X.T @ X)
+    e = y - X @ ref
+    A = inv @ X.T
+    h = np.einsum("ij,ji->i", X, A)
+    dof = n - p
+    forms = {
+        "se": np.sqrt(e @ e / dof * np.diag(inv)),
+        "hc0": np.sqrt(np.diag((A * e**2) @ A.T)),
+        "hc1": np.sqrt(np.diag((A * e**2) @ A.T) * n / (n - p)),
+        "hc2": np.sqrt(np.diag((A * (e**2 / (1 - h))) @ A.T)),
+        "hc3": np.sqrt(np.diag((A * (e**2 / (1 - h) ** 2)) @ A.T)),
+    }
+    for k, se in forms.items():
+        r = orc.lin_reg_report(X, y, std_err=k)
+        np.testing.assert_allclose(r["beta"], ref, rtol=1e-10)
+        np.testing.assert_allclose(r["std_err"], se, rtol=1e-9)
+        t = ref / se
+        np.testing.assert_allclose(r["t"], t, rtol=1e-8)
+        np.testing.assert_allclose(r["p"], 2 * stats.t.sf(np.abs(t), dof), rtol=1e-8, atol=1e-300)
+        ta = stats.t.ppf(0.975, dof)
+        np.testing.assert_allclose(r["ci_lo"], ref - ta * se, rtol=1e-6, atol=1e-9)
+    yv = np.var(y, ddof=1)
+    r = orc.lin_reg_report(X, y)
+    assert abs(r["r2"] - (1 - e @ e / (yv * n))) < 1e-12  # ddof=1 variance times N, as in the reference
+
+
+def test_wls_vs_numpy(orc):
+    rng = np.random.default_rng(3)
+    n = 3000
+    X = np.c_[rng.normal(size=(n, 3)), np.ones(n)]
+    w = rng.random(size=n) + 0.1
+    y = X @ [1.0, 2.0, -1.0, 0.3] + rng.normal(size=n) / np.sqrt(w)
+    ref = np.linalg.solve(X.T @ (X * w[:, None]), X.T @ (w * y))
+    np.testing.assert_allclose(orc.weighted_lr(X, y, w), ref, rtol=1e-10)
+    r = orc.wls_report(X, y, w)
+    np.testing.assert_allclose(r["beta"], ref, rtol=1e-10)
+    e = y - X @ ref
+    se = np.sqrt((w * e**2).sum() / (n - 4) * np.diag(np.linalg.inv(X.T @ (X * w[:, None]))))
+    np.testing.assert_allclose(r["std_err"], se, rtol=1e-9)
+
+
+def test_special_functions_vs_scipy(orc):
+    # restated src/stats_utils: <=2e-12 against scipy for dof <= 1e4 (SURVEY 8c iii)
+    for dof in (3.0, 10.0, 97.0, 4995.0, 1e4):
+        for t in (0.0, 0.3, 1.0, 1.96, 4.0, 12.0):
+            np.testing.assert_allclose(orc.student_t_sf(t, dof), stats.t.sf(t, dof), rtol=5e-12, atol=1e-300)
+        np.testing.assert_allclose(orc.student_t_ppf(0.975, dof), stats.t.ppf(0.975, dof), rtol=1e-9)
+    from scipy.special import gammaln
+
+    for x in (0.1, 0.5, 1.0, 7.3, 250.0, 5e7):
+        np.testing.assert_allclose(orc.ln_gamma(x), gammaln(x), rtol=1e-14, atol=1e-14)
+    # reference defect: the AS109 loop never terminates for dof > ~1.42e7; the oracle returns NaN
+    assert np.isnan(orc.student_t_ppf(0.975, 1e8))
+    # the documented accuracy loss of the reference algorithm at huge dof: ~1e-7 relative
+    assert abs(orc.student_t_sf(1.96, 1e8) / stats.t.sf(1.96, 1e8) - 1) < 5e-7
+
+
+def test_f32_matches_f64_within_reference_tolerance(orc):
+    # tests/test_linear_exprs.py:313-373: f32 vs sklearn abs 1e-4 / 1e-3
+    rng = np.random.default_rng(8)
+    X = rng.random(size=(5000, 3))
+    y = X @ [0.2, 0.3, -0.1] + 0.5 + rng.random(size=5000) * 1e-3
+    b64 = orc.pl_lr(X, y, add_bias=True)
+    b32 = orc.pl_lr(X.astype(np.float32), y.astype(np.float32), add_bias=True, singular_x_tol=1e-6)
+    assert b32.dtype == np.float32
+    np.testing.assert_allclose(b32, b64, atol=1e-3)
