@@ -1,0 +1,220 @@
+/*
+ * include/pds_lstsq.h -- C ABI of libpds_lstsq_hip.so, the MI355X (gfx950) implementation of the
+ * polars_ds least-squares expression path.
+ *
+ * This is the drop-in boundary: the entry points are what the reference's Rust plugin functions
+ * (`#[polars_expr] fn pl_lr / pl_lr_pred / pl_lin_reg_report / pl_rolling_lr / pl_recursive_lr`,
+ * /root/reference/src/num_ext/linear_regression.rs:419,704,822,1121,1206 and the *_f32 twins in
+ * linear_regression_f32.rs) would bind over `extern "C"` after unwrapping the Arrow column buffers.
+ * They replace the calls those functions make into src/linear/lr/lr_solvers.rs and
+ * src/linear/online_lr/lr_online_solvers.rs.  INTEGRATION.md shows the Rust-side binding.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / HIP types in any signature.
+ *   - `cols` is an array (in HOST memory) of n_feat + 1 column pointers in the reference's input
+ *     order [y, x1, ..., xp] (expr_linear.py:250-258; weighted variants take `weights` separately).
+ *     Each column is a contiguous buffer of n_rows values, exactly an Arrow Float64/Float32 values
+ *     buffer.  `space` says where the column *buffers* live (PDS_HOST: host memory, staged to HBM in
+ *     row chunks through pinned buffers; PDS_DEVICE: already resident in HBM).
+ *   - output buffers are host memory unless the parameter is documented "space-resident".
+ *   - every function returns PDS_OK (0) or a negative pds_status; pds_last_error() returns the
+ *     message (thread-local), with the reference's error strings where the reference has one.
+ *   - all launches go to the stream of the context (pds_ctx_set_stream); calls are synchronous with
+ *     respect to the host on return (results are ready), except the *_async moment builders.
+ *   - f64 symbols end in _f64, the f32 twins in _f32 (LIN_REG_EXPR_F64=False path, config.py:15-16).
+ */
+#ifndef PDS_LSTSQ_H
+#define PDS_LSTSQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pds_ctx pds_ctx; /* opaque: device, stream, HBM workspace, pinned staging */
+
+typedef enum { PDS_HOST = 0, PDS_DEVICE = 1 } pds_space;
+
+typedef enum {
+    PDS_OK = 0,
+    PDS_ERR_INVALID = -1,     /* bad argument */
+    PDS_ERR_EMPTY = -2,       /* "Empty data"                       linear_regression.rs:167 */
+    PDS_ERR_TOO_FEW_ROWS = -3, /* "#Data < #features. No conclusive result."          :170-172 */
+    PDS_ERR_HIP = -4,         /* HIP runtime failure / no gfx950 device */
+    PDS_ERR_UNSUPPORTED = -5,
+    PDS_ERR_NUMERIC = -6      /* e.g. "SVD failed."                 lr_solvers.rs:256 */
+} pds_status;
+
+/* LRSolverMethods::from(&str): "qr" (default, also any unknown string), "svd", "choleskey"
+ * (src/linear/lr/mod.rs:17-26 -- the misspelling is the reference's). */
+typedef enum { PDS_SOLVER_QR = 0, PDS_SOLVER_SVD = 1, PDS_SOLVER_CHOLESKEY = 2 } pds_solver;
+
+/* StandardError::from(String): linear_regression.rs:113-132 */
+typedef enum { PDS_SE = 0, PDS_HC0 = 1, PDS_HC1 = 2, PDS_HC2 = 3, PDS_HC3 = 4 } pds_se_type;
+
+/* ---- library / context ------------------------------------------------------------------- */
+const char* pds_last_error(void);
+const char* pds_version(void);
+/* Creates a context on HIP device `device` (must be gfx950).  */
+int pds_ctx_create(int device, pds_ctx** out);
+void pds_ctx_destroy(pds_ctx* ctx);
+/* Use an existing hipStream_t (passed as void*) for all work of this context; NULL = own stream. */
+int pds_ctx_set_stream(pds_ctx* ctx, void* hip_stream);
+int pds_ctx_synchronize(pds_ctx* ctx);
+/* Number of compute units of the context's device (256 on MI355X). */
+int pds_ctx_num_cus(const pds_ctx* ctx);
+
+/* ---- LRKwargs mirror (linear_regression.rs:27-45), minus the strings parsed by the host ---- */
+typedef struct {
+    int add_bias;          /* kwargs.bias */
+    double l1_reg;         /* kwargs.l1_reg */
+    double l2_reg;         /* kwargs.l2_reg */
+    double tol;            /* kwargs.tol (CD / NNLS convergence; rcond for pds_lr_rcond) */
+    int solver;            /* pds_solver, from kwargs.solver */
+    int positive;          /* kwargs.positive */
+    int max_iter;          /* kwargs.max_iter (the f32 twin ignores it: 2000 CD / 200 NNLS) */
+    double singular_x_tol; /* kwargs.singular_x_tol: > 0 enables the log-det rank gate */
+} pds_lr_params;
+
+/*
+ * pds_lr_*: the compute part of `pl_lr` (linear_regression.rs:419-513; f32: linear_regression_f32.rs
+ * :289-384) on null-free columns: dispatch on (LRMethods::from((l1,l2)), positive) exactly as
+ * :447-497, i.e. faer_solve_lr_gated / faer_solve_lr / faer_nn_lr / faer_coordinate_descent, or
+ * faer_weighted_lr when `weights` != NULL (lr_solvers.rs:386-409).
+ *   coeffs   out, n_feat + add_bias values (bias last).
+ *   is_null  out, 1 when the rank gate fired (the reference returns a 1-row null list,
+ *            linear_regression.rs:462-468); coeffs is then filled with NaN.
+ */
+int pds_lr_f64(pds_ctx* ctx, const double* const* cols, const double* weights, int n_feat,
+               int64_t n_rows, pds_space space, const pds_lr_params* prm, double* coeffs,
+               int* is_null);
+int pds_lr_f32(pds_ctx* ctx, const float* const* cols, const float* weights, int n_feat,
+               int64_t n_rows, pds_space space, const pds_lr_params* prm, float* coeffs,
+               int* is_null);
+
+/*
+ * pds_lr_pred_*: `pl_lr_pred` (linear_regression.rs:704-820): same fit, then pred = X b and
+ * resid = y - pred for every row.  pred/resid are `space`-resident buffers of n_rows values.
+ */
+int pds_lr_pred_f64(pds_ctx* ctx, const double* const* cols, const double* weights, int n_feat,
+                    int64_t n_rows, pds_space space, const pds_lr_params* prm, double* coeffs,
+                    int* is_null, double* pred, double* resid);
+int pds_lr_pred_f32(pds_ctx* ctx, const float* const* cols, const float* weights, int n_feat,
+                    int64_t n_rows, pds_space space, const pds_lr_params* prm, float* coeffs,
+                    int* is_null, float* pred, float* resid);
+
+/*
+ * pds_lr_rcond_*: `pl_lr_w_rcond` -> faer_solve_lr_rcond (lr_solvers.rs:216-258).
+ * rcond is max(kwargs.tol, eps * max(n, p')) as computed by the caller (linear_regression.rs:651-702).
+ */
+int pds_lr_rcond_f64(pds_ctx* ctx, const double* const* cols, int n_feat, int64_t n_rows,
+                     pds_space space, int add_bias, double l2_reg, double rcond, double* coeffs,
+                     double* singular_values);
+
+/*
+ * pds_lin_reg_report_*: the arithmetic of `pl_lin_reg_report` (linear_regression.rs:822-980) and, with
+ * weights != NULL, `pl_wls_report` (:982-1117).  y_var is inputs[0][0] of the expression
+ * (`target.var()`, ddof = 1, computed by Polars; expr_linear.py:614-617).  Each output has
+ * n_feat + add_bias entries; r2 / adj_r2 are scalars (the reference broadcasts them).
+ */
+typedef struct {
+    double* beta;
+    double* std_err;
+    double* t;
+    double* p;
+    double* ci_lower; /* "0.025" */
+    double* ci_upper; /* "0.975" */
+    double r2;
+    double adj_r2;
+} pds_report_f64;
+typedef struct {
+    float* beta;
+    float* std_err;
+    float* t;
+    float* p;
+    float* ci_lower;
+    float* ci_upper;
+    float r2;
+    float adj_r2;
+} pds_report_f32;
+int pds_lin_reg_report_f64(pds_ctx* ctx, const double* const* cols, const double* weights,
+                           int n_feat, int64_t n_rows, pds_space space, int add_bias, int se_type,
+                           double y_var, pds_report_f64* out);
+int pds_lin_reg_report_f32(pds_ctx* ctx, const float* const* cols, const float* weights,
+                           int n_feat, int64_t n_rows, pds_space space, int add_bias, int se_type,
+                           float y_var, pds_report_f32* out);
+
+/*
+ * pds_lr_grouped_*: the key-aware batched symbol of SURVEY.md 8(b) ("pl_lr_by"): what
+ * `df.group_by(key).agg(pds.lin_reg(...))` makes Polars compute by calling `pl_lr` once per group
+ * (tests/test_linear_exprs.py:918-953).  Rows of one group are contiguous; group g is rows
+ * [group_offsets[g], group_offsets[g+1]).  OLS / ridge with the rank gate (the default path).
+ *   group_offsets  n_groups + 1 int64 values, `space`-resident.
+ *   coeffs         out, n_groups x (n_feat + add_bias), row-major, `space`-resident.
+ *   is_null        out, n_groups bytes, `space`-resident: 1 = gated or fewer rows than features
+ *                  (per-group `pl_lr` raises / returns null there).
+ */
+int pds_lr_grouped_f64(pds_ctx* ctx, const double* const* cols, int n_feat, int64_t n_rows,
+                       const int64_t* group_offsets, int64_t n_groups, pds_space space,
+                       const pds_lr_params* prm, double* coeffs, uint8_t* is_null);
+int pds_lr_grouped_f32(pds_ctx* ctx, const float* const* cols, int n_feat, int64_t n_rows,
+                       const int64_t* group_offsets, int64_t n_groups, pds_space space,
+                       const pds_lr_params* prm, float* coeffs, uint8_t* is_null);
+
+/*
+ * pds_rolling_lr_* / pds_recursive_lr_*: `pl_rolling_lr` (linear_regression.rs:1206-1283) and
+ * `pl_recursive_lr` (:1121-1204) on null-free columns, i.e. faer_rolling_lr / faer_recursive_lr
+ * (lr_online_solvers.rs:148-212) plus the plugin's pred_i = x_i . coeffs_i.  SWWLRKwargs: n = window
+ * (or start_with), bias, lambda.  As in the reference the ones column is part of the data and lambda is
+ * added to every diagonal entry.
+ *   coeffs  out, n_rows x (n_feat + add_bias) row-major (the values buffer of the List column),
+ *           `space`-resident; rows [0, n-1) are unspecified and marked invalid.
+ *   pred    out, n_rows, `space`-resident.
+ *   valid   out, n_rows bytes (1 = row has a result), `space`-resident.
+ * min_size > 0 selects the skipping variant (faer_rolling_skipping_lr :218-301): rows holding a
+ * non-finite value are left out of the window and a window with fewer than min_size rows is invalid.
+ */
+int pds_rolling_lr_f64(pds_ctx* ctx, const double* const* cols, int n_feat, int64_t n_rows,
+                       pds_space space, int add_bias, int64_t window, int64_t min_size,
+                       double lambda, double* coeffs, double* pred, uint8_t* valid);
+int pds_rolling_lr_f32(pds_ctx* ctx, const float* const* cols, int n_feat, int64_t n_rows,
+                       pds_space space, int add_bias, int64_t window, int64_t min_size,
+                       float lambda, float* coeffs, float* pred, uint8_t* valid);
+int pds_recursive_lr_f64(pds_ctx* ctx, const double* const* cols, int n_feat, int64_t n_rows,
+                         pds_space space, int add_bias, int64_t start_with, double lambda,
+                         double* coeffs, double* pred, uint8_t* valid);
+int pds_recursive_lr_f32(pds_ctx* ctx, const float* const* cols, int n_feat, int64_t n_rows,
+                         pds_space space, int add_bias, int64_t start_with, float lambda,
+                         float* coeffs, float* pred, uint8_t* valid);
+
+/*
+ * Moment-level entry points (what a multi-GPU host composes; also the measured Gram build).
+ *
+ * pds_moments_*: one streaming pass over [y | X] building the augmented moment matrix
+ *     A = Z'Z,  Z = [x1 .. xp | 1 | y]   ((p+2) x (p+2), column-major, symmetric)
+ * i.e. X'X (get_xtx_with_lambda lr_solvers.rs:183-198), X'y (build_xty :262-278), the column sums and
+ * sum(y) used by the coordinate-descent bias shortcut (:483-484), y'y and n -- every input element is
+ * read from HBM exactly once.  With weights != NULL: Z'WZ.  The result is written to `moments`
+ * ((n_feat+2)^2 values) in `out_space`; for PDS_DEVICE the call only enqueues work (no host sync), so
+ * a caller can all-reduce the buffer across ranks (RCCL) and then call pds_lr_from_moments_*.
+ */
+int pds_moments_f64(pds_ctx* ctx, const double* const* cols, const double* weights, int n_feat,
+                    int64_t n_rows, pds_space space, double* moments, pds_space out_space);
+int pds_moments_f32(pds_ctx* ctx, const float* const* cols, const float* weights, int n_feat,
+                    int64_t n_rows, pds_space space, float* moments, pds_space out_space);
+/* Same dispatch as pds_lr_* but starting from (already all-reduced) moments in `mom_space`. */
+int pds_lr_from_moments_f64(pds_ctx* ctx, const double* moments, pds_space mom_space, int n_feat,
+                            const pds_lr_params* prm, double* coeffs, int* is_null);
+int pds_lr_from_moments_f32(pds_ctx* ctx, const float* moments, pds_space mom_space, int n_feat,
+                            const pds_lr_params* prm, float* coeffs, int* is_null);
+
+/* Bit-faithful host restatements of src/stats_utils (beta.rs:24-37, 365-377) used by the report. */
+double pds_student_t_sf(double x, double df);
+double pds_student_t_ppf(double q, double df);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDS_LSTSQ_H */

@@ -1,0 +1,22 @@
+"""
+polars_ds_extension_amd -- MI355X (gfx950) implementation of polars_ds's least-squares expression path.
+
+Only that path (pds.lin_reg / lin_reg_report / rolling_lin_reg / recursive_lin_reg, OLS / ridge / lasso /
+elastic net / NNLS / WLS) is implemented; see DESIGN.md for the scope table and INTEGRATION.md for how
+the C ABI (include/pds_lstsq.h) drops in behind the reference's `#[polars_expr]` functions.
+"""
+from . import config  # noqa: F401
+from .lstsq import (  # noqa: F401
+    Context,
+    default_context,
+    gram_moments,
+    lin_reg,
+    lin_reg_by,
+    lin_reg_from_moments,
+    lin_reg_report,
+    lin_reg_w_rcond,
+    recursive_lin_reg,
+    rolling_lin_reg,
+)
+
+__version__ = "0.1.0"

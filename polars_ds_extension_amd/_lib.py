@@ -1,0 +1,104 @@
+"""
+ctypes binding of libpds_lstsq_hip.so (the C ABI of include/pds_lstsq.h).
+
+The library is built in-tree by `polars_ds_extension_amd._build.build()` (hipcc, gfx950).  There is NO
+CPU fallback: if the shared object is missing or the device is not an MI355X-class gfx950 GPU every
+entry point raises -- a silently different code path would void the parity claims.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "csrc" / "libpds_lstsq_hip.so"
+
+PDS_HOST, PDS_DEVICE = 0, 1
+SOLVERS = {"qr": 0, "svd": 1, "choleskey": 2}  # any other string -> qr (src/linear/lr/mod.rs:17-26)
+SE_TYPES = {"se": 0, "hc0": 1, "hc1": 2, "hc2": 3, "hc3": 4}
+
+EXPORTS = [
+    "pds_last_error", "pds_version", "pds_ctx_create", "pds_ctx_destroy", "pds_ctx_set_stream",
+    "pds_ctx_synchronize", "pds_ctx_num_cus",
+    "pds_lr_f64", "pds_lr_f32", "pds_lr_pred_f64", "pds_lr_pred_f32", "pds_lr_rcond_f64",
+    "pds_lin_reg_report_f64", "pds_lin_reg_report_f32",
+    "pds_lr_grouped_f64", "pds_lr_grouped_f32",
+    "pds_rolling_lr_f64", "pds_rolling_lr_f32", "pds_recursive_lr_f64", "pds_recursive_lr_f32",
+    "pds_moments_f64", "pds_moments_f32", "pds_lr_from_moments_f64", "pds_lr_from_moments_f32",
+    "pds_student_t_sf", "pds_student_t_ppf",
+]
+
+
+class LRParams(C.Structure):
+    """pds_lr_params == the numeric fields of LRKwargs (src/num_ext/linear_regression.rs:27-45)."""
+
+    _fields_ = [
+        ("add_bias", C.c_int),
+        ("l1_reg", C.c_double),
+        ("l2_reg", C.c_double),
+        ("tol", C.c_double),
+        ("solver", C.c_int),
+        ("positive", C.c_int),
+        ("max_iter", C.c_int),
+        ("singular_x_tol", C.c_double),
+    ]
+
+
+class ReportF64(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("beta", "std_err", "t", "p", "ci_lower", "ci_upper")] + [
+        ("r2", C.c_double),
+        ("adj_r2", C.c_double),
+    ]
+
+
+class ReportF32(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("beta", "std_err", "t", "p", "ci_lower", "ci_upper")] + [
+        ("r2", C.c_float),
+        ("adj_r2", C.c_float),
+    ]
+
+
+class PdsError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[pds {code}] {msg}")
+        self.code = code
+        self.msg = msg
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen the HIP library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise ImportError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
+            )
+        lib = C.CDLL(str(LIB_PATH))
+        lib.pds_last_error.restype = C.c_char_p
+        lib.pds_version.restype = C.c_char_p
+        lib.pds_student_t_sf.restype = C.c_double
+        lib.pds_student_t_sf.argtypes = [C.c_double, C.c_double]
+        lib.pds_student_t_ppf.restype = C.c_double
+        lib.pds_student_t_ppf.argtypes = [C.c_double, C.c_double]
+        lib.pds_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        lib.pds_ctx_destroy.argtypes = [C.c_void_p]
+        lib.pds_ctx_destroy.restype = None
+        lib.pds_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        lib.pds_ctx_synchronize.argtypes = [C.c_void_p]
+        lib.pds_ctx_num_cus.argtypes = [C.c_void_p]
+        _lib = lib
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise PdsError(rc, load().pds_last_error().decode("utf-8", "replace"))
+
+
+def missing_exports() -> list[str]:
+    lib = load()
+    return [s for s in EXPORTS if not hasattr(lib, s)]

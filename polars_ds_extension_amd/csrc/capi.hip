@@ -1,0 +1,714 @@
+// capi.hip -- the extern "C" surface declared in include/pds_lstsq.h: context management, host <-> HBM
+// staging, and the per-expression pipelines that string the kernels together.
+#include <algorithm>
+#include <cstdlib>
+#include <mutex>
+
+#include "common.hpp"
+
+namespace pds {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+int ensure_ws(pds_ctx* ctx, Workspace& w, size_t bytes) {
+    if (bytes <= w.bytes) return PDS_OK;
+    if (w.ptr) {
+        PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        PDS_HIP_CHECK(hipFree(w.ptr));
+        w.ptr = nullptr;
+        w.bytes = 0;
+    }
+    size_t want = std::max(bytes, (size_t)1 << 20);
+    want = (want + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    PDS_HIP_CHECK(hipMalloc(&w.ptr, want));
+    w.bytes = want;
+    return PDS_OK;
+}
+
+int ensure_pinned(pds_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->pinned_bytes) return PDS_OK;
+    if (ctx->pinned) {
+        PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        PDS_HIP_CHECK(hipHostFree(ctx->pinned));
+        ctx->pinned = nullptr;
+        ctx->pinned_bytes = 0;
+    }
+    size_t want = std::max(bytes, (size_t)1 << 16);
+    PDS_HIP_CHECK(hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));
+    ctx->pinned_bytes = want;
+    return PDS_OK;
+}
+
+int ws_reserve(pds_ctx* ctx, size_t total_bytes) {
+    ctx->ws_used = 0;
+    return ensure_ws(ctx, ctx->ws, total_bytes + 4096);
+}
+void* ws_take(pds_ctx* ctx, size_t bytes) {
+    const size_t off = (ctx->ws_used + 255) & ~(size_t)255;
+    ctx->ws_used = off + bytes;
+    return static_cast<char*>(ctx->ws.ptr) + off;
+}
+
+template <typename T>
+int make_device_cols(pds_ctx* ctx, const T* const* cols, const T* weights, int n_feat, int64_t n_rows,
+                     pds_space space, DeviceCols<T>& out) {
+    const int nc = n_feat + 1 + (weights ? 1 : 0);
+    out.nc = nc;
+    out.h_ptrs.resize(nc);
+    std::vector<const T*> src(nc);
+    for (int c = 0; c < n_feat; ++c) src[c] = cols[c + 1];  // reference order is [y, x1..xp]
+    src[n_feat] = cols[0];
+    if (weights) src[n_feat + 1] = weights;
+    if (space == PDS_DEVICE) {
+        for (int c = 0; c < nc; ++c) out.h_ptrs[c] = src[c];
+    } else {
+        // stage the host column buffers into HBM (one hipMemcpyAsync per column; see DESIGN.md for the
+        // PCIe-inclusive rate -- the timed path of bench.py is device resident)
+        const size_t col_bytes = ((size_t)n_rows * sizeof(T) + 255) & ~(size_t)255;
+        if (int rc = ensure_ws(ctx, ctx->stage, col_bytes * nc)) return rc;
+        for (int c = 0; c < nc; ++c) {
+            T* dst = reinterpret_cast<T*>(static_cast<char*>(ctx->stage.ptr) + col_bytes * c);
+            PDS_HIP_CHECK(hipMemcpyAsync(dst, src[c], (size_t)n_rows * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+            out.h_ptrs[c] = dst;
+        }
+    }
+    out.d_ptrs = reinterpret_cast<const T**>(ws_take(ctx, sizeof(T*) * nc));
+    PDS_HIP_CHECK(hipMemcpyAsync(out.d_ptrs, out.h_ptrs.data(), sizeof(T*) * nc, hipMemcpyHostToDevice, ctx->stream));
+    // h_ptrs lives in `out` (caller's stack) until the call returns, and every API call synchronises
+    // before returning, so the async copy source stays valid.
+    return PDS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side p' x p' SVD solve (solver = "svd", rcond path): one-sided Jacobi on the Gram matrix.
+// O(p'^3) on a 2 KB matrix -- not worth a kernel; only reached for single systems.
+// ---------------------------------------------------------------------------------------------
+static bool jacobi_svd(const std::vector<double>& a, int n, std::vector<double>& u, std::vector<double>& s,
+                       std::vector<double>& v) {
+    u = a;
+    v.assign((size_t)n * n, 0.0);
+    s.assign(n, 0.0);
+    for (int i = 0; i < n; ++i) v[i + (size_t)i * n] = 1.0;
+    for (double x : u)
+        if (!std::isfinite(x)) return false;
+    const double eps = 2.220446049250313e-16;
+    bool conv = false;
+    for (int sweep = 0; sweep < 60 && !conv; ++sweep) {
+        conv = true;
+        for (int i = 0; i < n - 1; ++i)
+            for (int j = i + 1; j < n; ++j) {
+                double al = 0, be = 0, ga = 0;
+                for (int r = 0; r < n; ++r) {
+                    al += u[r + (size_t)i * n] * u[r + (size_t)i * n];
+                    be += u[r + (size_t)j * n] * u[r + (size_t)j * n];
+                    ga += u[r + (size_t)i * n] * u[r + (size_t)j * n];
+                }
+                if (ga == 0.0 || std::fabs(ga) <= eps * std::sqrt(al * be)) continue;
+                conv = false;
+                const double zeta = (be - al) / (2 * ga);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1 + zeta * zeta));
+                const double c = 1 / std::sqrt(1 + t * t), sn = c * t;
+                for (int r = 0; r < n; ++r) {
+                    double x = u[r + (size_t)i * n], y = u[r + (size_t)j * n];
+                    u[r + (size_t)i * n] = c * x - sn * y;
+                    u[r + (size_t)j * n] = sn * x + c * y;
+                    x = v[r + (size_t)i * n];
+                    y = v[r + (size_t)j * n];
+                    v[r + (size_t)i * n] = c * x - sn * y;
+                    v[r + (size_t)j * n] = sn * x + c * y;
+                }
+            }
+    }
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) {
+        double nn = 0;
+        for (int r = 0; r < n; ++r) nn += u[r + (size_t)i * n] * u[r + (size_t)i * n];
+        s[i] = std::sqrt(nn);
+        if (s[i] > 0)
+            for (int r = 0; r < n; ++r) u[r + (size_t)i * n] /= s[i];
+        order[i] = i;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return s[x] > s[y]; });
+    std::vector<double> u2(u.size()), v2(v.size()), s2(n);
+    for (int k = 0; k < n; ++k) {
+        s2[k] = s[order[k]];
+        for (int r = 0; r < n; ++r) {
+            u2[r + (size_t)k * n] = u[r + (size_t)order[k] * n];
+            v2[r + (size_t)k * n] = v[r + (size_t)order[k] * n];
+        }
+    }
+    u.swap(u2);
+    v.swap(v2);
+    s.swap(s2);
+    return true;
+}
+
+// G (pp x pp) and rhs from a host copy of the moment matrix
+template <typename T>
+static void host_normal_eq(const std::vector<T>& M, int p, int bias, double lambda, std::vector<double>& G,
+                           std::vector<double>& c) {
+    const int pp = p + bias, q = p + 2;
+    G.assign((size_t)pp * pp, 0.0);
+    c.assign(pp, 0.0);
+    for (int j = 0; j < pp; ++j) {
+        for (int i = 0; i < pp; ++i) G[i + (size_t)j * pp] = (double)M[i + (size_t)j * q];
+        c[j] = (double)M[j + (size_t)(p + 1) * q];
+    }
+    if (lambda > 0)
+        for (int i = 0; i < p; ++i) G[i + (size_t)i * pp] += lambda;
+}
+
+struct Method {
+    enum Kind { OLS, NNLS, CD } kind;
+    double l1, l2;
+    int positive;
+};
+static Method pick_method(const pds_lr_params* prm) {
+    // LRMethods::from((l1, l2)) + the (method, positive) match of pl_lr: linear_regression.rs:447-497
+    const bool l1 = prm->l1_reg > 0.0, l2 = prm->l2_reg > 0.0;
+    Method m;
+    m.positive = prm->positive ? 1 : 0;
+    if (!l1) {  // Normal or L2
+        if (!m.positive) return {Method::OLS, 0.0, prm->l2_reg, 0};
+        if (!l2) return {Method::NNLS, 0.0, 0.0, 1};
+        return {Method::CD, 0.0, prm->l2_reg, 1};
+    }
+    return {Method::CD, prm->l1_reg, l2 ? prm->l2_reg : 0.0, m.positive};
+}
+
+// Device moments -> coefficients on the host.  `is_f32_path` applies the f32 twin's iteration caps.
+template <typename T>
+static int lr_from_device_moments(pds_ctx* ctx, const T* d_mom, int p, const pds_lr_params* prm, bool weighted,
+                                  T* coeffs, int* is_null, T* d_coeffs_keep /*nullable device copy*/) {
+    const int bias = prm->add_bias ? 1 : 0, pp = p + bias, q = p + 2;
+    if (is_null) *is_null = 0;
+    T* d_coeffs = d_coeffs_keep ? d_coeffs_keep : reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * (pp + 2)));
+    uint8_t* d_flag = reinterpret_cast<uint8_t*>(ws_take(ctx, 16));
+    int* d_info = reinterpret_cast<int*>(ws_take(ctx, 16));
+    if (int rc = ensure_pinned(ctx, 4096 + sizeof(T) * (size_t)(q * q + pp))) return rc;
+    Method m = weighted ? Method{Method::OLS, 0.0, 0.0, 0} : pick_method(prm);
+    const bool f32 = sizeof(T) == 4;
+    if (m.kind == Method::OLS && prm->solver == PDS_SOLVER_SVD) {
+        // svd: small host solve on the moments
+        std::vector<T> M((size_t)q * q);
+        PDS_HIP_CHECK(hipMemcpyAsync(M.data(), d_mom, sizeof(T) * M.size(), hipMemcpyDeviceToHost, ctx->stream));
+        PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        std::vector<double> G, c, u, s, v;
+        host_normal_eq(M, p, bias, weighted ? 0.0 : m.l2, G, c);
+        const bool gate = !weighted && prm->singular_x_tol > 0.0;
+        double ln_den = 0.0;
+        bool null = false;
+        if (gate)
+            for (int i = 0; i < pp; ++i) {
+                if (G[i + (size_t)i * pp] <= 0.0) null = true;
+                else ln_den += std::log(G[i + (size_t)i * pp]);
+            }
+        bool ok = !null && jacobi_svd(G, pp, u, s, v);
+        if (gate && !null) {
+            if (!ok) null = true;  // "SVD failure -> treat as rank-deficient" lr_solvers.rs:361-362
+            else {
+                double ln_det = 0.0;
+                for (int i = 0; i < pp; ++i) ln_det += std::log(s[i]);
+                if (ln_det - ln_den <= std::log(prm->singular_x_tol)) null = true;
+            }
+        }
+        if (null) {
+            for (int i = 0; i < pp; ++i) coeffs[i] = (T)NAN;
+            if (is_null) *is_null = 1;
+        } else if (ok) {
+            std::vector<double> z(pp);
+            for (int i = 0; i < pp; ++i) {
+                double acc = 0;
+                for (int r = 0; r < pp; ++r) acc += u[r + (size_t)i * pp] * c[r];
+                z[i] = acc / s[i];
+            }
+            for (int r = 0; r < pp; ++r) {
+                double acc = 0;
+                for (int i = 0; i < pp; ++i) acc += v[r + (size_t)i * pp] * z[i];
+                coeffs[r] = (T)acc;
+            }
+        } else {
+            // ungated SVD failure falls back to QR (lr_solvers.rs:284-287)
+            SolveParams sp{p, bias, PDS_SOLVER_QR, m.l2, 0.0, 0};
+            if (int rc = launch_solve<T>(ctx, d_mom, 1, sp, d_coeffs, d_flag, nullptr, nullptr)) return rc;
+            PDS_HIP_CHECK(hipMemcpyAsync(coeffs, d_coeffs, sizeof(T) * pp, hipMemcpyDeviceToHost, ctx->stream));
+            PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        }
+        if (d_coeffs_keep)
+            PDS_HIP_CHECK(hipMemcpyAsync(d_coeffs_keep, coeffs, sizeof(T) * pp, hipMemcpyHostToDevice, ctx->stream));
+        return PDS_OK;
+    }
+    if (m.kind == Method::OLS) {
+        SolveParams sp{p, bias, prm->solver, weighted ? 0.0 : m.l2, weighted ? 0.0 : prm->singular_x_tol, 0};
+        if (int rc = launch_solve<T>(ctx, d_mom, 1, sp, d_coeffs, d_flag, nullptr, nullptr)) return rc;
+    } else if (m.kind == Method::NNLS) {
+        if (int rc = launch_nnls<T>(ctx, d_mom, p, bias, prm->tol, f32 ? 200 : prm->max_iter, d_coeffs)) return rc;
+        PDS_HIP_CHECK(hipMemsetAsync(d_flag, 0, 1, ctx->stream));
+    } else {
+        if (int rc = launch_cd<T>(ctx, d_mom, p, bias, m.l1, m.l2, prm->tol, f32 ? 2000 : prm->max_iter, m.positive,
+                                  d_coeffs, d_info))
+            return rc;
+        PDS_HIP_CHECK(hipMemsetAsync(d_flag, 0, 1, ctx->stream));
+    }
+    char* pin = static_cast<char*>(ctx->pinned);
+    PDS_HIP_CHECK(hipMemcpyAsync(pin, d_coeffs, sizeof(T) * pp, hipMemcpyDeviceToHost, ctx->stream));
+    PDS_HIP_CHECK(hipMemcpyAsync(pin + 2048, d_flag, 1, hipMemcpyDeviceToHost, ctx->stream));
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    std::memcpy(coeffs, pin, sizeof(T) * pp);
+    if (is_null) *is_null = pin[2048] ? 1 : 0;
+    return PDS_OK;
+}
+
+static int check_shape(int n_feat, int64_t n_rows, int add_bias) {
+    if (n_feat < 1) return fail(PDS_ERR_INVALID, "need at least one feature column");
+    if (n_rows == 0) return fail(PDS_ERR_EMPTY, "Empty data");  // linear_regression.rs:166-168
+    if (n_rows < n_feat + (add_bias ? 1 : 0))
+        return fail(PDS_ERR_TOO_FEW_ROWS, "#Data < #features. No conclusive result.");  // :169-173
+    return PDS_OK;
+}
+
+template <typename T>
+static int lr_impl(pds_ctx* ctx, const T* const* cols, const T* weights, int n_feat, int64_t n_rows, pds_space space,
+                   const pds_lr_params* prm, T* coeffs, int* is_null, T* pred, T* resid) {
+    if (!ctx || !cols || !prm || !coeffs) return fail(PDS_ERR_INVALID, "null argument");
+    if (int rc = check_shape(n_feat, n_rows, prm->add_bias)) return rc;
+    PDS_HIP_CHECK(hipSetDevice(ctx->device));
+    const int q = n_feat + 2, pp = n_feat + (prm->add_bias ? 1 : 0);
+    const bool want_pred = pred || resid;
+    size_t need = 65536 + sizeof(T) * (size_t)q * q;
+    if (want_pred && space == PDS_HOST) need += 2 * ((size_t)n_rows * sizeof(T) + 512);
+    if (int rc = ws_reserve(ctx, need)) return rc;
+    DeviceCols<T> dc;
+    if (int rc = make_device_cols<T>(ctx, cols, weights, n_feat, n_rows, space, dc)) return rc;
+    T* d_mom = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * q * q));
+    if (int rc = launch_moments<T>(ctx, dc, n_feat, n_rows, weights != nullptr, d_mom)) return rc;
+    T* d_coeffs = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * (pp + 2)));
+    int null_flag = 0;
+    if (int rc = lr_from_device_moments<T>(ctx, d_mom, n_feat, prm, weights != nullptr, coeffs, &null_flag, d_coeffs))
+        return rc;
+    if (is_null) *is_null = null_flag;
+    if (want_pred) {
+        T* d_pred = pred;
+        T* d_resid = resid;
+        if (space == PDS_HOST) {
+            d_pred = reinterpret_cast<T*>(ws_take(ctx, (size_t)n_rows * sizeof(T)));
+            d_resid = reinterpret_cast<T*>(ws_take(ctx, (size_t)n_rows * sizeof(T)));
+        }
+        double* d_sums = reinterpret_cast<double*>(ws_take(ctx, 64));
+        // a gated fit yields all-null pred/resid in the reference (:745-750); here NaN coefficients
+        // propagate to NaN rows and the caller marks them invalid through *is_null.
+        if (int rc = launch_pass2<T>(ctx, dc, n_feat, n_rows, prm->add_bias, false, d_coeffs, nullptr, 0, d_pred, d_resid,
+                                     d_sums, nullptr))
+            return rc;
+        if (space == PDS_HOST) {
+            if (pred) PDS_HIP_CHECK(hipMemcpyAsync(pred, d_pred, (size_t)n_rows * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+            if (resid) PDS_HIP_CHECK(hipMemcpyAsync(resid, d_resid, (size_t)n_rows * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+        }
+    }
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PDS_OK;
+}
+
+template <typename T>
+static int moments_impl(pds_ctx* ctx, const T* const* cols, const T* weights, int n_feat, int64_t n_rows,
+                        pds_space space, T* moments, pds_space out_space) {
+    if (!ctx || !cols || !moments) return fail(PDS_ERR_INVALID, "null argument");
+    if (n_feat < 1) return fail(PDS_ERR_INVALID, "need at least one feature column");
+    if (n_rows <= 0) return fail(PDS_ERR_EMPTY, "Empty data");
+    PDS_HIP_CHECK(hipSetDevice(ctx->device));
+    const int q = n_feat + 2;
+    if (int rc = ws_reserve(ctx, 65536 + sizeof(T) * (size_t)q * q)) return rc;
+    DeviceCols<T> dc;
+    if (int rc = make_device_cols<T>(ctx, cols, weights, n_feat, n_rows, space, dc)) return rc;
+    T* d_mom = out_space == PDS_DEVICE ? moments : reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * q * q));
+    if (int rc = launch_moments<T>(ctx, dc, n_feat, n_rows, weights != nullptr, d_mom)) return rc;
+    if (out_space == PDS_HOST) {
+        PDS_HIP_CHECK(hipMemcpyAsync(moments, d_mom, sizeof(T) * q * q, hipMemcpyDeviceToHost, ctx->stream));
+        PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    } else if (space == PDS_HOST) {
+        PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // staging buffers / pointer array must outlive the kernel
+    } else {
+        // device in, device out: the pointer array was copied from dc.h_ptrs (stack) -> wait for that copy only
+        PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    return PDS_OK;
+}
+
+template <typename T>
+static int from_moments_impl(pds_ctx* ctx, const T* moments, pds_space mom_space, int n_feat, const pds_lr_params* prm,
+                             T* coeffs, int* is_null) {
+    if (!ctx || !moments || !prm || !coeffs) return fail(PDS_ERR_INVALID, "null argument");
+    PDS_HIP_CHECK(hipSetDevice(ctx->device));
+    const int q = n_feat + 2;
+    if (int rc = ws_reserve(ctx, 65536 + sizeof(T) * (size_t)q * q)) return rc;
+    const T* d_mom = moments;
+    if (mom_space == PDS_HOST) {
+        T* tmp = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * q * q));
+        PDS_HIP_CHECK(hipMemcpyAsync(tmp, moments, sizeof(T) * q * q, hipMemcpyHostToDevice, ctx->stream));
+        d_mom = tmp;
+    }
+    int rc = lr_from_device_moments<T>(ctx, d_mom, n_feat, prm, false, coeffs, is_null, nullptr);
+    if (rc) return rc;
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PDS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// lin_reg_report / wls_report
+// ---------------------------------------------------------------------------------------------
+template <typename T, typename R>
+static int report_impl(pds_ctx* ctx, const T* const* cols, const T* weights, int n_feat, int64_t n_rows,
+                       pds_space space, int add_bias, int se_type, T y_var, R* out) {
+    if (!ctx || !cols || !out) return fail(PDS_ERR_INVALID, "null argument");
+    if (int rc = check_shape(n_feat, n_rows, add_bias)) return rc;
+    if (weights && se_type != PDS_SE) se_type = PDS_SE;  // pl_wls_report only knows "std_err"
+    PDS_HIP_CHECK(hipSetDevice(ctx->device));
+    const int p = n_feat, bias = add_bias ? 1 : 0, pp = p + bias, q = p + 2;
+    size_t need = 131072 + sizeof(T) * (size_t)(2 * q * q + pp * pp + pp);
+    if (se_type != PDS_SE) need += (size_t)n_rows * sizeof(T) + 512;
+    if (int rc = ws_reserve(ctx, need)) return rc;
+    DeviceCols<T> dc;
+    if (int rc = make_device_cols<T>(ctx, cols, weights, p, n_rows, space, dc)) return rc;
+    T* d_mom = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * q * q));
+    T* d_mom2 = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * q * q));
+    T* d_beta = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * (pp + 2)));
+    T* d_inv = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * pp * pp));
+    uint8_t* d_flag = reinterpret_cast<uint8_t*>(ws_take(ctx, 16));
+    double* d_sums = reinterpret_cast<double*>(ws_take(ctx, 64));
+    const bool weighted = weights != nullptr;
+    if (int rc = launch_moments<T>(ctx, dc, p, n_rows, weighted, d_mom)) return rc;
+    // xtx.col_piv_qr() -> inverse() and the solve (:855-858, 1028-1030)
+    SolveParams sp{p, bias, PDS_SOLVER_QR, 0.0, 0.0, 0};
+    if (int rc = launch_solve<T>(ctx, d_mom, 1, sp, d_beta, d_flag, d_inv, nullptr)) return rc;
+    const int hc = (se_type == PDS_SE) ? 0 : (se_type == PDS_HC2 ? 2 : (se_type == PDS_HC3 ? 3 : 1));
+    T* d_s = hc ? reinterpret_cast<T*>(ws_take(ctx, (size_t)n_rows * sizeof(T))) : nullptr;
+    if (int rc = launch_pass2<T>(ctx, dc, p, n_rows, bias, weighted, d_beta, d_inv, hc, nullptr, nullptr, d_sums,
+                                 reinterpret_cast<double*>(d_s)))
+        return rc;
+    if (hc) {
+        // meat = X' diag(s) X : one more weighted Gram build with w = s
+        DeviceCols<T> dc2;
+        dc2.nc = p + 2;
+        dc2.h_ptrs.assign(dc.h_ptrs.begin(), dc.h_ptrs.begin() + p + 1);
+        dc2.h_ptrs.push_back(d_s);
+        dc2.d_ptrs = reinterpret_cast<const T**>(ws_take(ctx, sizeof(T*) * (p + 2)));
+        PDS_HIP_CHECK(hipMemcpyAsync(dc2.d_ptrs, dc2.h_ptrs.data(), sizeof(T*) * (p + 2), hipMemcpyHostToDevice, ctx->stream));
+        if (int rc = launch_moments<T>(ctx, dc2, p, n_rows, true, d_mom2)) return rc;
+        PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    std::vector<T> beta(pp), inv((size_t)pp * pp), meat((size_t)q * q);
+    double sums[2] = {0, 0};
+    PDS_HIP_CHECK(hipMemcpyAsync(beta.data(), d_beta, sizeof(T) * pp, hipMemcpyDeviceToHost, ctx->stream));
+    PDS_HIP_CHECK(hipMemcpyAsync(inv.data(), d_inv, sizeof(T) * pp * pp, hipMemcpyDeviceToHost, ctx->stream));
+    PDS_HIP_CHECK(hipMemcpyAsync(sums, d_sums, sizeof(sums), hipMemcpyDeviceToHost, ctx->stream));
+    if (hc) PDS_HIP_CHECK(hipMemcpyAsync(meat.data(), d_mom2, sizeof(T) * q * q, hipMemcpyDeviceToHost, ctx->stream));
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+
+    // ---- O(p'^2) host epilogue (linear_regression.rs:861-939)
+    const T dof = (T)n_rows - (T)pp;
+    const T nf = (T)n_rows;
+    const T ssr = (T)sums[0];
+    const T ratio = ssr / (y_var * nf);
+    out->r2 = (T)1 - ratio;
+    out->adj_r2 = (T)1 - ratio * (((T)(n_rows - 1)) / (dof - (T)1));
+    std::vector<T> se(pp);
+    if (se_type == PDS_SE) {
+        const T mse = (weighted ? (T)sums[1] : ssr) / dof;
+        for (int i = 0; i < pp; ++i) se[i] = (T)std::sqrt((double)(mse * inv[i + (size_t)i * pp]));
+    } else {
+        // var_hc_ii = inv_i . meat . inv_i ; meat is the (p+bias) leading block of the weighted moments
+        const T factor = (se_type == PDS_HC1) ? nf / (T)(n_rows - pp) : (T)1;
+        for (int i = 0; i < pp; ++i) {
+            double acc = 0.0;
+            for (int a = 0; a < pp; ++a) {
+                double t = 0.0;
+                for (int b = 0; b < pp; ++b) t += (double)meat[a + (size_t)b * q] * (double)inv[b + (size_t)i * pp];
+                acc += (double)inv[a + (size_t)i * pp] * t;
+            }
+            se[i] = (T)std::sqrt((double)((T)acc * factor));
+        }
+    }
+    const double t_alpha = student_t_ppf(0.975, (double)dof);
+    for (int i = 0; i < pp; ++i) {
+        out->beta[i] = beta[i];
+        out->std_err[i] = se[i];
+        const T tv = beta[i] / se[i];
+        out->t[i] = tv;
+        bool err = false;
+        const double sf = student_t_sf(std::fabs((double)tv), (double)dof, &err);
+        out->p[i] = err ? (T)NAN : (T)(2.0 * sf);
+        out->ci_lower[i] = (T)((double)beta[i] - t_alpha * (double)se[i]);
+        out->ci_upper[i] = (T)((double)beta[i] + t_alpha * (double)se[i]);
+    }
+    return PDS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// grouped
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t n_rows, const int64_t* offsets,
+                        int64_t n_groups, pds_space space, const pds_lr_params* prm, T* coeffs, uint8_t* is_null) {
+    if (!ctx || !cols || !offsets || !prm || !coeffs) return fail(PDS_ERR_INVALID, "null argument");
+    if (n_feat < 1) return fail(PDS_ERR_INVALID, "need at least one feature column");
+    if (n_groups <= 0 || n_rows <= 0) return fail(PDS_ERR_EMPTY, "Empty data");
+    if (prm->l1_reg > 0.0 || prm->positive)
+        return fail(PDS_ERR_UNSUPPORTED, "grouped path implements OLS / ridge (the default pl_lr dispatch)");
+    PDS_HIP_CHECK(hipSetDevice(ctx->device));
+    const int bias = prm->add_bias ? 1 : 0, pp = n_feat + bias, q = n_feat + 2;
+    // chunk the groups so one chunk's moment records (q*q values per group) stay inside the 256 MiB
+    // Infinity Cache between the Gram kernel that writes them and the solve kernel that reads them
+    int64_t chunk = std::max<int64_t>(4096, (int64_t)(128ll << 20) / (int64_t)(sizeof(T) * q * q));
+    chunk = std::min(chunk, n_groups);
+    size_t need = 131072 + sizeof(T) * (size_t)chunk * q * q;
+    if (space == PDS_HOST) need += (size_t)(n_groups + 1) * 8 + (size_t)n_groups * (pp * sizeof(T) + 1) + 4096;
+    if (int rc = ws_reserve(ctx, need)) return rc;
+    DeviceCols<T> dc;
+    if (int rc = make_device_cols<T>(ctx, cols, (const T*)nullptr, n_feat, n_rows, space, dc)) return rc;
+    const int64_t* d_off = offsets;
+    T* d_coeffs = coeffs;
+    uint8_t* d_null = is_null;
+    if (space == PDS_HOST) {
+        int64_t* t = reinterpret_cast<int64_t*>(ws_take(ctx, (size_t)(n_groups + 1) * 8));
+        PDS_HIP_CHECK(hipMemcpyAsync(t, offsets, (size_t)(n_groups + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        d_off = t;
+        d_coeffs = reinterpret_cast<T*>(ws_take(ctx, (size_t)n_groups * pp * sizeof(T)));
+        d_null = reinterpret_cast<uint8_t*>(ws_take(ctx, (size_t)n_groups));
+    } else if (!d_null) {
+        d_null = reinterpret_cast<uint8_t*>(ws_take(ctx, (size_t)n_groups));
+    }
+    T* d_mom = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * (size_t)chunk * q * q));
+    SolveParams sp{n_feat, bias, prm->solver == PDS_SOLVER_SVD ? PDS_SOLVER_QR : prm->solver, prm->l2_reg,
+                   prm->singular_x_tol, 0};
+    for (int64_t g0 = 0; g0 < n_groups; g0 += chunk) {
+        const int64_t gc = std::min(chunk, n_groups - g0);
+        if (int rc = launch_grouped_moments<T>(ctx, dc, n_feat, d_off + g0, gc, d_mom)) return rc;
+        if (int rc = launch_solve<T>(ctx, d_mom, gc, sp, d_coeffs + g0 * pp, d_null + g0, nullptr, d_off + g0)) return rc;
+    }
+    if (space == PDS_HOST) {
+        PDS_HIP_CHECK(hipMemcpyAsync(coeffs, d_coeffs, (size_t)n_groups * pp * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+        if (is_null) PDS_HIP_CHECK(hipMemcpyAsync(is_null, d_null, (size_t)n_groups, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PDS_OK;
+}
+
+template <typename T>
+static int rolling_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t n_rows, pds_space space, int add_bias,
+                        int64_t window, int64_t min_size, double lambda, bool expanding, T* coeffs, T* pred,
+                        uint8_t* valid) {
+    if (!ctx || !cols || !coeffs || !pred || !valid) return fail(PDS_ERR_INVALID, "null argument");
+    if (int rc = check_shape(n_feat, n_rows, add_bias)) return rc;
+    const int pp = n_feat + (add_bias ? 1 : 0);
+    if (window < 1 || window > n_rows) return fail(PDS_ERR_INVALID, "window / start_with must be in [1, n_rows]");
+    PDS_HIP_CHECK(hipSetDevice(ctx->device));
+    size_t need = 131072;
+    if (space == PDS_HOST) need += (size_t)n_rows * ((pp + 1) * sizeof(T) + 1) + 4096;
+    if (int rc = ws_reserve(ctx, need)) return rc;
+    DeviceCols<T> dc;
+    if (int rc = make_device_cols<T>(ctx, cols, (const T*)nullptr, n_feat, n_rows, space, dc)) return rc;
+    T* d_co = coeffs;
+    T* d_pr = pred;
+    uint8_t* d_va = valid;
+    if (space == PDS_HOST) {
+        d_co = reinterpret_cast<T*>(ws_take(ctx, (size_t)n_rows * pp * sizeof(T)));
+        d_pr = reinterpret_cast<T*>(ws_take(ctx, (size_t)n_rows * sizeof(T)));
+        d_va = reinterpret_cast<uint8_t*>(ws_take(ctx, (size_t)n_rows));
+    }
+    if (int rc = launch_rolling<T>(ctx, dc, n_feat, n_rows, add_bias, window, min_size, lambda, expanding, d_co, d_pr, d_va))
+        return rc;
+    if (space == PDS_HOST) {
+        PDS_HIP_CHECK(hipMemcpyAsync(coeffs, d_co, (size_t)n_rows * pp * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+        PDS_HIP_CHECK(hipMemcpyAsync(pred, d_pr, (size_t)n_rows * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+        PDS_HIP_CHECK(hipMemcpyAsync(valid, d_va, (size_t)n_rows, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PDS_OK;
+}
+
+}  // namespace pds
+
+// =============================================================================================
+// extern "C"
+// =============================================================================================
+using namespace pds;
+
+extern "C" {
+
+const char* pds_last_error(void) { return g_err.c_str(); }
+const char* pds_version(void) { return "pds_lstsq_hip 0.1.0 (gfx950)"; }
+
+int pds_ctx_create(int device, pds_ctx** out) {
+    if (!out) return fail(PDS_ERR_INVALID, "null out pointer");
+    int ndev = 0;
+    PDS_HIP_CHECK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(PDS_ERR_HIP, "no such HIP device");
+    hipDeviceProp_t prop;
+    PDS_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(PDS_ERR_HIP, std::string("libpds_lstsq_hip is built for gfx950 only, device is ") + prop.gcnArchName);
+    PDS_HIP_CHECK(hipSetDevice(device));
+    pds_ctx* c = new pds_ctx();
+    c->device = device;
+    c->num_cus = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return fail(PDS_ERR_HIP, "hipStreamCreate failed");
+    }
+    c->own_stream = true;
+    const size_t pbytes = (size_t)c->num_cus * 8 * kPartStride * sizeof(double);
+    if (hipMalloc(reinterpret_cast<void**>(&c->partials), pbytes) != hipSuccess) {
+        hipStreamDestroy(c->stream);
+        delete c;
+        return fail(PDS_ERR_HIP, "hipMalloc(partials) failed");
+    }
+    *out = c;
+    return PDS_OK;
+}
+
+void pds_ctx_destroy(pds_ctx* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    if (ctx->partials) hipFree(ctx->partials);
+    if (ctx->ws.ptr) hipFree(ctx->ws.ptr);
+    if (ctx->stage.ptr) hipFree(ctx->stage.ptr);
+    if (ctx->pinned) hipHostFree(ctx->pinned);
+    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int pds_ctx_set_stream(pds_ctx* ctx, void* hip_stream) {
+    if (!ctx) return fail(PDS_ERR_INVALID, "null ctx");
+    PDS_HIP_CHECK(hipSetDevice(ctx->device));
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    if (hip_stream) {
+        ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+        ctx->own_stream = false;
+    } else {
+        PDS_HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    return PDS_OK;
+}
+
+int pds_ctx_synchronize(pds_ctx* ctx) {
+    if (!ctx) return fail(PDS_ERR_INVALID, "null ctx");
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PDS_OK;
+}
+
+int pds_ctx_num_cus(const pds_ctx* ctx) { return ctx ? ctx->num_cus : 0; }
+
+int pds_lr_f64(pds_ctx* ctx, const double* const* cols, const double* weights, int n_feat, int64_t n_rows,
+               pds_space space, const pds_lr_params* prm, double* coeffs, int* is_null) {
+    return lr_impl<double>(ctx, cols, weights, n_feat, n_rows, space, prm, coeffs, is_null, nullptr, nullptr);
+}
+int pds_lr_f32(pds_ctx* ctx, const float* const* cols, const float* weights, int n_feat, int64_t n_rows,
+               pds_space space, const pds_lr_params* prm, float* coeffs, int* is_null) {
+    return lr_impl<float>(ctx, cols, weights, n_feat, n_rows, space, prm, coeffs, is_null, nullptr, nullptr);
+}
+int pds_lr_pred_f64(pds_ctx* ctx, const double* const* cols, const double* weights, int n_feat, int64_t n_rows,
+                    pds_space space, const pds_lr_params* prm, double* coeffs, int* is_null, double* pred,
+                    double* resid) {
+    if (!pred || !resid) return fail(PDS_ERR_INVALID, "pred / resid buffers required");
+    return lr_impl<double>(ctx, cols, weights, n_feat, n_rows, space, prm, coeffs, is_null, pred, resid);
+}
+int pds_lr_pred_f32(pds_ctx* ctx, const float* const* cols, const float* weights, int n_feat, int64_t n_rows,
+                    pds_space space, const pds_lr_params* prm, float* coeffs, int* is_null, float* pred, float* resid) {
+    if (!pred || !resid) return fail(PDS_ERR_INVALID, "pred / resid buffers required");
+    return lr_impl<float>(ctx, cols, weights, n_feat, n_rows, space, prm, coeffs, is_null, pred, resid);
+}
+
+int pds_lr_rcond_f64(pds_ctx* ctx, const double* const* cols, int n_feat, int64_t n_rows, pds_space space,
+                     int add_bias, double l2_reg, double rcond, double* coeffs, double* singular_values) {
+    if (!ctx || !cols || !coeffs || !singular_values) return fail(PDS_ERR_INVALID, "null argument");
+    if (int rc = check_shape(n_feat, n_rows, add_bias)) return rc;
+    const int bias = add_bias ? 1 : 0, pp = n_feat + bias, q = n_feat + 2;
+    std::vector<double> M((size_t)q * q);
+    if (int rc = moments_impl<double>(ctx, cols, nullptr, n_feat, n_rows, space, M.data(), PDS_HOST)) return rc;
+    std::vector<double> G, c, u, s, v;
+    host_normal_eq(M, n_feat, bias, l2_reg, G, c);
+    if (!jacobi_svd(G, pp, u, s, v)) return fail(PDS_ERR_NUMERIC, "SVD failed.");
+    for (int i = 0; i < pp; ++i) singular_values[i] = std::sqrt(s[i]);
+    const double thr = rcond * singular_values[0];  // lr_solvers.rs:230-240 (eigenvalue vs rcond * s_max, as written)
+    std::vector<double> z(pp);
+    for (int i = 0; i < pp; ++i) {
+        const double sinv = s[i] >= thr ? 1.0 / s[i] : 0.0;
+        double acc = 0;
+        for (int r = 0; r < pp; ++r) acc += u[r + (size_t)i * pp] * c[r];
+        z[i] = acc * sinv;
+    }
+    for (int r = 0; r < pp; ++r) {
+        double acc = 0;
+        for (int i = 0; i < pp; ++i) acc += v[r + (size_t)i * pp] * z[i];
+        coeffs[r] = acc;
+    }
+    return PDS_OK;
+}
+
+int pds_lin_reg_report_f64(pds_ctx* ctx, const double* const* cols, const double* weights, int n_feat,
+                           int64_t n_rows, pds_space space, int add_bias, int se_type, double y_var,
+                           pds_report_f64* out) {
+    return report_impl<double, pds_report_f64>(ctx, cols, weights, n_feat, n_rows, space, add_bias, se_type, y_var, out);
+}
+int pds_lin_reg_report_f32(pds_ctx* ctx, const float* const* cols, const float* weights, int n_feat, int64_t n_rows,
+                           pds_space space, int add_bias, int se_type, float y_var, pds_report_f32* out) {
+    return report_impl<float, pds_report_f32>(ctx, cols, weights, n_feat, n_rows, space, add_bias, se_type, y_var, out);
+}
+
+int pds_lr_grouped_f64(pds_ctx* ctx, const double* const* cols, int n_feat, int64_t n_rows,
+                       const int64_t* group_offsets, int64_t n_groups, pds_space space, const pds_lr_params* prm,
+                       double* coeffs, uint8_t* is_null) {
+    return grouped_impl<double>(ctx, cols, n_feat, n_rows, group_offsets, n_groups, space, prm, coeffs, is_null);
+}
+int pds_lr_grouped_f32(pds_ctx* ctx, const float* const* cols, int n_feat, int64_t n_rows,
+                       const int64_t* group_offsets, int64_t n_groups, pds_space space, const pds_lr_params* prm,
+                       float* coeffs, uint8_t* is_null) {
+    return grouped_impl<float>(ctx, cols, n_feat, n_rows, group_offsets, n_groups, space, prm, coeffs, is_null);
+}
+
+int pds_rolling_lr_f64(pds_ctx* ctx, const double* const* cols, int n_feat, int64_t n_rows, pds_space space,
+                       int add_bias, int64_t window, int64_t min_size, double lambda, double* coeffs, double* pred,
+                       uint8_t* valid) {
+    return rolling_impl<double>(ctx, cols, n_feat, n_rows, space, add_bias, window, min_size, lambda, false, coeffs, pred, valid);
+}
+int pds_rolling_lr_f32(pds_ctx* ctx, const float* const* cols, int n_feat, int64_t n_rows, pds_space space,
+                       int add_bias, int64_t window, int64_t min_size, float lambda, float* coeffs, float* pred,
+                       uint8_t* valid) {
+    return rolling_impl<float>(ctx, cols, n_feat, n_rows, space, add_bias, window, min_size, lambda, false, coeffs, pred, valid);
+}
+int pds_recursive_lr_f64(pds_ctx* ctx, const double* const* cols, int n_feat, int64_t n_rows, pds_space space,
+                         int add_bias, int64_t start_with, double lambda, double* coeffs, double* pred,
+                         uint8_t* valid) {
+    return rolling_impl<double>(ctx, cols, n_feat, n_rows, space, add_bias, start_with, 0, lambda, true, coeffs, pred, valid);
+}
+int pds_recursive_lr_f32(pds_ctx* ctx, const float* const* cols, int n_feat, int64_t n_rows, pds_space space,
+                         int add_bias, int64_t start_with, float lambda, float* coeffs, float* pred, uint8_t* valid) {
+    return rolling_impl<float>(ctx, cols, n_feat, n_rows, space, add_bias, start_with, 0, lambda, true, coeffs, pred, valid);
+}
+
+int pds_moments_f64(pds_ctx* ctx, const double* const* cols, const double* weights, int n_feat, int64_t n_rows,
+                    pds_space space, double* moments, pds_space out_space) {
+    return moments_impl<double>(ctx, cols, weights, n_feat, n_rows, space, moments, out_space);
+}
+int pds_moments_f32(pds_ctx* ctx, const float* const* cols, const float* weights, int n_feat, int64_t n_rows,
+                    pds_space space, float* moments, pds_space out_space) {
+    return moments_impl<float>(ctx, cols, weights, n_feat, n_rows, space, moments, out_space);
+}
+int pds_lr_from_moments_f64(pds_ctx* ctx, const double* moments, pds_space mom_space, int n_feat,
+                            const pds_lr_params* prm, double* coeffs, int* is_null) {
+    return from_moments_impl<double>(ctx, moments, mom_space, n_feat, prm, coeffs, is_null);
+}
+int pds_lr_from_moments_f32(pds_ctx* ctx, const float* moments, pds_space mom_space, int n_feat,
+                            const pds_lr_params* prm, float* coeffs, int* is_null) {
+    return from_moments_impl<float>(ctx, moments, mom_space, n_feat, prm, coeffs, is_null);
+}
+
+}  // extern "C"

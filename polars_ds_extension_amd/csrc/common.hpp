@@ -1,0 +1,136 @@
+// common.hpp -- shared declarations of libpds_lstsq_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pds_lstsq.h"
+
+namespace pds {
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing: thread-local message, like the plugin ABI's `_polars_plugin_get_last_error_message`
+// ---------------------------------------------------------------------------------------------
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+#define PDS_HIP_CHECK(expr)                                                                     \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess)                                                                   \
+            return pds::fail(PDS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));  \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// moment-matrix layout.  For p features: q = p + 2, Z = [x_0 .. x_{p-1} | 1 | y], A = Z'Z stored
+// column-major q x q.  Index helpers:
+//   A[i + j*q], i,j < p : X'X          A[i + p*q]      : column sums (bias row/col)
+//   A[p + p*q]          : n (or sum w) A[i + (p+1)*q]  : X'y
+//   A[p + (p+1)*q]      : sum y        A[(p+1)+(p+1)*q]: y'y
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxFeatSmall = 16;   // one MFMA 16x16 block of features
+constexpr int kMaxFeatWide = 64;    // four blocks; beyond that -> tiled SYRK kernel (f32) / unsupported
+constexpr int kTileBytesPerLane = 16;
+
+// per-block partial record of the small-p moment kernel (doubles):
+//   [0,256)  D[i + 16*j]   X'X tile     [256,272) xy[f]   [272,288) cs[f]   288 yy  289 ys  290 sw
+constexpr int kPartD = 0, kPartXY = 256, kPartCS = 272, kPartYY = 288, kPartYS = 289, kPartSW = 290;
+constexpr int kPartStride = 296;
+
+struct Workspace {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace pds
+
+struct pds_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cus = 256;
+    double* partials = nullptr; // per-block partial records (num_cus * 8 blocks * kPartStride doubles)
+    pds::Workspace ws;       // HBM scratch for call-local arrays (bump allocated per call)
+    size_t ws_used = 0;
+    pds::Workspace stage;    // HBM staging of PDS_HOST column buffers
+    void* pinned = nullptr;  // pinned host scratch (small results, pointer arrays)
+    size_t pinned_bytes = 0;
+};
+
+namespace pds {
+
+int ensure_ws(pds_ctx* ctx, Workspace& w, size_t bytes);
+int ensure_pinned(pds_ctx* ctx, size_t bytes);
+// call-local bump allocation inside ctx->ws: ws_reserve() once per API call with an upper bound, then
+// ws_take() hands out 256-byte aligned slices (never fails after a successful reserve).
+int ws_reserve(pds_ctx* ctx, size_t total_bytes);
+void* ws_take(pds_ctx* ctx, size_t bytes);
+
+// Columns resident in HBM for the duration of one call.  For PDS_DEVICE inputs this is just the
+// pointer array copied to the device; for PDS_HOST inputs the column buffers are staged into HBM.
+template <typename T>
+struct DeviceCols {
+    const T** d_ptrs = nullptr;  // device array of nc pointers
+    std::vector<const T*> h_ptrs; // the same pointers on the host
+    int nc = 0;
+};
+
+// order on device: x_0..x_{p-1}, y, [w]
+template <typename T>
+int make_device_cols(pds_ctx* ctx, const T* const* cols /*[y,x1..xp]*/, const T* weights, int n_feat,
+                     int64_t n_rows, pds_space space, DeviceCols<T>& out);
+
+// ---- kernels' host launchers (moments.hip) ----
+template <typename T>
+int launch_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, bool weighted,
+                   T* d_moments /*device, (p+2)^2*/);
+
+// segmented (per-group) moments: d_moments [n_groups][(p+2)^2]
+template <typename T>
+int launch_grouped_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, const int64_t* d_offsets,
+                           int64_t n_groups, T* d_moments);
+
+// ---- solve.hip ----
+struct SolveParams {
+    int p;         // features (without bias)
+    int add_bias;
+    int solver;
+    double lambda; // l2 added to the first p diagonals (not the bias)
+    double gate_tol; // <= 0: no gate
+    int lambda_on_bias; // rolling / recursive: lambda on every diagonal
+};
+// batched: moments [n_sys][(p+2)^2] -> coeffs [n_sys][p+bias], flags [n_sys] (1 = null)
+// optional inv_out [n_sys][p'*p'] (column-major) = (X'X + lambda)^-1 via the QR, and logdet.
+template <typename T>
+int launch_solve(pds_ctx* ctx, const T* d_moments, int64_t n_sys, const SolveParams& sp, T* d_coeffs,
+                 uint8_t* d_flags, T* d_inv_out, const int64_t* d_rows_per_sys /*nullable*/);
+
+template <typename T>
+int launch_cd(pds_ctx* ctx, const T* d_moments, int p, int add_bias, double l1, double l2, double tol,
+              int max_iter, int positive, T* d_coeffs, int* d_info /*[0]=sweeps,[1]=converged*/);
+template <typename T>
+int launch_nnls(pds_ctx* ctx, const T* d_moments, int p, int add_bias, double tol, int max_iter, T* d_coeffs);
+
+// ---- pass2.hip ----
+// streaming residual pass: pred/resid (nullable outputs), sums: [0]=sum e^2, [1]=sum w e^2,
+// meat (p' x p') = sum s_i x_i x_i' with s_i = e_i^2 * hc_scale(h_ii) when meat != null.
+template <typename T>
+int launch_pass2(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, int add_bias,
+                 bool weighted, const T* d_beta, const T* d_inv /*nullable, for HC2/3*/, int hc_mode,
+                 T* d_pred, T* d_resid, double* d_sums /*[2]*/, double* d_meat /*p'*p' or null*/);
+
+// ---- rolling.hip ----
+template <typename T>
+int launch_rolling(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, int add_bias,
+                   int64_t window, int64_t min_size, double lambda, bool expanding, T* d_coeffs,
+                   T* d_pred, uint8_t* d_valid);
+
+// ---- stats.cpp ----
+double student_t_sf(double x, double df, bool* err);
+double student_t_ppf(double q, double df);
+
+}  // namespace pds

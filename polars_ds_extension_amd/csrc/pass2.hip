@@ -1,0 +1,202 @@
+// pass2.hip -- the second streaming pass of pl_lr_pred / pl_lin_reg_report / pl_wls_report:
+//   pred = X b, resid = y - pred                      (linear_regression.rs:782-785, 863, 1036)
+//   sum e^2, sum w e^2                                 (:866-879, 1037-1042)
+//   s_i = e_i^2 * {1, 1/(1-h_ii), 1/(1-h_ii)^2}        (HC0/1, HC2, HC3 :880-909), h_ii = x_i' (X'X)^-1 x_i
+// The HC "meat" sum_i s_i x_i x_i' is then ONE MORE weighted Gram build (moments.hip with w = s), so the
+// reference's p' x N temporary (X'X)^-1 X' (:857) never exists.
+//
+// Layout: lane = row (RPL consecutive rows per lane, 16-byte loads, 1 KiB coalesced per instruction);
+// b and (X'X)^-1 are wave-uniform and come through the scalar cache.  HBM-bound: reads N(p+1)[+1]
+// elements, writes 0..3 N.
+#include "common.hpp"
+
+namespace pds {
+
+template <typename T>
+struct V16;
+template <>
+struct V16<double> {
+    typedef double type __attribute__((ext_vector_type(2), aligned(8)));
+    static constexpr int RPL = 2;
+};
+template <>
+struct V16<float> {
+    typedef float type __attribute__((ext_vector_type(4), aligned(4)));
+    static constexpr int RPL = 4;
+};
+
+constexpr int kP2Threads = 256;
+
+template <typename T, bool WEIGHTED, int HC>
+__global__ __launch_bounds__(kP2Threads) void pass2_kernel(const T* const* __restrict__ cols, int p, int bias,
+                                                           int64_t n, const T* __restrict__ beta,
+                                                           const T* __restrict__ inv, T* __restrict__ pred_out,
+                                                           T* __restrict__ resid_out, T* __restrict__ s_out,
+                                                           double* __restrict__ partials) {
+    using V = typename V16<T>::type;
+    constexpr int RPL = V16<T>::RPL;
+    const int pp = p + bias;
+    double sse = 0.0, wsse = 0.0;
+    const int64_t nvec = (n + RPL - 1) / RPL;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = v * RPL;
+        const bool full = row + RPL <= n;
+        V x[16];
+        V yv, wv;
+        if (full) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                if (c < p) x[c] = *reinterpret_cast<const V*>(cols[c] + row);
+            yv = *reinterpret_cast<const V*>(cols[p] + row);
+            if (WEIGHTED) wv = *reinterpret_cast<const V*>(cols[p + 1] + row);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                if (c < p) {
+#pragma unroll
+                    for (int e = 0; e < RPL; ++e) x[c][e] = (row + e < n) ? cols[c][row + e] : T(0);
+                }
+#pragma unroll
+            for (int e = 0; e < RPL; ++e) yv[e] = (row + e < n) ? cols[p][row + e] : T(0);
+            if (WEIGHTED) {
+#pragma unroll
+                for (int e = 0; e < RPL; ++e) wv[e] = (row + e < n) ? cols[p + 1][row + e] : T(0);
+            }
+        }
+        V pr, rs, sv;
+#pragma unroll
+        for (int e = 0; e < RPL; ++e) {
+            T acc = bias ? beta[p] : T(0);
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                if (c < p) acc += x[c][e] * beta[c];
+            pr[e] = acc;
+            const T r = yv[e] - acc;
+            rs[e] = r;
+            const bool in = row + e < n;
+            const double rd = in ? (double)r : 0.0;
+            sse = fma(rd, rd, sse);
+            if (WEIGHTED) wsse = fma((double)wv[e], rd * rd, wsse);
+            if (HC) {
+                T s = r * r;
+                if (HC >= 2) {  // leverage h = x' inv x (inv is pp x pp column-major, symmetric)
+                    T h = T(0);
+#pragma unroll
+                    for (int a = 0; a < 16; ++a)
+                        if (a < p) {
+                            T t = bias ? inv[a + p * pp] : T(0);
+#pragma unroll
+                            for (int b = 0; b < 16; ++b)
+                                if (b < p) t += inv[a + b * pp] * x[b][e];
+                            h += x[a][e] * t;
+                        }
+                    if (bias) {
+                        T t = inv[p + p * pp];
+#pragma unroll
+                        for (int b = 0; b < 16; ++b)
+                            if (b < p) t += inv[p + b * pp] * x[b][e];
+                        h += t;
+                    }
+                    const T om = T(1) - h;
+                    s = (HC == 2) ? s * (T(1) / om) : s * (T(1) / (om * om));
+                }
+                sv[e] = in ? s : T(0);
+            }
+        }
+        if (full) {
+            if (pred_out) *reinterpret_cast<V*>(pred_out + row) = pr;
+            if (resid_out) *reinterpret_cast<V*>(resid_out + row) = rs;
+            if (HC) *reinterpret_cast<V*>(s_out + row) = sv;
+        } else {
+#pragma unroll
+            for (int e = 0; e < RPL; ++e)
+                if (row + e < n) {
+                    if (pred_out) pred_out[row + e] = pr[e];
+                    if (resid_out) resid_out[row + e] = rs[e];
+                    if (HC) s_out[row + e] = sv[e];
+                }
+        }
+    }
+    // block reduction (fixed order) -> one partial pair per block
+    __shared__ double red[2][kP2Threads / 64];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        sse += __shfl_xor(sse, o);
+        wsse += __shfl_xor(wsse, o);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[0][wave] = sse;
+        red[1][wave] = wsse;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int w = 0; w < kP2Threads / 64; ++w) {
+            a += red[0][w];
+            b += red[1][w];
+        }
+        partials[2 * blockIdx.x] = a;
+        partials[2 * blockIdx.x + 1] = b;
+    }
+}
+
+__global__ void pass2_finalize_kernel(const double* __restrict__ partials, int nblocks, double* __restrict__ sums) {
+    // single wave, fixed order
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 64) {
+        a += partials[2 * i];
+        b += partials[2 * i + 1];
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        a += __shfl_xor(a, o);
+        b += __shfl_xor(b, o);
+    }
+    if (threadIdx.x == 0) {
+        sums[0] = a;
+        sums[1] = b;
+    }
+}
+
+template <typename T, bool W>
+static void launch_p2(int hc, dim3 g, hipStream_t st, const T* const* cols, int p, int bias, int64_t n, const T* beta,
+                      const T* inv, T* pred, T* resid, T* s, double* partials) {
+    switch (hc) {
+        case 0: hipLaunchKernelGGL((pass2_kernel<T, W, 0>), g, dim3(kP2Threads), 0, st, cols, p, bias, n, beta, inv, pred, resid, s, partials); break;
+        case 1: hipLaunchKernelGGL((pass2_kernel<T, W, 1>), g, dim3(kP2Threads), 0, st, cols, p, bias, n, beta, inv, pred, resid, s, partials); break;
+        case 2: hipLaunchKernelGGL((pass2_kernel<T, W, 2>), g, dim3(kP2Threads), 0, st, cols, p, bias, n, beta, inv, pred, resid, s, partials); break;
+        default: hipLaunchKernelGGL((pass2_kernel<T, W, 3>), g, dim3(kP2Threads), 0, st, cols, p, bias, n, beta, inv, pred, resid, s, partials); break;
+    }
+}
+
+// d_meat: when hc_mode != 0 the caller passes a device buffer of n_rows T values in d_meat (reused as
+// the per-row weight vector s); the caller then runs the weighted moment kernel on it.
+template <typename T>
+int launch_pass2(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, int add_bias, bool weighted,
+                 const T* d_beta, const T* d_inv, int hc_mode, T* d_pred, T* d_resid, double* d_sums,
+                 double* d_s_rows) {
+    if (n_feat < 1 || n_feat > kMaxFeatSmall) return fail(PDS_ERR_UNSUPPORTED, "pass2: 1..16 features supported");
+    constexpr int RPL = V16<T>::RPL;
+    const int64_t nvec = (n_rows + RPL - 1) / RPL;
+    int64_t want = (nvec + kP2Threads - 1) / kP2Threads;
+    const int nblocks = (int)std::min<int64_t>(std::max<int64_t>(want, 1), (int64_t)ctx->num_cus * 8);
+    double* partials = ctx->partials;
+    T* s_rows = reinterpret_cast<T*>(d_s_rows);
+    if (weighted)
+        launch_p2<T, true>(hc_mode, dim3(nblocks), ctx->stream, dc.d_ptrs, n_feat, add_bias ? 1 : 0, n_rows, d_beta,
+                           d_inv, d_pred, d_resid, s_rows, partials);
+    else
+        launch_p2<T, false>(hc_mode, dim3(nblocks), ctx->stream, dc.d_ptrs, n_feat, add_bias ? 1 : 0, n_rows, d_beta,
+                            d_inv, d_pred, d_resid, s_rows, partials);
+    hipLaunchKernelGGL(pass2_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream, partials, nblocks, d_sums);
+    PDS_HIP_CHECK(hipGetLastError());
+    return PDS_OK;
+}
+
+template int launch_pass2<double>(pds_ctx*, const DeviceCols<double>&, int, int64_t, int, bool, const double*,
+                                  const double*, int, double*, double*, double*, double*);
+template int launch_pass2<float>(pds_ctx*, const DeviceCols<float>&, int, int64_t, int, bool, const float*,
+                                 const float*, int, float*, float*, double*, double*);
+
+}  // namespace pds

@@ -1,0 +1,353 @@
+"""
+Host-side mirror of the reference's least-squares expression interface on top of the C ABI.
+
+Function names, keyword names, defaults and error behaviour follow
+/root/reference/python/polars_ds/exprs/expr_linear.py (`lin_reg` :105-274, `lin_reg_report` :561-631,
+`rolling_lin_reg` :482-558, `recursive_lin_reg` :413-479) and the Rust plugin functions they call
+(src/num_ext/linear_regression.rs).  What differs is only the carrier: instead of a lazy `pl.Expr`
+evaluated by Polars (not installable in this image) the functions take the column buffers directly --
+numpy arrays (host memory, what an Arrow Float64/Float32 buffer is) or torch CUDA tensors (already in HBM).
+All arithmetic happens in libpds_lstsq_hip.so; nothing here computes a regression on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence
+
+import numpy as np
+
+from . import _lib, config
+
+__all__ = [
+    "Context", "default_context", "lin_reg", "lin_reg_report", "lin_reg_by", "rolling_lin_reg",
+    "recursive_lin_reg", "lin_reg_w_rcond", "gram_moments", "lin_reg_from_moments",
+]
+
+
+def _is_torch(a) -> bool:
+    return type(a).__module__.startswith("torch")
+
+
+def _dtype():
+    return np.float64 if config.LIN_REG_EXPR_F64 else np.float32
+
+
+def _suffix() -> str:
+    return "_f64" if config.LIN_REG_EXPR_F64 else "_f32"
+
+
+class _Cols:
+    """Column buffers (kept alive) + the void** array the C ABI wants, in the order [y, x1..xp]."""
+
+    def __init__(self, y, xs: Sequence, weights=None):
+        dt = _dtype()
+        arrs = [y, *xs] + ([weights] if weights is not None else [])
+        if any(_is_torch(a) for a in arrs):
+            import torch
+
+            tdt = torch.float64 if dt == np.float64 else torch.float32
+            keep = []
+            for a in arrs:
+                if not _is_torch(a):
+                    a = torch.as_tensor(np.asarray(a))
+                if not a.is_cuda:
+                    a = a.cuda()
+                keep.append(a.to(tdt).contiguous())  # cast like series_to_slice_inner (src/utils/mod.rs:134-205)
+            self.space = _lib.PDS_DEVICE
+            ptrs = [int(a.data_ptr()) for a in keep]
+            self.n_rows = int(keep[0].shape[0])
+            self.device_index = keep[0].device.index or 0
+        else:
+            keep = [np.ascontiguousarray(np.asarray(a), dtype=dt) for a in arrs]
+            self.space = _lib.PDS_HOST
+            ptrs = [int(a.ctypes.data) for a in keep]
+            self.n_rows = int(keep[0].shape[0])
+            self.device_index = None
+        for a in keep:
+            if a.ndim != 1 or int(a.shape[0]) != self.n_rows:
+                raise ValueError("all columns must be 1-D and of equal length")
+        self.keep = keep
+        self.n_feat = len(xs)
+        nb = 1 + self.n_feat
+        self.cols = (C.c_void_p * nb)(*ptrs[:nb])
+        self.weights = C.c_void_p(ptrs[nb]) if weights is not None else C.c_void_p(None)
+
+
+class Context:
+    """One pds_ctx: a device, a stream, HBM workspace.  Not thread-safe; use one per thread."""
+
+    def __init__(self, device: int = 0, stream=None):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        _lib.check(self._lib.pds_ctx_create(int(device), C.byref(self._h)))
+        self.device = int(device)
+        if stream is not None:
+            self.set_stream(stream)
+
+    def set_stream(self, stream) -> None:
+        """stream: a torch.cuda.Stream, a raw hipStream_t integer, or None (private stream)."""
+        raw = getattr(stream, "cuda_stream", stream)
+        _lib.check(self._lib.pds_ctx_set_stream(self._h, C.c_void_p(int(raw) if raw else None)))
+
+    def synchronize(self) -> None:
+        _lib.check(self._lib.pds_ctx_synchronize(self._h))
+
+    @property
+    def num_cus(self) -> int:
+        return int(self._lib.pds_ctx_num_cus(self._h))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.pds_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def fn(self, name: str):
+        return getattr(self._lib, name + _suffix())
+
+
+_default: Context | None = None
+
+
+def default_context() -> Context:
+    global _default
+    if _default is None:
+        _default = Context(0)
+    return _default
+
+
+def _params(add_bias, l1_reg, l2_reg, tol, solver, positive, max_iter, singular_x_tol) -> _lib.LRParams:
+    if singular_x_tol is None:  # dtype-aware default, expr_linear.py:184-186
+        singular_x_tol = 1e-12 if config.LIN_REG_EXPR_F64 else 1e-6
+    return _lib.LRParams(int(bool(add_bias)), float(l1_reg), float(l2_reg), float(tol), _lib.SOLVERS.get(solver, 0),
+                         int(bool(positive)), int(max_iter), float(singular_x_tol))
+
+
+def _out_like(cols: _Cols, shape):
+    """An output buffer in the same memory space as the inputs."""
+    if cols.space == _lib.PDS_DEVICE:
+        import torch
+
+        tdt = torch.float64 if config.LIN_REG_EXPR_F64 else torch.float32
+        t = torch.empty(shape, dtype=tdt, device=cols.keep[0].device)
+        return t, C.c_void_p(int(t.data_ptr()))
+    a = np.empty(shape, dtype=_dtype())
+    return a, C.c_void_p(a.ctypes.data)
+
+
+def _out_u8(cols: _Cols, n):
+    if cols.space == _lib.PDS_DEVICE:
+        import torch
+
+        t = torch.empty(n, dtype=torch.uint8, device=cols.keep[0].device)
+        return t, C.c_void_p(int(t.data_ptr()))
+    a = np.empty(n, dtype=np.uint8)
+    return a, C.c_void_p(a.ctypes.data)
+
+
+def lin_reg(*x, target, add_bias: bool = False, weights=None, return_pred: bool = False, l1_reg: float = 0.0,
+            l2_reg: float = 0.0, tol: float = 1e-5, solver: str = "qr", max_iter: int = 200, positive: bool = False,
+            singular_x_tol: float | None = None, ctx: Context | None = None):
+    """
+    pds.lin_reg on null-free column buffers (pl_lr / pl_lr_pred).
+
+    Returns the coefficient vector (bias last) or None when the rank gate fires (the reference returns
+    a null list).  With return_pred=True returns (pred, resid) -- or None when gated (the reference
+    returns an all-null struct).
+    """
+    if max_iter <= 0:
+        raise ValueError("Input `max_iter` must be a positive.")  # expr_linear.py:231-232
+    ctx = ctx or default_context()
+    cols = _Cols(target, x, weights)
+    prm = _params(add_bias, l1_reg, l2_reg, tol, solver, positive, max_iter, singular_x_tol)
+    pp = cols.n_feat + int(bool(add_bias))
+    coeffs = np.empty(pp, dtype=_dtype())
+    is_null = C.c_int(0)
+    if return_pred:
+        pred, pred_p = _out_like(cols, cols.n_rows)
+        resid, resid_p = _out_like(cols, cols.n_rows)
+        _lib.check(ctx.fn("pds_lr_pred")(ctx._h, cols.cols, cols.weights, cols.n_feat, C.c_int64(cols.n_rows), cols.space,
+                                         C.byref(prm), C.c_void_p(coeffs.ctypes.data), C.byref(is_null), pred_p, resid_p))
+        return None if is_null.value else (pred, resid)
+    _lib.check(ctx.fn("pds_lr")(ctx._h, cols.cols, cols.weights, cols.n_feat, C.c_int64(cols.n_rows), cols.space,
+                                C.byref(prm), C.c_void_p(coeffs.ctypes.data), C.byref(is_null)))
+    return None if is_null.value else coeffs
+
+
+def lin_reg_w_rcond(*x, target, add_bias: bool = False, rcond: float = 0.0, l2_reg: float = 0.0, ctx: Context | None = None):
+    """pds.lin_reg_w_rcond (pl_lr_w_rcond): returns (coeffs, singular_values).  f64 only."""
+    if not config.LIN_REG_EXPR_F64:
+        raise NotImplementedError("lin_reg_w_rcond is f64 only here")
+    ctx = ctx or default_context()
+    cols = _Cols(target, x)
+    pp = cols.n_feat + int(bool(add_bias))
+    rc = max(float(rcond), np.finfo(np.float64).eps * max(cols.n_rows, pp))  # linear_regression.rs:651-702
+    coeffs = np.empty(pp)
+    sv = np.empty(pp)
+    _lib.check(ctx._lib.pds_lr_rcond_f64(ctx._h, cols.cols, cols.n_feat, C.c_int64(cols.n_rows), cols.space,
+                                         int(bool(add_bias)), C.c_double(l2_reg), C.c_double(rc),
+                                         C.c_void_p(coeffs.ctypes.data), C.c_void_p(sv.ctypes.data)))
+    return coeffs, sv
+
+
+def lin_reg_report(*x, target, add_bias: bool = False, weights=None, std_err: str = "se", y_var: float | None = None,
+                   feature_names: Sequence[str] | None = None, ctx: Context | None = None) -> dict:
+    """
+    pds.lin_reg_report (pl_lin_reg_report / pl_wls_report).  `y_var` is what Polars evaluates as
+    `target.var()` (ddof=1) and hands to the plugin as input 0 (expr_linear.py:614-617); when omitted it
+    is taken from the moment pass (sum y, sum y^2 are by-products of the Gram build).
+    Returns the 9 report columns as a dict of arrays (r2 / adj_r2 broadcast like the reference's struct).
+    """
+    ctx = ctx or default_context()
+    cols = _Cols(target, x, weights)
+    pp = cols.n_feat + int(bool(add_bias))
+    if y_var is None:
+        M = gram_moments(*x, target=target, ctx=ctx)
+        q = cols.n_feat + 2
+        n = float(cols.n_rows)
+        sy, syy = float(M[q - 2, q - 1]), float(M[q - 1, q - 1])
+        y_var = (syy - sy * sy / n) / (n - 1.0)
+    dt = _dtype()
+    outs = {k: np.empty(pp, dtype=dt) for k in ("beta", "std_err", "t", "p", "ci_lower", "ci_upper")}
+    R = _lib.ReportF64 if config.LIN_REG_EXPR_F64 else _lib.ReportF32
+    rep = R(*[C.c_void_p(outs[k].ctypes.data) for k in ("beta", "std_err", "t", "p", "ci_lower", "ci_upper")], 0.0, 0.0)
+    yv = C.c_double(y_var) if config.LIN_REG_EXPR_F64 else C.c_float(y_var)
+    _lib.check(ctx.fn("pds_lin_reg_report")(ctx._h, cols.cols, cols.weights, cols.n_feat, C.c_int64(cols.n_rows),
+                                            cols.space, int(bool(add_bias)), _lib.SE_TYPES.get(std_err, 0), yv,
+                                            C.byref(rep)))
+    names = list(feature_names) if feature_names is not None else [f"x{i + 1}" for i in range(cols.n_feat)]
+    if add_bias:
+        names.append("__bias__")  # linear_regression.rs:843-845
+    se_name = {"se": "std_err", "hc0": "hc0_se", "hc1": "hc1_se", "hc2": "hc2_se", "hc3": "hc3_se"}.get(std_err, "std_err")
+    if weights is not None:
+        se_name = "std_err"
+    return {
+        "features": names, "beta": outs["beta"], se_name: outs["std_err"], "t": outs["t"], "p>|t|": outs["p"],
+        "0.025": outs["ci_lower"], "0.975": outs["ci_upper"],
+        "r2": np.full(pp, rep.r2, dtype=dt), "adj_r2": np.full(pp, rep.adj_r2, dtype=dt),
+    }
+
+
+def lin_reg_by(*x, target, group_offsets, add_bias: bool = False, l2_reg: float = 0.0, solver: str = "qr",
+               singular_x_tol: float | None = None, ctx: Context | None = None):
+    """
+    The key-aware batched form of `df.group_by(key).agg(pds.lin_reg(...))` (SURVEY.md 8b "pl_lr_by").
+    Rows of a group are contiguous; group g = rows [group_offsets[g], group_offsets[g+1]).
+    Returns (coeffs [n_groups, p'], is_null [n_groups]) in the memory space of the inputs.
+    """
+    ctx = ctx or default_context()
+    cols = _Cols(target, x)
+    prm = _params(add_bias, 0.0, l2_reg, 1e-5, solver, False, 200, singular_x_tol)
+    pp = cols.n_feat + int(bool(add_bias))
+    if cols.space == _lib.PDS_DEVICE:
+        import torch
+
+        off = group_offsets if _is_torch(group_offsets) else torch.as_tensor(np.asarray(group_offsets))
+        off = off.to(device=cols.keep[0].device, dtype=torch.int64).contiguous()
+        off_p = C.c_void_p(int(off.data_ptr()))
+    else:
+        off = np.ascontiguousarray(np.asarray(group_offsets), dtype=np.int64)
+        off_p = C.c_void_p(off.ctypes.data)
+    ng = int(off.shape[0]) - 1
+    coeffs, co_p = _out_like(cols, (ng, pp))
+    nulls, nu_p = _out_u8(cols, ng)
+    _lib.check(ctx.fn("pds_lr_grouped")(ctx._h, cols.cols, cols.n_feat, C.c_int64(cols.n_rows), off_p, C.c_int64(ng),
+                                        cols.space, C.byref(prm), co_p, nu_p))
+    return coeffs, nulls
+
+
+def _windowed(name, x, target, n, add_bias, l2_reg, min_size, ctx):
+    ctx = ctx or default_context()
+    cols = _Cols(target, x)
+    pp = cols.n_feat + int(bool(add_bias))
+    coeffs, co_p = _out_like(cols, (cols.n_rows, pp))
+    pred, pr_p = _out_like(cols, cols.n_rows)
+    valid, va_p = _out_u8(cols, cols.n_rows)
+    lam = C.c_double(abs(l2_reg)) if config.LIN_REG_EXPR_F64 else C.c_float(abs(l2_reg))  # `lambda`: abs(l2_reg) :546-552
+    if name == "pds_rolling_lr":
+        _lib.check(ctx.fn(name)(ctx._h, cols.cols, cols.n_feat, C.c_int64(cols.n_rows), cols.space, int(bool(add_bias)),
+                                C.c_int64(n), C.c_int64(min_size), lam, co_p, pr_p, va_p))
+    else:
+        _lib.check(ctx.fn(name)(ctx._h, cols.cols, cols.n_feat, C.c_int64(cols.n_rows), cols.space, int(bool(add_bias)),
+                                C.c_int64(n), lam, co_p, pr_p, va_p))
+    return coeffs, pred, valid
+
+
+def rolling_lin_reg(*x, target, window_size: int, add_bias: bool = False, l2_reg: float = 0.0,
+                    min_valid_rows: int | None = None, skip_non_finite: bool = False, ctx: Context | None = None):
+    """
+    pds.rolling_lin_reg (pl_rolling_lr).  Returns (coeffs [N, p'], pred [N], valid [N]); the first
+    window_size-1 rows are invalid (null in the reference).  skip_non_finite=True selects the
+    null_policy="skip" window algorithm (faer_rolling_skipping_lr) with min_valid_rows.
+    """
+    n_features = len(x) + int(bool(add_bias))
+    if window_size < 2:
+        raise ValueError("`window_size` must be >= 2.")  # expr_linear.py:524-526
+    if n_features > window_size:
+        raise ValueError("# features > window size. Linear regression is not well-defined.")  # :527-531
+    min_size = 0
+    if skip_non_finite:
+        min_size = min(n_features, window_size) if min_valid_rows is None else int(min_valid_rows)  # :535-543
+        if min_size < n_features or min_size > window_size:
+            raise ValueError("`min_valid_rows` must be in [#features, window_size].")
+    return _windowed("pds_rolling_lr", x, target, window_size, add_bias, l2_reg, min_size, ctx)
+
+
+def recursive_lin_reg(*x, target, start_with: int, add_bias: bool = False, l2_reg: float = 0.0, ctx: Context | None = None):
+    """pds.recursive_lin_reg (pl_recursive_lr): expanding-window fit from row start_with-1 on."""
+    n_features = len(x) + int(bool(add_bias))
+    if start_with < n_features:
+        raise ValueError("# features > number of rows for the initial fit.")  # expr_linear.py:455-459
+    return _windowed("pds_recursive_lr", x, target, start_with, add_bias, l2_reg, 0, ctx)
+
+
+def gram_moments(*x, target, weights=None, ctx: Context | None = None, out_device: bool = False):
+    """The augmented moment matrix A = Z'Z, Z = [x1..xp | 1 | y] ((p+2)^2), the measured Gram build."""
+    ctx = ctx or default_context()
+    cols = _Cols(target, x, weights)
+    q = cols.n_feat + 2
+    if out_device:
+        if cols.space != _lib.PDS_DEVICE:
+            raise ValueError("out_device requires device-resident inputs")
+        out, out_p = _out_like(cols, (q, q))
+        _lib.check(ctx.fn("pds_moments")(ctx._h, cols.cols, cols.weights, cols.n_feat, C.c_int64(cols.n_rows), cols.space,
+                                         out_p, _lib.PDS_DEVICE))
+        return out.t()  # column-major -> logical (symmetric anyway)
+    out = np.empty((q, q), dtype=_dtype())
+    _lib.check(ctx.fn("pds_moments")(ctx._h, cols.cols, cols.weights, cols.n_feat, C.c_int64(cols.n_rows), cols.space,
+                                     C.c_void_p(out.ctypes.data), _lib.PDS_HOST))
+    return out.T
+
+
+def lin_reg_from_moments(moments, *, add_bias: bool = False, l1_reg: float = 0.0, l2_reg: float = 0.0, tol: float = 1e-5,
+                         solver: str = "qr", max_iter: int = 200, positive: bool = False,
+                         singular_x_tol: float | None = None, ctx: Context | None = None):
+    """Solve from an (all-reduced) moment matrix: the replicated tail of the multi-GPU single-OLS path."""
+    ctx = ctx or default_context()
+    prm = _params(add_bias, l1_reg, l2_reg, tol, solver, positive, max_iter, singular_x_tol)
+    if _is_torch(moments):
+        import torch
+
+        tdt = torch.float64 if config.LIN_REG_EXPR_F64 else torch.float32
+        m = moments.to(tdt).t().contiguous() if moments.is_cuda else None
+        if m is None:
+            moments = moments.numpy()
+    if _is_torch(moments):
+        q = int(m.shape[0])
+        mp, space = C.c_void_p(int(m.data_ptr())), _lib.PDS_DEVICE
+    else:
+        m = np.asfortranarray(np.asarray(moments, dtype=_dtype()))
+        q = int(m.shape[0])
+        mp, space = C.c_void_p(m.ctypes.data), _lib.PDS_HOST
+    p = q - 2
+    pp = p + int(bool(add_bias))
+    coeffs = np.empty(pp, dtype=_dtype())
+    is_null = C.c_int(0)
+    _lib.check(ctx.fn("pds_lr_from_moments")(ctx._h, mp, space, p, C.byref(prm), C.c_void_p(coeffs.ctypes.data),
+                                             C.byref(is_null)))
+    return None if is_null.value else coeffs
