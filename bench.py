@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""
+bench.py -- headline measurement of the MI355X least-squares path.
+
+A "step" is one pass of the grouped least-squares hot path over one synthetic frame already resident in
+HBM: `group_by(key).agg(pds.lin_reg(x1..x16, target=y))` on 1e8 rows x 16 f64 features cut into 1e6
+contiguous groups of 100 rows (BASELINE.json: "grouped lstsq regressions/sec ... 1e8 rows x 16 f64
+feats").  `value` = regressions/s over the whole job (all ranks), wall clock bracketed by barrier +
+synchronize, max over ranks.  The same frame is then fed as ONE regression (config 2, single OLS) to
+measure the Gram build GB/s, reported under "gram_build".
+
+  roofline      dominant kernel of the step (the per-group Gram build): algorithmic bytes per launch /
+                average launch duration measured with HIP events on the launch stream (library hooks
+                pds_ctx_set_timing / pds_ctx_get_timing), against the 8 TB/s HBM3E peak.
+  cpu_baseline  the CPU restatement of the reference (oracle/, kind "port": the Rust crate cannot be
+                built here) timed on the host cores of this box on a bounded sample of the same frame.
+
+Multi-GPU (--gpus N, launched by torch.distributed.run): groups shard by key across ranks, no data-path
+collective (weak scaling: every rank owns 1e6 groups); see DESIGN.md "multi-GPU".
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--groups", type=int, default=1_000_000, help="groups per rank")
+    ap.add_argument("--rows-per-group", type=int, default=100)
+    ap.add_argument("--feats", type=int, default=16)
+    ap.add_argument("--cpu-sample-groups", type=int, default=200_000)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import polars_ds_extension_amd as pds
+
+    G, R, P = args.groups, args.rows_per_group, args.feats
+    N = G * R
+    ctx = pds.Context(local_rank)
+    ctx.set_stream(torch.cuda.current_stream(dev))
+
+    # ---- synthetic frame, generated in HBM (seeded per rank): x ~ N(0,1), per-group beta, noise 0.1
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    xs = [torch.randn(N, dtype=torch.float64, device=dev, generator=gen) for _ in range(P)]
+    y = torch.zeros(N, dtype=torch.float64, device=dev)
+    for j in range(P):
+        bj = torch.randn(G, dtype=torch.float64, device=dev, generator=gen)
+        y.add_(xs[j] * bj.repeat_interleave(R))
+        del bj
+    y.add_(torch.randn(N, dtype=torch.float64, device=dev, generator=gen), alpha=0.1)
+    offsets = torch.arange(0, N + 1, R, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize(dev)
+
+    def step():
+        return pds.lin_reg_by(*xs, target=y, group_offsets=offsets, add_bias=False, ctx=ctx)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.get_timing(reset=True)
+    ctx.set_timing(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        coeffs, nulls = step()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    ctx.set_timing(False)
+    timing = ctx.get_timing(reset=True)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * G / (elapsed / args.steps)
+
+    # ---- roofline of the dominant kernel (grouped Gram build), rank 0's launches
+    q = P + 2
+    gm_ms, gm_cnt = timing["grouped_moments"]
+    sv_ms, sv_cnt = timing["solve"]
+    launches_per_step = max(gm_cnt // max(args.steps, 1), 1)
+    groups_per_launch = G / launches_per_step
+    # algorithmic bytes per launch: every input element once + the group's moment record
+    bytes_per_group = R * (P + 1) * 8 + q * q * 8 + 16
+    alg_bytes = groups_per_launch * bytes_per_group
+    avg_ms = gm_ms / max(gm_cnt, 1)
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    roofline = {
+        "bound": "hbm", "kernel": "grouped_moments_kernel<double>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+        "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches_per_step,
+        "algorithmic_bytes_per_launch": int(alg_bytes),
+        "solve_ms_per_step": round(sv_ms / max(args.steps, 1), 4), "gram_ms_per_step": round(gm_ms / max(args.steps, 1), 4),
+    }
+
+    # ---- config 2 on the same frame: single OLS Gram build (pds_moments), HBM GB/s
+    gram = None
+    if rank == 0:
+        for _ in range(2):
+            pds.gram_moments(*xs, target=y, ctx=ctx)
+        ctx.get_timing(reset=True)
+        ctx.set_timing(True)
+        reps = 5
+        for _ in range(reps):
+            pds.gram_moments(*xs, target=y, ctx=ctx)
+        ctx.set_timing(False)
+        ms, cnt = ctx.get_timing(reset=True)["moments"]
+        gb = N * (P + 1) * 8 / 1e9
+        g_ms = ms / max(cnt, 1)
+        gram = {"workload": f"single OLS Gram build, {N:.0e} rows x {P} f64 feats", "algorithmic_GB": round(gb, 3),
+                "avg_launch_ms": round(g_ms, 4), "achieved_GBps": round(gb / (g_ms * 1e-3), 1),
+                "frac_of_hbm_peak": round(gb / (g_ms * 1e-3) / HBM_PEAK_GBPS, 4)}
+
+    # ---- CPU baseline + parity spot check on a bounded sample (rank 0, N = 1 only)
+    cpu = None
+    parity = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        from oracle import oracle as orc
+
+        orc.build()
+        gs = min(args.cpu_sample_groups, G)
+        ns = gs * R
+        host_cols = [y[:ns].cpu().numpy()] + [x[:ns].cpu().numpy() for x in xs]
+        off_h = np.arange(0, ns + 1, R, dtype=np.int64)
+        nthreads = orc.max_threads()
+        orc.grouped_lr(host_cols, off_h[: 1001], nthreads=nthreads)  # warm the thread pool
+        t1 = time.perf_counter()
+        co_cpu, nu_cpu = orc.grouped_lr(host_cols, off_h, add_bias=False, tol=1e-12, nthreads=nthreads)
+        t_cpu = time.perf_counter() - t1
+        cpu = {"value": round(gs / t_cpu, 1), "unit": "regressions/s", "cores": nthreads, "kind": "port",
+               "sample": f"{gs} groups x {R} rows x {P} f64 feats (first {ns} rows of the same frame), OpenMP over groups, "
+                         f"{t_cpu:.2f} s; per-group copy + X'X + gated col-piv QR as Polars drives pl_lr",
+               "nproc": os.cpu_count()}
+        co_gpu = coeffs[:gs].cpu().numpy()
+        num = np.linalg.norm(co_gpu - co_cpu, axis=1)
+        den = np.linalg.norm(co_cpu, axis=1)
+        parity = {"groups_checked": int(gs), "max_normwise_rel_err": float(np.max(num / den)),
+                  "null_mismatches": int(np.sum(nulls[:gs].cpu().numpy().astype(bool) != nu_cpu))}
+
+    if rank == 0:
+        line = {
+            "metric": "grouped lstsq regressions/sec (1e8 rows x 16 f64 feats; Gram-build GB/s under gram_build)",
+            "value": round(value, 1), "unit": "regressions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"group_by(key).agg(lin_reg): {G} groups x {R} rows x {P} f64 feats per GPU "
+                                   f"({N:.0e} rows), OLS with rank gate (pl_lr default path), inputs resident in HBM",
+                       "groups_per_gpu": G, "rows_per_group": R, "features": P, "parallelism": f"group-sharded x{world}"},
+            "roofline": roofline, "gram_build": gram, "cpu_baseline": cpu, "parity_spot_check": parity,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

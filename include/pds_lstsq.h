@@ -60,11 +60,20 @@ const char* pds_version(void);
 /* Creates a context on HIP device `device` (must be gfx950).  */
 int pds_ctx_create(int device, pds_ctx** out);
 void pds_ctx_destroy(pds_ctx* ctx);
-/* Use an existing hipStream_t (passed as void*) for all work of this context; NULL = own stream. */
+/* Use an existing hipStream_t (passed as void*) for all work of this context instead of the private
+ * non-blocking stream created with the context.  NULL selects HIP's default (null) stream. */
 int pds_ctx_set_stream(pds_ctx* ctx, void* hip_stream);
 int pds_ctx_synchronize(pds_ctx* ctx);
 /* Number of compute units of the context's device (256 on MI355X). */
 int pds_ctx_num_cus(const pds_ctx* ctx);
+/*
+ * Measurement hooks (bench.py): with timing enabled every kernel class is bracketed by a HIP event
+ * pair recorded on the context's stream.  pds_ctx_get_timing synchronises and returns, per class,
+ * the summed duration in ms and the number of bracketed launches.  Classes: 0 Gram/moments (single
+ * system, incl. its finalize), 1 grouped Gram, 2 batched solve, 3 residual pass, 4 rolling, 5 CD/NNLS.
+ */
+int pds_ctx_set_timing(pds_ctx* ctx, int enable);
+int pds_ctx_get_timing(pds_ctx* ctx, double* ms_sum, long long* counts, int n_kinds, int reset);
 
 /* ---- LRKwargs mirror (linear_regression.rs:27-45), minus the strings parsed by the host ---- */
 typedef struct {

@@ -272,6 +272,27 @@ def nn_lr(X, y, add_bias=False, tol=1e-5, max_iter=200, nthreads=1) -> np.ndarra
     return beta
 
 
+def grouped_lr(cols, group_offsets, add_bias=False, l2_reg=0.0, solver="qr", tol=1e-12, nthreads=1):
+    """
+    Per-group pl_lr as Polars' group_by drives it (one copy + gated solve per group, OpenMP over
+    groups).  cols = [y, x1..xp]; returns (coeffs [G, p'], is_null [G]).
+    """
+    dt = np.dtype(cols[0].dtype)
+    cols = [np.ascontiguousarray(c, dtype=dt) for c in cols]
+    p = len(cols) - 1
+    off = np.ascontiguousarray(group_offsets, dtype=np.int64)
+    G = off.shape[0] - 1
+    pp = p + int(bool(add_bias))
+    ptrs = (C.c_void_p * (p + 1))(*[c.ctypes.data for c in cols])
+    out = np.zeros((G, pp), dtype=dt)
+    flags = np.zeros(G, dtype=np.uint8)
+    fn = getattr(lib(), "orc_grouped_lr" + _suf(dt))
+    R = _real(dt)
+    fn(ptrs, C.c_int(p), _p(off), C.c_int64(G), C.c_int(bool(add_bias)), R(l2_reg), C.c_int(SOLVERS.get(solver, 0)),
+       R(tol), _p(out), _p(flags), C.c_int(nthreads))
+    return out, flags.astype(bool)
+
+
 # ----------------------------------------------------------------------------- online solvers
 def recursive_lr(X, y, start_with: int, l2_reg=0.0) -> np.ndarray:
     """faer_recursive_lr: (n - start_with + 1, p) coefficient rows."""

@@ -49,6 +49,9 @@ int orc_max_threads(void);
     int orc_solve_lr_rcond##S(const REAL* x, const REAL* y, int64_t n, int p, REAL lambda,        \
                               int add_bias, REAL rcond, REAL* beta, REAL* singular_values,        \
                               int nthreads);                                                       \
+    void orc_grouped_lr##S(const REAL* const* cols, int p, const int64_t* off, int64_t n_groups,  \
+                           int add_bias, REAL lambda, int solver, REAL tol, REAL* coeffs,         \
+                           unsigned char* flags, int nthreads);                                    \
     void orc_weighted_lr##S(const REAL* x, const REAL* y, const REAL* w, int64_t n, int p,        \
                             int solver, REAL* beta);                                               \
     int orc_cd_from_gram##S(const REAL* g, const REAL* xty, const REAL* col_sums, REAL y_sum,     \

@@ -19,7 +19,7 @@ SE_TYPES = {"se": 0, "hc0": 1, "hc1": 2, "hc2": 3, "hc3": 4}
 
 EXPORTS = [
     "pds_last_error", "pds_version", "pds_ctx_create", "pds_ctx_destroy", "pds_ctx_set_stream",
-    "pds_ctx_synchronize", "pds_ctx_num_cus",
+    "pds_ctx_synchronize", "pds_ctx_num_cus", "pds_ctx_set_timing", "pds_ctx_get_timing",
     "pds_lr_f64", "pds_lr_f32", "pds_lr_pred_f64", "pds_lr_pred_f32", "pds_lr_rcond_f64",
     "pds_lin_reg_report_f64", "pds_lin_reg_report_f32",
     "pds_lr_grouped_f64", "pds_lr_grouped_f32",
@@ -77,6 +77,14 @@ def load() -> C.CDLL:
                 f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
             )
+        # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64.  If this library
+        # were loaded first it would bind /opt/rocm's copy, torch would then bring a second runtime and
+        # whichever initialises HSA second sees "no ROCm-capable device".  Importing torch first makes the
+        # loader resolve our DT_NEEDED libamdhip64.so.7 to the copy that is already mapped.
+        try:
+            import torch  # noqa: F401
+        except Exception:  # torch-less host (e.g. a Rust plugin process): the system runtime is the only one
+            pass
         lib = C.CDLL(str(LIB_PATH))
         lib.pds_last_error.restype = C.c_char_p
         lib.pds_version.restype = C.c_char_p

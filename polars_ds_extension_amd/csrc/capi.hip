@@ -15,6 +15,28 @@ int fail(int code, const std::string& msg) {
     return code;
 }
 
+static hipEvent_t take_event(pds_ctx* ctx) {
+    if (!ctx->ev_pool.empty()) {
+        hipEvent_t e = ctx->ev_pool.back();
+        ctx->ev_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+KernelTimer::KernelTimer(pds_ctx* c, int k) : ctx(c), kind(k) {
+    if (!ctx->timing) return;
+    a = take_event(ctx);
+    b = take_event(ctx);
+    if (a) (void)hipEventRecord(a, ctx->stream);
+}
+KernelTimer::~KernelTimer() {
+    if (!ctx->timing || !a || !b) return;
+    (void)hipEventRecord(b, ctx->stream);
+    ctx->ev_pending.push_back({kind, a, b});
+}
+
 int ensure_ws(pds_ctx* ctx, Workspace& w, size_t bytes) {
     if (bytes <= w.bytes) return PDS_OK;
     if (w.ptr) {
@@ -507,7 +529,7 @@ static int rolling_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
     const int pp = n_feat + (add_bias ? 1 : 0);
     if (window < 1 || window > n_rows) return fail(PDS_ERR_INVALID, "window / start_with must be in [1, n_rows]");
     PDS_HIP_CHECK(hipSetDevice(ctx->device));
-    size_t need = 131072;
+    size_t need = 131072 + ((size_t)(n_rows / 4096) + 2) * 96 * sizeof(double);  // + per-tile totals (expanding)
     if (space == PDS_HOST) need += (size_t)n_rows * ((pp + 1) * sizeof(T) + 1) + 4096;
     if (int rc = ws_reserve(ctx, need)) return rc;
     DeviceCols<T> dc;
@@ -579,6 +601,11 @@ void pds_ctx_destroy(pds_ctx* ctx) {
     if (ctx->ws.ptr) hipFree(ctx->ws.ptr);
     if (ctx->stage.ptr) hipFree(ctx->stage.ptr);
     if (ctx->pinned) hipHostFree(ctx->pinned);
+    for (auto& e : ctx->ev_pending) {
+        hipEventDestroy(e.a);
+        hipEventDestroy(e.b);
+    }
+    for (auto e : ctx->ev_pool) hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -588,13 +615,9 @@ int pds_ctx_set_stream(pds_ctx* ctx, void* hip_stream) {
     PDS_HIP_CHECK(hipSetDevice(ctx->device));
     PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
-    if (hip_stream) {
-        ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
-        ctx->own_stream = false;
-    } else {
-        PDS_HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-        ctx->own_stream = true;
-    }
+    // NULL is a valid hipStream_t: the (legacy) default stream, which is what torch uses unless told otherwise
+    ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    ctx->own_stream = false;
     return PDS_OK;
 }
 
@@ -605,6 +628,37 @@ int pds_ctx_synchronize(pds_ctx* ctx) {
 }
 
 int pds_ctx_num_cus(const pds_ctx* ctx) { return ctx ? ctx->num_cus : 0; }
+
+int pds_ctx_set_timing(pds_ctx* ctx, int enable) {
+    if (!ctx) return fail(PDS_ERR_INVALID, "null ctx");
+    ctx->timing = enable != 0;
+    return PDS_OK;
+}
+
+int pds_ctx_get_timing(pds_ctx* ctx, double* ms_sum, long long* counts, int n_kinds, int reset) {
+    if (!ctx) return fail(PDS_ERR_INVALID, "null ctx");
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (auto& e : ctx->ev_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess && e.kind >= 0 && e.kind < 8) {
+            ctx->kind_ms[e.kind] += ms;
+            ctx->kind_count[e.kind] += 1;
+        }
+        ctx->ev_pool.push_back(e.a);
+        ctx->ev_pool.push_back(e.b);
+    }
+    ctx->ev_pending.clear();
+    for (int k = 0; k < n_kinds && k < 8; ++k) {
+        if (ms_sum) ms_sum[k] = ctx->kind_ms[k];
+        if (counts) counts[k] = ctx->kind_count[k];
+    }
+    if (reset)
+        for (int k = 0; k < 8; ++k) {
+            ctx->kind_ms[k] = 0;
+            ctx->kind_count[k] = 0;
+        }
+    return PDS_OK;
+}
 
 int pds_lr_f64(pds_ctx* ctx, const double* const* cols, const double* weights, int n_feat, int64_t n_rows,
                pds_space space, const pds_lr_params* prm, double* coeffs, int* is_null) {

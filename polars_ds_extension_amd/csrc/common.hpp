@@ -59,9 +59,27 @@ struct pds_ctx {
     pds::Workspace stage;    // HBM staging of PDS_HOST column buffers
     void* pinned = nullptr;  // pinned host scratch (small results, pointer arrays)
     size_t pinned_bytes = 0;
+    // optional per-kernel-class HIP-event timing (pds_ctx_set_timing / pds_ctx_get_timing)
+    bool timing = false;
+    std::vector<hipEvent_t> ev_pool;
+    struct EvPair { int kind; hipEvent_t a, b; };
+    std::vector<EvPair> ev_pending;
+    double kind_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long kind_count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 namespace pds {
+
+// kernel classes for the timing hooks
+enum { kKindMoments = 0, kKindGroupedMoments = 1, kKindSolve = 2, kKindPass2 = 3, kKindRolling = 4, kKindIter = 5 };
+// RAII: records a HIP event pair around the launches issued in its scope when ctx->timing is on
+struct KernelTimer {
+    pds_ctx* ctx;
+    int kind;
+    hipEvent_t a = nullptr, b = nullptr;
+    KernelTimer(pds_ctx* c, int k);
+    ~KernelTimer();
+};
 
 int ensure_ws(pds_ctx* ctx, Workspace& w, size_t bytes);
 int ensure_pinned(pds_ctx* ctx, size_t bytes);
@@ -108,6 +126,11 @@ struct SolveParams {
 template <typename T>
 int launch_solve(pds_ctx* ctx, const T* d_moments, int64_t n_sys, const SolveParams& sp, T* d_coeffs,
                  uint8_t* d_flags, T* d_inv_out, const int64_t* d_rows_per_sys /*nullable*/);
+
+// solve_reg.hip: register-resident variant (p' <= 16, QR, no inverse); used by launch_solve
+template <typename T>
+int launch_solve_reg(pds_ctx* ctx, const T* d_moments, int64_t n_sys, const SolveParams& sp, T* d_coeffs,
+                     uint8_t* d_flags, const int64_t* d_rows_per_sys);
 
 template <typename T>
 int launch_cd(pds_ctx* ctx, const T* d_moments, int p, int add_bias, double l1, double l2, double tol,

@@ -402,6 +402,7 @@ int launch_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_
     int64_t want = (ntiles + kWaves - 1) / kWaves;
     int nblocks = (int)std::min<int64_t>(std::max<int64_t>(want, 1), (int64_t)ctx->num_cus * 2);
     double* partials = ctx->partials;  // sized for 8 blocks per CU at context creation
+    KernelTimer timer(ctx, kKindMoments);
     size_t lds = (size_t)kWaves * kWaveLds;
     if (weighted)
         hipLaunchKernelGGL((moments_small_kernel<T, true>), dim3(nblocks), dim3(256), lds, ctx->stream, dc.d_ptrs,
@@ -424,6 +425,7 @@ int launch_grouped_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, co
     int64_t want = (n_groups + kWaves - 1) / kWaves;
     int nblocks = (int)std::min<int64_t>(want, (int64_t)ctx->num_cus * 2);
     size_t lds = (size_t)kWaves * kWaveLds;
+    KernelTimer timer(ctx, kKindGroupedMoments);
     hipLaunchKernelGGL((grouped_moments_kernel<T>), dim3(nblocks), dim3(256), lds, ctx->stream, dc.d_ptrs, n_feat,
                        d_offsets, n_groups, d_moments);
     PDS_HIP_CHECK(hipGetLastError());

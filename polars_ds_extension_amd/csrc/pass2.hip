@@ -183,6 +183,7 @@ int launch_pass2(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_ro
     const int nblocks = (int)std::min<int64_t>(std::max<int64_t>(want, 1), (int64_t)ctx->num_cus * 8);
     double* partials = ctx->partials;
     T* s_rows = reinterpret_cast<T*>(d_s_rows);
+    KernelTimer timer(ctx, kKindPass2);
     if (weighted)
         launch_p2<T, true>(hc_mode, dim3(nblocks), ctx->stream, dc.d_ptrs, n_feat, add_bias ? 1 : 0, n_rows, d_beta,
                            d_inv, d_pred, d_resid, s_rows, partials);

@@ -1,15 +1,297 @@
-// rolling.hip -- sliding / expanding window regressions (pl_rolling_lr, pl_recursive_lr).
+// rolling.hip -- pl_rolling_lr / pl_recursive_lr (/root/reference/src/num_ext/linear_regression.rs
+// :1121-1283) without the reference's strictly sequential Sherman-Morrison-Woodbury chain
+// (lr_online_solvers.rs:148-332: 2 rank-1 updates per row, one row after the other, 1e8 times).
+//
+// The window normal equations are rebuilt instead of the inverse being dragged along:
+//     G(r) = sum_{i in window(r), row i finite} z_i z_i' ,  z = [x_0..x_{p-1}, (1)],   c(r) likewise,
+//     (G(r) + lambda I) beta(r) = c(r)          (lambda on every diagonal)
+// which is what the reference's recursion equals in exact arithmetic, without its drift.
+//
+// gfx950 mapping.  One wavefront owns a tile of kTileRows consecutive rows and walks it 64 rows at a time:
+//   A  lane = row: coalesced 8-byte/lane loads of row r and row r-w, the NV = p'(p'+1)/2 + p' + 1 moment
+//      increments d_v = z_a z_b (new) - z_a z_b (old) go to LDS as D[v][lane]          (stride 65: no conflicts)
+//   B  lane = moment v: a 64-long running sum W_v(r) = W_v(r-1) + D[v][r] in place (carry kept in a VGPR)
+//   C  lane = row again: reads its own G(r), c(r) back, Cholesky-solves the p' x p' system in registers
+//      (fully unrolled), forms pred = x_r . beta, and stores the List<f64> values / pred / validity.
+// A tile is anchored exactly: the carry is rebuilt from the w rows in front of the tile (rolling) or
+// from an exclusive prefix over per-tile totals (expanding), so round-off never accumulates over more
+// than kTileRows additions.  Non-finite rows are left out of the sums (OnlineLR::update :85-89) and, with
+// min_size > 0, counted for the skipping variant's validity rule (faer_rolling_skipping_lr :218-301).
+// HBM traffic: every input element read twice (as "new" and as "old", the second read served by
+// L2/Infinity Cache for w = 256), every output element written once.
 #include "common.hpp"
 
 namespace pds {
 
+#define RSYNC()                                                  \
+    do {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   \
+        __builtin_amdgcn_wave_barrier();                         \
+    } while (0)
+
+constexpr int kTileRows = 4096;   // rows per wave tile (64 steps of 64 rows)
+constexpr int kRollWaves = 2;     // waves per block
+constexpr int kLdsStride = 65;    // doubles per moment row in LDS
+
+template <int PP>
+struct RollDims {
+    static constexpr int NG = PP * (PP + 1) / 2;
+    static constexpr int NV = NG + PP + 1;  // Gram upper triangle, X'y, finite-row count
+};
+
+struct RollArgs {
+    int p, pp, bias;        // features, p + bias, bias flag
+    int64_t n, window;      // window = n0 (start_with) for expanding
+    int64_t min_size;
+    double lambda;
+    int mode;               // 0 rolling, 1 expanding pass 1 (tile totals), 2 expanding main
+    int64_t tile_rows;
+};
+
+// z (PP entries, padded with zeros) and y of row r; returns false (and zeros) when r is out of range or
+// the row holds a non-finite value
+template <typename T, int PP>
+__device__ __forceinline__ bool load_row(const T* const* __restrict__ cols, const RollArgs& ra, int64_t r,
+                                         double (&z)[PP], double& yv) {
+    bool ok = r >= 0 && r < ra.n;
+#pragma unroll
+    for (int a = 0; a < PP; ++a) {
+        double v = 0.0;
+        if (a < ra.p) v = ok ? (double)cols[a][r] : 0.0;
+        else if (a == ra.p && ra.bias) v = 1.0;
+        z[a] = v;
+    }
+    yv = ok ? (double)cols[ra.p][r] : 0.0;
+    bool fin = isfinite(yv);
+#pragma unroll
+    for (int a = 0; a < PP; ++a) fin = fin && isfinite(z[a]);
+    ok = ok && fin;
+    return ok;
+}
+
+template <typename T, int PP>
+__global__ __launch_bounds__(kRollWaves * 64) void rolling_kernel(const T* const* __restrict__ cols, RollArgs ra,
+                                                                  double* __restrict__ tile_tot /*[tiles][NV]*/,
+                                                                  T* __restrict__ coeffs, T* __restrict__ pred,
+                                                                  uint8_t* __restrict__ valid) {
+    constexpr int NG = RollDims<PP>::NG, NV = RollDims<PP>::NV;
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* D = sm + (size_t)wave * NV * kLdsStride;
+    const int64_t T_ = ra.tile_rows;
+    const int64_t ntiles = (ra.n + T_ - 1) / T_;
+    const int64_t wid = (int64_t)blockIdx.x * kRollWaves + wave, nw = (int64_t)gridDim.x * kRollWaves;
+    const int64_t w = ra.window;
+
+    for (int64_t t = wid; t < ntiles; t += nw) {
+        const int64_t t0 = t * T_, t1 = (t0 + T_ < ra.n) ? t0 + T_ : ra.n;
+        double W = 0.0;  // lane v < NV: running moment v
+        int64_t r_begin = t0;
+        if (ra.mode == 0) {
+            r_begin = t0 - ((w + 63) / 64) * 64;  // warm-up steps rebuild the window in front of the tile
+        } else if (ra.mode == 2) {
+            if (lane < NV) W = tile_tot[t * NV + lane];  // exclusive prefix over the previous tiles
+        }
+        for (int64_t base = r_begin; base < t1; base += 64) {
+            const bool warm = base < t0;
+            const int64_t r = base + lane;
+            // ---------------- phase A
+            double zn[PP], zo[PP], yn, yo;
+            bool okn = load_row<T, PP>(cols, ra, r, zn, yn);
+            if (warm) okn = okn && (r >= t0 - w);          // only the w rows in front of the tile
+            else okn = okn && (r < t1);
+            bool oko = false;
+            if (ra.mode == 0 && !warm) oko = load_row<T, PP>(cols, ra, r - w, zo, yo) && (r < t1);
+            if (!okn) {
+#pragma unroll
+                for (int a = 0; a < PP; ++a) zn[a] = 0.0;
+                yn = 0.0;
+            }
+            if (!oko) {
+#pragma unroll
+                for (int a = 0; a < PP; ++a) zo[a] = 0.0;
+                yo = 0.0;
+            }
+            {
+                int v = 0;
+#pragma unroll
+                for (int a = 0; a < PP; ++a)
+#pragma unroll
+                    for (int b = a; b < PP; ++b) {
+                        D[v * kLdsStride + lane] = fma(zn[a], zn[b], -(zo[a] * zo[b]));
+                        ++v;
+                    }
+#pragma unroll
+                for (int a = 0; a < PP; ++a) D[(NG + a) * kLdsStride + lane] = fma(zn[a], yn, -(zo[a] * yo));
+                D[(NG + PP) * kLdsStride + lane] = (okn ? 1.0 : 0.0) - (oko ? 1.0 : 0.0);
+            }
+            RSYNC();
+            // ---------------- phase B: lane v scans its moment over the 64 rows of this step
+            if (lane < NV) {
+                double* row = D + lane * kLdsStride;
+#pragma unroll 8
+                for (int i = 0; i < 64; ++i) {
+                    W += row[i];
+                    row[i] = W;
+                }
+            }
+            RSYNC();
+            if (warm || ra.mode == 1) continue;
+            // ---------------- phase C: lane = row, solve (G + lambda I) beta = c
+            if (r < t1) {
+                double g[NG], c[PP];
+                {
+                    int v = 0;
+#pragma unroll
+                    for (int a = 0; a < PP; ++a)
+#pragma unroll
+                        for (int b = a; b < PP; ++b) {
+                            double x = D[v * kLdsStride + lane];
+                            if (a == b) {
+                                if (a < ra.pp) x += ra.lambda;
+                                else x = 1.0;  // padding dimension: identity, beta_pad = 0
+                            }
+                            g[v] = x;
+                            ++v;
+                        }
+#pragma unroll
+                    for (int a = 0; a < PP; ++a) c[a] = D[(NG + a) * kLdsStride + lane];
+                }
+                const double cnt = D[(NG + PP) * kLdsStride + lane];
+                // Cholesky G = L L' in place (packed upper storage read as lower by symmetry):
+                // idx(a,b), a <= b  ->  a*PP - a(a-1)/2 + (b-a)
+                bool okc = true;
+#define GI(a, b) g[(a) * PP - ((a) * ((a)-1)) / 2 + ((b) - (a))]
+#pragma unroll
+                for (int k = 0; k < PP; ++k) {
+                    double d = GI(k, k);
+                    okc = okc && (d > 0.0);
+                    const double inv = 1.0 / sqrt(d);
+                    GI(k, k) = d * inv;  // l_kk
+#pragma unroll
+                    for (int b = k + 1; b < PP; ++b) GI(k, b) *= inv;  // l_bk stored at (k,b)
+#pragma unroll
+                    for (int a = k + 1; a < PP; ++a)
+#pragma unroll
+                        for (int b = a; b < PP; ++b) GI(a, b) = fma(-GI(k, a), GI(k, b), GI(a, b));
+                }
+                // forward L u = c, backward L' beta = u
+#pragma unroll
+                for (int a = 0; a < PP; ++a) {
+                    double s = c[a];
+#pragma unroll
+                    for (int k = 0; k < a; ++k) s = fma(-GI(k, a), c[k], s);
+                    c[a] = s / GI(a, a);
+                }
+#pragma unroll
+                for (int a = PP - 1; a >= 0; --a) {
+                    double s = c[a];
+#pragma unroll
+                    for (int k = a + 1; k < PP; ++k) s = fma(-GI(a, k), c[k], s);
+                    c[a] = s / GI(a, a);
+                }
+#undef GI
+                const double nanv = __builtin_nan("");
+                const bool row_ok = (ra.mode == 0) ? (r >= w - 1) : (r >= w - 1);
+                bool v_ok = row_ok;
+                if (ra.min_size > 0) v_ok = v_ok && (cnt >= (double)ra.min_size);
+                double pr = 0.0;
+#pragma unroll
+                for (int a = 0; a < PP; ++a) pr = fma(zn[a], c[a], pr);
+                if (!okn) pr = nanv;  // the row itself is non-finite: x_r . beta is NaN in the reference too
+                T* out = coeffs + r * (int64_t)ra.pp;
+#pragma unroll
+                for (int a = 0; a < PP; ++a)
+                    if (a < ra.pp) out[a] = (v_ok && okc) ? (T)c[a] : (T)nanv;
+                pred[r] = (v_ok && okc) ? (T)pr : (T)nanv;
+                valid[r] = v_ok ? 1 : 0;
+            }
+            RSYNC();
+        }
+        if (ra.mode == 1 && lane < NV) tile_tot[t * NV + lane] = W;
+    }
+}
+
+// exclusive prefix over the per-tile totals (expanding window), one wave, lane = moment
+__global__ __launch_bounds__(64) void tile_prefix_kernel(double* __restrict__ tot, int64_t ntiles, int nv) {
+    const int lane = threadIdx.x;
+    if (lane >= nv) return;
+    double run = 0.0;
+    int64_t t = 0;
+    for (; t + 8 <= ntiles; t += 8) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = tot[(t + k) * nv + lane];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            tot[(t + k) * nv + lane] = run;
+            run += v[k];
+        }
+    }
+    for (; t < ntiles; ++t) {
+        const double v = tot[t * nv + lane];
+        tot[t * nv + lane] = run;
+        run += v;
+    }
+}
+
+template <typename T, int PP>
+static int launch_pp(pds_ctx* ctx, const DeviceCols<T>& dc, RollArgs ra, bool expanding, T* d_coeffs, T* d_pred,
+                     uint8_t* d_valid) {
+    constexpr int NV = RollDims<PP>::NV;
+    const size_t lds = (size_t)kRollWaves * NV * kLdsStride * sizeof(double);
+    ra.tile_rows = kTileRows;
+    const int64_t ntiles = (ra.n + ra.tile_rows - 1) / ra.tile_rows;
+    int64_t nb = (ntiles + kRollWaves - 1) / kRollWaves;
+    nb = std::min<int64_t>(std::max<int64_t>(nb, 1), (int64_t)ctx->num_cus * 4);
+    if (lds > 64 * 1024)
+        PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rolling_kernel<T, PP>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    KernelTimer timer(ctx, kKindRolling);
+    if (!expanding) {
+        ra.mode = 0;
+        hipLaunchKernelGGL((rolling_kernel<T, PP>), dim3((unsigned)nb), dim3(kRollWaves * 64), lds, ctx->stream,
+                           dc.d_ptrs, ra, (double*)nullptr, d_coeffs, d_pred, d_valid);
+    } else {
+        double* tot = reinterpret_cast<double*>(ws_take(ctx, (size_t)ntiles * NV * sizeof(double)));
+        ra.mode = 1;
+        hipLaunchKernelGGL((rolling_kernel<T, PP>), dim3((unsigned)nb), dim3(kRollWaves * 64), lds, ctx->stream,
+                           dc.d_ptrs, ra, tot, d_coeffs, d_pred, d_valid);
+        hipLaunchKernelGGL(tile_prefix_kernel, dim3(1), dim3(64), 0, ctx->stream, tot, ntiles, NV);
+        ra.mode = 2;
+        hipLaunchKernelGGL((rolling_kernel<T, PP>), dim3((unsigned)nb), dim3(kRollWaves * 64), lds, ctx->stream,
+                           dc.d_ptrs, ra, tot, d_coeffs, d_pred, d_valid);
+    }
+    PDS_HIP_CHECK(hipGetLastError());
+    return PDS_OK;
+}
+
 template <typename T>
 int launch_rolling(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, int add_bias, int64_t window,
                    int64_t min_size, double lambda, bool expanding, T* d_coeffs, T* d_pred, uint8_t* d_valid) {
-    return fail(PDS_ERR_UNSUPPORTED, "rolling / recursive kernels: not built yet");
+    RollArgs ra;
+    ra.p = n_feat;
+    ra.bias = add_bias ? 1 : 0;
+    ra.pp = n_feat + ra.bias;
+    ra.n = n_rows;
+    ra.window = window;
+    ra.min_size = min_size;
+    ra.lambda = lambda > 0.0 ? lambda : 0.0;
+    ra.mode = 0;
+    ra.tile_rows = kTileRows;
+    const int pp = ra.pp;
+    if (pp <= 2) return launch_pp<T, 2>(ctx, dc, ra, expanding, d_coeffs, d_pred, d_valid);
+    if (pp <= 4) return launch_pp<T, 4>(ctx, dc, ra, expanding, d_coeffs, d_pred, d_valid);
+    if (pp <= 6) return launch_pp<T, 6>(ctx, dc, ra, expanding, d_coeffs, d_pred, d_valid);
+    if (pp <= 8) return launch_pp<T, 8>(ctx, dc, ra, expanding, d_coeffs, d_pred, d_valid);
+    if (pp <= 10) return launch_pp<T, 10>(ctx, dc, ra, expanding, d_coeffs, d_pred, d_valid);
+    if (pp <= 12) return launch_pp<T, 12>(ctx, dc, ra, expanding, d_coeffs, d_pred, d_valid);
+    return fail(PDS_ERR_UNSUPPORTED, "rolling / recursive: at most 12 coefficients (features + bias) in this build");
 }
+
 template int launch_rolling<double>(pds_ctx*, const DeviceCols<double>&, int, int64_t, int, int64_t, int64_t, double,
                                     bool, double*, double*, uint8_t*);
 template int launch_rolling<float>(pds_ctx*, const DeviceCols<float>&, int, int64_t, int, int64_t, int64_t, double, bool,
                                    float*, float*, uint8_t*);
+
 }  // namespace pds

@@ -302,6 +302,7 @@ static int launch_solve_lps(pds_ctx* ctx, const T* d_moments, int64_t n_sys, con
     if (lds > 64 * 1024)
         PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<T, LPS>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    KernelTimer timer(ctx, kKindSolve);
     hipLaunchKernelGGL((solve_kernel<T, LPS>), dim3((unsigned)nb), dim3(waves * 64), lds, ctx->stream, d_moments,
                        n_sys, sd, d_coeffs, d_flags, d_inv_out, d_rows);
     PDS_HIP_CHECK(hipGetLastError());
@@ -323,6 +324,9 @@ int launch_solve(pds_ctx* ctx, const T* d_moments, int64_t n_sys, const SolvePar
     sd.ln_tol = sd.gate_on ? std::log(sp.gate_tol) : 0.0;
     if (n_sys <= 0) return PDS_OK;
     const int pp = sd.pp;
+    // hot path: register-resident pivoted QR (solve_reg.hip) for p' <= 16 when no inverse is wanted
+    if (pp >= 1 && pp <= 16 && !d_inv_out && sp.solver != PDS_SOLVER_CHOLESKEY)
+        return launch_solve_reg<T>(ctx, d_moments, n_sys, sp, d_coeffs, d_flags, d_rows_per_sys);
     if (pp < 1 || pp > 64) return fail(PDS_ERR_UNSUPPORTED, "solve: 1..64 coefficients supported on the LDS path");
     if (pp <= 4) return launch_solve_lps<T, 4>(ctx, d_moments, n_sys, sd, d_coeffs, d_flags, d_inv_out, d_rows_per_sys);
     if (pp <= 8) return launch_solve_lps<T, 8>(ctx, d_moments, n_sys, sd, d_coeffs, d_flags, d_inv_out, d_rows_per_sys);
@@ -436,6 +440,7 @@ template <typename T>
 int launch_cd(pds_ctx* ctx, const T* d_moments, int p, int add_bias, double l1, double l2, double tol, int max_iter,
               int positive, T* d_coeffs, int* d_info) {
     const size_t lds = (size_t)(p + 2) * sizeof(double);
+    KernelTimer timer(ctx, kKindIter);
     hipLaunchKernelGGL((cd_kernel<T>), dim3(1), dim3(64), lds, ctx->stream, d_moments, p, add_bias ? 1 : 0, l1, l2,
                        tol, max_iter, positive, d_coeffs, d_info);
     PDS_HIP_CHECK(hipGetLastError());
@@ -445,6 +450,7 @@ int launch_cd(pds_ctx* ctx, const T* d_moments, int p, int add_bias, double l1, 
 template <typename T>
 int launch_nnls(pds_ctx* ctx, const T* d_moments, int p, int add_bias, double tol, int max_iter, T* d_coeffs) {
     const size_t lds = (size_t)2 * (p + 2) * sizeof(double);
+    KernelTimer timer(ctx, kKindIter);
     hipLaunchKernelGGL((nnls_kernel<T>), dim3(1), dim3(64), lds, ctx->stream, d_moments, p, add_bias ? 1 : 0, tol,
                        max_iter, d_coeffs);
     PDS_HIP_CHECK(hipGetLastError());

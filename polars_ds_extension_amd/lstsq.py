@@ -57,6 +57,7 @@ class _Cols:
             ptrs = [int(a.data_ptr()) for a in keep]
             self.n_rows = int(keep[0].shape[0])
             self.device_index = keep[0].device.index or 0
+            self.torch_device = keep[0].device
         else:
             keep = [np.ascontiguousarray(np.asarray(a), dtype=dt) for a in arrs]
             self.space = _lib.PDS_HOST
@@ -85,9 +86,22 @@ class Context:
             self.set_stream(stream)
 
     def set_stream(self, stream) -> None:
-        """stream: a torch.cuda.Stream, a raw hipStream_t integer, or None (private stream)."""
+        """stream: a torch.cuda.Stream, a raw hipStream_t integer, or None / 0 (HIP's default stream)."""
         raw = getattr(stream, "cuda_stream", stream)
         _lib.check(self._lib.pds_ctx_set_stream(self._h, C.c_void_p(int(raw) if raw else None)))
+        self._stream_raw = int(raw) if raw else 0
+
+    def follow_torch_stream(self, device) -> None:
+        """
+        Device-resident inputs are produced by work queued on torch's current stream: run on that stream
+        so the kernels are ordered after the producers (and torch consumers after the kernels).
+        """
+        import torch
+
+        raw = int(torch.cuda.current_stream(device).cuda_stream)
+        if getattr(self, "_stream_raw", -1) != raw:
+            self.set_stream(raw)
+            self._stream_raw = raw
 
     def synchronize(self) -> None:
         _lib.check(self._lib.pds_ctx_synchronize(self._h))
@@ -95,6 +109,18 @@ class Context:
     @property
     def num_cus(self) -> int:
         return int(self._lib.pds_ctx_num_cus(self._h))
+
+    KINDS = ("moments", "grouped_moments", "solve", "pass2", "rolling", "iterative")
+
+    def set_timing(self, enable: bool) -> None:
+        _lib.check(self._lib.pds_ctx_set_timing(self._h, int(bool(enable))))
+
+    def get_timing(self, reset: bool = True) -> dict:
+        """Per kernel class: (summed ms, launches) measured with HIP events on the context's stream."""
+        ms = (C.c_double * 8)()
+        cnt = (C.c_longlong * 8)()
+        _lib.check(self._lib.pds_ctx_get_timing(self._h, ms, cnt, 8, int(bool(reset))))
+        return {k: (ms[i], int(cnt[i])) for i, k in enumerate(self.KINDS)}
 
     def close(self) -> None:
         if getattr(self, "_h", None) and self._h.value:
@@ -119,6 +145,11 @@ def default_context() -> Context:
     if _default is None:
         _default = Context(0)
     return _default
+
+
+def _follow(ctx: "Context", cols: "_Cols") -> None:
+    if cols.space == _lib.PDS_DEVICE:
+        ctx.follow_torch_stream(cols.torch_device)
 
 
 def _params(add_bias, l1_reg, l2_reg, tol, solver, positive, max_iter, singular_x_tol) -> _lib.LRParams:
@@ -164,6 +195,7 @@ def lin_reg(*x, target, add_bias: bool = False, weights=None, return_pred: bool 
         raise ValueError("Input `max_iter` must be a positive.")  # expr_linear.py:231-232
     ctx = ctx or default_context()
     cols = _Cols(target, x, weights)
+    _follow(ctx, cols)
     prm = _params(add_bias, l1_reg, l2_reg, tol, solver, positive, max_iter, singular_x_tol)
     pp = cols.n_feat + int(bool(add_bias))
     coeffs = np.empty(pp, dtype=_dtype())
@@ -185,6 +217,7 @@ def lin_reg_w_rcond(*x, target, add_bias: bool = False, rcond: float = 0.0, l2_r
         raise NotImplementedError("lin_reg_w_rcond is f64 only here")
     ctx = ctx or default_context()
     cols = _Cols(target, x)
+    _follow(ctx, cols)
     pp = cols.n_feat + int(bool(add_bias))
     rc = max(float(rcond), np.finfo(np.float64).eps * max(cols.n_rows, pp))  # linear_regression.rs:651-702
     coeffs = np.empty(pp)
@@ -205,6 +238,7 @@ def lin_reg_report(*x, target, add_bias: bool = False, weights=None, std_err: st
     """
     ctx = ctx or default_context()
     cols = _Cols(target, x, weights)
+    _follow(ctx, cols)
     pp = cols.n_feat + int(bool(add_bias))
     if y_var is None:
         M = gram_moments(*x, target=target, ctx=ctx)
@@ -242,6 +276,7 @@ def lin_reg_by(*x, target, group_offsets, add_bias: bool = False, l2_reg: float 
     """
     ctx = ctx or default_context()
     cols = _Cols(target, x)
+    _follow(ctx, cols)
     prm = _params(add_bias, 0.0, l2_reg, 1e-5, solver, False, 200, singular_x_tol)
     pp = cols.n_feat + int(bool(add_bias))
     if cols.space == _lib.PDS_DEVICE:
@@ -264,6 +299,7 @@ def lin_reg_by(*x, target, group_offsets, add_bias: bool = False, l2_reg: float 
 def _windowed(name, x, target, n, add_bias, l2_reg, min_size, ctx):
     ctx = ctx or default_context()
     cols = _Cols(target, x)
+    _follow(ctx, cols)
     pp = cols.n_feat + int(bool(add_bias))
     coeffs, co_p = _out_like(cols, (cols.n_rows, pp))
     pred, pr_p = _out_like(cols, cols.n_rows)
@@ -310,6 +346,7 @@ def gram_moments(*x, target, weights=None, ctx: Context | None = None, out_devic
     """The augmented moment matrix A = Z'Z, Z = [x1..xp | 1 | y] ((p+2)^2), the measured Gram build."""
     ctx = ctx or default_context()
     cols = _Cols(target, x, weights)
+    _follow(ctx, cols)
     q = cols.n_feat + 2
     if out_device:
         if cols.space != _lib.PDS_DEVICE:
