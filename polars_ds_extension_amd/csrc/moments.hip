@@ -249,39 +249,45 @@ __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* _
     }
 }
 
-// fixed-order reduction of the per-block partials and assembly of the (p+2)x(p+2) moment matrix
+// fixed-order reduction of the per-block partials and assembly of the (p+2)x(p+2) moment matrix.
+// One 64-lane block per record element: lane l sums blocks l, l+64, ... in order, then a fixed
+// butterfly combines the lanes -- deterministic, and ~2 us instead of a 512-long dependent load chain.
 template <typename T>
-__global__ __launch_bounds__(320) void moments_finalize_kernel(const double* __restrict__ partials, int nblocks,
-                                                               int p, double n_rows, int weighted,
-                                                               T* __restrict__ out) {
-    __shared__ double rec[kPartStride];
-    const int e = threadIdx.x;
-    if (e < kPartStride) {
-        // two-level fixed-order sum: chunks of 32 blocks, then the chunk sums
-        double tot = 0.0;
-        for (int b0 = 0; b0 < nblocks; b0 += 32) {
-            double s = 0.0;
-            const int b1 = min(b0 + 32, nblocks);
-            for (int b = b0; b < b1; ++b) s += partials[(int64_t)b * kPartStride + e];
-            tot += s;
-        }
-        rec[e] = tot;
-    }
-    __syncthreads();
+__global__ __launch_bounds__(64) void moments_finalize_kernel(const double* __restrict__ partials, int nblocks,
+                                                              int p, double n_rows, int weighted,
+                                                              T* __restrict__ out) {
+    const int e = blockIdx.x;  // element of the partial record, 0 .. kPartSW
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 64) s += partials[(int64_t)b * kPartStride + e];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    if (threadIdx.x != 0) return;
     const int q = p + 2;
-    for (int idx = threadIdx.x; idx < q * q; idx += blockDim.x) {
-        int i = idx % q, j = idx / q;
-        if (i > j) { int tmp = i; i = j; j = tmp; }
-        double v;
-        if (j < p) {
-            // the MFMA tile is symmetric up to rounding order; average nothing, take the upper element
-            v = rec[kPartD + i + 16 * j];
-        } else if (j == p) {
-            v = (i < p) ? rec[kPartCS + i] : (weighted ? rec[kPartSW] : n_rows);
-        } else {
-            v = (i < p) ? rec[kPartXY + i] : (i == p ? rec[kPartYS] : rec[kPartYY]);
+    if (e < kPartXY) {  // D[i + 16 j]: take the upper triangle and mirror it
+        const int i = e & 15, j = e >> 4;
+        if (i <= j && j < p) {
+            out[i + j * q] = (T)s;
+            out[j + i * q] = (T)s;
         }
-        out[idx] = (T)v;
+    } else if (e < kPartCS) {
+        const int i = e - kPartXY;
+        if (i < p) {
+            out[i + (p + 1) * q] = (T)s;
+            out[(p + 1) + i * q] = (T)s;
+        }
+    } else if (e < kPartYY) {
+        const int i = e - kPartCS;
+        if (i < p) {
+            out[i + p * q] = (T)s;
+            out[p + i * q] = (T)s;
+        }
+    } else if (e == kPartYY) {
+        out[(p + 1) + (p + 1) * q] = (T)s;
+    } else if (e == kPartYS) {
+        out[p + (p + 1) * q] = (T)s;
+        out[(p + 1) + p * q] = (T)s;
+    } else if (e == kPartSW) {
+        out[p + p * q] = (T)(weighted ? s : n_rows);
     }
 }
 
@@ -410,7 +416,7 @@ int launch_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_
     else
         hipLaunchKernelGGL((moments_small_kernel<T, false>), dim3(nblocks), dim3(256), lds, ctx->stream, dc.d_ptrs,
                            n_feat, n_rows, partials);
-    hipLaunchKernelGGL((moments_finalize_kernel<T>), dim3(1), dim3(320), 0, ctx->stream, partials, nblocks, n_feat,
+    hipLaunchKernelGGL((moments_finalize_kernel<T>), dim3(kPartSW + 1), dim3(64), 0, ctx->stream, partials, nblocks, n_feat,
                        (double)n_rows, weighted ? 1 : 0, d_moments);
     PDS_HIP_CHECK(hipGetLastError());
     return PDS_OK;

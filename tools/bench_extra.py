@@ -1,0 +1,77 @@
+"""
+Secondary measurements quoted in DESIGN.md (not the driver's bench line): the other BASELINE configs on one
+MI355X, inputs resident in HBM, kernel time from the library's HIP-event hooks, plus a bounded CPU sample of
+the oracle where it is the reference's own algorithm (rolling: sequential Woodbury, single thread).
+Usage: python tools/bench_extra.py [rolling] [report] [single] [host]
+"""
+import json, sys, time
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import numpy as np
+import torch
+import polars_ds_extension_amd as pds
+
+which = set(sys.argv[1:]) or {"rolling", "report", "single", "host"}
+dev = torch.device("cuda", 0)
+ctx = pds.Context(0)
+ctx.set_stream(torch.cuda.current_stream(dev))
+gen = torch.Generator(device=dev); gen.manual_seed(3)
+out = {}
+
+def timed(fn, reps=5, warm=2):
+    for _ in range(warm): fn()
+    ctx.get_timing(True); ctx.set_timing(True)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps): r = fn()
+    torch.cuda.synchronize(); wall = (time.perf_counter() - t0) / reps
+    ctx.set_timing(False)
+    t = {k: (ms / max(c, 1), c // reps) for k, (ms, c) in ctx.get_timing(True).items() if c}
+    return wall, t, r
+
+if "rolling" in which:
+    n, p, w = 100_000_000, 8, 256
+    xs = [torch.rand(n, dtype=torch.float64, device=dev, generator=gen) for _ in range(p)]
+    y = sum(xs[j] * (0.1 * (j + 1)) for j in range(p)) + 1e-3 * torch.randn(n, dtype=torch.float64, device=dev, generator=gen)
+    wall, t, (co, pr, va) = timed(lambda: pds.rolling_lin_reg(*xs, target=y, window_size=w, ctx=ctx), reps=3, warm=1)
+    alg = n * ((p + 1) * 8 + (p + 1) * 8 + 8)  # 152 B/row at p'=8
+    ms = t["rolling"][0]
+    out["rolling_c4"] = {"rows": n, "p": p, "window": w, "kernel_ms": round(ms, 3), "wall_ms": round(wall * 1e3, 3),
+                         "rows_per_s": round(n / (ms * 1e-3), 1), "algorithmic_GBps": round(alg / (ms * 1e-3) / 1e9, 1)}
+    # CPU: the reference's sequential Woodbury chain, 1 thread, bounded sample
+    from oracle import oracle as orc
+    ns = 2_000_000
+    Xh = np.stack([x[:ns].cpu().numpy() for x in xs], axis=1); yh = y[:ns].cpu().numpy()
+    t0 = time.perf_counter(); ref = orc.rolling_lr(Xh, yh, w); tc = time.perf_counter() - t0
+    err = np.linalg.norm(co[w - 1:ns].cpu().numpy() - ref, axis=1) / np.linalg.norm(ref, axis=1)
+    out["rolling_c4"]["cpu_rows_per_s_1thread"] = round(ns / tc, 1)
+    out["rolling_c4"]["max_rel_err_vs_chain_2e6_rows"] = float(err.max())
+    wall, t, _ = timed(lambda: pds.recursive_lin_reg(*xs, target=y, start_with=16, ctx=ctx), reps=2, warm=1)
+    out["recursive_1e8x8"] = {"kernel_ms_total": round(sum(v[0] * v[1] for v in t.values()), 3), "wall_ms": round(wall * 1e3, 3)}
+    del xs, y, co, pr, va
+    torch.cuda.empty_cache()
+
+if "report" in which or "single" in which or "host" in which:
+    n, p = 100_000_000, 16
+    xs = [torch.rand(n, dtype=torch.float64, device=dev, generator=gen) for _ in range(p)]
+    beta = [(-1.0) ** j * (0.05 + 0.03 * j) for j in range(p)]; beta[3] = 0.0; beta[11] = 0.0
+    y = torch.zeros(n, dtype=torch.float64, device=dev)
+    for j in range(p): y.add_(xs[j], alpha=beta[j])
+    y.add_(torch.randn(n, dtype=torch.float64, device=dev, generator=gen), alpha=1e-2)
+    if "single" in which:
+        wall, t, b = timed(lambda: pds.lin_reg(*xs, target=y, add_bias=True, ctx=ctx))
+        out["single_ols_c2"] = {"wall_ms": round(wall * 1e3, 3), "kernels": {k: round(v[0], 4) for k, v in t.items()},
+                                "gram_GBps": round(n * (p + 1) * 8 / (t["moments"][0] * 1e-3) / 1e9, 1)}
+    if "report" in which:
+        yv = float(y.var(unbiased=True).item())
+        for se in ("se", "hc1"):
+            wall, t, r = timed(lambda: pds.lin_reg_report(*xs, target=y, add_bias=True, std_err=se, y_var=yv, ctx=ctx), reps=3, warm=1)
+            out[f"report_c2_{se}"] = {"wall_ms": round(wall * 1e3, 3), "kernels_ms": {k: [round(v[0], 4), v[1]] for k, v in t.items()},
+                                      "p_values": [float(v) for v in r["p>|t|"][[3, 11]]]}
+    if "host" in which:
+        ns = 20_000_000
+        hx = [x[:ns].cpu().numpy() for x in xs]; hy = y[:ns].cpu().numpy()
+        pds.lin_reg(*hx, target=hy, add_bias=True, ctx=ctx)
+        t0 = time.perf_counter(); pds.lin_reg(*hx, target=hy, add_bias=True, ctx=ctx); th = time.perf_counter() - t0
+        out["single_ols_host_buffers"] = {"rows": ns, "wall_s": round(th, 3), "GBps_incl_pcie": round(ns * 17 * 8 / th / 1e9, 2),
+                                         "note": "pageable numpy buffers -> hipMemcpyAsync staging -> kernels"}
+print(json.dumps(out, indent=1))
