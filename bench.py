@@ -116,13 +116,15 @@ def main() -> int:
     sv_ms, sv_cnt = timing["solve"]
     launches_per_step = max(gm_cnt // max(args.steps, 1), 1)
     groups_per_launch = G / launches_per_step
-    # algorithmic bytes per launch: every input element once + the group's moment record
-    bytes_per_group = R * (P + 1) * 8 + q * q * 8 + 16
+    fused = sv_cnt == 0  # Gram + solve in one kernel: no moment record traffic
+    # algorithmic bytes per launch: every input element once + offsets, plus what the kernel must
+    # write: the coefficients (fused) or the (p+2)^2 moment record (two-kernel pipeline)
+    bytes_per_group = R * (P + 1) * 8 + 16 + (P * 8 + 1 if fused else q * q * 8)
     alg_bytes = groups_per_launch * bytes_per_group
     avg_ms = gm_ms / max(gm_cnt, 1)
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     roofline = {
-        "bound": "hbm", "kernel": "grouped_moments_kernel<double>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+        "bound": "hbm", "kernel": "grouped_stream_kernel<double,16,cholesky> (Gram + solve fused)" if fused else "grouped_moments_kernel<double>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
         "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches_per_step,
         "algorithmic_bytes_per_launch": int(alg_bytes),

@@ -99,8 +99,11 @@ int make_device_cols(pds_ctx* ctx, const T* const* cols, const T* weights, int n
             out.h_ptrs[c] = dst;
         }
     }
-    out.d_ptrs = reinterpret_cast<const T**>(ws_take(ctx, sizeof(T*) * nc));
-    PDS_HIP_CHECK(hipMemcpyAsync(out.d_ptrs, out.h_ptrs.data(), sizeof(T*) * nc, hipMemcpyHostToDevice, ctx->stream));
+    // the device table always has 18 readable entries (16 features, y, w); unused ones alias column 0 so that
+    // kernels may fetch the whole table with wide scalar loads
+    out.h_ptrs.resize(std::max(nc, 18), out.h_ptrs[0]);
+    out.d_ptrs = reinterpret_cast<const T**>(ws_take(ctx, sizeof(T*) * out.h_ptrs.size()));
+    PDS_HIP_CHECK(hipMemcpyAsync(out.d_ptrs, out.h_ptrs.data(), sizeof(T*) * out.h_ptrs.size(), hipMemcpyHostToDevice, ctx->stream));
     // h_ptrs lives in `out` (caller's stack) until the call returns, and every API call synchronises
     // before returning, so the async copy source stays valid.
     return PDS_OK;
@@ -507,10 +510,25 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
     T* d_mom = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * (size_t)chunk * q * q));
     SolveParams sp{n_feat, bias, prm->solver == PDS_SOLVER_SVD ? PDS_SOLVER_QR : prm->solver, prm->l2_reg,
                    prm->singular_x_tol, 0};
-    for (int64_t g0 = 0; g0 < n_groups; g0 += chunk) {
-        const int64_t gc = std::min(chunk, n_groups - g0);
-        if (int rc = launch_grouped_moments<T>(ctx, dc, n_feat, d_off + g0, gc, d_mom)) return rc;
-        if (int rc = launch_solve<T>(ctx, d_mom, gc, sp, d_coeffs + g0 * pp, d_null + g0, nullptr, d_off + g0)) return rc;
+    {
+        const char* piv0 = std::getenv("PDS_GROUPED_PIVOTED");
+        if (piv0 && piv0[0] == '1' && sp.solver == PDS_SOLVER_CHOLESKEY) sp.solver = PDS_SOLVER_QR;
+    }
+    // Default (rank gate on): ONE streaming kernel, Gram + in-register Cholesky, no moment records in HBM.
+    // Gate off (singular_x_tol = 0) needs the pivoted QR to reproduce the reference's answers on rank-deficient
+    // groups; that solver is register hungry and runs faster as its own kernel behind the grouped Gram build.
+    // PDS_GROUPED_UNFUSED=1 / PDS_GROUPED_PIVOTED=1 force the two-kernel pipeline / the pivoted QR (development).
+    const char* unfused_env = std::getenv("PDS_GROUPED_UNFUSED");
+    const char* piv_env = std::getenv("PDS_GROUPED_PIVOTED");
+    const bool want_piv = !(sp.gate_tol > 0.0) || (piv_env && piv_env[0] == '1');
+    if (pp <= 16 && !want_piv && !(unfused_env && unfused_env[0] == '1')) {
+        if (int rc = launch_grouped_fused<T>(ctx, dc, n_feat, n_rows, d_off, n_groups, sp, d_coeffs, d_null)) return rc;
+    } else {
+        for (int64_t g0 = 0; g0 < n_groups; g0 += chunk) {
+            const int64_t gc = std::min(chunk, n_groups - g0);
+            if (int rc = launch_grouped_moments<T>(ctx, dc, n_feat, d_off + g0, gc, d_mom)) return rc;
+            if (int rc = launch_solve<T>(ctx, d_mom, gc, sp, d_coeffs + g0 * pp, d_null + g0, nullptr, d_off + g0)) return rc;
+        }
     }
     if (space == PDS_HOST) {
         PDS_HIP_CHECK(hipMemcpyAsync(coeffs, d_coeffs, (size_t)n_groups * pp * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));

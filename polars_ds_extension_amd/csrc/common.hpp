@@ -112,6 +112,12 @@ template <typename T>
 int launch_grouped_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, const int64_t* d_offsets,
                            int64_t n_groups, T* d_moments);
 
+struct SolveParams;
+// grouped_fused.hip: per-group Gram + pivoted-QR solve in one kernel (p' <= 16, OLS / ridge)
+template <typename T>
+int launch_grouped_fused(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, const int64_t* d_offsets,
+                         int64_t n_groups, const SolveParams& sp, T* d_coeffs, uint8_t* d_flags);
+
 // ---- solve.hip ----
 struct SolveParams {
     int p;         // features (without bias)

@@ -1,0 +1,332 @@
+// grouped_fused.hip -- `group_by(key).agg(pds.lin_reg(...))` as ONE streaming kernel: the rows are read
+// exactly like the single-regression Gram build (moments.hip: 128-row tiles, 16 B per lane straight down each
+// column, next tile prefetched in registers, MFMA consumption from a wave-private LDS tile) and the running
+// accumulators are simply CUT at group boundaries.  Each finished group's normal equations are transposed
+// through a 2.6 KB LDS scratch into the registers of a 16/8/4-lane sub-group; when all sub-groups of the wave
+// hold a pending system they are solved side by side in registers (solve_reg_dev.hpp) and the coefficients are
+// written.  The per-group moment records of the two-kernel pipeline (2.6 KB written + re-read per group at
+// p = 16) never exist, HBM traffic is input + coefficients only, and memory-bound tile streaming of some waves
+// overlaps the VALU-bound solves of others on the same CU.
+//
+// Work split: wave w owns the groups whose first row lies in [w N / W, (w+1) N / W) -- balanced in ROWS
+// (binary search in the offsets), so skewed group sizes do not unbalance the stream.
+//
+// Solver: with the rank gate on (the default of pds.lin_reg) the systems are factored by Cholesky in registers
+// (breakdown or rel. determinant <= tol => null, exactly the reference's `choleskey` rule, lr_solvers.rs:369-380);
+// accepted systems are well conditioned and the reference's three solvers agree on them to rounding.  With the
+// gate off (singular_x_tol = 0) the pivoted Householder QR runs instead, because only pivoting reproduces the
+// reference's finite answers on rank-deficient groups.  PDS_GROUPED_PIVOTED=1 forces QR everywhere.
+#include "moments_dev.hpp"
+#include "solve_reg_dev.hpp"
+
+namespace pds {
+
+constexpr int kFQ = 18;                  // LDS scratch moment matrix: indices 0..15 features, 16 bias, 17 y
+constexpr int kFM = kFQ * kFQ;           // doubles
+constexpr int kFTile = 17 * kColStride;  // 16 feature slots + y
+constexpr int kFWaveLds = kFTile + kFM * 8;
+
+// consume rows [rel0, rel1) of the tile (relative row indices, 0 <= rel0 < rel1 <= TR) into `a`
+template <typename T>
+__device__ __forceinline__ void consume_range(const char* wl, int lane, int rel0, int rel1, WaveAcc& a) {
+    const int f = lane & 15, q = lane >> 4;
+    const T* xcol = reinterpret_cast<const T*>(wl + f * kColStride) + q;
+    const T* ycol = reinterpret_cast<const T*>(wl + kSlotY * kColStride) + q;
+    int s0 = rel0 >> 2;
+    const int s1 = (rel1 + 3) >> 2;  // exclusive
+    using Acc = typename Tile<T>::acc;
+    Acc acc;
+    double xy, cs, yy, ys;
+    if constexpr (sizeof(T) == 8) {
+        acc = Acc{a.d[0], a.d[1], a.d[2], a.d[3]};
+        xy = a.xy; cs = a.cs; yy = a.yy; ys = a.ys;
+    } else {
+        acc = Acc{0, 0, 0, 0};
+        xy = cs = yy = ys = 0.0;
+    }
+    T fxy = 0, fcs = 0, fyy = 0, fys = 0;  // f32 path accumulates the side sums in f32 per call, like the tile kernel
+    auto step_v = [&](T x, T yv) __attribute__((always_inline)) {
+        acc = Tile<T>::mfma(x, x, acc);
+        if constexpr (sizeof(T) == 8) {
+            xy = fma(x, yv, xy);
+            cs += x;
+            yy = fma(yv, yv, yy);
+            ys += yv;
+        } else {
+            fxy = fmaf(x, yv, fxy);
+            fcs += x;
+            fyy = fmaf(yv, yv, fyy);
+            fys += yv;
+        }
+    };
+    auto step = [&](int s, bool masked, int lo, int hi) __attribute__((always_inline)) {
+        T x = xcol[4 * s];
+        T yv = ycol[4 * s];
+        if (masked) {
+            const bool in = q >= lo && q < hi;
+            x = in ? x : T(0);
+            yv = in ? yv : T(0);
+        }
+        acc = Tile<T>::mfma(x, x, acc);
+        if constexpr (sizeof(T) == 8) {
+            xy = fma(x, yv, xy);
+            cs += x;
+            yy = fma(yv, yv, yy);
+            ys += yv;
+        } else {
+            fxy = fmaf(x, yv, fxy);
+            fcs += x;
+            fyy = fmaf(yv, yv, fyy);
+            fys += yv;
+        }
+    };
+    // head: a first step that starts inside a 4-row group
+    if (rel0 & 3) {
+        const int lo = rel0 & 3;
+        const int hi = min(rel1 - 4 * s0, 4);
+        step(s0, true, lo, hi);
+        ++s0;
+    }
+    // body: whole steps
+    const int sfull = rel1 >> 2;  // steps [s0, sfull) are complete
+    // (software pipelined like consume_tile: operands of step s+2 are in flight while step s multiplies)
+    if (s0 < sfull) {
+        T xn0 = xcol[4 * s0], yn0 = ycol[4 * s0];
+        T xn1 = xcol[4 * s0 + 4], yn1 = ycol[4 * s0 + 4];
+#pragma unroll 4
+        for (int s = s0; s < sfull; ++s) {
+            const T x = xn0, yv = yn0;
+            xn0 = xn1;
+            yn0 = yn1;
+            xn1 = xcol[4 * s + 8];
+            yn1 = ycol[4 * s + 8];
+            step_v(x, yv);
+        }
+    }
+    // tail: a last step that ends inside a 4-row group (and was not already the head step)
+    if ((rel1 & 3) && sfull >= s0 && sfull < s1) step(sfull, true, 0, rel1 & 3);
+    if constexpr (sizeof(T) == 8) {
+        a.d[0] = acc[0]; a.d[1] = acc[1]; a.d[2] = acc[2]; a.d[3] = acc[3];
+        a.xy = xy; a.cs = cs; a.yy = yy; a.ys = ys;
+    } else {
+        a.d[0] += (double)acc[0]; a.d[1] += (double)acc[1]; a.d[2] += (double)acc[2]; a.d[3] += (double)acc[3];
+        a.xy += (double)fxy; a.cs += (double)fcs; a.yy += (double)fyy; a.ys += (double)fys;
+    }
+}
+
+__device__ __forceinline__ int64_t lower_bound_i64(const int64_t* __restrict__ a, int64_t n, int64_t key) {
+    int64_t lo = 0, hi = n;  // first index with a[idx] >= key
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (a[mid] < key) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+template <typename T, int LPS, bool CHOL>
+__global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __restrict__ cols, int p,
+                                                            const int64_t* __restrict__ offsets, int64_t n_groups,
+                                                            int64_t n_rows, SolveRegDev sp, T* __restrict__ coeffs,
+                                                            uint8_t* __restrict__ flags) {
+    constexpr int SPW = 64 / LPS;
+    constexpr int RPL = Tile<T>::RPL;
+    constexpr int TR = 64 * RPL;
+    constexpr int NA = CHOL ? LPS + 1 : LPS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    char* wl = smem;
+    double* Msc = reinterpret_cast<double*>(smem + kFTile);
+    const int pp = sp.pp;
+    const int sub = lane / LPS, j = lane % LPS;
+    const bool colv = j < pp;
+    const int lj = (j < p) ? j : 16;
+
+    // ---- this wave's groups: balanced in rows
+    const int64_t W = gridDim.x, w = blockIdx.x;
+    const int64_t base_row = offsets[0];
+    const int64_t total = offsets[n_groups] - base_row;
+    const int64_t gl = (w == 0) ? 0 : lower_bound_i64(offsets, n_groups, base_row + (total * w) / W);
+    const int64_t gh = (w == W - 1) ? n_groups : lower_bound_i64(offsets, n_groups, base_row + (total * (w + 1)) / W);
+    if (gl >= gh) return;
+    const int64_t rlo = offsets[gl], rhi = offsets[gh];
+
+    // zero the unused feature slots of the tile once
+    {
+        typename Tile<T>::vec z;
+#pragma unroll
+        for (int e = 0; e < RPL; ++e) z[e] = T(0);
+        for (int c = p; c < 16; ++c) *reinterpret_cast<typename Tile<T>::vec*>(wl + c * kColStride + lane * 16) = z;
+    }
+    // pending systems (one per sub-group), held in registers in solver layout
+    double a_p[NA];
+    double b_p[CHOL ? 1 : LPS];
+    double dj_p = 1.0;
+    bool null_p = false;
+    int npend = 0;
+    int64_t gbase = gl;  // group id of pending system 0
+
+    auto solve_pending = [&]() __attribute__((always_inline)) {
+        const int64_t sys = gbase + sub;
+        const bool live = sub < npend;
+        bool is_null = null_p;
+        double zj = 0.0;
+        int pj = j;
+        if constexpr (CHOL) {
+            chol_core<LPS>(a_p, dj_p, j, sp, is_null, zj);
+        } else {
+            solve_core<LPS>(a_p, b_p, dj_p, j, lane, sp, is_null, pj, zj);
+        }
+        if (live && colv) coeffs[sys * (int64_t)pp + pj] = is_null ? (T)__builtin_nan("") : (T)zj;
+        if (live && j == 0 && flags) flags[sys] = is_null ? 1 : 0;
+        gbase += npend;
+        npend = 0;
+    };
+
+    WaveAcc acc;
+    zero_acc(acc);
+    int64_t g = gl;
+    int64_t ge = offsets[g + 1];
+    int64_t pos = rlo;
+
+    auto flush_group = [&]() __attribute__((always_inline)) {
+        // ---- normal equations of group g -> LDS scratch (full symmetric square, bias at 16, y at 17)
+        const int64_t ng = ge - offsets[g];
+        {
+            const int jj = lane & 15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Msc[Tile<T>::drow(lane, r) + kFQ * jj] = acc.d[r];
+            const double xy = xor_sum_q(acc.xy), cs = xor_sum_q(acc.cs), ys = xor_sum_q(acc.ys);
+            if (lane < 16) {
+                Msc[lane + kFQ * 17] = xy;
+                Msc[lane + kFQ * 16] = cs;
+                Msc[16 + kFQ * lane] = cs;
+            }
+            if (lane == 0) {
+                Msc[16 + kFQ * 16] = (double)ng;
+                Msc[16 + kFQ * 17] = ys;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- sub-group `npend` takes it into registers (solver layout: lane j = column j)
+        {
+            const bool mine = sub == npend;
+            double dj = colv ? Msc[lj + kFQ * lj] : 1.0;
+            const bool lam = sp.lambda > 0.0 && colv && (j < p || sp.lambda_on_bias);
+            if (lam) dj += sp.lambda;
+#pragma unroll
+            for (int i = 0; i < LPS; ++i) {
+                const int li = (i < p) ? i : 16;
+                double v = (colv && i < pp) ? Msc[li + kFQ * lj] : 0.0;
+                if (lam && i == j) v += sp.lambda;
+                if (mine) a_p[i] = v;
+                if constexpr (!CHOL) {
+                    const double bv = (i < pp) ? Msc[li + kFQ * 17] : 0.0;
+                    if (mine) b_p[i] = bv;
+                }
+            }
+            if constexpr (CHOL) {
+                const double cv = colv ? Msc[lj + kFQ * 17] : 0.0;
+                if (mine) a_p[LPS] = cv;
+            }
+            if (mine) {
+                dj_p = dj;
+                null_p = ng < pp;  // per-group pl_lr raises "#Data < #features": reported as null
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        zero_acc(acc);
+        ++npend;
+        if (npend == SPW) solve_pending();
+    };
+
+    // ---- stream the tiles covering [rlo, rhi)
+    TileRegs<T> regs;
+    const int64_t t_first = rlo / TR, t_last = (rhi > rlo) ? (rhi - 1) / TR : t_first - 1;
+    auto load_tile = [&](int64_t t) __attribute__((always_inline)) {
+        // the 18-entry pointer table is re-read per tile (two wide scalar loads, one wait): keeping 17 base
+        // pointers resident costs 34 SGPRs for the whole kernel and pushed the solver's scalars into spills
+        ColPtrs<T> cp;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) cp.x[c] = cols[c];
+        cp.y = cols[p];
+        cp.w = cp.y;
+        const int64_t row = t * TR + lane * RPL;
+        if ((t + 1) * TR <= n_rows) load_full_tile<T, false>(cp, p, row, regs);
+        else load_tail_tile<T, false>(cp, p, row, n_rows, regs);
+    };
+    if (t_first <= t_last) load_tile(t_first);
+    for (int64_t t = t_first; t <= t_last; ++t) {
+        store_tile_lds<T, false>(wl, p, lane, regs);
+        if (t + 1 <= t_last) load_tile(t + 1);
+        const int64_t row0 = t * TR;
+        const int64_t tile_end = (row0 + TR < rhi) ? row0 + TR : rhi;
+        while (g < gh && pos < tile_end) {
+            if (ge <= pos) {  // group complete (or empty)
+                flush_group();
+                ++g;
+                if (g < gh) ge = offsets[g + 1];
+                continue;
+            }
+            const int64_t seg_end = (ge < tile_end) ? ge : tile_end;
+            consume_range<T>(wl, lane, (int)(pos - row0), (int)(seg_end - row0), acc);
+            pos = seg_end;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // groups that end exactly at rhi (and trailing empty groups)
+    while (g < gh) {
+        flush_group();
+        ++g;
+        if (g < gh) ge = offsets[g + 1];
+    }
+    if (npend > 0) solve_pending();
+}
+
+template <typename T, int LPS>
+static int launch_stream_lps(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, const int64_t* d_offsets,
+                             int64_t n_groups, int64_t n_rows, const SolveRegDev& sd, bool chol, T* d_coeffs,
+                             uint8_t* d_flags) {
+    const size_t lds = (size_t)kFWaveLds;
+    const int per_cu = std::max(1, (int)((160 * 1024) / lds));
+    int64_t nb = std::min<int64_t>(std::max<int64_t>(n_groups / (64 / LPS), 1), (int64_t)ctx->num_cus * per_cu);
+    KernelTimer timer(ctx, kKindGroupedMoments);
+    if (chol)
+        hipLaunchKernelGGL((grouped_stream_kernel<T, LPS, true>), dim3((unsigned)nb), dim3(64), lds, ctx->stream, dc.d_ptrs,
+                           n_feat, d_offsets, n_groups, n_rows, sd, d_coeffs, d_flags);
+    else
+        hipLaunchKernelGGL((grouped_stream_kernel<T, LPS, false>), dim3((unsigned)nb), dim3(64), lds, ctx->stream, dc.d_ptrs,
+                           n_feat, d_offsets, n_groups, n_rows, sd, d_coeffs, d_flags);
+    PDS_HIP_CHECK(hipGetLastError());
+    return PDS_OK;
+}
+
+// OLS / ridge, p' <= 16
+template <typename T>
+int launch_grouped_fused(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, const int64_t* d_offsets,
+                         int64_t n_groups, const SolveParams& sp, T* d_coeffs, uint8_t* d_flags) {
+    SolveRegDev sd;
+    sd.p = sp.p;
+    sd.bias = sp.add_bias ? 1 : 0;
+    sd.pp = sp.p + sd.bias;
+    sd.lambda_on_bias = sp.lambda_on_bias;
+    sd.lambda = sp.lambda;
+    sd.gate_on = sp.gate_tol > 0.0 ? 1 : 0;
+    sd.ln_tol = sd.gate_on ? std::log(sp.gate_tol) : 0.0;
+    if (n_groups <= 0) return PDS_OK;
+    const char* piv = std::getenv("PDS_GROUPED_PIVOTED");
+    const bool chol = sd.gate_on && !(piv && piv[0] == '1');
+    if (sd.pp <= 4) return launch_stream_lps<T, 4>(ctx, dc, n_feat, d_offsets, n_groups, n_rows, sd, chol, d_coeffs, d_flags);
+    if (sd.pp <= 8) return launch_stream_lps<T, 8>(ctx, dc, n_feat, d_offsets, n_groups, n_rows, sd, chol, d_coeffs, d_flags);
+    return launch_stream_lps<T, 16>(ctx, dc, n_feat, d_offsets, n_groups, n_rows, sd, chol, d_coeffs, d_flags);
+}
+
+template int launch_grouped_fused<double>(pds_ctx*, const DeviceCols<double>&, int, int64_t, const int64_t*, int64_t,
+                                          const SolveParams&, double*, uint8_t*);
+template int launch_grouped_fused<float>(pds_ctx*, const DeviceCols<float>&, int, int64_t, const int64_t*, int64_t,
+                                         const SolveParams&, float*, uint8_t*);
+
+}  // namespace pds

@@ -37,6 +37,17 @@ __global__ __launch_bounds__(kP2Threads) void pass2_kernel(const T* const* __res
     constexpr int RPL = V16<T>::RPL;
     const int pp = p + bias;
     double sse = 0.0, wsse = 0.0;
+    // loop-invariant, wave-uniform: column pointers and coefficients live in SGPRs
+    const T* cx[16];
+    T bx[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        cx[c] = cols[c < p ? c : 0];
+        bx[c] = (c < p) ? beta[c] : T(0);
+    }
+    const T* cy = cols[p];
+    const T* cw = WEIGHTED ? cols[p + 1] : cols[p];
+    const T b0 = bias ? beta[p] : T(0);
     const int64_t nvec = (n + RPL - 1) / RPL;
     for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = v * RPL;
@@ -46,30 +57,30 @@ __global__ __launch_bounds__(kP2Threads) void pass2_kernel(const T* const* __res
         if (full) {
 #pragma unroll
             for (int c = 0; c < 16; ++c)
-                if (c < p) x[c] = *reinterpret_cast<const V*>(cols[c] + row);
-            yv = *reinterpret_cast<const V*>(cols[p] + row);
-            if (WEIGHTED) wv = *reinterpret_cast<const V*>(cols[p + 1] + row);
+                if (c < p) x[c] = *reinterpret_cast<const V*>(cx[c] + row);
+            yv = *reinterpret_cast<const V*>(cy + row);
+            if (WEIGHTED) wv = *reinterpret_cast<const V*>(cw + row);
         } else {
 #pragma unroll
             for (int c = 0; c < 16; ++c)
                 if (c < p) {
 #pragma unroll
-                    for (int e = 0; e < RPL; ++e) x[c][e] = (row + e < n) ? cols[c][row + e] : T(0);
+                    for (int e = 0; e < RPL; ++e) x[c][e] = (row + e < n) ? cx[c][row + e] : T(0);
                 }
 #pragma unroll
-            for (int e = 0; e < RPL; ++e) yv[e] = (row + e < n) ? cols[p][row + e] : T(0);
+            for (int e = 0; e < RPL; ++e) yv[e] = (row + e < n) ? cy[row + e] : T(0);
             if (WEIGHTED) {
 #pragma unroll
-                for (int e = 0; e < RPL; ++e) wv[e] = (row + e < n) ? cols[p + 1][row + e] : T(0);
+                for (int e = 0; e < RPL; ++e) wv[e] = (row + e < n) ? cw[row + e] : T(0);
             }
         }
         V pr, rs, sv;
 #pragma unroll
         for (int e = 0; e < RPL; ++e) {
-            T acc = bias ? beta[p] : T(0);
+            T acc = b0;
 #pragma unroll
             for (int c = 0; c < 16; ++c)
-                if (c < p) acc += x[c][e] * beta[c];
+                if (c < p) acc += x[c][e] * bx[c];
             pr[e] = acc;
             const T r = yv[e] - acc;
             rs[e] = r;
