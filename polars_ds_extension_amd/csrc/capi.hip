@@ -305,7 +305,8 @@ static int lr_impl(pds_ctx* ctx, const T* const* cols, const T* weights, int n_f
     PDS_HIP_CHECK(hipSetDevice(ctx->device));
     const int q = n_feat + 2, pp = n_feat + (prm->add_bias ? 1 : 0);
     const bool want_pred = pred || resid;
-    size_t need = 65536 + sizeof(T) * (size_t)q * q;
+    size_t need = 65536 + sizeof(T) * (size_t)q * q + sizeof(T*) * (size_t)(n_feat + 32);
+    if (n_feat > kMaxFeatSmall) need += moments_wide_workspace(ctx->num_cus, n_feat, n_rows);
     if (want_pred && space == PDS_HOST) need += 2 * ((size_t)n_rows * sizeof(T) + 512);
     if (int rc = ws_reserve(ctx, need)) return rc;
     DeviceCols<T> dc;
@@ -347,7 +348,9 @@ static int moments_impl(pds_ctx* ctx, const T* const* cols, const T* weights, in
     if (n_rows <= 0) return fail(PDS_ERR_EMPTY, "Empty data");
     PDS_HIP_CHECK(hipSetDevice(ctx->device));
     const int q = n_feat + 2;
-    if (int rc = ws_reserve(ctx, 65536 + sizeof(T) * (size_t)q * q)) return rc;
+    if (int rc = ws_reserve(ctx, 65536 + sizeof(T) * (size_t)q * q + sizeof(T*) * (size_t)(n_feat + 32) +
+                                     (n_feat > kMaxFeatSmall ? moments_wide_workspace(ctx->num_cus, n_feat, n_rows) : 0)))
+        return rc;
     DeviceCols<T> dc;
     if (int rc = make_device_cols<T>(ctx, cols, weights, n_feat, n_rows, space, dc)) return rc;
     T* d_mom = out_space == PDS_DEVICE ? moments : reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * q * q));

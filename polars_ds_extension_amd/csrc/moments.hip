@@ -191,8 +191,11 @@ __global__ __launch_bounds__(256, 2) void grouped_moments_kernel(const T* const*
 template <typename T>
 int launch_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, bool weighted,
                    T* d_moments) {
-    if (n_feat < 1 || n_feat > kMaxFeatSmall)
-        return fail(PDS_ERR_UNSUPPORTED, "moments: this build handles 1..16 features in the MFMA tile kernel");
+    if (n_feat > kMaxFeatSmall) {
+        if (weighted) return fail(PDS_ERR_UNSUPPORTED, "weighted regression with more than 16 features is not built yet");
+        return launch_moments_wide<T>(ctx, dc, n_feat, n_rows, d_moments);
+    }
+    if (n_feat < 1) return fail(PDS_ERR_INVALID, "need at least one feature column");
     constexpr int TR = 64 * Tile<T>::RPL;
     int64_t ntiles = (n_rows + TR - 1) / TR;
     int64_t want = (ntiles + kWaves - 1) / kWaves;

@@ -1,0 +1,289 @@
+// moments_wide.hip -- the Gram build for p > 16 features (config 5: elastic net on 1e7 rows x 512 f32
+// features, `faer_coordinate_descent`'s one-off X'X / X'y, /root/reference/src/linear/lr/lr_solvers.rs:447-484).
+//
+// Z = [x_0 .. x_{p-1} | 1 | y] has q = p + 2 columns; A = Z'Z is a tall-skinny SYRK: at p = 512 f32 it is
+// 256 flop/B, i.e. MFMA bound (5.3e12 flop vs 20.5 GB), not HBM bound like the p <= 16 kernel.
+//   * output tiled 128 x 128 per workgroup (4 waves, each 64 x 64 = 2x2 tiles of v_mfma_f32_32x32x2_f32 or
+//     4x4 tiles of v_mfma_f64_16x16x4_f64); only the upper block triangle is computed;
+//   * split-K over the row axis (grid.y) so that a few hundred workgroups are in flight; every workgroup
+//     writes its f64 partial tile and a fixed-order kernel reduces them (deterministic, no atomics);
+//   * the K-panels (128 columns x 128 B of rows) are read with 16-byte loads -- each 8-lane group covers one
+//     contiguous 128-byte line of a column -- prefetched into registers one stage ahead and parked in LDS
+//     column-major with an odd leading dimension, from where the MFMA operands are conflict-free b32/b64 reads;
+//   * f32 accumulates 1024 rows per matrix-core accumulator and folds into f64 registers (the reference
+//     accumulates everything in f32).
+#include "common.hpp"
+
+namespace pds {
+
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f4w __attribute__((ext_vector_type(4), aligned(4)));
+typedef double d4w __attribute__((ext_vector_type(4)));
+typedef double d2w __attribute__((ext_vector_type(2), aligned(8)));
+
+constexpr int kWB = 128;     // block tile edge (columns of Z)
+constexpr int kWThreads = 256;
+
+template <typename T>
+struct Wide;
+template <>
+struct Wide<float> {
+    static constexpr int KC = 32;   // rows per stage (128 B per column)
+    static constexpr int CS = 33;   // LDS leading dimension (floats)
+    static constexpr int MT = 32;   // MFMA tile edge
+    static constexpr int NT = 2;    // tiles per wave edge (64 / MT)
+    static constexpr int KS = 16;   // MFMA k-steps per stage (KC / 2)
+    static constexpr int FLUSH = 32;  // stages between folds into f64
+    using vec = f4w;
+    static constexpr int VL = 4;
+};
+template <>
+struct Wide<double> {
+    static constexpr int KC = 16;
+    static constexpr int CS = 17;
+    static constexpr int MT = 16;
+    static constexpr int NT = 4;
+    static constexpr int KS = 4;
+    static constexpr int FLUSH = 1 << 30;
+    using vec = d2w;
+    static constexpr int VL = 2;
+};
+
+// pair index -> (I, J), I <= J, row-major over the upper triangle of an nb x nb block grid
+__host__ __device__ inline void pair_to_ij(int pair, int nb, int& I, int& J) {
+    int i = 0;
+    while (pair >= nb - i) {
+        pair -= nb - i;
+        ++i;
+    }
+    I = i;
+    J = i + pair;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kWThreads) void moments_wide_kernel(const T* const* __restrict__ cols, int p, int64_t n,
+                                                                 int nb, int64_t rows_per_split,
+                                                                 double* __restrict__ partials) {
+    using W = Wide<T>;
+    constexpr int KC = W::KC, CS = W::CS, MT = W::MT, NT = W::NT, VL = W::VL;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* LI = reinterpret_cast<T*>(smem);
+    T* LJ = LI + kWB * CS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    int I, J;
+    pair_to_ij(blockIdx.x, nb, I, J);
+    const bool diag = I == J;
+    const int q = p + 2;
+    const int64_t r_begin = (int64_t)blockIdx.y * rows_per_split;
+    const int64_t r_end = (r_begin + rows_per_split < n) ? r_begin + rows_per_split : n;
+
+    // this thread's 4 chunks per panel: chunk id = tid + 256 u  ->  column id/8, 16-byte piece id%8
+    const T* ptrI[4];
+    const T* ptrJ[4];
+    int kindI[4], kindJ[4];  // 0 data column, 1 ones column, 2 zero padding
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int id = tid + kWThreads * u;
+        const int cI = I * kWB + (id >> 3), cJ = J * kWB + (id >> 3);
+        kindI[u] = (cI < p || cI == p + 1) ? 0 : (cI == p ? 1 : 2);
+        kindJ[u] = (cJ < p || cJ == p + 1) ? 0 : (cJ == p ? 1 : 2);
+        ptrI[u] = cols[cI < p ? cI : p];  // index p is y in the device table
+        ptrJ[u] = cols[cJ < p ? cJ : p];
+    }
+    (void)q;
+
+    typename W::vec rI[4], rJ[4];
+    auto load_stage = [&](int64_t row0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int id = tid + kWThreads * u;
+            const int64_t r = row0 + (id & 7) * VL;
+#pragma unroll
+            for (int pnl = 0; pnl < 2; ++pnl) {
+                if (pnl == 1 && diag) continue;
+                const int kind = pnl ? kindJ[u] : kindI[u];
+                const T* ptr = pnl ? ptrJ[u] : ptrI[u];
+                typename W::vec v;
+                if (kind == 0 && r + VL <= r_end) {
+                    v = *reinterpret_cast<const typename W::vec*>(ptr + r);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VL; ++e) {
+                        const bool in = r + e < r_end;
+                        v[e] = !in ? T(0) : (kind == 0 ? ptr[r + e] : (kind == 1 ? T(1) : T(0)));
+                    }
+                }
+                if (pnl) rJ[u] = v;
+                else rI[u] = v;
+            }
+        }
+    };
+    auto store_stage = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int id = tid + kWThreads * u;
+            const int c = id >> 3, k0 = (id & 7) * VL;
+#pragma unroll
+            for (int e = 0; e < VL; ++e) {
+                LI[c * CS + k0 + e] = rI[u][e];
+                if (!diag) LJ[c * CS + k0 + e] = rJ[u][e];
+            }
+        }
+    };
+
+    // accumulators: f64 registers; the f32 path adds a matrix-core f32 tile folded in every FLUSH stages
+    double accd[NT][NT][sizeof(T) == 4 ? 16 : 4];
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+#pragma unroll
+        for (int nn = 0; nn < NT; ++nn)
+#pragma unroll
+            for (int r = 0; r < (sizeof(T) == 4 ? 16 : 4); ++r) accd[m][nn][r] = 0.0;
+    f16v accf[2][2];
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accf[m][nn][r] = 0.f;
+    }
+    const T* PJ = diag ? LI : LJ;
+    int since_flush = 0;
+    if (r_begin < r_end) load_stage(r_begin);
+    for (int64_t row0 = r_begin; row0 < r_end; row0 += KC) {
+        __syncthreads();  // previous stage's reads are done
+        store_stage();
+        __syncthreads();
+        if (row0 + KC < r_end) load_stage(row0 + KC);
+        if constexpr (sizeof(T) == 4) {
+            const int li = lane & 31, kq = lane >> 5;
+#pragma unroll
+            for (int ks = 0; ks < W::KS; ++ks) {
+                const int k = 2 * ks + kq;
+                float a[2], b[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) a[m] = LI[(wr * 64 + m * 32 + li) * CS + k];
+#pragma unroll
+                for (int nn = 0; nn < 2; ++nn) b[nn] = PJ[(wc * 64 + nn * 32 + li) * CS + k];
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int nn = 0; nn < 2; ++nn)
+                        accf[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[nn], accf[m][nn], 0, 0, 0);
+            }
+            if (++since_flush == W::FLUSH) {
+                since_flush = 0;
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            accd[m][nn][r] += (double)accf[m][nn][r];
+                            accf[m][nn][r] = 0.f;
+                        }
+            }
+        } else {
+            const int li = lane & 15, kq = lane >> 4;
+#pragma unroll
+            for (int ks = 0; ks < W::KS; ++ks) {
+                const int k = 4 * ks + kq;
+                double a[4], b[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) a[m] = LI[(wr * 64 + m * 16 + li) * CS + k];
+#pragma unroll
+                for (int nn = 0; nn < 4; ++nn) b[nn] = PJ[(wc * 64 + nn * 16 + li) * CS + k];
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int nn = 0; nn < 4; ++nn) {
+                        d4w c = {accd[m][nn][0], accd[m][nn][1], accd[m][nn][2], accd[m][nn][3]};
+                        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[nn], c, 0, 0, 0);
+                        accd[m][nn][0] = c[0];
+                        accd[m][nn][1] = c[1];
+                        accd[m][nn][2] = c[2];
+                        accd[m][nn][3] = c[3];
+                    }
+            }
+        }
+    }
+    // ---- write the f64 partial tile: P[split][pair][i * 128 + j]
+    double* P = partials + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (kWB * kWB);
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+#pragma unroll
+        for (int nn = 0; nn < NT; ++nn) {
+            if constexpr (sizeof(T) == 4) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31;
+                    P[(wr * 64 + m * 32 + row) * kWB + wc * 64 + nn * 32 + col] = accd[m][nn][r] + (double)accf[m][nn][r];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = (lane >> 4) + 4 * r, col = lane & 15;
+                    P[(wr * 64 + m * 16 + row) * kWB + wc * 64 + nn * 16 + col] = accd[m][nn][r];
+                }
+            }
+        }
+}
+
+// out (q x q column-major, symmetric) = sum over splits of the partial tiles, fixed order
+template <typename T>
+__global__ __launch_bounds__(256) void moments_wide_reduce_kernel(const double* __restrict__ partials, int nsplit,
+                                                                  int npairs, int nb, int p, T* __restrict__ out) {
+    const int q = p + 2;
+    int I, J;
+    pair_to_ij(blockIdx.x, nb, I, J);
+    for (int e = threadIdx.x + blockIdx.y * blockDim.x; e < kWB * kWB; e += blockDim.x * gridDim.y) {
+        const int i = e / kWB, j = e % kWB;
+        const int gi = I * kWB + i, gj = J * kWB + j;
+        if (gi >= q || gj >= q) continue;
+        if (I == J && gi > gj) continue;
+        double s = 0.0;
+        for (int sidx = 0; sidx < nsplit; ++sidx) s += partials[((int64_t)sidx * npairs + blockIdx.x) * (kWB * kWB) + e];
+        out[gi + (int64_t)gj * q] = (T)s;
+        out[gj + (int64_t)gi * q] = (T)s;
+    }
+}
+
+template <typename T>
+int launch_moments_wide(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, T* d_moments) {
+    using W = Wide<T>;
+    const int q = n_feat + 2;
+    const int nb = (q + kWB - 1) / kWB;
+    const int npairs = nb * (nb + 1) / 2;
+    // split the row axis so that ~4 workgroups per CU are in flight; splits are multiples of the stage size
+    int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)ctx->num_cus * 4 + npairs - 1) / npairs,
+                                                             (n_rows + 4095) / 4096));
+    int64_t rows_per_split = (n_rows + nsplit - 1) / nsplit;
+    rows_per_split = ((rows_per_split + W::KC - 1) / W::KC) * W::KC;
+    nsplit = (int)((n_rows + rows_per_split - 1) / rows_per_split);
+    const size_t part_bytes = (size_t)nsplit * npairs * kWB * kWB * sizeof(double);
+    double* partials = reinterpret_cast<double*>(ws_take(ctx, part_bytes));
+    if (ctx->ws_used > ctx->ws.bytes) return fail(PDS_ERR_INVALID, "internal: workspace for the wide Gram build was not reserved");
+    const size_t lds = (size_t)2 * kWB * W::CS * sizeof(T);
+    KernelTimer timer(ctx, kKindMoments);
+    hipLaunchKernelGGL((moments_wide_kernel<T>), dim3(npairs, nsplit), dim3(kWThreads), lds, ctx->stream, dc.d_ptrs, n_feat,
+                       n_rows, nb, rows_per_split, partials);
+    hipLaunchKernelGGL((moments_wide_reduce_kernel<T>), dim3(npairs, 16), dim3(256), 0, ctx->stream, partials, nsplit,
+                       npairs, nb, n_feat, d_moments);
+    PDS_HIP_CHECK(hipGetLastError());
+    return PDS_OK;
+}
+
+size_t moments_wide_workspace(int num_cus, int n_feat, int64_t n_rows) {
+    const int q = n_feat + 2;
+    const int nb = (q + kWB - 1) / kWB;
+    const int npairs = nb * (nb + 1) / 2;
+    const int64_t nsplit = std::max<int64_t>(1, ((int64_t)num_cus * 4 + npairs - 1) / npairs) + 1;
+    return (size_t)nsplit * npairs * kWB * kWB * sizeof(double) + 4096;
+}
+
+template int launch_moments_wide<double>(pds_ctx*, const DeviceCols<double>&, int, int64_t, double*);
+template int launch_moments_wide<float>(pds_ctx*, const DeviceCols<float>&, int, int64_t, float*);
+
+}  // namespace pds

@@ -440,3 +440,40 @@ def test_full_size_grouped_noise_free(pds):
     assert int(nu.sum().item()) == 0
     err = (co - bg).norm(dim=1) / bg.norm(dim=1)
     assert float(err.max().item()) < 1e-11
+
+
+# ------------------------------------------------------------------------------------------ p > 16: tiled-SYRK Gram build
+@pytest.mark.parametrize("n,p", [(5000, 17), (20_011, 40), (3000, 130), (40_000, 64)])
+def test_wide_moments_and_ols_f64(pds, orc, n, p):
+    rng = np.random.default_rng(p)
+    X = rng.normal(size=(n, p))
+    y = X @ rng.normal(size=p) + 0.3 + 0.1 * rng.normal(size=n)
+    M = pds.gram_moments(*cols_of(X), target=dev(y))
+    Z = np.c_[X, np.ones(n), y]
+    assert nrel(M, Z.T @ Z) < 1e-13
+    if p + 1 <= 64:
+        b = pds.lin_reg(*cols_of(X), target=dev(y), add_bias=True)
+        assert nrel(b, orc.pl_lr(X, y, add_bias=True)) < F64_TOL
+    b = pds.lin_reg(*cols_of(X), target=dev(y), add_bias=True, l1_reg=0.01, l2_reg=0.01, tol=1e-9, max_iter=3000)
+    assert nrel(b, orc.pl_lr(X, y, add_bias=True, l1_reg=0.01, l2_reg=0.01, tol=1e-9, max_iter=3000)) < 1e-9
+
+
+def test_config5_elastic_net_f32_wide(pds, orc, f32):
+    # configs[4] at reduced N: elastic net, p = 512 f32, AR(0.5)-correlated columns, 32 non-zero coefficients
+    rng = np.random.default_rng(4)
+    n, p = 60_000, 512
+    E = rng.normal(size=(n, p)).astype(np.float32)
+    X = np.empty_like(E)
+    X[:, 0] = E[:, 0]
+    for j in range(1, p):
+        X[:, j] = 0.5 * X[:, j - 1] + np.sqrt(0.75) * E[:, j]
+    beta = np.zeros(p)
+    beta[rng.choice(p, 32, replace=False)] = rng.normal(size=32)
+    y = (X @ beta + 0.5 * rng.normal(size=n)).astype(np.float32)
+    M = pds.gram_moments(*cols_of(X), target=dev(y))
+    Z = np.c_[X.astype(np.float64), np.ones(n), y.astype(np.float64)]
+    assert nrel(M, Z.T @ Z) < 3e-7
+    b = pds.lin_reg(*cols_of(X), target=dev(y), l1_reg=0.01, l2_reg=0.01, tol=1e-5)
+    truth = orc.pl_lr(X.astype(np.float64), y.astype(np.float64), l1_reg=0.01, l2_reg=0.01, tol=1e-7, max_iter=2000)
+    assert b.dtype == np.float32 and nrel(b, truth) < 1e-3
+    assert np.sum(np.abs(b) > 1e-6) < 200  # sparse solution

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 import polars_ds_extension_amd as pds
 
-which = set(sys.argv[1:]) or {"rolling", "report", "single", "host"}
+which = set(sys.argv[1:]) or {"rolling", "report", "single", "host", "en"}
 dev = torch.device("cuda", 0)
 ctx = pds.Context(0)
 ctx.set_stream(torch.cuda.current_stream(dev))
@@ -74,4 +74,26 @@ if "report" in which or "single" in which or "host" in which:
         t0 = time.perf_counter(); pds.lin_reg(*hx, target=hy, add_bias=True, ctx=ctx); th = time.perf_counter() - t0
         out["single_ols_host_buffers"] = {"rows": ns, "wall_s": round(th, 3), "GBps_incl_pcie": round(ns * 17 * 8 / th / 1e9, 2),
                                          "note": "pageable numpy buffers -> hipMemcpyAsync staging -> kernels"}
+if "en" in which:
+    torch.cuda.empty_cache()
+    pds.config.LIN_REG_EXPR_F64 = False
+    n, p = 10_000_000, 512
+    xs = []
+    prev = None
+    for j in range(p):
+        e = torch.randn(n, dtype=torch.float32, device=dev, generator=gen)
+        prev = e if prev is None else 0.5 * prev + (0.75 ** 0.5) * e
+        xs.append(prev)
+    idx = torch.randperm(p, generator=torch.Generator().manual_seed(4))[:32]
+    y = torch.zeros(n, dtype=torch.float32, device=dev)
+    for j in idx.tolist(): y.add_(xs[j], alpha=float(torch.randn(1).item()))
+    y.add_(torch.randn(n, dtype=torch.float32, device=dev, generator=gen), alpha=0.5)
+    wall, t, b = timed(lambda: pds.lin_reg(*xs, target=y, l1_reg=0.01, l2_reg=0.01, tol=1e-5, ctx=ctx), reps=3, warm=1)
+    flops = 2.0 * n * (p + 2) * (p + 2)  # full square, as the reference computes it
+    gms = t["moments"][0]
+    out["elastic_net_c5"] = {"rows": n, "p": p, "dtype": "f32", "wall_ms": round(wall * 1e3, 2), "gram_ms": round(gms, 3),
+                             "gram_TFLOPs_full_square": round(flops / (gms * 1e-3) / 1e12, 1),
+                             "gram_TFLOPs_upper_triangle": round(flops / 2 / (gms * 1e-3) / 1e12, 1),
+                             "cd_ms": round(t.get("iterative", (0, 0))[0], 3), "nonzero": int((abs(b) > 1e-6).sum())}
+    pds.config.LIN_REG_EXPR_F64 = True
 print(json.dumps(out, indent=1))
