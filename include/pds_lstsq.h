@@ -44,8 +44,13 @@ typedef enum {
     PDS_ERR_TOO_FEW_ROWS = -3, /* "#Data < #features. No conclusive result."          :170-172 */
     PDS_ERR_HIP = -4,         /* HIP runtime failure / no gfx950 device */
     PDS_ERR_UNSUPPORTED = -5,
-    PDS_ERR_NUMERIC = -6      /* e.g. "SVD failed."                 lr_solvers.rs:256 */
+    PDS_ERR_NUMERIC = -6,     /* e.g. "SVD failed."                 lr_solvers.rs:256 */
+    PDS_ERR_NULLS = -7        /* "Nulls found in data"              linear_regression.rs:198 */
 } pds_status;
+
+/* NullPolicy (src/linear/mod.rs:34-66) as the plugin functions use it for pl_lr / pl_lr_pred:
+ * "raise" | "skip" | "zero"/"one"/numeric string -> FILL(value) | "ignore". */
+typedef enum { PDS_NULL_RAISE = 0, PDS_NULL_SKIP = 1, PDS_NULL_FILL = 2, PDS_NULL_IGNORE = 3 } pds_null_policy;
 
 /* LRSolverMethods::from(&str): "qr" (default, also any unknown string), "svd", "choleskey"
  * (src/linear/lr/mod.rs:17-26 -- the misspelling is the reference's). */
@@ -113,6 +118,26 @@ int pds_lr_pred_f64(pds_ctx* ctx, const double* const* cols, const double* weigh
 int pds_lr_pred_f32(pds_ctx* ctx, const float* const* cols, const float* weights, int n_feat,
                     int64_t n_rows, pds_space space, const pds_lr_params* prm, float* coeffs,
                     int* is_null, float* pred, float* resid);
+
+/*
+ * pds_lr_nullable_*: `pl_lr` / `pl_lr_pred` on columns that carry Arrow validity bitmaps, i.e. the null handling of
+ * series_to_mat_for_lr (linear_regression.rs:151-267) done on the device (stream compaction / fill), then the same
+ * fit.  validity[c] is the validity bitmap of cols[c] (LSB-first, one bit per row, NULL = column has no nulls),
+ * bit_offsets[c] the Arrow array offset into it; both in the same memory space as the column buffers.
+ *   pred / resid / row_valid  optional (all NULL = coefficients only), n_rows entries, `space`-resident.  Dropped rows
+ *                             get NaN and row_valid = 0 -- the null re-expansion of linear_regression.rs:790-812.
+ *   n_used                    out, rows that took part in the fit.
+ * Errors: PDS_ERR_NULLS ("Nulls found in data") under PDS_NULL_RAISE; PDS_ERR_EMPTY / PDS_ERR_TOO_FEW_ROWS are
+ * judged on the rows that survive the policy, like the reference (:250-254).
+ */
+int pds_lr_nullable_f64(pds_ctx* ctx, const double* const* cols, const uint8_t* const* validity,
+                        const int64_t* bit_offsets, int n_feat, int64_t n_rows, pds_space space, int null_policy,
+                        double fill_value, const pds_lr_params* prm, double* coeffs, int* is_null, double* pred,
+                        double* resid, uint8_t* row_valid, int64_t* n_used);
+int pds_lr_nullable_f32(pds_ctx* ctx, const float* const* cols, const uint8_t* const* validity,
+                        const int64_t* bit_offsets, int n_feat, int64_t n_rows, pds_space space, int null_policy,
+                        float fill_value, const pds_lr_params* prm, float* coeffs, int* is_null, float* pred,
+                        float* resid, uint8_t* row_valid, int64_t* n_used);
 
 /*
  * pds_lr_rcond_*: `pl_lr_w_rcond` -> faer_solve_lr_rcond (lr_solvers.rs:216-258).

@@ -340,6 +340,96 @@ static int lr_impl(pds_ctx* ctx, const T* const* cols, const T* weights, int n_f
     return PDS_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// pl_lr / pl_lr_pred with Arrow validity bitmaps: null policy on the device, then the ordinary fit
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+static int lr_nullable_impl(pds_ctx* ctx, const T* const* cols, const uint8_t* const* validity, const int64_t* bit_offsets,
+                            int n_feat, int64_t n_rows, pds_space space, int policy, T fill_value,
+                            const pds_lr_params* prm, T* coeffs, int* is_null, T* pred, T* resid, uint8_t* row_valid,
+                            int64_t* n_used) {
+    if (!ctx || !cols || !prm || !coeffs) return fail(PDS_ERR_INVALID, "null argument");
+    if (n_feat < 1) return fail(PDS_ERR_INVALID, "need at least one feature column");
+    if (n_rows == 0) return fail(PDS_ERR_EMPTY, "Empty data");
+    if (policy < PDS_NULL_RAISE || policy > PDS_NULL_IGNORE) return fail(PDS_ERR_INVALID, "Invalid NullPolicy.");
+    PDS_HIP_CHECK(hipSetDevice(ctx->device));
+    const int nc = n_feat + 1, q = n_feat + 2, pp = n_feat + (prm->add_bias ? 1 : 0);
+    const bool want_pred = pred || resid;
+    size_t need = (1 << 20) + sizeof(T) * (size_t)q * q + null_policy_workspace(nc, n_rows, sizeof(T));
+    if (n_feat > kMaxFeatSmall) need += moments_wide_workspace(ctx->num_cus, n_feat, n_rows);
+    if (space == PDS_HOST) need += (size_t)nc * ((size_t)n_rows / 8 + 4096);
+    if (want_pred) need += 4 * ((size_t)n_rows * sizeof(T) + 512) + (size_t)n_rows + 512;
+    if (int rc = ws_reserve(ctx, need)) return rc;
+    DeviceCols<T> dc;
+    if (int rc = make_device_cols<T>(ctx, cols, (const T*)nullptr, n_feat, n_rows, space, dc)) return rc;
+    std::vector<const T*> ref_order(nc);
+    ref_order[0] = dc.h_ptrs[n_feat];
+    for (int c = 0; c < n_feat; ++c) ref_order[c + 1] = dc.h_ptrs[c];
+    std::vector<const uint8_t*> bms(nc, nullptr);
+    std::vector<int64_t> boff(nc, 0);
+    for (int c = 0; c < nc; ++c) {
+        boff[c] = bit_offsets ? bit_offsets[c] : 0;
+        const uint8_t* b = validity ? validity[c] : nullptr;
+        if (b && space == PDS_HOST) {
+            const size_t bytes = (size_t)((boff[c] + n_rows + 7) / 8);
+            uint8_t* d = reinterpret_cast<uint8_t*>(ws_take(ctx, bytes));
+            PDS_HIP_CHECK(hipMemcpyAsync(d, b, bytes, hipMemcpyHostToDevice, ctx->stream));
+            b = d;
+        }
+        bms[c] = b;
+    }
+    NullPrepared<T> prep;
+    if (int rc = apply_null_policy<T>(ctx, ref_order, bms, boff, n_rows, policy, fill_value, prep)) return rc;
+    if (n_used) *n_used = prep.n_kept;
+    if (prep.n_kept == 0) return fail(PDS_ERR_EMPTY, "Empty data");
+    if (prep.n_kept < pp) return fail(PDS_ERR_TOO_FEW_ROWS, "#Data < #features. No conclusive result.");
+    DeviceCols<T> dk;
+    dk.nc = nc;
+    dk.h_ptrs.resize(nc);
+    for (int c = 0; c < n_feat; ++c) dk.h_ptrs[c] = prep.cols[c + 1];
+    dk.h_ptrs[n_feat] = prep.cols[0];
+    dk.h_ptrs.resize(std::max(nc, 18), dk.h_ptrs[0]);
+    dk.d_ptrs = reinterpret_cast<const T**>(ws_take(ctx, sizeof(T*) * dk.h_ptrs.size()));
+    PDS_HIP_CHECK(hipMemcpyAsync(dk.d_ptrs, dk.h_ptrs.data(), sizeof(T*) * dk.h_ptrs.size(), hipMemcpyHostToDevice, ctx->stream));
+    T* d_mom = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * q * q));
+    if (int rc = launch_moments<T>(ctx, dk, n_feat, prep.n_kept, false, d_mom)) return rc;
+    T* d_coeffs = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * (pp + 2)));
+    int null_flag = 0;
+    if (int rc = lr_from_device_moments<T>(ctx, d_mom, n_feat, prm, false, coeffs, &null_flag, d_coeffs)) return rc;
+    if (is_null) *is_null = null_flag;
+    if (want_pred) {
+        T* c_pred = reinterpret_cast<T*>(ws_take(ctx, (size_t)prep.n_kept * sizeof(T)));
+        T* c_resid = reinterpret_cast<T*>(ws_take(ctx, (size_t)prep.n_kept * sizeof(T)));
+        double* d_sums = reinterpret_cast<double*>(ws_take(ctx, 64));
+        if (int rc = launch_pass2<T>(ctx, dk, n_feat, prep.n_kept, prm->add_bias, false, d_coeffs, nullptr, 0, c_pred, c_resid,
+                                     d_sums, nullptr))
+            return rc;
+        T* o_pred = pred;
+        T* o_resid = resid;
+        uint8_t* o_valid = row_valid;
+        if (space == PDS_HOST) {
+            o_pred = reinterpret_cast<T*>(ws_take(ctx, (size_t)n_rows * sizeof(T)));
+            o_resid = reinterpret_cast<T*>(ws_take(ctx, (size_t)n_rows * sizeof(T)));
+            o_valid = reinterpret_cast<uint8_t*>(ws_take(ctx, (size_t)n_rows));
+        }
+        if (prep.dropped) {
+            if (o_pred) if (int rc = expand_rows<T>(ctx, c_pred, prep.d_keep, prep.d_rank, n_rows, o_pred, o_valid)) return rc;
+            if (o_resid) if (int rc = expand_rows<T>(ctx, c_resid, prep.d_keep, prep.d_rank, n_rows, o_resid, nullptr)) return rc;
+        } else {
+            if (o_pred) PDS_HIP_CHECK(hipMemcpyAsync(o_pred, c_pred, (size_t)n_rows * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+            if (o_resid) PDS_HIP_CHECK(hipMemcpyAsync(o_resid, c_resid, (size_t)n_rows * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+            if (o_valid) PDS_HIP_CHECK(hipMemsetAsync(o_valid, 1, (size_t)n_rows, ctx->stream));
+        }
+        if (space == PDS_HOST) {
+            if (pred) PDS_HIP_CHECK(hipMemcpyAsync(pred, o_pred, (size_t)n_rows * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+            if (resid) PDS_HIP_CHECK(hipMemcpyAsync(resid, o_resid, (size_t)n_rows * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+            if (row_valid) PDS_HIP_CHECK(hipMemcpyAsync(row_valid, o_valid, (size_t)n_rows, hipMemcpyDeviceToHost, ctx->stream));
+        }
+    }
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PDS_OK;
+}
+
 template <typename T>
 static int moments_impl(pds_ctx* ctx, const T* const* cols, const T* weights, int n_feat, int64_t n_rows,
                         pds_space space, T* moments, pds_space out_space) {
@@ -699,6 +789,21 @@ int pds_lr_pred_f32(pds_ctx* ctx, const float* const* cols, const float* weights
                     pds_space space, const pds_lr_params* prm, float* coeffs, int* is_null, float* pred, float* resid) {
     if (!pred || !resid) return fail(PDS_ERR_INVALID, "pred / resid buffers required");
     return lr_impl<float>(ctx, cols, weights, n_feat, n_rows, space, prm, coeffs, is_null, pred, resid);
+}
+
+int pds_lr_nullable_f64(pds_ctx* ctx, const double* const* cols, const uint8_t* const* validity, const int64_t* bit_offsets,
+                        int n_feat, int64_t n_rows, pds_space space, int null_policy, double fill_value,
+                        const pds_lr_params* prm, double* coeffs, int* is_null, double* pred, double* resid,
+                        uint8_t* row_valid, int64_t* n_used) {
+    return lr_nullable_impl<double>(ctx, cols, validity, bit_offsets, n_feat, n_rows, space, null_policy, fill_value, prm,
+                                    coeffs, is_null, pred, resid, row_valid, n_used);
+}
+int pds_lr_nullable_f32(pds_ctx* ctx, const float* const* cols, const uint8_t* const* validity, const int64_t* bit_offsets,
+                        int n_feat, int64_t n_rows, pds_space space, int null_policy, float fill_value,
+                        const pds_lr_params* prm, float* coeffs, int* is_null, float* pred, float* resid,
+                        uint8_t* row_valid, int64_t* n_used) {
+    return lr_nullable_impl<float>(ctx, cols, validity, bit_offsets, n_feat, n_rows, space, null_policy, fill_value, prm,
+                                   coeffs, is_null, pred, resid, row_valid, n_used);
 }
 
 int pds_lr_rcond_f64(pds_ctx* ctx, const double* const* cols, int n_feat, int64_t n_rows, pds_space space,

@@ -158,6 +158,24 @@ int launch_pass2(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_ro
                  bool weighted, const T* d_beta, const T* d_inv /*nullable, for HC2/3*/, int hc_mode,
                  T* d_pred, T* d_resid, double* d_sums /*[2]*/, double* d_meat /*p'*p' or null*/);
 
+// ---- nulls.hip ----
+template <typename T>
+struct NullPrepared {
+    std::vector<const T*> cols;  // device pointers, reference order [y, x1..xp]
+    int64_t n_kept = 0;
+    bool dropped = false;         // rows were removed -> d_keep / d_rank are valid
+    uint8_t* d_keep = nullptr;
+    int64_t* d_rank = nullptr;
+};
+template <typename T>
+int apply_null_policy(pds_ctx* ctx, const std::vector<const T*>& cols_dev, const std::vector<const uint8_t*>& bm_dev,
+                      const std::vector<int64_t>& bit_off, int64_t n_rows, int policy, T fill_value,
+                      NullPrepared<T>& out);
+template <typename T>
+int expand_rows(pds_ctx* ctx, const T* d_compact, const uint8_t* d_keep, const int64_t* d_rank, int64_t n_rows, T* d_out,
+                uint8_t* d_valid);
+size_t null_policy_workspace(int n_cols, int64_t n_rows, size_t elem);
+
 // ---- rolling.hip ----
 template <typename T>
 int launch_rolling(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, int add_bias,

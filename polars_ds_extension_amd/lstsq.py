@@ -181,9 +181,81 @@ def _out_u8(cols: _Cols, n):
     return a, C.c_void_p(a.ctypes.data)
 
 
+def parse_null_policy(value: str):
+    """NullPolicy::try_from (src/linear/mod.rs:43-66): returns (policy code, fill value)."""
+    v = str(value).lower()
+    if v == "raise":
+        return 0, 0.0
+    if v == "skip":
+        return 1, 0.0
+    if v == "zero":
+        return 2, 0.0
+    if v == "one":
+        return 2, 1.0
+    if v == "ignore":
+        return 3, 0.0
+    try:
+        return 2, float(value)
+    except ValueError:
+        raise ValueError("Invalid NullPolicy.") from None
+
+
+def _is_arrow(a) -> bool:
+    return type(a).__module__.startswith("pyarrow")
+
+
+def _arrow_parts(a, dt):
+    """(values ndarray, validity buffer address or 0, bit offset, keepalive) of a pyarrow (Chunked)Array."""
+    import pyarrow as pa
+
+    if isinstance(a, pa.ChunkedArray):
+        a = a.combine_chunks() if a.num_chunks != 1 else a.chunk(0)  # like .rechunk()
+    want = pa.float64() if dt == np.float64 else pa.float32()
+    if a.type != want:
+        a = a.cast(want)  # the Rust side casts non-matching inputs the same way (src/utils/mod.rs:134-205)
+    vbuf, dbuf = a.buffers()
+    vals = np.frombuffer(dbuf, dtype=dt)[a.offset : a.offset + len(a)]
+    has_nulls = vbuf is not None and a.null_count > 0
+    return vals, (vbuf.address if has_nulls else 0), a.offset, (a, vbuf, dbuf)
+
+
+def _lin_reg_arrow(x, target, add_bias, return_pred, null_policy, prm, ctx):
+    """pl_lr / pl_lr_pred on Arrow columns with validity bitmaps (host memory)."""
+    dt = _dtype()
+    parts = [_arrow_parts(c, dt) if _is_arrow(c) else (np.ascontiguousarray(np.asarray(c), dtype=dt), 0, 0, None)
+             for c in (target, *x)]
+    n = len(parts[0][0])
+    if any(len(pt[0]) != n for pt in parts):
+        raise ValueError("all columns must be 1-D and of equal length")
+    nc = len(parts)
+    cols = (C.c_void_p * nc)(*[pt[0].ctypes.data for pt in parts])
+    vals = (C.c_void_p * nc)(*[pt[1] or None for pt in parts])
+    offs = (C.c_int64 * nc)(*[pt[2] for pt in parts])
+    code, fill = parse_null_policy(null_policy)
+    pp = nc - 1 + int(bool(add_bias))
+    coeffs = np.empty(pp, dtype=dt)
+    is_null, n_used = C.c_int(0), C.c_int64(0)
+    fillv = C.c_double(fill) if config.LIN_REG_EXPR_F64 else C.c_float(fill)
+    if return_pred:
+        pred, resid, valid = np.empty(n, dtype=dt), np.empty(n, dtype=dt), np.empty(n, dtype=np.uint8)
+        pp_, rp_, vp_ = (C.c_void_p(a.ctypes.data) for a in (pred, resid, valid))
+    else:
+        pred = resid = valid = None
+        pp_ = rp_ = vp_ = C.c_void_p(None)
+    _lib.check(ctx.fn("pds_lr_nullable")(ctx._h, cols, vals, offs, nc - 1, C.c_int64(n), _lib.PDS_HOST, code, fillv, C.byref(prm),
+                                         C.c_void_p(coeffs.ctypes.data), C.byref(is_null), pp_, rp_, vp_, C.byref(n_used)))
+    if return_pred:
+        if is_null.value:  # all-null {pred, resid} struct of the same length (linear_regression.rs:745-750)
+            valid[:] = 0
+            pred[:] = np.nan
+            resid[:] = np.nan
+        return pred, resid, valid.astype(bool)
+    return None if is_null.value else coeffs
+
+
 def lin_reg(*x, target, add_bias: bool = False, weights=None, return_pred: bool = False, l1_reg: float = 0.0,
             l2_reg: float = 0.0, tol: float = 1e-5, solver: str = "qr", max_iter: int = 200, positive: bool = False,
-            singular_x_tol: float | None = None, ctx: Context | None = None):
+            singular_x_tol: float | None = None, null_policy: str = "skip", ctx: Context | None = None):
     """
     pds.lin_reg on null-free column buffers (pl_lr / pl_lr_pred).
 
@@ -194,6 +266,12 @@ def lin_reg(*x, target, add_bias: bool = False, weights=None, return_pred: bool 
     if max_iter <= 0:
         raise ValueError("Input `max_iter` must be a positive.")  # expr_linear.py:231-232
     ctx = ctx or default_context()
+    if weights is None and any(_is_arrow(c) for c in (target, *x)):
+        # Arrow columns may carry nulls: `null_policy` applies ("skip" is the reference's default, expr_linear.py:116);
+        # with return_pred the result is (pred, resid, row_valid)
+        prm = _params(add_bias, l1_reg, l2_reg, tol, solver, positive, max_iter, singular_x_tol)
+        return _lin_reg_arrow(x, target, add_bias, return_pred, null_policy, prm, ctx)
+    parse_null_policy(null_policy)  # validated even when no column can hold a null
     cols = _Cols(target, x, weights)
     _follow(ctx, cols)
     prm = _params(add_bias, l1_reg, l2_reg, tol, solver, positive, max_iter, singular_x_tol)

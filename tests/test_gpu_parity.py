@@ -477,3 +477,71 @@ def test_config5_elastic_net_f32_wide(pds, orc, f32):
     truth = orc.pl_lr(X.astype(np.float64), y.astype(np.float64), l1_reg=0.01, l2_reg=0.01, tol=1e-7, max_iter=2000)
     assert b.dtype == np.float32 and nrel(b, truth) < 1e-3
     assert np.sum(np.abs(b) > 1e-6) < 200  # sparse solution
+
+
+# ------------------------------------------------------------------------------------------ null policies (Arrow validity)
+def _arrow_frame(rng, n, p, null_cols, frac=0.07, offset=0):
+    import pyarrow as pa
+
+    X = rng.random((n, p))
+    y = X @ rng.normal(size=p) + 0.2 + 0.05 * rng.normal(size=n)
+    masks = {}
+    arrs = []
+    for c, v in enumerate([y] + [X[:, j] for j in range(p)]):
+        m = (rng.random(n) < frac) if c in null_cols else np.zeros(n, dtype=bool)
+        masks[c] = m
+        a = pa.array(np.where(m, 123456.0, v), mask=m)  # null slots hold junk on purpose
+        arrs.append(a.slice(offset) if offset else a)
+    valid = [~masks[c][offset:] for c in range(p + 1)]
+    return arrs, X[offset:], y[offset:], valid
+
+
+@pytest.mark.parametrize("offset", [0, 5])
+def test_null_policies_match_reference_semantics(pds, orc, offset):
+    # tests/test_many.py:1636-1726 + tests/test_linear_exprs.py:411-432: skip / raise / zero / one / "0.5" / ignore / invalid
+    from polars_ds_extension_amd._lib import PdsError
+
+    rng = np.random.default_rng(7)
+    n, p = 40_000, 3
+    arrs, X, y, valid = _arrow_frame(rng, n, p, null_cols={1, 3}, offset=offset)
+    keep = np.logical_and.reduce(valid)
+    b = pds.lin_reg(*arrs[1:], target=arrs[0], add_bias=True, null_policy="skip")
+    assert nrel(b, orc.pl_lr(X[keep], y[keep], add_bias=True)) < F64_TOL
+    pred, resid, rv = pds.lin_reg(*arrs[1:], target=arrs[0], add_bias=True, null_policy="skip", return_pred=True)
+    assert np.array_equal(rv, keep) and np.isnan(pred[~keep]).all()
+    ref = np.c_[X[keep], np.ones(keep.sum())] @ b
+    assert nrel(pred[keep], ref) < F64_TOL and np.max(np.abs(resid[keep] - (y[keep] - ref))) < 1e-11
+    for pol, fill in (("zero", 0.0), ("one", 1.0), ("0.5", 0.5), ("ZERO", 0.0)):
+        Xf = X.copy()
+        for j in range(p):
+            Xf[~valid[j + 1], j] = fill
+        b = pds.lin_reg(*arrs[1:], target=arrs[0], add_bias=True, null_policy=pol)
+        assert nrel(b, orc.pl_lr(Xf, y, add_bias=True)) < F64_TOL  # the target has no nulls here: nothing is dropped
+    with pytest.raises(PdsError, match="Nulls found in data"):
+        pds.lin_reg(*arrs[1:], target=arrs[0], null_policy="raise")
+    with pytest.raises(ValueError, match="Invalid NullPolicy"):
+        pds.lin_reg(*arrs[1:], target=arrs[0], null_policy="nonsense")
+    b = pds.lin_reg(*arrs[1:], target=arrs[0], null_policy="ignore", singular_x_tol=0.0)
+    assert np.isnan(b).all()  # nulls become NaN and poison the normal equations, as in the reference
+    # target nulls + fill: rows with a null target are dropped, feature nulls filled (linear_regression.rs:207-227)
+    arrs2, X2, y2, valid2 = _arrow_frame(rng, n, p, null_cols={0, 2}, offset=offset)
+    Xf = X2.copy()
+    Xf[~valid2[2], 1] = 0.0
+    k2 = valid2[0]
+    b = pds.lin_reg(*arrs2[1:], target=arrs2[0], null_policy="zero")
+    assert nrel(b, orc.pl_lr(Xf[k2], y2[k2])) < F64_TOL
+    # a frame without nulls takes the fast path under every policy, incl. raise
+    arrs3, X3, y3, _ = _arrow_frame(rng, 5000, p, null_cols=set())
+    assert nrel(pds.lin_reg(*arrs3[1:], target=arrs3[0], null_policy="raise"), orc.pl_lr(X3, y3)) < F64_TOL
+
+
+def test_literal_skip_null_frame(pds):
+    # tests/test_linear_exprs.py:411-432 (literal frame): a null in row 0 -> pred [None, 9.5, 10.5, 11.5, 12.5], resid [None, 0, 0, 0, 0]
+    import pyarrow as pa
+
+    x = pa.array([None, 2.0, 3.0, 4.0, 5.0])
+    y = pa.array([8.5, 9.5, 10.5, 11.5, 12.5])
+    pred, resid, valid = pds.lin_reg(x, target=y, add_bias=True, null_policy="skip", return_pred=True)
+    assert list(valid) == [False, True, True, True, True]
+    np.testing.assert_allclose(pred[1:], [9.5, 10.5, 11.5, 12.5], atol=1e-10)
+    np.testing.assert_allclose(resid[1:], 0.0, atol=1e-10)
