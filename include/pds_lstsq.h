@@ -140,6 +140,21 @@ int pds_lr_nullable_f32(pds_ctx* ctx, const float* const* cols, const uint8_t* c
                         float* resid, uint8_t* row_valid, int64_t* n_used);
 
 /*
+ * pds_lr_multi_*: `pl_lr_multi` / `pl_lr_multi_pred` (linear_regression.rs:517-649): k targets share one design
+ * matrix.  cols = [t_0 .. t_{k-1}, x_1 .. x_p] (the expression's input order, MultiLRKwargs.last_target_idx = k).
+ * OLS / ridge only; the rank gate depends on X alone, so either every target gets coefficients or none does.
+ * One pass over the data builds X'X and all k X't_i together (the extra targets ride in the Gram tile).
+ *   coeffs  out, k x (n_feat + add_bias), row-major (target i's coefficients contiguous).
+ *   pred / resid  optional, k x n_rows row-major, `space`-resident ("{target}_pred" / "{target}_resid" fields).
+ */
+int pds_lr_multi_f64(pds_ctx* ctx, const double* const* cols, int n_targets, int n_feat, int64_t n_rows,
+                     pds_space space, int add_bias, double l2_reg, int solver, double singular_x_tol, double* coeffs,
+                     int* is_null, double* pred, double* resid);
+int pds_lr_multi_f32(pds_ctx* ctx, const float* const* cols, int n_targets, int n_feat, int64_t n_rows,
+                     pds_space space, int add_bias, float l2_reg, int solver, float singular_x_tol, float* coeffs,
+                     int* is_null, float* pred, float* resid);
+
+/*
  * pds_lr_rcond_*: `pl_lr_w_rcond` -> faer_solve_lr_rcond (lr_solvers.rs:216-258).
  * rcond is max(kwargs.tol, eps * max(n, p')) as computed by the caller (linear_regression.rs:651-702).
  */

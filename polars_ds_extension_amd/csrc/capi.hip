@@ -430,6 +430,94 @@ static int lr_nullable_impl(pds_ctx* ctx, const T* const* cols, const uint8_t* c
     return PDS_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// pl_lr_multi / pl_lr_multi_pred: k targets, one Gram build (targets 1..k-1 ride along as Gram columns)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+static int lr_multi_impl(pds_ctx* ctx, const T* const* cols, int k, int n_feat, int64_t n_rows, pds_space space,
+                         int add_bias, double l2_reg, int solver, double gate_tol, T* coeffs, int* is_null, T* pred,
+                         T* resid) {
+    if (!ctx || !cols || !coeffs) return fail(PDS_ERR_INVALID, "null argument");
+    if (k < 1) return fail(PDS_ERR_INVALID, "need at least one target");
+    if (n_feat < 1) return fail(PDS_ERR_INVALID, "need at least one feature column");
+    if (n_rows == 0) return fail(PDS_ERR_EMPTY, "Empty data");  // series_to_mat_for_multi_lr :285-288
+    PDS_HIP_CHECK(hipSetDevice(ctx->device));
+    const int p = n_feat, bias = add_bias ? 1 : 0, pp = p + bias, q = p + 2;
+    const int pa = p + k - 1, qa = pa + 2;  // augmented feature count: [x.., t_1..t_{k-1}], target t_0
+    const bool want_pred = pred || resid;
+    size_t need = (1 << 20) + sizeof(T) * ((size_t)qa * qa + (size_t)k * (q * q + pp + 2)) + sizeof(T*) * (size_t)(pa + 64);
+    if (pa > kMaxFeatSmall) need += moments_wide_workspace(ctx->num_cus, pa, n_rows);
+    if (want_pred && space == PDS_HOST) need += 2 * ((size_t)n_rows * sizeof(T) + 512);
+    if (int rc = ws_reserve(ctx, need)) return rc;
+    // reference order for make_device_cols is [y, x1..]: y = t_0, features = x_1..x_p, t_1..t_{k-1}
+    std::vector<const T*> order(pa + 1);
+    order[0] = cols[0];
+    for (int c = 0; c < p; ++c) order[1 + c] = cols[k + c];
+    for (int i = 1; i < k; ++i) order[p + i] = cols[i];
+    DeviceCols<T> dc;
+    if (int rc = make_device_cols<T>(ctx, order.data(), (const T*)nullptr, pa, n_rows, space, dc)) return rc;
+    T* d_moma = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * qa * qa));
+    if (int rc = launch_moments<T>(ctx, dc, pa, n_rows, false, d_moma)) return rc;
+    std::vector<T> Ma((size_t)qa * qa);
+    PDS_HIP_CHECK(hipMemcpyAsync(Ma.data(), d_moma, sizeof(T) * Ma.size(), hipMemcpyDeviceToHost, ctx->stream));
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    // per-target (p+2)^2 moment matrices: same X'X / column sums / n, its own X't, sum t, t't
+    std::vector<T> Mk((size_t)k * q * q, T(0));
+    auto A = [&](int i, int j) { return Ma[i + (size_t)j * qa]; };
+    for (int t = 0; t < k; ++t) {
+        T* M = Mk.data() + (size_t)t * q * q;
+        const int ti = (t == 0) ? pa + 1 : p + t - 1;  // index of target t inside the augmented matrix
+        for (int j = 0; j < p; ++j) {
+            for (int i = 0; i < p; ++i) M[i + j * q] = A(i, j);
+            M[j + p * q] = M[p + j * q] = A(j, pa);           // column sums
+            M[j + (p + 1) * q] = M[(p + 1) + j * q] = A(j, ti);  // X't
+        }
+        M[p + p * q] = A(pa, pa);                               // n
+        M[p + (p + 1) * q] = M[(p + 1) + p * q] = A(pa, ti);    // sum t
+        M[(p + 1) + (p + 1) * q] = A(ti, ti);
+    }
+    T* d_mk = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * Mk.size()));
+    T* d_co = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * (size_t)k * pp));
+    uint8_t* d_fl = reinterpret_cast<uint8_t*>(ws_take(ctx, (size_t)k + 16));
+    PDS_HIP_CHECK(hipMemcpyAsync(d_mk, Mk.data(), sizeof(T) * Mk.size(), hipMemcpyHostToDevice, ctx->stream));
+    SolveParams sp{p, bias, solver == PDS_SOLVER_SVD ? PDS_SOLVER_QR : solver, l2_reg, gate_tol, 0};
+    if (int rc = launch_solve<T>(ctx, d_mk, k, sp, d_co, d_fl, nullptr, nullptr)) return rc;
+    std::vector<uint8_t> fl(k);
+    PDS_HIP_CHECK(hipMemcpyAsync(coeffs, d_co, sizeof(T) * (size_t)k * pp, hipMemcpyDeviceToHost, ctx->stream));
+    PDS_HIP_CHECK(hipMemcpyAsync(fl.data(), d_fl, (size_t)k, hipMemcpyDeviceToHost, ctx->stream));
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (is_null) *is_null = fl[0] ? 1 : 0;
+    if (want_pred) {
+        if (p > kMaxFeatSmall) return fail(PDS_ERR_UNSUPPORTED, "multi-target predictions: 1..16 features supported");
+        double* d_sums = reinterpret_cast<double*>(ws_take(ctx, 64));
+        T* t_pred = nullptr;
+        T* t_resid = nullptr;
+        if (space == PDS_HOST) {
+            t_pred = reinterpret_cast<T*>(ws_take(ctx, (size_t)n_rows * sizeof(T)));
+            t_resid = reinterpret_cast<T*>(ws_take(ctx, (size_t)n_rows * sizeof(T)));
+        }
+        for (int t = 0; t < k; ++t) {
+            DeviceCols<T> dt;
+            dt.nc = p + 1;
+            dt.h_ptrs.assign(dc.h_ptrs.begin(), dc.h_ptrs.begin() + p);
+            dt.h_ptrs.push_back(t == 0 ? dc.h_ptrs[pa] : dc.h_ptrs[p + t - 1]);
+            dt.h_ptrs.resize(18, dt.h_ptrs[0]);
+            dt.d_ptrs = reinterpret_cast<const T**>(ws_take(ctx, sizeof(T*) * 18));
+            PDS_HIP_CHECK(hipMemcpyAsync(dt.d_ptrs, dt.h_ptrs.data(), sizeof(T*) * 18, hipMemcpyHostToDevice, ctx->stream));
+            T* op = (space == PDS_HOST) ? t_pred : (pred ? pred + (size_t)t * n_rows : nullptr);
+            T* orr = (space == PDS_HOST) ? t_resid : (resid ? resid + (size_t)t * n_rows : nullptr);
+            if (int rc = launch_pass2<T>(ctx, dt, p, n_rows, bias, false, d_co + (size_t)t * pp, nullptr, 0, op, orr, d_sums, nullptr))
+                return rc;
+            if (space == PDS_HOST) {
+                if (pred) PDS_HIP_CHECK(hipMemcpyAsync(pred + (size_t)t * n_rows, t_pred, (size_t)n_rows * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+                if (resid) PDS_HIP_CHECK(hipMemcpyAsync(resid + (size_t)t * n_rows, t_resid, (size_t)n_rows * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+            }
+            PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // dt.h_ptrs goes out of scope
+        }
+    }
+    return PDS_OK;
+}
+
 template <typename T>
 static int moments_impl(pds_ctx* ctx, const T* const* cols, const T* weights, int n_feat, int64_t n_rows,
                         pds_space space, T* moments, pds_space out_space) {
@@ -804,6 +892,19 @@ int pds_lr_nullable_f32(pds_ctx* ctx, const float* const* cols, const uint8_t* c
                         uint8_t* row_valid, int64_t* n_used) {
     return lr_nullable_impl<float>(ctx, cols, validity, bit_offsets, n_feat, n_rows, space, null_policy, fill_value, prm,
                                    coeffs, is_null, pred, resid, row_valid, n_used);
+}
+
+int pds_lr_multi_f64(pds_ctx* ctx, const double* const* cols, int n_targets, int n_feat, int64_t n_rows, pds_space space,
+                     int add_bias, double l2_reg, int solver, double singular_x_tol, double* coeffs, int* is_null,
+                     double* pred, double* resid) {
+    return lr_multi_impl<double>(ctx, cols, n_targets, n_feat, n_rows, space, add_bias, l2_reg, solver, singular_x_tol,
+                                 coeffs, is_null, pred, resid);
+}
+int pds_lr_multi_f32(pds_ctx* ctx, const float* const* cols, int n_targets, int n_feat, int64_t n_rows, pds_space space,
+                     int add_bias, float l2_reg, int solver, float singular_x_tol, float* coeffs, int* is_null, float* pred,
+                     float* resid) {
+    return lr_multi_impl<float>(ctx, cols, n_targets, n_feat, n_rows, space, add_bias, l2_reg, solver, singular_x_tol, coeffs,
+                                is_null, pred, resid);
 }
 
 int pds_lr_rcond_f64(pds_ctx* ctx, const double* const* cols, int n_feat, int64_t n_rows, pds_space space,

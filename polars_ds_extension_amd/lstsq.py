@@ -263,6 +263,13 @@ def lin_reg(*x, target, add_bias: bool = False, weights=None, return_pred: bool 
     a null list).  With return_pred=True returns (pred, resid) -- or None when gated (the reference
     returns an all-null struct).
     """
+    if isinstance(target, (list, tuple)):  # multi-target: expr_linear.py:188-228
+        if len(target) == 0:
+            raise ValueError("If `target` is a list, it cannot be empty.")
+        if len(target) == 1:
+            return lin_reg(*x, target=target[0], add_bias=add_bias, weights=weights, return_pred=return_pred, l1_reg=l1_reg,
+                           l2_reg=l2_reg, tol=tol, solver=solver, null_policy=null_policy, singular_x_tol=singular_x_tol, ctx=ctx)
+        return _lin_reg_multi(x, list(target), add_bias, return_pred, l2_reg, solver, singular_x_tol, ctx or default_context())
     if max_iter <= 0:
         raise ValueError("Input `max_iter` must be a positive.")  # expr_linear.py:231-232
     ctx = ctx or default_context()
@@ -287,6 +294,38 @@ def lin_reg(*x, target, add_bias: bool = False, weights=None, return_pred: bool 
     _lib.check(ctx.fn("pds_lr")(ctx._h, cols.cols, cols.weights, cols.n_feat, C.c_int64(cols.n_rows), cols.space,
                                 C.byref(prm), C.c_void_p(coeffs.ctypes.data), C.byref(is_null)))
     return None if is_null.value else coeffs
+
+
+def _lin_reg_multi(x, targets, add_bias, return_pred, l2_reg, solver, singular_x_tol, ctx):
+    """pl_lr_multi / pl_lr_multi_pred: dict with the reference's struct field names (target_i[_pred|_resid])."""
+    k = len(targets)
+    cols = _Cols(targets[0], [*targets[1:], *x])  # C order: [t_0 .. t_{k-1}, x_1 .. x_p]
+    _follow(ctx, cols)
+    if singular_x_tol is None:
+        singular_x_tol = 1e-12 if config.LIN_REG_EXPR_F64 else 1e-6
+    p = len(x)
+    pp = p + int(bool(add_bias))
+    coeffs = np.empty((k, pp), dtype=_dtype())
+    is_null = C.c_int(0)
+    R = C.c_double if config.LIN_REG_EXPR_F64 else C.c_float
+    if return_pred:
+        pred, pr_p = _out_like(cols, (k, cols.n_rows))
+        resid, rs_p = _out_like(cols, (k, cols.n_rows))
+    else:
+        pred = resid = None
+        pr_p = rs_p = C.c_void_p(None)
+    _lib.check(ctx.fn("pds_lr_multi")(ctx._h, cols.cols, k, p, C.c_int64(cols.n_rows), cols.space, int(bool(add_bias)),
+                                      R(l2_reg), _lib.SOLVERS.get(solver, 0), R(singular_x_tol),
+                                      C.c_void_p(coeffs.ctypes.data), C.byref(is_null), pr_p, rs_p))
+    if return_pred:
+        if is_null.value:
+            return None
+        out = {}
+        for i in range(k):
+            out[f"target_{i}_pred"] = pred[i]
+            out[f"target_{i}_resid"] = resid[i]
+        return out
+    return {f"target_{i}": (None if is_null.value else coeffs[i]) for i in range(k)}
 
 
 def lin_reg_w_rcond(*x, target, add_bias: bool = False, rcond: float = 0.0, l2_reg: float = 0.0, ctx: Context | None = None):

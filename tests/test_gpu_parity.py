@@ -545,3 +545,28 @@ def test_literal_skip_null_frame(pds):
     assert list(valid) == [False, True, True, True, True]
     np.testing.assert_allclose(pred[1:], [9.5, 10.5, 11.5, 12.5], atol=1e-10)
     np.testing.assert_allclose(resid[1:], 0.0, atol=1e-10)
+
+
+# ------------------------------------------------------------------------------------------ multi-target
+def test_multi_target(pds, orc):
+    # tests/test_linear_exprs.py:1069-1113 (struct fields target_i == single-target fits, 1e-12) and :376-408 (pred)
+    rng = np.random.default_rng(4)
+    n, p = 30_000, 5
+    X = rng.normal(size=(n, p))
+    Y = np.c_[X @ rng.normal(size=p) + 0.3, X @ rng.normal(size=p) - 1.0, rng.normal(size=n)] + 0.05 * rng.normal(size=(n, 3))
+    for bias, lam in ((False, 0.0), (True, 0.0), (True, 0.2)):
+        out = pds.lin_reg(*cols_of(X), target=[dev(Y[:, i]) for i in range(3)], add_bias=bias, l2_reg=lam)
+        assert list(out) == ["target_0", "target_1", "target_2"]
+        for i in range(3):
+            single = pds.lin_reg(*cols_of(X), target=dev(Y[:, i]), add_bias=bias, l2_reg=lam)
+            assert nrel(out[f"target_{i}"], single) < 1e-11
+            assert nrel(out[f"target_{i}"], orc.pl_lr(X, Y[:, i], add_bias=bias, l2_reg=lam)) < F64_TOL
+    pr = pds.lin_reg(*cols_of(X), target=[dev(Y[:, 0]), dev(Y[:, 1])], add_bias=True, return_pred=True)
+    Xb = np.c_[X, np.ones(n)]
+    for i in range(2):
+        b = orc.pl_lr(X, Y[:, i], add_bias=True)
+        assert nrel(pr[f"target_{i}_pred"].cpu().numpy(), Xb @ b) < F64_TOL
+        assert np.max(np.abs(pr[f"target_{i}_resid"].cpu().numpy() - (Y[:, i] - Xb @ b))) < 1e-10
+    Xc = np.c_[X[:, 0], 2 * X[:, 0], X[:, 1]]
+    out = pds.lin_reg(*cols_of(Xc), target=[dev(Y[:, 0]), dev(Y[:, 1])])
+    assert out["target_0"] is None and out["target_1"] is None  # the gate depends on X only: all targets null
