@@ -123,9 +123,18 @@ def main() -> int:
     alg_bytes = groups_per_launch * bytes_per_group
     avg_ms = gm_ms / max(gm_cnt, 1)
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    # HBM bytes per launch measured offline with rocprofv3 PMC passes (profiles/r01_traffic.json, committed)
+    traffic = None
+    try:
+        tj = json.loads((ROOT / "profiles" / "r01_traffic.json").read_text())["kernels"]
+        key = "pds::grouped_stream_kernel<double, 16, true>" if fused else "pds::grouped_moments_kernel<double>"
+        if key in tj and G == 1_000_000 and R == 100 and P == 16:
+            traffic = int(tj[key]["hbm_bytes_per_launch"])
+    except Exception:
+        traffic = None
     roofline = {
         "bound": "hbm", "kernel": "grouped_stream_kernel<double,16,cholesky> (Gram + solve fused)" if fused else "grouped_moments_kernel<double>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
         "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches_per_step,
         "algorithmic_bytes_per_launch": int(alg_bytes),
         "solve_ms_per_step": round(sv_ms / max(args.steps, 1), 4), "gram_ms_per_step": round(gm_ms / max(args.steps, 1), 4),
