@@ -1,0 +1,104 @@
+"""
+Polars expression builders that route through libpds_lstsq_hip.so's `_polars_plugin_*` symbols.
+
+Same call signatures as /root/reference/python/polars_ds/exprs/expr_linear.py (`lin_reg` :105-274,
+`lin_reg_report` :561-631, `rolling_lin_reg` :482-558, `recursive_lin_reg` :413-479) plus the key-aware
+`lin_reg(..., by=key)` of SURVEY.md 8(b).  Importing this module needs `polars` (>= 1.4), which is NOT installable
+in the build image: the module is exercised only through the plugin ABI tests (tests/test_plugin_abi.py, pyarrow
+standing in for the engine) and is UNVERIFIED against a real Polars until run next to one.
+"""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Any, List
+
+from . import config as cfg
+
+PLUGIN_PATH = Path(__file__).resolve().parent / "csrc" / "libpds_lstsq_hip.so"
+
+
+def _pl():
+    import polars as pl  # deferred: keeps the rest of the package importable without polars
+
+    return pl
+
+
+def _formula(s: Any):
+    pl = _pl()
+    if isinstance(s, str):
+        return pl.sql_expr(s).alias(s)
+    if isinstance(s, pl.Series):
+        return pl.lit(s)
+    if isinstance(s, pl.Expr):
+        return s
+    if hasattr(s, "__array__"):
+        return pl.lit(pl.Series(values=s.__array__()))
+    raise ValueError("Input can only be str or polars expression. The str must be valid SQL strings that polars can understand.")
+
+
+def _plugin(symbol: str, args, kwargs, **flags):
+    from polars.plugins import register_plugin_function
+
+    return register_plugin_function(plugin_path=PLUGIN_PATH, function_name=cfg._which_lin_reg(symbol), args=args, kwargs=kwargs,
+                                    pass_name_to_apply=True, **flags)
+
+
+def _dtype():
+    pl = _pl()
+    return pl.Float64 if cfg.LIN_REG_EXPR_F64 else pl.Float32
+
+
+def lin_reg(*x, target, add_bias: bool = False, weights=None, return_pred: bool = False, l1_reg: float = 0.0,
+            l2_reg: float = 0.0, tol: float = 1e-5, solver: str = "qr", max_iter: int = 200, null_policy: str = "skip",
+            positive: bool = False, singular_x_tol: float | None = None, by=None):
+    if isinstance(target, list):
+        raise NotImplementedError("multi-target lin_reg goes through polars_ds_extension_amd.lstsq.lin_reg for now")
+    if max_iter <= 0:
+        raise ValueError("Input `max_iter` must be a positive.")
+    if singular_x_tol is None:
+        singular_x_tol = 1e-12 if cfg.LIN_REG_EXPR_F64 else 1e-6
+    weighted = weights is not None
+    kwargs = {"bias": add_bias, "null_policy": null_policy, "l1_reg": l1_reg, "l2_reg": l2_reg, "solver": solver, "tol": tol,
+              "max_iter": max_iter, "weighted": weighted, "positive": positive, "singular_x_tol": singular_x_tol}
+    dt = _dtype()
+    cols = ([_formula(weights).cast(dt).rechunk()] if weighted else []) + [_formula(target).cast(dt)] + [_formula(z) for z in x]
+    if by is not None:  # one call computes every group: Struct{key, coeffs}, one row per (contiguous) group
+        if weighted or return_pred:
+            raise ValueError("`by` supports coefficient output of unweighted fits")
+        return _plugin("pl_lr_by", [_formula(by), *cols], kwargs, changes_length=True).alias("coeffs_by")
+    if return_pred:
+        return _plugin("pl_lr_pred", cols, kwargs).alias("lr_pred")
+    return _plugin("pl_lr", cols, kwargs, returns_scalar=True).alias("coeffs")
+
+
+def lin_reg_report(*x, target, add_bias: bool = False, weights=None, std_err: str = "se", null_policy: str = "raise"):
+    dt = _dtype()
+    t = _formula(target).cast(dt)
+    kwargs = {"bias": add_bias, "null_policy": null_policy, "std_err": std_err, "solver": "qr", "l1_reg": 0.0, "l2_reg": 0.0, "tol": 0.0}
+    feats: List[Any] = [_formula(z) for z in x]
+    if weights is None:
+        return _plugin("pl_lin_reg_report", [t.var(), t, *feats], kwargs, changes_length=True).alias("lin_reg_report")
+    return _plugin("pl_wls_report", [_formula(weights).cast(dt).rechunk(), t.var(), t, *feats], kwargs,
+                   changes_length=True).alias("lin_reg_report")
+
+
+def rolling_lin_reg(*x, target, window_size: int, add_bias: bool = False, l2_reg: float = 0.0, min_valid_rows: int | None = None,
+                    null_policy: str = "raise"):
+    n_features = len(x) + int(add_bias)
+    if window_size < 2:
+        raise ValueError("`window_size` must be >= 2.")
+    if n_features > window_size:
+        raise ValueError("# features > window size. Linear regression is not well-defined.")
+    min_size = min(n_features, window_size) if min_valid_rows is None else int(min_valid_rows)
+    kwargs = {"null_policy": null_policy, "n": window_size, "bias": add_bias, "lambda": abs(l2_reg), "min_size": min_size}
+    cols = [_formula(target).cast(_dtype())] + [_formula(z) for z in x]
+    return _plugin("pl_rolling_lr", cols, kwargs).alias("rolling_lin_reg")
+
+
+def recursive_lin_reg(*x, target, start_with: int, add_bias: bool = False, l2_reg: float = 0.0, null_policy: str = "raise"):
+    n_features = len(x) + int(add_bias)
+    if start_with < n_features:
+        raise ValueError("# features > number of rows for the initial fit.")
+    kwargs = {"null_policy": null_policy, "n": start_with, "bias": add_bias, "lambda": abs(l2_reg), "min_size": 0}
+    cols = [_formula(target).cast(_dtype())] + [_formula(z) for z in x]
+    return _plugin("pl_recursive_lr", cols, kwargs).alias("recursive_lin_reg")

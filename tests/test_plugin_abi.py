@@ -1,0 +1,191 @@
+"""
+The Polars plugin C ABI layer (csrc/plugin.cpp): pyarrow + ctypes play the engine (tests/plugin_harness.py).
+CPU tests: symbol table, version, pickled-kwargs parser against real `pickle.dumps(..., protocol=5)` of the
+reference's kwargs dicts, output-field functions.  GPU tests: Series in -> Series out through `_polars_plugin_*`,
+compared with the oracle and with the reference's literal frames.
+"""
+import ctypes as C
+import pickle
+import sys
+from pathlib import Path
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "tests"))
+import plugin_harness as ph  # noqa: E402
+
+SYMBOLS = ["pl_lr", "pl_lr_pred", "pl_lin_reg_report", "pl_wls_report", "pl_rolling_lr", "pl_recursive_lr", "pl_lr_by"]
+
+
+@pytest.fixture(scope="module")
+def so():
+    sys.path.insert(0, str(ROOT))
+    from polars_ds_extension_amd import _build, _lib
+
+    if not _lib.LIB_PATH.exists():
+        _build.build()
+    return _lib.load()
+
+
+def test_plugin_symbols_and_version(so):
+    for s in SYMBOLS:
+        for suffix in ("", "_f32"):
+            assert hasattr(so, f"_polars_plugin_{s}{suffix}") and hasattr(so, f"_polars_plugin_field_{s}{suffix}")
+    so._polars_plugin_get_version.restype = C.c_uint32
+    assert so._polars_plugin_get_version() == 1  # (major 0 << 16) | minor 1
+    so._polars_plugin_get_last_error_message.restype = C.c_char_p
+    assert isinstance(so._polars_plugin_get_last_error_message(), bytes)
+
+
+def test_kwargs_pickle_parser(so):
+    # the exact dicts python/polars_ds/exprs/expr_linear.py builds (:237-248, :546-552)
+    lr_kwargs = {"bias": True, "null_policy": "skip", "l1_reg": 0.0, "l2_reg": 0.25, "solver": "qr", "tol": 1e-5,
+                 "max_iter": 200, "weighted": False, "positive": False, "singular_x_tol": 1e-12}
+    sww = {"null_policy": "0.5", "n": 256, "bias": False, "lambda": 0.1, "min_size": 70000}
+    for d in (lr_kwargs, sww, {"n": -3, "big": 2**40, "s": "x" * 300, "f": -1.5e300}):
+        raw = pickle.dumps(d, protocol=5)
+        buf = (C.c_uint8 * len(raw)).from_buffer_copy(raw)
+        out = C.create_string_buffer(4096)
+        assert so.pds_plugin_debug_parse_kwargs(buf, len(raw), out, 4096) == 0
+        got = dict(item.split("=", 1) for item in out.value.decode().strip(";").split(";"))
+        for k, v in d.items():
+            if isinstance(v, bool):
+                assert got[k] == ("true" if v else "false")
+            elif isinstance(v, int):
+                assert int(got[k]) == v
+            elif isinstance(v, float):
+                assert float(got[k]) == v
+            else:
+                assert got[k] == f"'{v}'"
+
+
+def test_output_fields(so):
+    f = ph.output_field(so, "pl_lr")
+    assert f.name == "coeffs" and f.type == pa.large_list(pa.field("item", pa.float64()))
+    assert ph.output_field(so, "pl_lr_f32").type == pa.large_list(pa.field("item", pa.float32()))
+    f = ph.output_field(so, "pl_lr_pred")
+    assert [c.name for c in f.type] == ["pred", "resid"]
+    f = ph.output_field(so, "pl_lin_reg_report")
+    assert f.name == "lin_reg_report" and [c.name for c in f.type] == ["features", "beta", "std_err", "t", "p>|t|", "0.025", "0.975", "r2", "adj_r2"]
+    f = ph.output_field(so, "pl_rolling_lr")
+    assert [c.name for c in f.type] == ["coeffs", "pred"]
+
+
+# ---------------------------------------------------------------------------------------------------- GPU
+LR = {"bias": False, "null_policy": "skip", "l1_reg": 0.0, "l2_reg": 0.0, "solver": "qr", "tol": 1e-5, "max_iter": 200,
+      "weighted": False, "positive": False, "singular_x_tol": 1e-12}
+
+
+def _cols(X, y, names=None):
+    names = names or [f"x{j + 1}" for j in range(X.shape[1])]
+    return [("y", pa.array(y))] + [(nm, pa.array(np.ascontiguousarray(X[:, j]))) for j, nm in enumerate(names)]
+
+
+@pytest.mark.gpu
+def test_pl_lr_series_in_series_out(so, orc):
+    rng = np.random.default_rng(208)
+    X = rng.random((100_000, 4))
+    y = X @ [0.5, 0.25, -0.15, 0.2] + 1e-4 * rng.random(100_000)  # BASELINE configs[0]
+    field, out = ph.call_plugin(so, "pl_lr", _cols(X, y), LR)
+    assert field.name == "coeffs" and len(out) == 1
+    b = np.array(out[0].as_py())
+    ref = orc.pl_lr(X, y)
+    assert np.linalg.norm(b - ref) / np.linalg.norm(ref) < 1e-10
+    # multi-chunk + int column (cast like series_to_slice_inner) + bias + ridge
+    xi = rng.integers(0, 10, size=100_000)
+    ins = [("y", pa.chunked_array([pa.array(y[:30_000]), pa.array(y[30_000:])])), ("xi", pa.array(xi)), ("x2", pa.array(X[:, 1]))]
+    _, out = ph.call_plugin(so, "pl_lr", ins, dict(LR, bias=True, l2_reg=0.1))
+    ref = orc.pl_lr(np.c_[xi.astype(float), X[:, 1]], y, add_bias=True, l2_reg=0.1)
+    assert np.linalg.norm(np.array(out[0].as_py()) - ref) / np.linalg.norm(ref) < 1e-10
+    # collinear -> the gate returns a 1-row null list
+    _, out = ph.call_plugin(so, "pl_lr", [("y", pa.array(y)), ("a", pa.array(X[:, 0])), ("b", pa.array(2 * X[:, 0]))], LR)
+    assert len(out) == 1 and out[0].as_py() is None
+    # f32 twin
+    _, out = ph.call_plugin(so, "pl_lr_f32", _cols(X.astype(np.float32), y.astype(np.float32)), dict(LR, singular_x_tol=1e-6))
+    assert out.type == pa.large_list(pa.field("item", pa.float32()))
+    assert np.allclose(out[0].as_py(), [0.5, 0.25, -0.15, 0.2], atol=1e-3)
+    # errors keep the reference's strings
+    with pytest.raises(ph.PluginFailure, match="#Data < #features"):
+        ph.call_plugin(so, "pl_lr", _cols(X[:2], y[:2]), LR)
+    with pytest.raises(ph.PluginFailure, match="Invalid NullPolicy"):
+        ph.call_plugin(so, "pl_lr", _cols(X, y), dict(LR, null_policy="bogus"))
+
+
+@pytest.mark.gpu
+def test_pl_lr_pred_literal_skip_null_frame(so):
+    # tests/test_linear_exprs.py:411-432
+    ins = [("y", pa.array([8.5, 9.5, 10.5, 11.5, 12.5])), ("x", pa.array([None, 2.0, 3.0, 4.0, 5.0]))]
+    field, out = ph.call_plugin(so, "pl_lr_pred", ins, dict(LR, bias=True))
+    rows = out.to_pylist()
+    assert rows[0] == {"pred": None, "resid": None}
+    np.testing.assert_allclose([r["pred"] for r in rows[1:]], [9.5, 10.5, 11.5, 12.5], atol=1e-10)
+    np.testing.assert_allclose([r["resid"] for r in rows[1:]], 0.0, atol=1e-10)
+    with pytest.raises(ph.PluginFailure, match="Nulls found in data"):
+        ph.call_plugin(so, "pl_lr_pred", ins, dict(LR, bias=True, null_policy="raise"))
+
+
+@pytest.mark.gpu
+def test_pl_lin_reg_report_struct(so, orc):
+    rng = np.random.default_rng(2)
+    n = 20_000
+    X = rng.normal(size=(n, 3))
+    y = X @ [0.5, 0.0, -1.0] + 2.0 + rng.normal(size=n)
+    ins = [("y_var", pa.array([float(np.var(y, ddof=1))])), ("y", pa.array(y))] + [(nm, pa.array(X[:, j])) for j, nm in enumerate(["a", "b", "c"])]
+    field, out = ph.call_plugin(so, "pl_lin_reg_report", ins, dict(LR, bias=True, std_err="hc1", null_policy="raise"))
+    t = pa.Table.from_struct_array(out) if hasattr(pa.Table, "from_struct_array") else pa.Table.from_batches([pa.RecordBatch.from_struct_array(out)])
+    assert t.column_names == ["features", "beta", "hc1_se", "t", "p>|t|", "0.025", "0.975", "r2", "adj_r2"]
+    assert t["features"].to_pylist() == ["a", "b", "c", "__bias__"]
+    ro = orc.lin_reg_report(np.c_[X, np.ones(n)], y, std_err="hc1")
+    np.testing.assert_allclose(t["beta"].to_numpy(), ro["beta"], rtol=1e-10)
+    np.testing.assert_allclose(t["hc1_se"].to_numpy(), ro["std_err"], rtol=1e-10)
+    np.testing.assert_allclose(t["p>|t|"].to_numpy(), ro["p"], rtol=1e-8, atol=1e-300)
+    assert len(set(t["r2"].to_pylist())) == 1 and abs(t["r2"][0].as_py() - ro["r2"]) < 1e-12
+
+
+@pytest.mark.gpu
+def test_pl_rolling_and_recursive_struct(so, orc, golden):
+    rows = golden["rolling_w5_head"]
+    ins = [("y", pa.array([r["y"] for r in rows])), ("x1", pa.array([r["x1"] for r in rows])), ("x2", pa.array([r["x2"] for r in rows]))]
+    kw = {"null_policy": "zero", "n": 5, "bias": False, "lambda": 0.0, "min_size": 2}  # the notebook's call
+    _, out = ph.call_plugin(so, "pl_rolling_lr", ins, kw)
+    res = out.to_pylist()
+    assert all(r == {"coeffs": None, "pred": None} for r in res[:4])
+    np.testing.assert_allclose(res[4]["coeffs"], rows[4]["coeffs"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(res[4]["pred"], rows[4]["pred"], rtol=2e-5, atol=2e-6)
+    rng = np.random.default_rng(5)
+    X = rng.random((3000, 2))
+    y = X @ [1.0, -1.0] + 0.01 * rng.random(3000)
+    _, out = ph.call_plugin(so, "pl_recursive_lr", _cols(X, y), {"null_policy": "raise", "n": 4, "bias": True, "lambda": 0.0, "min_size": 0})
+    res = out.to_pylist()
+    ref = orc.recursive_lr(np.c_[X, np.ones(3000)], y, 4)
+    assert res[2]["coeffs"] is None and res[3]["coeffs"] is not None
+    np.testing.assert_allclose(res[-1]["coeffs"], ref[-1], rtol=1e-8)
+    # rolling with nulls under "skip": rows holding a null leave the window, short windows are null (:858-908)
+    xn = X[:, 0].copy()
+    mask = rng.random(3000) < 0.1
+    ins = [("y", pa.array(y)), ("x1", pa.array(xn, mask=mask)), ("x2", pa.array(X[:, 1]))]
+    _, out = ph.call_plugin(so, "pl_rolling_lr", ins, {"null_policy": "skip", "n": 8, "bias": False, "lambda": 0.0, "min_size": 6})
+    Xn = np.c_[np.where(mask, np.nan, xn), X[:, 1]]
+    ref, valid = orc.rolling_skipping_lr(Xn, y, 8, 6)
+    got_valid = np.array([r["coeffs"] is not None for r in out.to_pylist()])
+    assert np.array_equal(got_valid[7:], valid) and not got_valid[:7].any()
+
+
+@pytest.mark.gpu
+def test_pl_lr_by_matches_per_group_calls(so, orc):
+    # tests/test_linear_exprs.py:918-953: the batched path == one pl_lr call per group
+    rng = np.random.default_rng(0)
+    G, per = 200, 25
+    key = np.repeat(np.arange(G) * 3 + 7, per)
+    X = rng.normal(size=(G * per, 2))
+    y = X @ [1.5, -0.5] + rng.normal(size=G * per)
+    field, out = ph.call_plugin(so, "pl_lr_by", [("key", pa.array(key))] + _cols(X, y), LR)
+    res = out.to_pylist()
+    assert len(res) == G and res[0]["key"] == 7 and res[-1]["key"] == (G - 1) * 3 + 7
+    for g in (0, 17, G - 1):
+        s = slice(g * per, (g + 1) * per)
+        _, single = ph.call_plugin(so, "pl_lr", _cols(X[s], y[s]), LR)
+        np.testing.assert_allclose(res[g]["coeffs"], single[0].as_py(), rtol=1e-10, atol=1e-12)
