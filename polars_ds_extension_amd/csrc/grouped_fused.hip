@@ -27,7 +27,9 @@ constexpr int kFTile = 17 * kColStride;  // 16 feature slots + y
 constexpr int kFWaveLds = kFTile + kFM * 8;
 
 // consume rows [rel0, rel1) of the tile (relative row indices, 0 <= rel0 < rel1 <= TR) into `a`
-template <typename T>
+// BIAS = false drops the column sums / sum y (only the bias row of the normal equations needs them); y'y is never
+// needed by the solve.  These side sums are VALU work per 4-row step, and the fused kernel is VALU-issue bound.
+template <typename T, bool BIAS>
 __device__ __forceinline__ void consume_range(const char* wl, int lane, int rel0, int rel1, WaveAcc& a) {
     const int f = lane & 15, q = lane >> 4;
     const T* xcol = reinterpret_cast<const T*>(wl + f * kColStride) + q;
@@ -49,14 +51,16 @@ __device__ __forceinline__ void consume_range(const char* wl, int lane, int rel0
         acc = Tile<T>::mfma(x, x, acc);
         if constexpr (sizeof(T) == 8) {
             xy = fma(x, yv, xy);
-            cs += x;
-            yy = fma(yv, yv, yy);
-            ys += yv;
+            if constexpr (BIAS) {
+                cs += x;
+                ys += yv;
+            }
         } else {
             fxy = fmaf(x, yv, fxy);
-            fcs += x;
-            fyy = fmaf(yv, yv, fyy);
-            fys += yv;
+            if constexpr (BIAS) {
+                fcs += x;
+                fys += yv;
+            }
         }
     };
     auto step = [&](int s, bool masked, int lo, int hi) __attribute__((always_inline)) {
@@ -70,14 +74,16 @@ __device__ __forceinline__ void consume_range(const char* wl, int lane, int rel0
         acc = Tile<T>::mfma(x, x, acc);
         if constexpr (sizeof(T) == 8) {
             xy = fma(x, yv, xy);
-            cs += x;
-            yy = fma(yv, yv, yy);
-            ys += yv;
+            if constexpr (BIAS) {
+                cs += x;
+                ys += yv;
+            }
         } else {
             fxy = fmaf(x, yv, fxy);
-            fcs += x;
-            fyy = fmaf(yv, yv, fyy);
-            fys += yv;
+            if constexpr (BIAS) {
+                fcs += x;
+                fys += yv;
+            }
         }
     };
     // head: a first step that starts inside a 4-row group
@@ -90,19 +96,19 @@ __device__ __forceinline__ void consume_range(const char* wl, int lane, int rel0
     // body: whole steps
     const int sfull = rel1 >> 2;  // steps [s0, sfull) are complete
     // (software pipelined like consume_tile: operands of step s+2 are in flight while step s multiplies)
-    if (s0 < sfull) {
-        T xn0 = xcol[4 * s0], yn0 = ycol[4 * s0];
-        T xn1 = xcol[4 * s0 + 4], yn1 = ycol[4 * s0 + 4];
-#pragma unroll 4
-        for (int s = s0; s < sfull; ++s) {
-            const T x = xn0, yv = yn0;
-            xn0 = xn1;
-            yn0 = yn1;
-            xn1 = xcol[4 * s + 8];
-            yn1 = ycol[4 * s + 8];
-            step_v(x, yv);
-        }
+    // four steps per iteration: eight independent LDS reads first, then four back-to-back matrix instructions, so
+    // the ds_read latency is paid once per 16 rows (left as a 1-step loop the compiler put a full lgkmcnt wait in
+    // front of every MFMA)
+    int s = s0;
+    for (; s + 4 <= sfull; s += 4) {
+        const T x0 = xcol[4 * s], x1 = xcol[4 * s + 4], x2 = xcol[4 * s + 8], x3 = xcol[4 * s + 12];
+        const T y0 = ycol[4 * s], y1 = ycol[4 * s + 4], y2 = ycol[4 * s + 8], y3 = ycol[4 * s + 12];
+        step_v(x0, y0);
+        step_v(x1, y1);
+        step_v(x2, y2);
+        step_v(x3, y3);
     }
+    for (; s < sfull; ++s) step_v(xcol[4 * s], ycol[4 * s]);
     // tail: a last step that ends inside a 4-row group (and was not already the head step)
     if ((rel1 & 3) && sfull >= s0 && sfull < s1) step(sfull, true, 0, rel1 & 3);
     if constexpr (sizeof(T) == 8) {
@@ -124,7 +130,7 @@ __device__ __forceinline__ int64_t lower_bound_i64(const int64_t* __restrict__ a
     return lo;
 }
 
-template <typename T, int LPS, bool CHOL>
+template <typename T, int LPS, bool CHOL, bool BIAS>
 __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __restrict__ cols, int p,
                                                             const int64_t* __restrict__ offsets, int64_t n_groups,
                                                             int64_t n_rows, SolveRegDev sp, T* __restrict__ coeffs,
@@ -138,9 +144,7 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
     char* wl = smem;
     double* Msc = reinterpret_cast<double*>(smem + kFTile);
     const int pp = sp.pp;
-    const int sub = lane / LPS, j = lane % LPS;
-    const bool colv = j < pp;
-    const int lj = (j < p) ? j : 16;
+    const int sub = lane / LPS, j_in = lane % LPS;
 
     // ---- this wave's groups: balanced in rows
     const int64_t W = gridDim.x, w = blockIdx.x;
@@ -167,6 +171,11 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
     int64_t gbase = gl;  // group id of pending system 0
 
     auto solve_pending = [&]() __attribute__((always_inline)) {
+        // the solver compares the lane index against 16 constants; hiding it behind an empty asm makes the compiler
+        // rebuild those lane masks here instead of keeping 30+ SGPR pairs alive (and spilled) across the whole kernel
+        int j = j_in;
+        asm volatile("" : "+v"(j));
+        const bool colv = j < pp;
         const int64_t sys = gbase + sub;
         const bool live = sub < npend;
         bool is_null = null_p;
@@ -186,31 +195,43 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
     WaveAcc acc;
     zero_acc(acc);
     int64_t g = gl;
+    // group bounds are carried, not re-loaded: gs = start of group g, ge = its end, ge_next = end of group g+1
+    // (fetched one group ahead, so the dependent global load sits under a whole group of work instead of in
+    // front of every boundary decision)
+    int64_t gs = rlo;
     int64_t ge = offsets[g + 1];
+    int64_t ge_next = offsets[(g + 2 <= n_groups) ? g + 2 : n_groups];
     int64_t pos = rlo;
 
     auto flush_group = [&]() __attribute__((always_inline)) {
         // ---- normal equations of group g -> LDS scratch (full symmetric square, bias at 16, y at 17)
-        const int64_t ng = ge - offsets[g];
+        const int64_t ng = ge - gs;
         {
             const int jj = lane & 15;
 #pragma unroll
             for (int r = 0; r < 4; ++r) Msc[Tile<T>::drow(lane, r) + kFQ * jj] = acc.d[r];
-            const double xy = xor_sum_q(acc.xy), cs = xor_sum_q(acc.cs), ys = xor_sum_q(acc.ys);
-            if (lane < 16) {
-                Msc[lane + kFQ * 17] = xy;
-                Msc[lane + kFQ * 16] = cs;
-                Msc[16 + kFQ * lane] = cs;
-            }
-            if (lane == 0) {
-                Msc[16 + kFQ * 16] = (double)ng;
-                Msc[16 + kFQ * 17] = ys;
+            const double xy = xor_sum_q(acc.xy);
+            if (lane < 16) Msc[lane + kFQ * 17] = xy;
+            if constexpr (BIAS) {
+                const double cs = xor_sum_q(acc.cs), ys = xor_sum_q(acc.ys);
+                if (lane < 16) {
+                    Msc[lane + kFQ * 16] = cs;
+                    Msc[16 + kFQ * lane] = cs;
+                }
+                if (lane == 0) {
+                    Msc[16 + kFQ * 16] = (double)ng;
+                    Msc[16 + kFQ * 17] = ys;
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // ---- sub-group `npend` takes it into registers (solver layout: lane j = column j)
         {
+            int j = j_in;
+            asm volatile("" : "+v"(j));
+            const bool colv = j < pp;
+            const int lj = (j < p) ? j : 16;
             const bool mine = sub == npend;
             double dj = colv ? Msc[lj + kFQ * lj] : 1.0;
             const bool lam = sp.lambda > 0.0 && colv && (j < p || sp.lambda_on_bias);
@@ -257,6 +278,8 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
         if ((t + 1) * TR <= n_rows) load_full_tile<T, false>(cp, p, row, regs);
         else load_tail_tile<T, false>(cp, p, row, n_rows, regs);
     };
+    // (A flat state machine with flush / solve instantiated once each was tried: 4.7k instead of 10.9k static
+    //  instructions but 255 live VGPRs and 8 % slower than this nested form at 219.)
     if (t_first <= t_last) load_tile(t_first);
     for (int64_t t = t_first; t <= t_last; ++t) {
         store_tile_lds<T, false>(wl, p, lane, regs);
@@ -267,11 +290,13 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
             if (ge <= pos) {  // group complete (or empty)
                 flush_group();
                 ++g;
-                if (g < gh) ge = offsets[g + 1];
+                gs = ge;
+                ge = ge_next;
+                ge_next = offsets[(g + 2 <= n_groups) ? g + 2 : n_groups];
                 continue;
             }
             const int64_t seg_end = (ge < tile_end) ? ge : tile_end;
-            consume_range<T>(wl, lane, (int)(pos - row0), (int)(seg_end - row0), acc);
+            consume_range<T, BIAS>(wl, lane, (int)(pos - row0), (int)(seg_end - row0), acc);
             pos = seg_end;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -281,7 +306,9 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
     while (g < gh) {
         flush_group();
         ++g;
-        if (g < gh) ge = offsets[g + 1];
+        gs = ge;
+        ge = ge_next;
+        ge_next = offsets[(g + 2 <= n_groups) ? g + 2 : n_groups];
     }
     if (npend > 0) solve_pending();
 }
@@ -294,11 +321,14 @@ static int launch_stream_lps(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, 
     const int per_cu = std::max(1, (int)((160 * 1024) / lds));
     int64_t nb = std::min<int64_t>(std::max<int64_t>(n_groups / (64 / LPS), 1), (int64_t)ctx->num_cus * per_cu);
     KernelTimer timer(ctx, kKindGroupedMoments);
-    if (chol)
-        hipLaunchKernelGGL((grouped_stream_kernel<T, LPS, true>), dim3((unsigned)nb), dim3(64), lds, ctx->stream, dc.d_ptrs,
+    // (the pivoted-QR variant of this kernel measured slower than the two-kernel pipeline and is not instantiated;
+    //  callers route the ungated case to grouped_moments_kernel + solve_reg_kernel)
+    if (!chol) return fail(PDS_ERR_INVALID, "internal: fused grouped kernel is Cholesky-only");
+    if (sd.bias)
+        hipLaunchKernelGGL((grouped_stream_kernel<T, LPS, true, true>), dim3((unsigned)nb), dim3(64), lds, ctx->stream, dc.d_ptrs,
                            n_feat, d_offsets, n_groups, n_rows, sd, d_coeffs, d_flags);
     else
-        hipLaunchKernelGGL((grouped_stream_kernel<T, LPS, false>), dim3((unsigned)nb), dim3(64), lds, ctx->stream, dc.d_ptrs,
+        hipLaunchKernelGGL((grouped_stream_kernel<T, LPS, true, false>), dim3((unsigned)nb), dim3(64), lds, ctx->stream, dc.d_ptrs,
                            n_feat, d_offsets, n_groups, n_rows, sd, d_coeffs, d_flags);
     PDS_HIP_CHECK(hipGetLastError());
     return PDS_OK;

@@ -251,15 +251,18 @@ __device__ __forceinline__ void chol_step(double (&a)[LPS + 1], int j, int pp, d
                                           bool& ok) {
     const double d = Grp<LPS>::template bcast<K>(a[K]);
     ok = ok && (d > 0.0);
-    const double r = 1.0 / sqrt(d);
-    const double t = a[K] * r * r;  // l_jK / l_KK
-    // DPP reads from EXEC-disabled lanes are invalid, so the broadcasts run with every lane active and the
-    // update is a select (lanes <= K keep their finished columns: their a[i], i > K, are the unscaled l_iK)
+    // 1/sqrt(d): hardware estimate (v_rsq_f64) + two Newton steps -- a third of the instructions of sqrt + divide,
+    // accurate to an ulp or two, which is all the elimination multipliers need (and fails the same way for d <= 0)
+    double r = __builtin_amdgcn_rsq(d);
+    r = r * fma(-0.5 * d * r, r, 1.5);
+    r = r * fma(-0.5 * d * r, r, 1.5);
+    // lanes <= K keep their finished columns (their a[i], i > K, are the unscaled l_iK): a zero multiplier instead
+    // of a select per element.  DPP reads from EXEC-disabled lanes are invalid, so every lane takes part.
+    const double t = (j > K) ? a[K] * r * r : 0.0;  // l_jK / l_KK
 #pragma unroll
     for (int i = K + 1; i <= LPS; ++i) {
         const double v = Grp<LPS>::template bcast<K>(a[i]);
-        const double nv = fma(-v, t, a[i]);
-        a[i] = (j > K) ? nv : a[i];
+        a[i] = fma(-v, t, a[i]);
     }
     if (j == K) {
         rinv_j = r;
