@@ -10,6 +10,17 @@
 
 #include "../../include/pds_lstsq.h"
 
+// Wave-private LDS hand-off (one lane writes, another lane of the SAME wave reads): LDS operations of a wave
+// execute in issue order, so all that is needed is (a) the compiler not moving LDS accesses across this point and
+// (b) outstanding LDS traffic drained.  A `fence(acq_rel, "wavefront")` also works but makes the compiler wait for
+// EVERY outstanding memory operation (vmcnt(0)) -- which silently serialised the register prefetch of the next tile
+// behind every LDS hand-off in the streaming kernels.
+#define PDS_WAVE_LDS_SYNC()                                   \
+    do {                                                      \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+        __builtin_amdgcn_wave_barrier();                      \
+    } while (0)
+
 namespace pds {
 
 // ---------------------------------------------------------------------------------------------

@@ -224,8 +224,7 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
                 }
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        PDS_WAVE_LDS_SYNC();
         // ---- sub-group `npend` takes it into registers (solver layout: lane j = column j)
         {
             int j = j_in;
@@ -256,8 +255,7 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
                 null_p = ng < pp;  // per-group pl_lr raises "#Data < #features": reported as null
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        PDS_WAVE_LDS_SYNC();
         zero_acc(acc);
         ++npend;
         if (npend == SPW) solve_pending();
@@ -299,8 +297,7 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
             consume_range<T, BIAS>(wl, lane, (int)(pos - row0), (int)(seg_end - row0), acc);
             pos = seg_end;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        PDS_WAVE_LDS_SYNC();
     }
     // groups that end exactly at rhi (and trailing empty groups)
     while (g < gh) {

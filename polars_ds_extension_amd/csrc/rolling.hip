@@ -23,11 +23,7 @@
 
 namespace pds {
 
-#define RSYNC()                                                  \
-    do {                                                         \
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   \
-        __builtin_amdgcn_wave_barrier();                         \
-    } while (0)
+#define RSYNC() PDS_WAVE_LDS_SYNC()
 
 constexpr int kTileRows = 4096;   // rows per wave tile (64 steps of 64 rows)
 constexpr int kRollWaves = 2;     // waves per block
@@ -48,25 +44,29 @@ struct RollArgs {
     int64_t tile_rows;
 };
 
-// z (PP entries, padded with zeros) and y of row r; returns false (and zeros) when r is out of range or
-// the row holds a non-finite value
+// fetch_row: raw z (PP entries, padding = 0, bias entry = 1) and y of row r (zeros when r is out of range) -- only
+// issues the loads, so the next step's rows can be in flight while the current step is scanned and solved;
+// finish_row: the finiteness rule (a non-finite row is left out, OnlineLR::update lr_online_solvers.rs:85-89).
 template <typename T, int PP>
-__device__ __forceinline__ bool load_row(const T* const* __restrict__ cols, const RollArgs& ra, int64_t r,
-                                         double (&z)[PP], double& yv) {
-    bool ok = r >= 0 && r < ra.n;
+__device__ __forceinline__ bool fetch_row(const T* const* __restrict__ cols, const RollArgs& ra, int64_t r,
+                                          double (&z)[PP], double& yv) {
+    const bool in = r >= 0 && r < ra.n;
 #pragma unroll
     for (int a = 0; a < PP; ++a) {
         double v = 0.0;
-        if (a < ra.p) v = ok ? (double)cols[a][r] : 0.0;
+        if (a < ra.p) v = in ? (double)cols[a][r] : 0.0;
         else if (a == ra.p && ra.bias) v = 1.0;
         z[a] = v;
     }
-    yv = ok ? (double)cols[ra.p][r] : 0.0;
+    yv = in ? (double)cols[ra.p][r] : 0.0;
+    return in;
+}
+template <int PP>
+__device__ __forceinline__ bool finish_row(bool in, const double (&z)[PP], double yv) {
     bool fin = isfinite(yv);
 #pragma unroll
     for (int a = 0; a < PP; ++a) fin = fin && isfinite(z[a]);
-    ok = ok && fin;
-    return ok;
+    return in && fin;
 }
 
 template <typename T, int PP>
@@ -92,16 +92,34 @@ __global__ __launch_bounds__(kRollWaves * 64) void rolling_kernel(const T* const
         } else if (ra.mode == 2) {
             if (lane < NV) W = tile_tot[t * NV + lane];  // exclusive prefix over the previous tiles
         }
+        // rows of the first step
+        double nn[PP], no[PP], nyn, nyo = 0.0;
+        bool nin_n = fetch_row<T, PP>(cols, ra, r_begin + lane, nn, nyn), nin_o = false;
+        if (ra.mode == 0 && r_begin >= t0) nin_o = fetch_row<T, PP>(cols, ra, r_begin + lane - w, no, nyo);
         for (int64_t base = r_begin; base < t1; base += 64) {
             const bool warm = base < t0;
             const int64_t r = base + lane;
             // ---------------- phase A
-            double zn[PP], zo[PP], yn, yo;
-            bool okn = load_row<T, PP>(cols, ra, r, zn, yn);
+            double zn[PP], zo[PP], yn = nyn, yo = nyo;
+#pragma unroll
+            for (int a = 0; a < PP; ++a) {
+                zn[a] = nn[a];
+                zo[a] = no[a];
+            }
+            bool okn = finish_row<PP>(nin_n, zn, yn);
             if (warm) okn = okn && (r >= t0 - w);          // only the w rows in front of the tile
             else okn = okn && (r < t1);
             bool oko = false;
-            if (ra.mode == 0 && !warm) oko = load_row<T, PP>(cols, ra, r - w, zo, yo) && (r < t1);
+            if (ra.mode == 0 && !warm) oko = finish_row<PP>(nin_o, zo, yo) && (r < t1);
+            // next step's rows go in flight now; they are consumed after this step's scan and solve
+            {
+                const int64_t nb = base + 64;
+                if (nb < t1) {
+                    nin_n = fetch_row<T, PP>(cols, ra, nb + lane, nn, nyn);
+                    nin_o = false;
+                    if (ra.mode == 0 && nb >= t0) nin_o = fetch_row<T, PP>(cols, ra, nb + lane - w, no, nyo);
+                }
+            }
             if (!okn) {
 #pragma unroll
                 for (int a = 0; a < PP; ++a) zn[a] = 0.0;
@@ -128,11 +146,21 @@ __global__ __launch_bounds__(kRollWaves * 64) void rolling_kernel(const T* const
             RSYNC();
             // ---------------- phase B: lane v scans its moment over the 64 rows of this step
             if (lane < NV) {
+                // 16 independent LDS reads, 16 dependent adds, 16 writes per batch (a read-add-write loop would put
+                // an LDS round trip into every one of the 64 links of the chain)
                 double* row = D + lane * kLdsStride;
-#pragma unroll 8
-                for (int i = 0; i < 64; ++i) {
-                    W += row[i];
-                    row[i] = W;
+#pragma unroll
+                for (int i0 = 0; i0 < 64; i0 += 16) {
+                    double v[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) v[i] = row[i0 + i];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        W += v[i];
+                        v[i] = W;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) row[i0 + i] = v[i];
                 }
             }
             RSYNC();
@@ -161,13 +189,17 @@ __global__ __launch_bounds__(kRollWaves * 64) void rolling_kernel(const T* const
                 // Cholesky G = L L' in place (packed upper storage read as lower by symmetry):
                 // idx(a,b), a <= b  ->  a*PP - a(a-1)/2 + (b-a)
                 bool okc = true;
+                double ri[PP];  // 1 / l_kk: hardware rsqrt estimate + two Newton steps; the substitutions multiply by it
+                                // (sqrt + 24 divisions per row were ~3/4 of this kernel's VALU instructions)
 #define GI(a, b) g[(a) * PP - ((a) * ((a)-1)) / 2 + ((b) - (a))]
 #pragma unroll
                 for (int k = 0; k < PP; ++k) {
-                    double d = GI(k, k);
+                    const double d = GI(k, k);
                     okc = okc && (d > 0.0);
-                    const double inv = 1.0 / sqrt(d);
-                    GI(k, k) = d * inv;  // l_kk
+                    double inv = __builtin_amdgcn_rsq(d);
+                    inv = inv * fma(-0.5 * d * inv, inv, 1.5);
+                    inv = inv * fma(-0.5 * d * inv, inv, 1.5);
+                    ri[k] = inv;
 #pragma unroll
                     for (int b = k + 1; b < PP; ++b) GI(k, b) *= inv;  // l_bk stored at (k,b)
 #pragma unroll
@@ -181,14 +213,14 @@ __global__ __launch_bounds__(kRollWaves * 64) void rolling_kernel(const T* const
                     double s = c[a];
 #pragma unroll
                     for (int k = 0; k < a; ++k) s = fma(-GI(k, a), c[k], s);
-                    c[a] = s / GI(a, a);
+                    c[a] = s * ri[a];
                 }
 #pragma unroll
                 for (int a = PP - 1; a >= 0; --a) {
                     double s = c[a];
 #pragma unroll
                     for (int k = a + 1; k < PP; ++k) s = fma(-GI(a, k), c[k], s);
-                    c[a] = s / GI(a, a);
+                    c[a] = s * ri[a];
                 }
 #undef GI
                 const double nanv = __builtin_nan("");

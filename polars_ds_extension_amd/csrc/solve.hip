@@ -17,11 +17,7 @@
 
 namespace pds {
 
-#define WSYNC()                                                  \
-    do {                                                         \
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   \
-        __builtin_amdgcn_wave_barrier();                         \
-    } while (0)
+#define WSYNC() PDS_WAVE_LDS_SYNC()
 
 struct SolveDev {
     int p, pp, bias, solver, want_inv, lambda_on_bias;
