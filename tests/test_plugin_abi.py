@@ -17,7 +17,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "tests"))
 import plugin_harness as ph  # noqa: E402
 
-SYMBOLS = ["pl_lr", "pl_lr_pred", "pl_lin_reg_report", "pl_wls_report", "pl_rolling_lr", "pl_recursive_lr", "pl_lr_by"]
+SYMBOLS = ["pl_lr", "pl_lr_pred", "pl_lin_reg_report", "pl_wls_report", "pl_rolling_lr", "pl_recursive_lr", "pl_lr_by", "pl_lr_multi", "pl_lr_multi_pred"]
 
 
 @pytest.fixture(scope="module")
@@ -189,3 +189,29 @@ def test_pl_lr_by_matches_per_group_calls(so, orc):
         s = slice(g * per, (g + 1) * per)
         _, single = ph.call_plugin(so, "pl_lr", _cols(X[s], y[s]), LR)
         np.testing.assert_allclose(res[g]["coeffs"], single[0].as_py(), rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_pl_lr_multi_and_rcond(so, orc):
+    # tests/test_linear_exprs.py:1069-1113: struct fields named after the (aliased) targets; :477-512 rcond
+    rng = np.random.default_rng(4)
+    n = 8000
+    X = rng.normal(size=(n, 3))
+    Y = np.c_[X @ [1.0, 2.0, -1.0] + 0.5, X @ [0.0, -1.0, 3.0]] + 0.1 * rng.normal(size=(n, 2))
+    ins = [("target_0", pa.array(Y[:, 0])), ("target_1", pa.array(Y[:, 1]))] + [(f"x{j}", pa.array(X[:, j])) for j in range(3)]
+    kw = {"bias": True, "null_policy": "raise", "solver": "qr", "last_target_idx": 2, "l2_reg": 0.0, "singular_x_tol": 1e-12}
+    field, out = ph.call_plugin(so, "pl_lr_multi", ins, kw)
+    row = out.to_pylist()[0]
+    assert list(row) == ["target_0", "target_1"]
+    for i in range(2):
+        np.testing.assert_allclose(row[f"target_{i}"], orc.pl_lr(X, Y[:, i], add_bias=True), rtol=1e-10, atol=1e-12)
+    _, out = ph.call_plugin(so, "pl_lr_multi_pred", ins, kw)
+    t = out.to_pylist()
+    assert list(t[0]) == ["target_0_pred", "target_0_resid", "target_1_pred", "target_1_resid"] and len(t) == n
+    b = orc.pl_lr(X, Y[:, 1], add_bias=True)
+    np.testing.assert_allclose([r["target_1_pred"] for r in t[:50]], (np.c_[X, np.ones(n)] @ b)[:50], rtol=1e-10)
+    _, out = ph.call_plugin(so, "pl_lr_w_rcond", [("y", pa.array(Y[:, 0]))] + ins[2:], dict(LR, tol=0.3))
+    r = out.to_pylist()[0]
+    ref, _, _, sv = np.linalg.lstsq(X, Y[:, 0], rcond=0.3)
+    np.testing.assert_allclose(r["coeffs"], ref, atol=1e-10)
+    np.testing.assert_allclose(r["singular_values"], sv, rtol=1e-10)
