@@ -575,7 +575,8 @@ static int report_impl(pds_ctx* ctx, const T* const* cols, const T* weights, int
     if (weights && se_type != PDS_SE) se_type = PDS_SE;  // pl_wls_report only knows "std_err"
     PDS_HIP_CHECK(hipSetDevice(ctx->device));
     const int p = n_feat, bias = add_bias ? 1 : 0, pp = p + bias, q = p + 2;
-    size_t need = 131072 + sizeof(T) * (size_t)(2 * q * q + pp * pp + pp);
+    size_t need = 131072 + sizeof(T) * (size_t)(2 * q * q + pp * pp + pp) + sizeof(T*) * (size_t)(p + 64);
+    if (p > kMaxFeatSmall) need += moments_wide_workspace(ctx->num_cus, p, n_rows);
     if (se_type != PDS_SE) need += (size_t)n_rows * sizeof(T) + 512;
     if (int rc = ws_reserve(ctx, need)) return rc;
     DeviceCols<T> dc;

@@ -170,6 +170,49 @@ __global__ void pass2_finalize_kernel(const double* __restrict__ partials, int n
     }
 }
 
+// p > 16: same pass with a run-time loop over the columns (beta from the scalar cache), SE / pred / resid only
+template <typename T, bool WEIGHTED>
+__global__ __launch_bounds__(kP2Threads) void pass2_wide_kernel(const T* const* __restrict__ cols, int p, int bias,
+                                                                int64_t n, const T* __restrict__ beta,
+                                                                T* __restrict__ pred_out, T* __restrict__ resid_out,
+                                                                double* __restrict__ partials) {
+    double sse = 0.0, wsse = 0.0;
+    const T* cy = cols[p];
+    const T* cw = WEIGHTED ? cols[p + 1] : cols[p];
+    const T b0 = bias ? beta[p] : T(0);
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+        T acc = b0;
+        for (int c = 0; c < p; ++c) acc += cols[c][r] * beta[c];
+        const T res = cy[r] - acc;
+        if (pred_out) pred_out[r] = acc;
+        if (resid_out) resid_out[r] = res;
+        const double rd = (double)res;
+        sse = fma(rd, rd, sse);
+        if (WEIGHTED) wsse = fma((double)cw[r], rd * rd, wsse);
+    }
+    __shared__ double red[2][kP2Threads / 64];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        sse += __shfl_xor(sse, o);
+        wsse += __shfl_xor(wsse, o);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[0][wave] = sse;
+        red[1][wave] = wsse;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int w = 0; w < kP2Threads / 64; ++w) {
+            a += red[0][w];
+            b += red[1][w];
+        }
+        partials[2 * blockIdx.x] = a;
+        partials[2 * blockIdx.x + 1] = b;
+    }
+}
+
 template <typename T, bool W>
 static void launch_p2(int hc, dim3 g, hipStream_t st, const T* const* cols, int p, int bias, int64_t n, const T* beta,
                       const T* inv, T* pred, T* resid, T* s, double* partials) {
@@ -187,7 +230,17 @@ template <typename T>
 int launch_pass2(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, int add_bias, bool weighted,
                  const T* d_beta, const T* d_inv, int hc_mode, T* d_pred, T* d_resid, double* d_sums,
                  double* d_s_rows) {
-    if (n_feat < 1 || n_feat > kMaxFeatSmall) return fail(PDS_ERR_UNSUPPORTED, "pass2: 1..16 features supported");
+    if (n_feat < 1) return fail(PDS_ERR_INVALID, "need at least one feature column");
+    if (n_feat > kMaxFeatSmall) {
+        if (hc_mode != 0 || weighted) return fail(PDS_ERR_UNSUPPORTED, "HC / weighted standard errors with more than 16 features are not built yet");
+        const int nb = (int)std::min<int64_t>(std::max<int64_t>((n_rows + kP2Threads - 1) / kP2Threads, 1), (int64_t)ctx->num_cus * 8);
+        KernelTimer timer(ctx, kKindPass2);
+        hipLaunchKernelGGL((pass2_wide_kernel<T, false>), dim3(nb), dim3(kP2Threads), 0, ctx->stream, dc.d_ptrs, n_feat,
+                           add_bias ? 1 : 0, n_rows, d_beta, d_pred, d_resid, ctx->partials);
+        hipLaunchKernelGGL(pass2_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->partials, nb, d_sums);
+        PDS_HIP_CHECK(hipGetLastError());
+        return PDS_OK;
+    }
     constexpr int RPL = V16<T>::RPL;
     const int64_t nvec = (n_rows + RPL - 1) / RPL;
     int64_t want = (nvec + kP2Threads - 1) / kP2Threads;

@@ -570,3 +570,19 @@ def test_multi_target(pds, orc):
     Xc = np.c_[X[:, 0], 2 * X[:, 0], X[:, 1]]
     out = pds.lin_reg(*cols_of(Xc), target=[dev(Y[:, 0]), dev(Y[:, 1])])
     assert out["target_0"] is None and out["target_1"] is None  # the gate depends on X only: all targets null
+
+
+def test_wide_pred_and_report(pds, orc):
+    rng = np.random.default_rng(31)
+    n, p = 30_000, 24
+    X = rng.normal(size=(n, p))
+    beta = rng.normal(size=p)
+    beta[[3, 7]] = 0.0
+    y = X @ beta + 0.4 + rng.normal(size=n)
+    pred, resid = pds.lin_reg(*cols_of(X), target=dev(y), add_bias=True, return_pred=True)
+    b = orc.pl_lr(X, y, add_bias=True)
+    assert nrel(pred.cpu().numpy(), np.c_[X, np.ones(n)] @ b) < F64_TOL
+    r = pds.lin_reg_report(*cols_of(X), target=dev(y), add_bias=True, y_var=float(np.var(y, ddof=1)))
+    ro = orc.lin_reg_report(np.c_[X, np.ones(n)], y)
+    assert nrel(r["beta"], ro["beta"]) < F64_TOL and frel(r["std_err"], ro["std_err"], 1e-12) < F64_TOL
+    assert frel(r["p>|t|"], ro["p"], 1e-12) < 1e-8 and abs(r["r2"][0] - ro["r2"]) < 1e-12
