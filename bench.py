@@ -178,6 +178,12 @@ def main() -> int:
                "sample": f"{gs} groups x {R} rows x {P} f64 feats (first {ns} rows of the same frame), OpenMP over groups, "
                          f"{t_cpu:.2f} s; per-group copy + X'X + gated col-piv QR as Polars drives pl_lr",
                "nproc": os.cpu_count()}
+        # the Gram build of the single regression on the same sample, all host cores
+        t2 = time.perf_counter()
+        orc.gram_cols(host_cols, nthreads=nthreads)
+        t_gram = time.perf_counter() - t2
+        cpu["gram_build_GBps"] = round(ns * (P + 1) * 8 / t_gram / 1e9, 2)
+        cpu["gram_build_sample"] = f"{ns} rows x {P + 1} f64 columns, blocked X'X | X'y restatement, {nthreads} threads, {t_gram:.2f} s"
         co_gpu = coeffs[:gs].cpu().numpy()
         num = np.linalg.norm(co_gpu - co_cpu, axis=1)
         den = np.linalg.norm(co_cpu, axis=1)

@@ -10,9 +10,11 @@
 //   * the K-panels (128 columns x 128 B of rows) are read with 16-byte loads -- each 8-lane group covers one
 //     contiguous 128-byte line of a column -- prefetched into registers one stage ahead and parked in LDS
 //     column-major with an odd leading dimension, from where the MFMA operands are conflict-free b32/b64 reads;
-//   * f32 accumulates 1024 rows per matrix-core accumulator and folds into f64 registers (the reference
+//   * f32 splits are at most 8192 rows, accumulated in the f32 matrix-core tile, summed across splits in f64 (the reference
 //     accumulates everything in f32).
 #include "common.hpp"
+
+#include <type_traits>
 
 namespace pds {
 
@@ -33,7 +35,6 @@ struct Wide<float> {
     static constexpr int MT = 32;   // MFMA tile edge
     static constexpr int NT = 2;    // tiles per wave edge (64 / MT)
     static constexpr int KS = 16;   // MFMA k-steps per stage (KC / 2)
-    static constexpr int FLUSH = 32;  // stages between folds into f64
     using vec = f4w;
     static constexpr int VL = 4;
 };
@@ -44,7 +45,6 @@ struct Wide<double> {
     static constexpr int MT = 16;
     static constexpr int NT = 4;
     static constexpr int KS = 4;
-    static constexpr int FLUSH = 1 << 30;
     using vec = d2w;
     static constexpr int VL = 2;
 };
@@ -60,10 +60,21 @@ __host__ __device__ inline void pair_to_ij(int pair, int nb, int& I, int& J) {
     J = i + pair;
 }
 
-template <typename T>
-__global__ __launch_bounds__(kWThreads) void moments_wide_kernel(const T* const* __restrict__ cols, int p, int64_t n,
-                                                                 int nb, int64_t rows_per_split,
-                                                                 double* __restrict__ partials) {
+__host__ __device__ inline int ij_to_pair(int I, int J, int nb) { return I * nb - I * (I - 1) / 2 + (J - I); }
+
+// A last block column holding at most one MFMA tile of valid columns (the [1 | y] tail when p is a multiple of 128)
+// must not cost full 128 x 128 tiles of matrix-core time on padding:
+// MODE 0: blockIdx.x enumerates the upper triangle of the leading nb_main x nb_main block grid, nothing special.
+// MODE 1: "narrow" launch for that tail column, blockIdx.x = I, J = nb - 1: each wave takes 32 rows of the I panel
+//         against the first MFMA tile of the J panel (used for f64).
+// MODE 2: (f32) like MODE 0, and the tail is fused into the diagonal blocks: there the wave that would compute the
+//         redundant lower-left quadrant instead multiplies all 128 rows of the I panel with the tail tile, which is
+//         parked in the otherwise unused J half of LDS.  No extra pass over X; tail' tail (a few columns) comes from
+//         a one-block-wide MODE 1 launch.
+template <typename T, int MODE>
+__global__ __launch_bounds__(kWThreads, 2) void moments_wide_kernel(const T* const* __restrict__ cols, int p, int64_t n,
+                                                                 int nb, int nb_main, int i_first, int64_t rows_per_split,
+                                                                 T* __restrict__ partials) {
     using W = Wide<T>;
     constexpr int KC = W::KC, CS = W::CS, MT = W::MT, NT = W::NT, VL = W::VL;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -71,8 +82,16 @@ __global__ __launch_bounds__(kWThreads) void moments_wide_kernel(const T* const*
     T* LJ = LI + kWB * CS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
+    constexpr bool NARROW = MODE == 1, FUSE = MODE == 2;
+    static_assert(!FUSE || (sizeof(T) == 4 && MT * 8 == kWThreads), "tail fusion is laid out for the f32 tile");
     int I, J;
-    pair_to_ij(blockIdx.x, nb, I, J);
+    if constexpr (NARROW) {
+        I = i_first + blockIdx.x;
+        J = nb - 1;
+    } else {
+        pair_to_ij(blockIdx.x, nb_main, I, J);
+    }
+    const int pair = ij_to_pair(I, J, nb), npairs = nb * (nb + 1) / 2;
     const bool diag = I == J;
     const int q = p + 2;
     const int64_t r_begin = (int64_t)blockIdx.y * rows_per_split;
@@ -85,7 +104,7 @@ __global__ __launch_bounds__(kWThreads) void moments_wide_kernel(const T* const*
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int id = tid + kWThreads * u;
-        const int cI = I * kWB + (id >> 3), cJ = J * kWB + (id >> 3);
+        const int cI = I * kWB + (id >> 3), cJ = ((FUSE && diag) ? nb - 1 : J) * kWB + (id >> 3);
         kindI[u] = (cI < p || cI == p + 1) ? 0 : (cI == p ? 1 : 2);
         kindJ[u] = (cJ < p || cJ == p + 1) ? 0 : (cJ == p ? 1 : 2);
         ptrI[u] = cols[cI < p ? cI : p];  // index p is y in the device table
@@ -101,7 +120,7 @@ __global__ __launch_bounds__(kWThreads) void moments_wide_kernel(const T* const*
             const int64_t r = row0 + (id & 7) * VL;
 #pragma unroll
             for (int pnl = 0; pnl < 2; ++pnl) {
-                if (pnl == 1 && diag) continue;
+                if (pnl == 1 && diag && !(FUSE && u == 0)) continue;  // diagonal: J half unused, or the tail tile
                 const int kind = pnl ? kindJ[u] : kindI[u];
                 const T* ptr = pnl ? ptrJ[u] : ptrI[u];
                 typename W::vec v;
@@ -127,19 +146,23 @@ __global__ __launch_bounds__(kWThreads) void moments_wide_kernel(const T* const*
 #pragma unroll
             for (int e = 0; e < VL; ++e) {
                 LI[c * CS + k0 + e] = rI[u][e];
-                if (!diag) LJ[c * CS + k0 + e] = rJ[u][e];
+                if (!diag || (FUSE && u == 0)) LJ[c * CS + k0 + e] = rJ[u][e];
             }
         }
     };
 
-    // accumulators: f64 registers; the f32 path adds a matrix-core f32 tile folded in every FLUSH stages
-    double accd[NT][NT][sizeof(T) == 4 ? 16 : 4];
+    // accumulators live in the matrix core's own precision.  f32: a split covers only a few thousand rows
+    // (rows_per_split), so the f32 tile error stays ~sqrt(rows) eps and the cross-split sum is done in f64 by the
+    // reduce kernel -- keeping 64 f64 accumulators next to the f32 tile cost half the occupancy.
+    double accd[sizeof(T) == 4 ? 1 : NT][sizeof(T) == 4 ? 1 : NT][4];
+    if constexpr (sizeof(T) == 8) {
 #pragma unroll
-    for (int m = 0; m < NT; ++m)
+        for (int m = 0; m < NT; ++m)
 #pragma unroll
-        for (int nn = 0; nn < NT; ++nn)
+            for (int nn = 0; nn < NT; ++nn)
 #pragma unroll
-            for (int r = 0; r < (sizeof(T) == 4 ? 16 : 4); ++r) accd[m][nn][r] = 0.0;
+                for (int r = 0; r < 4; ++r) accd[m][nn][r] = 0.0;
+    }
     f16v accf[2][2];
     if constexpr (sizeof(T) == 4) {
 #pragma unroll
@@ -150,55 +173,58 @@ __global__ __launch_bounds__(kWThreads) void moments_wide_kernel(const T* const*
                 for (int r = 0; r < 16; ++r) accf[m][nn][r] = 0.f;
     }
     const T* PJ = diag ? LI : LJ;
-    int since_flush = 0;
-    if (r_begin < r_end) load_stage(r_begin);
-    for (int64_t row0 = r_begin; row0 < r_end; row0 += KC) {
-        __syncthreads();  // previous stage's reads are done
-        store_stage();
-        __syncthreads();
-        if (row0 + KC < r_end) load_stage(row0 + KC);
+    const bool tailwave = FUSE && diag && wave == 2;
+    auto mma_tail = [&]() __attribute__((always_inline)) {
+        if constexpr (FUSE) {
+            const int li = lane & 31, kq = lane >> 5;
+#pragma unroll
+            for (int ks = 0; ks < W::KS; ++ks) {
+                const int k = 2 * ks + kq;
+                float a[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) a[t] = LI[(t * 32 + li) * CS + k];
+                const float b = LJ[li * CS + k];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    accf[t >> 1][t & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b, accf[t >> 1][t & 1], 0, 0, 0);
+            }
+        }
+    };
+    constexpr bool narrow = NARROW;
+    const int rb = narrow ? wave * 32 : wr * 64, cb = narrow ? 0 : wc * 64;
+    constexpr int NMN = 32 / MT;  // m-tiles per wave in narrow mode
+    auto mma_stage = [&](auto nm_c, auto nn_c) __attribute__((always_inline)) {
+        constexpr int NM = decltype(nm_c)::value, NN = decltype(nn_c)::value;
         if constexpr (sizeof(T) == 4) {
             const int li = lane & 31, kq = lane >> 5;
 #pragma unroll
             for (int ks = 0; ks < W::KS; ++ks) {
                 const int k = 2 * ks + kq;
-                float a[2], b[2];
+                float a[NM], b[NN];
 #pragma unroll
-                for (int m = 0; m < 2; ++m) a[m] = LI[(wr * 64 + m * 32 + li) * CS + k];
+                for (int m = 0; m < NM; ++m) a[m] = LI[(rb + m * 32 + li) * CS + k];
 #pragma unroll
-                for (int nn = 0; nn < 2; ++nn) b[nn] = PJ[(wc * 64 + nn * 32 + li) * CS + k];
+                for (int nn = 0; nn < NN; ++nn) b[nn] = PJ[(cb + nn * 32 + li) * CS + k];
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
+                for (int m = 0; m < NM; ++m)
 #pragma unroll
-                    for (int nn = 0; nn < 2; ++nn)
+                    for (int nn = 0; nn < NN; ++nn)
                         accf[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[nn], accf[m][nn], 0, 0, 0);
-            }
-            if (++since_flush == W::FLUSH) {
-                since_flush = 0;
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int nn = 0; nn < 2; ++nn)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            accd[m][nn][r] += (double)accf[m][nn][r];
-                            accf[m][nn][r] = 0.f;
-                        }
             }
         } else {
             const int li = lane & 15, kq = lane >> 4;
 #pragma unroll
             for (int ks = 0; ks < W::KS; ++ks) {
                 const int k = 4 * ks + kq;
-                double a[4], b[4];
+                double a[NM], b[NN];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) a[m] = LI[(wr * 64 + m * 16 + li) * CS + k];
+                for (int m = 0; m < NM; ++m) a[m] = LI[(rb + m * 16 + li) * CS + k];
 #pragma unroll
-                for (int nn = 0; nn < 4; ++nn) b[nn] = PJ[(wc * 64 + nn * 16 + li) * CS + k];
+                for (int nn = 0; nn < NN; ++nn) b[nn] = PJ[(cb + nn * 16 + li) * CS + k];
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
+                for (int m = 0; m < NM; ++m)
 #pragma unroll
-                    for (int nn = 0; nn < 4; ++nn) {
+                    for (int nn = 0; nn < NN; ++nn) {
                         d4w c = {accd[m][nn][0], accd[m][nn][1], accd[m][nn][2], accd[m][nn][3]};
                         c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[nn], c, 0, 0, 0);
                         accd[m][nn][0] = c[0];
@@ -208,24 +234,47 @@ __global__ __launch_bounds__(kWThreads) void moments_wide_kernel(const T* const*
                     }
             }
         }
+    };
+    if (r_begin < r_end) load_stage(r_begin);
+    for (int64_t row0 = r_begin; row0 < r_end; row0 += KC) {
+        __syncthreads();  // previous stage's reads are done
+        store_stage();
+        __syncthreads();
+        if (row0 + KC < r_end) load_stage(row0 + KC);
+        if constexpr (narrow) mma_stage(std::integral_constant<int, NMN>{}, std::integral_constant<int, 1>{});
+        else if (tailwave) mma_tail();
+        else mma_stage(std::integral_constant<int, NT>{}, std::integral_constant<int, NT>{});
     }
-    // ---- write the f64 partial tile: P[split][pair][i * 128 + j]
-    double* P = partials + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (kWB * kWB);
+    // ---- write the partial tile: P[split][pair][i * 128 + j] (narrow: only the first MFMA tile column)
+    T* P = partials + ((int64_t)blockIdx.y * npairs + pair) * (kWB * kWB);
+    if constexpr (FUSE) {
+        if (tailwave) {  // rows t * 32.. of pair (I, nb-1), first tile column
+            T* PT = partials + ((int64_t)blockIdx.y * npairs + ij_to_pair(I, nb - 1, nb)) * (kWB * kWB);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) PT[(t * 32 + row) * kWB + col] = accf[t >> 1][t & 1][r];
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int m = 0; m < NT; ++m)
 #pragma unroll
         for (int nn = 0; nn < NT; ++nn) {
+            if (narrow && (m >= NMN || nn >= 1)) continue;
             if constexpr (sizeof(T) == 4) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31;
-                    P[(wr * 64 + m * 32 + row) * kWB + wc * 64 + nn * 32 + col] = accd[m][nn][r] + (double)accf[m][nn][r];
+                    P[(rb + m * 32 + row) * kWB + cb + nn * 32 + col] = accf[m][nn][r];
                 }
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = (lane >> 4) + 4 * r, col = lane & 15;
-                    P[(wr * 64 + m * 16 + row) * kWB + wc * 64 + nn * 16 + col] = accd[m][nn][r];
+                    P[(rb + m * 16 + row) * kWB + cb + nn * 16 + col] = accd[m][nn][r];
                 }
             }
         }
@@ -233,7 +282,7 @@ __global__ __launch_bounds__(kWThreads) void moments_wide_kernel(const T* const*
 
 // out (q x q column-major, symmetric) = sum over splits of the partial tiles, fixed order
 template <typename T>
-__global__ __launch_bounds__(256) void moments_wide_reduce_kernel(const double* __restrict__ partials, int nsplit,
+__global__ __launch_bounds__(256) void moments_wide_reduce_kernel(const T* __restrict__ partials, int nsplit,
                                                                   int npairs, int nb, int p, T* __restrict__ out) {
     const int q = p + 2;
     int I, J;
@@ -244,10 +293,33 @@ __global__ __launch_bounds__(256) void moments_wide_reduce_kernel(const double* 
         if (gi >= q || gj >= q) continue;
         if (I == J && gi > gj) continue;
         double s = 0.0;
-        for (int sidx = 0; sidx < nsplit; ++sidx) s += partials[((int64_t)sidx * npairs + blockIdx.x) * (kWB * kWB) + e];
+        const T* src = partials + (int64_t)blockIdx.x * (kWB * kWB) + e;
+        const int64_t stride = (int64_t)npairs * (kWB * kWB);
+        int sidx = 0;
+        for (; sidx + 8 <= nsplit; sidx += 8) {  // 8 independent loads in flight, summed in split order
+            T v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(sidx + u) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += (double)v[u];
+        }
+        for (; sidx < nsplit; ++sidx) s += (double)src[sidx * stride];
         out[gi + (int64_t)gj * q] = (T)s;
         out[gj + (int64_t)gi * q] = (T)s;
     }
+}
+
+// split-K plan: enough workgroups to fill the chip, and (f32) few enough rows per split that an f32 accumulator tile
+// is safe; splits are multiples of the stage size
+template <typename T>
+static void wide_split(int num_cus, int npairs, int64_t n_rows, int& nsplit, int64_t& rows_per_split) {
+    using W = Wide<T>;
+    int64_t want = std::max<int64_t>(1, ((int64_t)num_cus * 4 + npairs - 1) / npairs);
+    if (sizeof(T) == 4) want = std::max<int64_t>(want, (n_rows + 8191) / 8192);
+    want = std::min<int64_t>(want, std::max<int64_t>(1, (n_rows + 1023) / 1024));
+    rows_per_split = (n_rows + want - 1) / want;
+    rows_per_split = ((rows_per_split + W::KC - 1) / W::KC) * W::KC;
+    nsplit = (int)((n_rows + rows_per_split - 1) / rows_per_split);
 }
 
 template <typename T>
@@ -256,20 +328,36 @@ int launch_moments_wide(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64
     const int q = n_feat + 2;
     const int nb = (q + kWB - 1) / kWB;
     const int npairs = nb * (nb + 1) / 2;
-    // split the row axis so that ~4 workgroups per CU are in flight; splits are multiples of the stage size
-    int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)ctx->num_cus * 4 + npairs - 1) / npairs,
-                                                             (n_rows + 4095) / 4096));
-    int64_t rows_per_split = (n_rows + nsplit - 1) / nsplit;
-    rows_per_split = ((rows_per_split + W::KC - 1) / W::KC) * W::KC;
-    nsplit = (int)((n_rows + rows_per_split - 1) / rows_per_split);
-    const size_t part_bytes = (size_t)nsplit * npairs * kWB * kWB * sizeof(double);
-    double* partials = reinterpret_cast<double*>(ws_take(ctx, part_bytes));
+    int nsplit;
+    int64_t rows_per_split;
+    wide_split<T>(ctx->num_cus, npairs, n_rows, nsplit, rows_per_split);
+    const size_t part_bytes = (size_t)nsplit * npairs * kWB * kWB * sizeof(T);
+    T* partials = reinterpret_cast<T*>(ws_take(ctx, part_bytes));
     if (ctx->ws_used > ctx->ws.bytes) return fail(PDS_ERR_INVALID, "internal: workspace for the wide Gram build was not reserved");
     const size_t lds = (size_t)2 * kWB * W::CS * sizeof(T);
     KernelTimer timer(ctx, kKindMoments);
-    hipLaunchKernelGGL((moments_wide_kernel<T>), dim3(npairs, nsplit), dim3(kWThreads), lds, ctx->stream, dc.d_ptrs, n_feat,
-                       n_rows, nb, rows_per_split, partials);
-    hipLaunchKernelGGL((moments_wide_reduce_kernel<T>), dim3(npairs, 16), dim3(256), 0, ctx->stream, partials, nsplit,
+    const bool tail_narrow = q - (nb - 1) * kWB <= W::MT;
+    const int nb_main = tail_narrow ? nb - 1 : nb;
+    const dim3 grid_main(nb_main * (nb_main + 1) / 2, nsplit);
+    bool fused = false;
+    if constexpr (sizeof(T) == 4) {
+        if (tail_narrow && nb_main > 0) {
+            fused = true;
+            hipLaunchKernelGGL((moments_wide_kernel<T, 2>), grid_main, dim3(kWThreads), lds, ctx->stream, dc.d_ptrs, n_feat,
+                               n_rows, nb, nb_main, 0, rows_per_split, partials);
+            hipLaunchKernelGGL((moments_wide_kernel<T, 1>), dim3(1, nsplit), dim3(kWThreads), lds, ctx->stream, dc.d_ptrs,
+                               n_feat, n_rows, nb, nb_main, nb - 1, rows_per_split, partials);
+        }
+    }
+    if (!fused) {
+        if (nb_main > 0)
+            hipLaunchKernelGGL((moments_wide_kernel<T, 0>), grid_main, dim3(kWThreads), lds, ctx->stream, dc.d_ptrs, n_feat,
+                               n_rows, nb, nb_main, 0, rows_per_split, partials);
+        if (tail_narrow)
+            hipLaunchKernelGGL((moments_wide_kernel<T, 1>), dim3(nb, nsplit), dim3(kWThreads), lds, ctx->stream, dc.d_ptrs,
+                               n_feat, n_rows, nb, nb_main, 0, rows_per_split, partials);
+    }
+    hipLaunchKernelGGL((moments_wide_reduce_kernel<T>), dim3(npairs, 64), dim3(256), 0, ctx->stream, partials, nsplit,
                        npairs, nb, n_feat, d_moments);
     PDS_HIP_CHECK(hipGetLastError());
     return PDS_OK;
@@ -279,8 +367,10 @@ size_t moments_wide_workspace(int num_cus, int n_feat, int64_t n_rows) {
     const int q = n_feat + 2;
     const int nb = (q + kWB - 1) / kWB;
     const int npairs = nb * (nb + 1) / 2;
-    const int64_t nsplit = std::max<int64_t>(1, ((int64_t)num_cus * 4 + npairs - 1) / npairs) + 1;
-    return (size_t)nsplit * npairs * kWB * kWB * sizeof(double) + 4096;
+    int ns;
+    int64_t rps;
+    wide_split<float>(num_cus, npairs, n_rows, ns, rps);  // the f32 plan has the most splits; 8 B covers both types
+    return (size_t)(ns + 1) * npairs * kWB * kWB * sizeof(double) + 4096;
 }
 
 template int launch_moments_wide<double>(pds_ctx*, const DeviceCols<double>&, int, int64_t, double*);

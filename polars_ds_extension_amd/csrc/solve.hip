@@ -335,6 +335,15 @@ int launch_solve(pds_ctx* ctx, const T* d_moments, int64_t n_sys, const SolvePar
 // coordinate descent / NNLS on the moment matrix: one wavefront, beta and the scalars in LDS,
 // Gram columns read from L2 (the matrix is tiny next to the 4 MiB L2: 1 MiB at p = 512 f32)
 // =============================================================================================
+// The reference (lr_solvers.rs:486-530) recomputes dot_j = sum_{k != j} G[k,j] beta_k for every coordinate of every
+// sweep: p^2 work per sweep and a dependent L2 round trip per coordinate.  Here the same iteration is carried by the
+// gradient  r_j = (X'y)_j - sum_k G[k,j] beta_k  (all k), kept in LDS: the reference's
+//   main_update_j = (X'y)_j - dot_j  is  r_j + G[j,j] beta_j,
+// and r only moves when a coefficient moves (r -= delta * G[:,j], one coalesced column read).  Coordinates are
+// evaluated 64 at a time against the current r; the first lane whose coefficient would change commits it, the
+// evaluation restarts behind it -- lanes in front of it saw exactly the state the sequential sweep would have
+// shown them, so the iterates are the reference's up to f64 rounding of the running r.  A sweep costs
+// (p / 64 + #coefficients that move) steps instead of p.
 template <typename T>
 __global__ __launch_bounds__(64) void cd_kernel(const T* __restrict__ M, int p, int bias, double l1_reg,
                                                 double l2_reg, double tol, int max_iter, int positive,
@@ -342,46 +351,62 @@ __global__ __launch_bounds__(64) void cd_kernel(const T* __restrict__ M, int p, 
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int lane = threadIdx.x;
     const int pp = p + bias, q = p + 2;
-    double* beta = sm;  // pp
+    double* beta = sm;           // pp
+    double* r = sm + (p + 2);    // pp
+    double* gd = r + (p + 2);    // p: G[j,j]
     const double m = (double)M[p + p * q];  // n (row count) lives in the bias/bias slot
-    const double lambda_l1 = m * l1_reg;
-    for (int i = lane; i < pp; i += 64) beta[i] = 0.0;
+    const double lambda_l1 = m * l1_reg, ridge = m * l2_reg;
+    for (int i = lane; i < pp; i += 64) {
+        beta[i] = 0.0;
+        r[i] = (double)M[i + (p + 1) * q];  // X'y, and sum y in the bias slot
+        if (i < p) gd[i] = (double)M[i + i * q];
+    }
     WSYNC();
     int it = 0, conv = 0;
     for (it = 0; it < max_iter; ++it) {
         double max_change = 0.0;
-        for (int jc = 0; jc < p; ++jc) {
-            // dot = sum_k G[k,jc] beta_k over all pp entries with beta_jc treated as 0  (:497-500)
-            double part = 0.0;
-            for (int k = lane; k < pp; k += 64)
-                if (k != jc) part = fma((double)M[k + jc * q], beta[k], part);
-            double dot = part;
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) dot += __shfl_xor(dot, o);
-            const double before = beta[jc];
-            const double main_update = (double)M[jc + (p + 1) * q] - dot;
-            const double norm = (double)M[jc + jc * q] + m * l2_reg;
-            double after;
-            if (positive && main_update < 0.0)
-                after = 0.0;
-            else {
-                const double sg = (main_update < 0.0 || (main_update == 0.0 && signbit(main_update))) ? -1.0 : 1.0;
-                const double mag = fabs(main_update) - lambda_l1;
-                after = sg * (mag > 0.0 ? mag : 0.0) / norm;
+        int j0 = 0;
+        while (j0 < p) {
+            const int j = j0 + lane;
+            double before = 0.0, after = 0.0;
+            if (j < p) {
+                before = beta[j];
+                const double g = gd[j];
+                const double main_update = fma(g, before, r[j]);
+                if (positive && main_update < 0.0)
+                    after = 0.0;
+                else {
+                    const double sg = (main_update < 0.0 || (main_update == 0.0 && signbit(main_update))) ? -1.0 : 1.0;
+                    const double mag = fabs(main_update) - lambda_l1;
+                    after = sg * (mag > 0.0 ? mag : 0.0) / (g + ridge);
+                }
             }
+            const unsigned long long moved = __ballot(j < p && after != before);
+            if (moved == 0ull) {
+                j0 += 64;
+                continue;
+            }
+            const int f = __ffsll((long long)moved) - 1;
+            const int jc = j0 + f;
+            const double delta = __shfl(after - before, f);
+            const double committed = __shfl(after, f);
             WSYNC();
-            if (lane == 0) beta[jc] = after;
+            if (lane == 0) beta[jc] = committed;
+            const T* col = M + (int64_t)jc * q;
+            for (int k = lane; k < pp; k += 64) r[k] = fma(-delta, (double)col[k], r[k]);
             WSYNC();
-            const double d = fabs(after - before);
+            const double d = fabs(delta);
             max_change = d > max_change ? d : max_change;
+            j0 = jc + 1;
         }
-        if (bias) {  // bias = (sum y - sum_j beta_j colsum_j) / m   (:514-522)
-            double part = 0.0;
-            for (int k = lane; k < p; k += 64) part = fma(beta[k], (double)M[k + p * q], part);
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
+        if (bias) {  // bias = (sum y - sum_j beta_j colsum_j) / m = (r_p + m beta_p) / m   (:514-522)
+            const double old = beta[p];
+            const double nb = fma(m, old, r[p]) / m;
+            const double delta = nb - old;
             WSYNC();
-            if (lane == 0) beta[p] = ((double)M[p + (p + 1) * q] - part) / m;
+            if (lane == 0) beta[p] = nb;
+            const T* col = M + (int64_t)p * q;
+            for (int k = lane; k < pp; k += 64) r[k] = fma(-delta, (double)col[k], r[k]);
             WSYNC();
         }
         conv = max_change < tol;
@@ -435,7 +460,11 @@ __global__ __launch_bounds__(64) void nnls_kernel(const T* __restrict__ M, int p
 template <typename T>
 int launch_cd(pds_ctx* ctx, const T* d_moments, int p, int add_bias, double l1, double l2, double tol, int max_iter,
               int positive, T* d_coeffs, int* d_info) {
-    const size_t lds = (size_t)(p + 2) * sizeof(double);
+    const size_t lds = (size_t)3 * (p + 2) * sizeof(double);
+    if (lds > 160 * 1024) return fail(PDS_ERR_INVALID, "coordinate descent: more than 6800 features are not supported");
+    if (lds > 48 * 1024)
+        PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cd_kernel<T>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     KernelTimer timer(ctx, kKindIter);
     hipLaunchKernelGGL((cd_kernel<T>), dim3(1), dim3(64), lds, ctx->stream, d_moments, p, add_bias ? 1 : 0, l1, l2,
                        tol, max_iter, positive, d_coeffs, d_info);

@@ -443,7 +443,8 @@ def test_full_size_grouped_noise_free(pds):
 
 
 # ------------------------------------------------------------------------------------------ p > 16: tiled-SYRK Gram build
-@pytest.mark.parametrize("n,p", [(5000, 17), (20_011, 40), (3000, 130), (40_000, 64)])
+@pytest.mark.parametrize("n,p", [(5000, 17), (20_011, 40), (3000, 130), (40_000, 64), (2500, 126), (2600, 128), (2100, 140),
+                                 (2200, 144), (1500, 256)])
 def test_wide_moments_and_ols_f64(pds, orc, n, p):
     rng = np.random.default_rng(p)
     X = rng.normal(size=(n, p))
@@ -456,6 +457,20 @@ def test_wide_moments_and_ols_f64(pds, orc, n, p):
         assert nrel(b, orc.pl_lr(X, y, add_bias=True)) < F64_TOL
     b = pds.lin_reg(*cols_of(X), target=dev(y), add_bias=True, l1_reg=0.01, l2_reg=0.01, tol=1e-9, max_iter=3000)
     assert nrel(b, orc.pl_lr(X, y, add_bias=True, l1_reg=0.01, l2_reg=0.01, tol=1e-9, max_iter=3000)) < 1e-9
+
+
+@pytest.mark.parametrize("n,p", [(9000, 30), (70_000, 126), (33_333, 128), (10_000, 150), (20_000, 158), (12_345, 256)])
+def test_wide_moments_f32_split_k(pds, f32, n, p):
+    # f32: <= 8192-row splits in f32 matrix-core tiles, cross-split sum in f64; the [1 | y] tail column block runs narrow
+    rng = np.random.default_rng(n + p)
+    X = rng.normal(size=(n, p)).astype(np.float32)
+    y = rng.normal(size=n).astype(np.float32)
+    M = pds.gram_moments(*cols_of(X), target=dev(y))
+    Z = np.c_[X.astype(np.float64), np.ones(n), y.astype(np.float64)]
+    G = Z.T @ Z
+    assert M.dtype == np.float32 and M.shape == G.shape
+    assert np.max(np.abs(M - G) / np.sqrt(np.outer(np.diag(G), np.diag(G)))) < 2e-6
+    assert np.array_equal(M, M.T)
 
 
 def test_config5_elastic_net_f32_wide(pds, orc, f32):

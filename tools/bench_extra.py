@@ -86,7 +86,8 @@ if "en" in which:
         xs.append(prev)
     idx = torch.randperm(p, generator=torch.Generator().manual_seed(4))[:32]
     y = torch.zeros(n, dtype=torch.float32, device=dev)
-    for j in idx.tolist(): y.add_(xs[j], alpha=float(torch.randn(1).item()))
+    cgen = torch.Generator().manual_seed(5)
+    for j in idx.tolist(): y.add_(xs[j], alpha=float(torch.randn(1, generator=cgen).item()))
     y.add_(torch.randn(n, dtype=torch.float32, device=dev, generator=gen), alpha=0.5)
     wall, t, b = timed(lambda: pds.lin_reg(*xs, target=y, l1_reg=0.01, l2_reg=0.01, tol=1e-5, ctx=ctx), reps=3, warm=1)
     flops = 2.0 * n * (p + 2) * (p + 2)  # full square, as the reference computes it
