@@ -23,6 +23,20 @@
 
 namespace pds {
 
+// Column base pointers reach the kernels through a device-side table, so the compiler only knows them as generic
+// ("flat") addresses.  Flat loads tick lgkmcnt as well as vmcnt -- every wait for an LDS or scalar result then also
+// waits for the HBM loads in flight -- and cannot use the SGPR-base + 32-bit-VGPR-offset addressing form.  The
+// kernels therefore retag the pointers as global (address space 1) once, where they fetch them.
+#if defined(__HIPCC__)
+template <typename T>
+using gptr = const __attribute__((address_space(1))) T*;
+template <typename T>
+__device__ __forceinline__ gptr<T> as_global(const T* p) {
+    return (gptr<T>)p;
+}
+#endif
+
+
 // ---------------------------------------------------------------------------------------------
 // error plumbing: thread-local message, like the plugin ABI's `_polars_plugin_get_last_error_message`
 // ---------------------------------------------------------------------------------------------

@@ -269,8 +269,8 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
         // pointers resident costs 34 SGPRs for the whole kernel and pushed the solver's scalars into spills
         ColPtrs<T> cp;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) cp.x[c] = cols[c];
-        cp.y = cols[p];
+        for (int c = 0; c < 16; ++c) cp.x[c] = as_global(cols[c]);
+        cp.y = as_global(cols[p]);
         cp.w = cp.y;
         const int64_t row = t * TR + lane * RPL;
         if ((t + 1) * TR <= n_rows) load_full_tile<T, false>(cp, p, row, regs);

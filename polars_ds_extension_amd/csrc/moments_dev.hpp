@@ -57,17 +57,17 @@ struct TileRegs {
 // The column base pointers are loop invariant and wave uniform: fetch them ONCE into SGPRs.  (Left to the
 // compiler, every tile re-issued 17 dependent s_load + s_waitcnt pairs in front of the global loads.)
 template <typename T>
-struct ColPtrs {
-    const T* x[16];
-    const T* y;
-    const T* w;
+struct ColPtrs {  // global address space: see gptr in common.hpp
+    gptr<T> x[16];
+    gptr<T> y;
+    gptr<T> w;
 };
 template <typename T, bool WEIGHTED>
 __device__ __forceinline__ void fetch_col_ptrs(const T* const* __restrict__ cols, int p, ColPtrs<T>& cp) {
 #pragma unroll
-    for (int c = 0; c < 16; ++c) cp.x[c] = cols[c < p ? c : 0];
-    cp.y = cols[p];
-    cp.w = WEIGHTED ? cols[p + 1] : cols[p];
+    for (int c = 0; c < 16; ++c) cp.x[c] = as_global(cols[c < p ? c : 0]);
+    cp.y = as_global(cols[p]);
+    cp.w = as_global(WEIGHTED ? cols[p + 1] : cols[p]);
 }
 
 // ---- full-tile load: lane reads RPL consecutive rows of every column (16 B, coalesced 1 KiB/instr)
@@ -76,9 +76,9 @@ __device__ __forceinline__ void load_full_tile(const ColPtrs<T>& cp, int p, int6
     using V = typename Tile<T>::vec;
 #pragma unroll
     for (int c = 0; c < 16; ++c)
-        if (c < p) r.x[c] = *reinterpret_cast<const V*>(cp.x[c] + row);
-    r.y = *reinterpret_cast<const V*>(cp.y + row);
-    if (WEIGHTED) r.w = *reinterpret_cast<const V*>(cp.w + row);
+        if (c < p) r.x[c] = *reinterpret_cast<gptr<V>>(cp.x[c] + row);
+    r.y = *reinterpret_cast<gptr<V>>(cp.y + row);
+    if (WEIGHTED) r.w = *reinterpret_cast<gptr<V>>(cp.w + row);
 }
 
 // ---- guarded load for the ragged last tile (rows >= n contribute exact zeros)

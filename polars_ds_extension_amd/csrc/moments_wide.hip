@@ -84,22 +84,40 @@ __global__ __launch_bounds__(kWThreads, 2) void moments_wide_kernel(const T* con
     const int wr = wave >> 1, wc = wave & 1;
     constexpr bool NARROW = MODE == 1, FUSE = MODE == 2;
     static_assert(!FUSE || (sizeof(T) == 4 && MT * 8 == kWThreads), "tail fusion is laid out for the f32 tile");
+    // workgroups are handed to the 8 XCDs round-robin in launch order.  Remap so that all pairs of one row split run
+    // on the same XCD back to back: they walk the same rows at the same pace, so each K-panel is pulled from HBM once
+    // per split into that XCD's L2 instead of once per pair (every panel is used by ~nb pairs).
+    int bx, by;
+    {
+        const int nx = gridDim.x, ns = gridDim.y;
+        const int L = blockIdx.x + nx * blockIdx.y;
+        const int ns_full = ns & ~7;
+        if (L < nx * ns_full) {
+            const int xcd = L & 7, slot = L >> 3;
+            bx = slot % nx;
+            by = (slot / nx) * 8 + xcd;
+        } else {
+            const int R = L - nx * ns_full;
+            bx = R % nx;
+            by = ns_full + R / nx;
+        }
+    }
     int I, J;
     if constexpr (NARROW) {
-        I = i_first + blockIdx.x;
+        I = i_first + bx;
         J = nb - 1;
     } else {
-        pair_to_ij(blockIdx.x, nb_main, I, J);
+        pair_to_ij(bx, nb_main, I, J);
     }
     const int pair = ij_to_pair(I, J, nb), npairs = nb * (nb + 1) / 2;
     const bool diag = I == J;
     const int q = p + 2;
-    const int64_t r_begin = (int64_t)blockIdx.y * rows_per_split;
+    const int64_t r_begin = (int64_t)by * rows_per_split;
     const int64_t r_end = (r_begin + rows_per_split < n) ? r_begin + rows_per_split : n;
 
     // this thread's 4 chunks per panel: chunk id = tid + 256 u  ->  column id/8, 16-byte piece id%8
-    const T* ptrI[4];
-    const T* ptrJ[4];
+    gptr<T> ptrI[4];
+    gptr<T> ptrJ[4];
     int kindI[4], kindJ[4];  // 0 data column, 1 ones column, 2 zero padding
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -107,8 +125,8 @@ __global__ __launch_bounds__(kWThreads, 2) void moments_wide_kernel(const T* con
         const int cI = I * kWB + (id >> 3), cJ = ((FUSE && diag) ? nb - 1 : J) * kWB + (id >> 3);
         kindI[u] = (cI < p || cI == p + 1) ? 0 : (cI == p ? 1 : 2);
         kindJ[u] = (cJ < p || cJ == p + 1) ? 0 : (cJ == p ? 1 : 2);
-        ptrI[u] = cols[cI < p ? cI : p];  // index p is y in the device table
-        ptrJ[u] = cols[cJ < p ? cJ : p];
+        ptrI[u] = as_global(cols[cI < p ? cI : p]);  // index p is y in the device table
+        ptrJ[u] = as_global(cols[cJ < p ? cJ : p]);
     }
     (void)q;
 
@@ -122,10 +140,10 @@ __global__ __launch_bounds__(kWThreads, 2) void moments_wide_kernel(const T* con
             for (int pnl = 0; pnl < 2; ++pnl) {
                 if (pnl == 1 && diag && !(FUSE && u == 0)) continue;  // diagonal: J half unused, or the tail tile
                 const int kind = pnl ? kindJ[u] : kindI[u];
-                const T* ptr = pnl ? ptrJ[u] : ptrI[u];
+                const gptr<T> ptr = pnl ? ptrJ[u] : ptrI[u];
                 typename W::vec v;
                 if (kind == 0 && r + VL <= r_end) {
-                    v = *reinterpret_cast<const typename W::vec*>(ptr + r);
+                    v = *reinterpret_cast<gptr<typename W::vec>>(ptr + r);
                 } else {
 #pragma unroll
                     for (int e = 0; e < VL; ++e) {
@@ -246,10 +264,10 @@ __global__ __launch_bounds__(kWThreads, 2) void moments_wide_kernel(const T* con
         else mma_stage(std::integral_constant<int, NT>{}, std::integral_constant<int, NT>{});
     }
     // ---- write the partial tile: P[split][pair][i * 128 + j] (narrow: only the first MFMA tile column)
-    T* P = partials + ((int64_t)blockIdx.y * npairs + pair) * (kWB * kWB);
+    T* P = partials + ((int64_t)by * npairs + pair) * (kWB * kWB);
     if constexpr (FUSE) {
         if (tailwave) {  // rows t * 32.. of pair (I, nb-1), first tile column
-            T* PT = partials + ((int64_t)blockIdx.y * npairs + ij_to_pair(I, nb - 1, nb)) * (kWB * kWB);
+            T* PT = partials + ((int64_t)by * npairs + ij_to_pair(I, nb - 1, nb)) * (kWB * kWB);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31;

@@ -38,15 +38,15 @@ __global__ __launch_bounds__(kP2Threads) void pass2_kernel(const T* const* __res
     const int pp = p + bias;
     double sse = 0.0, wsse = 0.0;
     // loop-invariant, wave-uniform: column pointers and coefficients live in SGPRs
-    const T* cx[16];
+    gptr<T> cx[16];
     T bx[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
-        cx[c] = cols[c < p ? c : 0];
+        cx[c] = as_global(cols[c < p ? c : 0]);
         bx[c] = (c < p) ? beta[c] : T(0);
     }
-    const T* cy = cols[p];
-    const T* cw = WEIGHTED ? cols[p + 1] : cols[p];
+    const gptr<T> cy = as_global(cols[p]);
+    const gptr<T> cw = as_global(WEIGHTED ? cols[p + 1] : cols[p]);
     const T b0 = bias ? beta[p] : T(0);
     const int64_t nvec = (n + RPL - 1) / RPL;
     for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
@@ -57,9 +57,9 @@ __global__ __launch_bounds__(kP2Threads) void pass2_kernel(const T* const* __res
         if (full) {
 #pragma unroll
             for (int c = 0; c < 16; ++c)
-                if (c < p) x[c] = *reinterpret_cast<const V*>(cx[c] + row);
-            yv = *reinterpret_cast<const V*>(cy + row);
-            if (WEIGHTED) wv = *reinterpret_cast<const V*>(cw + row);
+                if (c < p) x[c] = *reinterpret_cast<gptr<V>>(cx[c] + row);
+            yv = *reinterpret_cast<gptr<V>>(cy + row);
+            if (WEIGHTED) wv = *reinterpret_cast<gptr<V>>(cw + row);
         } else {
 #pragma unroll
             for (int c = 0; c < 16; ++c)
@@ -177,12 +177,12 @@ __global__ __launch_bounds__(kP2Threads) void pass2_wide_kernel(const T* const* 
                                                                 T* __restrict__ pred_out, T* __restrict__ resid_out,
                                                                 double* __restrict__ partials) {
     double sse = 0.0, wsse = 0.0;
-    const T* cy = cols[p];
-    const T* cw = WEIGHTED ? cols[p + 1] : cols[p];
+    const gptr<T> cy = as_global(cols[p]);
+    const gptr<T> cw = as_global(WEIGHTED ? cols[p + 1] : cols[p]);
     const T b0 = bias ? beta[p] : T(0);
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
         T acc = b0;
-        for (int c = 0; c < p; ++c) acc += cols[c][r] * beta[c];
+        for (int c = 0; c < p; ++c) acc += as_global(cols[c])[r] * beta[c];
         const T res = cy[r] - acc;
         if (pred_out) pred_out[r] = acc;
         if (resid_out) resid_out[r] = res;

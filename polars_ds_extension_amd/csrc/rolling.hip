@@ -54,11 +54,11 @@ __device__ __forceinline__ bool fetch_row(const T* const* __restrict__ cols, con
 #pragma unroll
     for (int a = 0; a < PP; ++a) {
         double v = 0.0;
-        if (a < ra.p) v = in ? (double)cols[a][r] : 0.0;
+        if (a < ra.p) v = in ? (double)as_global(cols[a])[r] : 0.0;
         else if (a == ra.p && ra.bias) v = 1.0;
         z[a] = v;
     }
-    yv = in ? (double)cols[ra.p][r] : 0.0;
+    yv = in ? (double)as_global(cols[ra.p])[r] : 0.0;
     return in;
 }
 template <int PP>
