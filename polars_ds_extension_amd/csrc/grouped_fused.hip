@@ -224,34 +224,38 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
                 }
             }
         }
+        if (sp.lambda > 0.0) {  // ridge: lambda goes onto the diagonal while the matrix is still in LDS
+            PDS_WAVE_LDS_SYNC();
+            if (lane < p) Msc[lane * (kFQ + 1)] += sp.lambda;
+            if (BIAS && sp.lambda_on_bias && lane == 16) Msc[16 * (kFQ + 1)] += sp.lambda;
+        }
         PDS_WAVE_LDS_SYNC();
-        // ---- sub-group `npend` takes it into registers (solver layout: lane j = column j)
+        // ---- sub-group `npend` takes it into registers (solver layout: lane j = column j, a_p[i] = row i).
+        // Rows / columns beyond p' read scratch slot 15: whenever such a row exists p <= 15, and slot 15 then holds
+        // the exact zeros the matrix core produced from the zero-padded tile column -- so the 17 reads are
+        // unconditional, under ONE exec mask (the taking sub-group), instead of a select per element.
         {
             int j = j_in;
             asm volatile("" : "+v"(j));
-            const bool colv = j < pp;
-            const int lj = (j < p) ? j : 16;
-            const bool mine = sub == npend;
-            double dj = colv ? Msc[lj + kFQ * lj] : 1.0;
-            const bool lam = sp.lambda > 0.0 && colv && (j < p || sp.lambda_on_bias);
-            if (lam) dj += sp.lambda;
+            const int lj = (j < p) ? j : ((BIAS && j == p) ? 16 : 15);
+            if (sub == npend) {
+                const double* colp = Msc + kFQ * lj;
+                if (p >= LPS) {  // every row is a feature: immediate offsets, the reads pair up into 16-byte loads
 #pragma unroll
-            for (int i = 0; i < LPS; ++i) {
-                const int li = (i < p) ? i : 16;
-                double v = (colv && i < pp) ? Msc[li + kFQ * lj] : 0.0;
-                if (lam && i == j) v += sp.lambda;
-                if (mine) a_p[i] = v;
-                if constexpr (!CHOL) {
-                    const double bv = (i < pp) ? Msc[li + kFQ * 17] : 0.0;
-                    if (mine) b_p[i] = bv;
+                    for (int i = 0; i < LPS; ++i) {
+                        a_p[i] = colp[i];
+                        if constexpr (!CHOL) b_p[i] = Msc[i + kFQ * 17];
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < LPS; ++i) {
+                        const int li = (i < p) ? i : ((BIAS && i == p) ? 16 : 15);
+                        a_p[i] = colp[li];
+                        if constexpr (!CHOL) b_p[i] = Msc[li + kFQ * 17];
+                    }
                 }
-            }
-            if constexpr (CHOL) {
-                const double cv = colv ? Msc[lj + kFQ * 17] : 0.0;
-                if (mine) a_p[LPS] = cv;
-            }
-            if (mine) {
-                dj_p = dj;
+                if constexpr (CHOL) a_p[LPS] = Msc[lj + kFQ * 17];
+                dj_p = (j < pp) ? colp[lj] : 1.0;
                 null_p = ng < pp;  // per-group pl_lr raises "#Data < #features": reported as null
             }
         }

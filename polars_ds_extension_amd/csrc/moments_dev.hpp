@@ -176,9 +176,23 @@ __device__ __forceinline__ void consume_tile(const char* wl, int lane, int steps
     }
 }
 
-__device__ __forceinline__ double xor_sum_q(double v) {  // sum over the four row slots (lanes l, l^16, l^32, l^48)
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
+// sum over the four row slots (lanes l, l^16, l^32, l^48).  gfx950's v_permlane16_swap / v_permlane32_swap exchange
+// the odd rows (upper half) of one operand with the even rows (lower half) of the other: fed the same value twice they
+// leave {own-or-partner, partner-or-own}, whose sum is v + xor-partner(v) on every lane -- no LDS round trip
+// (__shfl_xor is ds_bpermute) and the same additions in the same order.
+__device__ __forceinline__ double xor_sum_q(double v) {
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+    }
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+    }
     return v;
 }
 

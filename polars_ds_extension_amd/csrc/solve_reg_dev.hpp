@@ -10,17 +10,22 @@ struct SolveRegDev {
     double lambda, ln_tol;
 };
 
+// Cross-lane moves of a double.  The f64 overload of update_dpp matters: with row_newbcast it is ONE v_mov_b64_dpp
+// (the only DPP control the DP ALU takes), where moving the halves as two ints cost 2 x (v_mov_b32 to seed `old` +
+// v_mov_b32_dpp).  Unmasked moves use bound_ctrl (lanes without a source read 0), which also spares the seeding
+// moves of the two-instruction forms (row_ror, quad_perm, row_half_mirror); `old` is only honoured with a bank mask.
 template <int CTRL, int BANK = 0xf>
 __device__ __forceinline__ double dpp_mov(double old, double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    int olo = __double2loint(old), ohi = __double2hiint(old);
-    lo = __builtin_amdgcn_update_dpp(olo, lo, CTRL, 0xf, BANK, false);
-    hi = __builtin_amdgcn_update_dpp(ohi, hi, CTRL, 0xf, BANK, false);
-    return __hiloint2double(hi, lo);
+    if constexpr (BANK == 0xf) {
+        (void)old;  // every unmasked caller passes 0
+        return __builtin_amdgcn_update_dpp(0.0, v, CTRL, 0xf, 0xf, true);
+    } else {
+        return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xf, BANK, false);
+    }
 }
 template <int CTRL>
 __device__ __forceinline__ int dpp_mov_i(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
 }
 
 constexpr int kRor8 = 0x128, kRor4 = 0x124, kRor2 = 0x122, kRor1 = 0x121;
