@@ -239,6 +239,23 @@ int pds_recursive_lr_f32(pds_ctx* ctx, const float* const* cols, int n_feat, int
                          float* coeffs, float* pred, uint8_t* valid);
 
 /*
+ * pds_recursive_lr_seeded_*: the expanding fit of a frame that CONTINUES earlier rows -- the row-sharded
+ * multi-GPU form of `pl_recursive_lr` ("recursive needs prefix Gram").  `seed_moments` is the
+ * HOST-resident augmented moment matrix A = Z'Z ((n_feat+2)^2, layout of pds_moments_*) of all rows in
+ * front of this frame (rank r passes the sum of the moment matrices of ranks < r; NULL = no rows = the
+ * plain call).  The fit at local row i is over seed + rows [0, i]; the seed's row count (entry [n_feat, n_feat]) counts
+ * towards start_with.  The seed must come from finite rows only.
+ */
+int pds_recursive_lr_seeded_f64(pds_ctx* ctx, const double* const* cols, int n_feat, int64_t n_rows,
+                                pds_space space, int add_bias, int64_t start_with, double lambda,
+                                const double* seed_moments, double* coeffs, double* pred,
+                                uint8_t* valid);
+int pds_recursive_lr_seeded_f32(pds_ctx* ctx, const float* const* cols, int n_feat, int64_t n_rows,
+                                pds_space space, int add_bias, int64_t start_with, float lambda,
+                                const float* seed_moments, float* coeffs, float* pred,
+                                uint8_t* valid);
+
+/*
  * Moment-level entry points (what a multi-GPU host composes; also the measured Gram build).
  *
  * pds_moments_*: one streaming pass over [y | X] building the augmented moment matrix

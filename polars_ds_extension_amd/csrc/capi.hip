@@ -723,11 +723,23 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
 template <typename T>
 static int rolling_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t n_rows, pds_space space, int add_bias,
                         int64_t window, int64_t min_size, double lambda, bool expanding, T* coeffs, T* pred,
-                        uint8_t* valid) {
+                        uint8_t* valid, const T* seed_moments = nullptr) {
     if (!ctx || !cols || !coeffs || !pred || !valid) return fail(PDS_ERR_INVALID, "null argument");
     if (int rc = check_shape(n_feat, n_rows, add_bias)) return rc;
     const int pp = n_feat + (add_bias ? 1 : 0);
-    if (window < 1 || window > n_rows) return fail(PDS_ERR_INVALID, "window / start_with must be in [1, n_rows]");
+    std::vector<double> seed;
+    if (seed_moments) {  // rows in front of this frame: they count towards start_with
+        const int q = n_feat + 2;
+        seed.assign(seed_moments, seed_moments + (size_t)q * q);
+        for (double v : seed)
+            if (!std::isfinite(v)) return fail(PDS_ERR_INVALID, "seed moments must be finite");
+        const double seen = seed[n_feat + (size_t)n_feat * q];
+        if (window < 1 || seen < 0.0) return fail(PDS_ERR_INVALID, "start_with must be >= 1 and the seed row count >= 0");
+        const double left = (double)window - seen;
+        window = left <= 1.0 ? 1 : (left > (double)n_rows ? n_rows + 1 : (int64_t)left);
+    } else if (window < 1 || window > n_rows) {
+        return fail(PDS_ERR_INVALID, "window / start_with must be in [1, n_rows]");
+    }
     PDS_HIP_CHECK(hipSetDevice(ctx->device));
     size_t need = 131072 + ((size_t)(n_rows / 4096) + 2) * 96 * sizeof(double);  // + per-tile totals (expanding)
     if (space == PDS_HOST) need += (size_t)n_rows * ((pp + 1) * sizeof(T) + 1) + 4096;
@@ -742,7 +754,8 @@ static int rolling_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
         d_pr = reinterpret_cast<T*>(ws_take(ctx, (size_t)n_rows * sizeof(T)));
         d_va = reinterpret_cast<uint8_t*>(ws_take(ctx, (size_t)n_rows));
     }
-    if (int rc = launch_rolling<T>(ctx, dc, n_feat, n_rows, add_bias, window, min_size, lambda, expanding, d_co, d_pr, d_va))
+    if (int rc = launch_rolling<T>(ctx, dc, n_feat, n_rows, add_bias, window, min_size, lambda, expanding,
+                                   seed.empty() ? nullptr : seed.data(), d_co, d_pr, d_va))
         return rc;
     if (space == PDS_HOST) {
         PDS_HIP_CHECK(hipMemcpyAsync(coeffs, d_co, (size_t)n_rows * pp * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
@@ -974,6 +987,19 @@ int pds_recursive_lr_f64(pds_ctx* ctx, const double* const* cols, int n_feat, in
 int pds_recursive_lr_f32(pds_ctx* ctx, const float* const* cols, int n_feat, int64_t n_rows, pds_space space,
                          int add_bias, int64_t start_with, float lambda, float* coeffs, float* pred, uint8_t* valid) {
     return rolling_impl<float>(ctx, cols, n_feat, n_rows, space, add_bias, start_with, 0, lambda, true, coeffs, pred, valid);
+}
+
+int pds_recursive_lr_seeded_f64(pds_ctx* ctx, const double* const* cols, int n_feat, int64_t n_rows, pds_space space,
+                                int add_bias, int64_t start_with, double lambda, const double* seed_moments,
+                                double* coeffs, double* pred, uint8_t* valid) {
+    return rolling_impl<double>(ctx, cols, n_feat, n_rows, space, add_bias, start_with, 0, lambda, true, coeffs, pred, valid,
+                                seed_moments);
+}
+int pds_recursive_lr_seeded_f32(pds_ctx* ctx, const float* const* cols, int n_feat, int64_t n_rows, pds_space space,
+                                int add_bias, int64_t start_with, float lambda, const float* seed_moments, float* coeffs,
+                                float* pred, uint8_t* valid) {
+    return rolling_impl<float>(ctx, cols, n_feat, n_rows, space, add_bias, start_with, 0, lambda, true, coeffs, pred, valid,
+                               seed_moments);
 }
 
 int pds_moments_f64(pds_ctx* ctx, const double* const* cols, const double* weights, int n_feat, int64_t n_rows,

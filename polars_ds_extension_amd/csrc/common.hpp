@@ -204,8 +204,8 @@ size_t null_policy_workspace(int n_cols, int64_t n_rows, size_t elem);
 // ---- rolling.hip ----
 template <typename T>
 int launch_rolling(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, int add_bias,
-                   int64_t window, int64_t min_size, double lambda, bool expanding, T* d_coeffs,
-                   T* d_pred, uint8_t* d_valid);
+                   int64_t window, int64_t min_size, double lambda, bool expanding, const double* seed_moments,
+                   T* d_coeffs, T* d_pred, uint8_t* d_valid);
 
 // ---- stats.cpp ----
 double student_t_sf(double x, double df, bool* err);

@@ -245,10 +245,12 @@ __global__ __launch_bounds__(kRollWaves * 64) void rolling_kernel(const T* const
 }
 
 // exclusive prefix over the per-tile totals (expanding window), one wave, lane = moment
-__global__ __launch_bounds__(64) void tile_prefix_kernel(double* __restrict__ tot, int64_t ntiles, int nv) {
+// (`seed`: moments of rows that precede this frame -- the row-sharded multi-GPU expanding fit -- or nullptr)
+__global__ __launch_bounds__(64) void tile_prefix_kernel(double* __restrict__ tot, int64_t ntiles, int nv,
+                                                         const double* __restrict__ seed) {
     const int lane = threadIdx.x;
     if (lane >= nv) return;
-    double run = 0.0;
+    double run = seed ? seed[lane] : 0.0;
     int64_t t = 0;
     for (; t + 8 <= ntiles; t += 8) {
         double v[8];
@@ -268,8 +270,8 @@ __global__ __launch_bounds__(64) void tile_prefix_kernel(double* __restrict__ to
 }
 
 template <typename T, int PP>
-static int launch_pp(pds_ctx* ctx, const DeviceCols<T>& dc, RollArgs ra, bool expanding, T* d_coeffs, T* d_pred,
-                     uint8_t* d_valid) {
+static int launch_pp(pds_ctx* ctx, const DeviceCols<T>& dc, RollArgs ra, bool expanding, const double* seed_moments,
+                     T* d_coeffs, T* d_pred, uint8_t* d_valid) {
     constexpr int NV = RollDims<PP>::NV;
     const size_t lds = (size_t)kRollWaves * NV * kLdsStride * sizeof(double);
     ra.tile_rows = kTileRows;
@@ -286,10 +288,26 @@ static int launch_pp(pds_ctx* ctx, const DeviceCols<T>& dc, RollArgs ra, bool ex
                            dc.d_ptrs, ra, (double*)nullptr, d_coeffs, d_pred, d_valid);
     } else {
         double* tot = reinterpret_cast<double*>(ws_take(ctx, (size_t)ntiles * NV * sizeof(double)));
+        double* d_seed = nullptr;
+        if (seed_moments) {
+            // augmented (p+2)^2 moment matrix (pds_moments layout, Z = [x | 1 | y]) -> this kernel's moment vector:
+            // upper triangle of z z' with z = [x, (1)], then z y, then the row count
+            const int p = ra.p, q = ra.p + 2;
+            double h[RollDims<PP>::NV];
+            auto zi = [&](int a) { return a < p ? a : p; };
+            int v = 0;
+            for (int a = 0; a < PP; ++a)
+                for (int b = a; b < PP; ++b) h[v++] = (a < ra.pp && b < ra.pp) ? seed_moments[zi(a) + (size_t)zi(b) * q] : 0.0;
+            for (int a = 0; a < PP; ++a) h[v++] = (a < ra.pp) ? seed_moments[zi(a) + (size_t)(p + 1) * q] : 0.0;
+            h[v++] = seed_moments[p + (size_t)p * q];
+            d_seed = reinterpret_cast<double*>(ws_take(ctx, NV * sizeof(double)));
+            PDS_HIP_CHECK(hipMemcpyAsync(d_seed, h, NV * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // h is on this stack frame
+        }
         ra.mode = 1;
         hipLaunchKernelGGL((rolling_kernel<T, PP>), dim3((unsigned)nb), dim3(kRollWaves * 64), lds, ctx->stream,
                            dc.d_ptrs, ra, tot, d_coeffs, d_pred, d_valid);
-        hipLaunchKernelGGL(tile_prefix_kernel, dim3(1), dim3(64), 0, ctx->stream, tot, ntiles, NV);
+        hipLaunchKernelGGL(tile_prefix_kernel, dim3(1), dim3(64), 0, ctx->stream, tot, ntiles, NV, d_seed);
         ra.mode = 2;
         hipLaunchKernelGGL((rolling_kernel<T, PP>), dim3((unsigned)nb), dim3(kRollWaves * 64), lds, ctx->stream,
                            dc.d_ptrs, ra, tot, d_coeffs, d_pred, d_valid);
@@ -300,7 +318,8 @@ static int launch_pp(pds_ctx* ctx, const DeviceCols<T>& dc, RollArgs ra, bool ex
 
 template <typename T>
 int launch_rolling(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, int add_bias, int64_t window,
-                   int64_t min_size, double lambda, bool expanding, T* d_coeffs, T* d_pred, uint8_t* d_valid) {
+                   int64_t min_size, double lambda, bool expanding, const double* seed_moments, T* d_coeffs, T* d_pred,
+                   uint8_t* d_valid) {
     RollArgs ra;
     ra.p = n_feat;
     ra.bias = add_bias ? 1 : 0;
@@ -312,18 +331,18 @@ int launch_rolling(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_
     ra.mode = 0;
     ra.tile_rows = kTileRows;
     const int pp = ra.pp;
-    if (pp <= 2) return launch_pp<T, 2>(ctx, dc, ra, expanding, d_coeffs, d_pred, d_valid);
-    if (pp <= 4) return launch_pp<T, 4>(ctx, dc, ra, expanding, d_coeffs, d_pred, d_valid);
-    if (pp <= 6) return launch_pp<T, 6>(ctx, dc, ra, expanding, d_coeffs, d_pred, d_valid);
-    if (pp <= 8) return launch_pp<T, 8>(ctx, dc, ra, expanding, d_coeffs, d_pred, d_valid);
-    if (pp <= 10) return launch_pp<T, 10>(ctx, dc, ra, expanding, d_coeffs, d_pred, d_valid);
-    if (pp <= 12) return launch_pp<T, 12>(ctx, dc, ra, expanding, d_coeffs, d_pred, d_valid);
+    if (pp <= 2) return launch_pp<T, 2>(ctx, dc, ra, expanding, seed_moments, d_coeffs, d_pred, d_valid);
+    if (pp <= 4) return launch_pp<T, 4>(ctx, dc, ra, expanding, seed_moments, d_coeffs, d_pred, d_valid);
+    if (pp <= 6) return launch_pp<T, 6>(ctx, dc, ra, expanding, seed_moments, d_coeffs, d_pred, d_valid);
+    if (pp <= 8) return launch_pp<T, 8>(ctx, dc, ra, expanding, seed_moments, d_coeffs, d_pred, d_valid);
+    if (pp <= 10) return launch_pp<T, 10>(ctx, dc, ra, expanding, seed_moments, d_coeffs, d_pred, d_valid);
+    if (pp <= 12) return launch_pp<T, 12>(ctx, dc, ra, expanding, seed_moments, d_coeffs, d_pred, d_valid);
     return fail(PDS_ERR_UNSUPPORTED, "rolling / recursive: at most 12 coefficients (features + bias) in this build");
 }
 
 template int launch_rolling<double>(pds_ctx*, const DeviceCols<double>&, int, int64_t, int, int64_t, int64_t, double,
-                                    bool, double*, double*, uint8_t*);
+                                    bool, const double*, double*, double*, uint8_t*);
 template int launch_rolling<float>(pds_ctx*, const DeviceCols<float>&, int, int64_t, int, int64_t, int64_t, double, bool,
-                                   float*, float*, uint8_t*);
+                                   const double*, float*, float*, uint8_t*);
 
 }  // namespace pds

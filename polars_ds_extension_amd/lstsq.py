@@ -413,7 +413,7 @@ def lin_reg_by(*x, target, group_offsets, add_bias: bool = False, l2_reg: float 
     return coeffs, nulls
 
 
-def _windowed(name, x, target, n, add_bias, l2_reg, min_size, ctx):
+def _windowed(name, x, target, n, add_bias, l2_reg, min_size, ctx, seed_moments=None):
     ctx = ctx or default_context()
     cols = _Cols(target, x)
     _follow(ctx, cols)
@@ -425,6 +425,15 @@ def _windowed(name, x, target, n, add_bias, l2_reg, min_size, ctx):
     if name == "pds_rolling_lr":
         _lib.check(ctx.fn(name)(ctx._h, cols.cols, cols.n_feat, C.c_int64(cols.n_rows), cols.space, int(bool(add_bias)),
                                 C.c_int64(n), C.c_int64(min_size), lam, co_p, pr_p, va_p))
+    elif seed_moments is not None:
+        q = cols.n_feat + 2
+        seed = np.asarray(seed_moments.cpu() if _is_torch(seed_moments) else seed_moments, dtype=_dtype())
+        if seed.shape != (q, q):
+            raise ValueError(f"seed_moments must be the ({q}, {q}) augmented moment matrix of the preceding rows")
+        seed = np.asfortranarray(seed)
+        _lib.check(ctx.fn("pds_recursive_lr_seeded")(ctx._h, cols.cols, cols.n_feat, C.c_int64(cols.n_rows), cols.space,
+                                                     int(bool(add_bias)), C.c_int64(n), lam, C.c_void_p(seed.ctypes.data),
+                                                     co_p, pr_p, va_p))
     else:
         _lib.check(ctx.fn(name)(ctx._h, cols.cols, cols.n_feat, C.c_int64(cols.n_rows), cols.space, int(bool(add_bias)),
                                 C.c_int64(n), lam, co_p, pr_p, va_p))
@@ -451,12 +460,17 @@ def rolling_lin_reg(*x, target, window_size: int, add_bias: bool = False, l2_reg
     return _windowed("pds_rolling_lr", x, target, window_size, add_bias, l2_reg, min_size, ctx)
 
 
-def recursive_lin_reg(*x, target, start_with: int, add_bias: bool = False, l2_reg: float = 0.0, ctx: Context | None = None):
-    """pds.recursive_lin_reg (pl_recursive_lr): expanding-window fit from row start_with-1 on."""
+def recursive_lin_reg(*x, target, start_with: int, add_bias: bool = False, l2_reg: float = 0.0, ctx: Context | None = None,
+                      seed_moments=None):
+    """
+    pds.recursive_lin_reg (pl_recursive_lr): expanding-window fit from row start_with-1 on.
+    seed_moments (the gram_moments matrix of rows that precede this frame) continues an earlier frame: the
+    row-sharded multi-GPU form, see parallel.recursive_lin_reg_row_sharded.
+    """
     n_features = len(x) + int(bool(add_bias))
     if start_with < n_features:
         raise ValueError("# features > number of rows for the initial fit.")  # expr_linear.py:455-459
-    return _windowed("pds_recursive_lr", x, target, start_with, add_bias, l2_reg, 0, ctx)
+    return _windowed("pds_recursive_lr", x, target, start_with, add_bias, l2_reg, 0, ctx, seed_moments=seed_moments)
 
 
 def gram_moments(*x, target, weights=None, ctx: Context | None = None, out_device: bool = False):

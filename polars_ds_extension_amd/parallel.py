@@ -10,9 +10,14 @@ The reference has no distributed layer at all; what shards
     all-reduce(SUM) of that (p+2)^2 block (2.6 KB at p = 16 -- latency bound, any algorithm) makes the
     normal equations global; the O(p^3) solve is replicated.  lin_reg_report adds one more all-reduce of
     (sum e^2, sum w e^2) after the residual pass.
+  * rolling regressions shard BY ROW RANGE with a halo: rank r also reads the window-1 rows in front of its range
+    (its windows reach back into them) and drops their outputs; no collective.  Expanding ("recursive")
+    regressions need what came before: every rank builds the moment matrix of its rows, ONE all-gather of
+    those (p+2)^2 blocks gives each rank the exclusive prefix, which seeds its local expanding fit
+    (pds_recursive_lr_seeded_*).
   * coordinate-descent sweeps do not shard (sequential Gauss-Seidel on a p x p matrix): replicas only.
 
-The compute steps are injected (`moments_fn`, `solve_fn`, `grouped_fn`) so the orchestration can be
+The compute steps are injected (`moments_fn`, `solve_fn`, `grouped_fn`, `rolling_fn`, `recursive_fn`) so the orchestration can be
 exercised on CPU with the gloo backend (tests/test_parallel_gloo.py); by default they are the HIP path.
 """
 from __future__ import annotations
@@ -149,3 +154,65 @@ def lin_reg_by_group_sharded(xs, y, group_offsets, *, rank: int | None = None, w
         dist.send(co_t.contiguous(), dst=gather_to, group=group)
         dist.send(nu_t.contiguous(), dst=gather_to, group=group)
     return g_lo, g_hi, co, nu
+
+
+def _hip_rolling(xs, y, **kw):
+    from . import lstsq
+
+    return lstsq.rolling_lin_reg(*xs, target=y, **kw)
+
+
+def _hip_recursive(xs, y, **kw):
+    from . import lstsq
+
+    return lstsq.recursive_lin_reg(*xs, target=y, **kw)
+
+
+def rolling_lin_reg_row_sharded(xs, y, window_size: int, *, rank: int | None = None, world: int | None = None,
+                                rolling_fn: Callable | None = None, group=None, **rolling_kwargs):
+    """
+    pds.rolling_lin_reg over a frame every rank can slice (`xs`, `y`: the whole columns as visible to this rank).
+    Rank r owns output rows [lo, hi) = shard_bounds(N, world, r) and runs the rolling kernel on rows
+    [lo - (window_size - 1), hi): the halo rows only feed the first windows, their outputs are dropped.  Returns
+    (lo, hi, coeffs_local, pred_local, valid_local); rows < window_size - 1 of the frame stay invalid on rank 0.
+    No collective on the data path (outputs stay sharded like the inputs).
+    """
+    dist = _dist()
+    rank = dist.get_rank(group) if rank is None else rank
+    world = dist.get_world_size(group) if world is None else world
+    rolling_fn = rolling_fn or _hip_rolling
+    n = len(y)
+    lo, hi = shard_bounds(n, world, rank)
+    if hi <= lo:
+        return lo, hi, None, None, None
+    h0 = max(0, lo - (int(window_size) - 1))
+    if hi - h0 < window_size:  # (only a frame shorter than one window) nothing valid here
+        return lo, hi, None, None, None
+    co, pr, va = rolling_fn([x[h0:hi] for x in xs], y[h0:hi], window_size=window_size, **rolling_kwargs)
+    k = lo - h0
+    return lo, hi, co[k:], pr[k:], va[k:]
+
+
+def recursive_lin_reg_row_sharded(xs_local: Sequence, y_local, start_with: int, *, moments_fn: Callable | None = None,
+                                  recursive_fn: Callable | None = None, group=None, **recursive_kwargs):
+    """
+    pds.recursive_lin_reg over row-sharded columns (rank r holds the r-th contiguous row range).  One all-gather of
+    the per-rank moment matrices; rank r seeds its expanding fit with the sum of the matrices of ranks < r.
+    Returns this rank's (coeffs, pred, valid).
+    """
+    import torch
+
+    dist = _dist()
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    moments_fn = moments_fn or _hip_moments
+    recursive_fn = recursive_fn or _hip_recursive
+    m = moments_fn(xs_local, y_local, None)
+    if not isinstance(m, torch.Tensor):
+        m = torch.as_tensor(np.asarray(m))
+    m = m.contiguous()
+    blocks = [torch.empty_like(m) for _ in range(world)]
+    dist.all_gather(blocks, m, group=group)  # the one exchange step: world x (p+2)^2 values
+    seed = None
+    if rank > 0:
+        seed = torch.stack(blocks[:rank]).sum(dim=0)  # fixed order: identical on every run
+    return recursive_fn(xs_local, y_local, start_with=start_with, seed_moments=seed, **recursive_kwargs)

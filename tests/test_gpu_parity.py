@@ -355,6 +355,53 @@ def test_recursive_vs_oracle(pds, orc):
             assert nrel(co[i], direct) < F64_TOL
 
 
+@pytest.mark.parametrize("bias,lam", [(True, 0.0), (False, 0.0), (True, 0.03)])
+def test_recursive_seeded_continues_a_frame(pds, bias, lam):
+    # row-sharded expanding fit = local fit seeded with the moment matrix of the rows in front of the shard
+    rng = np.random.default_rng(21)
+    n, p = 40_000, 5
+    X = rng.random((n, p))
+    y = X @ rng.normal(size=p) + 0.4 + rng.normal(size=n) * 0.1
+    n0 = 9
+    co, pr, va = pds.recursive_lin_reg(*cols_of(X), target=dev(y), start_with=n0, add_bias=bias, l2_reg=lam)
+    co, pr, va = co.cpu().numpy(), pr.cpu().numpy(), va.cpu().numpy()
+    for k in (4, 13_337):  # cut before start_with is reached / deep inside
+        seed = pds.gram_moments(*cols_of(X[:k]), target=dev(y[:k]))
+        co2, pr2, va2 = pds.recursive_lin_reg(*cols_of(X[k:]), target=dev(y[k:]), start_with=n0, add_bias=bias, l2_reg=lam,
+                                              seed_moments=seed)
+        co2, pr2, va2 = co2.cpu().numpy(), pr2.cpu().numpy(), va2.cpu().numpy()
+        assert np.array_equal(va2, va[k:])
+        ok = va[k:].astype(bool)
+        ok[: max(0, 60 - k)] = False  # the very first fits are near-singular
+        err = np.linalg.norm(co2[ok] - co[k:][ok], axis=1) / np.linalg.norm(co[k:][ok], axis=1)
+        assert np.max(err) < 1e-9
+        assert np.max(np.abs(pr2[ok] - pr[k:][ok])) < 1e-9
+    # a seed that is not the (p+2)^2 block is refused
+    with pytest.raises(ValueError):
+        pds.recursive_lin_reg(*cols_of(X), target=dev(y), start_with=n0, seed_moments=np.zeros((3, 3)))
+
+
+def test_rolling_halo_shards_equal_single_frame(pds):
+    # rolling shards by row range with a (window - 1)-row halo; no collective
+    rng = np.random.default_rng(22)
+    n, p, w = 50_000, 4, 128
+    X = rng.random((n, p))
+    y = X @ rng.normal(size=p) - 0.2 + rng.normal(size=n) * 0.05
+    co, pr, va = pds.rolling_lin_reg(*cols_of(X), target=dev(y), window_size=w, add_bias=True)
+    co, pr, va = co.cpu().numpy(), pr.cpu().numpy(), va.cpu().numpy()
+    from polars_ds_extension_amd import parallel as par
+
+    for world in (2, 3):
+        for r in range(world):
+            lo, hi = par.shard_bounds(n, world, r)
+            h0 = max(0, lo - (w - 1))
+            c2, p2, v2 = pds.rolling_lin_reg(*cols_of(X[h0:hi]), target=dev(y[h0:hi]), window_size=w, add_bias=True)
+            c2, p2, v2 = c2.cpu().numpy()[lo - h0 :], p2.cpu().numpy()[lo - h0 :], v2.cpu().numpy()[lo - h0 :]
+            assert np.array_equal(v2, va[lo:hi])
+            ok = v2.astype(bool)
+            assert np.max(np.abs(c2[ok] - co[lo:hi][ok])) < 1e-9 and np.max(np.abs(p2[ok] - pr[lo:hi][ok])) < 1e-9
+
+
 def test_rolling_skip_non_finite(pds, orc):
     rng = np.random.default_rng(9)
     n = 3000

@@ -65,7 +65,62 @@ def _worker(rank, world, port, q):
 
         g_lo, g_hi, co, nu = par.lin_reg_by_group_sharded([X[:, j] for j in range(p)], y, off, grouped_fn=grouped_fn,
                                                           gather_to=0, add_bias=False)
-        out = {"rank": rank, "err_rows": err_rows, "range": (g_lo, g_hi)}
+        # ---- rolling, row-sharded with a (window - 1)-row halo; compute step = the sequential oracle
+        win = 37
+
+        def rolling_fn(xs, yy, window_size, add_bias=False, **kw):
+            Xl = np.stack(xs, axis=1)
+            if add_bias:
+                Xl = np.c_[Xl, np.ones(len(yy))]
+            co = orc.rolling_lr(Xl, yy, window_size)
+            full = np.full((len(yy), Xl.shape[1]), np.nan)
+            full[window_size - 1 :] = co
+            va = np.zeros(len(yy), dtype=np.uint8)
+            va[window_size - 1 :] = 1
+            return full, np.einsum("ij,ij->i", Xl, np.nan_to_num(full)), va
+
+        nr = 2003
+        r_lo, r_hi, rco, rpr, rva = par.rolling_lin_reg_row_sharded([X[:nr, j] for j in range(p)], y[:nr], win,
+                                                                      rolling_fn=rolling_fn, add_bias=True)
+        ref_roll = orc.rolling_lr(np.c_[X[:nr], np.ones(nr)], y[:nr], win)  # rows win-1 .. nr-1
+        first = max(r_lo, win - 1)
+        err_roll = float(np.max(np.abs(rco[first - r_lo :] - ref_roll[first - (win - 1) : r_hi - (win - 1)])))
+        roll_valid_ok = bool(np.all(rva[first - r_lo :] == 1) and np.all(rva[: first - r_lo] == 0))
+
+        # ---- expanding ("recursive"), row-sharded: all-gather of moment blocks, exclusive prefix seeds each rank
+        n0 = 11
+
+        def rec_moments_fn(xs, yy, w):
+            Z = np.c_[np.stack(xs, axis=1), np.ones(len(yy)), yy]
+            return torch.from_numpy(np.ascontiguousarray(Z.T @ Z))
+
+        def recursive_fn(xs, yy, start_with, seed_moments=None, add_bias=False, **kw):
+            Xl = np.stack(xs, axis=1)
+            k = Xl.shape[1]
+            if add_bias:
+                Xl = np.c_[Xl, np.ones(len(yy))]
+            pp_ = Xl.shape[1]
+            G = np.zeros((pp_, pp_)); c = np.zeros(pp_); seen = 0.0
+            if seed_moments is not None:
+                M = seed_moments.numpy()
+                idx = list(range(k)) + ([k] if add_bias else [])
+                G = M[np.ix_(idx, idx)].copy(); c = M[idx, k + 1].copy(); seen = M[k, k]
+            out = np.full((len(yy), pp_), np.nan); va = np.zeros(len(yy), dtype=np.uint8)
+            for i in range(len(yy)):
+                G += np.outer(Xl[i], Xl[i]); c += Xl[i] * yy[i]; seen += 1
+                if seen >= start_with:
+                    out[i] = np.linalg.solve(G, c); va[i] = 1
+            return out, None, va
+
+        e_lo, e_hi = par.shard_bounds(nr, world, rank)
+        eco, _, eva = par.recursive_lin_reg_row_sharded([X[e_lo:e_hi, j] for j in range(p)], y[e_lo:e_hi], n0,
+                                                        moments_fn=rec_moments_fn, recursive_fn=recursive_fn, add_bias=True)
+        ref_rec = orc.recursive_lr(np.c_[X[:nr], np.ones(nr)], y[:nr], n0)  # rows n0-1 .. nr-1
+        first = max(e_lo, n0 - 1)
+        err_rec = float(np.max(np.abs(eco[first - e_lo :] - ref_rec[first - (n0 - 1) : e_hi - (n0 - 1)])))
+        rec_valid_ok = bool(np.all(eva[first - e_lo :] == 1) and np.all(eva[: first - e_lo] == 0))
+        out = {"rank": rank, "err_rows": err_rows, "range": (g_lo, g_hi), "err_roll": err_roll, "roll_valid_ok": roll_valid_ok,
+               "err_rec": err_rec, "rec_valid_ok": rec_valid_ok}
         if rank == 0:
             ref_co, ref_nu = orc.grouped_lr([y] + [X[:, j] for j in range(p)], off)
             out["groups"] = ng
@@ -110,3 +165,7 @@ def test_world2_gloo():
     assert all(o["err_rows"] < 1e-11 for o in outs)  # all-reduced moments -> same solution on every rank
     assert outs[0]["range"][1] == outs[1]["range"][0] and outs[0]["range"][0] == 0 and outs[1]["range"][1] == outs[0]["groups"]
     assert outs[0]["gathered"][0] == outs[0]["groups"] and outs[0]["err_groups"] < 1e-12 and outs[0]["null_equal"]
+    # halo-sharded rolling == the sequential chain over the whole frame (the chain of rank 1 starts at its halo,
+    # so it differs from the reference's never re-anchored chain by that chain's own round-off only)
+    assert all(o["err_roll"] < 1e-8 and o["roll_valid_ok"] for o in outs)
+    assert all(o["err_rec"] < 1e-8 and o["rec_valid_ok"] for o in outs)
