@@ -254,6 +254,7 @@ __device__ __forceinline__ void solve_core(double (&a)[LPS], double (&b)[LPS], d
 template <int LPS, int K>
 __device__ __forceinline__ void chol_step(double (&a)[LPS + 1], int j, int pp, double& rinv_j, double& dcap,
                                           bool& ok) {
+    if constexpr (LPS == 16) asm volatile("s_nop 1" ::: "memory");  // see the inline-asm update below
     const double d = Grp<LPS>::template bcast<K>(a[K]);
     ok = ok && (d > 0.0);
     // 1/sqrt(d): hardware estimate (v_rsq_f64) + two Newton steps -- a third of the instructions of sqrt + divide,
@@ -264,10 +265,21 @@ __device__ __forceinline__ void chol_step(double (&a)[LPS + 1], int j, int pp, d
     // lanes <= K keep their finished columns (their a[i], i > K, are the unscaled l_iK): a zero multiplier instead
     // of a select per element.  DPP reads from EXEC-disabled lanes are invalid, so every lane takes part.
     const double t = (j > K) ? a[K] * r * r : 0.0;  // l_jK / l_KK
+    if constexpr (LPS == 16) {
+        // a[i] += bcast_K(a[i]) * (-t) as ONE instruction per row: the DP ALU takes row_newbcast on its first source
+        // (the compiler only ever emits v_mov_b64_dpp + v_fma_f64 for this).  The 2-wait-state rule between a VALU
+        // write and a DPP read of the same register is ours to keep inside inline asm: a[i] was last written one
+        // whole elimination step ago, and chol_step opens with an s_nop for the shortest steps.
+        const double nt = -t;
 #pragma unroll
-    for (int i = K + 1; i <= LPS; ++i) {
-        const double v = Grp<LPS>::template bcast<K>(a[i]);
-        a[i] = fma(-v, t, a[i]);
+        for (int i = K + 1; i <= LPS; ++i)
+            asm volatile("v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(nt), "n"(K));
+    } else {
+#pragma unroll
+        for (int i = K + 1; i <= LPS; ++i) {
+            const double v = Grp<LPS>::template bcast<K>(a[i]);
+            a[i] = fma(-v, t, a[i]);
+        }
     }
     if (j == K) {
         rinv_j = r;
