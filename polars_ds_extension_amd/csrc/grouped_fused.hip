@@ -120,6 +120,77 @@ __device__ __forceinline__ void consume_range(const char* wl, int lane, int rel0
     }
 }
 
+// p <= 8: TWO 4-row slabs per matrix instruction.  Operand columns 0-7 carry the features of rows 8s+q, columns 8-15
+// the same features of rows 8s+4+q; the product's two diagonal 8 x 8 blocks are the Gram contributions of the two
+// slabs (the off-diagonal blocks are cross terms nobody reads), folded together at flush time.  Half the MFMAs per
+// row -- at 8 features the f64 matrix pipe (86 clk per 16x16x4) is as scarce as HBM bandwidth.
+template <typename T, bool BIAS>
+__device__ __forceinline__ void consume_range_pack(const char* wl, int lane, int rel0, int rel1, WaveAcc& a) {
+    const int f = lane & 15, q = lane >> 4;
+    const int roff = q + 4 * (f >> 3);  // this lane's row inside an 8-row step
+    const T* xcol = reinterpret_cast<const T*>(wl + (f & 7) * kColStride) + roff;
+    const T* ycol = reinterpret_cast<const T*>(wl + kSlotY * kColStride) + roff;
+    int s0 = rel0 >> 3;
+    const int s1 = (rel1 + 7) >> 3;  // exclusive
+    using Acc = typename Tile<T>::acc;
+    Acc acc;
+    double xy, cs, yy, ys;
+    if constexpr (sizeof(T) == 8) {
+        acc = Acc{a.d[0], a.d[1], a.d[2], a.d[3]};
+        xy = a.xy; cs = a.cs; yy = a.yy; ys = a.ys;
+    } else {
+        acc = Acc{0, 0, 0, 0};
+        xy = cs = yy = ys = 0.0;
+    }
+    T fxy = 0, fcs = 0, fyy = 0, fys = 0;
+    auto step_v = [&](T x, T yv) __attribute__((always_inline)) {
+        acc = Tile<T>::mfma(x, x, acc);
+        if constexpr (sizeof(T) == 8) {
+            xy = fma(x, yv, xy);
+            if constexpr (BIAS) {
+                cs += x;
+                ys += yv;
+            }
+        } else {
+            fxy = fmaf(x, yv, fxy);
+            if constexpr (BIAS) {
+                fcs += x;
+                fys += yv;
+            }
+        }
+    };
+    auto step_m = [&](int s) __attribute__((always_inline)) {  // a step that straddles rel0 and / or rel1
+        const int r = 8 * s + roff;
+        const bool in = r >= rel0 && r < rel1;
+        const T x = in ? xcol[8 * s] : T(0);
+        const T yv = in ? ycol[8 * s] : T(0);
+        step_v(x, yv);
+    };
+    if (rel0 & 7) {
+        step_m(s0);
+        ++s0;
+    }
+    const int sfull = rel1 >> 3;  // steps [s0, sfull) are complete
+    int s = s0;
+    for (; s + 4 <= sfull; s += 4) {
+        const T x0 = xcol[8 * s], x1 = xcol[8 * s + 8], x2 = xcol[8 * s + 16], x3 = xcol[8 * s + 24];
+        const T y0 = ycol[8 * s], y1 = ycol[8 * s + 8], y2 = ycol[8 * s + 16], y3 = ycol[8 * s + 24];
+        step_v(x0, y0);
+        step_v(x1, y1);
+        step_v(x2, y2);
+        step_v(x3, y3);
+    }
+    for (; s < sfull; ++s) step_v(xcol[8 * s], ycol[8 * s]);
+    if ((rel1 & 7) && sfull >= s0 && sfull < s1) step_m(sfull);
+    if constexpr (sizeof(T) == 8) {
+        a.d[0] = acc[0]; a.d[1] = acc[1]; a.d[2] = acc[2]; a.d[3] = acc[3];
+        a.xy = xy; a.cs = cs; a.yy = yy; a.ys = ys;
+    } else {
+        a.d[0] += (double)acc[0]; a.d[1] += (double)acc[1]; a.d[2] += (double)acc[2]; a.d[3] += (double)acc[3];
+        a.xy += (double)fxy; a.cs += (double)fcs; a.yy += (double)fyy; a.ys += (double)fys;
+    }
+}
+
 __device__ __forceinline__ int64_t lower_bound_i64(const int64_t* __restrict__ a, int64_t n, int64_t key) {
     int64_t lo = 0, hi = n;  // first index with a[idx] >= key
     while (lo < hi) {
@@ -139,6 +210,8 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
     constexpr int RPL = Tile<T>::RPL;
     constexpr int TR = 64 * RPL;
     constexpr int NA = CHOL ? LPS + 1 : LPS;
+    constexpr bool PACK = LPS <= 8;        // p <= 8: two row slabs per MFMA (consume_range_pack)
+    constexpr int ZSLOT = PACK ? 7 : 15;   // a scratch row / column that holds exact zeros whenever it is read
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     char* wl = smem;
@@ -222,7 +295,29 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
                     Msc[16 + kFQ * 16] = (double)ng;
                     Msc[16 + kFQ * 17] = ys;
                 }
+                if (PACK && lane == 8) Msc[17 + kFQ * 17] = ys;  // sum y over the second row slab
             }
+        }
+        if constexpr (PACK) {  // fold the second slab's diagonal block (and side sums) onto the first
+            PDS_WAVE_LDS_SYNC();
+            const int fi = lane & 7, fj = lane >> 3;
+            const double dsum = Msc[fi + kFQ * fj] + Msc[fi + 8 + kFQ * (fj + 8)];
+            double xys = 0.0, css = 0.0, yss = 0.0;
+            if (lane < 8) {
+                xys = Msc[lane + kFQ * 17] + Msc[lane + 8 + kFQ * 17];
+                if constexpr (BIAS) css = Msc[lane + kFQ * 16] + Msc[lane + 8 + kFQ * 16];
+            }
+            if (BIAS && lane == 0) yss = Msc[16 + kFQ * 17] + Msc[17 + kFQ * 17];
+            PDS_WAVE_LDS_SYNC();
+            Msc[fi + kFQ * fj] = dsum;
+            if (lane < 8) {
+                Msc[lane + kFQ * 17] = xys;
+                if constexpr (BIAS) {
+                    Msc[lane + kFQ * 16] = css;
+                    Msc[16 + kFQ * lane] = css;
+                }
+            }
+            if (BIAS && lane == 0) Msc[16 + kFQ * 17] = yss;
         }
         if (sp.lambda > 0.0) {  // ridge: lambda goes onto the diagonal while the matrix is still in LDS
             PDS_WAVE_LDS_SYNC();
@@ -231,13 +326,14 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
         }
         PDS_WAVE_LDS_SYNC();
         // ---- sub-group `npend` takes it into registers (solver layout: lane j = column j, a_p[i] = row i).
-        // Rows / columns beyond p' read scratch slot 15: whenever such a row exists p <= 15, and slot 15 then holds
-        // the exact zeros the matrix core produced from the zero-padded tile column -- so the 17 reads are
+        // Rows / columns beyond p' read scratch slot ZSLOT (15; 7 in the packed kernels): whenever such a row exists
+        // p <= ZSLOT, and that slot then holds the exact zeros the matrix core produced from the zero-padded tile
+        // column -- so the 17 reads are
         // unconditional, under ONE exec mask (the taking sub-group), instead of a select per element.
         {
             int j = j_in;
             asm volatile("" : "+v"(j));
-            const int lj = (j < p) ? j : ((BIAS && j == p) ? 16 : 15);
+            const int lj = (j < p) ? j : ((BIAS && j == p) ? 16 : ZSLOT);
             if (sub == npend) {
                 const double* colp = Msc + kFQ * lj;
                 if (p >= LPS) {  // every row is a feature: immediate offsets, the reads pair up into 16-byte loads
@@ -249,7 +345,7 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
                 } else {
 #pragma unroll
                     for (int i = 0; i < LPS; ++i) {
-                        const int li = (i < p) ? i : ((BIAS && i == p) ? 16 : 15);
+                        const int li = (i < p) ? i : ((BIAS && i == p) ? 16 : ZSLOT);
                         a_p[i] = colp[li];
                         if constexpr (!CHOL) b_p[i] = Msc[li + kFQ * 17];
                     }
@@ -300,7 +396,8 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
                 continue;
             }
             const int64_t seg_end = (ge < tile_end) ? ge : tile_end;
-            consume_range<T, BIAS>(wl, lane, (int)(pos - row0), (int)(seg_end - row0), acc);
+            if constexpr (PACK) consume_range_pack<T, BIAS>(wl, lane, (int)(pos - row0), (int)(seg_end - row0), acc);
+            else consume_range<T, BIAS>(wl, lane, (int)(pos - row0), (int)(seg_end - row0), acc);
             pos = seg_end;
         }
         PDS_WAVE_LDS_SYNC();

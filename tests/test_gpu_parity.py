@@ -235,7 +235,8 @@ def test_report_y_var_from_moments(pds):
 
 
 # ------------------------------------------------------------------------------------------ grouped
-@pytest.mark.parametrize("p,bias", [(2, False), (3, True), (7, False), (8, True), (15, True), (16, False)])
+@pytest.mark.parametrize("p,bias", [(1, False), (2, False), (3, True), (4, True), (5, False), (7, False), (7, True), (8, False),
+                                    (8, True), (9, False), (15, True), (16, False)])
 def test_grouped(pds, orc, p, bias):
     rng = np.random.default_rng(100 + p)
     G = 3000
@@ -442,6 +443,26 @@ def test_f32_path(pds, orc, f32):
     co, pr, va = pds.rolling_lin_reg(*cols_of(X32[:50_000, :3]), target=dev(y32[:50_000]), window_size=64)
     ref = orc.rolling_lr(X32[:50_000, :3].astype(np.float64), y32[:50_000].astype(np.float64), 64)
     assert np.max(np.linalg.norm(co.cpu().numpy()[63:] - ref, axis=1) / np.linalg.norm(ref, axis=1)) < 1e-3
+
+
+@pytest.mark.parametrize("p,bias", [(3, False), (5, True), (8, False), (12, True)])
+def test_grouped_f32_ragged(pds, orc, f32, p, bias):
+    # f32 frames, group boundaries at arbitrary rows (p <= 8 runs the two-slab matrix-core path and its masked steps)
+    rng = np.random.default_rng(300 + p)
+    G = 2000
+    sizes = rng.integers(40, 400, size=G)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    N = int(off[-1])
+    X = rng.normal(size=(N, p)).astype(np.float32)
+    y = np.empty(N, dtype=np.float32)
+    for g in range(G):
+        sl = slice(off[g], off[g + 1])
+        y[sl] = X[sl] @ rng.normal(size=p) + 0.1 * rng.normal(size=sizes[g]) + (0.5 if bias else 0.0)
+    co, nu = pds.lin_reg_by(*cols_of(X), target=dev(y), group_offsets=off, add_bias=bias)
+    co, nu = co.cpu().numpy(), nu.cpu().numpy().astype(bool)
+    assert co.dtype == np.float32 and not nu.any()
+    co_o, _ = orc.grouped_lr([y.astype(np.float64)] + [X[:, j].astype(np.float64) for j in range(p)], off, add_bias=bias, nthreads=4)
+    assert np.max(np.linalg.norm(co - co_o, axis=1) / np.linalg.norm(co_o, axis=1)) < F32_TOL
 
 
 # ------------------------------------------------------------------------------------------ full BASELINE sizes
