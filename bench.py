@@ -127,9 +127,10 @@ def main() -> int:
     traffic = None
     try:
         tj = json.loads((ROOT / "profiles" / "r01_traffic.json").read_text())["kernels"]
-        key = "pds::grouped_stream_kernel<double, 16, true>" if fused else "pds::grouped_moments_kernel<double>"
-        if key in tj and G == 1_000_000 and R == 100 and P == 16:
-            traffic = int(tj[key]["hbm_bytes_per_launch"])
+        want = "pds::grouped_stream_kernel<double, 16," if fused else "pds::grouped_moments_kernel<double>"
+        hit = [v for k, v in tj.items() if k.startswith(want)]
+        if hit and G == 1_000_000 and R == 100 and P == 16:
+            traffic = int(hit[0]["hbm_bytes_per_launch"])
     except Exception:
         traffic = None
     roofline = {

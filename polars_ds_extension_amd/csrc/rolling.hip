@@ -85,12 +85,18 @@ __global__ __launch_bounds__(kRollWaves * 64) void rolling_kernel(const T* const
 
     for (int64_t t = wid; t < ntiles; t += nw) {
         const int64_t t0 = t * T_, t1 = (t0 + T_ < ra.n) ? t0 + T_ : ra.n;
-        double W = 0.0;  // lane v < NV: running moment v
+        // running moments: lane owns moment v = lane (and v = lane + 64 when p' >= 10 makes NV exceed the wave)
+        constexpr int NSL = (NV + 63) / 64;
+        double W[NSL];
+#pragma unroll
+        for (int k = 0; k < NSL; ++k) W[k] = 0.0;
         int64_t r_begin = t0;
         if (ra.mode == 0) {
             r_begin = t0 - ((w + 63) / 64) * 64;  // warm-up steps rebuild the window in front of the tile
         } else if (ra.mode == 2) {
-            if (lane < NV) W = tile_tot[t * NV + lane];  // exclusive prefix over the previous tiles
+#pragma unroll
+            for (int k = 0; k < NSL; ++k)
+                if (lane + 64 * k < NV) W[k] = tile_tot[t * NV + lane + 64 * k];  // exclusive prefix over the previous tiles
         }
         // rows of the first step
         double nn[PP], no[PP], nyn, nyo = 0.0;
@@ -145,10 +151,13 @@ __global__ __launch_bounds__(kRollWaves * 64) void rolling_kernel(const T* const
             }
             RSYNC();
             // ---------------- phase B: lane v scans its moment over the 64 rows of this step
-            if (lane < NV) {
+#pragma unroll
+            for (int k = 0; k < NSL; ++k) {
+                if (lane + 64 * k >= NV) continue;
                 // 16 independent LDS reads, 16 dependent adds, 16 writes per batch (a read-add-write loop would put
                 // an LDS round trip into every one of the 64 links of the chain)
-                double* row = D + lane * kLdsStride;
+                double* row = D + (lane + 64 * k) * kLdsStride;
+                double Wk = W[k];
 #pragma unroll
                 for (int i0 = 0; i0 < 64; i0 += 16) {
                     double v[16];
@@ -156,12 +165,13 @@ __global__ __launch_bounds__(kRollWaves * 64) void rolling_kernel(const T* const
                     for (int i = 0; i < 16; ++i) v[i] = row[i0 + i];
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        W += v[i];
-                        v[i] = W;
+                        Wk += v[i];
+                        v[i] = Wk;
                     }
 #pragma unroll
                     for (int i = 0; i < 16; ++i) row[i0 + i] = v[i];
                 }
+                W[k] = Wk;
             }
             RSYNC();
             if (warm || ra.mode == 1) continue;
@@ -240,32 +250,58 @@ __global__ __launch_bounds__(kRollWaves * 64) void rolling_kernel(const T* const
             }
             RSYNC();
         }
-        if (ra.mode == 1 && lane < NV) tile_tot[t * NV + lane] = W;
+        if (ra.mode == 1) {
+#pragma unroll
+            for (int k = 0; k < NSL; ++k)
+                if (lane + 64 * k < NV) tile_tot[t * NV + lane + 64 * k] = W[k];
+        }
     }
 }
 
-// exclusive prefix over the per-tile totals (expanding window), one wave, lane = moment
+// exclusive prefix over the per-tile totals (expanding window): one block of kPrefixWaves waves, lane = moment,
+// wave = a contiguous chunk of tiles.  Pass 1 sums each chunk, the chunk bases are formed in LDS in chunk order, pass 2
+// writes the running prefix -- a fixed summation order, so results do not depend on scheduling.
 // (`seed`: moments of rows that precede this frame -- the row-sharded multi-GPU expanding fit -- or nullptr)
-__global__ __launch_bounds__(64) void tile_prefix_kernel(double* __restrict__ tot, int64_t ntiles, int nv,
-                                                         const double* __restrict__ seed) {
-    const int lane = threadIdx.x;
-    if (lane >= nv) return;
-    double run = seed ? seed[lane] : 0.0;
-    int64_t t = 0;
-    for (; t + 8 <= ntiles; t += 8) {
-        double v[8];
+constexpr int kPrefixWaves = 16;
+__global__ __launch_bounds__(kPrefixWaves * 64) void tile_prefix_kernel(double* __restrict__ tot, int64_t ntiles, int nv,
+                                                                        const double* __restrict__ seed) {
+    __shared__ double base[kPrefixWaves][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t per = (ntiles + kPrefixWaves - 1) / kPrefixWaves;
+    const int64_t t0 = wave * per, t1 = (t0 + per < ntiles) ? t0 + per : ntiles;
+    for (int v = lane; v < nv; v += 64) {  // nv <= 91 (p' = 12): at most two moments per lane
+        double sum = 0.0;
+        int64_t t = t0;
+        for (; t + 8 <= t1; t += 8) {
+            double x[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = tot[(t + k) * nv + lane];
+            for (int k = 0; k < 8; ++k) x[k] = tot[(t + k) * nv + v];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            tot[(t + k) * nv + lane] = run;
-            run += v[k];
+            for (int k = 0; k < 8; ++k) sum += x[k];
         }
+        for (; t < t1; ++t) sum += tot[t * nv + v];
+        base[wave][v] = sum;
     }
-    for (; t < ntiles; ++t) {
-        const double v = tot[t * nv + lane];
-        tot[t * nv + lane] = run;
-        run += v;
+    __syncthreads();
+    for (int v = lane; v < nv; v += 64) {
+        double run = seed ? seed[v] : 0.0;
+        for (int w = 0; w < wave; ++w) run += base[w][v];
+        int64_t t = t0;
+        for (; t + 8 <= t1; t += 8) {
+            double x[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] = tot[(t + k) * nv + v];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                tot[(t + k) * nv + v] = run;
+                run += x[k];
+            }
+        }
+        for (; t < t1; ++t) {
+            const double x = tot[t * nv + v];
+            tot[t * nv + v] = run;
+            run += x;
+        }
     }
 }
 
@@ -307,7 +343,7 @@ static int launch_pp(pds_ctx* ctx, const DeviceCols<T>& dc, RollArgs ra, bool ex
         ra.mode = 1;
         hipLaunchKernelGGL((rolling_kernel<T, PP>), dim3((unsigned)nb), dim3(kRollWaves * 64), lds, ctx->stream,
                            dc.d_ptrs, ra, tot, d_coeffs, d_pred, d_valid);
-        hipLaunchKernelGGL(tile_prefix_kernel, dim3(1), dim3(64), 0, ctx->stream, tot, ntiles, NV, d_seed);
+        hipLaunchKernelGGL(tile_prefix_kernel, dim3(1), dim3(kPrefixWaves * 64), 0, ctx->stream, tot, ntiles, NV, d_seed);
         ra.mode = 2;
         hipLaunchKernelGGL((rolling_kernel<T, PP>), dim3((unsigned)nb), dim3(kRollWaves * 64), lds, ctx->stream,
                            dc.d_ptrs, ra, tot, d_coeffs, d_pred, d_valid);

@@ -403,6 +403,27 @@ def test_rolling_halo_shards_equal_single_frame(pds):
             assert np.max(np.abs(c2[ok] - co[lo:hi][ok])) < 1e-9 and np.max(np.abs(p2[ok] - pr[lo:hi][ok])) < 1e-9
 
 
+@pytest.mark.parametrize("p,bias", [(8, True), (9, False), (10, False), (10, True), (11, True), (12, False)])
+def test_rolling_recursive_many_coefficients(pds, orc, p, bias):
+    # p' >= 10 carries more than 64 running moments per wave (two per lane)
+    rng = np.random.default_rng(40 + p)
+    n, w, n0 = 6000, 64, 40
+    X = rng.random((n, p))
+    y = X @ rng.normal(size=p) + 0.3 + 0.05 * rng.normal(size=n)
+    Xb = np.c_[X, np.ones(n)] if bias else X
+    co, pr, va = pds.rolling_lin_reg(*cols_of(X), target=dev(y), window_size=w, add_bias=bias)
+    ref = orc.rolling_lr(Xb, y, w)
+    co = co.cpu().numpy()
+    assert np.max(np.linalg.norm(co[w - 1 :] - ref, axis=1) / np.linalg.norm(ref, axis=1)) < 1e-9
+    assert np.max(np.abs(pr.cpu().numpy()[w - 1 :] - np.einsum("ij,ij->i", Xb[w - 1 :], ref))) < 1e-9
+    co2, _, va2 = pds.recursive_lin_reg(*cols_of(X), target=dev(y), start_with=n0, add_bias=bias)
+    ref2 = orc.recursive_lr(Xb, y, n0)
+    assert va2.cpu().numpy()[n0 - 1 :].all()
+    late = 100  # the first fits are near-singular
+    err = np.linalg.norm(co2.cpu().numpy()[n0 - 1 + late :] - ref2[late:], axis=1) / np.linalg.norm(ref2[late:], axis=1)
+    assert np.max(err) < 1e-9
+
+
 def test_rolling_skip_non_finite(pds, orc):
     rng = np.random.default_rng(9)
     n = 3000

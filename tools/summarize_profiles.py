@@ -1,0 +1,81 @@
+"""Builds profiles/<round>_* from what tools/profile_round.sh left in gpurun_out/prof/ (run in the repo, no GPU)."""
+import csv
+import json
+import sys
+from collections import defaultdict
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+SRC = ROOT / "gpurun_out" / "prof"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+OUT = ROOT / "profiles"
+OUT.mkdir(exist_ok=True)
+
+
+def short(name):
+    name = name.replace("void ", "")
+    return name.split("(")[0]
+
+
+def stats(path, only_pds=True):
+    rows = []
+    for r in csv.DictReader(open(path)):
+        n = short(r["Name"])
+        if only_pds and not n.startswith("pds::"):
+            continue
+        rows.append((n, int(r["Calls"]), float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
+    return rows
+
+
+def pmc(path):
+    acc = defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        n = short(r["Kernel_Name"])
+        if n.startswith("pds::"):
+            acc[n].append(float(r["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+
+
+line = json.loads((SRC / "bench_line.json").read_text().strip().splitlines()[-1])
+(OUT / f"{rnd}_bench_line.json").write_text(json.dumps(line, indent=1) + "\n")
+(OUT / f"{rnd}_bench_kernel_stats.csv").write_text((SRC / "bench_kernel_stats.csv").read_text())
+(OUT / f"{rnd}_extra_kernel_stats.csv").write_text((SRC / "extra_kernel_stats.csv").read_text())
+extra = json.loads((SRC / "bench_extra.json").read_text())
+(OUT / f"{rnd}_bench_extra.json").write_text(json.dumps(extra, indent=1) + "\n")
+
+fetch, write = pmc(SRC / "pmc_FETCH_SIZE.csv"), pmc(SRC / "pmc_WRITE_SIZE.csv")
+traffic = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) on `python bench.py --steps 2 "
+                   "--warmup 1 --no-cpu`; read bytes = 2 x FETCH_SIZE x 1024 (gfx950 correction, MI355X_MICROARCH.md HBM section), "
+                   "write bytes = WRITE_SIZE x 1024", "kernels": {}}
+for k in fetch:
+    rd = 2.0 * fetch[k][0] * 1024
+    wr = write.get(k, (0.0, 0))[0] * 1024
+    traffic["kernels"][k] = {"fetch_size_KiB": fetch[k][0], "write_size_KiB": write.get(k, (0.0, 0))[0], "read_bytes_corrected": rd,
+                             "write_bytes": wr, "hbm_bytes_per_launch": rd + wr, "launches_sampled": fetch[k][1]}
+(OUT / f"{rnd}_traffic.json").write_text(json.dumps(traffic, indent=1) + "\n")
+
+md = [f"# profiles/{rnd} -- one MI355X (gfx950), ROCm 7.2", "",
+      f"* `{rnd}_bench_line.json` -- the `python bench.py` JSON line.",
+      f"* `{rnd}_bench_kernel_stats.csv` -- `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 5 --warmup 2 --no-cpu`.",
+      f"* `{rnd}_traffic.json` -- HBM bytes per launch from `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (two separate passes).",
+      f"* `{rnd}_bench_extra.json` / `{rnd}_extra_kernel_stats.csv` -- `python tools/bench_extra.py`: the other BASELINE configs (single OLS + "
+      "report, rolling, recursive, elastic net) and the host-buffer rate, and the rocprofv3 kernel stats of that run.",
+      "* produced by `tools/profile_round.sh` (GPU box) + `tools/summarize_profiles.py`.", "",
+      "## Headline step (bench.py): kernel time, rocprofv3 --stats", "", "| kernel | calls | avg us | % of GPU time |", "|---|---|---|---|"]
+for n, c, us, pct in stats(SRC / "bench_kernel_stats.csv"):
+    md.append(f"| `{n}` | {c} | {us:.1f} | {pct:.2f} |")
+rf = line["roofline"]
+md += ["", f"HIP-event timing inside bench.py for the same kernels: grouped fused {rf['avg_launch_ms']:.4f} ms per launch "
+       f"({rf['achieved']:.0f} GB/s algorithmic, frac {rf['frac']:.3f} of 8 TB/s); single-OLS Gram "
+       f"{line['gram_build']['avg_launch_ms']:.4f} ms ({line['gram_build']['achieved_GBps']:.0f} GB/s, frac {line['gram_build']['frac_of_hbm_peak']:.3f}).", "",
+       "## HBM traffic (PMC, per launch)", "", "| kernel | read MB (2 x FETCH_SIZE KiB x 1024) | write MB |", "|---|---|---|"]
+for k, v in traffic["kernels"].items():
+    md.append(f"| `{k}` | {v['read_bytes_corrected'] / 1e6:.1f} | {v['write_bytes'] / 1e6:.1f} |")
+md += ["", f"Algorithmic bytes per launch of the fused grouped kernel: {rf['algorithmic_bytes_per_launch'] / 1e6:.1f} MB "
+       "(1e8 rows x 17 f64 columns + offsets + coefficients).", "",
+       "## Other configs (tools/bench_extra.py): kernel time, rocprofv3 --stats", "", "| kernel | calls | avg us |", "|---|---|---|"]
+for n, c, us, pct in stats(SRC / "extra_kernel_stats.csv"):
+    md.append(f"| `{n}` | {c} | {us:.1f} |")
+md += ["", "```json", json.dumps({k: v for k, v in extra.items()}, indent=1), "```", ""]
+(OUT / f"{rnd}_summary.md").write_text("\n".join(md))
+print("wrote", sorted(p.name for p in OUT.glob(f"{rnd}_*")))
