@@ -813,6 +813,7 @@ void pds_ctx_destroy(pds_ctx* ctx) {
     if (ctx->partials) hipFree(ctx->partials);
     if (ctx->ws.ptr) hipFree(ctx->ws.ptr);
     if (ctx->stage.ptr) hipFree(ctx->stage.ptr);
+    if (ctx->solve_ws.ptr) hipFree(ctx->solve_ws.ptr);
     if (ctx->pinned) hipHostFree(ctx->pinned);
     for (auto& e : ctx->ev_pending) {
         hipEventDestroy(e.a);

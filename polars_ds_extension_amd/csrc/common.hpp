@@ -82,6 +82,7 @@ struct pds_ctx {
     pds::Workspace ws;       // HBM scratch for call-local arrays (bump allocated per call)
     size_t ws_used = 0;
     pds::Workspace stage;    // HBM staging of PDS_HOST column buffers
+    pds::Workspace solve_ws; // factor workspace of the p' > 64 solver (solve_big.hip)
     void* pinned = nullptr;  // pinned host scratch (small results, pointer arrays)
     size_t pinned_bytes = 0;
     // optional per-kernel-class HIP-event timing (pds_ctx_set_timing / pds_ctx_get_timing)
@@ -163,6 +164,11 @@ struct SolveParams {
 template <typename T>
 int launch_solve(pds_ctx* ctx, const T* d_moments, int64_t n_sys, const SolveParams& sp, T* d_coeffs,
                  uint8_t* d_flags, T* d_inv_out, const int64_t* d_rows_per_sys /*nullable*/);
+
+// solve_big.hip: p' > 64 (Cholesky on an HBM/L2 workspace, one workgroup per system); used by launch_solve
+template <typename T>
+int launch_solve_big(pds_ctx* ctx, const T* d_moments, int64_t n_sys, const SolveParams& sp, T* d_coeffs, uint8_t* d_flags,
+                     T* d_inv_out);
 
 // solve_reg.hip: register-resident variant (p' <= 16, QR, no inverse); used by launch_solve
 template <typename T>

@@ -323,7 +323,11 @@ int launch_solve(pds_ctx* ctx, const T* d_moments, int64_t n_sys, const SolvePar
     // hot path: register-resident pivoted QR (solve_reg.hip) for p' <= 16 when no inverse is wanted
     if (pp >= 1 && pp <= 16 && !d_inv_out && (sp.solver != PDS_SOLVER_CHOLESKEY || sp.gate_tol > 0.0))
         return launch_solve_reg<T>(ctx, d_moments, n_sys, sp, d_coeffs, d_flags, d_rows_per_sys);
-    if (pp < 1 || pp > 64) return fail(PDS_ERR_UNSUPPORTED, "solve: 1..64 coefficients supported on the LDS path");
+    if (pp < 1) return fail(PDS_ERR_INVALID, "solve: no coefficients");
+    if (pp > 64) {
+        if (d_rows_per_sys) return fail(PDS_ERR_UNSUPPORTED, "grouped solve: at most 64 coefficients");
+        return launch_solve_big<T>(ctx, d_moments, n_sys, sp, d_coeffs, d_flags, d_inv_out);
+    }
     if (pp <= 4) return launch_solve_lps<T, 4>(ctx, d_moments, n_sys, sd, d_coeffs, d_flags, d_inv_out, d_rows_per_sys);
     if (pp <= 8) return launch_solve_lps<T, 8>(ctx, d_moments, n_sys, sd, d_coeffs, d_flags, d_inv_out, d_rows_per_sys);
     if (pp <= 16) return launch_solve_lps<T, 16>(ctx, d_moments, n_sys, sd, d_coeffs, d_flags, d_inv_out, d_rows_per_sys);

@@ -548,6 +548,41 @@ def test_wide_moments_and_ols_f64(pds, orc, n, p):
     assert nrel(b, orc.pl_lr(X, y, add_bias=True, l1_reg=0.01, l2_reg=0.01, tol=1e-9, max_iter=3000)) < 1e-9
 
 
+@pytest.mark.parametrize("p,bias", [(64, True), (65, False), (100, True), (257, True)])
+def test_ols_more_than_64_coefficients(pds, orc, p, bias):
+    # p' > 64: Cholesky on an HBM/L2 workspace (solve_big.hip); every solver string, ridge, report (SE), pred, the gate
+    rng = np.random.default_rng(500 + p)
+    n = 6 * p + 2000
+    X = rng.normal(size=(n, p))
+    X[:, 1] = 0.5 * X[:, 0] + 0.8 * X[:, 1]
+    y = X @ rng.normal(size=p) + 0.25 + 0.1 * rng.normal(size=n)
+    for kw in ({}, {"solver": "svd"}, {"solver": "choleskey"}, {"l2_reg": 0.3}):
+        b = pds.lin_reg(*cols_of(X), target=dev(y), add_bias=bias, **kw)
+        assert nrel(b, orc.pl_lr(X, y, add_bias=bias, **kw)) < F64_TOL
+    Xb = np.c_[X, np.ones(n)] if bias else X
+    r = pds.lin_reg_report(*cols_of(X), target=dev(y), add_bias=bias)
+    ro = orc.lin_reg_report(Xb, y)
+    assert nrel(r["beta"], ro["beta"]) < F64_TOL and frel(r["std_err"], ro["std_err"], 1e-12) < 1e-9
+    assert frel(r["t"], ro["t"], 1e-9) < 1e-8 and abs(np.ravel(r["r2"])[0] - np.ravel(ro["r2"])[0]) < 1e-10
+    pred, resid = pds.lin_reg(*cols_of(X), target=dev(y), add_bias=bias, return_pred=True)
+    bo = orc.pl_lr(X, y, add_bias=bias)
+    assert np.max(np.abs(pred.cpu().numpy() - Xb @ bo)) < 1e-9
+    Xc = X.copy()
+    Xc[:, 7] = Xc[:, 3] - 2.0 * Xc[:, 5]  # exactly collinear: the gate answers null, as the reference does
+    assert pds.lin_reg(*cols_of(Xc), target=dev(y), add_bias=bias) is None
+    assert orc.pl_lr(Xc, y, add_bias=bias) is None
+
+
+def test_ols_more_than_64_coefficients_f32(pds, orc, f32):
+    rng = np.random.default_rng(77)
+    n, p = 20_000, 130
+    X = rng.normal(size=(n, p)).astype(np.float32)
+    y = (X @ rng.normal(size=p) + 0.1 * rng.normal(size=n)).astype(np.float32)
+    b = pds.lin_reg(*cols_of(X), target=dev(y), add_bias=True)
+    assert b.dtype == np.float32
+    assert nrel(b, orc.pl_lr(X.astype(np.float64), y.astype(np.float64), add_bias=True)) < F32_TOL
+
+
 @pytest.mark.parametrize("n,p", [(9000, 30), (70_000, 126), (33_333, 128), (10_000, 150), (20_000, 158), (12_345, 256)])
 def test_wide_moments_f32_split_k(pds, f32, n, p):
     # f32: <= 8192-row splits in f32 matrix-core tiles, cross-split sum in f64; the [1 | y] tail column block runs narrow
