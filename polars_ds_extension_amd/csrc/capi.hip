@@ -306,7 +306,7 @@ static int lr_impl(pds_ctx* ctx, const T* const* cols, const T* weights, int n_f
     const int q = n_feat + 2, pp = n_feat + (prm->add_bias ? 1 : 0);
     const bool want_pred = pred || resid;
     size_t need = 65536 + sizeof(T) * (size_t)q * q + sizeof(T*) * (size_t)(n_feat + 32);
-    if (n_feat > kMaxFeatSmall) need += moments_wide_workspace(ctx->num_cus, n_feat, n_rows);
+    if (n_feat > kMaxFeatSmall) need += moments_wide_workspace(ctx->num_cus, n_feat, n_rows, weights != nullptr);
     if (want_pred && space == PDS_HOST) need += 2 * ((size_t)n_rows * sizeof(T) + 512);
     if (int rc = ws_reserve(ctx, need)) return rc;
     DeviceCols<T> dc;
@@ -527,7 +527,7 @@ static int moments_impl(pds_ctx* ctx, const T* const* cols, const T* weights, in
     PDS_HIP_CHECK(hipSetDevice(ctx->device));
     const int q = n_feat + 2;
     if (int rc = ws_reserve(ctx, 65536 + sizeof(T) * (size_t)q * q + sizeof(T*) * (size_t)(n_feat + 32) +
-                                     (n_feat > kMaxFeatSmall ? moments_wide_workspace(ctx->num_cus, n_feat, n_rows) : 0)))
+                                     (n_feat > kMaxFeatSmall ? moments_wide_workspace(ctx->num_cus, n_feat, n_rows, weights != nullptr) : 0)))
         return rc;
     DeviceCols<T> dc;
     if (int rc = make_device_cols<T>(ctx, cols, weights, n_feat, n_rows, space, dc)) return rc;
@@ -576,7 +576,7 @@ static int report_impl(pds_ctx* ctx, const T* const* cols, const T* weights, int
     PDS_HIP_CHECK(hipSetDevice(ctx->device));
     const int p = n_feat, bias = add_bias ? 1 : 0, pp = p + bias, q = p + 2;
     size_t need = 131072 + sizeof(T) * (size_t)(2 * q * q + pp * pp + pp) + sizeof(T*) * (size_t)(p + 64);
-    if (p > kMaxFeatSmall) need += moments_wide_workspace(ctx->num_cus, p, n_rows);
+    if (p > kMaxFeatSmall) need += (se_type != PDS_SE ? 2 : 1) * moments_wide_workspace(ctx->num_cus, p, n_rows, true);
     if (se_type != PDS_SE) need += (size_t)n_rows * sizeof(T) + 512;
     if (int rc = ws_reserve(ctx, need)) return rc;
     DeviceCols<T> dc;

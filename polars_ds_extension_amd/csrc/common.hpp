@@ -136,8 +136,8 @@ int launch_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_
 // moments_wide.hip: p > 16 (tiled MFMA SYRK with split-K); partials come out of ctx->ws (reserve
 // moments_wide_workspace() bytes on top of the call's other needs)
 template <typename T>
-int launch_moments_wide(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, T* d_moments);
-size_t moments_wide_workspace(int num_cus, int n_feat, int64_t n_rows);
+int launch_moments_wide(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, bool weighted, T* d_moments);
+size_t moments_wide_workspace(int num_cus, int n_feat, int64_t n_rows, bool weighted = false);
 
 // segmented (per-group) moments: d_moments [n_groups][(p+2)^2]
 template <typename T>

@@ -192,8 +192,7 @@ template <typename T>
 int launch_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, bool weighted,
                    T* d_moments) {
     if (n_feat > kMaxFeatSmall) {
-        if (weighted) return fail(PDS_ERR_UNSUPPORTED, "weighted regression with more than 16 features is not built yet");
-        return launch_moments_wide<T>(ctx, dc, n_feat, n_rows, d_moments);
+        return launch_moments_wide<T>(ctx, dc, n_feat, n_rows, weighted, d_moments);
     }
     if (n_feat < 1) return fail(PDS_ERR_INVALID, "need at least one feature column");
     constexpr int TR = 64 * Tile<T>::RPL;

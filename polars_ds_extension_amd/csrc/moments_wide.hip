@@ -71,10 +71,13 @@ __host__ __device__ inline int ij_to_pair(int I, int J, int nb) { return I * nb 
 //         redundant lower-left quadrant instead multiplies all 128 rows of the I panel with the tail tile, which is
 //         parked in the otherwise unused J half of LDS.  No extra pass over X; tail' tail (a few columns) comes from
 //         a one-block-wide MODE 1 launch.
-template <typename T, int MODE>
+// WEIGHTED: A = Z' diag(w) Z (faer_weighted_lr, lr_solvers.rs:386-409) as the plain Gram of sqrt(w) * Z: every value is
+// scaled by sqrt(w_row) on its way into LDS (`sw`, precomputed once per call), which keeps the product symmetric, so
+// the diagonal-block and tail shortcuts apply unchanged.
+template <typename T, int MODE, bool WEIGHTED>
 __global__ __launch_bounds__(kWThreads, 2) void moments_wide_kernel(const T* const* __restrict__ cols, int p, int64_t n,
                                                                  int nb, int nb_main, int i_first, int64_t rows_per_split,
-                                                                 T* __restrict__ partials) {
+                                                                 const T* __restrict__ sw, T* __restrict__ partials) {
     using W = Wide<T>;
     constexpr int KC = W::KC, CS = W::CS, MT = W::MT, NT = W::NT, VL = W::VL;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -132,6 +135,16 @@ __global__ __launch_bounds__(kWThreads, 2) void moments_wide_kernel(const T* con
 
     typename W::vec rI[4], rJ[4];
     auto load_stage = [&](int64_t row0) __attribute__((always_inline)) {
+        typename W::vec swv;  // sqrt(w) of this thread's VL rows (the same rows for all of its chunks)
+        if constexpr (WEIGHTED) {
+            const int64_t r = row0 + (tid & 7) * VL;
+            if (r + VL <= r_end) {
+                swv = *reinterpret_cast<gptr<typename W::vec>>(as_global(sw) + r);
+            } else {
+#pragma unroll
+                for (int e = 0; e < VL; ++e) swv[e] = (r + e < r_end) ? sw[r + e] : T(0);
+            }
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int id = tid + kWThreads * u;
@@ -150,6 +163,10 @@ __global__ __launch_bounds__(kWThreads, 2) void moments_wide_kernel(const T* con
                         const bool in = r + e < r_end;
                         v[e] = !in ? T(0) : (kind == 0 ? ptr[r + e] : (kind == 1 ? T(1) : T(0)));
                     }
+                }
+                if constexpr (WEIGHTED) {
+#pragma unroll
+                    for (int e = 0; e < VL; ++e) v[e] *= swv[e];
                 }
                 if (pnl) rJ[u] = v;
                 else rI[u] = v;
@@ -298,6 +315,12 @@ __global__ __launch_bounds__(kWThreads, 2) void moments_wide_kernel(const T* con
         }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void sqrt_weights_kernel(const T* __restrict__ w, int64_t n, T* __restrict__ sw) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        sw[i] = (T)sqrt((double)w[i]);
+}
+
 // out (q x q column-major, symmetric) = sum over splits of the partial tiles, fixed order
 template <typename T>
 __global__ __launch_bounds__(256) void moments_wide_reduce_kernel(const T* __restrict__ partials, int nsplit,
@@ -340,8 +363,8 @@ static void wide_split(int num_cus, int npairs, int64_t n_rows, int& nsplit, int
     nsplit = (int)((n_rows + rows_per_split - 1) / rows_per_split);
 }
 
-template <typename T>
-int launch_moments_wide(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, T* d_moments) {
+template <typename T, bool WEIGHTED>
+static int launch_moments_wide_w(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, T* d_moments) {
     using W = Wide<T>;
     const int q = n_feat + 2;
     const int nb = (q + kWB - 1) / kWB;
@@ -353,7 +376,13 @@ int launch_moments_wide(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64
     T* partials = reinterpret_cast<T*>(ws_take(ctx, part_bytes));
     if (ctx->ws_used > ctx->ws.bytes) return fail(PDS_ERR_INVALID, "internal: workspace for the wide Gram build was not reserved");
     const size_t lds = (size_t)2 * kWB * W::CS * sizeof(T);
+    T* d_sw = nullptr;
+    if constexpr (WEIGHTED) d_sw = reinterpret_cast<T*>(ws_take(ctx, (size_t)n_rows * sizeof(T)));
+    if (ctx->ws_used > ctx->ws.bytes) return fail(PDS_ERR_INVALID, "internal: workspace for the wide Gram build was not reserved");
     KernelTimer timer(ctx, kKindMoments);
+    if constexpr (WEIGHTED)
+        hipLaunchKernelGGL((sqrt_weights_kernel<T>), dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, dc.h_ptrs[n_feat + 1], n_rows,
+                           d_sw);
     const bool tail_narrow = q - (nb - 1) * kWB <= W::MT;
     const int nb_main = tail_narrow ? nb - 1 : nb;
     const dim3 grid_main(nb_main * (nb_main + 1) / 2, nsplit);
@@ -361,19 +390,19 @@ int launch_moments_wide(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64
     if constexpr (sizeof(T) == 4) {
         if (tail_narrow && nb_main > 0) {
             fused = true;
-            hipLaunchKernelGGL((moments_wide_kernel<T, 2>), grid_main, dim3(kWThreads), lds, ctx->stream, dc.d_ptrs, n_feat,
-                               n_rows, nb, nb_main, 0, rows_per_split, partials);
-            hipLaunchKernelGGL((moments_wide_kernel<T, 1>), dim3(1, nsplit), dim3(kWThreads), lds, ctx->stream, dc.d_ptrs,
-                               n_feat, n_rows, nb, nb_main, nb - 1, rows_per_split, partials);
+            hipLaunchKernelGGL((moments_wide_kernel<T, 2, WEIGHTED>), grid_main, dim3(kWThreads), lds, ctx->stream, dc.d_ptrs, n_feat,
+                               n_rows, nb, nb_main, 0, rows_per_split, d_sw, partials);
+            hipLaunchKernelGGL((moments_wide_kernel<T, 1, WEIGHTED>), dim3(1, nsplit), dim3(kWThreads), lds, ctx->stream, dc.d_ptrs,
+                               n_feat, n_rows, nb, nb_main, nb - 1, rows_per_split, d_sw, partials);
         }
     }
     if (!fused) {
         if (nb_main > 0)
-            hipLaunchKernelGGL((moments_wide_kernel<T, 0>), grid_main, dim3(kWThreads), lds, ctx->stream, dc.d_ptrs, n_feat,
-                               n_rows, nb, nb_main, 0, rows_per_split, partials);
+            hipLaunchKernelGGL((moments_wide_kernel<T, 0, WEIGHTED>), grid_main, dim3(kWThreads), lds, ctx->stream, dc.d_ptrs, n_feat,
+                               n_rows, nb, nb_main, 0, rows_per_split, d_sw, partials);
         if (tail_narrow)
-            hipLaunchKernelGGL((moments_wide_kernel<T, 1>), dim3(nb, nsplit), dim3(kWThreads), lds, ctx->stream, dc.d_ptrs,
-                               n_feat, n_rows, nb, nb_main, 0, rows_per_split, partials);
+            hipLaunchKernelGGL((moments_wide_kernel<T, 1, WEIGHTED>), dim3(nb, nsplit), dim3(kWThreads), lds, ctx->stream, dc.d_ptrs,
+                               n_feat, n_rows, nb, nb_main, 0, rows_per_split, d_sw, partials);
     }
     hipLaunchKernelGGL((moments_wide_reduce_kernel<T>), dim3(npairs, 64), dim3(256), 0, ctx->stream, partials, nsplit,
                        npairs, nb, n_feat, d_moments);
@@ -381,17 +410,23 @@ int launch_moments_wide(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64
     return PDS_OK;
 }
 
-size_t moments_wide_workspace(int num_cus, int n_feat, int64_t n_rows) {
+template <typename T>
+int launch_moments_wide(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, bool weighted, T* d_moments) {
+    return weighted ? launch_moments_wide_w<T, true>(ctx, dc, n_feat, n_rows, d_moments)
+                    : launch_moments_wide_w<T, false>(ctx, dc, n_feat, n_rows, d_moments);
+}
+
+size_t moments_wide_workspace(int num_cus, int n_feat, int64_t n_rows, bool weighted) {
     const int q = n_feat + 2;
     const int nb = (q + kWB - 1) / kWB;
     const int npairs = nb * (nb + 1) / 2;
     int ns;
     int64_t rps;
     wide_split<float>(num_cus, npairs, n_rows, ns, rps);  // the f32 plan has the most splits; 8 B covers both types
-    return (size_t)(ns + 1) * npairs * kWB * kWB * sizeof(double) + 4096;
+    return (size_t)(ns + 1) * npairs * kWB * kWB * sizeof(double) + 4096 + (weighted ? (size_t)n_rows * sizeof(double) + 512 : 0);
 }
 
-template int launch_moments_wide<double>(pds_ctx*, const DeviceCols<double>&, int, int64_t, double*);
-template int launch_moments_wide<float>(pds_ctx*, const DeviceCols<float>&, int, int64_t, float*);
+template int launch_moments_wide<double>(pds_ctx*, const DeviceCols<double>&, int, int64_t, bool, double*);
+template int launch_moments_wide<float>(pds_ctx*, const DeviceCols<float>&, int, int64_t, bool, float*);
 
 }  // namespace pds

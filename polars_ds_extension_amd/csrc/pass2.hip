@@ -175,6 +175,7 @@ template <typename T, bool WEIGHTED>
 __global__ __launch_bounds__(kP2Threads) void pass2_wide_kernel(const T* const* __restrict__ cols, int p, int bias,
                                                                 int64_t n, const T* __restrict__ beta,
                                                                 T* __restrict__ pred_out, T* __restrict__ resid_out,
+                                                                T* __restrict__ s_out /* e^2 per row (HC0 / HC1) */,
                                                                 double* __restrict__ partials) {
     double sse = 0.0, wsse = 0.0;
     const gptr<T> cy = as_global(cols[p]);
@@ -186,6 +187,7 @@ __global__ __launch_bounds__(kP2Threads) void pass2_wide_kernel(const T* const* 
         const T res = cy[r] - acc;
         if (pred_out) pred_out[r] = acc;
         if (resid_out) resid_out[r] = res;
+        if (s_out) s_out[r] = res * res;
         const double rd = (double)res;
         sse = fma(rd, rd, sse);
         if (WEIGHTED) wsse = fma((double)cw[r], rd * rd, wsse);
@@ -232,11 +234,17 @@ int launch_pass2(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_ro
                  double* d_s_rows) {
     if (n_feat < 1) return fail(PDS_ERR_INVALID, "need at least one feature column");
     if (n_feat > kMaxFeatSmall) {
-        if (hc_mode != 0 || weighted) return fail(PDS_ERR_UNSUPPORTED, "HC / weighted standard errors with more than 16 features are not built yet");
+        // HC2 / HC3 need the leverages x_i' (X'X)^-1 x_i: O(p'^2) per row, not built for the wide path
+        if (hc_mode >= 2) return fail(PDS_ERR_UNSUPPORTED, "HC2 / HC3 standard errors with more than 16 features are not built yet");
         const int nb = (int)std::min<int64_t>(std::max<int64_t>((n_rows + kP2Threads - 1) / kP2Threads, 1), (int64_t)ctx->num_cus * 8);
+        T* s_rows = hc_mode ? reinterpret_cast<T*>(d_s_rows) : nullptr;
         KernelTimer timer(ctx, kKindPass2);
-        hipLaunchKernelGGL((pass2_wide_kernel<T, false>), dim3(nb), dim3(kP2Threads), 0, ctx->stream, dc.d_ptrs, n_feat,
-                           add_bias ? 1 : 0, n_rows, d_beta, d_pred, d_resid, ctx->partials);
+        if (weighted)
+            hipLaunchKernelGGL((pass2_wide_kernel<T, true>), dim3(nb), dim3(kP2Threads), 0, ctx->stream, dc.d_ptrs, n_feat,
+                               add_bias ? 1 : 0, n_rows, d_beta, d_pred, d_resid, s_rows, ctx->partials);
+        else
+            hipLaunchKernelGGL((pass2_wide_kernel<T, false>), dim3(nb), dim3(kP2Threads), 0, ctx->stream, dc.d_ptrs, n_feat,
+                               add_bias ? 1 : 0, n_rows, d_beta, d_pred, d_resid, s_rows, ctx->partials);
         hipLaunchKernelGGL(pass2_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->partials, nb, d_sums);
         PDS_HIP_CHECK(hipGetLastError());
         return PDS_OK;

@@ -711,6 +711,31 @@ def test_multi_target(pds, orc):
     assert out["target_0"] is None and out["target_1"] is None  # the gate depends on X only: all targets null
 
 
+@pytest.mark.parametrize("p,bias", [(17, True), (40, False), (130, True)])
+def test_wide_weighted_and_hc(pds, orc, p, bias):
+    # p > 16 with a weight column: X' diag(w) X as the Gram of sqrt(w) Z; WLS report; HC0 / HC1 sandwich
+    rng = np.random.default_rng(900 + p)
+    n = 12_000 + 50 * p
+    X = rng.normal(size=(n, p))
+    y = X @ rng.normal(size=p) + 0.4 + rng.normal(size=n) * (0.5 + np.abs(X[:, 0]))
+    w = rng.random(n) + 0.25
+    Xb = np.c_[X, np.ones(n)] if bias else X
+    b = pds.lin_reg(*cols_of(X), target=dev(y), add_bias=bias, weights=dev(w))
+    assert nrel(b, orc.pl_lr(X, y, add_bias=bias, weights=w)) < F64_TOL
+    M = pds.gram_moments(*cols_of(X), target=dev(y), weights=dev(w))
+    Z = np.c_[X, np.ones(n), y]
+    assert nrel(M, Z.T @ (w[:, None] * Z)) < 1e-13
+    r = pds.lin_reg_report(*cols_of(X), target=dev(y), add_bias=bias, weights=dev(w))
+    ro = orc.wls_report(Xb, y, w)
+    assert nrel(r["beta"], ro["beta"]) < F64_TOL and frel(r["std_err"], ro["std_err"], 1e-12) < 1e-9
+    for se in ("hc0", "hc1"):
+        r = pds.lin_reg_report(*cols_of(X), target=dev(y), add_bias=bias, std_err=se)
+        ro = orc.lin_reg_report(Xb, y, std_err=se)
+        assert nrel(r["beta"], ro["beta"]) < F64_TOL and frel(r[f"{se}_se"], ro["std_err"], 1e-12) < 1e-9
+    with pytest.raises(Exception):
+        pds.lin_reg_report(*cols_of(X), target=dev(y), add_bias=bias, std_err="hc3")
+
+
 def test_wide_pred_and_report(pds, orc):
     rng = np.random.default_rng(31)
     n, p = 30_000, 24
