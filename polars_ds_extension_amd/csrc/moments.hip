@@ -214,12 +214,113 @@ int launch_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_
     return PDS_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// grouped Gram build for 17 .. 64 features: one wave per group, Z = [x | 1 | y] (q = p + 2 <= 66 columns) as
+// NB = ceil(q / 16) blocks of 16 columns.  32 rows at a time are staged column-major in LDS (f32 frames are widened to
+// f64 on the way in), every 4-row step feeds the NB operand registers to the upper-triangular block pairs of
+// v_mfma_f64_16x16x4_f64 (<= 15 accumulator tiles = 120 VGPRs), and the finished group writes its full symmetric
+// (p+2)^2 moment record.  Two-kernel pipeline (record -> solve_kernel): at these widths a group's record is as large
+// as its rows, so nothing is gained by fusing; this path exists for coverage, the headline path is p <= 16.
+// ---------------------------------------------------------------------------------------------
+constexpr int kMidRows = 32;
+constexpr int kMidStride = 34;  // doubles per LDS column: 68 dwords = 4 mod 64 -> conflict-free b64 operand reads
+
+template <typename T, int NB>
+__global__ __launch_bounds__(64) void grouped_moments_mid_kernel(const T* const* __restrict__ cols, int p,
+                                                                 const int64_t* __restrict__ offsets, int64_t n_groups,
+                                                                 T* __restrict__ moments) {
+    constexpr int NT = NB * (NB + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) double tile[];  // [NB * 16][kMidStride]
+    const int lane = threadIdx.x;
+    const int q = p + 2;
+    const int f = lane & 15, kq = lane >> 4;
+    for (int i = lane; i < NB * 16 * kMidStride; i += 64) tile[i] = 0.0;  // columns >= q stay zero for good
+    PDS_WAVE_LDS_SYNC();
+    for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const int64_t r0 = offsets[g], r1 = offsets[g + 1];
+        d4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+        for (int64_t base = r0; base < r1; base += kMidRows) {
+            // stage 32 rows: lanes 0-31 take an even column, lanes 32-63 the next one
+            const int row = lane & 31;
+            const int64_t r = base + row;
+            const bool in = r < r1;
+            for (int c0 = 0; c0 < q; c0 += 2) {
+                const int c = c0 + (lane >> 5);
+                if (c < q) {
+                    double v = 0.0;
+                    if (in) v = (c < p) ? (double)as_global(cols[c])[r] : (c == p ? 1.0 : (double)as_global(cols[p])[r]);
+                    tile[c * kMidStride + row] = v;
+                }
+            }
+            PDS_WAVE_LDS_SYNC();
+#pragma unroll
+            for (int s = 0; s < kMidRows / 4; ++s) {
+                double a[NB];
+#pragma unroll
+                for (int b = 0; b < NB; ++b) a[b] = tile[(16 * b + f) * kMidStride + 4 * s + kq];
+                int t = 0;
+#pragma unroll
+                for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+                    for (int bj = bi; bj < NB; ++bj) {
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[bi], a[bj], acc[t], 0, 0, 0);
+                        ++t;
+                    }
+            }
+            PDS_WAVE_LDS_SYNC();
+        }
+        // ---- record: D tile (bi, bj) holds rows 16 bi + (lane >> 4) + 4 r, column 16 bj + (lane & 15)
+        T* M = moments + g * (int64_t)q * q;
+        int t = 0;
+#pragma unroll
+        for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+            for (int bj = bi; bj < NB; ++bj) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int i = 16 * bi + kq + 4 * rr, j = 16 * bj + f;
+                    if (i < q && j < q) {
+                        const T v = (T)acc[t][rr];
+                        M[i + (int64_t)j * q] = v;
+                        if (bi != bj) M[j + (int64_t)i * q] = v;
+                    }
+                }
+                ++t;
+            }
+    }
+}
+
+template <typename T, int NB>
+static void launch_mid_nb(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, const int64_t* d_offsets, int64_t n_groups,
+                          T* d_moments) {
+    const size_t lds = (size_t)NB * 16 * kMidStride * sizeof(double);
+    const int per_cu = std::max(1, std::min(8, (int)((160 * 1024) / lds)));
+    const int nblocks = (int)std::min<int64_t>(n_groups, (int64_t)ctx->num_cus * per_cu);
+    hipLaunchKernelGGL((grouped_moments_mid_kernel<T, NB>), dim3(nblocks), dim3(64), lds, ctx->stream, dc.d_ptrs, n_feat,
+                       d_offsets, n_groups, d_moments);
+}
+
 template <typename T>
 int launch_grouped_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, const int64_t* d_offsets,
                            int64_t n_groups, T* d_moments) {
-    if (n_feat < 1 || n_feat > kMaxFeatSmall)
-        return fail(PDS_ERR_UNSUPPORTED, "grouped moments: 1..16 features supported");
+    if (n_feat < 1 || n_feat > kMaxFeatWide)
+        return fail(PDS_ERR_UNSUPPORTED, "grouped regressions: 1..64 features supported");
     if (n_groups <= 0) return PDS_OK;
+    if (n_feat > kMaxFeatSmall) {
+        const int nb = (n_feat + 2 + 15) / 16;  // 2 .. 5
+        KernelTimer timer(ctx, kKindGroupedMoments);
+        switch (nb) {
+            case 2: launch_mid_nb<T, 2>(ctx, dc, n_feat, d_offsets, n_groups, d_moments); break;
+            case 3: launch_mid_nb<T, 3>(ctx, dc, n_feat, d_offsets, n_groups, d_moments); break;
+            case 4: launch_mid_nb<T, 4>(ctx, dc, n_feat, d_offsets, n_groups, d_moments); break;
+            default: launch_mid_nb<T, 5>(ctx, dc, n_feat, d_offsets, n_groups, d_moments); break;
+        }
+        PDS_HIP_CHECK(hipGetLastError());
+        return PDS_OK;
+    }
     int64_t want = (n_groups + kWaves - 1) / kWaves;
     int nblocks = (int)std::min<int64_t>(want, (int64_t)ctx->num_cus * 2);
     size_t lds = (size_t)kWaves * kWaveLds;

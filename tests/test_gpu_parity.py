@@ -466,7 +466,35 @@ def test_f32_path(pds, orc, f32):
     assert np.max(np.linalg.norm(co.cpu().numpy()[63:] - ref, axis=1) / np.linalg.norm(ref, axis=1)) < 1e-3
 
 
-@pytest.mark.parametrize("p,bias", [(3, False), (5, True), (8, False), (12, True)])
+@pytest.mark.parametrize("p,bias", [(17, True), (30, False), (31, True), (47, True), (63, True), (64, False)])
+def test_grouped_17_to_64_features(pds, orc, p, bias):
+    # one wave per group over ceil((p+2)/16) column blocks (grouped_moments_mid_kernel) + the LDS solve
+    rng = np.random.default_rng(700 + p)
+    G = 300
+    sizes = rng.integers(1, 5 * p, size=G)
+    sizes[::41] = rng.integers(0, p, size=len(sizes[::41]))  # too-small groups -> null
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    N = int(off[-1])
+    X = rng.normal(size=(N, p))
+    y = np.empty(N)
+    for g in range(G):
+        sl = slice(off[g], off[g + 1])
+        y[sl] = X[sl] @ rng.normal(size=p) + 0.1 * rng.normal(size=sizes[g]) + (0.7 if bias else 0.0)
+    co, nu = pds.lin_reg_by(*cols_of(X), target=dev(y), group_offsets=off, add_bias=bias)
+    co, nu = co.cpu().numpy(), nu.cpu().numpy().astype(bool)
+    co_o, nu_o = orc.grouped_lr([y] + [X[:, j] for j in range(p)], off, add_bias=bias, nthreads=4)
+    assert np.array_equal(nu, nu_o) and nu.sum() >= 5
+    ok = ~nu
+    err = np.linalg.norm(co[ok] - co_o[ok], axis=1) / np.linalg.norm(co_o[ok], axis=1)
+    well = sizes[ok] >= 2 * (p + bias) + 8
+    assert well.sum() > 50 and np.max(err[well]) < F64_TOL
+    co2, nu2 = pds.lin_reg_by(*cols_of(X), target=dev(y), group_offsets=off, add_bias=bias, l2_reg=0.2)
+    co2_o, _ = orc.grouped_lr([y] + [X[:, j] for j in range(p)], off, add_bias=bias, l2_reg=0.2, nthreads=4)
+    big = sizes >= 2 * (p + bias) + 8  # (tiny groups under a small ridge are as ill-conditioned as without it)
+    assert np.max(np.linalg.norm(co2.cpu().numpy()[big] - co2_o[big], axis=1) / np.linalg.norm(co2_o[big], axis=1)) < F64_TOL
+
+
+@pytest.mark.parametrize("p,bias", [(3, False), (5, True), (8, False), (12, True), (20, True)])
 def test_grouped_f32_ragged(pds, orc, f32, p, bias):
     # f32 frames, group boundaries at arbitrary rows (p <= 8 runs the two-slab matrix-core path and its masked steps)
     rng = np.random.default_rng(300 + p)
