@@ -445,7 +445,8 @@ static int lr_multi_impl(pds_ctx* ctx, const T* const* cols, int k, int n_feat, 
     const int p = n_feat, bias = add_bias ? 1 : 0, pp = p + bias, q = p + 2;
     const int pa = p + k - 1, qa = pa + 2;  // augmented feature count: [x.., t_1..t_{k-1}], target t_0
     const bool want_pred = pred || resid;
-    size_t need = (1 << 20) + sizeof(T) * ((size_t)qa * qa + (size_t)k * (q * q + pp + 2)) + sizeof(T*) * (size_t)(pa + 64);
+    size_t need = (1 << 20) + sizeof(T) * ((size_t)qa * qa + (size_t)k * (q * q + pp + 2)) + sizeof(T*) * (size_t)(pa + 64) +
+                  (size_t)k * (sizeof(T*) * (size_t)(p + 20) + 256);
     if (pa > kMaxFeatSmall) need += moments_wide_workspace(ctx->num_cus, pa, n_rows);
     if (want_pred && space == PDS_HOST) need += 2 * ((size_t)n_rows * sizeof(T) + 512);
     if (int rc = ws_reserve(ctx, need)) return rc;
@@ -488,7 +489,7 @@ static int lr_multi_impl(pds_ctx* ctx, const T* const* cols, int k, int n_feat, 
     PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (is_null) *is_null = fl[0] ? 1 : 0;
     if (want_pred) {
-        if (p > kMaxFeatSmall) return fail(PDS_ERR_UNSUPPORTED, "multi-target predictions: 1..16 features supported");
+        const int tl = std::max(18, p + 2);  // pointer table length (the p <= 16 kernels read 18 entries)
         double* d_sums = reinterpret_cast<double*>(ws_take(ctx, 64));
         T* t_pred = nullptr;
         T* t_resid = nullptr;
@@ -501,9 +502,9 @@ static int lr_multi_impl(pds_ctx* ctx, const T* const* cols, int k, int n_feat, 
             dt.nc = p + 1;
             dt.h_ptrs.assign(dc.h_ptrs.begin(), dc.h_ptrs.begin() + p);
             dt.h_ptrs.push_back(t == 0 ? dc.h_ptrs[pa] : dc.h_ptrs[p + t - 1]);
-            dt.h_ptrs.resize(18, dt.h_ptrs[0]);
-            dt.d_ptrs = reinterpret_cast<const T**>(ws_take(ctx, sizeof(T*) * 18));
-            PDS_HIP_CHECK(hipMemcpyAsync(dt.d_ptrs, dt.h_ptrs.data(), sizeof(T*) * 18, hipMemcpyHostToDevice, ctx->stream));
+            dt.h_ptrs.resize(tl, dt.h_ptrs[0]);
+            dt.d_ptrs = reinterpret_cast<const T**>(ws_take(ctx, sizeof(T*) * tl));
+            PDS_HIP_CHECK(hipMemcpyAsync(dt.d_ptrs, dt.h_ptrs.data(), sizeof(T*) * tl, hipMemcpyHostToDevice, ctx->stream));
             T* op = (space == PDS_HOST) ? t_pred : (pred ? pred + (size_t)t * n_rows : nullptr);
             T* orr = (space == PDS_HOST) ? t_resid : (resid ? resid + (size_t)t * n_rows : nullptr);
             if (int rc = launch_pass2<T>(ctx, dt, p, n_rows, bias, false, d_co + (size_t)t * pp, nullptr, 0, op, orr, d_sums, nullptr))

@@ -715,10 +715,11 @@ def test_literal_skip_null_frame(pds):
 
 
 # ------------------------------------------------------------------------------------------ multi-target
-def test_multi_target(pds, orc):
+@pytest.mark.parametrize("p", [5, 15, 16, 22, 70])
+def test_multi_target(pds, orc, p):
     # tests/test_linear_exprs.py:1069-1113 (struct fields target_i == single-target fits, 1e-12) and :376-408 (pred)
     rng = np.random.default_rng(4)
-    n, p = 30_000, 5
+    n = 30_000
     X = rng.normal(size=(n, p))
     Y = np.c_[X @ rng.normal(size=p) + 0.3, X @ rng.normal(size=p) - 1.0, rng.normal(size=n)] + 0.05 * rng.normal(size=(n, 3))
     for bias, lam in ((False, 0.0), (True, 0.0), (True, 0.2)):
