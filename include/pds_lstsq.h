@@ -196,6 +196,21 @@ int pds_lin_reg_report_f32(pds_ctx* ctx, const float* const* cols, const float* 
                            float y_var, pds_report_f32* out);
 
 /*
+ * pds_lin_reg_report_nullable_*: `pl_lin_reg_report` on columns with Arrow validity bitmaps: the null policy of
+ * series_to_mat_for_lr (linear_regression.rs:151-267, called at :846) on the device, then the same report on the rows
+ * that survive it (dof, r2 use that row count).  Arguments as pds_lr_nullable_*; `y_var` stays what Polars computed
+ * on the original target.  `pl_wls_report` has no nullable form: the reference does not compact its weights.
+ */
+int pds_lin_reg_report_nullable_f64(pds_ctx* ctx, const double* const* cols, const uint8_t* const* validity,
+                                    const int64_t* bit_offsets, int n_feat, int64_t n_rows, pds_space space,
+                                    int null_policy, double fill_value, int add_bias, int se_type, double y_var,
+                                    pds_report_f64* out, int64_t* n_used);
+int pds_lin_reg_report_nullable_f32(pds_ctx* ctx, const float* const* cols, const uint8_t* const* validity,
+                                    const int64_t* bit_offsets, int n_feat, int64_t n_rows, pds_space space,
+                                    int null_policy, float fill_value, int add_bias, int se_type, float y_var,
+                                    pds_report_f32* out, int64_t* n_used);
+
+/*
  * pds_lr_grouped_*: the key-aware batched symbol of SURVEY.md 8(b) ("pl_lr_by"): what
  * `df.group_by(key).agg(pds.lin_reg(...))` makes Polars compute by calling `pl_lr` once per group
  * (tests/test_linear_exprs.py:918-953).  Rows of one group are contiguous; group g is rows

@@ -570,18 +570,67 @@ static int from_moments_impl(pds_ctx* ctx, const T* moments, pds_space mom_space
 // ---------------------------------------------------------------------------------------------
 template <typename T, typename R>
 static int report_impl(pds_ctx* ctx, const T* const* cols, const T* weights, int n_feat, int64_t n_rows,
-                       pds_space space, int add_bias, int se_type, T y_var, R* out) {
+                       pds_space space, int add_bias, int se_type, T y_var, R* out,
+                       // nullable form (pl_lin_reg_report with a null policy): Arrow validity per column [y, x1..xp]
+                       bool nullable = false, const uint8_t* const* validity = nullptr, const int64_t* bit_offsets = nullptr,
+                       int policy = PDS_NULL_RAISE, T fill_value = T(0), int64_t* n_used = nullptr) {
     if (!ctx || !cols || !out) return fail(PDS_ERR_INVALID, "null argument");
-    if (int rc = check_shape(n_feat, n_rows, add_bias)) return rc;
+    if (nullable) {
+        if (weights) return fail(PDS_ERR_UNSUPPORTED, "wls_report takes null-free inputs (the reference does not compact its weights)");
+        if (n_feat < 1) return fail(PDS_ERR_INVALID, "need at least one feature column");
+        if (n_rows == 0) return fail(PDS_ERR_EMPTY, "Empty data");
+        if (policy < PDS_NULL_RAISE || policy > PDS_NULL_IGNORE) return fail(PDS_ERR_INVALID, "Invalid NullPolicy.");
+    } else if (int rc = check_shape(n_feat, n_rows, add_bias)) {
+        return rc;
+    }
     if (weights && se_type != PDS_SE) se_type = PDS_SE;  // pl_wls_report only knows "std_err"
     PDS_HIP_CHECK(hipSetDevice(ctx->device));
     const int p = n_feat, bias = add_bias ? 1 : 0, pp = p + bias, q = p + 2;
     size_t need = 131072 + sizeof(T) * (size_t)(2 * q * q + pp * pp + pp) + sizeof(T*) * (size_t)(p + 64);
     if (p > kMaxFeatSmall) need += (se_type != PDS_SE ? 2 : 1) * moments_wide_workspace(ctx->num_cus, p, n_rows, true);
     if (se_type != PDS_SE) need += (size_t)n_rows * sizeof(T) + 512;
+    if (nullable) {
+        need += (1 << 20) + null_policy_workspace(p + 1, n_rows, sizeof(T));
+        if (space == PDS_HOST) need += (size_t)(p + 1) * ((size_t)n_rows / 8 + 4096);
+    }
     if (int rc = ws_reserve(ctx, need)) return rc;
     DeviceCols<T> dc;
     if (int rc = make_device_cols<T>(ctx, cols, weights, p, n_rows, space, dc)) return rc;
+    if (nullable) {
+        const int nc = p + 1;
+        std::vector<const T*> ref_order(nc);
+        ref_order[0] = dc.h_ptrs[p];
+        for (int c = 0; c < p; ++c) ref_order[c + 1] = dc.h_ptrs[c];
+        std::vector<const uint8_t*> bms(nc, nullptr);
+        std::vector<int64_t> boff(nc, 0);
+        for (int c = 0; c < nc; ++c) {
+            boff[c] = bit_offsets ? bit_offsets[c] : 0;
+            const uint8_t* b = validity ? validity[c] : nullptr;
+            if (b && space == PDS_HOST) {
+                const size_t bytes = (size_t)((boff[c] + n_rows + 7) / 8);
+                uint8_t* d = reinterpret_cast<uint8_t*>(ws_take(ctx, bytes));
+                PDS_HIP_CHECK(hipMemcpyAsync(d, b, bytes, hipMemcpyHostToDevice, ctx->stream));
+                b = d;
+            }
+            bms[c] = b;
+        }
+        NullPrepared<T> prep;
+        if (int rc = apply_null_policy<T>(ctx, ref_order, bms, boff, n_rows, policy, fill_value, prep)) return rc;
+        if (n_used) *n_used = prep.n_kept;
+        if (prep.n_kept == 0) return fail(PDS_ERR_EMPTY, "Empty data");
+        if (prep.n_kept < pp) return fail(PDS_ERR_TOO_FEW_ROWS, "#Data < #features. No conclusive result.");
+        n_rows = prep.n_kept;  // everything below works on the rows that survive the policy
+        DeviceCols<T> dk;
+        dk.nc = nc;
+        dk.h_ptrs.resize(nc);
+        for (int c = 0; c < p; ++c) dk.h_ptrs[c] = prep.cols[c + 1];
+        dk.h_ptrs[p] = prep.cols[0];
+        dk.h_ptrs.resize(std::max(nc, 18), dk.h_ptrs[0]);
+        dk.d_ptrs = reinterpret_cast<const T**>(ws_take(ctx, sizeof(T*) * dk.h_ptrs.size()));
+        PDS_HIP_CHECK(hipMemcpyAsync(dk.d_ptrs, dk.h_ptrs.data(), sizeof(T*) * dk.h_ptrs.size(), hipMemcpyHostToDevice, ctx->stream));
+        PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // dk.h_ptrs is copied from before dc takes it over
+        dc = dk;
+    }
     T* d_mom = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * q * q));
     T* d_mom2 = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * q * q));
     T* d_beta = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * (pp + 2)));
@@ -958,6 +1007,21 @@ int pds_lin_reg_report_f64(pds_ctx* ctx, const double* const* cols, const double
 int pds_lin_reg_report_f32(pds_ctx* ctx, const float* const* cols, const float* weights, int n_feat, int64_t n_rows,
                            pds_space space, int add_bias, int se_type, float y_var, pds_report_f32* out) {
     return report_impl<float, pds_report_f32>(ctx, cols, weights, n_feat, n_rows, space, add_bias, se_type, y_var, out);
+}
+
+int pds_lin_reg_report_nullable_f64(pds_ctx* ctx, const double* const* cols, const uint8_t* const* validity,
+                                    const int64_t* bit_offsets, int n_feat, int64_t n_rows, pds_space space, int null_policy,
+                                    double fill_value, int add_bias, int se_type, double y_var, pds_report_f64* out,
+                                    int64_t* n_used) {
+    return report_impl<double, pds_report_f64>(ctx, cols, nullptr, n_feat, n_rows, space, add_bias, se_type, y_var, out, true,
+                                               validity, bit_offsets, null_policy, fill_value, n_used);
+}
+int pds_lin_reg_report_nullable_f32(pds_ctx* ctx, const float* const* cols, const uint8_t* const* validity,
+                                    const int64_t* bit_offsets, int n_feat, int64_t n_rows, pds_space space, int null_policy,
+                                    float fill_value, int add_bias, int se_type, float y_var, pds_report_f32* out,
+                                    int64_t* n_used) {
+    return report_impl<float, pds_report_f32>(ctx, cols, nullptr, n_feat, n_rows, space, add_bias, se_type, y_var, out, true,
+                                              validity, bit_offsets, null_policy, fill_value, n_used);
 }
 
 int pds_lr_grouped_f64(pds_ctx* ctx, const double* const* cols, int n_feat, int64_t n_rows,

@@ -346,14 +346,45 @@ def lin_reg_w_rcond(*x, target, add_bias: bool = False, rcond: float = 0.0, l2_r
 
 
 def lin_reg_report(*x, target, add_bias: bool = False, weights=None, std_err: str = "se", y_var: float | None = None,
-                   feature_names: Sequence[str] | None = None, ctx: Context | None = None) -> dict:
+                   feature_names: Sequence[str] | None = None, null_policy: str = "raise", ctx: Context | None = None) -> dict:
     """
     pds.lin_reg_report (pl_lin_reg_report / pl_wls_report).  `y_var` is what Polars evaluates as
     `target.var()` (ddof=1) and hands to the plugin as input 0 (expr_linear.py:614-617); when omitted it
     is taken from the moment pass (sum y, sum y^2 are by-products of the Gram build).
     Returns the 9 report columns as a dict of arrays (r2 / adj_r2 broadcast like the reference's struct).
+    pyarrow columns may carry nulls: `null_policy` then applies as in series_to_mat_for_lr (the reference's default for
+    this expression is "raise", expr_linear.py:566); `y_var` must be given in that case (Polars computes it on the
+    original target).
     """
     ctx = ctx or default_context()
+    arrow = weights is None and any(_is_arrow(c) for c in (target, *x))
+    code, fill = parse_null_policy(null_policy)
+    if arrow:
+        if y_var is None:
+            import pyarrow.compute as pc
+
+            y_var = float(pc.variance(target, ddof=1).as_py())  # Polars' var() skips nulls the same way
+        dt = _dtype()
+        parts = [_arrow_parts(c, dt) if _is_arrow(c) else (np.ascontiguousarray(np.asarray(c), dtype=dt), 0, 0, None)
+                 for c in (target, *x)]
+        n = len(parts[0][0])
+        if any(len(pt[0]) != n for pt in parts):
+            raise ValueError("all columns must be 1-D and of equal length")
+        nc = len(parts)
+        n_feat = nc - 1
+        pp = n_feat + int(bool(add_bias))
+        outs = {k: np.empty(pp, dtype=dt) for k in ("beta", "std_err", "t", "p", "ci_lower", "ci_upper")}
+        R = _lib.ReportF64 if config.LIN_REG_EXPR_F64 else _lib.ReportF32
+        rep = R(*[C.c_void_p(outs[k].ctypes.data) for k in ("beta", "std_err", "t", "p", "ci_lower", "ci_upper")], 0.0, 0.0)
+        cp = (C.c_void_p * nc)(*[pt[0].ctypes.data for pt in parts])
+        vp = (C.c_void_p * nc)(*[pt[1] or None for pt in parts])
+        op = (C.c_int64 * nc)(*[pt[2] for pt in parts])
+        f = (C.c_double if config.LIN_REG_EXPR_F64 else C.c_float)
+        n_used = C.c_int64(0)
+        _lib.check(ctx.fn("pds_lin_reg_report_nullable")(ctx._h, cp, vp, op, n_feat, C.c_int64(n), _lib.PDS_HOST, code, f(fill),
+                                                         int(bool(add_bias)), _lib.SE_TYPES.get(std_err, 0), f(y_var),
+                                                         C.byref(rep), C.byref(n_used)))
+        return _report_dict(outs, rep, n_feat, add_bias, std_err, False, feature_names, dt)
     cols = _Cols(target, x, weights)
     _follow(ctx, cols)
     pp = cols.n_feat + int(bool(add_bias))
@@ -371,11 +402,16 @@ def lin_reg_report(*x, target, add_bias: bool = False, weights=None, std_err: st
     _lib.check(ctx.fn("pds_lin_reg_report")(ctx._h, cols.cols, cols.weights, cols.n_feat, C.c_int64(cols.n_rows),
                                             cols.space, int(bool(add_bias)), _lib.SE_TYPES.get(std_err, 0), yv,
                                             C.byref(rep)))
-    names = list(feature_names) if feature_names is not None else [f"x{i + 1}" for i in range(cols.n_feat)]
+    return _report_dict(outs, rep, cols.n_feat, add_bias, std_err, weights is not None, feature_names, dt)
+
+
+def _report_dict(outs, rep, n_feat, add_bias, std_err, weighted, feature_names, dt):
+    pp = n_feat + int(bool(add_bias))
+    names = list(feature_names) if feature_names is not None else [f"x{i + 1}" for i in range(n_feat)]
     if add_bias:
         names.append("__bias__")  # linear_regression.rs:843-845
     se_name = {"se": "std_err", "hc0": "hc0_se", "hc1": "hc1_se", "hc2": "hc2_se", "hc3": "hc3_se"}.get(std_err, "std_err")
-    if weights is not None:
+    if weighted:
         se_name = "std_err"
     return {
         "features": names, "beta": outs["beta"], se_name: outs["std_err"], "t": outs["t"], "p>|t|": outs["p"],

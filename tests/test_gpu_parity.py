@@ -702,6 +702,34 @@ def test_null_policies_match_reference_semantics(pds, orc, offset):
     assert nrel(pds.lin_reg(*arrs3[1:], target=arrs3[0], null_policy="raise"), orc.pl_lr(X3, y3)) < F64_TOL
 
 
+@pytest.mark.parametrize("se", ["se", "hc1"])
+def test_report_null_policies(pds, orc, se):
+    # pl_lin_reg_report runs series_to_mat_for_lr with the expression's null_policy (linear_regression.rs:846)
+    from polars_ds_extension_amd._lib import PdsError
+
+    rng = np.random.default_rng(17)
+    n, p = 30_000, 4
+    arrs, X, y, valid = _arrow_frame(rng, n, p, null_cols={0, 2, 4}, offset=3)
+    keep = np.logical_and.reduce(valid)
+    yv = float(np.var(y[valid[0]], ddof=1))
+    key = {"se": "std_err"}.get(se, f"{se}_se")
+    r = pds.lin_reg_report(*arrs[1:], target=arrs[0], add_bias=True, std_err=se, null_policy="skip", y_var=yv)
+    ro = orc.lin_reg_report(np.c_[X[keep], np.ones(keep.sum())], y[keep], y_var=yv, std_err=se)
+    assert nrel(r["beta"], ro["beta"]) < F64_TOL and frel(r[key], ro["std_err"], 1e-12) < 1e-9
+    assert frel(r["p>|t|"], ro["p"], 1e-12) < 1e-7 and abs(r["r2"][0] - ro["r2"]) < 1e-12 and abs(r["adj_r2"][0] - ro["adj_r2"]) < 1e-12
+    r2 = pds.lin_reg_report(*arrs[1:], target=arrs[0], add_bias=True, std_err=se, null_policy="skip")  # y_var from pyarrow
+    assert abs(r2["r2"][0] - r["r2"][0]) < 1e-12
+    Xf = X.copy()
+    for j in range(p):
+        Xf[~valid[j + 1], j] = 1.0
+    k0 = valid[0]
+    r = pds.lin_reg_report(*arrs[1:], target=arrs[0], add_bias=True, std_err=se, null_policy="one", y_var=yv)
+    ro = orc.lin_reg_report(np.c_[Xf[k0], np.ones(k0.sum())], y[k0], y_var=yv, std_err=se)
+    assert nrel(r["beta"], ro["beta"]) < F64_TOL and frel(r[key], ro["std_err"], 1e-12) < 1e-9
+    with pytest.raises(PdsError, match="Nulls found in data"):
+        pds.lin_reg_report(*arrs[1:], target=arrs[0], add_bias=True, null_policy="raise", y_var=yv)
+
+
 def test_literal_skip_null_frame(pds):
     # tests/test_linear_exprs.py:411-432 (literal frame): a null in row 0 -> pred [None, 9.5, 10.5, 11.5, 12.5], resid [None, 0, 0, 0, 0]
     import pyarrow as pa

@@ -143,6 +143,16 @@ def test_pl_lin_reg_report_struct(so, orc):
     np.testing.assert_allclose(t["hc1_se"].to_numpy(), ro["std_err"], rtol=1e-10)
     np.testing.assert_allclose(t["p>|t|"].to_numpy(), ro["p"], rtol=1e-8, atol=1e-300)
     assert len(set(t["r2"].to_pylist())) == 1 and abs(t["r2"][0].as_py() - ro["r2"]) < 1e-12
+    # nulls + null_policy through the plugin ABI: rows with a null anywhere are skipped (series_to_mat_for_lr)
+    m = rng.random(n) < 0.05
+    ins2 = [ins[0], ins[1], ("a", pa.array(np.where(m, -7.0, X[:, 0]), mask=m)), ins[3], ins[4]]
+    _, out2 = ph.call_plugin(so, "pl_lin_reg_report", ins2, dict(LR, bias=True, std_err="se", null_policy="skip"))
+    t2 = pa.Table.from_batches([pa.RecordBatch.from_struct_array(out2)])
+    ro2 = orc.lin_reg_report(np.c_[X[~m], np.ones((~m).sum())], y[~m], y_var=float(np.var(y, ddof=1)))
+    np.testing.assert_allclose(t2["beta"].to_numpy(), ro2["beta"], rtol=1e-10)
+    np.testing.assert_allclose(t2["std_err"].to_numpy(), ro2["std_err"], rtol=1e-10)
+    with pytest.raises(ph.PluginFailure, match="Nulls found in data"):
+        ph.call_plugin(so, "pl_lin_reg_report", ins2, dict(LR, bias=True, std_err="se", null_policy="raise"))
 
 
 @pytest.mark.gpu
