@@ -228,6 +228,20 @@ int pds_lr_grouped_f32(pds_ctx* ctx, const float* const* cols, int n_feat, int64
                        const pds_lr_params* prm, float* coeffs, uint8_t* is_null);
 
 /*
+ * pds_lr_grouped_nullable_*: the same with Arrow validity bitmaps (arguments as pds_lr_nullable_*): what Polars gets
+ * from `group_by(key).agg(pds.lin_reg(..., null_policy=...))` -- every group is fitted on the rows of it that survive the
+ * policy; a group left with fewer rows than coefficients is null.  PDS_NULL_RAISE fails on the first null anywhere.
+ */
+int pds_lr_grouped_nullable_f64(pds_ctx* ctx, const double* const* cols, const uint8_t* const* validity,
+                                const int64_t* bit_offsets, int n_feat, int64_t n_rows,
+                                const int64_t* group_offsets, int64_t n_groups, pds_space space, int null_policy,
+                                double fill_value, const pds_lr_params* prm, double* coeffs, uint8_t* is_null);
+int pds_lr_grouped_nullable_f32(pds_ctx* ctx, const float* const* cols, const uint8_t* const* validity,
+                                const int64_t* bit_offsets, int n_feat, int64_t n_rows,
+                                const int64_t* group_offsets, int64_t n_groups, pds_space space, int null_policy,
+                                float fill_value, const pds_lr_params* prm, float* coeffs, uint8_t* is_null);
+
+/*
  * pds_rolling_lr_* / pds_recursive_lr_*: `pl_rolling_lr` (linear_regression.rs:1206-1283) and
  * `pl_recursive_lr` (:1121-1204) on null-free columns, i.e. faer_rolling_lr / faer_recursive_lr
  * (lr_online_solvers.rs:148-212) plus the plugin's pred_i = x_i . coeffs_i.  SWWLRKwargs: n = window

@@ -710,7 +710,11 @@ static int report_impl(pds_ctx* ctx, const T* const* cols, const T* weights, int
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t n_rows, const int64_t* offsets,
-                        int64_t n_groups, pds_space space, const pds_lr_params* prm, T* coeffs, uint8_t* is_null) {
+                        int64_t n_groups, pds_space space, const pds_lr_params* prm, T* coeffs, uint8_t* is_null,
+                        // nullable form: Arrow validity per column [y, x1..xp]; every group is fitted on the rows of it that
+                        // survive the policy, like Polars calling pl_lr(null_policy=...) per group
+                        bool nullable = false, const uint8_t* const* validity = nullptr, const int64_t* bit_offsets = nullptr,
+                        int policy = PDS_NULL_RAISE, T fill_value = T(0)) {
     if (!ctx || !cols || !offsets || !prm || !coeffs) return fail(PDS_ERR_INVALID, "null argument");
     if (n_feat < 1) return fail(PDS_ERR_INVALID, "need at least one feature column");
     if (n_groups <= 0 || n_rows <= 0) return fail(PDS_ERR_EMPTY, "Empty data");
@@ -724,6 +728,11 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
     chunk = std::min(chunk, n_groups);
     size_t need = 131072 + sizeof(T) * (size_t)chunk * q * q;
     if (space == PDS_HOST) need += (size_t)(n_groups + 1) * 8 + (size_t)n_groups * (pp * sizeof(T) + 1) + 4096;
+    if (nullable) {
+        if (policy < PDS_NULL_RAISE || policy > PDS_NULL_IGNORE) return fail(PDS_ERR_INVALID, "Invalid NullPolicy.");
+        need += (1 << 20) + null_policy_workspace(n_feat + 1, n_rows, sizeof(T)) + (size_t)(n_groups + 1) * 8 + 4096;
+        if (space == PDS_HOST) need += (size_t)(n_feat + 1) * ((size_t)n_rows / 8 + 4096);
+    }
     if (int rc = ws_reserve(ctx, need)) return rc;
     DeviceCols<T> dc;
     if (int rc = make_device_cols<T>(ctx, cols, (const T*)nullptr, n_feat, n_rows, space, dc)) return rc;
@@ -738,6 +747,44 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
         d_null = reinterpret_cast<uint8_t*>(ws_take(ctx, (size_t)n_groups));
     } else if (!d_null) {
         d_null = reinterpret_cast<uint8_t*>(ws_take(ctx, (size_t)n_groups));
+    }
+    if (nullable) {
+        const int nc = n_feat + 1;
+        std::vector<const T*> ref_order(nc);
+        ref_order[0] = dc.h_ptrs[n_feat];
+        for (int c = 0; c < n_feat; ++c) ref_order[c + 1] = dc.h_ptrs[c];
+        std::vector<const uint8_t*> bms(nc, nullptr);
+        std::vector<int64_t> boff(nc, 0);
+        for (int c = 0; c < nc; ++c) {
+            boff[c] = bit_offsets ? bit_offsets[c] : 0;
+            const uint8_t* b = validity ? validity[c] : nullptr;
+            if (b && space == PDS_HOST) {
+                const size_t bytes = (size_t)((boff[c] + n_rows + 7) / 8);
+                uint8_t* d = reinterpret_cast<uint8_t*>(ws_take(ctx, bytes));
+                PDS_HIP_CHECK(hipMemcpyAsync(d, b, bytes, hipMemcpyHostToDevice, ctx->stream));
+                b = d;
+            }
+            bms[c] = b;
+        }
+        NullPrepared<T> prep;
+        if (int rc = apply_null_policy<T>(ctx, ref_order, bms, boff, n_rows, policy, fill_value, prep)) return rc;
+        if (prep.dropped) {
+            int64_t* off2 = reinterpret_cast<int64_t*>(ws_take(ctx, (size_t)(n_groups + 1) * 8));
+            if (int rc = remap_group_offsets(ctx, d_off, n_groups, prep.d_rank, n_rows, prep.n_kept, off2)) return rc;
+            d_off = off2;
+        }
+        DeviceCols<T> dk;
+        dk.nc = nc;
+        dk.h_ptrs.resize(nc);
+        for (int c = 0; c < n_feat; ++c) dk.h_ptrs[c] = prep.cols[c + 1];
+        dk.h_ptrs[n_feat] = prep.cols[0];
+        dk.h_ptrs.resize(std::max(nc, 18), dk.h_ptrs[0]);
+        dk.d_ptrs = reinterpret_cast<const T**>(ws_take(ctx, sizeof(T*) * dk.h_ptrs.size()));
+        PDS_HIP_CHECK(hipMemcpyAsync(dk.d_ptrs, dk.h_ptrs.data(), sizeof(T*) * dk.h_ptrs.size(), hipMemcpyHostToDevice, ctx->stream));
+        PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        dc = dk;
+        n_rows = prep.n_kept;
+        if (n_rows == 0) return fail(PDS_ERR_EMPTY, "Empty data");
     }
     T* d_mom = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * (size_t)chunk * q * q));
     SolveParams sp{n_feat, bias, prm->solver == PDS_SOLVER_SVD ? PDS_SOLVER_QR : prm->solver, prm->l2_reg,
@@ -1033,6 +1080,21 @@ int pds_lr_grouped_f32(pds_ctx* ctx, const float* const* cols, int n_feat, int64
                        const int64_t* group_offsets, int64_t n_groups, pds_space space, const pds_lr_params* prm,
                        float* coeffs, uint8_t* is_null) {
     return grouped_impl<float>(ctx, cols, n_feat, n_rows, group_offsets, n_groups, space, prm, coeffs, is_null);
+}
+
+int pds_lr_grouped_nullable_f64(pds_ctx* ctx, const double* const* cols, const uint8_t* const* validity,
+                                const int64_t* bit_offsets, int n_feat, int64_t n_rows, const int64_t* group_offsets,
+                                int64_t n_groups, pds_space space, int null_policy, double fill_value, const pds_lr_params* prm,
+                                double* coeffs, uint8_t* is_null) {
+    return grouped_impl<double>(ctx, cols, n_feat, n_rows, group_offsets, n_groups, space, prm, coeffs, is_null, true, validity,
+                                bit_offsets, null_policy, fill_value);
+}
+int pds_lr_grouped_nullable_f32(pds_ctx* ctx, const float* const* cols, const uint8_t* const* validity,
+                                const int64_t* bit_offsets, int n_feat, int64_t n_rows, const int64_t* group_offsets,
+                                int64_t n_groups, pds_space space, int null_policy, float fill_value, const pds_lr_params* prm,
+                                float* coeffs, uint8_t* is_null) {
+    return grouped_impl<float>(ctx, cols, n_feat, n_rows, group_offsets, n_groups, space, prm, coeffs, is_null, true, validity,
+                               bit_offsets, null_policy, fill_value);
 }
 
 int pds_rolling_lr_f64(pds_ctx* ctx, const double* const* cols, int n_feat, int64_t n_rows, pds_space space,

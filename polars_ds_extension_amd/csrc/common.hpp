@@ -206,6 +206,8 @@ template <typename T>
 int expand_rows(pds_ctx* ctx, const T* d_compact, const uint8_t* d_keep, const int64_t* d_rank, int64_t n_rows, T* d_out,
                 uint8_t* d_valid);
 size_t null_policy_workspace(int n_cols, int64_t n_rows, size_t elem);
+int remap_group_offsets(pds_ctx* ctx, const int64_t* d_off, int64_t n_groups, const int64_t* d_rank, int64_t n_rows,
+                        int64_t n_kept, int64_t* d_out);
 
 // ---- rolling.hip ----
 template <typename T>

@@ -149,6 +149,25 @@ int expand_rows(pds_ctx* ctx, const T* d_compact, const uint8_t* d_keep, const i
     return PDS_OK;
 }
 
+// group g = rows [off[g], off[g+1]) of the original frame -> the same group in the compacted frame
+__global__ __launch_bounds__(256) void remap_offsets_kernel(const int64_t* __restrict__ off, int64_t n_groups,
+                                                            const int64_t* __restrict__ rank, int64_t n_rows, int64_t n_kept,
+                                                            int64_t* __restrict__ out) {
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g <= n_groups; g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = off[g];
+        out[g] = r < n_rows ? rank[r] : n_kept;  // rank = number of kept rows in front of row r
+    }
+}
+
+int remap_group_offsets(pds_ctx* ctx, const int64_t* d_off, int64_t n_groups, const int64_t* d_rank, int64_t n_rows,
+                        int64_t n_kept, int64_t* d_out) {
+    const int nblocks = (int)std::min<int64_t>((n_groups + 256) / 256, (int64_t)ctx->num_cus * 8);
+    hipLaunchKernelGGL(remap_offsets_kernel, dim3(nblocks), dim3(256), 0, ctx->stream, d_off, n_groups, d_rank, n_rows, n_kept,
+                       d_out);
+    PDS_HIP_CHECK(hipGetLastError());
+    return PDS_OK;
+}
+
 size_t null_policy_workspace(int n_cols, int64_t n_rows, size_t elem) {
     // keep + rank + (fill + compact) copies of every column + cub temporaries
     return (size_t)n_rows * (1 + 8 + 2 * (size_t)n_cols * elem) + ((size_t)n_rows / 64 + 65536) * 8 + (1 << 20);

@@ -421,13 +421,38 @@ def _report_dict(outs, rep, n_feat, add_bias, std_err, weighted, feature_names, 
 
 
 def lin_reg_by(*x, target, group_offsets, add_bias: bool = False, l2_reg: float = 0.0, solver: str = "qr",
-               singular_x_tol: float | None = None, ctx: Context | None = None):
+               singular_x_tol: float | None = None, null_policy: str = "skip", ctx: Context | None = None):
     """
     The key-aware batched form of `df.group_by(key).agg(pds.lin_reg(...))` (SURVEY.md 8b "pl_lr_by").
     Rows of a group are contiguous; group g = rows [group_offsets[g], group_offsets[g+1]).
     Returns (coeffs [n_groups, p'], is_null [n_groups]) in the memory space of the inputs.
+    pyarrow columns may carry nulls; `null_policy` then applies inside every group, as it does when Polars calls pl_lr
+    once per group.
     """
     ctx = ctx or default_context()
+    code, fill = parse_null_policy(null_policy)
+    if any(_is_arrow(c) for c in (target, *x)):
+        dt = _dtype()
+        parts = [_arrow_parts(c, dt) if _is_arrow(c) else (np.ascontiguousarray(np.asarray(c), dtype=dt), 0, 0, None)
+                 for c in (target, *x)]
+        n = len(parts[0][0])
+        if any(len(pt[0]) != n for pt in parts):
+            raise ValueError("all columns must be 1-D and of equal length")
+        nc = len(parts)
+        prm = _params(add_bias, 0.0, l2_reg, 1e-5, solver, False, 200, singular_x_tol)
+        pp = nc - 1 + int(bool(add_bias))
+        off = np.ascontiguousarray(np.asarray(group_offsets), dtype=np.int64)
+        ng = int(off.shape[0]) - 1
+        coeffs = np.empty((ng, pp), dtype=dt)
+        nulls = np.empty(ng, dtype=np.uint8)
+        cp = (C.c_void_p * nc)(*[pt[0].ctypes.data for pt in parts])
+        vp = (C.c_void_p * nc)(*[pt[1] or None for pt in parts])
+        op = (C.c_int64 * nc)(*[pt[2] for pt in parts])
+        f = (C.c_double if config.LIN_REG_EXPR_F64 else C.c_float)
+        _lib.check(ctx.fn("pds_lr_grouped_nullable")(ctx._h, cp, vp, op, nc - 1, C.c_int64(n), C.c_void_p(off.ctypes.data),
+                                                     C.c_int64(ng), _lib.PDS_HOST, code, f(fill), C.byref(prm),
+                                                     C.c_void_p(coeffs.ctypes.data), C.c_void_p(nulls.ctypes.data)))
+        return coeffs, nulls
     cols = _Cols(target, x)
     _follow(ctx, cols)
     prm = _params(add_bias, 0.0, l2_reg, 1e-5, solver, False, 200, singular_x_tol)

@@ -730,6 +730,39 @@ def test_report_null_policies(pds, orc, se):
         pds.lin_reg_report(*arrs[1:], target=arrs[0], add_bias=True, null_policy="raise", y_var=yv)
 
 
+def test_grouped_null_policies(pds, orc):
+    # group_by(key).agg(pds.lin_reg(null_policy=...)): every group is fitted on its rows that survive the policy
+    from polars_ds_extension_amd._lib import PdsError
+
+    rng = np.random.default_rng(23)
+    p = 3
+    G = 400
+    sizes = rng.integers(1, 80, size=G)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    n = int(off[-1])
+    arrs, X, y, valid = _arrow_frame(rng, n, p, null_cols={0, 2}, frac=0.15)
+    keep = np.logical_and.reduce(valid)
+    co, nu = pds.lin_reg_by(*arrs[1:], target=arrs[0], group_offsets=off, add_bias=True, null_policy="skip")
+    rank = np.concatenate([[0], np.cumsum(keep)])
+    off_k = rank[off]
+    co_o, nu_o = orc.grouped_lr([y[keep]] + [X[keep][:, j] for j in range(p)], off_k, add_bias=True, nthreads=2)
+    assert np.array_equal(nu.astype(bool), nu_o) and nu_o.sum() > 3
+    ok = ~nu_o & (np.diff(off_k) >= 2 * (p + 1) + 8)
+    assert np.max(np.linalg.norm(co[ok] - co_o[ok], axis=1) / np.linalg.norm(co_o[ok], axis=1)) < F64_TOL
+    # fill: feature nulls become the fill value, rows with a null target are dropped
+    Xf = X.copy()
+    Xf[~valid[2], 1] = 0.0
+    k0 = valid[0]
+    rank0 = np.concatenate([[0], np.cumsum(k0)])
+    co, nu = pds.lin_reg_by(*arrs[1:], target=arrs[0], group_offsets=off, add_bias=True, null_policy="zero")
+    co_o, nu_o = orc.grouped_lr([y[k0]] + [Xf[k0][:, j] for j in range(p)], rank0[off], add_bias=True, nthreads=2)
+    assert np.array_equal(nu.astype(bool), nu_o)
+    ok = ~nu_o & (np.diff(rank0[off]) >= 2 * (p + 1) + 8)
+    assert np.max(np.linalg.norm(co[ok] - co_o[ok], axis=1) / np.linalg.norm(co_o[ok], axis=1)) < F64_TOL
+    with pytest.raises(PdsError, match="Nulls found in data"):
+        pds.lin_reg_by(*arrs[1:], target=arrs[0], group_offsets=off, null_policy="raise")
+
+
 def test_literal_skip_null_frame(pds):
     # tests/test_linear_exprs.py:411-432 (literal frame): a null in row 0 -> pred [None, 9.5, 10.5, 11.5, 12.5], resid [None, 0, 0, 0, 0]
     import pyarrow as pa
