@@ -57,11 +57,14 @@ def main() -> int:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # PDS_BENCH_FORCE_DIST=1 runs the RCCL init / barrier / all-reduce code path at world_size 1 (single-GPU smoke of the N > 1 path)
+    use_dist = world > 1 or os.environ.get("PDS_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     import polars_ds_extension_amd as pds
 
@@ -88,7 +91,7 @@ def main() -> int:
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -103,7 +106,7 @@ def main() -> int:
     elapsed = time.perf_counter() - t0
     ctx.set_timing(False)
     timing = ctx.get_timing(reset=True)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -221,7 +224,7 @@ def main() -> int:
             "roofline": roofline, "gram_build": gram, "grouped_p8": p8, "cpu_baseline": cpu, "parity_spot_check": parity,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     return 0

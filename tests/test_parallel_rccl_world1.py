@@ -1,0 +1,68 @@
+"""
+The multi-GPU orchestration with its DEFAULT compute steps (the HIP library) and the RCCL backend, at world_size 1 on
+the one GPU a test box has: init / all-reduce / all-gather / gather run through RCCL, the sharding arithmetic through
+its rank-0-of-1 case.  (World-2 logic is covered on CPU with gloo in test_parallel_gloo.py.)
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.fixture(scope="module")
+def world1():
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield dist
+    dist.destroy_process_group()
+
+
+def test_sharded_paths_on_rccl(world1):
+    import torch
+
+    import polars_ds_extension_amd as pds
+    from polars_ds_extension_amd import parallel as par
+
+    rng = np.random.default_rng(3)
+    n, p = 60_000, 6
+    X = rng.random((n, p))
+    y = X @ rng.normal(size=p) + 0.3 + 0.05 * rng.normal(size=n)
+    xs = [torch.from_numpy(np.ascontiguousarray(X[:, j])).cuda() for j in range(p)]
+    yt = torch.from_numpy(y).cuda()
+    # row-sharded single regression: moments -> all-reduce -> replicated solve
+    b = par.lin_reg_row_sharded(xs, yt, add_bias=True)
+    b0 = pds.lin_reg(*xs, target=yt, add_bias=True)
+    assert np.linalg.norm(np.asarray(b) - b0) / np.linalg.norm(b0) < 1e-12
+    # group-sharded, gathered on rank 0
+    sizes = rng.integers(10, 200, size=500)
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    off = off[off <= n]
+    g_lo, g_hi, co_all, nu_all = par.lin_reg_by_group_sharded(xs, yt, off, gather_to=0, add_bias=False)
+    ref_co, ref_nu = pds.lin_reg_by(*xs, target=yt, group_offsets=off)
+    assert (g_lo, g_hi) == (0, len(off) - 1)
+    assert torch.allclose(co_all.to(ref_co.device), ref_co, rtol=0, atol=0, equal_nan=True)
+    assert torch.equal(nu_all.to(ref_nu.device), ref_nu)
+    # rolling with halo / expanding with an all-gathered prefix
+    lo, hi, rc, rp, rv = par.rolling_lin_reg_row_sharded(xs, yt, 64, add_bias=True)
+    c0, p0, v0 = pds.rolling_lin_reg(*xs, target=yt, window_size=64, add_bias=True)
+    assert (lo, hi) == (0, n) and torch.equal(rv, v0) and torch.allclose(rc[63:], c0[63:], rtol=0, atol=0)
+    ec, ep, ev = par.recursive_lin_reg_row_sharded(xs, yt, 12, add_bias=True)
+    c1, p1, v1 = pds.recursive_lin_reg(*xs, target=yt, start_with=12, add_bias=True)
+    assert torch.equal(ev, v1) and torch.allclose(ec[11:], c1[11:], rtol=0, atol=0)
