@@ -85,6 +85,8 @@ struct pds_ctx {
     pds::Workspace solve_ws; // factor workspace of the p' > 64 solver (solve_big.hip)
     void* pinned = nullptr;  // pinned host scratch (small results, pointer arrays)
     size_t pinned_bytes = 0;
+    void* pinned_in = nullptr;  // pinned staging of small PDS_HOST frames: all columns + pointer table, ONE H2D copy
+    size_t pinned_in_bytes = 0;
     // optional per-kernel-class HIP-event timing (pds_ctx_set_timing / pds_ctx_get_timing)
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;
