@@ -33,6 +33,11 @@ template <int PP>
 struct RollDims {
     static constexpr int NG = PP * (PP + 1) / 2;
     static constexpr int NV = NG + PP + 1;  // Gram upper triangle, X'y, finite-row count
+    // The moments go through LDS in NSET passes of NH moments each (moment v = pass v / NH, lane v % NH): one wave's
+    // LDS stays under 20 KB, so 8 waves per CU fit (at p' = 8 all 45 moments at once were 23.4 KB -> 6 waves per CU,
+    // and the step is latency bound: measured 1.5x between 6 and 8 waves per CU).
+    static constexpr int NSET = (NV + 36) / 37;
+    static constexpr int NH = (NV + NSET - 1) / NSET;
 };
 
 struct RollArgs {
@@ -70,14 +75,14 @@ __device__ __forceinline__ bool finish_row(bool in, const double (&z)[PP], doubl
 }
 
 template <typename T, int PP>
-__global__ __launch_bounds__(kRollWaves * 64) void rolling_kernel(const T* const* __restrict__ cols, RollArgs ra,
-                                                                  double* __restrict__ tile_tot /*[tiles][NV]*/,
-                                                                  T* __restrict__ coeffs, T* __restrict__ pred,
-                                                                  uint8_t* __restrict__ valid) {
-    constexpr int NG = RollDims<PP>::NG, NV = RollDims<PP>::NV;
+__device__ __forceinline__ void rolling_body(const T* const* __restrict__ cols, const RollArgs& ra,
+                                             double* __restrict__ tile_tot /*[tiles][NV]*/, T* __restrict__ coeffs,
+                                             T* __restrict__ pred, uint8_t* __restrict__ valid) {
+    constexpr int NG = RollDims<PP>::NG, NV = RollDims<PP>::NV, NSET = RollDims<PP>::NSET, NH = RollDims<PP>::NH;
+    static_assert(NH <= 64, "one lane per moment of a pass");
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double* D = sm + (size_t)wave * NV * kLdsStride;
+    double* D = sm + (size_t)wave * NH * kLdsStride;
     const int64_t T_ = ra.tile_rows;
     const int64_t ntiles = (ra.n + T_ - 1) / T_;
     const int64_t wid = (int64_t)blockIdx.x * kRollWaves + wave, nw = (int64_t)gridDim.x * kRollWaves;
@@ -85,18 +90,17 @@ __global__ __launch_bounds__(kRollWaves * 64) void rolling_kernel(const T* const
 
     for (int64_t t = wid; t < ntiles; t += nw) {
         const int64_t t0 = t * T_, t1 = (t0 + T_ < ra.n) ? t0 + T_ : ra.n;
-        // running moments: lane owns moment v = lane (and v = lane + 64 when p' >= 10 makes NV exceed the wave)
-        constexpr int NSL = (NV + 63) / 64;
-        double W[NSL];
+        // running moments: lane l < NH owns moment k * NH + l of every pass k
+        double W[NSET];
 #pragma unroll
-        for (int k = 0; k < NSL; ++k) W[k] = 0.0;
+        for (int k = 0; k < NSET; ++k) W[k] = 0.0;
         int64_t r_begin = t0;
         if (ra.mode == 0) {
             r_begin = t0 - ((w + 63) / 64) * 64;  // warm-up steps rebuild the window in front of the tile
         } else if (ra.mode == 2) {
 #pragma unroll
-            for (int k = 0; k < NSL; ++k)
-                if (lane + 64 * k < NV) W[k] = tile_tot[t * NV + lane + 64 * k];  // exclusive prefix over the previous tiles
+            for (int k = 0; k < NSET; ++k)
+                if (lane < NH && k * NH + lane < NV) W[k] = tile_tot[t * NV + k * NH + lane];  // exclusive prefix over the previous tiles
         }
         // rows of the first step
         double nn[PP], no[PP], nyn, nyo = 0.0;
@@ -136,66 +140,75 @@ __global__ __launch_bounds__(kRollWaves * 64) void rolling_kernel(const T* const
                 for (int a = 0; a < PP; ++a) zo[a] = 0.0;
                 yo = 0.0;
             }
-            {
-                int v = 0;
+            double g[NG], c[PP], cnt = 0.0;
+            const bool want_c = !(warm || ra.mode == 1);
 #pragma unroll
-                for (int a = 0; a < PP; ++a)
-#pragma unroll
-                    for (int b = a; b < PP; ++b) {
-                        D[v * kLdsStride + lane] = fma(zn[a], zn[b], -(zo[a] * zo[b]));
-                        ++v;
-                    }
-#pragma unroll
-                for (int a = 0; a < PP; ++a) D[(NG + a) * kLdsStride + lane] = fma(zn[a], yn, -(zo[a] * yo));
-                D[(NG + PP) * kLdsStride + lane] = (okn ? 1.0 : 0.0) - (oko ? 1.0 : 0.0);
-            }
-            RSYNC();
-            // ---------------- phase B: lane v scans its moment over the 64 rows of this step
-#pragma unroll
-            for (int k = 0; k < NSL; ++k) {
-                if (lane + 64 * k >= NV) continue;
-                // 16 independent LDS reads, 16 dependent adds, 16 writes per batch (a read-add-write loop would put
-                // an LDS round trip into every one of the 64 links of the chain)
-                double* row = D + (lane + 64 * k) * kLdsStride;
-                double Wk = W[k];
-#pragma unroll
-                for (int i0 = 0; i0 < 64; i0 += 16) {
-                    double v[16];
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) v[i] = row[i0 + i];
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        Wk += v[i];
-                        v[i] = Wk;
-                    }
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) row[i0 + i] = v[i];
-                }
-                W[k] = Wk;
-            }
-            RSYNC();
-            if (warm || ra.mode == 1) continue;
-            // ---------------- phase C: lane = row, solve (G + lambda I) beta = c
-            if (r < t1) {
-                double g[NG], c[PP];
+            for (int ks = 0; ks < NSET; ++ks) {
+                // ---- A: the increments of this pass's moments, D[moment % NH][row]
                 {
                     int v = 0;
 #pragma unroll
                     for (int a = 0; a < PP; ++a)
 #pragma unroll
                         for (int b = a; b < PP; ++b) {
-                            double x = D[v * kLdsStride + lane];
-                            if (a == b) {
-                                if (a < ra.pp) x += ra.lambda;
-                                else x = 1.0;  // padding dimension: identity, beta_pad = 0
-                            }
-                            g[v] = x;
+                            if (v / NH == ks) D[(v % NH) * kLdsStride + lane] = fma(zn[a], zn[b], -(zo[a] * zo[b]));
                             ++v;
                         }
 #pragma unroll
-                    for (int a = 0; a < PP; ++a) c[a] = D[(NG + a) * kLdsStride + lane];
+                    for (int a = 0; a < PP; ++a)
+                        if ((NG + a) / NH == ks) D[((NG + a) % NH) * kLdsStride + lane] = fma(zn[a], yn, -(zo[a] * yo));
+                    if ((NG + PP) / NH == ks) D[((NG + PP) % NH) * kLdsStride + lane] = (okn ? 1.0 : 0.0) - (oko ? 1.0 : 0.0);
                 }
-                const double cnt = D[(NG + PP) * kLdsStride + lane];
+                RSYNC();
+                // ---- B: lane v scans its moment over the 64 rows of this step
+                if (lane < NH && ks * NH + lane < NV) {
+                    // 16 independent LDS reads, 16 dependent adds, 16 writes per batch (a read-add-write loop would put
+                    // an LDS round trip into every one of the 64 links of the chain)
+                    double* row = D + lane * kLdsStride;
+                    double Wk = W[ks];
+#pragma unroll
+                    for (int i0 = 0; i0 < 64; i0 += 16) {
+                        double v[16];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) v[i] = row[i0 + i];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            Wk += v[i];
+                            v[i] = Wk;
+                        }
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) row[i0 + i] = v[i];
+                    }
+                    W[ks] = Wk;
+                }
+                RSYNC();
+                // ---- C (first half): lane = row again takes its window sums of this pass into registers
+                if (want_c) {
+                    int v = 0;
+#pragma unroll
+                    for (int a = 0; a < PP; ++a)
+#pragma unroll
+                        for (int b = a; b < PP; ++b) {
+                            if (v / NH == ks) {
+                                double x = D[(v % NH) * kLdsStride + lane];
+                                if (a == b) {
+                                    if (a < ra.pp) x += ra.lambda;
+                                    else x = 1.0;  // padding dimension: identity, beta_pad = 0
+                                }
+                                g[v] = x;
+                            }
+                            ++v;
+                        }
+#pragma unroll
+                    for (int a = 0; a < PP; ++a)
+                        if ((NG + a) / NH == ks) c[a] = D[((NG + a) % NH) * kLdsStride + lane];
+                    if ((NG + PP) / NH == ks) cnt = D[((NG + PP) % NH) * kLdsStride + lane];
+                }
+                if (ks + 1 < NSET) RSYNC();  // the next pass overwrites D
+            }
+            if (!want_c) continue;
+            // ---------------- phase C: lane = row, solve (G + lambda I) beta = c
+            if (r < t1) {
                 // Cholesky G = L L' in place (packed upper storage read as lower by symmetry):
                 // idx(a,b), a <= b  ->  a*PP - a(a-1)/2 + (b-a)
                 bool okc = true;
@@ -252,10 +265,25 @@ __global__ __launch_bounds__(kRollWaves * 64) void rolling_kernel(const T* const
         }
         if (ra.mode == 1) {
 #pragma unroll
-            for (int k = 0; k < NSL; ++k)
-                if (lane + 64 * k < NV) tile_tot[t * NV + lane + 64 * k] = W[k];
+            for (int k = 0; k < NSET; ++k)
+                if (lane < NH && k * NH + lane < NV) tile_tot[t * NV + k * NH + lane] = W[k];
         }
     }
+}
+
+// p' <= 8 is compiled for two waves per SIMD (248 VGPRs, no spills): with the moments passing through LDS in halves
+// the CU then holds 8 waves.  p' >= 10 would spill at that budget (measured 2x slower) and keeps one wave per SIMD.
+template <typename T, int PP>
+__global__ __launch_bounds__(kRollWaves * 64) __attribute__((amdgpu_waves_per_eu(2))) void rolling_kernel(
+    const T* const* __restrict__ cols, RollArgs ra, double* __restrict__ tile_tot, T* __restrict__ coeffs, T* __restrict__ pred,
+    uint8_t* __restrict__ valid) {
+    rolling_body<T, PP>(cols, ra, tile_tot, coeffs, pred, valid);
+}
+template <typename T, int PP>
+__global__ __launch_bounds__(kRollWaves * 64) void rolling_kernel_1w(const T* const* __restrict__ cols, RollArgs ra,
+                                                                     double* __restrict__ tile_tot, T* __restrict__ coeffs,
+                                                                     T* __restrict__ pred, uint8_t* __restrict__ valid) {
+    rolling_body<T, PP>(cols, ra, tile_tot, coeffs, pred, valid);
 }
 
 // exclusive prefix over the per-tile totals (expanding window): one block of kPrefixWaves waves, lane = moment,
@@ -309,18 +337,18 @@ template <typename T, int PP>
 static int launch_pp(pds_ctx* ctx, const DeviceCols<T>& dc, RollArgs ra, bool expanding, const double* seed_moments,
                      T* d_coeffs, T* d_pred, uint8_t* d_valid) {
     constexpr int NV = RollDims<PP>::NV;
-    const size_t lds = (size_t)kRollWaves * NV * kLdsStride * sizeof(double);
+    const size_t lds = (size_t)kRollWaves * RollDims<PP>::NH * kLdsStride * sizeof(double);
     ra.tile_rows = kTileRows;
     const int64_t ntiles = (ra.n + ra.tile_rows - 1) / ra.tile_rows;
     int64_t nb = (ntiles + kRollWaves - 1) / kRollWaves;
     nb = std::min<int64_t>(std::max<int64_t>(nb, 1), (int64_t)ctx->num_cus * 4);
+    auto kern = PP >= 10 ? &rolling_kernel_1w<T, PP> : &rolling_kernel<T, PP>;
     if (lds > 64 * 1024)
-        PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rolling_kernel<T, PP>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     KernelTimer timer(ctx, kKindRolling);
     if (!expanding) {
         ra.mode = 0;
-        hipLaunchKernelGGL((rolling_kernel<T, PP>), dim3((unsigned)nb), dim3(kRollWaves * 64), lds, ctx->stream,
+        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(kRollWaves * 64), lds, ctx->stream,
                            dc.d_ptrs, ra, (double*)nullptr, d_coeffs, d_pred, d_valid);
     } else {
         double* tot = reinterpret_cast<double*>(ws_take(ctx, (size_t)ntiles * NV * sizeof(double)));
@@ -341,11 +369,11 @@ static int launch_pp(pds_ctx* ctx, const DeviceCols<T>& dc, RollArgs ra, bool ex
             PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // h is on this stack frame
         }
         ra.mode = 1;
-        hipLaunchKernelGGL((rolling_kernel<T, PP>), dim3((unsigned)nb), dim3(kRollWaves * 64), lds, ctx->stream,
+        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(kRollWaves * 64), lds, ctx->stream,
                            dc.d_ptrs, ra, tot, d_coeffs, d_pred, d_valid);
         hipLaunchKernelGGL(tile_prefix_kernel, dim3(1), dim3(kPrefixWaves * 64), 0, ctx->stream, tot, ntiles, NV, d_seed);
         ra.mode = 2;
-        hipLaunchKernelGGL((rolling_kernel<T, PP>), dim3((unsigned)nb), dim3(kRollWaves * 64), lds, ctx->stream,
+        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(kRollWaves * 64), lds, ctx->stream,
                            dc.d_ptrs, ra, tot, d_coeffs, d_pred, d_valid);
     }
     PDS_HIP_CHECK(hipGetLastError());
