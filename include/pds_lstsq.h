@@ -214,7 +214,9 @@ int pds_lin_reg_report_nullable_f32(pds_ctx* ctx, const float* const* cols, cons
  * pds_lr_grouped_*: the key-aware batched symbol of SURVEY.md 8(b) ("pl_lr_by"): what
  * `df.group_by(key).agg(pds.lin_reg(...))` makes Polars compute by calling `pl_lr` once per group
  * (tests/test_linear_exprs.py:918-953).  Rows of one group are contiguous; group g is rows
- * [group_offsets[g], group_offsets[g+1]).  OLS / ridge with the rank gate (the default path).
+ * [group_offsets[g], group_offsets[g+1]).  The dispatch on (l1_reg, l2_reg, positive) is pl_lr's (:447-497), per group:
+ * OLS / ridge with the rank gate (the default path; streaming Gram + solve in one kernel), lasso / elastic net /
+ * positive fits by coordinate descent on the group's Gram matrix (faer_coordinate_descent, faer_nn_lr).
  *   group_offsets  n_groups + 1 int64 values, `space`-resident.
  *   coeffs         out, n_groups x (n_feat + add_bias), row-major, `space`-resident.
  *   is_null        out, n_groups bytes, `space`-resident: 1 = gated or fewer rows than features

@@ -760,8 +760,7 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
     if (!ctx || !cols || !offsets || !prm || !coeffs) return fail(PDS_ERR_INVALID, "null argument");
     if (n_feat < 1) return fail(PDS_ERR_INVALID, "need at least one feature column");
     if (n_groups <= 0 || n_rows <= 0) return fail(PDS_ERR_EMPTY, "Empty data");
-    if (prm->l1_reg > 0.0 || prm->positive)
-        return fail(PDS_ERR_UNSUPPORTED, "grouped path implements OLS / ridge (the default pl_lr dispatch)");
+    const Method method = pick_method(prm);  // per group what pl_lr does per call: linear_regression.rs:447-497
     PDS_HIP_CHECK(hipSetDevice(ctx->device));
     const int bias = prm->add_bias ? 1 : 0, pp = n_feat + bias, q = n_feat + 2;
     // chunk the groups so one chunk's moment records (q*q values per group) stay inside the 256 MiB
@@ -842,7 +841,23 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
     const char* unfused_env = std::getenv("PDS_GROUPED_UNFUSED");
     const char* piv_env = std::getenv("PDS_GROUPED_PIVOTED");
     const bool want_piv = !(sp.gate_tol > 0.0) || (piv_env && piv_env[0] == '1');
-    if (pp <= 16 && !want_piv && !(unfused_env && unfused_env[0] == '1')) {
+    if (method.kind != Method::OLS) {
+        // lasso / elastic net / positive fits per group: grouped Gram build, then one wavefront per group runs the
+        // reference's coordinate descent (faer_coordinate_descent / faer_nn_lr) on that group's moment record
+        const bool f32 = sizeof(T) == 4;
+        for (int64_t g0 = 0; g0 < n_groups; g0 += chunk) {
+            const int64_t gc = std::min(chunk, n_groups - g0);
+            if (int rc = launch_grouped_moments<T>(ctx, dc, n_feat, d_off + g0, gc, d_mom)) return rc;
+            if (method.kind == Method::NNLS) {
+                if (int rc = launch_nnls<T>(ctx, d_mom, n_feat, bias, prm->tol, f32 ? 200 : prm->max_iter, d_coeffs + g0 * pp, gc,
+                                            d_null + g0, d_off + g0))
+                    return rc;
+            } else if (int rc = launch_cd<T>(ctx, d_mom, n_feat, bias, method.l1, method.l2, prm->tol,
+                                             f32 ? 2000 : prm->max_iter, method.positive, d_coeffs + g0 * pp, nullptr, gc,
+                                             d_null + g0, d_off + g0))
+                return rc;
+        }
+    } else if (pp <= 16 && !want_piv && !(unfused_env && unfused_env[0] == '1')) {
         if (int rc = launch_grouped_fused<T>(ctx, dc, n_feat, n_rows, d_off, n_groups, sp, d_coeffs, d_null)) return rc;
     } else {
         for (int64_t g0 = 0; g0 < n_groups; g0 += chunk) {

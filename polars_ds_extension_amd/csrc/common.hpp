@@ -179,9 +179,11 @@ int launch_solve_reg(pds_ctx* ctx, const T* d_moments, int64_t n_sys, const Solv
 
 template <typename T>
 int launch_cd(pds_ctx* ctx, const T* d_moments, int p, int add_bias, double l1, double l2, double tol,
-              int max_iter, int positive, T* d_coeffs, int* d_info /*[0]=sweeps,[1]=converged*/);
+              int max_iter, int positive, T* d_coeffs, int* d_info /*per system: [0]=sweeps,[1]=converged; nullable*/,
+              int64_t n_sys = 1, uint8_t* d_flags = nullptr, const int64_t* d_rows_per_sys = nullptr);
 template <typename T>
-int launch_nnls(pds_ctx* ctx, const T* d_moments, int p, int add_bias, double tol, int max_iter, T* d_coeffs);
+int launch_nnls(pds_ctx* ctx, const T* d_moments, int p, int add_bias, double tol, int max_iter, T* d_coeffs,
+                int64_t n_sys = 1, uint8_t* d_flags = nullptr, const int64_t* d_rows_per_sys = nullptr);
 
 // ---- pass2.hip ----
 // streaming residual pass: pred/resid (nullable outputs), sums: [0]=sum e^2, [1]=sum w e^2,

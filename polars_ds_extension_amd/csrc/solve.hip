@@ -339,6 +339,19 @@ int launch_solve(pds_ctx* ctx, const T* d_moments, int64_t n_sys, const SolvePar
 // coordinate descent / NNLS on the moment matrix: one wavefront, beta and the scalars in LDS,
 // Gram columns read from L2 (the matrix is tiny next to the 4 MiB L2: 1 MiB at p = 512 f32)
 // =============================================================================================
+// Batched CD / NNLS (one workgroup per group): a group with fewer rows than coefficients is what per-group `pl_lr`
+// rejects with "#Data < #features" (linear_regression.rs:169-173) -> null, like solve_kernel does for OLS.
+template <typename T>
+__device__ __forceinline__ bool batched_too_few_rows(const int64_t* __restrict__ rows_per_sys, int pp, T* coeffs,
+                                                     uint8_t* flags) {
+    bool small = false;
+    if (rows_per_sys) small = rows_per_sys[blockIdx.x + 1] - rows_per_sys[blockIdx.x] < pp;
+    if (small)
+        for (int i = threadIdx.x; i < pp; i += 64) coeffs[i] = (T)NAN;
+    if (flags && threadIdx.x == 0) flags[blockIdx.x] = small ? 1 : 0;
+    return small;
+}
+
 // The reference (lr_solvers.rs:486-530) recomputes dot_j = sum_{k != j} G[k,j] beta_k for every coordinate of every
 // sweep: p^2 work per sweep and a dependent L2 round trip per coordinate.  Here the same iteration is carried by the
 // gradient  r_j = (X'y)_j - sum_k G[k,j] beta_k  (all k), kept in LDS: the reference's
@@ -351,10 +364,15 @@ int launch_solve(pds_ctx* ctx, const T* d_moments, int64_t n_sys, const SolvePar
 template <typename T>
 __global__ __launch_bounds__(64) void cd_kernel(const T* __restrict__ M, int p, int bias, double l1_reg,
                                                 double l2_reg, double tol, int max_iter, int positive,
-                                                T* __restrict__ coeffs, int* __restrict__ info) {
+                                                T* __restrict__ coeffs, int* __restrict__ info,
+                                                uint8_t* __restrict__ flags, const int64_t* __restrict__ rows_per_sys) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int lane = threadIdx.x;
     const int pp = p + bias, q = p + 2;
+    // batched form (grouped regressions): workgroup b owns system b
+    M += (int64_t)blockIdx.x * q * q;
+    coeffs += (int64_t)blockIdx.x * pp;
+    if (batched_too_few_rows(rows_per_sys, pp, coeffs, flags)) return;
     double* beta = sm;           // pp
     double* r = sm + (p + 2);    // pp
     double* gd = r + (p + 2);    // p: G[j,j]
@@ -421,17 +439,21 @@ __global__ __launch_bounds__(64) void cd_kernel(const T* __restrict__ M, int p, 
     }
     for (int i = lane; i < pp; i += 64) coeffs[i] = (T)beta[i];
     if (lane == 0 && info) {
-        info[0] = it;
-        info[1] = conv;
+        info[2 * blockIdx.x] = it;
+        info[2 * blockIdx.x + 1] = conv;
     }
 }
 
 template <typename T>
 __global__ __launch_bounds__(64) void nnls_kernel(const T* __restrict__ M, int p, int bias, double tol,
-                                                  int max_iter, T* __restrict__ coeffs) {
+                                                  int max_iter, T* __restrict__ coeffs, uint8_t* __restrict__ flags,
+                                                  const int64_t* __restrict__ rows_per_sys) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int lane = threadIdx.x;
     const int pp = p + bias, q = p + 2;
+    M += (int64_t)blockIdx.x * q * q;
+    coeffs += (int64_t)blockIdx.x * pp;
+    if (batched_too_few_rows(rows_per_sys, pp, coeffs, flags)) return;
     double* beta = sm;
     double* mu = sm + pp;
     for (int i = lane; i < pp; i += 64) {
@@ -463,25 +485,28 @@ __global__ __launch_bounds__(64) void nnls_kernel(const T* __restrict__ M, int p
 
 template <typename T>
 int launch_cd(pds_ctx* ctx, const T* d_moments, int p, int add_bias, double l1, double l2, double tol, int max_iter,
-              int positive, T* d_coeffs, int* d_info) {
+              int positive, T* d_coeffs, int* d_info, int64_t n_sys, uint8_t* d_flags, const int64_t* d_rows_per_sys) {
+    if (n_sys <= 0) return PDS_OK;
     const size_t lds = (size_t)3 * (p + 2) * sizeof(double);
     if (lds > 160 * 1024) return fail(PDS_ERR_INVALID, "coordinate descent: more than 6800 features are not supported");
     if (lds > 48 * 1024)
         PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cd_kernel<T>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     KernelTimer timer(ctx, kKindIter);
-    hipLaunchKernelGGL((cd_kernel<T>), dim3(1), dim3(64), lds, ctx->stream, d_moments, p, add_bias ? 1 : 0, l1, l2,
-                       tol, max_iter, positive, d_coeffs, d_info);
+    hipLaunchKernelGGL((cd_kernel<T>), dim3((unsigned)n_sys), dim3(64), lds, ctx->stream, d_moments, p, add_bias ? 1 : 0,
+                       l1, l2, tol, max_iter, positive, d_coeffs, d_info, d_flags, d_rows_per_sys);
     PDS_HIP_CHECK(hipGetLastError());
     return PDS_OK;
 }
 
 template <typename T>
-int launch_nnls(pds_ctx* ctx, const T* d_moments, int p, int add_bias, double tol, int max_iter, T* d_coeffs) {
+int launch_nnls(pds_ctx* ctx, const T* d_moments, int p, int add_bias, double tol, int max_iter, T* d_coeffs,
+                int64_t n_sys, uint8_t* d_flags, const int64_t* d_rows_per_sys) {
+    if (n_sys <= 0) return PDS_OK;
     const size_t lds = (size_t)2 * (p + 2) * sizeof(double);
     KernelTimer timer(ctx, kKindIter);
-    hipLaunchKernelGGL((nnls_kernel<T>), dim3(1), dim3(64), lds, ctx->stream, d_moments, p, add_bias ? 1 : 0, tol,
-                       max_iter, d_coeffs);
+    hipLaunchKernelGGL((nnls_kernel<T>), dim3((unsigned)n_sys), dim3(64), lds, ctx->stream, d_moments, p,
+                       add_bias ? 1 : 0, tol, max_iter, d_coeffs, d_flags, d_rows_per_sys);
     PDS_HIP_CHECK(hipGetLastError());
     return PDS_OK;
 }
@@ -490,9 +515,11 @@ template int launch_solve<double>(pds_ctx*, const double*, int64_t, const SolveP
                                   const int64_t*);
 template int launch_solve<float>(pds_ctx*, const float*, int64_t, const SolveParams&, float*, uint8_t*, float*,
                                  const int64_t*);
-template int launch_cd<double>(pds_ctx*, const double*, int, int, double, double, double, int, int, double*, int*);
-template int launch_cd<float>(pds_ctx*, const float*, int, int, double, double, double, int, int, float*, int*);
-template int launch_nnls<double>(pds_ctx*, const double*, int, int, double, int, double*);
-template int launch_nnls<float>(pds_ctx*, const float*, int, int, double, int, float*);
+template int launch_cd<double>(pds_ctx*, const double*, int, int, double, double, double, int, int, double*, int*, int64_t,
+                               uint8_t*, const int64_t*);
+template int launch_cd<float>(pds_ctx*, const float*, int, int, double, double, double, int, int, float*, int*, int64_t,
+                              uint8_t*, const int64_t*);
+template int launch_nnls<double>(pds_ctx*, const double*, int, int, double, int, double*, int64_t, uint8_t*, const int64_t*);
+template int launch_nnls<float>(pds_ctx*, const float*, int, int, double, int, float*, int64_t, uint8_t*, const int64_t*);
 
 }  // namespace pds

@@ -420,15 +420,19 @@ def _report_dict(outs, rep, n_feat, add_bias, std_err, weighted, feature_names, 
     }
 
 
-def lin_reg_by(*x, target, group_offsets, add_bias: bool = False, l2_reg: float = 0.0, solver: str = "qr",
+def lin_reg_by(*x, target, group_offsets, add_bias: bool = False, l1_reg: float = 0.0, l2_reg: float = 0.0,
+               tol: float = 1e-5, solver: str = "qr", max_iter: int = 200, positive: bool = False,
                singular_x_tol: float | None = None, null_policy: str = "skip", ctx: Context | None = None):
     """
     The key-aware batched form of `df.group_by(key).agg(pds.lin_reg(...))` (SURVEY.md 8b "pl_lr_by").
     Rows of a group are contiguous; group g = rows [group_offsets[g], group_offsets[g+1]).
     Returns (coeffs [n_groups, p'], is_null [n_groups]) in the memory space of the inputs.
     pyarrow columns may carry nulls; `null_policy` then applies inside every group, as it does when Polars calls pl_lr
-    once per group.
+    once per group.  `l1_reg` / `l2_reg` / `positive` select the method per group exactly as `lin_reg` does
+    (lasso / elastic net / non-negative fits run the reference's coordinate descent on every group's Gram matrix).
     """
+    if max_iter <= 0:
+        raise ValueError("Input `max_iter` must be a positive.")  # expr_linear.py:231-232
     ctx = ctx or default_context()
     code, fill = parse_null_policy(null_policy)
     if any(_is_arrow(c) for c in (target, *x)):
@@ -439,7 +443,7 @@ def lin_reg_by(*x, target, group_offsets, add_bias: bool = False, l2_reg: float 
         if any(len(pt[0]) != n for pt in parts):
             raise ValueError("all columns must be 1-D and of equal length")
         nc = len(parts)
-        prm = _params(add_bias, 0.0, l2_reg, 1e-5, solver, False, 200, singular_x_tol)
+        prm = _params(add_bias, l1_reg, l2_reg, tol, solver, positive, max_iter, singular_x_tol)
         pp = nc - 1 + int(bool(add_bias))
         off = np.ascontiguousarray(np.asarray(group_offsets), dtype=np.int64)
         ng = int(off.shape[0]) - 1
@@ -455,7 +459,7 @@ def lin_reg_by(*x, target, group_offsets, add_bias: bool = False, l2_reg: float 
         return coeffs, nulls
     cols = _Cols(target, x)
     _follow(ctx, cols)
-    prm = _params(add_bias, 0.0, l2_reg, 1e-5, solver, False, 200, singular_x_tol)
+    prm = _params(add_bias, l1_reg, l2_reg, tol, solver, positive, max_iter, singular_x_tol)
     pp = cols.n_feat + int(bool(add_bias))
     if cols.space == _lib.PDS_DEVICE:
         import torch

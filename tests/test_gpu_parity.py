@@ -281,6 +281,39 @@ def test_grouped_ridge_host_space(pds, orc):
     assert np.max(np.linalg.norm(co - co_o, axis=1) / np.linalg.norm(co_o, axis=1)) < F64_TOL
 
 
+@pytest.mark.parametrize("p,bias", [(3, True), (8, False), (16, True), (24, False)])
+@pytest.mark.parametrize("kw", [dict(l1_reg=0.02), dict(l1_reg=0.01, l2_reg=0.05), dict(positive=True),
+                                dict(l2_reg=0.2, positive=True), dict(l1_reg=0.01, positive=True)])
+def test_grouped_lasso_elastic_net_nnls(pds, orc, kw, p, bias):
+    """group_by(key).agg(pds.lin_reg(l1_reg=..., positive=...)): per group the dispatch of pl_lr (:447-497)."""
+    rng = np.random.default_rng(300 + p)
+    G = 300
+    sizes = rng.integers(p + 10, 200, size=G)
+    sizes[::41] = rng.integers(0, p + 1, size=len(sizes[::41]))  # empty / too-small groups -> null
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    N = int(off[-1])
+    X = rng.normal(size=(N, p))
+    y = np.empty(N)
+    for g in range(G):
+        s = slice(off[g], off[g + 1])
+        y[s] = X[s] @ rng.normal(size=p) + 0.1 * rng.normal(size=sizes[g]) + (0.7 if bias else 0.0)
+    co, nu = pds.lin_reg_by(*cols_of(X), target=dev(y), group_offsets=off, add_bias=bias, tol=1e-11, max_iter=5000, **kw)
+    co, nu = co.cpu().numpy(), nu.cpu().numpy().astype(bool)
+    pp = p + bias
+    assert np.array_equal(nu, sizes < pp)
+    assert np.isnan(co[nu]).all()
+    worst = 0.0
+    for g in np.flatnonzero(~nu):
+        s = slice(off[g], off[g + 1])
+        bo = orc.pl_lr(X[s], y[s], add_bias=bias, tol=1e-11, max_iter=5000, **kw)
+        worst = max(worst, float(np.linalg.norm(co[g] - bo) / max(np.linalg.norm(bo), 1e-300)))
+    assert worst < 1e-8  # both sides iterate to |delta| < 1e-11; the fixed points agree to the conditioning of the group
+    # host-space call (numpy in, numpy out) takes the same route
+    co_h, nu_h = pds.lin_reg_by(*[np.ascontiguousarray(X[:, j]) for j in range(p)], target=y, group_offsets=off, add_bias=bias,
+                                tol=1e-11, max_iter=5000, **kw)
+    assert np.array_equal(nu_h.astype(bool), nu) and np.array_equal(co_h[~nu], co[~nu])
+
+
 # ------------------------------------------------------------------------------------------ rolling / recursive
 def test_rolling_golden_notebook(pds, golden):
     for part in ("rolling_w5_head", "rolling_w5_tail"):
