@@ -253,6 +253,8 @@ int pds_lr_grouped_nullable_f32(pds_ctx* ctx, const float* const* cols, const ui
  *           `space`-resident; rows [0, n-1) are unspecified and marked invalid.
  *   pred    out, n_rows, `space`-resident.
  *   valid   out, n_rows bytes (1 = row has a result), `space`-resident.
+ * Up to 64 coefficients (n_feat + add_bias): <= 12 in the one-kernel lane-per-row form, 13 .. 64 through per-row moment
+ * records and the batched solver.
  * min_size > 0 selects the skipping variant (faer_rolling_skipping_lr :218-301): rows holding a
  * non-finite value are left out of the window and a window with fewer than min_size rows is invalid.
  */

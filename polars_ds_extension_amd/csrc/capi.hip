@@ -897,6 +897,7 @@ static int rolling_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
     PDS_HIP_CHECK(hipSetDevice(ctx->device));
     size_t need = 131072 + ((size_t)(n_rows / 4096) + 2) * 96 * sizeof(double);  // + per-tile totals (expanding)
     if (space == PDS_HOST) need += (size_t)n_rows * ((pp + 1) * sizeof(T) + 1) + 4096;
+    if (pp > 12) need += rolling_wide_workspace(n_feat, n_rows, sizeof(T));
     if (int rc = ws_reserve(ctx, need)) return rc;
     DeviceCols<T> dc;
     if (int rc = make_device_cols<T>(ctx, cols, (const T*)nullptr, n_feat, n_rows, space, dc)) return rc;

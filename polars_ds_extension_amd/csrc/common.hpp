@@ -219,6 +219,13 @@ int launch_rolling(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_
                    int64_t window, int64_t min_size, double lambda, bool expanding, const double* seed_moments,
                    T* d_coeffs, T* d_pred, uint8_t* d_valid);
 
+// rolling_wide.hip: 13 .. 64 coefficients (per-row moment records + launch_solve); workspace comes out of ctx->ws
+template <typename T>
+int launch_rolling_wide(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, int add_bias, int64_t window,
+                        int64_t min_size, double lambda, bool expanding, const double* seed_moments, T* d_coeffs, T* d_pred,
+                        uint8_t* d_valid);
+size_t rolling_wide_workspace(int n_feat, int64_t n_rows, size_t elem);
+
 // ---- stats.cpp ----
 double student_t_sf(double x, double df, bool* err);
 double student_t_ppf(double q, double df);

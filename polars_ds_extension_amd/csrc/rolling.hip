@@ -401,7 +401,9 @@ int launch_rolling(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_
     if (pp <= 8) return launch_pp<T, 8>(ctx, dc, ra, expanding, seed_moments, d_coeffs, d_pred, d_valid);
     if (pp <= 10) return launch_pp<T, 10>(ctx, dc, ra, expanding, seed_moments, d_coeffs, d_pred, d_valid);
     if (pp <= 12) return launch_pp<T, 12>(ctx, dc, ra, expanding, seed_moments, d_coeffs, d_pred, d_valid);
-    return fail(PDS_ERR_UNSUPPORTED, "rolling / recursive: at most 12 coefficients (features + bias) in this build");
+    // 13 .. 64 coefficients: per-row moment records + the batched solver (rolling_wide.hip)
+    return launch_rolling_wide<T>(ctx, dc, n_feat, n_rows, add_bias, window, min_size, lambda, expanding, seed_moments, d_coeffs,
+                                  d_pred, d_valid);
 }
 
 template int launch_rolling<double>(pds_ctx*, const DeviceCols<double>&, int, int64_t, int, int64_t, int64_t, double,

@@ -457,6 +457,57 @@ def test_rolling_recursive_many_coefficients(pds, orc, p, bias):
     assert np.max(err) < 1e-9
 
 
+@pytest.mark.parametrize("p,bias,w", [(13, False, 64), (15, True, 100), (16, True, 257), (20, True, 300), (33, False, 128),
+                                      (63, True, 200), (64, False, 500)])
+def test_rolling_recursive_13_to_64_coefficients(pds, orc, p, bias, w):
+    """p' > 12: per-row moment records + the batched pivoted QR (rolling_wide.hip); crosses segment (256 rows) borders."""
+    rng = np.random.default_rng(140 + p)
+    n, n0 = 2500, 2 * p + 30
+    X = rng.random((n, p))
+    y = X @ rng.normal(size=p) + 0.3 + 0.05 * rng.normal(size=n)
+    Xb = np.c_[X, np.ones(n)] if bias else X
+    for lam in (0.0, 0.05):
+        co, pr, va = pds.rolling_lin_reg(*cols_of(X), target=dev(y), window_size=w, add_bias=bias, l2_reg=lam)
+        co, va = co.cpu().numpy(), va.cpu().numpy().astype(bool)
+        assert va[w - 1 :].all() and not va[: w - 1].any() and np.isnan(co[: w - 1]).all()
+        for i in list(range(w - 1, n, 97)) + [n - 1]:  # direct window fits (lambda on every diagonal, SURVEY A.8)
+            Z, t = Xb[i - w + 1 : i + 1], y[i - w + 1 : i + 1]
+            direct = np.linalg.solve(Z.T @ Z + lam * np.eye(Z.shape[1]), Z.T @ t)
+            assert nrel(co[i], direct) < 1e-8
+            assert abs(float(pr[i]) - Xb[i] @ direct) < 1e-8
+    ref = orc.rolling_lr(Xb, y, w)  # the reference's Woodbury chain
+    co, _, _ = pds.rolling_lin_reg(*cols_of(X), target=dev(y), window_size=w, add_bias=bias)
+    assert np.max(np.linalg.norm(co.cpu().numpy()[w - 1 :] - ref, axis=1) / np.linalg.norm(ref, axis=1)) < 1e-7
+    co2, pr2, va2 = pds.recursive_lin_reg(*cols_of(X), target=dev(y), start_with=n0, add_bias=bias)
+    co2, va2 = co2.cpu().numpy(), va2.cpu().numpy().astype(bool)
+    assert va2[n0 - 1 :].all() and not va2[: n0 - 1].any()
+    for i in (n0 + 50, 255, 256, 257, 1000, n - 1):
+        direct = np.linalg.lstsq(Xb[: i + 1], y[: i + 1], rcond=None)[0]
+        assert nrel(co2[i], direct) < 1e-8
+    # seeded continuation (row-sharded expanding fit): second half seeded with the first half's moments
+    h = 1111
+    M = pds.gram_moments(*cols_of(X[:h]), target=dev(y[:h]))
+    co3, _, va3 = pds.recursive_lin_reg(*cols_of(X[h:]), target=dev(y[h:]), start_with=n0, add_bias=bias, seed_moments=M)
+    assert va3.cpu().numpy().all()
+    assert np.max(np.linalg.norm(co3.cpu().numpy() - co2[h:], axis=1) / np.linalg.norm(co2[h:], axis=1)) < 1e-9
+    # skipping variant: non-finite rows are left out, min_valid_rows on the finite-row count
+    Xn = X.copy()
+    bad = rng.choice(n, size=60, replace=False)
+    Xn[bad, 1] = np.nan
+    m = w - 3
+    co4, _, va4 = pds.rolling_lin_reg(*cols_of(Xn), target=dev(y), window_size=w, add_bias=bias, skip_non_finite=True,
+                                      min_valid_rows=m)
+    co4, va4 = co4.cpu().numpy(), va4.cpu().numpy().astype(bool)
+    fin = np.isfinite(Xn).all(axis=1)
+    cnt = np.convolve(fin.astype(int), np.ones(w, dtype=int))[w - 1 : n]
+    assert np.array_equal(va4[w - 1 :], cnt >= m) and not va4[: w - 1].any()
+    for i in np.flatnonzero(va4)[::211]:
+        rows = np.arange(i - w + 1, i + 1)[fin[i - w + 1 : i + 1]]
+        direct = np.linalg.lstsq(Xb[rows], y[rows], rcond=None)[0]
+        if fin[i]:
+            assert nrel(co4[i], direct) < 1e-8
+
+
 def test_rolling_skip_non_finite(pds, orc):
     rng = np.random.default_rng(9)
     n = 3000
