@@ -215,6 +215,30 @@ __global__ __launch_bounds__(kP2Threads) void pass2_wide_kernel(const T* const* 
     }
 }
 
+// p > 16, HC2 / HC3: the leverages h_i = z_i' (X'X)^-1 z_i (z = [x, (1)]; linear_regression.rs:893-909 takes them from
+// the diagonal of X (X'X)^-1 X') scale the squared residuals the wide pass left in s: s_i /= (1 - h_i) or (1 - h_i)^2.
+// lane = row; the p' x p' inverse is read with wave-uniform indices (scalar cache), the row's values p' times from
+// L1 / L2 -- O(p'^2) per row, a coverage path (HC0 / HC1 never come here).
+template <typename T>
+__global__ __launch_bounds__(kP2Threads) void leverage_scale_wide_kernel(const T* const* __restrict__ cols, int p, int bias,
+                                                                         int64_t n, const T* __restrict__ inv, int hc,
+                                                                         T* __restrict__ s_rows) {
+    const int pp = p + bias;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+        double h = 0.0;
+        for (int a = 0; a < pp; ++a) {
+            double t = bias ? (double)inv[a + (size_t)p * pp] : 0.0;
+            const T* ia = inv + (size_t)a * pp;  // row a = column a (symmetric)
+            for (int b = 0; b < p; ++b) t = fma((double)ia[b], (double)as_global(cols[b])[r], t);
+            const double za = a < p ? (double)as_global(cols[a])[r] : 1.0;
+            h = fma(za, t, h);
+        }
+        const double om = 1.0 - h;
+        const double sc = (hc == 2) ? 1.0 / om : 1.0 / (om * om);
+        s_rows[r] = (T)((double)s_rows[r] * sc);
+    }
+}
+
 template <typename T, bool W>
 static void launch_p2(int hc, dim3 g, hipStream_t st, const T* const* cols, int p, int bias, int64_t n, const T* beta,
                       const T* inv, T* pred, T* resid, T* s, double* partials) {
@@ -234,8 +258,7 @@ int launch_pass2(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_ro
                  double* d_s_rows) {
     if (n_feat < 1) return fail(PDS_ERR_INVALID, "need at least one feature column");
     if (n_feat > kMaxFeatSmall) {
-        // HC2 / HC3 need the leverages x_i' (X'X)^-1 x_i: O(p'^2) per row, not built for the wide path
-        if (hc_mode >= 2) return fail(PDS_ERR_UNSUPPORTED, "HC2 / HC3 standard errors with more than 16 features are not built yet");
+        if (hc_mode >= 2 && !d_inv) return fail(PDS_ERR_INVALID, "HC2 / HC3 need the inverse of X'X");
         const int nb = (int)std::min<int64_t>(std::max<int64_t>((n_rows + kP2Threads - 1) / kP2Threads, 1), (int64_t)ctx->num_cus * 8);
         T* s_rows = hc_mode ? reinterpret_cast<T*>(d_s_rows) : nullptr;
         KernelTimer timer(ctx, kKindPass2);
@@ -246,6 +269,9 @@ int launch_pass2(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_ro
             hipLaunchKernelGGL((pass2_wide_kernel<T, false>), dim3(nb), dim3(kP2Threads), 0, ctx->stream, dc.d_ptrs, n_feat,
                                add_bias ? 1 : 0, n_rows, d_beta, d_pred, d_resid, s_rows, ctx->partials);
         hipLaunchKernelGGL(pass2_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->partials, nb, d_sums);
+        if (hc_mode >= 2)
+            hipLaunchKernelGGL((leverage_scale_wide_kernel<T>), dim3(nb), dim3(kP2Threads), 0, ctx->stream, dc.d_ptrs, n_feat,
+                               add_bias ? 1 : 0, n_rows, d_inv, hc_mode, s_rows);
         PDS_HIP_CHECK(hipGetLastError());
         return PDS_OK;
     }

@@ -902,12 +902,11 @@ def test_wide_weighted_and_hc(pds, orc, p, bias):
     r = pds.lin_reg_report(*cols_of(X), target=dev(y), add_bias=bias, weights=dev(w))
     ro = orc.wls_report(Xb, y, w)
     assert nrel(r["beta"], ro["beta"]) < F64_TOL and frel(r["std_err"], ro["std_err"], 1e-12) < 1e-9
-    for se in ("hc0", "hc1"):
+    for se in ("hc0", "hc1", "hc2", "hc3"):  # hc2 / hc3: per-row leverages x_i' (X'X)^-1 x_i on the device
         r = pds.lin_reg_report(*cols_of(X), target=dev(y), add_bias=bias, std_err=se)
         ro = orc.lin_reg_report(Xb, y, std_err=se)
         assert nrel(r["beta"], ro["beta"]) < F64_TOL and frel(r[f"{se}_se"], ro["std_err"], 1e-12) < 1e-9
-    with pytest.raises(Exception):
-        pds.lin_reg_report(*cols_of(X), target=dev(y), add_bias=bias, std_err="hc3")
+        assert frel(r["t"], ro["t"], 1e-6) < 1e-8 and frel(r["p>|t|"], ro["p"], 1e-12) < 1e-6
 
 
 def test_wide_pred_and_report(pds, orc):
