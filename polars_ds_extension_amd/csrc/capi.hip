@@ -750,6 +750,72 @@ static int report_impl(pds_ctx* ctx, const T* const* cols, const T* weights, int
 // ---------------------------------------------------------------------------------------------
 // grouped
 // ---------------------------------------------------------------------------------------------
+// Groups with more than 64 features (coverage path): every group's Gram matrix comes from the tiled matrix-core SYRK of the
+// single-regression path (moments_wide.hip) on that group's row range, the records of a chunk of groups are then solved
+// together (solve_big.hip: Cholesky on an L2-resident workspace, one workgroup per system; CD / NNLS: one wavefront each).
+__global__ void mark_small_groups_kernel(const int64_t* __restrict__ off, int64_t n_groups, int pp, uint8_t* __restrict__ flags) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n_groups && off[g + 1] - off[g] < pp) flags[g] = 1;
+}
+template <typename T>
+__global__ void nan_flagged_kernel(const uint8_t* __restrict__ flags, int64_t n_groups, int pp, T* __restrict__ coeffs) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_groups * pp && flags[i / pp]) coeffs[i] = (T)__builtin_nan("");
+}
+
+template <typename T>
+static int grouped_big(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, const int64_t* d_off, int64_t n_groups, int64_t chunk,
+                       const Method& method, const pds_lr_params* prm, const SolveParams& sp, T* d_mom, T* d_coeffs,
+                       uint8_t* d_null) {
+    const int bias = prm->add_bias ? 1 : 0, pp = n_feat + bias, q = n_feat + 2, nc = n_feat + 1;
+    std::vector<int64_t> off((size_t)n_groups + 1);
+    PDS_HIP_CHECK(hipMemcpyAsync(off.data(), d_off, off.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    // one pointer table per group: the column bases moved to the group's first row
+    std::vector<const T*> tables((size_t)n_groups * nc);
+    for (int64_t g = 0; g < n_groups; ++g)
+        for (int c = 0; c < nc; ++c) tables[(size_t)g * nc + c] = dc.h_ptrs[c] + off[g];
+    const T** d_tables = reinterpret_cast<const T**>(ws_take(ctx, tables.size() * sizeof(T*)));
+    PDS_HIP_CHECK(hipMemcpyAsync(d_tables, tables.data(), tables.size() * sizeof(T*), hipMemcpyHostToDevice, ctx->stream));
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const bool f32 = sizeof(T) == 4;
+    for (int64_t g0 = 0; g0 < n_groups; g0 += chunk) {
+        const int64_t gc = std::min(chunk, n_groups - g0);
+        for (int64_t g = g0; g < g0 + gc; ++g) {
+            T* rec = d_mom + (size_t)(g - g0) * q * q;
+            const int64_t ng = off[g + 1] - off[g];
+            if (ng <= 0) {
+                PDS_HIP_CHECK(hipMemsetAsync(rec, 0, sizeof(T) * (size_t)q * q, ctx->stream));
+                continue;
+            }
+            DeviceCols<T> dg;
+            dg.nc = nc;
+            dg.d_ptrs = d_tables + (size_t)g * nc;
+            dg.h_ptrs.assign(tables.begin() + (size_t)g * nc, tables.begin() + (size_t)(g + 1) * nc);
+            const size_t mark = ctx->ws_used;  // the SYRK partials are call-local: stream order makes the reuse safe
+            const int rc = launch_moments_wide<T>(ctx, dg, n_feat, ng, false, rec);
+            ctx->ws_used = mark;
+            if (rc) return rc;
+        }
+        T* co = d_coeffs + g0 * pp;
+        uint8_t* fl = d_null + g0;
+        if (method.kind == Method::OLS) {
+            if (int rc = launch_solve<T>(ctx, d_mom, gc, sp, co, fl, nullptr, nullptr)) return rc;
+            // per-group pl_lr rejects "#Data < #features": null
+            hipLaunchKernelGGL(mark_small_groups_kernel, dim3((unsigned)((gc + 255) / 256)), dim3(256), 0, ctx->stream, d_off + g0, gc,
+                               pp, fl);
+            hipLaunchKernelGGL((nan_flagged_kernel<T>), dim3((unsigned)((gc * pp + 255) / 256)), dim3(256), 0, ctx->stream, fl, gc, pp,
+                               co);
+            PDS_HIP_CHECK(hipGetLastError());
+        } else if (method.kind == Method::NNLS) {
+            if (int rc = launch_nnls<T>(ctx, d_mom, n_feat, bias, prm->tol, f32 ? 200 : prm->max_iter, co, gc, fl, d_off + g0)) return rc;
+        } else if (int rc = launch_cd<T>(ctx, d_mom, n_feat, bias, method.l1, method.l2, prm->tol, f32 ? 2000 : prm->max_iter,
+                                         method.positive, co, nullptr, gc, fl, d_off + g0))
+            return rc;
+    }
+    return PDS_OK;
+}
+
 template <typename T>
 static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t n_rows, const int64_t* offsets,
                         int64_t n_groups, pds_space space, const pds_lr_params* prm, T* coeffs, uint8_t* is_null,
@@ -765,9 +831,11 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
     const int bias = prm->add_bias ? 1 : 0, pp = n_feat + bias, q = n_feat + 2;
     // chunk the groups so one chunk's moment records (q*q values per group) stay inside the 256 MiB
     // Infinity Cache between the Gram kernel that writes them and the solve kernel that reads them
-    int64_t chunk = std::max<int64_t>(4096, (int64_t)(128ll << 20) / (int64_t)(sizeof(T) * q * q));
+    const bool big = n_feat > kMaxFeatWide;  // > 64 features: one tiled-SYRK Gram build per group + solve_big
+    int64_t chunk = std::max<int64_t>(big ? 64 : 4096, (int64_t)(128ll << 20) / (int64_t)(sizeof(T) * q * q));
     chunk = std::min(chunk, n_groups);
     size_t need = 131072 + sizeof(T) * (size_t)chunk * q * q;
+    if (big) need += (size_t)n_groups * (n_feat + 1) * sizeof(T*) + moments_wide_workspace(ctx->num_cus, n_feat, n_rows) + 8192;
     if (space == PDS_HOST) need += (size_t)(n_groups + 1) * 8 + (size_t)n_groups * (pp * sizeof(T) + 1) + 4096;
     if (nullable) {
         if (policy < PDS_NULL_RAISE || policy > PDS_NULL_IGNORE) return fail(PDS_ERR_INVALID, "Invalid NullPolicy.");
@@ -841,7 +909,9 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
     const char* unfused_env = std::getenv("PDS_GROUPED_UNFUSED");
     const char* piv_env = std::getenv("PDS_GROUPED_PIVOTED");
     const bool want_piv = !(sp.gate_tol > 0.0) || (piv_env && piv_env[0] == '1');
-    if (method.kind != Method::OLS) {
+    if (big) {
+        if (int rc = grouped_big<T>(ctx, dc, n_feat, d_off, n_groups, chunk, method, prm, sp, d_mom, d_coeffs, d_null)) return rc;
+    } else if (method.kind != Method::OLS) {
         // lasso / elastic net / positive fits per group: grouped Gram build, then one wavefront per group runs the
         // reference's coordinate descent (faer_coordinate_descent / faer_nn_lr) on that group's moment record
         const bool f32 = sizeof(T) == 4;

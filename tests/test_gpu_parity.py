@@ -314,6 +314,28 @@ def test_grouped_lasso_elastic_net_nnls(pds, orc, kw, p, bias):
     assert np.array_equal(nu_h.astype(bool), nu) and np.array_equal(co_h[~nu], co[~nu])
 
 
+@pytest.mark.parametrize("p,bias", [(65, False), (70, True), (130, True)])
+def test_grouped_more_than_64_features(pds, orc, p, bias):
+    """> 64 features per group: tiled matrix-core Gram build per group + the big-system solver (coverage path)."""
+    rng = np.random.default_rng(500 + p)
+    pp = p + bias
+    sizes = np.array([3 * pp, pp + 40, 0, pp - 1, 2 * pp + 17, 5, 4 * pp, pp + 200])
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    N = int(off[-1])
+    X = rng.normal(size=(N, p))
+    y = X @ rng.normal(size=p) + (0.7 if bias else 0.0) + 0.1 * rng.normal(size=N)
+    for kw in (dict(), dict(l2_reg=0.3), dict(l1_reg=0.01, tol=1e-11, max_iter=5000)):
+        co, nu = pds.lin_reg_by(*cols_of(X), target=dev(y), group_offsets=off, add_bias=bias, **kw)
+        co, nu = co.cpu().numpy(), nu.cpu().numpy().astype(bool)
+        assert np.isnan(co[nu]).all() and nu[sizes < pp].all() and not nu[sizes >= 3 * pp].any()
+        for g in np.flatnonzero(sizes >= pp):
+            sl = slice(off[g], off[g + 1])
+            bo = orc.pl_lr(X[sl], y[sl], add_bias=bias, **kw)  # None: the rank gate fired (barely more rows than features)
+            assert (bo is None) == bool(nu[g])
+            if bo is not None:
+                assert nrel(co[g], bo) < 1e-8
+
+
 # ------------------------------------------------------------------------------------------ rolling / recursive
 def test_rolling_golden_notebook(pds, golden):
     for part in ("rolling_w5_head", "rolling_w5_tail"):
