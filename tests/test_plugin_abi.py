@@ -185,6 +185,35 @@ def test_pl_rolling_and_recursive_struct(so, orc, golden):
 
 
 @pytest.mark.gpu
+def test_pl_recursive_lr_null_policies(so, orc):
+    # pl_recursive_lr :1131-1181: skip / fill drop rows, the expanding fit runs on the rest and is spread back
+    rng = np.random.default_rng(11)
+    n, n0 = 2000, 6
+    X = rng.random((n, 2))
+    y = X @ [1.0, -1.0] + 0.3 + 0.01 * rng.random(n)
+    mx = rng.random(n) < 0.08
+    my = rng.random(n) < 0.03
+    mx[:3] = True  # nulls inside the first start_with rows push the first result back
+    ins = [("y", pa.array(y, mask=my)), ("x1", pa.array(X[:, 0], mask=mx)), ("x2", pa.array(X[:, 1]))]
+    for policy, keep, Xf in (("skip", ~(mx | my), X), ("0.5", ~my, np.c_[np.where(mx, 0.5, X[:, 0]), X[:, 1]])):
+        _, out = ph.call_plugin(so, "pl_recursive_lr", ins, {"null_policy": policy, "n": n0, "bias": True, "lambda": 0.0, "min_size": 0})
+        res = out.to_pylist()
+        idx = np.flatnonzero(keep)
+        ref = orc.recursive_lr(np.c_[Xf[idx], np.ones(len(idx))], y[idx], n0)  # row j of ref: fit on the first n0 + j kept rows
+        first = idx[n0 - 1]
+        for i in range(n):
+            if (not keep[i]) or i < first:
+                assert res[i] == {"coeffs": None, "pred": None}
+        for j in (0, 1, 50, len(idx) - n0):
+            i = idx[n0 - 1 + j]
+            tol = 1e-6 if j > 10 else 1e-3  # the earliest fits are nearly singular
+            np.testing.assert_allclose(res[i]["coeffs"], ref[j], rtol=tol, atol=tol)
+            np.testing.assert_allclose(res[i]["pred"], np.r_[Xf[i], 1.0] @ np.array(res[i]["coeffs"]), rtol=1e-10, atol=1e-12)
+    with pytest.raises(ph.PluginFailure, match="Nulls found in data"):
+        ph.call_plugin(so, "pl_recursive_lr", ins, {"null_policy": "raise", "n": n0, "bias": True, "lambda": 0.0, "min_size": 0})
+
+
+@pytest.mark.gpu
 def test_pl_lr_by_matches_per_group_calls(so, orc):
     # tests/test_linear_exprs.py:918-953: the batched path == one pl_lr call per group
     rng = np.random.default_rng(0)
