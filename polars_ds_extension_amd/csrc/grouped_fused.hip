@@ -21,6 +21,16 @@
 
 namespace pds {
 
+// -DPDS_PROFILE_PHASES: per-phase shader-clock sums of every wave (development; tools/phase_profile.py reads them)
+#ifdef PDS_PROFILE_PHASES
+__device__ unsigned long long g_phase_cycles[8];
+#define PDS_T0() const unsigned long long _t0 = __builtin_amdgcn_s_memtime()
+#define PDS_T1(k) prof[k] += __builtin_amdgcn_s_memtime() - _t0
+#else
+#define PDS_T0() do {} while (0)
+#define PDS_T1(k) do {} while (0)
+#endif
+
 constexpr int kFQ = 18;                  // LDS scratch moment matrix: indices 0..15 features, 16 bias, 17 y
 constexpr int kFM = kFQ * kFQ;           // doubles
 constexpr int kFTile = 17 * kColStride;  // 16 feature slots + y
@@ -108,6 +118,8 @@ __device__ __forceinline__ void consume_range(const char* wl, int lane, int rel0
         step_v(x2, y2);
         step_v(x3, y3);
     }
+    // (fetching the next iteration's operands ahead of these matrix instructions was measured slower: the rotation
+    //  costs sixteen register moves per iteration and the waits did not move)
     for (; s < sfull; ++s) step_v(xcol[4 * s], ycol[4 * s]);
     // tail: a last step that ends inside a 4-row group (and was not already the head step)
     if ((rel1 & 3) && sfull >= s0 && sfull < s1) step(sfull, true, 0, rel1 & 3);
@@ -235,6 +247,10 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
         for (int e = 0; e < RPL; ++e) z[e] = T(0);
         for (int c = p; c < 16; ++c) *reinterpret_cast<typename Tile<T>::vec*>(wl + c * kColStride + lane * 16) = z;
     }
+#ifdef PDS_PROFILE_PHASES
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
     // pending systems (one per sub-group), held in registers in solver layout
     double a_p[NA];
     double b_p[CHOL ? 1 : LPS];
@@ -254,6 +270,7 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
         bool is_null = null_p;
         double zj = 0.0;
         int pj = j;
+        PDS_T0();
         if constexpr (CHOL) {
             chol_core<LPS>(a_p, dj_p, j, sp, is_null, zj);
         } else {
@@ -261,6 +278,7 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
         }
         if (live && colv) coeffs[sys * (int64_t)pp + pj] = is_null ? (T)__builtin_nan("") : (T)zj;
         if (live && j == 0 && flags) flags[sys] = is_null ? 1 : 0;
+        PDS_T1(3);
         gbase += npend;
         npend = 0;
     };
@@ -278,6 +296,7 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
 
     auto flush_group = [&]() __attribute__((always_inline)) {
         // ---- normal equations of group g -> LDS scratch (full symmetric square, bias at 16, y at 17)
+        PDS_T0();
         const int64_t ng = ge - gs;
         {
             const int jj = lane & 15;
@@ -358,6 +377,7 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
         PDS_WAVE_LDS_SYNC();
         zero_acc(acc);
         ++npend;
+        PDS_T1(2);
         if (npend == SPW) solve_pending();
     };
 
@@ -381,12 +401,26 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
     // (A flat state machine with flush / solve instantiated once each was tried: 4.7k instead of 10.9k static
     //  instructions but 255 live VGPRs and 8 % slower than this nested form at 219.)
     if (t_first <= t_last) load_tile(t_first);
-    for (int64_t t = t_first; t <= t_last; ++t) {
-        store_tile_lds<T, false>(wl, p, lane, regs);
-        if (t + 1 <= t_last) load_tile(t + 1);
+    // One flush site: a group is flushed as soon as its last row has been consumed (the loop condition also holds while
+    // the current group is complete), so groups that end exactly at rhi and trailing empty groups are handled by the last
+    // pass; a wave whose groups are all empty makes one pass without a tile.  (Two inlined copies of flush + solve were
+    // 5 KB of code for nothing.)
+    for (int64_t t = t_first;; ++t) {
+        const bool have_tile = t <= t_last;
+        if (have_tile) {
+            {
+                PDS_T0();
+                store_tile_lds<T, false>(wl, p, lane, regs);
+                PDS_WAVE_LDS_SYNC();
+                PDS_T1(0);
+            }
+            PDS_T0();
+            if (t + 1 <= t_last) load_tile(t + 1);
+            PDS_T1(1);
+        }
         const int64_t row0 = t * TR;
-        const int64_t tile_end = (row0 + TR < rhi) ? row0 + TR : rhi;
-        while (g < gh && pos < tile_end) {
+        const int64_t tile_end = have_tile ? ((row0 + TR < rhi) ? row0 + TR : rhi) : pos;
+        while (g < gh && (pos < tile_end || ge <= pos)) {
             if (ge <= pos) {  // group complete (or empty)
                 flush_group();
                 ++g;
@@ -396,21 +430,21 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
                 continue;
             }
             const int64_t seg_end = (ge < tile_end) ? ge : tile_end;
+            PDS_T0();
             if constexpr (PACK) consume_range_pack<T, BIAS>(wl, lane, (int)(pos - row0), (int)(seg_end - row0), acc);
             else consume_range<T, BIAS>(wl, lane, (int)(pos - row0), (int)(seg_end - row0), acc);
+            PDS_T1(4);
             pos = seg_end;
         }
+        if (t >= t_last) break;
         PDS_WAVE_LDS_SYNC();
     }
-    // groups that end exactly at rhi (and trailing empty groups)
-    while (g < gh) {
-        flush_group();
-        ++g;
-        gs = ge;
-        ge = ge_next;
-        ge_next = offsets[(g + 2 <= n_groups) ? g + 2 : n_groups];
-    }
     if (npend > 0) solve_pending();
+#ifdef PDS_PROFILE_PHASES
+    prof[7] = __builtin_amdgcn_s_memtime() - t_begin;
+    if (lane == 0)
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_phase_cycles[k], prof[k]);
+#endif
 }
 
 template <typename T, int LPS>
@@ -446,6 +480,7 @@ int launch_grouped_fused(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int6
     sd.lambda = sp.lambda;
     sd.gate_on = sp.gate_tol > 0.0 ? 1 : 0;
     sd.ln_tol = sd.gate_on ? std::log(sp.gate_tol) : 0.0;
+    sd.inv_tol = sd.gate_on ? 1.0 / sp.gate_tol : HUGE_VAL;
     if (n_groups <= 0) return PDS_OK;
     const char* piv = std::getenv("PDS_GROUPED_PIVOTED");
     const bool chol = sd.gate_on && !(piv && piv[0] == '1');
@@ -453,6 +488,15 @@ int launch_grouped_fused(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int6
     if (sd.pp <= 8) return launch_stream_lps<T, 8>(ctx, dc, n_feat, d_offsets, n_groups, n_rows, sd, chol, d_coeffs, d_flags);
     return launch_stream_lps<T, 16>(ctx, dc, n_feat, d_offsets, n_groups, n_rows, sd, chol, d_coeffs, d_flags);
 }
+
+#ifdef PDS_PROFILE_PHASES
+extern "C" int pds_debug_phase_cycles(unsigned long long* out, int reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), sizeof(z)) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
 
 template int launch_grouped_fused<double>(pds_ctx*, const DeviceCols<double>&, int, int64_t, const int64_t*, int64_t,
                                           const SolveParams&, double*, uint8_t*);

@@ -91,6 +91,7 @@ int launch_solve_reg(pds_ctx* ctx, const T* d_moments, int64_t n_sys, const Solv
     sd.lambda = sp.lambda;
     sd.gate_on = sp.gate_tol > 0.0 ? 1 : 0;
     sd.ln_tol = sd.gate_on ? std::log(sp.gate_tol) : 0.0;
+    sd.inv_tol = sd.gate_on ? 1.0 / sp.gate_tol : HUGE_VAL;
     // Cholesky in registers when asked for and gated (an ungated breakdown must fall back to QR: solve.hip)
     const bool chol = sp.solver == PDS_SOLVER_CHOLESKEY && sd.gate_on;
     if (sd.pp <= 4) return launch_lps<T, 4>(ctx, d_moments, n_sys, sd, chol, d_coeffs, d_flags, d_rows_per_sys);

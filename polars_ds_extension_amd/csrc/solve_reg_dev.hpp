@@ -8,6 +8,7 @@ namespace pds {
 struct SolveRegDev {
     int p, pp, bias, lambda_on_bias, gate_on;
     double lambda, ln_tol;
+    double inv_tol;  // 1 / gate_tol (the Cholesky gate compares a product of pivot ratios)
 };
 
 // Cross-lane moves of a double.  The f64 overload of update_dpp matters: with row_newbcast it is ONE v_mov_b64_dpp
@@ -245,78 +246,98 @@ __device__ __forceinline__ void solve_core(double (&a)[LPS], double (&b)[LPS], d
 }
 
 // ---------------------------------------------------------------------------------------------
-// Cholesky (llt(Side::Lower), lr_solvers.rs:288,369) in the same lane-per-column register layout.
-// The full symmetric matrix is kept (lane j = column j, a[i] = G_ij), so the multiplier l_jK of column j is
-// its OWN row-K entry -- no transpose traffic -- and the rhs rides along as one extra ROW (a[LPS] = c_j):
-// after the factorisation lane j holds y_j = (L^-1 c)_j for free.  ~4x fewer instructions and a third of
-// the registers of the pivoted QR; a non-positive pivot means "not positive definite".
+// Cholesky (llt(Side::Lower), lr_solvers.rs:288,369) in the same lane-per-column register layout, carried out as
+// the square-root-free L D L' it is equivalent to.  The full symmetric matrix is kept (lane j = column j,
+// a[i] = G_ij), so the multiplier of column j in step K is its OWN row-K entry over the pivot -- no transpose
+// traffic -- and the rhs rides along as one extra ROW (a[LPS] = c_j).  After the elimination lane j holds
+// d_j = L_jj^2 (captured as 1 / d_j), the unscaled column L_ij L_jj in a[i] (i > j) and L_jj y_j in a[LPS], so
+//     beta_j = a[LPS] / d_j - sum_{M > j} (a[M] / d_j) beta_M
+// needs neither a square root nor 1 / L_jj.  A non-positive pivot means "not positive definite" (:370-371).
+// Instruction shape (the solve is a latency chain, every dependent instruction costs ~10 clk of a wave's time):
+//   * step K: pivot broadcast, v_rcp_f64 + two Newton steps (4 dependent FMAs; the rsqrt form needed 6 + 2),
+//     one multiply, then ONE v_fmac_f64_dpp per remaining row;
+//   * back substitution: w <- w + bcast_M(w) * (-a[M] / d_j) for M = p'-1 .. 1 is the same single instruction per
+//     step on a running vector w whose lane j is final (= beta_j) once step j + 1 has passed -- no selects;
+//   * the rank gate sum ln L_kk^2 - sum ln G_kk <= ln tol (:372-380) is taken as prod (G_kk / d_k) >= 1 / tol: the
+//     factors are >= 1, an overflow lands on the right side, and no logarithm sits on the chain.
 // ---------------------------------------------------------------------------------------------
+// a + bcast_K(a) * m over the sub-group's lanes
 template <int LPS, int K>
-__device__ __forceinline__ void chol_step(double (&a)[LPS + 1], int j, int pp, double& rinv_j, double& dcap,
-                                          bool& ok) {
-    if constexpr (LPS == 16) asm volatile("s_nop 1" ::: "memory");  // see the inline-asm update below
-    const double d = Grp<LPS>::template bcast<K>(a[K]);
-    ok = ok && (d > 0.0);
-    // 1/sqrt(d): hardware estimate (v_rsq_f64) + two Newton steps -- a third of the instructions of sqrt + divide,
-    // accurate to an ulp or two, which is all the elimination multipliers need (and fails the same way for d <= 0)
-    double r = __builtin_amdgcn_rsq(d);
-    r = r * fma(-0.5 * d * r, r, 1.5);
-    r = r * fma(-0.5 * d * r, r, 1.5);
-    // lanes <= K keep their finished columns (their a[i], i > K, are the unscaled l_iK): a zero multiplier instead
-    // of a select per element.  DPP reads from EXEC-disabled lanes are invalid, so every lane takes part.
-    const double t = (j > K) ? a[K] * r * r : 0.0;  // l_jK / l_KK
+__device__ __forceinline__ void bcast_fmac(double& a, double m) {
     if constexpr (LPS == 16) {
-        // a[i] += bcast_K(a[i]) * (-t) as ONE instruction per row: the DP ALU takes row_newbcast on its first source
-        // (the compiler only ever emits v_mov_b64_dpp + v_fma_f64 for this).  The 2-wait-state rule between a VALU
-        // write and a DPP read of the same register is ours to keep inside inline asm: a[i] was last written one
-        // whole elimination step ago, and chol_step opens with an s_nop for the shortest steps.
-        const double nt = -t;
-#pragma unroll
-        for (int i = K + 1; i <= LPS; ++i)
-            asm volatile("v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(nt), "n"(K));
+        // ONE instruction: the DP ALU takes row_newbcast on its first source (the compiler only ever emits
+        // v_mov_b64_dpp + v_fma_f64 for this).  A DPP read needs two wait states after a VALU write of the same
+        // register and the compiler cannot see into the asm -- it does place register copies directly in front of it
+        // (observed) -- so the wait states travel with the instruction.
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(m), "n"(K));
     } else {
-#pragma unroll
-        for (int i = K + 1; i <= LPS; ++i) {
-            const double v = Grp<LPS>::template bcast<K>(a[i]);
-            a[i] = fma(-v, t, a[i]);
-        }
-    }
-    if (j == K) {
-        rinv_j = r;
-        dcap = d;
+        a = fma(Grp<LPS>::template bcast<K>(a), m, a);
     }
 }
 
 template <int LPS, int K>
+__device__ __forceinline__ void chol_step(double (&a)[LPS + 1], int j, double& invd, bool& ok) {
+    const double d = Grp<LPS>::template bcast<K>(a[K]);
+    ok = ok && (d > 0.0);
+    double x = __builtin_amdgcn_rcp(d);
+    x = fma(fma(-d, x, 1.0), x, x);
+    x = fma(fma(-d, x, 1.0), x, x);
+    // lanes <= K keep their finished columns: a zero multiplier instead of a select per element (DPP reads from
+    // EXEC-disabled lanes are invalid, so every lane takes part)
+    const double nt = (j > K) ? -(a[K] * x) : 0.0;
+#pragma unroll
+    for (int i = K + 1; i <= LPS; ++i) bcast_fmac<LPS, K>(a[i], nt);
+    if (j == K) invd = x;
+}
+
+template <int LPS, int K>
 struct CholSteps {
-    static __device__ __forceinline__ void run(double (&a)[LPS + 1], int j, int pp, double& rinv_j, double& dcap,
-                                               bool& ok) {
-        CholSteps<LPS, K - 1>::run(a, j, pp, rinv_j, dcap, ok);
-        if (K < pp) chol_step<LPS, K>(a, j, pp, rinv_j, dcap, ok);
+    static __device__ __forceinline__ void run(double (&a)[LPS + 1], int j, int pp, double& invd, bool& ok) {
+        CholSteps<LPS, K - 1>::run(a, j, pp, invd, ok);
+        if (K < pp) chol_step<LPS, K>(a, j, invd, ok);
     }
 };
 template <int LPS>
 struct CholSteps<LPS, -1> {
-    static __device__ __forceinline__ void run(double (&)[LPS + 1], int, int, double&, double&, bool&) {}
+    static __device__ __forceinline__ void run(double (&)[LPS + 1], int, int, double&, bool&) {}
 };
 
+// rows / columns beyond p' are exact zeros (see the callers' loads), so their steps add zeros: no p' guard
 template <int LPS, int M>
 struct CholBack {
-    static __device__ __forceinline__ void run(const double (&a)[LPS + 1], int j, int pp, double yj, double rinv_j,
-                                               double& acc, double& beta) {
-        if (M < pp) {
-            const double cand = (yj - acc) * rinv_j;
-            const double bm = Grp<LPS>::template bcast<M>(cand);
-            if (j == M) beta = bm;
-            if (j < M) acc = fma(a[M] * rinv_j, bm, acc);  // l_Mj beta_M, l_Mj = a[M] / l_jj
-        }
-        CholBack<LPS, M - 1>::run(a, j, pp, yj, rinv_j, acc, beta);
+    static __device__ __forceinline__ void run(const double (&c)[LPS], double& w) {
+        bcast_fmac<LPS, M>(w, c[M]);
+        CholBack<LPS, M - 1>::run(c, w);
     }
 };
 template <int LPS>
-struct CholBack<LPS, -1> {
-    static __device__ __forceinline__ void run(const double (&)[LPS + 1], int, int, double, double, double&, double&) {}
+struct CholBack<LPS, 0> {
+    static __device__ __forceinline__ void run(const double (&)[LPS], double&) {}
 };
+
+template <int LPS>
+__device__ __forceinline__ double grp_prod(double v);
+template <>
+__device__ __forceinline__ double grp_prod<16>(double v) {
+    v *= dpp_mov<kRor8>(0.0, v);
+    v *= dpp_mov<kRor4>(0.0, v);
+    v *= dpp_mov<kRor2>(0.0, v);
+    v *= dpp_mov<kRor1>(0.0, v);
+    return v;
+}
+template <>
+__device__ __forceinline__ double grp_prod<8>(double v) {
+    v *= dpp_mov<kHalfMirror>(0.0, v);
+    v *= dpp_mov<kXor1>(0.0, v);
+    v *= dpp_mov<kXor2>(0.0, v);
+    return v;
+}
+template <>
+__device__ __forceinline__ double grp_prod<4>(double v) {
+    v *= dpp_mov<kXor1>(0.0, v);
+    v *= dpp_mov<kXor2>(0.0, v);
+    return v;
+}
 
 // a[0..LPS) = column j of G (+lambda), a[LPS] = c_j, dj = G_jj.  beta_j is the coefficient of column j.
 template <int LPS>
@@ -324,25 +345,25 @@ __device__ __forceinline__ void chol_core(double (&a)[LPS + 1], double dj, int j
                                           double& beta) {
     const int pp = sp.pp;
     const bool colv = j < pp;
-    double ln_den = 0.0;
     if (sp.gate_on) {
-        const double bad = Grp<LPS>::sum((colv && !(dj > 0.0)) ? 1.0 : 0.0);
-        const double badn = Grp<LPS>::sum((colv && dj != dj) ? 1.0 : 0.0);
-        if (bad - badn > 0.0) is_null = true;
-        ln_den = Grp<LPS>::sum(colv ? log(dj) : 0.0);
+        // a non-positive diagonal entry gates (NaN passes, as in Rust)   lr_solvers.rs:341-347
+        const double bad = Grp<LPS>::sum((colv && dj <= 0.0) ? 1.0 : 0.0);
+        if (bad > 0.0) is_null = true;
     }
-    double rinv_j = 1.0, dcap = 1.0;
+    double invd = 1.0;
     bool ok = true;
-    CholSteps<LPS, LPS - 1>::run(a, j, pp, rinv_j, dcap, ok);
+    CholSteps<LPS, LPS - 1>::run(a, j, pp, invd, ok);
     if (!ok) is_null = true;  // "Not positive-definite -> rank-deficient" (lr_solvers.rs:370-371)
-    if (sp.gate_on && !is_null) {
-        const double ln_det = Grp<LPS>::sum(colv ? log(dcap) : 0.0);  // = 2 sum ln L_kk
-        if (ln_det - ln_den <= sp.ln_tol) is_null = true;
+    if (sp.gate_on) {
+        const double grow = grp_prod<LPS>(colv ? dj * invd : 1.0);  // prod G_kk / L_kk^2
+        if (grow >= sp.inv_tol) is_null = true;
     }
-    const double yj = a[LPS] * rinv_j;
-    double acc = 0.0;
-    beta = 0.0;
-    CholBack<LPS, LPS - 1>::run(a, j, pp, yj, rinv_j, acc, beta);
+    double c[LPS];
+#pragma unroll
+    for (int m = 1; m < LPS; ++m) c[m] = (j < m) ? -(a[m] * invd) : 0.0;
+    double w = a[LPS] * invd;
+    CholBack<LPS, LPS - 1>::run(c, w);
+    beta = w;
 }
 
 }  // namespace pds
