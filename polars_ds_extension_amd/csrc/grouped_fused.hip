@@ -213,8 +213,12 @@ __device__ __forceinline__ int64_t lower_bound_i64(const int64_t* __restrict__ a
     return lo;
 }
 
-template <typename T, int LPS, bool CHOL, bool BIAS>
-__global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __restrict__ cols, int p,
+// FULLP: p' == LPS, i.e. the feature count is known at compile time (the 16- and 8-feature frames of the headline configs,
+// 15 / 7 / 3 features + bias): the per-column `c < p` branches of the tile load / store (17 scalar compares + branches per
+// tile, each re-reading a spilled SGPR) and the solver's per-step `K < p'` branches fold away -- 2.86 -> 2.63 ms at 16
+// features, 1.89 -> 1.52 ms at 8
+template <typename T, int LPS, bool CHOL, bool BIAS, bool FULLP>
+__global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __restrict__ cols, int p_arg,
                                                             const int64_t* __restrict__ offsets, int64_t n_groups,
                                                             int64_t n_rows, SolveRegDev sp, T* __restrict__ coeffs,
                                                             uint8_t* __restrict__ flags) {
@@ -228,7 +232,8 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
     const int lane = threadIdx.x & 63;
     char* wl = smem;
     double* Msc = reinterpret_cast<double*>(smem + kFTile);
-    const int pp = sp.pp;
+    const int p = FULLP ? LPS - (BIAS ? 1 : 0) : p_arg;
+    const int pp = FULLP ? LPS : sp.pp;
     const int sub = lane / LPS, j_in = lane % LPS;
 
     // ---- this wave's groups: balanced in rows
@@ -272,7 +277,9 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
         int pj = j;
         PDS_T0();
         if constexpr (CHOL) {
-            chol_core<LPS>(a_p, dj_p, j, sp, is_null, zj);
+            SolveRegDev spk = sp;
+            if constexpr (FULLP) spk.pp = LPS;  // compile-time p': the per-step `K < p'` branches fold away
+            chol_core<LPS>(a_p, dj_p, j, spk, is_null, zj);
         } else {
             solve_core<LPS>(a_p, b_p, dj_p, j, lane, sp, is_null, pj, zj);
         }
@@ -289,15 +296,19 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
     // group bounds are carried, not re-loaded: gs = start of group g, ge = its end, ge_next = end of group g+1
     // (fetched one group ahead, so the dependent global load sits under a whole group of work instead of in
     // front of every boundary decision)
+    // The loop below decides in tile-relative 32-bit numbers (scalar compares): 64-bit `<` has no scalar form and every
+    // one of them was a VALU compare + vcc branch on the per-group path.  g_left = groups of this wave not yet flushed.
     int64_t gs = rlo;
     int64_t ge = offsets[g + 1];
-    int64_t ge_next = offsets[(g + 2 <= n_groups) ? g + 2 : n_groups];
+    uint32_t g_left = (uint32_t)(gh - gl);  // launch_grouped_fused keeps n_groups below 2^31
+    int64_t ge_next = offsets[g_left >= 2 ? g + 2 : gh];
     int64_t pos = rlo;
 
     auto flush_group = [&]() __attribute__((always_inline)) {
         // ---- normal equations of group g -> LDS scratch (full symmetric square, bias at 16, y at 17)
         PDS_T0();
-        const int64_t ng = ge - gs;
+        const uint64_t ng = (uint64_t)(ge - gs);
+        const bool too_few = (uint32_t)(ng >> 32) == 0u && (uint32_t)ng < (uint32_t)pp;
         {
             const int jj = lane & 15;
 #pragma unroll
@@ -371,7 +382,7 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
                 }
                 if constexpr (CHOL) a_p[LPS] = Msc[lj + kFQ * 17];
                 dj_p = (j < pp) ? colp[lj] : 1.0;
-                null_p = ng < pp;  // per-group pl_lr raises "#Data < #features": reported as null
+                null_p = too_few;  // per-group pl_lr raises "#Data < #features": reported as null
             }
         }
         PDS_WAVE_LDS_SYNC();
@@ -411,7 +422,9 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
             {
                 PDS_T0();
                 store_tile_lds<T, false>(wl, p, lane, regs);
-                PDS_WAVE_LDS_SYNC();
+#ifdef PDS_PROFILE_PHASES
+                PDS_WAVE_LDS_SYNC();  // charge the LDS writes (and the wait for the tile) to this phase
+#endif
                 PDS_T1(0);
             }
             PDS_T0();
@@ -419,23 +432,38 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
             PDS_T1(1);
         }
         const int64_t row0 = t * TR;
-        const int64_t tile_end = have_tile ? ((row0 + TR < rhi) ? row0 + TR : rhi) : pos;
-        while (g < gh && (pos < tile_end || ge <= pos)) {
-            if (ge <= pos) {  // group complete (or empty)
+        // rows of this tile that belong to the wave, relative to row0 (no tile: nothing to consume, flushes only)
+        uint32_t rel_end = 0, pos_rel = 0;
+        if (have_tile) {
+            const uint64_t left = (uint64_t)(rhi - row0);
+            rel_end = ((uint32_t)(left >> 32) != 0u || (uint32_t)left > (uint32_t)TR) ? (uint32_t)TR : (uint32_t)left;
+            pos_rel = (uint32_t)(pos - row0);
+        }
+        // end of the current group relative to row0, saturated (ge >= pos >= row0 whenever a tile is present)
+        auto rel_of = [&](int64_t r) __attribute__((always_inline)) {
+            const uint64_t d = (uint64_t)(r - (have_tile ? row0 : pos));
+            return ((uint32_t)(d >> 32) != 0u) ? 0xFFFFFFFFu : (uint32_t)d;
+        };
+        uint32_t ge_rel = rel_of(ge);
+        while (g_left != 0u && (pos_rel < rel_end || ge_rel <= pos_rel)) {
+            if (ge_rel <= pos_rel) {  // group complete (or empty)
                 flush_group();
                 ++g;
+                --g_left;
                 gs = ge;
                 ge = ge_next;
-                ge_next = offsets[(g + 2 <= n_groups) ? g + 2 : n_groups];
+                ge_next = offsets[g_left >= 2u ? g + 2 : gh];
+                ge_rel = rel_of(ge);
                 continue;
             }
-            const int64_t seg_end = (ge < tile_end) ? ge : tile_end;
+            const uint32_t seg_end = (ge_rel < rel_end) ? ge_rel : rel_end;
             PDS_T0();
-            if constexpr (PACK) consume_range_pack<T, BIAS>(wl, lane, (int)(pos - row0), (int)(seg_end - row0), acc);
-            else consume_range<T, BIAS>(wl, lane, (int)(pos - row0), (int)(seg_end - row0), acc);
+            if constexpr (PACK) consume_range_pack<T, BIAS>(wl, lane, (int)pos_rel, (int)seg_end, acc);
+            else consume_range<T, BIAS>(wl, lane, (int)pos_rel, (int)seg_end, acc);
             PDS_T1(4);
-            pos = seg_end;
+            pos_rel = seg_end;
         }
+        if (have_tile) pos = row0 + pos_rel;
         if (t >= t_last) break;
         PDS_WAVE_LDS_SYNC();
     }
@@ -458,12 +486,18 @@ static int launch_stream_lps(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, 
     // (the pivoted-QR variant of this kernel measured slower than the two-kernel pipeline and is not instantiated;
     //  callers route the ungated case to grouped_moments_kernel + solve_reg_kernel)
     if (!chol) return fail(PDS_ERR_INVALID, "internal: fused grouped kernel is Cholesky-only");
-    if (sd.bias)
-        hipLaunchKernelGGL((grouped_stream_kernel<T, LPS, true, true>), dim3((unsigned)nb), dim3(64), lds, ctx->stream, dc.d_ptrs,
-                           n_feat, d_offsets, n_groups, n_rows, sd, d_coeffs, d_flags);
+    if (sd.bias && sd.pp == LPS)
+        hipLaunchKernelGGL((grouped_stream_kernel<T, LPS, true, true, true>), dim3((unsigned)nb), dim3(64), lds, ctx->stream,
+                           dc.d_ptrs, n_feat, d_offsets, n_groups, n_rows, sd, d_coeffs, d_flags);
+    else if (sd.bias)
+        hipLaunchKernelGGL((grouped_stream_kernel<T, LPS, true, true, false>), dim3((unsigned)nb), dim3(64), lds, ctx->stream,
+                           dc.d_ptrs, n_feat, d_offsets, n_groups, n_rows, sd, d_coeffs, d_flags);
+    else if (n_feat == LPS)
+        hipLaunchKernelGGL((grouped_stream_kernel<T, LPS, true, false, true>), dim3((unsigned)nb), dim3(64), lds, ctx->stream,
+                           dc.d_ptrs, n_feat, d_offsets, n_groups, n_rows, sd, d_coeffs, d_flags);
     else
-        hipLaunchKernelGGL((grouped_stream_kernel<T, LPS, true, false>), dim3((unsigned)nb), dim3(64), lds, ctx->stream, dc.d_ptrs,
-                           n_feat, d_offsets, n_groups, n_rows, sd, d_coeffs, d_flags);
+        hipLaunchKernelGGL((grouped_stream_kernel<T, LPS, true, false, false>), dim3((unsigned)nb), dim3(64), lds, ctx->stream,
+                           dc.d_ptrs, n_feat, d_offsets, n_groups, n_rows, sd, d_coeffs, d_flags);
     PDS_HIP_CHECK(hipGetLastError());
     return PDS_OK;
 }
@@ -482,6 +516,7 @@ int launch_grouped_fused(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int6
     sd.ln_tol = sd.gate_on ? std::log(sp.gate_tol) : 0.0;
     sd.inv_tol = sd.gate_on ? 1.0 / sp.gate_tol : HUGE_VAL;
     if (n_groups <= 0) return PDS_OK;
+    if (n_groups >= (1ll << 31)) return fail(PDS_ERR_INVALID, "internal: fused grouped kernel counts groups per wave in 32 bits");
     const char* piv = std::getenv("PDS_GROUPED_PIVOTED");
     const bool chol = sd.gate_on && !(piv && piv[0] == '1');
     if (sd.pp <= 4) return launch_stream_lps<T, 4>(ctx, dc, n_feat, d_offsets, n_groups, n_rows, sd, chol, d_coeffs, d_flags);
