@@ -19,9 +19,11 @@ namespace pds {
 // single big system: grid-stride over 128-row (f64) / 256-row (f32) tiles, register prefetch of the
 // next tile while the matrix core chews the current one.
 // =============================================================================================
-template <typename T, bool WEIGHTED>
-__global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* __restrict__ cols, int p,
+// P16: exactly 16 features, known at compile time -- the per-column `c < p` scalar branches of the tile load / store fold away
+template <typename T, bool WEIGHTED, bool P16>
+__global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* __restrict__ cols, int p_arg,
                                                                int64_t n, double* __restrict__ partials) {
+    const int p = P16 ? 16 : p_arg;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int RPL = Tile<T>::RPL;
     constexpr int TR = 64 * RPL;
@@ -202,11 +204,17 @@ int launch_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_
     double* partials = ctx->partials;  // sized for 8 blocks per CU at context creation
     KernelTimer timer(ctx, kKindMoments);
     size_t lds = (size_t)kWaves * kWaveLds + 64;  // + slack: the pipelined operand fetch reads two steps ahead
-    if (weighted)
-        hipLaunchKernelGGL((moments_small_kernel<T, true>), dim3(nblocks), dim3(256), lds, ctx->stream, dc.d_ptrs,
+    if (weighted && n_feat == 16)
+        hipLaunchKernelGGL((moments_small_kernel<T, true, true>), dim3(nblocks), dim3(256), lds, ctx->stream, dc.d_ptrs,
+                           n_feat, n_rows, partials);
+    else if (weighted)
+        hipLaunchKernelGGL((moments_small_kernel<T, true, false>), dim3(nblocks), dim3(256), lds, ctx->stream, dc.d_ptrs,
+                           n_feat, n_rows, partials);
+    else if (n_feat == 16)
+        hipLaunchKernelGGL((moments_small_kernel<T, false, true>), dim3(nblocks), dim3(256), lds, ctx->stream, dc.d_ptrs,
                            n_feat, n_rows, partials);
     else
-        hipLaunchKernelGGL((moments_small_kernel<T, false>), dim3(nblocks), dim3(256), lds, ctx->stream, dc.d_ptrs,
+        hipLaunchKernelGGL((moments_small_kernel<T, false, false>), dim3(nblocks), dim3(256), lds, ctx->stream, dc.d_ptrs,
                            n_feat, n_rows, partials);
     hipLaunchKernelGGL((moments_finalize_kernel<T>), dim3(kPartSW + 1), dim3(64), 0, ctx->stream, partials, nblocks, n_feat,
                        (double)n_rows, weighted ? 1 : 0, d_moments);

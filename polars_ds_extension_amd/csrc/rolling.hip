@@ -74,10 +74,20 @@ __device__ __forceinline__ bool finish_row(bool in, const double (&z)[PP], doubl
     return in && fin;
 }
 
-template <typename T, int PP>
-__device__ __forceinline__ void rolling_body(const T* const* __restrict__ cols, const RollArgs& ra,
+// MODE (0 rolling, 1 expanding totals, 2 expanding main) and FULLP (p == PP, no bias column) are compile-time: the step
+// is VALU bound, but the wave-uniform branches on them (a dozen per row fetch, more in the phases) each cost a scalar
+// compare + branch bubble inside it.
+template <typename T, int PP, int MODE, bool FULLP>
+__device__ __forceinline__ void rolling_body(const T* const* __restrict__ cols, const RollArgs& ra_in,
                                              double* __restrict__ tile_tot /*[tiles][NV]*/, T* __restrict__ coeffs,
                                              T* __restrict__ pred, uint8_t* __restrict__ valid) {
+    RollArgs ra = ra_in;
+    ra.mode = MODE;
+    if constexpr (FULLP) {
+        ra.p = PP;
+        ra.pp = PP;
+        ra.bias = 0;
+    }
     constexpr int NG = RollDims<PP>::NG, NV = RollDims<PP>::NV, NSET = RollDims<PP>::NSET, NH = RollDims<PP>::NH;
     static_assert(NH <= 64, "one lane per moment of a pass");
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -273,17 +283,22 @@ __device__ __forceinline__ void rolling_body(const T* const* __restrict__ cols, 
 
 // p' <= 8 is compiled for two waves per SIMD (248 VGPRs, no spills): with the moments passing through LDS in halves
 // the CU then holds 8 waves.  p' >= 10 would spill at that budget (measured 2x slower) and keeps one wave per SIMD.
-template <typename T, int PP>
+template <typename T, int PP, int MODE, bool FULLP>
 __global__ __launch_bounds__(kRollWaves * 64) __attribute__((amdgpu_waves_per_eu(2))) void rolling_kernel(
     const T* const* __restrict__ cols, RollArgs ra, double* __restrict__ tile_tot, T* __restrict__ coeffs, T* __restrict__ pred,
     uint8_t* __restrict__ valid) {
-    rolling_body<T, PP>(cols, ra, tile_tot, coeffs, pred, valid);
+    rolling_body<T, PP, MODE, FULLP>(cols, ra, tile_tot, coeffs, pred, valid);
 }
-template <typename T, int PP>
+template <typename T, int PP, int MODE, bool FULLP>
 __global__ __launch_bounds__(kRollWaves * 64) void rolling_kernel_1w(const T* const* __restrict__ cols, RollArgs ra,
                                                                      double* __restrict__ tile_tot, T* __restrict__ coeffs,
                                                                      T* __restrict__ pred, uint8_t* __restrict__ valid) {
-    rolling_body<T, PP>(cols, ra, tile_tot, coeffs, pred, valid);
+    rolling_body<T, PP, MODE, FULLP>(cols, ra, tile_tot, coeffs, pred, valid);
+}
+template <typename T, int PP, int MODE, bool FULLP>
+static auto roll_kernel_ptr() {
+    if constexpr (PP >= 10) return &rolling_kernel_1w<T, PP, MODE, FULLP>;
+    else return &rolling_kernel<T, PP, MODE, FULLP>;
 }
 
 // exclusive prefix over the per-tile totals (expanding window): one block of kPrefixWaves waves, lane = moment,
@@ -333,22 +348,25 @@ __global__ __launch_bounds__(kPrefixWaves * 64) void tile_prefix_kernel(double* 
     }
 }
 
-template <typename T, int PP>
-static int launch_pp(pds_ctx* ctx, const DeviceCols<T>& dc, RollArgs ra, bool expanding, const double* seed_moments,
-                     T* d_coeffs, T* d_pred, uint8_t* d_valid) {
+template <typename T, int PP, bool FULLP>
+static int launch_pp_f(pds_ctx* ctx, const DeviceCols<T>& dc, RollArgs ra, bool expanding, const double* seed_moments,
+                       T* d_coeffs, T* d_pred, uint8_t* d_valid) {
     constexpr int NV = RollDims<PP>::NV;
     const size_t lds = (size_t)kRollWaves * RollDims<PP>::NH * kLdsStride * sizeof(double);
     ra.tile_rows = kTileRows;
     const int64_t ntiles = (ra.n + ra.tile_rows - 1) / ra.tile_rows;
     int64_t nb = (ntiles + kRollWaves - 1) / kRollWaves;
     nb = std::min<int64_t>(std::max<int64_t>(nb, 1), (int64_t)ctx->num_cus * 4);
-    auto kern = PP >= 10 ? &rolling_kernel_1w<T, PP> : &rolling_kernel<T, PP>;
+    auto kern0 = roll_kernel_ptr<T, PP, 0, FULLP>();
+    auto kern1 = roll_kernel_ptr<T, PP, 1, FULLP>();
+    auto kern2 = roll_kernel_ptr<T, PP, 2, FULLP>();
     if (lds > 64 * 1024)
-        PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        for (const void* k : {reinterpret_cast<const void*>(kern0), reinterpret_cast<const void*>(kern1), reinterpret_cast<const void*>(kern2)})
+            PDS_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     KernelTimer timer(ctx, kKindRolling);
     if (!expanding) {
         ra.mode = 0;
-        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(kRollWaves * 64), lds, ctx->stream,
+        hipLaunchKernelGGL(kern0, dim3((unsigned)nb), dim3(kRollWaves * 64), lds, ctx->stream,
                            dc.d_ptrs, ra, (double*)nullptr, d_coeffs, d_pred, d_valid);
     } else {
         double* tot = reinterpret_cast<double*>(ws_take(ctx, (size_t)ntiles * NV * sizeof(double)));
@@ -369,15 +387,22 @@ static int launch_pp(pds_ctx* ctx, const DeviceCols<T>& dc, RollArgs ra, bool ex
             PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // h is on this stack frame
         }
         ra.mode = 1;
-        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(kRollWaves * 64), lds, ctx->stream,
+        hipLaunchKernelGGL(kern1, dim3((unsigned)nb), dim3(kRollWaves * 64), lds, ctx->stream,
                            dc.d_ptrs, ra, tot, d_coeffs, d_pred, d_valid);
         hipLaunchKernelGGL(tile_prefix_kernel, dim3(1), dim3(kPrefixWaves * 64), 0, ctx->stream, tot, ntiles, NV, d_seed);
         ra.mode = 2;
-        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(kRollWaves * 64), lds, ctx->stream,
+        hipLaunchKernelGGL(kern2, dim3((unsigned)nb), dim3(kRollWaves * 64), lds, ctx->stream,
                            dc.d_ptrs, ra, tot, d_coeffs, d_pred, d_valid);
     }
     PDS_HIP_CHECK(hipGetLastError());
     return PDS_OK;
+}
+
+template <typename T, int PP>
+static int launch_pp(pds_ctx* ctx, const DeviceCols<T>& dc, RollArgs ra, bool expanding, const double* seed_moments,
+                     T* d_coeffs, T* d_pred, uint8_t* d_valid) {
+    if (ra.p == PP && !ra.bias) return launch_pp_f<T, PP, true>(ctx, dc, ra, expanding, seed_moments, d_coeffs, d_pred, d_valid);
+    return launch_pp_f<T, PP, false>(ctx, dc, ra, expanding, seed_moments, d_coeffs, d_pred, d_valid);
 }
 
 template <typename T>
