@@ -244,6 +244,23 @@ int pds_lr_grouped_nullable_f32(pds_ctx* ctx, const float* const* cols, const ui
                                 float fill_value, const pds_lr_params* prm, float* coeffs, uint8_t* is_null);
 
 /*
+ * pds_lr_by_key_*: `df.group_by(key).agg(pds.lin_reg(...))` for an int64 key column in ANY row order -- the grouping
+ * Polars does on the host before it calls `pl_lr` per group (tests/test_linear_exprs.py:435-474), done on the device:
+ * keys already non-decreasing -> no data movement; otherwise a radix sort of (key, row) pairs and a gather of the columns.
+ * Then exactly pds_lr_grouped_*.  Groups come back in ascending key order.
+ *   keys        n_rows int64 values, `space`-resident.
+ *   max_groups  capacity of the outputs (n_rows is always enough).
+ *   out_keys    out, the distinct keys;  coeffs  out, n_groups x (n_feat + add_bias);  is_null  out, n_groups bytes
+ *               -- all `space`-resident.   n_groups  out (host), number of distinct keys.
+ */
+int pds_lr_by_key_f64(pds_ctx* ctx, const double* const* cols, const int64_t* keys, int n_feat, int64_t n_rows, pds_space space,
+                      const pds_lr_params* prm, int64_t max_groups, int64_t* out_keys, double* coeffs, uint8_t* is_null,
+                      int64_t* n_groups);
+int pds_lr_by_key_f32(pds_ctx* ctx, const float* const* cols, const int64_t* keys, int n_feat, int64_t n_rows, pds_space space,
+                      const pds_lr_params* prm, int64_t max_groups, int64_t* out_keys, float* coeffs, uint8_t* is_null,
+                      int64_t* n_groups);
+
+/*
  * pds_rolling_lr_* / pds_recursive_lr_*: `pl_rolling_lr` (linear_regression.rs:1206-1283) and
  * `pl_recursive_lr` (:1121-1204) on null-free columns, i.e. faer_rolling_lr / faer_recursive_lr
  * (lr_online_solvers.rs:148-212) plus the plugin's pred_i = x_i . coeffs_i.  SWWLRKwargs: n = window

@@ -12,6 +12,7 @@ from .lstsq import (  # noqa: F401
     gram_moments,
     lin_reg,
     lin_reg_by,
+    lin_reg_by_key,
     lin_reg_from_moments,
     lin_reg_report,
     lin_reg_w_rcond,

@@ -944,6 +944,90 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
     return PDS_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// grouped by an int64 key column in any row order (keyed.hip brings the frame into key order on the device)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* keys, int n_feat, int64_t n_rows, pds_space space,
+                          const pds_lr_params* prm, int64_t max_groups, int64_t* out_keys, T* coeffs, uint8_t* is_null,
+                          int64_t* n_groups) {
+    if (!ctx || !cols || !keys || !prm || !out_keys || !coeffs || !n_groups) return fail(PDS_ERR_INVALID, "null argument");
+    if (n_feat < 1) return fail(PDS_ERR_INVALID, "need at least one feature column");
+    if (n_rows <= 0) return fail(PDS_ERR_EMPTY, "Empty data");
+    if (n_rows >= (1ll << 31)) return fail(PDS_ERR_UNSUPPORTED, "keyed grouping: fewer than 2^31 rows per call");
+    if (max_groups < 1) return fail(PDS_ERR_INVALID, "max_groups must be positive");
+    PDS_HIP_CHECK(hipSetDevice(ctx->device));
+    const int nc = n_feat + 1, pp = n_feat + (prm->add_bias ? 1 : 0);
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t key_bytes = up((size_t)n_rows * 8), col_bytes = up((size_t)n_rows * sizeof(T)), idx_bytes = up((size_t)n_rows * 4);
+    // ---- keys on the device, and are they already in order?
+    const int64_t* d_keys = keys;
+    if (space == PDS_HOST) {
+        if (int rc = ensure_ws(ctx, ctx->stage, key_bytes + 256)) return rc;
+        PDS_HIP_CHECK(hipMemcpyAsync(ctx->stage.ptr, keys, (size_t)n_rows * 8, hipMemcpyHostToDevice, ctx->stream));
+        d_keys = static_cast<const int64_t*>(ctx->stage.ptr);
+    }
+    if (int rc = ensure_pinned(ctx, 4096)) return rc;
+    if (int rc = ensure_ws(ctx, ctx->solve_ws, 4096)) return rc;  // a flag word that outlives the workspace sizing below
+    bool sorted = false;
+    if (int rc = keys_nondecreasing(ctx, d_keys, n_rows, static_cast<unsigned*>(ctx->solve_ws.ptr), &sorted)) return rc;
+    // ---- workspace: [raw columns (host frames)] [sorted keys, index in/out, gathered columns (unsorted frames)] runs, temp
+    const int64_t cap = std::min<int64_t>(max_groups, n_rows);
+    const size_t temp_bytes = keyed_temp_bytes(n_rows);
+    size_t need = temp_bytes + 3 * up((size_t)(n_rows + 1) * 8) + 4096;  // unique keys, counts, offsets (at most one per row)
+    if (space == PDS_HOST) need += col_bytes * nc + up((size_t)cap * pp * sizeof(T)) + up((size_t)cap);
+    if (!sorted) need += key_bytes + 2 * idx_bytes + col_bytes * nc;
+    if (int rc = ensure_ws(ctx, ctx->keyed, need)) return rc;
+    char* w = static_cast<char*>(ctx->keyed.ptr);
+    auto take = [&](size_t b) { char* r = w; w += up(b); return r; };
+    void* d_temp = take(temp_bytes);
+    int64_t* d_unique = reinterpret_cast<int64_t*>(take((size_t)(n_rows + 1) * 8));
+    int64_t* d_counts = reinterpret_cast<int64_t*>(take((size_t)(n_rows + 1) * 8));
+    int64_t* d_offsets = reinterpret_cast<int64_t*>(take((size_t)(n_rows + 1) * 8));
+    int64_t* d_nruns = reinterpret_cast<int64_t*>(take(256));
+    std::vector<const T*> src(nc);  // reference order [y, x1..xp], device resident
+    for (int c = 0; c < nc; ++c) src[c] = cols[c];
+    if (space == PDS_HOST)
+        for (int c = 0; c < nc; ++c) {
+            T* d = reinterpret_cast<T*>(take((size_t)n_rows * sizeof(T)));
+            PDS_HIP_CHECK(hipMemcpyAsync(d, cols[c], (size_t)n_rows * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+            src[c] = d;
+        }
+    const int64_t* d_sorted_keys = d_keys;
+    if (!sorted) {
+        int64_t* sk = reinterpret_cast<int64_t*>(take((size_t)n_rows * 8));
+        uint32_t* idx_in = reinterpret_cast<uint32_t*>(take((size_t)n_rows * 4));
+        uint32_t* perm = reinterpret_cast<uint32_t*>(take((size_t)n_rows * 4));
+        if (int rc = keyed_sort(ctx, d_keys, n_rows, idx_in, sk, perm, d_temp, temp_bytes)) return rc;
+        d_sorted_keys = sk;
+        for (int c = 0; c < nc; ++c) {
+            T* d = reinterpret_cast<T*>(take((size_t)n_rows * sizeof(T)));
+            if (int rc = launch_gather_rows<T>(ctx, src[c], perm, n_rows, d)) return rc;
+            src[c] = d;
+        }
+    }
+    int64_t ng = 0;
+    if (int rc = keyed_runs(ctx, d_sorted_keys, n_rows, d_unique, d_counts, d_offsets, d_nruns, d_temp, temp_bytes, &ng)) return rc;
+    *n_groups = ng;
+    if (ng > max_groups) return fail(PDS_ERR_INVALID, "more distinct keys than max_groups");
+    T* d_co = coeffs;
+    uint8_t* d_nu = is_null;
+    if (space == PDS_HOST) {
+        d_co = reinterpret_cast<T*>(take((size_t)cap * pp * sizeof(T)));
+        d_nu = reinterpret_cast<uint8_t*>(take((size_t)cap));
+    }
+    if (int rc = grouped_impl<T>(ctx, src.data(), n_feat, n_rows, d_offsets, ng, PDS_DEVICE, prm, d_co, d_nu)) return rc;
+    if (space == PDS_HOST) {
+        PDS_HIP_CHECK(hipMemcpyAsync(coeffs, d_co, (size_t)ng * pp * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+        if (is_null) PDS_HIP_CHECK(hipMemcpyAsync(is_null, d_nu, (size_t)ng, hipMemcpyDeviceToHost, ctx->stream));
+        PDS_HIP_CHECK(hipMemcpyAsync(out_keys, d_unique, (size_t)ng * 8, hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        PDS_HIP_CHECK(hipMemcpyAsync(out_keys, d_unique, (size_t)ng * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PDS_OK;
+}
+
 template <typename T>
 static int rolling_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t n_rows, pds_space space, int add_bias,
                         int64_t window, int64_t min_size, double lambda, bool expanding, T* coeffs, T* pred,
@@ -1039,6 +1123,7 @@ void pds_ctx_destroy(pds_ctx* ctx) {
     if (ctx->ws.ptr) hipFree(ctx->ws.ptr);
     if (ctx->stage.ptr) hipFree(ctx->stage.ptr);
     if (ctx->solve_ws.ptr) hipFree(ctx->solve_ws.ptr);
+    if (ctx->keyed.ptr) hipFree(ctx->keyed.ptr);
     if (ctx->pinned) hipHostFree(ctx->pinned);
     if (ctx->pinned_in) hipHostFree(ctx->pinned_in);
     for (auto& e : ctx->ev_pending) {
@@ -1224,6 +1309,17 @@ int pds_lr_grouped_nullable_f32(pds_ctx* ctx, const float* const* cols, const ui
                                 float* coeffs, uint8_t* is_null) {
     return grouped_impl<float>(ctx, cols, n_feat, n_rows, group_offsets, n_groups, space, prm, coeffs, is_null, true, validity,
                                bit_offsets, null_policy, fill_value);
+}
+
+int pds_lr_by_key_f64(pds_ctx* ctx, const double* const* cols, const int64_t* keys, int n_feat, int64_t n_rows, pds_space space,
+                      const pds_lr_params* prm, int64_t max_groups, int64_t* out_keys, double* coeffs, uint8_t* is_null,
+                      int64_t* n_groups) {
+    return pds::lr_by_key_impl<double>(ctx, cols, keys, n_feat, n_rows, space, prm, max_groups, out_keys, coeffs, is_null, n_groups);
+}
+int pds_lr_by_key_f32(pds_ctx* ctx, const float* const* cols, const int64_t* keys, int n_feat, int64_t n_rows, pds_space space,
+                      const pds_lr_params* prm, int64_t max_groups, int64_t* out_keys, float* coeffs, uint8_t* is_null,
+                      int64_t* n_groups) {
+    return pds::lr_by_key_impl<float>(ctx, cols, keys, n_feat, n_rows, space, prm, max_groups, out_keys, coeffs, is_null, n_groups);
 }
 
 int pds_rolling_lr_f64(pds_ctx* ctx, const double* const* cols, int n_feat, int64_t n_rows, pds_space space,

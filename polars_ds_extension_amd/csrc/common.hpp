@@ -83,6 +83,7 @@ struct pds_ctx {
     size_t ws_used = 0;
     pds::Workspace stage;    // HBM staging of PDS_HOST column buffers
     pds::Workspace solve_ws; // factor workspace of the p' > 64 solver (solve_big.hip)
+    pds::Workspace keyed;    // pds_lr_by_key_*: staged / sorted keys, permutation, gathered columns, run-length results
     void* pinned = nullptr;  // pinned host scratch (small results, pointer arrays)
     size_t pinned_bytes = 0;
     void* pinned_in = nullptr;  // pinned staging of small PDS_HOST frames: all columns + pointer table, ONE H2D copy
@@ -225,6 +226,16 @@ int launch_rolling_wide(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64
                         int64_t min_size, double lambda, bool expanding, const double* seed_moments, T* d_coeffs, T* d_pred,
                         uint8_t* d_valid);
 size_t rolling_wide_workspace(int n_feat, int64_t n_rows, size_t elem);
+
+// ---- keyed.hip: int64 keys in any row order -> sorted keys, permutation, distinct keys, group offsets
+int keys_nondecreasing(pds_ctx* ctx, const int64_t* d_keys, int64_t n, unsigned* d_flag, bool* sorted);
+size_t keyed_temp_bytes(int64_t n);
+int keyed_sort(pds_ctx* ctx, const int64_t* d_keys, int64_t n, uint32_t* d_idx_in, int64_t* d_sorted_keys, uint32_t* d_perm,
+               void* d_temp, size_t temp_bytes);
+int keyed_runs(pds_ctx* ctx, const int64_t* d_sorted_keys, int64_t n, int64_t* d_unique, int64_t* d_counts, int64_t* d_offsets,
+               int64_t* d_nruns, void* d_temp, size_t temp_bytes, int64_t* n_groups);
+template <typename T>
+int launch_gather_rows(pds_ctx* ctx, const T* d_src, const uint32_t* d_perm, int64_t n, T* d_dst);
 
 // ---- stats.cpp ----
 double student_t_sf(double x, double df, bool* err);

@@ -1,0 +1,97 @@
+// keyed.hip -- from an int64 key column in ANY row order to the contiguous-group form the grouped kernels take:
+// what Polars' `group_by(key)` does on the host before it calls `pl_lr` once per group (the reference's call pattern,
+// tests/test_linear_exprs.py:435-474, 918-953), done on the device for the key-aware symbol `pl_lr_by`.
+//   1. one pass decides whether the keys are already non-decreasing (a frame sorted by its key needs no data movement);
+//   2. otherwise a radix sort of (key, row index) pairs (hipCUB; stable, so rows keep their order inside a group) and a
+//      gather of every column through the permutation -- the only part that moves the frame (8-byte reads at random
+//      rows: one 64-byte sector per element, a scan of the frame at 1/8 efficiency);
+//   3. run-length encoding of the sorted keys gives the distinct keys and the group sizes, an exclusive sum the offsets.
+// Groups come out in ascending key order.
+#include <hipcub/hipcub.hpp>
+
+#include "common.hpp"
+
+namespace pds {
+
+__global__ __launch_bounds__(256) void key_descent_kernel(const int64_t* __restrict__ keys, int64_t n, unsigned* __restrict__ flag) {
+    bool found = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        found = found || keys[i] < keys[i - 1];
+    if (__any(found) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
+__global__ __launch_bounds__(256) void iota_u32_kernel(uint32_t* __restrict__ idx, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) idx[i] = (uint32_t)i;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ src, const uint32_t* __restrict__ perm, int64_t n,
+                                                          T* __restrict__ dst) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = src[perm[i]];
+}
+
+__global__ void close_offsets_kernel(int64_t* __restrict__ off, const int64_t* __restrict__ n_runs, int64_t n) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) off[*n_runs] = n;
+}
+
+static inline size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+int keys_nondecreasing(pds_ctx* ctx, const int64_t* d_keys, int64_t n, unsigned* d_flag, bool* sorted) {
+    PDS_HIP_CHECK(hipMemsetAsync(d_flag, 0, sizeof(unsigned), ctx->stream));
+    const int nb = (int)std::min<int64_t>(std::max<int64_t>((n + 255) / 256, 1), (int64_t)ctx->num_cus * 8);
+    hipLaunchKernelGGL(key_descent_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_keys, n, d_flag);
+    unsigned h = 0;
+    PDS_HIP_CHECK(hipMemcpyAsync(&h, d_flag, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    *sorted = h == 0;
+    return PDS_OK;
+}
+
+// temp bytes of the sort + run-length + scan stages for n rows
+size_t keyed_temp_bytes(int64_t n) {
+    size_t a = 0, b = 0, c = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, (const int64_t*)nullptr, (int64_t*)nullptr, (const uint32_t*)nullptr,
+                                             (uint32_t*)nullptr, (int)std::min<int64_t>(n, INT32_MAX));
+    (void)hipcub::DeviceRunLengthEncode::Encode(nullptr, b, (const int64_t*)nullptr, (int64_t*)nullptr, (int64_t*)nullptr,
+                                                (int64_t*)nullptr, (int)std::min<int64_t>(n, INT32_MAX));
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, c, (const int64_t*)nullptr, (int64_t*)nullptr, (int)std::min<int64_t>(n, INT32_MAX));
+    return up256(std::max(a, std::max(b, c))) + 256;
+}
+
+// (key, row) radix sort: d_sorted_keys / d_perm out; d_idx_in is scratch of n uint32
+int keyed_sort(pds_ctx* ctx, const int64_t* d_keys, int64_t n, uint32_t* d_idx_in, int64_t* d_sorted_keys, uint32_t* d_perm,
+               void* d_temp, size_t temp_bytes) {
+    const int nb = (int)std::min<int64_t>(std::max<int64_t>((n + 255) / 256, 1), (int64_t)ctx->num_cus * 16);
+    hipLaunchKernelGGL(iota_u32_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_idx_in, n);
+    PDS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, d_keys, d_sorted_keys, (const uint32_t*)d_idx_in, d_perm, (int)n,
+                                                     0, 64, ctx->stream));
+    return PDS_OK;
+}
+
+// sorted keys -> distinct keys, offsets (n_groups + 1 entries), n_groups (host)
+int keyed_runs(pds_ctx* ctx, const int64_t* d_sorted_keys, int64_t n, int64_t* d_unique, int64_t* d_counts, int64_t* d_offsets,
+               int64_t* d_nruns, void* d_temp, size_t temp_bytes, int64_t* n_groups) {
+    PDS_HIP_CHECK(hipcub::DeviceRunLengthEncode::Encode(d_temp, temp_bytes, d_sorted_keys, d_unique, d_counts, d_nruns, (int)n, ctx->stream));
+    int64_t g = 0;
+    PDS_HIP_CHECK(hipMemcpyAsync(&g, d_nruns, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    PDS_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(d_temp, temp_bytes, (const int64_t*)d_counts, d_offsets, (int)g, ctx->stream));
+    hipLaunchKernelGGL(close_offsets_kernel, dim3(1), dim3(64), 0, ctx->stream, d_offsets, d_nruns, n);
+    PDS_HIP_CHECK(hipGetLastError());
+    *n_groups = g;
+    return PDS_OK;
+}
+
+template <typename T>
+int launch_gather_rows(pds_ctx* ctx, const T* d_src, const uint32_t* d_perm, int64_t n, T* d_dst) {
+    const int nb = (int)std::min<int64_t>(std::max<int64_t>((n + 255) / 256, 1), (int64_t)ctx->num_cus * 32);
+    hipLaunchKernelGGL((gather_rows_kernel<T>), dim3(nb), dim3(256), 0, ctx->stream, d_src, d_perm, n, d_dst);
+    PDS_HIP_CHECK(hipGetLastError());
+    return PDS_OK;
+}
+
+template int launch_gather_rows<double>(pds_ctx*, const double*, const uint32_t*, int64_t, double*);
+template int launch_gather_rows<float>(pds_ctx*, const float*, const uint32_t*, int64_t, float*);
+
+}  // namespace pds

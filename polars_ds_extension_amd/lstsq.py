@@ -478,6 +478,47 @@ def lin_reg_by(*x, target, group_offsets, add_bias: bool = False, l1_reg: float 
     return coeffs, nulls
 
 
+def lin_reg_by_key(*x, target, key, add_bias: bool = False, l1_reg: float = 0.0, l2_reg: float = 0.0, tol: float = 1e-5,
+                   solver: str = "qr", max_iter: int = 200, positive: bool = False, singular_x_tol: float | None = None,
+                   max_groups: int | None = None, ctx: Context | None = None):
+    """
+    `df.group_by(key).agg(pds.lin_reg(...))` for an integer key column in ANY row order: the frame is brought into key
+    order on the device (radix sort of (key, row) pairs + column gather; nothing moves when the keys are already
+    non-decreasing), then every group is fitted as in `lin_reg_by`.
+    Returns (keys [n_groups] ascending, coeffs [n_groups, p'], is_null [n_groups]) in the memory space of the inputs.
+    """
+    if max_iter <= 0:
+        raise ValueError("Input `max_iter` must be a positive.")  # expr_linear.py:231-232
+    ctx = ctx or default_context()
+    cols = _Cols(target, x)
+    _follow(ctx, cols)
+    prm = _params(add_bias, l1_reg, l2_reg, tol, solver, positive, max_iter, singular_x_tol)
+    pp = cols.n_feat + int(bool(add_bias))
+    cap = int(cols.n_rows if max_groups is None else max_groups)
+    if cols.space == _lib.PDS_DEVICE:
+        import torch
+
+        k = key if _is_torch(key) else torch.as_tensor(np.asarray(key))
+        k = k.to(device=cols.keep[0].device, dtype=torch.int64).contiguous()
+        k_p = C.c_void_p(int(k.data_ptr()))
+        ok = torch.empty(cap, dtype=torch.int64, device=k.device)
+        ok_p = C.c_void_p(int(ok.data_ptr()))
+    else:
+        k = np.ascontiguousarray(np.asarray(key), dtype=np.int64)
+        k_p = C.c_void_p(k.ctypes.data)
+        ok = np.empty(cap, dtype=np.int64)
+        ok_p = C.c_void_p(ok.ctypes.data)
+    if int(k.shape[0]) != cols.n_rows:
+        raise ValueError("`key` must have one entry per row")
+    coeffs, co_p = _out_like(cols, (cap, pp))
+    nulls, nu_p = _out_u8(cols, cap)
+    ng = C.c_int64(0)
+    _lib.check(ctx.fn("pds_lr_by_key")(ctx._h, cols.cols, k_p, cols.n_feat, C.c_int64(cols.n_rows), cols.space, C.byref(prm),
+                                       C.c_int64(cap), ok_p, co_p, nu_p, C.byref(ng)))
+    g = int(ng.value)
+    return ok[:g], coeffs[:g], nulls[:g]
+
+
 def _windowed(name, x, target, n, add_bias, l2_reg, min_size, ctx, seed_moments=None):
     ctx = ctx or default_context()
     cols = _Cols(target, x)

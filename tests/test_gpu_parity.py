@@ -336,6 +336,39 @@ def test_grouped_more_than_64_features(pds, orc, p, bias):
                 assert nrel(co[g], bo) < 1e-8
 
 
+@pytest.mark.parametrize("p,bias", [(3, True), (16, False)])
+def test_grouped_by_key_any_row_order(pds, orc, p, bias):
+    """group_by(key) on an unsorted key column: radix sort of (key, row) + gather on the device, then the grouped kernel."""
+    rng = np.random.default_rng(700 + p)
+    G = 700
+    keys_distinct = rng.choice(np.arange(-5000, 5000), size=G, replace=False).astype(np.int64)
+    sizes = rng.integers(p + 5, 120, size=G)
+    key = np.repeat(keys_distinct, sizes)
+    N = len(key)
+    X = rng.normal(size=(N, p))
+    beta_of = {int(k): rng.normal(size=p) for k in keys_distinct}
+    y = np.array([X[i] @ beta_of[int(key[i])] for i in range(N)]) + 0.05 * rng.normal(size=N) + (0.3 if bias else 0.0)
+    perm = rng.permutation(N)  # rows in random order
+    Xs, ys, ks = X[perm], y[perm], key[perm]
+    # reference: the same groups, contiguous (the order of rows inside a group does not matter to a regression)
+    order = np.argsort(key, kind="stable")
+    ko, off = np.unique(key[order], return_index=True)
+    off = np.append(off, N).astype(np.int64)
+    co_o, nu_o = orc.grouped_lr([y[order]] + [X[order][:, j] for j in range(p)], off, add_bias=bias, nthreads=4)
+    for space in ("device", "host"):
+        if space == "device":
+            k_out, co, nu = pds.lin_reg_by_key(*cols_of(Xs), target=dev(ys), key=dev(ks), add_bias=bias)
+            k_out, co, nu = k_out.cpu().numpy(), co.cpu().numpy(), nu.cpu().numpy()
+        else:
+            k_out, co, nu = pds.lin_reg_by_key(*[np.ascontiguousarray(Xs[:, j]) for j in range(p)], target=ys, key=ks, add_bias=bias)
+        assert np.array_equal(k_out, ko) and np.array_equal(nu.astype(bool), nu_o)
+        assert np.max(np.linalg.norm(co - co_o, axis=1) / np.linalg.norm(co_o, axis=1)) < 1e-9
+    # keys already in order: no data movement, identical results
+    k2, co2, nu2 = pds.lin_reg_by_key(*cols_of(X[order]), target=dev(y[order]), key=dev(key[order]), add_bias=bias)
+    assert np.array_equal(k2.cpu().numpy(), ko)
+    assert np.max(np.linalg.norm(co2.cpu().numpy() - co_o, axis=1) / np.linalg.norm(co_o, axis=1)) < 1e-9
+
+
 # ------------------------------------------------------------------------------------------ rolling / recursive
 def test_rolling_golden_notebook(pds, golden):
     for part in ("rolling_w5_head", "rolling_w5_tail"):

@@ -231,6 +231,33 @@ def test_pl_lr_by_matches_per_group_calls(so, orc):
 
 
 @pytest.mark.gpu
+def test_pl_lr_by_keys_in_any_row_order(so, orc):
+    # group_by(key) does not need a sorted frame: shuffled rows give the same per-key coefficients, keys ascending
+    rng = np.random.default_rng(3)
+    G, per = 150, 30
+    key = np.repeat(rng.permutation(G) * 2 - 50, per)
+    X = rng.normal(size=(G * per, 3))
+    y = X @ [0.5, -1.5, 2.0] + 0.2 * rng.normal(size=G * per) + key * 0.01
+    perm = rng.permutation(G * per)
+    _, out = ph.call_plugin(so, "pl_lr_by", [("key", pa.array(key[perm]))] + _cols(X[perm], y[perm]), dict(LR, bias=True))
+    res = out.to_pylist()
+    assert [r["key"] for r in res] == sorted(set(key.tolist()))
+    for r in res[::17]:
+        m = key == r["key"]
+        np.testing.assert_allclose(r["coeffs"], orc.pl_lr(X[m], y[m], add_bias=True), rtol=1e-9, atol=1e-11)
+    # with nulls (null_policy = skip) the rows are ordered on the host and take the bitmap-aware entry point
+    mask = rng.random(G * per) < 0.05
+    ins = [("key", pa.array(key[perm])), ("y", pa.array(y[perm])), ("x1", pa.array(X[perm][:, 0], mask=mask[perm]))] + [
+        (f"x{j + 1}", pa.array(X[perm][:, j])) for j in (1, 2)]
+    _, out = ph.call_plugin(so, "pl_lr_by", ins, dict(LR, bias=True, null_policy="skip"))
+    res = out.to_pylist()
+    assert [r["key"] for r in res] == sorted(set(key.tolist()))
+    for r in res[::23]:
+        m = (key == r["key"]) & ~mask
+        np.testing.assert_allclose(r["coeffs"], orc.pl_lr(X[m], y[m], add_bias=True), rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.gpu
 def test_pl_lr_multi_and_rcond(so, orc):
     # tests/test_linear_exprs.py:1069-1113: struct fields named after the (aliased) targets; :477-512 rcond
     rng = np.random.default_rng(4)
