@@ -2,7 +2,7 @@
 Secondary measurements quoted in DESIGN.md (not the driver's bench line): the other BASELINE configs on one
 MI355X, inputs resident in HBM, kernel time from the library's HIP-event hooks, plus a bounded CPU sample of
 the oracle where it is the reference's own algorithm (rolling: sequential Woodbury, single thread).
-Usage: python tools/bench_extra.py [rolling] [report] [single] [host]
+Usage: python tools/bench_extra.py [rolling] [report] [single] [host] [en] [keyed]
 """
 import json, sys, time
 from pathlib import Path
@@ -11,7 +11,7 @@ import numpy as np
 import torch
 import polars_ds_extension_amd as pds
 
-which = set(sys.argv[1:]) or {"rolling", "report", "single", "host", "en"}
+which = set(sys.argv[1:]) or {"rolling", "report", "single", "host", "en", "keyed"}
 dev = torch.device("cuda", 0)
 ctx = pds.Context(0)
 ctx.set_stream(torch.cuda.current_stream(dev))
@@ -97,4 +97,24 @@ if "en" in which:
                              "gram_TFLOPs_upper_triangle": round(flops / 2 / (gms * 1e-3) / 1e12, 1),
                              "cd_ms": round(t.get("iterative", (0, 0))[0], 3), "nonzero": int((abs(b) > 1e-6).sum())}
     pds.config.LIN_REG_EXPR_F64 = True
+if "keyed" in which:
+    # configs[2] with the rows in random order (SURVEY 8d "shuffled variant"): group_by on an unsorted key column
+    G, R, p = 1_000_000, 100, 8
+    n = G * R
+    for a in list(globals()):
+        if a in ("xs", "y", "co", "pr", "va"): del globals()[a]
+    torch.cuda.empty_cache()
+    xs = [torch.randn(n, dtype=torch.float64, device=dev, generator=gen) for _ in range(p)]
+    y = sum(xs[j] * (0.1 * (j + 1)) for j in range(p)) + 0.1 * torch.randn(n, dtype=torch.float64, device=dev, generator=gen)
+    key_sorted = torch.arange(n, dtype=torch.int64, device=dev) // R
+    key_shuf = key_sorted[torch.randperm(n, device=dev, generator=gen)]
+    res = {}
+    for name, key in (("sorted_keys", key_sorted), ("shuffled_rows", key_shuf)):
+        torch.cuda.synchronize(); f = lambda: pds.lin_reg_by_key(*xs, target=y, key=key, ctx=ctx)
+        f(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(3): k, co, nu = f()
+        torch.cuda.synchronize(); res[name] = round((time.perf_counter() - t0) / 3 * 1e3, 2)
+    out["grouped_by_key_1e6x100x8"] = {"wall_ms": res, "groups": int(k.shape[0]),
+                                       "note": "wall time of pds_lr_by_key_f64, frame resident in HBM: order check + run-length encoding "
+                                               "(+ radix sort of (key,row) and the gather of 9 columns when the rows are shuffled) + fused grouped kernel"}
 print(json.dumps(out, indent=1))
