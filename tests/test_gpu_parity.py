@@ -582,6 +582,48 @@ def test_rolling_skip_non_finite(pds, orc):
         assert nrel(co[i], direct) < 1e-9
 
 
+def test_new_paths_f32(pds, orc, f32):
+    """f32 twins of the coverage paths: wide rolling, keyed grouping, grouped lasso, grouped > 64 features, HC3 beyond 16."""
+    rng = np.random.default_rng(77)
+    n, p, w = 3000, 20, 200
+    X = rng.random((n, p)).astype(np.float32)
+    y = (X @ rng.normal(size=p) + 0.3 + 0.05 * rng.normal(size=n)).astype(np.float32)
+    co, pr, va = pds.rolling_lin_reg(*cols_of(X), target=dev(y), window_size=w, add_bias=True)
+    co = co.cpu().numpy()
+    assert co.dtype == np.float32 and va.cpu().numpy()[w - 1 :].all()
+    Xb = np.c_[X.astype(np.float64), np.ones(n)]
+    for i in (w - 1, 1500, n - 1):
+        direct = np.linalg.lstsq(Xb[i - w + 1 : i + 1], y[i - w + 1 : i + 1].astype(np.float64), rcond=None)[0]
+        assert nrel(co[i], direct) < 5e-3  # f32 normal equations of a 21-column window
+    # keyed grouping, shuffled rows
+    G, per, q = 300, 60, 4
+    key = np.repeat(np.arange(G) * 7 - 100, per)
+    Xg = rng.normal(size=(G * per, q)).astype(np.float32)
+    yg = (Xg @ rng.normal(size=q) + 0.1 * rng.normal(size=G * per)).astype(np.float32)
+    perm = rng.permutation(G * per)
+    k, cg, nu = pds.lin_reg_by_key(*cols_of(Xg[perm]), target=dev(yg[perm]), key=dev(key[perm]))
+    assert np.array_equal(k.cpu().numpy(), np.arange(G) * 7 - 100) and not nu.cpu().numpy().any()
+    cg = cg.cpu().numpy()
+    for g in (0, 123, G - 1):
+        m = key == g * 7 - 100
+        assert nrel(cg[g], np.linalg.lstsq(Xg[m].astype(np.float64), yg[m].astype(np.float64), rcond=None)[0]) < F32_TOL * 10
+    # grouped lasso
+    off = np.arange(0, G * per + 1, per)
+    cl, _ = pds.lin_reg_by(*cols_of(Xg), target=dev(yg), group_offsets=off, l1_reg=0.01, tol=1e-7)
+    bo = orc.pl_lr(Xg[:per].astype(np.float64), yg[:per].astype(np.float64), l1_reg=0.01, tol=1e-10, max_iter=2000)
+    assert nrel(cl.cpu().numpy()[0], bo) < 1e-3
+    # grouped with more than 64 features, HC3 with more than 16
+    pw = 70
+    Xw = rng.normal(size=(900, pw)).astype(np.float32)
+    yw = (Xw @ rng.normal(size=pw) + 0.1 * rng.normal(size=900)).astype(np.float32)
+    cw, nw = pds.lin_reg_by(*cols_of(Xw), target=dev(yw), group_offsets=np.array([0, 400, 900]))
+    assert not nw.cpu().numpy().any()
+    assert nrel(cw.cpu().numpy()[1], np.linalg.lstsq(Xw[400:].astype(np.float64), yw[400:].astype(np.float64), rcond=None)[0]) < 1e-3
+    r = pds.lin_reg_report(*cols_of(Xw[:, :20]), target=dev(yw), std_err="hc3")
+    ro = orc.lin_reg_report(Xw[:, :20].astype(np.float64), yw.astype(np.float64), std_err="hc3")
+    assert frel(r["hc3_se"], ro["std_err"], 1e-9) < 2e-3
+
+
 # ------------------------------------------------------------------------------------------ f32 twin
 def test_f32_path(pds, orc, f32):
     rng = np.random.default_rng(21)
