@@ -357,7 +357,9 @@ static int lr_impl(pds_ctx* ctx, const T* const* cols, const T* weights, int n_f
     if (int rc = launch_moments<T>(ctx, dc, n_feat, n_rows, weights != nullptr, d_mom)) return rc;
     T* d_coeffs = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * (pp + 2)));
     int null_flag = 0;
-    if (int rc = lr_from_device_moments<T>(ctx, d_mom, n_feat, prm, weights != nullptr, coeffs, &null_flag, d_coeffs))
+    // (a device copy of the coefficients is only kept for the residual pass: without it they come back with the null
+    //  flag in one copy)
+    if (int rc = lr_from_device_moments<T>(ctx, d_mom, n_feat, prm, weights != nullptr, coeffs, &null_flag, want_pred ? d_coeffs : nullptr))
         return rc;
     if (is_null) *is_null = null_flag;
     if (want_pred) {
@@ -437,7 +439,7 @@ static int lr_nullable_impl(pds_ctx* ctx, const T* const* cols, const uint8_t* c
     if (int rc = launch_moments<T>(ctx, dk, n_feat, prep.n_kept, false, d_mom)) return rc;
     T* d_coeffs = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * (pp + 2)));
     int null_flag = 0;
-    if (int rc = lr_from_device_moments<T>(ctx, d_mom, n_feat, prm, false, coeffs, &null_flag, d_coeffs)) return rc;
+    if (int rc = lr_from_device_moments<T>(ctx, d_mom, n_feat, prm, false, coeffs, &null_flag, want_pred ? d_coeffs : nullptr)) return rc;
     if (is_null) *is_null = null_flag;
     if (want_pred) {
         T* c_pred = reinterpret_cast<T*>(ws_take(ctx, (size_t)prep.n_kept * sizeof(T)));
@@ -848,12 +850,24 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
     const int64_t* d_off = offsets;
     T* d_coeffs = coeffs;
     uint8_t* d_null = is_null;
+    // small host batches (the plugin layer's coalesced per-group calls): offsets go up through pinned memory, coefficients
+    // and null flags come back in ONE copy -- every pageable hipMemcpyAsync is 5-10 us of a ~60 us call
+    const size_t co_bytes = ((size_t)n_groups * pp * sizeof(T) + 255) & ~(size_t)255;
+    const bool small_out = space == PDS_HOST && co_bytes + (size_t)n_groups + (size_t)(n_groups + 1) * 8 <= ((size_t)48 << 10);
     if (space == PDS_HOST) {
         int64_t* t = reinterpret_cast<int64_t*>(ws_take(ctx, (size_t)(n_groups + 1) * 8));
-        PDS_HIP_CHECK(hipMemcpyAsync(t, offsets, (size_t)(n_groups + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        if (small_out) {
+            if (int rc = ensure_pinned(ctx, (size_t)128 << 10)) return rc;
+            char* pin_off = static_cast<char*>(ctx->pinned) + ((size_t)64 << 10);
+            std::memcpy(pin_off, offsets, (size_t)(n_groups + 1) * 8);
+            PDS_HIP_CHECK(hipMemcpyAsync(t, pin_off, (size_t)(n_groups + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        } else {
+            PDS_HIP_CHECK(hipMemcpyAsync(t, offsets, (size_t)(n_groups + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        }
         d_off = t;
-        d_coeffs = reinterpret_cast<T*>(ws_take(ctx, (size_t)n_groups * pp * sizeof(T)));
-        d_null = reinterpret_cast<uint8_t*>(ws_take(ctx, (size_t)n_groups));
+        char* blk = reinterpret_cast<char*>(ws_take(ctx, co_bytes + (size_t)n_groups));
+        d_coeffs = reinterpret_cast<T*>(blk);
+        d_null = reinterpret_cast<uint8_t*>(blk + co_bytes);
     } else if (!d_null) {
         d_null = reinterpret_cast<uint8_t*>(ws_take(ctx, (size_t)n_groups));
     }
@@ -935,6 +949,14 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
             if (int rc = launch_grouped_moments<T>(ctx, dc, n_feat, d_off + g0, gc, d_mom)) return rc;
             if (int rc = launch_solve<T>(ctx, d_mom, gc, sp, d_coeffs + g0 * pp, d_null + g0, nullptr, d_off + g0)) return rc;
         }
+    }
+    if (small_out) {
+        char* pin = static_cast<char*>(ctx->pinned);
+        PDS_HIP_CHECK(hipMemcpyAsync(pin, d_coeffs, co_bytes + (size_t)n_groups, hipMemcpyDeviceToHost, ctx->stream));
+        PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        std::memcpy(coeffs, pin, (size_t)n_groups * pp * sizeof(T));
+        if (is_null) std::memcpy(is_null, pin + co_bytes, (size_t)n_groups);
+        return PDS_OK;
     }
     if (space == PDS_HOST) {
         PDS_HIP_CHECK(hipMemcpyAsync(coeffs, d_coeffs, (size_t)n_groups * pp * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));

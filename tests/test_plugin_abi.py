@@ -258,6 +258,50 @@ def test_pl_lr_by_keys_in_any_row_order(so, orc):
 
 
 @pytest.mark.gpu
+def test_concurrent_pl_lr_calls_are_coalesced(so, orc):
+    """group_by().agg(pds.lin_reg(...)) unchanged: Polars' rayon threads call pl_lr once per group.  Calls that arrive while
+    a batch is on the device leave together as one grouped launch; every caller must get its own group's coefficients."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    rng = np.random.default_rng(12)
+    frames = []
+    for g in range(96):
+        n = int(rng.integers(20, 200))
+        X = rng.normal(size=(n, 3))
+        y = X @ rng.normal(size=3) + 0.5 + 0.1 * rng.normal(size=n)
+        frames.append((X, y))
+    frames[7] = (np.c_[frames[7][0][:, 0], 2.0 * frames[7][0][:, 0], frames[7][0][:, 2]], frames[7][1])  # collinear -> null list
+
+    def one(i):
+        X, y = frames[i]
+        _, out = ph.call_plugin(so, "pl_lr", _cols(X, y), dict(LR, bias=True))
+        return out[0].as_py()
+
+    with ThreadPoolExecutor(max_workers=16) as ex:
+        res = list(ex.map(one, range(len(frames)))) + list(ex.map(one, range(len(frames))))
+    for i, r in enumerate(res):
+        X, y = frames[i % len(frames)]
+        bo = orc.pl_lr(X, y, add_bias=True)
+        if bo is None:
+            assert r is None
+        else:
+            np.testing.assert_allclose(r, bo, rtol=1e-9, atol=1e-11)
+    # the same through native threads (no GIL between the calls): results stable across repeats, requests accounted for
+    kw = pickle.dumps(dict(LR, bias=False), protocol=5)
+    buf = (C.c_uint8 * len(kw)).from_buffer_copy(kw)
+    sec, dev = C.c_double(), C.c_double()
+    so.pds_plugin_debug_coalesce_stats(None, None, None, 1)
+    fails = so.pds_plugin_debug_concurrent_lr(24, 40, 100, 8, buf, len(kw), C.byref(sec), C.byref(dev))
+    b, r, m = C.c_longlong(), C.c_longlong(), C.c_longlong()
+    so.pds_plugin_debug_coalesce_stats(C.byref(b), C.byref(r), C.byref(m), 0)
+    assert fails == 0 and dev.value < 1e-12
+    assert r.value == 24 * 40 and 1 <= b.value <= r.value and m.value <= 24
+    # errors stay per call: too few rows raises for that caller only
+    with pytest.raises(ph.PluginFailure, match="#Data < #features"):
+        ph.call_plugin(so, "pl_lr", _cols(frames[0][0][:2], frames[0][1][:2]), dict(LR, bias=True))
+
+
+@pytest.mark.gpu
 def test_pl_lr_multi_and_rcond(so, orc):
     # tests/test_linear_exprs.py:1069-1113: struct fields named after the (aliased) targets; :477-512 rcond
     rng = np.random.default_rng(4)
