@@ -102,7 +102,7 @@ def main() -> int:
     t0 = time.perf_counter()
     for _ in range(args.steps):
         coeffs, nulls = step()
-    torch.cuda.synchronize(dev)
+    barrier()
     elapsed = time.perf_counter() - t0
     ctx.set_timing(False)
     timing = ctx.get_timing(reset=True)
