@@ -27,14 +27,16 @@ struct V16<float> {
 
 constexpr int kP2Threads = 256;
 
-template <typename T, bool WEIGHTED, int HC>
-__global__ __launch_bounds__(kP2Threads) void pass2_kernel(const T* const* __restrict__ cols, int p, int bias,
+// P16: exactly 16 features, known at compile time (the per-column `c < p` scalar branches in the row loop fold away)
+template <typename T, bool WEIGHTED, int HC, bool P16>
+__global__ __launch_bounds__(kP2Threads) void pass2_kernel(const T* const* __restrict__ cols, int p_arg, int bias,
                                                            int64_t n, const T* __restrict__ beta,
                                                            const T* __restrict__ inv, T* __restrict__ pred_out,
                                                            T* __restrict__ resid_out, T* __restrict__ s_out,
                                                            double* __restrict__ partials) {
     using V = typename V16<T>::type;
     constexpr int RPL = V16<T>::RPL;
+    const int p = P16 ? 16 : p_arg;
     const int pp = p + bias;
     double sse = 0.0, wsse = 0.0;
     // loop-invariant, wave-uniform: column pointers and coefficients live in SGPRs
@@ -239,15 +241,21 @@ __global__ __launch_bounds__(kP2Threads) void leverage_scale_wide_kernel(const T
     }
 }
 
+template <typename T, bool W, bool P16>
+static void launch_p2_w(int hc, dim3 g, hipStream_t st, const T* const* cols, int p, int bias, int64_t n, const T* beta,
+                        const T* inv, T* pred, T* resid, T* s, double* partials) {
+    switch (hc) {
+        case 0: hipLaunchKernelGGL((pass2_kernel<T, W, 0, P16>), g, dim3(kP2Threads), 0, st, cols, p, bias, n, beta, inv, pred, resid, s, partials); break;
+        case 1: hipLaunchKernelGGL((pass2_kernel<T, W, 1, P16>), g, dim3(kP2Threads), 0, st, cols, p, bias, n, beta, inv, pred, resid, s, partials); break;
+        case 2: hipLaunchKernelGGL((pass2_kernel<T, W, 2, P16>), g, dim3(kP2Threads), 0, st, cols, p, bias, n, beta, inv, pred, resid, s, partials); break;
+        default: hipLaunchKernelGGL((pass2_kernel<T, W, 3, P16>), g, dim3(kP2Threads), 0, st, cols, p, bias, n, beta, inv, pred, resid, s, partials); break;
+    }
+}
 template <typename T, bool W>
 static void launch_p2(int hc, dim3 g, hipStream_t st, const T* const* cols, int p, int bias, int64_t n, const T* beta,
                       const T* inv, T* pred, T* resid, T* s, double* partials) {
-    switch (hc) {
-        case 0: hipLaunchKernelGGL((pass2_kernel<T, W, 0>), g, dim3(kP2Threads), 0, st, cols, p, bias, n, beta, inv, pred, resid, s, partials); break;
-        case 1: hipLaunchKernelGGL((pass2_kernel<T, W, 1>), g, dim3(kP2Threads), 0, st, cols, p, bias, n, beta, inv, pred, resid, s, partials); break;
-        case 2: hipLaunchKernelGGL((pass2_kernel<T, W, 2>), g, dim3(kP2Threads), 0, st, cols, p, bias, n, beta, inv, pred, resid, s, partials); break;
-        default: hipLaunchKernelGGL((pass2_kernel<T, W, 3>), g, dim3(kP2Threads), 0, st, cols, p, bias, n, beta, inv, pred, resid, s, partials); break;
-    }
+    if (p == 16) launch_p2_w<T, W, true>(hc, g, st, cols, p, bias, n, beta, inv, pred, resid, s, partials);
+    else launch_p2_w<T, W, false>(hc, g, st, cols, p, bias, n, beta, inv, pred, resid, s, partials);
 }
 
 // d_meat: when hc_mode != 0 the caller passes a device buffer of n_rows T values in d_meat (reused as
