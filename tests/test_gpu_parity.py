@@ -563,6 +563,27 @@ def test_rolling_recursive_13_to_64_coefficients(pds, orc, p, bias, w):
             assert nrel(co4[i], direct) < 1e-8
 
 
+def test_rolling_wide_many_chunks(pds):
+    """rolling_wide.hip streams its per-row moment records in chunks sized for the Infinity Cache: cross the chunk borders."""
+    rng = np.random.default_rng(5)
+    n, p, w = 13_000, 63, 150  # 65^2 doubles per row -> ~5.9k rows per chunk
+    X = rng.random((n, p))
+    y = X @ rng.normal(size=p) + 0.2 + 0.05 * rng.normal(size=n)
+    Xb = np.c_[X, np.ones(n)]
+    co, pr, va = pds.rolling_lin_reg(*cols_of(X), target=dev(y), window_size=w, add_bias=True)
+    co, va = co.cpu().numpy(), va.cpu().numpy().astype(bool)
+    assert va[w - 1 :].all() and not va[: w - 1].any()
+    for i in (w - 1, 5887, 5888, 5889, 6100, 11775, 11776, 11777, n - 1):
+        direct = np.linalg.lstsq(Xb[i - w + 1 : i + 1], y[i - w + 1 : i + 1], rcond=None)[0]
+        assert nrel(co[i], direct) < 1e-7
+        assert abs(float(pr[i]) - Xb[i] @ direct) < 1e-7
+    co2, _, va2 = pds.recursive_lin_reg(*cols_of(X), target=dev(y), start_with=200, add_bias=True)
+    co2 = co2.cpu().numpy()
+    for i in (199, 5888, 11776, n - 1):
+        direct = np.linalg.lstsq(Xb[: i + 1], y[: i + 1], rcond=None)[0]
+        assert nrel(co2[i], direct) < 1e-7
+
+
 def test_rolling_skip_non_finite(pds, orc):
     rng = np.random.default_rng(9)
     n = 3000
