@@ -25,6 +25,9 @@ namespace pds {
 
 #define RSYNC() PDS_WAVE_LDS_SYNC()
 
+#ifndef PDS_ROLL_WPE
+#define PDS_ROLL_WPE 2
+#endif
 constexpr int kTileRows = 4096;   // rows per wave tile (64 steps of 64 rows)
 constexpr int kRollWaves = 2;     // waves per block
 constexpr int kLdsStride = 65;    // doubles per moment row in LDS
@@ -284,7 +287,7 @@ __device__ __forceinline__ void rolling_body(const T* const* __restrict__ cols, 
 // p' <= 8 is compiled for two waves per SIMD (248 VGPRs, no spills): with the moments passing through LDS in halves
 // the CU then holds 8 waves.  p' >= 10 would spill at that budget (measured 2x slower) and keeps one wave per SIMD.
 template <typename T, int PP, int MODE, bool FULLP>
-__global__ __launch_bounds__(kRollWaves * 64) __attribute__((amdgpu_waves_per_eu(2))) void rolling_kernel(
+__global__ __launch_bounds__(kRollWaves * 64) __attribute__((amdgpu_waves_per_eu(PDS_ROLL_WPE))) void rolling_kernel(
     const T* const* __restrict__ cols, RollArgs ra, double* __restrict__ tile_tot, T* __restrict__ coeffs, T* __restrict__ pred,
     uint8_t* __restrict__ valid) {
     rolling_body<T, PP, MODE, FULLP>(cols, ra, tile_tot, coeffs, pred, valid);
@@ -356,7 +359,9 @@ static int launch_pp_f(pds_ctx* ctx, const DeviceCols<T>& dc, RollArgs ra, bool 
     ra.tile_rows = kTileRows;
     const int64_t ntiles = (ra.n + ra.tile_rows - 1) / ra.tile_rows;
     int64_t nb = (ntiles + kRollWaves - 1) / kRollWaves;
-    nb = std::min<int64_t>(std::max<int64_t>(nb, 1), (int64_t)ctx->num_cus * 4);
+    int per_cu = 2 * PDS_ROLL_WPE;  // blocks of kRollWaves waves: PDS_ROLL_WPE waves per SIMD
+    if (const char* e = std::getenv("PDS_ROLL_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e));
+    nb = std::min<int64_t>(std::max<int64_t>(nb, 1), (int64_t)ctx->num_cus * per_cu);
     auto kern0 = roll_kernel_ptr<T, PP, 0, FULLP>();
     auto kern1 = roll_kernel_ptr<T, PP, 1, FULLP>();
     auto kern2 = roll_kernel_ptr<T, PP, 2, FULLP>();
