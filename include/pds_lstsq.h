@@ -244,6 +244,19 @@ int pds_lr_grouped_nullable_f32(pds_ctx* ctx, const float* const* cols, const ui
                                 float fill_value, const pds_lr_params* prm, float* coeffs, uint8_t* is_null);
 
 /*
+ * pds_lr_grouped_weighted_*: `group_by(key).agg(pds.lin_reg(..., weights=w))` -- per group faer_weighted_lr
+ * (lr_solvers.rs:386-409: X'WX, X'Wy, plain solve with `solver`; no gate, no penalties, as pl_lr :436-446).  The frame is
+ * scaled by sqrt(w) once on the device and takes the grouped path.  weights: n_rows values, `space`-resident; the other
+ * arguments as pds_lr_grouped_*.
+ */
+int pds_lr_grouped_weighted_f64(pds_ctx* ctx, const double* const* cols, const double* weights, int n_feat, int64_t n_rows,
+                                const int64_t* group_offsets, int64_t n_groups, pds_space space, const pds_lr_params* prm,
+                                double* coeffs, uint8_t* is_null);
+int pds_lr_grouped_weighted_f32(pds_ctx* ctx, const float* const* cols, const float* weights, int n_feat, int64_t n_rows,
+                                const int64_t* group_offsets, int64_t n_groups, pds_space space, const pds_lr_params* prm,
+                                float* coeffs, uint8_t* is_null);
+
+/*
  * pds_lr_by_key_*: `df.group_by(key).agg(pds.lin_reg(...))` for an int64 key column in ANY row order -- the grouping
  * Polars does on the host before it calls `pl_lr` per group (tests/test_linear_exprs.py:435-474), done on the device:
  * keys already non-decreasing -> no data movement; otherwise a radix sort of (key, row) pairs and a gather of the columns.

@@ -967,6 +967,75 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
 }
 
 // ---------------------------------------------------------------------------------------------
+// weighted groups: per group faer_weighted_lr (lr_solvers.rs:386-409) -- X' W X = (sqrt(W) X)' (sqrt(W) X), so the frame
+// is scaled once on the device (the bias becomes an explicit sqrt(w) column) and takes the unweighted, ungated grouped path
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+static int grouped_weighted_impl(pds_ctx* ctx, const T* const* cols, const T* weights, int n_feat, int64_t n_rows,
+                                 const int64_t* offsets, int64_t n_groups, pds_space space, const pds_lr_params* prm, T* coeffs,
+                                 uint8_t* is_null) {
+    if (!ctx || !cols || !weights || !offsets || !prm || !coeffs) return fail(PDS_ERR_INVALID, "null argument");
+    if (n_feat < 1) return fail(PDS_ERR_INVALID, "need at least one feature column");
+    if (n_groups <= 0 || n_rows <= 0) return fail(PDS_ERR_EMPTY, "Empty data");
+    PDS_HIP_CHECK(hipSetDevice(ctx->device));
+    const int bias = prm->add_bias ? 1 : 0, pf = n_feat + bias, nc_in = n_feat + 1;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t col_bytes = up((size_t)n_rows * sizeof(T));
+    size_t need = col_bytes * (pf + 1) + 4096;
+    if (space == PDS_HOST) need += col_bytes * (nc_in + 1) + up((size_t)(n_groups + 1) * 8) + up((size_t)n_groups * pf * sizeof(T)) + up((size_t)n_groups);
+    if (int rc = ensure_ws(ctx, ctx->keyed, need)) return rc;
+    char* w = static_cast<char*>(ctx->keyed.ptr);
+    auto take = [&](size_t b) { char* r = w; w += up(b); return r; };
+    std::vector<const T*> src(nc_in);
+    const T* d_w = weights;
+    const int64_t* d_off = offsets;
+    T* d_co = coeffs;
+    uint8_t* d_nu = is_null;
+    if (space == PDS_HOST) {
+        for (int c = 0; c < nc_in; ++c) {
+            T* d = reinterpret_cast<T*>(take((size_t)n_rows * sizeof(T)));
+            PDS_HIP_CHECK(hipMemcpyAsync(d, cols[c], (size_t)n_rows * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+            src[c] = d;
+        }
+        T* dw = reinterpret_cast<T*>(take((size_t)n_rows * sizeof(T)));
+        PDS_HIP_CHECK(hipMemcpyAsync(dw, weights, (size_t)n_rows * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+        d_w = dw;
+        int64_t* doff = reinterpret_cast<int64_t*>(take((size_t)(n_groups + 1) * 8));
+        PDS_HIP_CHECK(hipMemcpyAsync(doff, offsets, (size_t)(n_groups + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        d_off = doff;
+        d_co = reinterpret_cast<T*>(take((size_t)n_groups * pf * sizeof(T)));
+        d_nu = reinterpret_cast<uint8_t*>(take((size_t)n_groups));
+    } else {
+        for (int c = 0; c < nc_in; ++c) src[c] = cols[c];
+    }
+    // scaled frame in reference order [y, x1..xp, (sqrt w)]
+    std::vector<const T*> scaled(pf + 1);
+    for (int c = 0; c < nc_in; ++c) {
+        T* d = reinterpret_cast<T*>(take((size_t)n_rows * sizeof(T)));
+        if (int rc = launch_scale_sqrt_w<T>(ctx, src[c], d_w, n_rows, d)) return rc;
+        scaled[c] = d;
+    }
+    if (bias) {
+        T* d = reinterpret_cast<T*>(take((size_t)n_rows * sizeof(T)));
+        if (int rc = launch_scale_sqrt_w<T>(ctx, (const T*)nullptr, d_w, n_rows, d)) return rc;
+        scaled[nc_in] = d;
+    }
+    pds_lr_params p2 = *prm;  // faer_weighted_lr: plain solve with `solver`, no gate, no penalties
+    p2.add_bias = 0;
+    p2.l1_reg = 0.0;
+    p2.l2_reg = 0.0;
+    p2.positive = 0;
+    p2.singular_x_tol = 0.0;
+    if (int rc = grouped_impl<T>(ctx, scaled.data(), pf, n_rows, d_off, n_groups, PDS_DEVICE, &p2, d_co, d_nu)) return rc;
+    if (space == PDS_HOST) {
+        PDS_HIP_CHECK(hipMemcpyAsync(coeffs, d_co, (size_t)n_groups * pf * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+        if (is_null) PDS_HIP_CHECK(hipMemcpyAsync(is_null, d_nu, (size_t)n_groups, hipMemcpyDeviceToHost, ctx->stream));
+        PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    return PDS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // grouped by an int64 key column in any row order (keyed.hip brings the frame into key order on the device)
 // ---------------------------------------------------------------------------------------------
 template <typename T>
@@ -1331,6 +1400,17 @@ int pds_lr_grouped_nullable_f32(pds_ctx* ctx, const float* const* cols, const ui
                                 float* coeffs, uint8_t* is_null) {
     return grouped_impl<float>(ctx, cols, n_feat, n_rows, group_offsets, n_groups, space, prm, coeffs, is_null, true, validity,
                                bit_offsets, null_policy, fill_value);
+}
+
+int pds_lr_grouped_weighted_f64(pds_ctx* ctx, const double* const* cols, const double* weights, int n_feat, int64_t n_rows,
+                                const int64_t* group_offsets, int64_t n_groups, pds_space space, const pds_lr_params* prm,
+                                double* coeffs, uint8_t* is_null) {
+    return pds::grouped_weighted_impl<double>(ctx, cols, weights, n_feat, n_rows, group_offsets, n_groups, space, prm, coeffs, is_null);
+}
+int pds_lr_grouped_weighted_f32(pds_ctx* ctx, const float* const* cols, const float* weights, int n_feat, int64_t n_rows,
+                                const int64_t* group_offsets, int64_t n_groups, pds_space space, const pds_lr_params* prm,
+                                float* coeffs, uint8_t* is_null) {
+    return pds::grouped_weighted_impl<float>(ctx, cols, weights, n_feat, n_rows, group_offsets, n_groups, space, prm, coeffs, is_null);
 }
 
 int pds_lr_by_key_f64(pds_ctx* ctx, const double* const* cols, const int64_t* keys, int n_feat, int64_t n_rows, pds_space space,

@@ -236,6 +236,8 @@ int keyed_runs(pds_ctx* ctx, const int64_t* d_sorted_keys, int64_t n, int64_t* d
                int64_t* d_nruns, void* d_temp, size_t temp_bytes, int64_t* n_groups);
 template <typename T>
 int launch_gather_rows(pds_ctx* ctx, const T* d_src, const uint32_t* d_perm, int64_t n, T* d_dst);
+template <typename T>
+int launch_scale_sqrt_w(pds_ctx* ctx, const T* d_src /*nullable: ones*/, const T* d_w, int64_t n, T* d_dst);
 
 // ---- stats.cpp ----
 double student_t_sf(double x, double df, bool* err);

@@ -91,6 +91,25 @@ int launch_gather_rows(pds_ctx* ctx, const T* d_src, const uint32_t* d_perm, int
     return PDS_OK;
 }
 
+// weighted groups: x_c * sqrt(w) (and sqrt(w) itself as the bias column) turn X' W X into a plain Gram matrix
+template <typename T>
+__global__ __launch_bounds__(256) void scale_sqrt_w_kernel(const T* __restrict__ src /*nullable: the ones column*/,
+                                                           const T* __restrict__ w, int64_t n, T* __restrict__ dst) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const T s = (T)sqrt((double)w[i]);
+        dst[i] = src ? src[i] * s : s;
+    }
+}
+template <typename T>
+int launch_scale_sqrt_w(pds_ctx* ctx, const T* d_src, const T* d_w, int64_t n, T* d_dst) {
+    const int nb = (int)std::min<int64_t>(std::max<int64_t>((n + 255) / 256, 1), (int64_t)ctx->num_cus * 32);
+    hipLaunchKernelGGL((scale_sqrt_w_kernel<T>), dim3(nb), dim3(256), 0, ctx->stream, d_src, d_w, n, d_dst);
+    PDS_HIP_CHECK(hipGetLastError());
+    return PDS_OK;
+}
+template int launch_scale_sqrt_w<double>(pds_ctx*, const double*, const double*, int64_t, double*);
+template int launch_scale_sqrt_w<float>(pds_ctx*, const float*, const float*, int64_t, float*);
+
 template int launch_gather_rows<double>(pds_ctx*, const double*, const uint32_t*, int64_t, double*);
 template int launch_gather_rows<float>(pds_ctx*, const float*, const uint32_t*, int64_t, float*);
 

@@ -422,7 +422,7 @@ def _report_dict(outs, rep, n_feat, add_bias, std_err, weighted, feature_names, 
 
 def lin_reg_by(*x, target, group_offsets, add_bias: bool = False, l1_reg: float = 0.0, l2_reg: float = 0.0,
                tol: float = 1e-5, solver: str = "qr", max_iter: int = 200, positive: bool = False,
-               singular_x_tol: float | None = None, null_policy: str = "skip", ctx: Context | None = None):
+               singular_x_tol: float | None = None, null_policy: str = "skip", weights=None, ctx: Context | None = None):
     """
     The key-aware batched form of `df.group_by(key).agg(pds.lin_reg(...))` (SURVEY.md 8b "pl_lr_by").
     Rows of a group are contiguous; group g = rows [group_offsets[g], group_offsets[g+1]).
@@ -430,10 +430,31 @@ def lin_reg_by(*x, target, group_offsets, add_bias: bool = False, l1_reg: float 
     pyarrow columns may carry nulls; `null_policy` then applies inside every group, as it does when Polars calls pl_lr
     once per group.  `l1_reg` / `l2_reg` / `positive` select the method per group exactly as `lin_reg` does
     (lasso / elastic net / non-negative fits run the reference's coordinate descent on every group's Gram matrix).
+    `weights`: per-group weighted least squares (faer_weighted_lr: no gate, no penalties, like `lin_reg(weights=...)`).
     """
     if max_iter <= 0:
         raise ValueError("Input `max_iter` must be a positive.")  # expr_linear.py:231-232
     ctx = ctx or default_context()
+    if weights is not None:
+        cols = _Cols(target, x, weights)
+        _follow(ctx, cols)
+        prm = _params(add_bias, 0.0, 0.0, tol, solver, False, max_iter, 0.0)
+        pp = cols.n_feat + int(bool(add_bias))
+        if cols.space == _lib.PDS_DEVICE:
+            import torch
+
+            off = group_offsets if _is_torch(group_offsets) else torch.as_tensor(np.asarray(group_offsets))
+            off = off.to(device=cols.keep[0].device, dtype=torch.int64).contiguous()
+            off_p = C.c_void_p(int(off.data_ptr()))
+        else:
+            off = np.ascontiguousarray(np.asarray(group_offsets), dtype=np.int64)
+            off_p = C.c_void_p(off.ctypes.data)
+        ng = int(off.shape[0]) - 1
+        coeffs, co_p = _out_like(cols, (ng, pp))
+        nulls, nu_p = _out_u8(cols, ng)
+        _lib.check(ctx.fn("pds_lr_grouped_weighted")(ctx._h, cols.cols, cols.weights, cols.n_feat, C.c_int64(cols.n_rows), off_p,
+                                                     C.c_int64(ng), cols.space, C.byref(prm), co_p, nu_p))
+        return coeffs, nulls
     code, fill = parse_null_policy(null_policy)
     if any(_is_arrow(c) for c in (target, *x)):
         dt = _dtype()

@@ -63,8 +63,8 @@ def lin_reg(*x, target, add_bias: bool = False, weights=None, return_pred: bool 
     dt = _dtype()
     cols = ([_formula(weights).cast(dt).rechunk()] if weighted else []) + [_formula(target).cast(dt)] + [_formula(z) for z in x]
     if by is not None:  # one call computes every group: Struct{key, coeffs}, one row per (contiguous) group
-        if weighted or return_pred:
-            raise ValueError("`by` supports coefficient output of unweighted fits")
+        if return_pred:
+            raise ValueError("`by` returns coefficients (one row per group)")
         return _plugin("pl_lr_by", [_formula(by), *cols], kwargs, changes_length=True).alias("coeffs_by")
     if return_pred:
         return _plugin("pl_lr_pred", cols, kwargs).alias("lr_pred")

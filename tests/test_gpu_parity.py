@@ -369,6 +369,33 @@ def test_grouped_by_key_any_row_order(pds, orc, p, bias):
     assert np.max(np.linalg.norm(co2.cpu().numpy() - co_o, axis=1) / np.linalg.norm(co_o, axis=1)) < 1e-9
 
 
+@pytest.mark.parametrize("p,bias", [(4, True), (15, True), (16, False), (20, True)])
+def test_grouped_weighted(pds, orc, p, bias):
+    """group_by(key).agg(pds.lin_reg(..., weights=w)): per group faer_weighted_lr (lr_solvers.rs:386-409)."""
+    rng = np.random.default_rng(900 + p)
+    G = 200
+    sizes = rng.integers(p + 8, 150, size=G)
+    sizes[::37] = rng.integers(0, p + 1, size=len(sizes[::37]))
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    N = int(off[-1])
+    X = rng.normal(size=(N, p))
+    y = X @ rng.normal(size=p) + (0.4 if bias else 0.0) + 0.2 * rng.normal(size=N)
+    w = rng.random(N) + 0.1
+    pp = p + bias
+    for space in ("device", "host"):
+        if space == "device":
+            co, nu = pds.lin_reg_by(*cols_of(X), target=dev(y), group_offsets=off, add_bias=bias, weights=dev(w))
+            co, nu = co.cpu().numpy(), nu.cpu().numpy().astype(bool)
+        else:
+            co, nu = pds.lin_reg_by(*[np.ascontiguousarray(X[:, j]) for j in range(p)], target=y, group_offsets=off, add_bias=bias,
+                                    weights=w)
+            nu = nu.astype(bool)
+        assert np.array_equal(nu, sizes < pp)
+        for g in np.flatnonzero(~nu)[::9]:
+            s = slice(off[g], off[g + 1])
+            assert nrel(co[g], orc.pl_lr(X[s], y[s], add_bias=bias, weights=w[s])) < 1e-9
+
+
 # ------------------------------------------------------------------------------------------ rolling / recursive
 def test_rolling_golden_notebook(pds, golden):
     for part in ("rolling_w5_head", "rolling_w5_tail"):

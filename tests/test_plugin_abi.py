@@ -245,6 +245,15 @@ def test_pl_lr_by_keys_in_any_row_order(so, orc):
     for r in res[::17]:
         m = key == r["key"]
         np.testing.assert_allclose(r["coeffs"], orc.pl_lr(X[m], y[m], add_bias=True), rtol=1e-9, atol=1e-11)
+    # weights: [key, w, y, x...] with kwargs.weighted -- per key the weighted fit of pl_lr
+    w = rng.random(G * per) + 0.2
+    ins_w = [("key", pa.array(key[perm])), ("w", pa.array(w[perm]))] + _cols(X[perm], y[perm])
+    _, out = ph.call_plugin(so, "pl_lr_by", ins_w, dict(LR, bias=True, weighted=True))
+    res_w = out.to_pylist()
+    assert [r["key"] for r in res_w] == sorted(set(key.tolist()))
+    for r in res_w[::19]:
+        m = key == r["key"]
+        np.testing.assert_allclose(r["coeffs"], orc.pl_lr(X[m], y[m], add_bias=True, weights=w[m]), rtol=1e-9, atol=1e-11)
     # with nulls (null_policy = skip) the rows are ordered on the host and take the bitmap-aware entry point
     mask = rng.random(G * per) < 0.05
     ins = [("key", pa.array(key[perm])), ("y", pa.array(y[perm])), ("x1", pa.array(X[perm][:, 0], mask=mask[perm]))] + [
