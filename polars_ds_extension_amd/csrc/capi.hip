@@ -941,7 +941,7 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
                                              d_null + g0, d_off + g0))
                 return rc;
         }
-    } else if (pp <= 16 && !want_piv && !(unfused_env && unfused_env[0] == '1') && n_groups < (1ll << 31)) {
+    } else if (n_feat <= 16 && !want_piv && !(unfused_env && unfused_env[0] == '1') && n_groups < (1ll << 31)) {
         if (int rc = launch_grouped_fused<T>(ctx, dc, n_feat, n_rows, d_off, n_groups, sp, d_coeffs, d_null)) return rc;
     } else {
         for (int64_t g0 = 0; g0 < n_groups; g0 += chunk) {

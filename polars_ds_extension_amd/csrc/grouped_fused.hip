@@ -232,8 +232,14 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
     const int lane = threadIdx.x & 63;
     char* wl = smem;
     double* Msc = reinterpret_cast<double*>(smem + kFTile);
-    const int p = FULLP ? LPS - (BIAS ? 1 : 0) : p_arg;
-    const int pp = FULLP ? LPS : sp.pp;
+    // BIAS: the intercept never takes a solver lane.  The group's normal equations are centred when they leave LDS
+    // (G_ij - s_i s_j / n, c_j - s_j sum(y) / n with the column sums s the kernel carries anyway), the p x p system is
+    // solved, and b0 = (sum(y) - s . beta) / n.  det([X 1]'[X 1]) = n det(Xc'Xc) and the diagonal products differ by the
+    // same n, so the reference's rank gate on the augmented matrix is the gate on the centred pivots over the UNcentred
+    // diagonal -- same accept / reject rule.  16 features + bias stay on this kernel, 8 + bias on the packed one.
+    const int p = FULLP ? LPS : p_arg;  // features = solver lanes in use
+    const int pp = p;                   // (solver size)
+    const int pout = p + (BIAS ? 1 : 0);
     const int sub = lane / LPS, j_in = lane % LPS;
 
     // ---- this wave's groups: balanced in rows
@@ -260,6 +266,7 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
     double a_p[NA];
     double b_p[CHOL ? 1 : LPS];
     double dj_p = 1.0;
+    double cs_p = 0.0, ys_p = 0.0, n_p = 1.0;  // BIAS: column sum of the lane's feature, sum(y), rows of the group
     bool null_p = false;
     int npend = 0;
     int64_t gbase = gl;  // group id of pending system 0
@@ -278,12 +285,18 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
         PDS_T0();
         if constexpr (CHOL) {
             SolveRegDev spk = sp;
-            if constexpr (FULLP) spk.pp = LPS;  // compile-time p': the per-step `K < p'` branches fold away
+            spk.pp = FULLP ? LPS : p;  // (compile-time under FULLP: the per-step `K < p'` branches fold away)
+            spk.p = spk.pp;
             chol_core<LPS>(a_p, dj_p, j, spk, is_null, zj);
         } else {
             solve_core<LPS>(a_p, b_p, dj_p, j, lane, sp, is_null, pj, zj);
         }
-        if (live && colv) coeffs[sys * (int64_t)pp + pj] = is_null ? (T)__builtin_nan("") : (T)zj;
+        if (live && colv) coeffs[sys * (int64_t)pout + pj] = is_null ? (T)__builtin_nan("") : (T)zj;
+        if constexpr (BIAS) {
+            const double sb = Grp<LPS>::sum(colv ? cs_p * zj : 0.0);
+            const double b0 = (ys_p - sb) / n_p;
+            if (live && j == 0) coeffs[sys * (int64_t)pout + p] = is_null ? (T)__builtin_nan("") : (T)b0;
+        }
         if (live && j == 0 && flags) flags[sys] = is_null ? 1 : 0;
         PDS_T1(3);
         gbase += npend;
@@ -308,7 +321,7 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
         // ---- normal equations of group g -> LDS scratch (full symmetric square, bias at 16, y at 17)
         PDS_T0();
         const uint64_t ng = (uint64_t)(ge - gs);
-        const bool too_few = (uint32_t)(ng >> 32) == 0u && (uint32_t)ng < (uint32_t)pp;
+        const bool too_few = (uint32_t)(ng >> 32) == 0u && (uint32_t)ng < (uint32_t)pout;
         {
             const int jj = lane & 15;
 #pragma unroll
@@ -351,8 +364,7 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
         }
         if (sp.lambda > 0.0) {  // ridge: lambda goes onto the diagonal while the matrix is still in LDS
             PDS_WAVE_LDS_SYNC();
-            if (lane < p) Msc[lane * (kFQ + 1)] += sp.lambda;
-            if (BIAS && sp.lambda_on_bias && lane == 16) Msc[16 * (kFQ + 1)] += sp.lambda;
+            if (lane < p) Msc[lane * (kFQ + 1)] += sp.lambda;  // (never on the intercept: lr_solvers.rs:199-208)
         }
         PDS_WAVE_LDS_SYNC();
         // ---- sub-group `npend` takes it into registers (solver layout: lane j = column j, a_p[i] = row i).
@@ -363,7 +375,7 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
         {
             int j = j_in;
             asm volatile("" : "+v"(j));
-            const int lj = (j < p) ? j : ((BIAS && j == p) ? 16 : ZSLOT);
+            const int lj = (j < p) ? j : ZSLOT;
             if (sub == npend) {
                 const double* colp = Msc + kFQ * lj;
                 if (p >= LPS) {  // every row is a feature: immediate offsets, the reads pair up into 16-byte loads
@@ -375,14 +387,29 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
                 } else {
 #pragma unroll
                     for (int i = 0; i < LPS; ++i) {
-                        const int li = (i < p) ? i : ((BIAS && i == p) ? 16 : ZSLOT);
+                        const int li = (i < p) ? i : ZSLOT;
                         a_p[i] = colp[li];
                         if constexpr (!CHOL) b_p[i] = Msc[li + kFQ * 17];
                     }
                 }
                 if constexpr (CHOL) a_p[LPS] = Msc[lj + kFQ * 17];
-                dj_p = (j < pp) ? colp[lj] : 1.0;
+                dj_p = (j < pp) ? colp[lj] : 1.0;  // the gate's denominators are the uncentred diagonal entries
                 null_p = too_few;  // per-group pl_lr raises "#Data < #features": reported as null
+                if constexpr (BIAS) {  // centre: rows beyond p read the zero slot's column sum (0)
+                    static_assert(CHOL, "the centred bias form exists for the Cholesky kernel");
+                    const double csj = Msc[lj + kFQ * 16];
+                    const double nn = (double)ng, sy = Msc[16 + kFQ * 17];
+                    const double m = csj / nn;  // mean of the lane's feature
+#pragma unroll
+                    for (int i = 0; i < LPS; ++i) {
+                        const int li = (p >= LPS || i < p) ? i : ZSLOT;
+                        a_p[i] = fma(-Msc[li + kFQ * 16], m, a_p[i]);
+                    }
+                    a_p[LPS] = fma(-sy, m, a_p[LPS]);
+                    cs_p = csj;
+                    ys_p = sy;
+                    n_p = nn;
+                }
             }
         }
         PDS_WAVE_LDS_SYNC();
@@ -486,7 +513,7 @@ static int launch_stream_lps(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, 
     // (the pivoted-QR variant of this kernel measured slower than the two-kernel pipeline and is not instantiated;
     //  callers route the ungated case to grouped_moments_kernel + solve_reg_kernel)
     if (!chol) return fail(PDS_ERR_INVALID, "internal: fused grouped kernel is Cholesky-only");
-    if (sd.bias && sd.pp == LPS)
+    if (sd.bias && n_feat == LPS)
         hipLaunchKernelGGL((grouped_stream_kernel<T, LPS, true, true, true>), dim3((unsigned)nb), dim3(64), lds, ctx->stream,
                            dc.d_ptrs, n_feat, d_offsets, n_groups, n_rows, sd, d_coeffs, d_flags);
     else if (sd.bias)
@@ -502,7 +529,7 @@ static int launch_stream_lps(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, 
     return PDS_OK;
 }
 
-// OLS / ridge, p' <= 16
+// OLS / ridge, p <= 16 features (+ intercept)
 template <typename T>
 int launch_grouped_fused(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, const int64_t* d_offsets,
                          int64_t n_groups, const SolveParams& sp, T* d_coeffs, uint8_t* d_flags) {
@@ -519,8 +546,9 @@ int launch_grouped_fused(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int6
     if (n_groups >= (1ll << 31)) return fail(PDS_ERR_INVALID, "internal: fused grouped kernel counts groups per wave in 32 bits");
     const char* piv = std::getenv("PDS_GROUPED_PIVOTED");
     const bool chol = sd.gate_on && !(piv && piv[0] == '1');
-    if (sd.pp <= 4) return launch_stream_lps<T, 4>(ctx, dc, n_feat, d_offsets, n_groups, n_rows, sd, chol, d_coeffs, d_flags);
-    if (sd.pp <= 8) return launch_stream_lps<T, 8>(ctx, dc, n_feat, d_offsets, n_groups, n_rows, sd, chol, d_coeffs, d_flags);
+    // (the intercept takes no solver lane: the kernel size follows the feature count)
+    if (sd.p <= 4) return launch_stream_lps<T, 4>(ctx, dc, n_feat, d_offsets, n_groups, n_rows, sd, chol, d_coeffs, d_flags);
+    if (sd.p <= 8) return launch_stream_lps<T, 8>(ctx, dc, n_feat, d_offsets, n_groups, n_rows, sd, chol, d_coeffs, d_flags);
     return launch_stream_lps<T, 16>(ctx, dc, n_feat, d_offsets, n_groups, n_rows, sd, chol, d_coeffs, d_flags);
 }
 
