@@ -1067,7 +1067,7 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
     const size_t temp_bytes = keyed_temp_bytes(n_rows);
     size_t need = temp_bytes + 3 * up((size_t)(n_rows + 1) * 8) + 4096;  // unique keys, counts, offsets (at most one per row)
     if (space == PDS_HOST) need += col_bytes * nc + up((size_t)cap * pp * sizeof(T)) + up((size_t)cap);
-    if (!sorted) need += key_bytes + 2 * idx_bytes + col_bytes * nc;
+    if (!sorted) need += 2 * key_bytes + 2 * idx_bytes + col_bytes * nc + 256;
     if (int rc = ensure_ws(ctx, ctx->keyed, need)) return rc;
     char* w = static_cast<char*>(ctx->keyed.ptr);
     auto take = [&](size_t b) { char* r = w; w += up(b); return r; };
@@ -1089,7 +1089,9 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
         int64_t* sk = reinterpret_cast<int64_t*>(take((size_t)n_rows * 8));
         uint32_t* idx_in = reinterpret_cast<uint32_t*>(take((size_t)n_rows * 4));
         uint32_t* perm = reinterpret_cast<uint32_t*>(take((size_t)n_rows * 4));
-        if (int rc = keyed_sort(ctx, d_keys, n_rows, idx_in, sk, perm, d_temp, temp_bytes)) return rc;
+        int64_t* sk2 = reinterpret_cast<int64_t*>(take((size_t)n_rows * 8));
+        int64_t* mm = reinterpret_cast<int64_t*>(take(256));
+        if (int rc = keyed_sort(ctx, d_keys, n_rows, idx_in, sk, perm, d_temp, temp_bytes, sk2, mm)) return rc;
         d_sorted_keys = sk;
         for (int c = 0; c < nc; ++c) {
             T* d = reinterpret_cast<T*>(take((size_t)n_rows * sizeof(T)));

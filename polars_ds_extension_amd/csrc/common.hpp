@@ -231,7 +231,7 @@ size_t rolling_wide_workspace(int n_feat, int64_t n_rows, size_t elem);
 int keys_nondecreasing(pds_ctx* ctx, const int64_t* d_keys, int64_t n, unsigned* d_flag, bool* sorted);
 size_t keyed_temp_bytes(int64_t n);
 int keyed_sort(pds_ctx* ctx, const int64_t* d_keys, int64_t n, uint32_t* d_idx_in, int64_t* d_sorted_keys, uint32_t* d_perm,
-               void* d_temp, size_t temp_bytes);
+               void* d_temp, size_t temp_bytes, int64_t* d_scratch_keys, int64_t* d_minmax);
 int keyed_runs(pds_ctx* ctx, const int64_t* d_sorted_keys, int64_t n, int64_t* d_unique, int64_t* d_counts, int64_t* d_offsets,
                int64_t* d_nruns, void* d_temp, size_t temp_bytes, int64_t* n_groups);
 template <typename T>

@@ -56,16 +56,41 @@ size_t keyed_temp_bytes(int64_t n) {
     (void)hipcub::DeviceRunLengthEncode::Encode(nullptr, b, (const int64_t*)nullptr, (int64_t*)nullptr, (int64_t*)nullptr,
                                                 (int64_t*)nullptr, (int)std::min<int64_t>(n, INT32_MAX));
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, c, (const int64_t*)nullptr, (int64_t*)nullptr, (int)std::min<int64_t>(n, INT32_MAX));
-    return up256(std::max(a, std::max(b, c))) + 256;
+    size_t d = 0;
+    (void)hipcub::DeviceReduce::Min(nullptr, d, (const int64_t*)nullptr, (int64_t*)nullptr, (int)std::min<int64_t>(n, INT32_MAX));
+    return up256(std::max(std::max(a, d), std::max(b, c))) + 256;
 }
 
-// (key, row) radix sort: d_sorted_keys / d_perm out; d_idx_in is scratch of n uint32
+// key - min as an unsigned number, and back: the radix sort then only walks the bits the key range needs
+__global__ __launch_bounds__(256) void rebase_keys_kernel(const int64_t* __restrict__ in, int64_t n, const int64_t* __restrict__ kmin,
+                                                          int sign, int64_t* __restrict__ out) {
+    const uint64_t base = (uint64_t)*kmin;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (int64_t)(sign > 0 ? (uint64_t)in[i] - base : (uint64_t)in[i] + base);
+}
+
+// (key, row) radix sort: d_sorted_keys / d_perm out; d_idx_in is scratch of n uint32; d_scratch_keys n int64; d_minmax 2 int64
 int keyed_sort(pds_ctx* ctx, const int64_t* d_keys, int64_t n, uint32_t* d_idx_in, int64_t* d_sorted_keys, uint32_t* d_perm,
-               void* d_temp, size_t temp_bytes) {
+               void* d_temp, size_t temp_bytes, int64_t* d_scratch_keys, int64_t* d_minmax) {
     const int nb = (int)std::min<int64_t>(std::max<int64_t>((n + 255) / 256, 1), (int64_t)ctx->num_cus * 16);
     hipLaunchKernelGGL(iota_u32_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_idx_in, n);
-    PDS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, d_keys, d_sorted_keys, (const uint32_t*)d_idx_in, d_perm, (int)n,
-                                                     0, 64, ctx->stream));
+    // key range -> number of significant bits of (key - min): a million groups sort in 3 radix passes instead of 8
+    PDS_HIP_CHECK(hipcub::DeviceReduce::Min(d_temp, temp_bytes, d_keys, d_minmax, (int)n, ctx->stream));
+    PDS_HIP_CHECK(hipcub::DeviceReduce::Max(d_temp, temp_bytes, d_keys, d_minmax + 1, (int)n, ctx->stream));
+    int64_t mm[2] = {0, 0};
+    PDS_HIP_CHECK(hipMemcpyAsync(mm, d_minmax, sizeof(mm), hipMemcpyDeviceToHost, ctx->stream));
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const uint64_t range = (uint64_t)mm[1] - (uint64_t)mm[0];
+    int bits = 1;
+    while (bits < 64 && (range >> bits) != 0) ++bits;
+    hipLaunchKernelGGL(rebase_keys_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_keys, n, d_minmax, 1, d_scratch_keys);
+    // (as unsigned numbers in [0, range]: the signed sort order of int64 agrees below bit 63, and bit 63 is only
+    //  walked when the range needs it, where the unsigned key type below sorts it correctly)
+    PDS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, reinterpret_cast<const uint64_t*>(d_scratch_keys),
+                                                     reinterpret_cast<uint64_t*>(d_sorted_keys), (const uint32_t*)d_idx_in, d_perm, (int)n,
+                                                     0, bits, ctx->stream));
+    hipLaunchKernelGGL(rebase_keys_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_sorted_keys, n, d_minmax, -1, d_sorted_keys);
+    PDS_HIP_CHECK(hipGetLastError());
     return PDS_OK;
 }
 

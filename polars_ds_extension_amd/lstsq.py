@@ -515,27 +515,38 @@ def lin_reg_by_key(*x, target, key, add_bias: bool = False, l1_reg: float = 0.0,
     _follow(ctx, cols)
     prm = _params(add_bias, l1_reg, l2_reg, tol, solver, positive, max_iter, singular_x_tol)
     pp = cols.n_feat + int(bool(add_bias))
-    cap = int(cols.n_rows if max_groups is None else max_groups)
+    # outputs are sized for max_groups distinct keys; without a hint start from n_rows / 16 (at least 2^20) and repeat with
+    # the exact count when there are more -- sizing for one key per row would allocate p' x n_rows coefficients
+    n_rows = cols.n_rows
+    cap = int(max_groups) if max_groups is not None else (n_rows if n_rows <= (1 << 20) else max(1 << 20, n_rows // 16))
     if cols.space == _lib.PDS_DEVICE:
         import torch
 
         k = key if _is_torch(key) else torch.as_tensor(np.asarray(key))
         k = k.to(device=cols.keep[0].device, dtype=torch.int64).contiguous()
         k_p = C.c_void_p(int(k.data_ptr()))
-        ok = torch.empty(cap, dtype=torch.int64, device=k.device)
-        ok_p = C.c_void_p(int(ok.data_ptr()))
     else:
         k = np.ascontiguousarray(np.asarray(key), dtype=np.int64)
         k_p = C.c_void_p(k.ctypes.data)
-        ok = np.empty(cap, dtype=np.int64)
-        ok_p = C.c_void_p(ok.ctypes.data)
-    if int(k.shape[0]) != cols.n_rows:
+    if int(k.shape[0]) != n_rows:
         raise ValueError("`key` must have one entry per row")
-    coeffs, co_p = _out_like(cols, (cap, pp))
-    nulls, nu_p = _out_u8(cols, cap)
     ng = C.c_int64(0)
-    _lib.check(ctx.fn("pds_lr_by_key")(ctx._h, cols.cols, k_p, cols.n_feat, C.c_int64(cols.n_rows), cols.space, C.byref(prm),
-                                       C.c_int64(cap), ok_p, co_p, nu_p, C.byref(ng)))
+    while True:
+        if cols.space == _lib.PDS_DEVICE:
+            ok = torch.empty(cap, dtype=torch.int64, device=k.device)
+            ok_p = C.c_void_p(int(ok.data_ptr()))
+        else:
+            ok = np.empty(cap, dtype=np.int64)
+            ok_p = C.c_void_p(ok.ctypes.data)
+        coeffs, co_p = _out_like(cols, (cap, pp))
+        nulls, nu_p = _out_u8(cols, cap)
+        rc = ctx.fn("pds_lr_by_key")(ctx._h, cols.cols, k_p, cols.n_feat, C.c_int64(n_rows), cols.space, C.byref(prm),
+                                     C.c_int64(cap), ok_p, co_p, nu_p, C.byref(ng))
+        if rc != 0 and max_groups is None and int(ng.value) > cap:
+            cap = int(ng.value)  # more distinct keys than the first guess
+            continue
+        _lib.check(rc)
+        break
     g = int(ng.value)
     return ok[:g], coeffs[:g], nulls[:g]
 

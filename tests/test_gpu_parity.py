@@ -396,6 +396,20 @@ def test_grouped_weighted(pds, orc, p, bias):
             assert nrel(co[g], orc.pl_lr(X[s], y[s], add_bias=bias, weights=w[s])) < 1e-9
 
 
+def test_grouped_by_key_more_groups_than_first_guess(pds):
+    """lin_reg_by_key sizes its outputs for n_rows / 16 keys and repeats with the exact count when there are more."""
+    n = (1 << 21) + 12_345
+    rng = np.random.default_rng(1)
+    key = rng.permutation(n).astype(np.int64) // 2  # ~1.05e6 + distinct keys, two rows each, shuffled
+    x = rng.normal(size=n)
+    y = 3.0 * x
+    k, co, nu = pds.lin_reg_by_key(dev(x), target=dev(y), key=dev(key))
+    k, co, nu = k.cpu().numpy(), co.cpu().numpy(), nu.cpu().numpy().astype(bool)
+    assert len(k) == (n + 1) // 2 and np.array_equal(k, np.arange(len(k)))
+    ok = ~nu
+    assert ok.sum() > len(k) - 2 and np.allclose(co[ok, 0], 3.0, rtol=1e-9)
+
+
 # ------------------------------------------------------------------------------------------ rolling / recursive
 def test_rolling_golden_notebook(pds, golden):
     for part in ("rolling_w5_head", "rolling_w5_tail"):
