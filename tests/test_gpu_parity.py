@@ -236,7 +236,7 @@ def test_report_y_var_from_moments(pds):
 
 # ------------------------------------------------------------------------------------------ grouped
 @pytest.mark.parametrize("p,bias", [(1, False), (2, False), (3, True), (4, True), (5, False), (7, False), (7, True), (8, False),
-                                    (8, True), (9, False), (15, True), (16, False)])
+                                    (8, True), (9, False), (15, True), (16, False), (16, True), (4, False)])
 def test_grouped(pds, orc, p, bias):
     rng = np.random.default_rng(100 + p)
     G = 3000
@@ -800,6 +800,20 @@ def test_full_size_grouped_noise_free(pds):
     assert int(nu.sum().item()) == 0
     err = (co - bg).norm(dim=1) / bg.norm(dim=1)
     assert float(err.max().item()) < 1e-11
+    # with an intercept (centred form): y + group-specific constant => same slopes, the constant as the last coefficient
+    cg = torch.randn(G, dtype=torch.float64, device="cuda", generator=g)
+    y.add_(cg.repeat_interleave(R))
+    co, nu = pds.lin_reg_by(*xs, target=y, group_offsets=off, add_bias=True)
+    assert int(nu.sum().item()) == 0 and co.shape[1] == p + 1
+    assert float(((co[:, :p] - bg).norm(dim=1) / bg.norm(dim=1)).max().item()) < 1e-10
+    assert float((co[:, p] - cg).abs().max().item()) < 1e-10
+    # ragged groups on the same frame: sizes 1 .. 300 (mean ~ 100), slopes of a group are still exact
+    gen = np.random.default_rng(3)
+    sizes = gen.integers(1, 300, size=G)
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    offs = offs[offs <= n]
+    co, nu = pds.lin_reg_by(*xs, target=y, group_offsets=torch.as_tensor(offs, device="cuda"), add_bias=False, singular_x_tol=1e-12)
+    assert co.shape[0] == len(offs) - 1 and bool(torch.isfinite(co[~nu.bool()]).all())
 
 
 # ------------------------------------------------------------------------------------------ p > 16: tiled-SYRK Gram build
