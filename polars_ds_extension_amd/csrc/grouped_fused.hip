@@ -324,24 +324,44 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
         const bool too_few = (uint32_t)(ng >> 32) == 0u && (uint32_t)ng < (uint32_t)pout;
         {
             const int jj = lane & 15;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Msc[Tile<T>::drow(lane, r) + kFQ * jj] = acc.d[r];
-            const double xy = xor_sum_q(acc.xy);
-            if (lane < 16) Msc[lane + kFQ * 17] = xy;
-            if constexpr (BIAS) {
-                const double cs = xor_sum_q(acc.cs), ys = xor_sum_q(acc.ys);
-                if (lane < 16) {
-                    Msc[lane + kFQ * 16] = cs;
-                    Msc[16 + kFQ * lane] = cs;
+            // packed kernels, f64: the second slab's diagonal block sits in the same row slot eight lanes to the right
+            // (D[i + 8][j + 8]: register r + 2, lane + 8), so it is folded onto the first with a DPP row shift before
+            // anything goes to LDS (the fold through LDS was two more synchronisations per group)
+            constexpr bool RFOLD = PACK && sizeof(T) == 8;
+            auto shl8 = [](double v) __attribute__((always_inline)) {
+                int lo = __double2loint(v), hi = __double2hiint(v);
+                lo = __builtin_amdgcn_update_dpp(0, lo, 0x108 /*row_shl:8*/, 0xf, 0xf, true);
+                hi = __builtin_amdgcn_update_dpp(0, hi, 0x108, 0xf, 0xf, true);
+                return __hiloint2double(hi, lo);
+            };
+            if constexpr (RFOLD) {
+                const double d0 = acc.d[0] + shl8(acc.d[2]), d1 = acc.d[1] + shl8(acc.d[3]);
+                if (jj < 8) {
+                    Msc[Tile<T>::drow(lane, 0) + kFQ * jj] = d0;
+                    Msc[Tile<T>::drow(lane, 1) + kFQ * jj] = d1;
                 }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Msc[Tile<T>::drow(lane, r) + kFQ * jj] = acc.d[r];
+            }
+            double xy = xor_sum_q(acc.xy);
+            if constexpr (RFOLD) xy += shl8(xy);
+            if (lane < (RFOLD ? 8 : 16)) Msc[lane + kFQ * 17] = xy;
+            if constexpr (BIAS) {
+                double cs = xor_sum_q(acc.cs), ys = xor_sum_q(acc.ys);
+                if constexpr (RFOLD) {
+                    cs += shl8(cs);
+                    ys += shl8(ys);
+                }
+                if (lane < (RFOLD ? 8 : 16)) Msc[lane + kFQ * 16] = cs;
                 if (lane == 0) {
                     Msc[16 + kFQ * 16] = (double)ng;
                     Msc[16 + kFQ * 17] = ys;
                 }
-                if (PACK && lane == 8) Msc[17 + kFQ * 17] = ys;  // sum y over the second row slab
+                if (PACK && !RFOLD && lane == 8) Msc[17 + kFQ * 17] = ys;  // sum y over the second row slab
             }
         }
-        if constexpr (PACK) {  // fold the second slab's diagonal block (and side sums) onto the first
+        if constexpr (PACK && sizeof(T) != 8) {  // f32 tile layout: fold the second slab's block (and side sums) through LDS
             PDS_WAVE_LDS_SYNC();
             const int fi = lane & 7, fj = lane >> 3;
             const double dsum = Msc[fi + kFQ * fj] + Msc[fi + 8 + kFQ * (fj + 8)];
@@ -355,10 +375,7 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
             Msc[fi + kFQ * fj] = dsum;
             if (lane < 8) {
                 Msc[lane + kFQ * 17] = xys;
-                if constexpr (BIAS) {
-                    Msc[lane + kFQ * 16] = css;
-                    Msc[16 + kFQ * lane] = css;
-                }
+                if constexpr (BIAS) Msc[lane + kFQ * 16] = css;
             }
             if (BIAS && lane == 0) Msc[16 + kFQ * 17] = yss;
         }
