@@ -25,6 +25,18 @@ namespace pds {
 
 #define RSYNC() PDS_WAVE_LDS_SYNC()
 
+// -DPDS_PROFILE_ROLLING: shader-clock sums per phase over all waves (development; tools/rolling_profile.py)
+#ifdef PDS_PROFILE_ROLLING
+__device__ unsigned long long g_roll_cycles[8];
+#define RT0() unsigned long long _t0 = __builtin_amdgcn_s_memtime()
+#define RTA() _t0 = __builtin_amdgcn_s_memtime()
+#define RT1(k) rprof[k] += __builtin_amdgcn_s_memtime() - _t0
+#else
+#define RT0() do {} while (0)
+#define RTA() do {} while (0)
+#define RT1(k) do {} while (0)
+#endif
+
 #ifndef PDS_ROLL_WPE
 #define PDS_ROLL_WPE 2
 #endif
@@ -39,7 +51,8 @@ struct RollDims {
     // The moments go through LDS in NSET passes of NH moments each (moment v = pass v / NH, lane v % NH): one wave's
     // LDS stays under 20 KB, so 8 waves per CU fit (at p' = 8 all 45 moments at once were 23.4 KB -> 6 waves per CU,
     // and the step is latency bound: measured 1.5x between 6 and 8 waves per CU).
-    static constexpr int NSET = (NV + 36) / 37;
+    // NH <= 32: a pass's moments are scanned by TWO lanes each (rows 0-31 and 32-63 of the step), see phase B.
+    static constexpr int NSET = (NV + 31) / 32;
     static constexpr int NH = (NV + NSET - 1) / NSET;
 };
 
@@ -92,7 +105,7 @@ __device__ __forceinline__ void rolling_body(const T* const* __restrict__ cols, 
         ra.bias = 0;
     }
     constexpr int NG = RollDims<PP>::NG, NV = RollDims<PP>::NV, NSET = RollDims<PP>::NSET, NH = RollDims<PP>::NH;
-    static_assert(NH <= 64, "one lane per moment of a pass");
+    static_assert(NH <= 32, "two lanes per moment of a pass");
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double* D = sm + (size_t)wave * NH * kLdsStride;
@@ -101,6 +114,10 @@ __device__ __forceinline__ void rolling_body(const T* const* __restrict__ cols, 
     const int64_t wid = (int64_t)blockIdx.x * kRollWaves + wave, nw = (int64_t)gridDim.x * kRollWaves;
     const int64_t w = ra.window;
 
+#ifdef PDS_PROFILE_ROLLING
+    unsigned long long rprof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
     for (int64_t t = wid; t < ntiles; t += nw) {
         const int64_t t0 = t * T_, t1 = (t0 + T_ < ra.n) ? t0 + T_ : ra.n;
         // running moments: lane l < NH owns moment k * NH + l of every pass k
@@ -123,6 +140,7 @@ __device__ __forceinline__ void rolling_body(const T* const* __restrict__ cols, 
             const bool warm = base < t0;
             const int64_t r = base + lane;
             // ---------------- phase A
+            RT0();
             double zn[PP], zo[PP], yn = nyn, yo = nyo;
 #pragma unroll
             for (int a = 0; a < PP; ++a) {
@@ -153,12 +171,14 @@ __device__ __forceinline__ void rolling_body(const T* const* __restrict__ cols, 
                 for (int a = 0; a < PP; ++a) zo[a] = 0.0;
                 yo = 0.0;
             }
+            RT1(0);  // row hand-over: wait for the prefetched rows, finiteness, issue of the next rows
             double g[NG], c[PP], cnt = 0.0;
             const bool want_c = !(warm || ra.mode == 1);
 #pragma unroll
             for (int ks = 0; ks < NSET; ++ks) {
                 // ---- A: the increments of this pass's moments, D[moment % NH][row]
                 {
+                    RT0();
                     int v = 0;
 #pragma unroll
                     for (int a = 0; a < PP; ++a)
@@ -171,39 +191,59 @@ __device__ __forceinline__ void rolling_body(const T* const* __restrict__ cols, 
                     for (int a = 0; a < PP; ++a)
                         if ((NG + a) / NH == ks) D[((NG + a) % NH) * kLdsStride + lane] = fma(zn[a], yn, -(zo[a] * yo));
                     if ((NG + PP) / NH == ks) D[((NG + PP) % NH) * kLdsStride + lane] = (okn ? 1.0 : 0.0) - (oko ? 1.0 : 0.0);
+#ifdef PDS_PROFILE_ROLLING
+                    RSYNC();
+#endif
+                    RT1(1);
                 }
                 RSYNC();
                 // ---- B: lane v scans its moment over the 64 rows of this step
-                if (lane < NH && ks * NH + lane < NV) {
-                    // 16 independent LDS reads, 16 dependent adds, 16 writes per batch (a read-add-write loop would put
-                    // an LDS round trip into every one of the 64 links of the chain)
-                    double* row = D + lane * kLdsStride;
-                    double Wk = W[ks];
+                RT0();
+                {
+                    // Two lanes per moment: lane m scans rows 0-31 from the carry, lane 32 + m rows 32-63 from zero, and
+                    // the total of the first half (carry included) goes to the row's spare LDS slot [64], which phase C
+                    // adds for the rows of the upper half.  Half the LDS instructions and half the dependent chain of
+                    // one lane per moment (the scan was 44 % of the kernel's time).  Per batch: 16 independent LDS
+                    // reads, 16 dependent adds, 16 writes (a read-add-write loop would put an LDS round trip into
+                    // every link of the chain).
+                    const int hh = lane >> 5, m = lane & 31;
+                    double run = 0.0;
+                    if (m < NH && ks * NH + m < NV) {
+                        double* row = D + m * kLdsStride + 32 * hh;
+                        run = (hh == 0) ? W[ks] : 0.0;
 #pragma unroll
-                    for (int i0 = 0; i0 < 64; i0 += 16) {
-                        double v[16];
+                        for (int i0 = 0; i0 < 32; i0 += 16) {
+                            double v[16];
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) v[i] = row[i0 + i];
+                            for (int i = 0; i < 16; ++i) v[i] = row[i0 + i];
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            Wk += v[i];
-                            v[i] = Wk;
+                            for (int i = 0; i < 16; ++i) {
+                                run += v[i];
+                                v[i] = run;
+                            }
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) row[i0 + i] = v[i];
                         }
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) row[i0 + i] = v[i];
+                        if (hh == 0) row[64] = run;
                     }
-                    W[ks] = Wk;
+                    // carry of the next step = first half's total (carry included) + second half's local total
+                    const unsigned lo = (unsigned)__double2loint(run), hi = (unsigned)__double2hiint(run);
+                    const auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+                    const auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+                    W[ks] = __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
                 }
                 RSYNC();
+                RT1(2);
                 // ---- C (first half): lane = row again takes its window sums of this pass into registers
                 if (want_c) {
+                    const double up = (lane >= 32) ? 1.0 : 0.0;  // rows of the upper half add the first half's total
                     int v = 0;
 #pragma unroll
                     for (int a = 0; a < PP; ++a)
 #pragma unroll
                         for (int b = a; b < PP; ++b) {
                             if (v / NH == ks) {
-                                double x = D[(v % NH) * kLdsStride + lane];
+                                double x = fma(up, D[(v % NH) * kLdsStride + 64], D[(v % NH) * kLdsStride + lane]);
                                 if (a == b) {
                                     if (a < ra.pp) x += ra.lambda;
                                     else x = 1.0;  // padding dimension: identity, beta_pad = 0
@@ -214,13 +254,14 @@ __device__ __forceinline__ void rolling_body(const T* const* __restrict__ cols, 
                         }
 #pragma unroll
                     for (int a = 0; a < PP; ++a)
-                        if ((NG + a) / NH == ks) c[a] = D[((NG + a) % NH) * kLdsStride + lane];
-                    if ((NG + PP) / NH == ks) cnt = D[((NG + PP) % NH) * kLdsStride + lane];
+                        if ((NG + a) / NH == ks) c[a] = fma(up, D[((NG + a) % NH) * kLdsStride + 64], D[((NG + a) % NH) * kLdsStride + lane]);
+                    if ((NG + PP) / NH == ks) cnt = fma(up, D[((NG + PP) % NH) * kLdsStride + 64], D[((NG + PP) % NH) * kLdsStride + lane]);
                 }
                 if (ks + 1 < NSET) RSYNC();  // the next pass overwrites D
             }
             if (!want_c) continue;
             // ---------------- phase C: lane = row, solve (G + lambda I) beta = c
+            RTA();
             if (r < t1) {
                 // Cholesky G = L L' in place (packed upper storage read as lower by symmetry):
                 // idx(a,b), a <= b  ->  a*PP - a(a-1)/2 + (b-a)
@@ -275,6 +316,7 @@ __device__ __forceinline__ void rolling_body(const T* const* __restrict__ cols, 
                 valid[r] = v_ok ? 1 : 0;
             }
             RSYNC();
+            RT1(3);
         }
         if (ra.mode == 1) {
 #pragma unroll
@@ -282,6 +324,11 @@ __device__ __forceinline__ void rolling_body(const T* const* __restrict__ cols, 
                 if (lane < NH && k * NH + lane < NV) tile_tot[t * NV + k * NH + lane] = W[k];
         }
     }
+#ifdef PDS_PROFILE_ROLLING
+    rprof[7] = __builtin_amdgcn_s_memtime() - t_begin;
+    if (lane == 0)
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_roll_cycles[k], rprof[k]);
+#endif
 }
 
 // p' <= 8 is compiled for two waves per SIMD (248 VGPRs, no spills): with the moments passing through LDS in halves
@@ -435,6 +482,15 @@ int launch_rolling(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_
     return launch_rolling_wide<T>(ctx, dc, n_feat, n_rows, add_bias, window, min_size, lambda, expanding, seed_moments, d_coeffs,
                                   d_pred, d_valid);
 }
+
+#ifdef PDS_PROFILE_ROLLING
+extern "C" int pds_debug_rolling_cycles(unsigned long long* out, int reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_roll_cycles), sizeof(z)) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_roll_cycles), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
 
 template int launch_rolling<double>(pds_ctx*, const DeviceCols<double>&, int, int64_t, int, int64_t, int64_t, double,
                                     bool, const double*, double*, double*, uint8_t*);
