@@ -244,6 +244,17 @@ int pds_lr_grouped_nullable_f32(pds_ctx* ctx, const float* const* cols, const ui
                                 float fill_value, const pds_lr_params* prm, float* coeffs, uint8_t* is_null);
 
 /*
+ * pds_lr_with_inv_*: faer_qr_lr_with_inv (lr_online_solvers.rs:120-143) -- the initial fit of OnlineLR (src/pymodels/py_lr.rs
+ * :169, lr_online_solvers.rs:101-113): X'X (+ lambda on the n_feat feature diagonals), column-pivoted QR, its inverse and
+ * the solution.  coeffs: n_feat + add_bias values (bias last); inv: (n_feat + add_bias)^2 values, column-major (symmetric).
+ * Host outputs.  The per-row `woodbury_step` updates that follow are O(p'^2) host arithmetic on this state.
+ */
+int pds_lr_with_inv_f64(pds_ctx* ctx, const double* const* cols, int n_feat, int64_t n_rows, pds_space space, int add_bias,
+                        double lambda, double* coeffs, double* inv);
+int pds_lr_with_inv_f32(pds_ctx* ctx, const float* const* cols, int n_feat, int64_t n_rows, pds_space space, int add_bias,
+                        float lambda, float* coeffs, float* inv);
+
+/*
  * pds_lr_grouped_weighted_*: `group_by(key).agg(pds.lin_reg(..., weights=w))` -- per group faer_weighted_lr
  * (lr_solvers.rs:386-409: X'WX, X'Wy, plain solve with `solver`; no gate, no penalties, as pl_lr :436-446).  The frame is
  * scaled by sqrt(w) once on the device and takes the grouped path.  weights: n_rows values, `space`-resident; the other

@@ -6,6 +6,7 @@ elastic net / NNLS / WLS) is implemented; see DESIGN.md for the scope table and 
 the C ABI (include/pds_lstsq.h) drops in behind the reference's `#[polars_expr]` functions.
 """
 from . import config  # noqa: F401
+from . import linear_models  # noqa: F401  (LR / ElasticNet / OnlineLR over NumPy or CUDA tensors)
 from .lstsq import (  # noqa: F401
     Context,
     default_context,

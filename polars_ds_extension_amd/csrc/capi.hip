@@ -967,6 +967,34 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
 }
 
 // ---------------------------------------------------------------------------------------------
+// faer_qr_lr_with_inv (lr_online_solvers.rs:120-143): the initial fit of OnlineLR -- coefficients and (X'X + lambda)^-1
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+static int lr_with_inv_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t n_rows, pds_space space, int add_bias,
+                            double lambda, T* coeffs, T* inv) {
+    if (!ctx || !cols || !coeffs || !inv) return fail(PDS_ERR_INVALID, "null argument");
+    if (int rc = check_shape(n_feat, n_rows, add_bias)) return rc;
+    PDS_HIP_CHECK(hipSetDevice(ctx->device));
+    const int bias = add_bias ? 1 : 0, pp = n_feat + bias, q = n_feat + 2;
+    size_t need = 65536 + sizeof(T) * ((size_t)q * q + (size_t)pp * pp + pp + 8) + sizeof(T*) * (size_t)(n_feat + 32);
+    if (n_feat > kMaxFeatSmall) need += moments_wide_workspace(ctx->num_cus, n_feat, n_rows);
+    if (int rc = ws_reserve(ctx, need)) return rc;
+    DeviceCols<T> dc;
+    if (int rc = make_device_cols<T>(ctx, cols, (const T*)nullptr, n_feat, n_rows, space, dc)) return rc;
+    T* d_mom = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * q * q));
+    T* d_beta = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * (pp + 2)));
+    T* d_inv = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * pp * pp));
+    uint8_t* d_flag = reinterpret_cast<uint8_t*>(ws_take(ctx, 16));
+    if (int rc = launch_moments<T>(ctx, dc, n_feat, n_rows, false, d_mom)) return rc;
+    SolveParams sp{n_feat, bias, PDS_SOLVER_QR, lambda > 0.0 ? lambda : 0.0, 0.0, 0};
+    if (int rc = launch_solve<T>(ctx, d_mom, 1, sp, d_beta, d_flag, d_inv, nullptr)) return rc;
+    PDS_HIP_CHECK(hipMemcpyAsync(coeffs, d_beta, sizeof(T) * pp, hipMemcpyDeviceToHost, ctx->stream));
+    PDS_HIP_CHECK(hipMemcpyAsync(inv, d_inv, sizeof(T) * pp * pp, hipMemcpyDeviceToHost, ctx->stream));
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PDS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // weighted groups: per group faer_weighted_lr (lr_solvers.rs:386-409) -- X' W X = (sqrt(W) X)' (sqrt(W) X), so the frame
 // is scaled once on the device (the bias becomes an explicit sqrt(w) column) and takes the unweighted, ungated grouped path
 // ---------------------------------------------------------------------------------------------
@@ -1402,6 +1430,15 @@ int pds_lr_grouped_nullable_f32(pds_ctx* ctx, const float* const* cols, const ui
                                 float* coeffs, uint8_t* is_null) {
     return grouped_impl<float>(ctx, cols, n_feat, n_rows, group_offsets, n_groups, space, prm, coeffs, is_null, true, validity,
                                bit_offsets, null_policy, fill_value);
+}
+
+int pds_lr_with_inv_f64(pds_ctx* ctx, const double* const* cols, int n_feat, int64_t n_rows, pds_space space, int add_bias,
+                        double lambda, double* coeffs, double* inv) {
+    return pds::lr_with_inv_impl<double>(ctx, cols, n_feat, n_rows, space, add_bias, lambda, coeffs, inv);
+}
+int pds_lr_with_inv_f32(pds_ctx* ctx, const float* const* cols, int n_feat, int64_t n_rows, pds_space space, int add_bias,
+                        float lambda, float* coeffs, float* inv) {
+    return pds::lr_with_inv_impl<float>(ctx, cols, n_feat, n_rows, space, add_bias, (double)lambda, coeffs, inv);
 }
 
 int pds_lr_grouped_weighted_f64(pds_ctx* ctx, const double* const* cols, const double* weights, int n_feat, int64_t n_rows,

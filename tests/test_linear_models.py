@@ -1,0 +1,138 @@
+"""
+The model classes (polars_ds_extension_amd/linear_models.py), mirroring /root/reference/tests/test_linear_models.py:
+`_handle_nans_in_np` (:9-50), LR against scikit-learn for every solver string (:53-75), OnlineLR fit + updates against
+refits (:78-122), ElasticNet against scikit-learn with and without intercept (:125-158) -- same tolerances.
+"""
+import numpy as np
+import pytest
+
+
+def _frame(seed, size=5000, noise=1e-4):
+    rng = np.random.default_rng(seed)
+    X = rng.random((size, 3))
+    y = X[:, 0] + 0.2 * X[:, 1] - 0.3 * X[:, 2] + noise * rng.random(size)
+    return X, y.reshape(-1, 1)
+
+
+def test_lr_null_policies_for_np():
+    from polars_ds_extension_amd.linear_models import _handle_nans_in_np
+
+    X, y = _frame(0)
+    nulls = X[:, 0] > 0.5
+    x = X.copy()
+    x[nulls, 0] = np.nan
+    x_nan, _ = _handle_nans_in_np(x, y, "ignore")
+    assert np.all(np.isnan(x_nan[nulls][:, 0]))
+    with pytest.raises(ValueError, match="Nulls found in X or y."):
+        _handle_nans_in_np(x, y, "raise")
+    x_skipped, y_skipped = _handle_nans_in_np(x, y, "skip")
+    assert np.all(x_skipped == x[~nulls]) and len(y_skipped) == (~nulls).sum()
+    x_zeroed, _ = _handle_nans_in_np(x, y, "zero")
+    assert np.all(x_zeroed[nulls][:, 0] == 0.0)
+    x_one, _ = _handle_nans_in_np(x, y, "one")
+    assert np.all(x_one[nulls][:, 0] == 1.0)
+    x_q, _ = _handle_nans_in_np(x, y, "0.25")
+    assert np.all(x_q[nulls][:, 0] == 0.25)
+    with pytest.raises(ValueError, match="Unknown null_policy"):
+        _handle_nans_in_np(x, y, "whatever")
+
+
+def test_constructors_and_state_without_gpu():
+    from polars_ds_extension_amd.linear_models import LR, ElasticNet, OnlineLR
+
+    lr = LR.from_values([1.0, 2.0], bias=0.5, feature_names_in_=["a", "b"])
+    assert lr.is_fit() and lr.bias() == 0.5 and list(lr.coeffs()) == [1.0, 2.0]
+    np.testing.assert_allclose(lr.predict(np.array([[1.0, 1.0], [0.0, 2.0]])).flatten(), [3.5, 4.5])
+    assert "Linear Regression Model" in repr(lr) and not LR().is_fit() and "Not fitted yet." in repr(LR())
+    with pytest.raises(ValueError, match="Cannot have both l1_reg and l2_reg <= 0."):
+        ElasticNet(0.0, 0.0)
+    en = ElasticNet.from_values([0.5], bias=0.0)
+    assert en.is_fit() and not en.has_bias()
+    o = OnlineLR.from_coeffs_bias_inverse([1.0, -1.0], 0.0, np.eye(2))
+    o.update(np.array([1.0, 0.0]), 3.0)  # woodbury_step on the identity: inv -> I - e1 e1' / 2, w -> w + e1 * (3 - 1) / 2
+    np.testing.assert_allclose(o.inv(), [[0.5, 0.0], [0.0, 1.0]])
+    np.testing.assert_allclose(o.coeffs(), [2.0, -1.0])
+    o.update(np.array([np.nan, 0.0]), 3.0)  # rows holding a NaN are ignored
+    np.testing.assert_allclose(o.coeffs(), [2.0, -1.0])
+    with pytest.raises(ValueError, match="You cannot update before the initial fit"):
+        OnlineLR().update(np.array([1.0]), 1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", ["svd", "cholesky", "qr"])
+def test_lr(solver):
+    from sklearn.linear_model import LinearRegression, Ridge
+
+    from polars_ds_extension_amd.linear_models import LR
+
+    X, y = _frame(1)
+    ols = LR(False, 0.0, solver).fit(X, y)
+    sk = LinearRegression(fit_intercept=False).fit(X, y)
+    assert np.all(np.abs(ols.coeffs() - sk.coef_) < 1e-6)
+    np.testing.assert_allclose(ols.predict(X[:7]).flatten(), sk.predict(X[:7]).flatten(), atol=1e-6)
+    rb = LR(True, 0.7, solver).fit(X, y)  # ridge with intercept: lambda on the features only
+    skr = Ridge(alpha=0.7, fit_intercept=True).fit(X, y.ravel())
+    assert np.all(np.abs(rb.coeffs() - skr.coef_) < 1e-6) and abs(rb.bias() - skr.intercept_) < 1e-6
+    Xn = X.copy()
+    Xn[::9, 1] = np.nan
+    sk2 = LinearRegression(fit_intercept=False).fit(X[np.isfinite(Xn).all(axis=1)], y[np.isfinite(Xn).all(axis=1)])
+    assert np.all(np.abs(LR().fit(Xn, y, null_policy="skip").coeffs() - sk2.coef_) < 1e-6)
+    with pytest.raises(ValueError, match="Not enough data."):
+        LR().fit(X[:2], y[:2])
+
+
+@pytest.mark.gpu
+def test_lr_on_device_tensors():
+    import torch
+
+    from polars_ds_extension_amd.linear_models import LR
+
+    X, y = _frame(2)
+    b_host = LR(True).fit(X, y)
+    b_dev = LR(True).fit(torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda())
+    np.testing.assert_allclose(b_dev.coeffs(), b_host.coeffs(), rtol=1e-10)
+    assert abs(b_dev.bias() - b_host.bias()) < 1e-10
+    pred = b_dev.predict(torch.from_numpy(X[:5]).cuda())
+    np.testing.assert_allclose(pred.cpu().numpy(), b_host.predict(X[:5]), rtol=1e-10)
+
+
+@pytest.mark.gpu
+def test_online_lr():
+    from sklearn.linear_model import LinearRegression
+
+    from polars_ds_extension_amd.linear_models import OnlineLR
+
+    X, y = _frame(3)
+    olr = OnlineLR().fit(X[:10], y[:10])
+    sk = LinearRegression(fit_intercept=False).fit(X[:10], y[:10])
+    assert np.all(np.abs(olr.predict(X[:10]).flatten() - sk.predict(X[:10]).flatten()) < 1e-6)
+    assert np.all(np.abs(olr.coeffs() - sk.coef_) < 1e-6)
+    np.testing.assert_allclose(olr.inv(), np.linalg.inv(X[:10].T @ X[:10]), rtol=1e-8)
+    for i in range(10, 20):
+        olr.update(X[i], y[i])
+        sk = LinearRegression(fit_intercept=False).fit(X[: i + 1], y[: i + 1])
+        assert np.all(np.abs(olr.coeffs() - sk.coef_) < 1e-6)
+    ob = OnlineLR(lambda_=0.3, has_bias=True).fit(X[:50], y[:50])
+    Xb = np.c_[X[:50], np.ones(50)]
+    G = Xb.T @ Xb + np.diag([0.3, 0.3, 0.3, 0.0])
+    np.testing.assert_allclose(np.r_[ob.coeffs(), ob.bias()], np.linalg.solve(G, Xb.T @ y[:50].ravel()), rtol=1e-8)
+    ob.update(X[50], y[50], c=1.0).update(X[50], y[50], c=-1.0)  # add a row, then remove it again
+    np.testing.assert_allclose(np.r_[ob.coeffs(), ob.bias()], np.linalg.solve(G, Xb.T @ y[:50].ravel()), rtol=1e-7)
+    with pytest.raises(ValueError, match="must fit without null"):
+        OnlineLR().fit(np.where(X[:10] > 0.9, np.nan, X[:10]), y[:10])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("add_bias", [False, True])
+def test_elastic_net(add_bias):
+    import sklearn.linear_model as lm
+
+    from polars_ds_extension_amd.linear_models import ElasticNet
+
+    l1_reg = l2_reg = 0.1
+    X, y = _frame(4, noise=0.0)
+    en = ElasticNet(l1_reg=l1_reg, l2_reg=l2_reg, has_bias=add_bias).fit(X, y)
+    sk = lm.ElasticNet(alpha=l1_reg + l2_reg, l1_ratio=l1_reg / (l1_reg + l2_reg), fit_intercept=add_bias).fit(X, y.ravel())
+    assert np.all(np.abs(en.coeffs() - sk.coef_) < 1e-4)
+    if add_bias:
+        assert abs(en.bias() - sk.intercept_) < 1e-4
