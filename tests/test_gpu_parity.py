@@ -1020,6 +1020,20 @@ def test_grouped_null_policies(pds, orc):
         pds.lin_reg_by(*arrs[1:], target=arrs[0], group_offsets=off, null_policy="raise")
 
 
+def test_linear_impute_frame(pds):
+    # tests/test_transforms.py:33-48 (`linear_impute`: pipeline/transforms.py:115-155 = lin_reg(null_policy="skip") + fill_null):
+    # c = a + b with one null; the skip-null fit must return beta = [1, 1] and the null must be imputed as 6.0
+    import pyarrow as pa
+
+    a = pa.array([3.0, 2, 3, 4, 5, 6, 7, 8, 9, 11])
+    b = pa.array([1.0, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+    c = pa.array([4.0, 4.0, None, 8.0, 10.0, 12.0, 14.0, 16.0, 18.0, 21.0])
+    beta = pds.lin_reg(a, b, target=c, add_bias=False, null_policy="skip")
+    np.testing.assert_allclose(beta, [1.0, 1.0], rtol=0, atol=1e-10)
+    filled = np.where(np.asarray(c.is_null()), np.asarray(a) * beta[0] + np.asarray(b) * beta[1], np.asarray(c.fill_null(0.0)))
+    np.testing.assert_allclose(filled, np.asarray(a) + np.asarray(b), atol=1e-9)
+
+
 def test_literal_skip_null_frame(pds):
     # tests/test_linear_exprs.py:411-432 (literal frame): a null in row 0 -> pred [None, 9.5, 10.5, 11.5, 12.5], resid [None, 0, 0, 0, 0]
     import pyarrow as pa
