@@ -1,8 +1,8 @@
 """
 Polars expression builders that route through libpds_lstsq_hip.so's `_polars_plugin_*` symbols.
 
-Same call signatures as /root/reference/python/polars_ds/exprs/expr_linear.py (`lin_reg` :105-274,
-`lin_reg_report` :561-631, `rolling_lin_reg` :482-558, `recursive_lin_reg` :413-479) plus the key-aware
+Same call signatures as /root/reference/python/polars_ds/exprs/expr_linear.py (`lin_reg` :105-274 incl. the multi-target
+form, `lin_reg_w_rcond` :356-410, `lin_reg_report` :561-631, `rolling_lin_reg` :482-558, `recursive_lin_reg` :413-479) plus the key-aware
 `lin_reg(..., by=key)` of SURVEY.md 8(b).  Importing this module needs `polars` (>= 1.4), which is NOT installable
 in the build image: the module is exercised only through the plugin ABI tests (tests/test_plugin_abi.py, pyarrow
 standing in for the engine) and is UNVERIFIED against a real Polars until run next to one.
@@ -51,12 +51,25 @@ def _dtype():
 def lin_reg(*x, target, add_bias: bool = False, weights=None, return_pred: bool = False, l1_reg: float = 0.0,
             l2_reg: float = 0.0, tol: float = 1e-5, solver: str = "qr", max_iter: int = 200, null_policy: str = "skip",
             positive: bool = False, singular_x_tol: float | None = None, by=None):
-    if isinstance(target, list):
-        raise NotImplementedError("multi-target lin_reg goes through polars_ds_extension_amd.lstsq.lin_reg for now")
+    if singular_x_tol is None:
+        singular_x_tol = 1e-12 if cfg.LIN_REG_EXPR_F64 else 1e-6  # expr_linear.py:179-186
+    if isinstance(target, list):  # expr_linear.py:188-233
+        n_targets = len(target)
+        if n_targets == 0:
+            raise ValueError("If `target` is a list, it cannot be empty.")
+        if n_targets == 1:
+            return lin_reg(*x, target=target[0], add_bias=add_bias, weights=weights, return_pred=return_pred, l1_reg=l1_reg,
+                           l2_reg=l2_reg, tol=tol, solver=solver, null_policy=null_policy, singular_x_tol=singular_x_tol)
+        dt = _dtype()
+        cols = [_formula(t).alias(f"target_{i}").cast(dt) for i, t in enumerate(target)]
+        kwargs = {"bias": add_bias, "null_policy": null_policy, "solver": solver, "last_target_idx": n_targets, "l2_reg": l2_reg,
+                  "singular_x_tol": singular_x_tol}
+        cols.extend(_formula(z) for z in x)
+        if return_pred:
+            return _plugin("pl_lr_multi_pred", cols, kwargs).alias("lr_pred")
+        return _plugin("pl_lr_multi", cols, kwargs, returns_scalar=True).alias("coeffs")
     if max_iter <= 0:
         raise ValueError("Input `max_iter` must be a positive.")
-    if singular_x_tol is None:
-        singular_x_tol = 1e-12 if cfg.LIN_REG_EXPR_F64 else 1e-6
     weighted = weights is not None
     kwargs = {"bias": add_bias, "null_policy": null_policy, "l1_reg": l1_reg, "l2_reg": l2_reg, "solver": solver, "tol": tol,
               "max_iter": max_iter, "weighted": weighted, "positive": positive, "singular_x_tol": singular_x_tol}
@@ -69,6 +82,13 @@ def lin_reg(*x, target, add_bias: bool = False, weights=None, return_pred: bool 
     if return_pred:
         return _plugin("pl_lr_pred", cols, kwargs).alias("lr_pred")
     return _plugin("pl_lr", cols, kwargs, returns_scalar=True).alias("coeffs")
+
+
+def lin_reg_w_rcond(*x, target, add_bias: bool = False, rcond: float = 0.0, l2_reg: float = 0.0, null_policy: str = "raise"):
+    """expr_linear.py:356-410: SVD solve with a singular-value cut-off; Struct{coeffs, singular_values}."""
+    cols = [_formula(target).cast(_dtype())] + [_formula(z) for z in x]
+    kwargs = {"bias": add_bias, "null_policy": null_policy, "l1_reg": 0.0, "l2_reg": l2_reg, "solver": "", "tol": abs(rcond)}
+    return _plugin("pl_lr_w_rcond", cols, kwargs)
 
 
 def lin_reg_report(*x, target, add_bias: bool = False, weights=None, std_err: str = "se", null_policy: str = "raise"):
