@@ -30,11 +30,15 @@ template <typename T>
 struct Wide;
 template <>
 struct Wide<float> {
-    static constexpr int KC = 32;   // rows per stage (128 B per column)
-    static constexpr int CS = 33;   // LDS leading dimension (floats)
+#ifndef PDS_WIDE_KC
+#define PDS_WIDE_KC 32
+#endif
+    static constexpr int KC = PDS_WIDE_KC;   // rows per stage (128 B per column at 32; 64 -- half the barriers per row, two
+                                             // workgroups per CU instead of three -- measured 31.0 ms against 29.5 at config 5)
+    static constexpr int CS = KC + 1;        // LDS leading dimension (floats)
     static constexpr int MT = 32;   // MFMA tile edge
     static constexpr int NT = 2;    // tiles per wave edge (64 / MT)
-    static constexpr int KS = 16;   // MFMA k-steps per stage (KC / 2)
+    static constexpr int KS = KC / 2;   // MFMA k-steps per stage
     using vec = f4w;
     static constexpr int VL = 4;
 };
@@ -80,6 +84,8 @@ __global__ __launch_bounds__(kWThreads, 2) void moments_wide_kernel(const T* con
                                                                  const T* __restrict__ sw, T* __restrict__ partials) {
     using W = Wide<T>;
     constexpr int KC = W::KC, CS = W::CS, MT = W::MT, NT = W::NT, VL = W::VL;
+    constexpr int PPC = KC / VL;                  // 16-byte pieces per column and stage
+    constexpr int NCH = kWB * PPC / kWThreads;    // chunks per thread and panel
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* LI = reinterpret_cast<T*>(smem);
     T* LJ = LI + kWB * CS;
@@ -119,13 +125,13 @@ __global__ __launch_bounds__(kWThreads, 2) void moments_wide_kernel(const T* con
     const int64_t r_end = (r_begin + rows_per_split < n) ? r_begin + rows_per_split : n;
 
     // this thread's 4 chunks per panel: chunk id = tid + 256 u  ->  column id/8, 16-byte piece id%8
-    gptr<T> ptrI[4];
-    gptr<T> ptrJ[4];
-    int kindI[4], kindJ[4];  // 0 data column, 1 ones column, 2 zero padding
+    gptr<T> ptrI[NCH];
+    gptr<T> ptrJ[NCH];
+    int kindI[NCH], kindJ[NCH];  // 0 data column, 1 ones column, 2 zero padding
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NCH; ++u) {
         const int id = tid + kWThreads * u;
-        const int cI = I * kWB + (id >> 3), cJ = ((FUSE && diag) ? nb - 1 : J) * kWB + (id >> 3);
+        const int cI = I * kWB + (id / PPC), cJ = ((FUSE && diag) ? nb - 1 : J) * kWB + (id / PPC);
         kindI[u] = (cI < p || cI == p + 1) ? 0 : (cI == p ? 1 : 2);
         kindJ[u] = (cJ < p || cJ == p + 1) ? 0 : (cJ == p ? 1 : 2);
         ptrI[u] = as_global(cols[cI < p ? cI : p]);  // index p is y in the device table
@@ -133,11 +139,11 @@ __global__ __launch_bounds__(kWThreads, 2) void moments_wide_kernel(const T* con
     }
     (void)q;
 
-    typename W::vec rI[4], rJ[4];
+    typename W::vec rI[NCH], rJ[NCH];
     auto load_stage = [&](int64_t row0) __attribute__((always_inline)) {
         typename W::vec swv;  // sqrt(w) of this thread's VL rows (the same rows for all of its chunks)
         if constexpr (WEIGHTED) {
-            const int64_t r = row0 + (tid & 7) * VL;
+            const int64_t r = row0 + (tid % PPC) * VL;
             if (r + VL <= r_end) {
                 swv = *reinterpret_cast<gptr<typename W::vec>>(as_global(sw) + r);
             } else {
@@ -146,12 +152,12 @@ __global__ __launch_bounds__(kWThreads, 2) void moments_wide_kernel(const T* con
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NCH; ++u) {
             const int id = tid + kWThreads * u;
-            const int64_t r = row0 + (id & 7) * VL;
+            const int64_t r = row0 + (id % PPC) * VL;
 #pragma unroll
             for (int pnl = 0; pnl < 2; ++pnl) {
-                if (pnl == 1 && diag && !(FUSE && u == 0)) continue;  // diagonal: J half unused, or the tail tile
+                if (pnl == 1 && diag && !(FUSE && (tid + kWThreads * u) / PPC < 32)) continue;  // diagonal: J half unused, or the tail tile
                 const int kind = pnl ? kindJ[u] : kindI[u];
                 const gptr<T> ptr = pnl ? ptrJ[u] : ptrI[u];
                 typename W::vec v;
@@ -175,13 +181,13 @@ __global__ __launch_bounds__(kWThreads, 2) void moments_wide_kernel(const T* con
     };
     auto store_stage = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NCH; ++u) {
             const int id = tid + kWThreads * u;
-            const int c = id >> 3, k0 = (id & 7) * VL;
+            const int c = id / PPC, k0 = (id % PPC) * VL;
 #pragma unroll
             for (int e = 0; e < VL; ++e) {
                 LI[c * CS + k0 + e] = rI[u][e];
-                if (!diag || (FUSE && u == 0)) LJ[c * CS + k0 + e] = rJ[u][e];
+                if (!diag || (FUSE && c < 32)) LJ[c * CS + k0 + e] = rJ[u][e];
             }
         }
     };
@@ -379,6 +385,12 @@ static int launch_moments_wide_w(pds_ctx* ctx, const DeviceCols<T>& dc, int n_fe
     T* d_sw = nullptr;
     if constexpr (WEIGHTED) d_sw = reinterpret_cast<T*>(ws_take(ctx, (size_t)n_rows * sizeof(T)));
     if (ctx->ws_used > ctx->ws.bytes) return fail(PDS_ERR_INVALID, "internal: workspace for the wide Gram build was not reserved");
+    if (lds > 64 * 1024) {
+        PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_wide_kernel<T, 0, WEIGHTED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_wide_kernel<T, 1, WEIGHTED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if constexpr (sizeof(T) == 4)
+            PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_wide_kernel<T, 2, WEIGHTED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     KernelTimer timer(ctx, kKindMoments);
     if constexpr (WEIGHTED)
         hipLaunchKernelGGL((sqrt_weights_kernel<T>), dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, dc.h_ptrs[n_feat + 1], n_rows,
