@@ -40,6 +40,21 @@ def test_plugin_symbols_and_version(so):
     assert isinstance(so._polars_plugin_get_last_error_message(), bytes)
 
 
+def test_coalescing_queue_fails_cleanly_without_a_device(so):
+    """No GPU here: every queued pl_lr call must come back with the library's error (nobody left waiting on a batch)."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a GPU")
+    kw = pickle.dumps({"bias": False, "null_policy": "raise", "l1_reg": 0.0, "l2_reg": 0.0, "solver": "qr", "tol": 1e-5,
+                       "max_iter": 200, "weighted": False, "positive": False, "singular_x_tol": 1e-12}, protocol=5)
+    buf = (C.c_uint8 * len(kw)).from_buffer_copy(kw)
+    sec, dev = C.c_double(), C.c_double()
+    fails = so.pds_plugin_debug_concurrent_lr(8, 5, 50, 3, buf, len(kw), C.byref(sec), C.byref(dev))
+    assert fails == 40
+    so._polars_plugin_get_last_error_message.restype = C.c_char_p
+
+
 def test_kwargs_pickle_parser(so):
     # the exact dicts python/polars_ds/exprs/expr_linear.py builds (:237-248, :546-552)
     lr_kwargs = {"bias": True, "null_policy": "skip", "l1_reg": 0.0, "l2_reg": 0.25, "solver": "qr", "tol": 1e-5,
