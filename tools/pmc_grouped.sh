@@ -1,12 +1,12 @@
 cd /tmp && export TMPDIR=/tmp
 for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAVES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "GRBM_GUI_ACTIVE"; do
-  rm -rf /tmp/pg; rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pg -o g -- python -u $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 > /tmp/pg.log 2>&1
+  rm -rf /tmp/pg; rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pg -o g -- python -u $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu > /tmp/pg.log 2>&1
   f=$(find /tmp/pg -name "*counter_collection.csv" | head -1)
   python - "$f" <<'PY'
 import csv,sys,collections
 acc=collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
-    if 'grouped_stream_kernel' in r['Kernel_Name']:
+    if "grouped_stream_kernel<double, 16" in r["Kernel_Name"]:
         acc[r['Counter_Name']].append(float(r['Counter_Value']))
 for k,v in acc.items(): print(k, sum(v)/len(v), len(v))
 PY
