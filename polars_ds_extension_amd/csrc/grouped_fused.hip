@@ -287,6 +287,7 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
             SolveRegDev spk = sp;
             spk.pp = FULLP ? LPS : p;  // (compile-time under FULLP: the per-step `K < p'` branches fold away)
             spk.p = spk.pp;
+            spk.gate_on = 1;           // this kernel only exists for the gated Cholesky (launch_stream_lps)
             chol_core<LPS>(a_p, dj_p, j, spk, is_null, zj);
         } else {
             solve_core<LPS>(a_p, b_p, dj_p, j, lane, sp, is_null, pj, zj);
