@@ -118,8 +118,8 @@ __device__ __forceinline__ void consume_range(const char* wl, int lane, int rel0
         step_v(x2, y2);
         step_v(x3, y3);
     }
-    // (fetching the next iteration's operands ahead of these matrix instructions was measured slower: the rotation
-    //  costs sixteen register moves per iteration and the waits did not move)
+    // (fetching the next iteration's operands ahead of these matrix instructions was measured slower with a register
+    //  rotation -- sixteen moves per iteration -- and no faster with two ping-pong operand sets: 2.43 ms either way)
     for (; s < sfull; ++s) step_v(xcol[4 * s], ycol[4 * s]);
     // tail: a last step that ends inside a 4-row group (and was not already the head step)
     if ((rel1 & 3) && sfull >= s0 && sfull < s1) step(sfull, true, 0, rel1 & 3);
