@@ -11,7 +11,7 @@ import numpy as np
 import torch
 import polars_ds_extension_amd as pds
 
-which = set(sys.argv[1:]) or {"rolling", "report", "single", "host", "en", "keyed"}
+which = set(sys.argv[1:]) or {"rolling", "report", "single", "host", "en", "keyed", "c1"}
 dev = torch.device("cuda", 0)
 ctx = pds.Context(0)
 ctx.set_stream(torch.cuda.current_stream(dev))
@@ -97,6 +97,24 @@ if "en" in which:
                              "gram_TFLOPs_upper_triangle": round(flops / 2 / (gms * 1e-3) / 1e12, 1),
                              "cd_ms": round(t.get("iterative", (0, 0))[0], 3), "nonzero": int((abs(b) > 1e-6).sum())}
     pds.config.LIN_REG_EXPR_F64 = True
+if "c1" in which:
+    # configs[0]: pds.lin_reg(x1..x4, target=y, add_bias=False) on a 100k-row f64 frame (benchmarks/test_linear_regression.py:9-31)
+    rng = np.random.default_rng(208)
+    n = 100_000
+    Xh = rng.random((n, 4))
+    yh = Xh @ [0.5, 0.25, -0.15, 0.2] + 1e-4 * rng.random(n)
+    hc = [np.ascontiguousarray(Xh[:, j]) for j in range(4)]
+    dcols = [torch.from_numpy(c).to(dev) for c in hc]
+    dy = torch.from_numpy(yh).to(dev)
+    res = {}
+    for name, f in (("host_columns", lambda: pds.lin_reg(*hc, target=yh, ctx=ctx)), ("device_columns", lambda: pds.lin_reg(*dcols, target=dy, ctx=ctx))):
+        for _ in range(5): b = f()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(50): b = f()
+        torch.cuda.synchronize(); res[name + "_us"] = round((time.perf_counter() - t0) / 50 * 1e6, 1)
+    res["max_abs_err_vs_numpy"] = float(np.max(np.abs(np.asarray(b.cpu() if hasattr(b, "cpu") else b) - np.linalg.lstsq(Xh, yh, rcond=None)[0])))
+    out["config1_100k_x4"] = res
+
 if "keyed" in which:
     # configs[2] with the rows in random order (SURVEY 8d "shuffled variant"): group_by on an unsorted key column
     G, R, p = 1_000_000, 100, 8
