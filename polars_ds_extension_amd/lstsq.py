@@ -12,6 +12,7 @@ All arithmetic happens in libpds_lstsq_hip.so; nothing here computes a regressio
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import Sequence
 
 import numpy as np
@@ -137,14 +138,15 @@ class Context:
         return getattr(self._lib, name + _suffix())
 
 
-_default: Context | None = None
+_tls = threading.local()
 
 
 def default_context() -> Context:
-    global _default
-    if _default is None:
-        _default = Context(0)
-    return _default
+    """One context per calling thread (a pds_ctx is not thread-safe: stream, workspace and pinned staging are per call)."""
+    ctx = getattr(_tls, "ctx", None)
+    if ctx is None:
+        ctx = _tls.ctx = Context(0)
+    return ctx
 
 
 def _follow(ctx: "Context", cols: "_Cols") -> None:

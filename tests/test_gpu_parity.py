@@ -234,6 +234,24 @@ def test_report_y_var_from_moments(pds):
     assert abs(a["r2"][0] - b["r2"][0]) < 1e-10
 
 
+def test_default_context_is_per_thread(pds):
+    """Python threads calling the functional API concurrently get their own context (stream, workspace, staging)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    rng = np.random.default_rng(8)
+    frames = [(rng.normal(size=(int(rng.integers(50, 5000)), 4)), rng.normal(size=4)) for _ in range(24)]
+
+    def one(i):
+        X, b = frames[i]
+        y = X @ b + 0.25
+        return pds.lin_reg(*[np.ascontiguousarray(X[:, j]) for j in range(4)], target=y, add_bias=True)
+
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        res = list(ex.map(one, list(range(24)) * 3))
+    for i, r in enumerate(res):
+        np.testing.assert_allclose(r, np.r_[frames[i % 24][1], 0.25], atol=1e-9)
+
+
 # ------------------------------------------------------------------------------------------ grouped
 @pytest.mark.parametrize("p,bias", [(1, False), (2, False), (3, True), (4, True), (5, False), (7, False), (7, True), (8, False),
                                     (8, True), (9, False), (15, True), (16, False), (16, True), (4, False)])
