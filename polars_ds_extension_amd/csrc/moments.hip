@@ -11,6 +11,8 @@
 //   * y, the bias (column sums) and the weights ride along on the VALU (it idles under the MFMA);
 //   * LDS column stride 1040 B makes the ds_read_b64 operand fetch conflict free;
 //   * no atomics: per-block partials + a fixed-order finalize kernel => run-to-run bit reproducible.
+#include <type_traits>
+
 #include "moments_dev.hpp"
 
 namespace pds {
@@ -20,9 +22,11 @@ namespace pds {
 // next tile while the matrix core chews the current one.
 // =============================================================================================
 // P16: exactly 16 features, known at compile time -- the per-column `c < p` scalar branches of the tile load / store fold away
-template <typename T, bool WEIGHTED, bool P16>
+// P2 (0 = off): p <= P2 <= 8 features, 16 / P2 row slabs per matrix instruction (consume_tile_pack)
+template <typename T, bool WEIGHTED, bool P16, int P2>
 __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* __restrict__ cols, int p_arg,
                                                                int64_t n, double* __restrict__ partials) {
+    static_assert(!(P16 && P2), "one or the other");
     const int p = P16 ? 16 : p_arg;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int RPL = Tile<T>::RPL;
@@ -52,18 +56,21 @@ __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* _
         store_tile_lds<T, WEIGHTED>(wl, p, lane, regs);
         const int64_t tn = t + nw;
         if (tn < nfull) load_full_tile<T, WEIGHTED>(cp, p, tn * TR + lane * RPL, regs);
-        consume_tile<T, WEIGHTED>(wl, lane, TR / 4, acc);
+        if constexpr (P2 != 0) consume_tile_pack<T, WEIGHTED, P2>(wl, lane, acc);
+        else consume_tile<T, WEIGHTED>(wl, lane, TR / 4, acc);
     }
     if (nfull * TR < n && (nfull % nw) == wid) {  // ragged tail: exactly one wave
         load_tail_tile<T, WEIGHTED>(cp, p, nfull * TR + lane * RPL, n, regs);
         store_tile_lds<T, WEIGHTED>(wl, p, lane, regs);
-        consume_tile<T, WEIGHTED>(wl, lane, TR / 4, acc);
+        if constexpr (P2 != 0) consume_tile_pack<T, WEIGHTED, P2>(wl, lane, acc);
+        else consume_tile<T, WEIGHTED>(wl, lane, TR / 4, acc);
     }
 
     // block reduction through LDS (tile storage is dead now)
     __syncthreads();
     double* recs = reinterpret_cast<double*>(smem);
-    wave_record<T>(acc, lane, recs + wave * kPartStride);
+    if constexpr (P2 != 0) wave_record_pack<T, P2>(acc, lane, recs + wave * kPartStride);
+    else wave_record<T>(acc, lane, recs + wave * kPartStride);
     __syncthreads();
     for (int e = threadIdx.x; e < kPartStride; e += blockDim.x) {
         double s = 0.0;
@@ -80,13 +87,30 @@ __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* _
 // butterfly combines the lanes -- deterministic, and ~2 us instead of a 512-long dependent load chain.
 template <typename T>
 __global__ __launch_bounds__(64) void moments_finalize_kernel(const double* __restrict__ partials, int nblocks,
-                                                              int p, double n_rows, int weighted,
+                                                              int p, double n_rows, int weighted, int p2,
                                                               T* __restrict__ out) {
     const int e = blockIdx.x;  // element of the partial record, 0 .. kPartSW
-    double s = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += 64) s += partials[(int64_t)b * kPartStride + e];
+    auto blocksum = [&](int el) {
+        double v = 0.0;
+        for (int b = threadIdx.x; b < nblocks; b += 64) v += partials[(int64_t)b * kPartStride + el];
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+        return v;
+    };
+    // packed build (p2 = feature slots per slab): fold the slabs -- diagonal p2 x p2 blocks of the tile, xy / cs lanes f % p2
+    const int nsl = p2 ? 16 / p2 : 1, st = p2 ? p2 : 0;
+    double s = 0.0;
+    if (e < kPartXY) {
+        const int i = e & 15, j = e >> 4;
+        if (p2 && (i >= p2 || j >= p2)) return;
+        for (int k = 0; k < nsl; ++k) s += blocksum((k * st + i) + 16 * (k * st + j));
+    } else if (e < kPartYY) {  // xy and cs lanes
+        const int base = e < kPartCS ? kPartXY : kPartCS, i = e - base;
+        if (p2 && i >= p2) return;
+        for (int k = 0; k < nsl; ++k) s += blocksum(base + k * st + i);
+    } else {
+        s = blocksum(e);
+    }
     if (threadIdx.x != 0) return;
     const int q = p + 2;
     if (e < kPartXY) {  // D[i + 16 j]: take the upper triangle and mirror it
@@ -204,20 +228,25 @@ int launch_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_
     double* partials = ctx->partials;  // sized for 8 blocks per CU at context creation
     KernelTimer timer(ctx, kKindMoments);
     size_t lds = (size_t)kWaves * kWaveLds + 64;  // + slack: the pipelined operand fetch reads two steps ahead
-    if (weighted && n_feat == 16)
-        hipLaunchKernelGGL((moments_small_kernel<T, true, true>), dim3(nblocks), dim3(256), lds, ctx->stream, dc.d_ptrs,
-                           n_feat, n_rows, partials);
-    else if (weighted)
-        hipLaunchKernelGGL((moments_small_kernel<T, true, false>), dim3(nblocks), dim3(256), lds, ctx->stream, dc.d_ptrs,
-                           n_feat, n_rows, partials);
-    else if (n_feat == 16)
-        hipLaunchKernelGGL((moments_small_kernel<T, false, true>), dim3(nblocks), dim3(256), lds, ctx->stream, dc.d_ptrs,
-                           n_feat, n_rows, partials);
-    else
-        hipLaunchKernelGGL((moments_small_kernel<T, false, false>), dim3(nblocks), dim3(256), lds, ctx->stream, dc.d_ptrs,
-                           n_feat, n_rows, partials);
+    const int p2 = n_feat > 8 ? 0 : (n_feat > 4 ? 8 : (n_feat > 2 ? 4 : (n_feat > 1 ? 2 : 1)));
+    auto launch = [&](auto w_c, auto p16_c, auto p2_c) {
+        hipLaunchKernelGGL((moments_small_kernel<T, decltype(w_c)::value, decltype(p16_c)::value, decltype(p2_c)::value>), dim3(nblocks),
+                           dim3(256), lds, ctx->stream, dc.d_ptrs, n_feat, n_rows, partials);
+    };
+    auto by_p2 = [&](auto w_c) {
+        using std::integral_constant;
+        using std::false_type;
+        if (n_feat == 16) launch(w_c, std::true_type{}, integral_constant<int, 0>{});
+        else if (p2 == 8) launch(w_c, false_type{}, integral_constant<int, 8>{});
+        else if (p2 == 4) launch(w_c, false_type{}, integral_constant<int, 4>{});
+        else if (p2 == 2) launch(w_c, false_type{}, integral_constant<int, 2>{});
+        else if (p2 == 1) launch(w_c, false_type{}, integral_constant<int, 1>{});
+        else launch(w_c, false_type{}, integral_constant<int, 0>{});
+    };
+    if (weighted) by_p2(std::true_type{});
+    else by_p2(std::false_type{});
     hipLaunchKernelGGL((moments_finalize_kernel<T>), dim3(kPartSW + 1), dim3(64), 0, ctx->stream, partials, nblocks, n_feat,
-                       (double)n_rows, weighted ? 1 : 0, d_moments);
+                       (double)n_rows, weighted ? 1 : 0, p2, d_moments);
     PDS_HIP_CHECK(hipGetLastError());
     return PDS_OK;
 }

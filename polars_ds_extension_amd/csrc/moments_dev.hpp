@@ -176,6 +176,57 @@ __device__ __forceinline__ void consume_tile(const char* wl, int lane, int steps
     }
 }
 
+
+// p <= 8 features: SEVERAL 4-row slabs per matrix instruction.  With P2 = 8 / 4 / 2 / 1 feature slots in use, operand
+// column f carries feature f % P2 of row slab f / P2, so one v_mfma 16x16x4 consumes 4 * (16 / P2) rows; the diagonal
+// P2 x P2 blocks of the product are the slabs' Gram contributions (the off-diagonal blocks are cross terms nobody reads)
+// and are folded by the finalize kernel.  At p <= 8 the f64 matrix pipe (86 clk per instruction) is the bound of the
+// unpacked kernel, not HBM: 1e8 rows cost 1.2 ms whether p is 1 or 8.
+template <typename T, bool WEIGHTED, int P2>
+__device__ __forceinline__ void consume_tile_pack(const char* wl, int lane, WaveAcc& a) {
+    constexpr int S = 16 / P2;                       // slabs per instruction
+    constexpr int TR = 64 * Tile<T>::RPL;
+    constexpr int steps = TR / (4 * S);
+    const int f = lane & 15, q = lane >> 4;
+    const int roff = q + 4 * (f / P2);               // this lane's row inside a 4 S-row step
+    const T* xcol = reinterpret_cast<const T*>(wl + (f % P2) * kColStride) + roff;
+    const T* ycol = reinterpret_cast<const T*>(wl + kSlotY * kColStride) + roff;
+    const T* wcol = reinterpret_cast<const T*>(wl + kSlotW * kColStride) + roff;
+    using Acc = typename Tile<T>::acc;
+    Acc acc;
+    if constexpr (sizeof(T) == 8) acc = Acc{a.d[0], a.d[1], a.d[2], a.d[3]};
+    else acc = Acc{0, 0, 0, 0};
+    T xy = 0, cs = 0, yy = 0, ys = 0, sw = 0;
+    if constexpr (sizeof(T) == 8) {
+        xy = a.xy; cs = a.cs; yy = a.yy; ys = a.ys; sw = a.sw;
+    }
+#pragma unroll
+    for (int s = 0; s < steps; ++s) {
+        const T x = xcol[4 * S * s], yv = ycol[4 * S * s];
+        T xa = x;
+        if constexpr (WEIGHTED) {
+            const T wv = wcol[4 * S * s];
+            xa = x * wv;
+            yy = fma(wv * yv, yv, yy);
+            ys = fma(wv, yv, ys);
+            sw += wv;
+        } else {
+            yy = fma(yv, yv, yy);
+            ys += yv;
+        }
+        acc = Tile<T>::mfma(xa, x, acc);
+        xy = fma(xa, yv, xy);
+        cs += xa;
+    }
+    if constexpr (sizeof(T) == 8) {
+        a.d[0] = acc[0]; a.d[1] = acc[1]; a.d[2] = acc[2]; a.d[3] = acc[3];
+        a.xy = xy; a.cs = cs; a.yy = yy; a.ys = ys; a.sw = sw;
+    } else {
+        a.d[0] += (double)acc[0]; a.d[1] += (double)acc[1]; a.d[2] += (double)acc[2]; a.d[3] += (double)acc[3];
+        a.xy += (double)xy; a.cs += (double)cs; a.yy += (double)yy; a.ys += (double)ys; a.sw += (double)sw;
+    }
+}
+
 // sum over the four row slots (lanes l, l^16, l^32, l^48).  gfx950's v_permlane16_swap / v_permlane32_swap exchange
 // the odd rows (upper half) of one operand with the even rows (lower half) of the other: fed the same value twice they
 // leave {own-or-partner, partner-or-own}, whose sum is v + xor-partner(v) on every lane -- no LDS round trip
@@ -204,6 +255,36 @@ __device__ __forceinline__ void wave_record(const WaveAcc& a, int lane, double* 
     for (int r = 0; r < 4; ++r) rec[kPartD + Tile<T>::drow(lane, r) + 16 * j] = a.d[r];
     double xy = xor_sum_q(a.xy), cs = xor_sum_q(a.cs), yy = xor_sum_q(a.yy), ys = xor_sum_q(a.ys),
            sw = xor_sum_q(a.sw);
+    if (lane < 16) {
+        rec[kPartXY + lane] = xy;
+        rec[kPartCS + lane] = cs;
+    }
+    if (lane == 0) {
+        rec[kPartYY] = yy;
+        rec[kPartYS] = ys;
+        rec[kPartSW] = sw;
+    }
+}
+
+// packed variant: the record keeps the full 16 x 16 tile and the 16 per-lane xy / cs sums (the finalize kernel folds the
+// slabs); y'y, sum y and sum w are per-ROW sums, every slab saw different rows: one representative lane per slab is summed.
+template <typename T, int P2>
+__device__ __forceinline__ void wave_record_pack(const WaveAcc& a, int lane, double* rec) {
+    const int j = lane & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rec[kPartD + Tile<T>::drow(lane, r) + 16 * j] = a.d[r];
+    const double xy = xor_sum_q(a.xy), cs = xor_sum_q(a.cs);
+    double yy = xor_sum_q(a.yy), ys = xor_sum_q(a.ys), sw = xor_sum_q(a.sw);
+    const bool rep = (j % P2) == 0;  // first feature lane of its slab
+    yy = rep ? yy : 0.0;
+    ys = rep ? ys : 0.0;
+    sw = rep ? sw : 0.0;
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) {  // over the 16 feature lanes of a row
+        yy += __shfl_xor(yy, o);
+        ys += __shfl_xor(ys, o);
+        sw += __shfl_xor(sw, o);
+    }
     if (lane < 16) {
         rec[kPartXY + lane] = xy;
         rec[kPartCS + lane] = cs;
