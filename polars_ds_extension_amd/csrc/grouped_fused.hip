@@ -16,6 +16,8 @@
 // accepted systems are well conditioned and the reference's three solvers agree on them to rounding.  With the
 // gate off (singular_x_tol = 0) the pivoted Householder QR runs instead, because only pivoting reproduces the
 // reference's finite answers on rank-deficient groups.  PDS_GROUPED_PIVOTED=1 forces QR everywhere.
+#include <type_traits>
+
 #include "moments_dev.hpp"
 #include "solve_reg_dev.hpp"
 
@@ -217,7 +219,7 @@ __device__ __forceinline__ int64_t lower_bound_i64(const int64_t* __restrict__ a
 // 15 / 7 / 3 features + bias): the per-column `c < p` branches of the tile load / store (17 scalar compares + branches per
 // tile, each re-reading a spilled SGPR) and the solver's per-step `K < p'` branches fold away -- 2.86 -> 2.63 ms at 16
 // features, 1.89 -> 1.52 ms at 8
-template <typename T, int LPS, bool CHOL, bool BIAS, bool FULLP>
+template <typename T, int LPS, bool CHOL, bool BIAS, int PC>
 __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __restrict__ cols, int p_arg,
                                                             const int64_t* __restrict__ offsets, int64_t n_groups,
                                                             int64_t n_rows, SolveRegDev sp, T* __restrict__ coeffs,
@@ -237,7 +239,9 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
     // solved, and b0 = (sum(y) - s . beta) / n.  det([X 1]'[X 1]) = n det(Xc'Xc) and the diagonal products differ by the
     // same n, so the reference's rank gate on the augmented matrix is the gate on the centred pivots over the UNcentred
     // diagonal -- same accept / reject rule.  16 features + bias stay on this kernel, 8 + bias on the packed one.
-    const int p = FULLP ? LPS : p_arg;  // features = solver lanes in use
+    constexpr bool FULLP = PC != 0;     // PC: the feature count as a compile-time constant (0 = run-time p_arg)
+    static_assert(PC >= 0 && PC <= LPS, "PC is a feature count of this kernel size");
+    const int p = FULLP ? PC : p_arg;   // features = solver lanes in use
     const int pp = p;                   // (solver size)
     const int pout = p + (BIAS ? 1 : 0);
     const int sub = lane / LPS, j_in = lane % LPS;
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
         PDS_T0();
         if constexpr (CHOL) {
             SolveRegDev spk = sp;
-            spk.pp = FULLP ? LPS : p;  // (compile-time under FULLP: the per-step `K < p'` branches fold away)
+            spk.pp = p;  // (a compile-time constant under PC != 0: the per-step `K < p'` branches fold away)
             spk.p = spk.pp;
             spk.gate_on = 1;           // this kernel only exists for the gated Cholesky (launch_stream_lps)
             chol_core<LPS>(a_p, dj_p, j, spk, is_null, zj);
@@ -531,18 +535,34 @@ static int launch_stream_lps(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, 
     // (the pivoted-QR variant of this kernel measured slower than the two-kernel pipeline and is not instantiated;
     //  callers route the ungated case to grouped_moments_kernel + solve_reg_kernel)
     if (!chol) return fail(PDS_ERR_INVALID, "internal: fused grouped kernel is Cholesky-only");
-    if (sd.bias && n_feat == LPS)
-        hipLaunchKernelGGL((grouped_stream_kernel<T, LPS, true, true, true>), dim3((unsigned)nb), dim3(64), lds, ctx->stream,
-                           dc.d_ptrs, n_feat, d_offsets, n_groups, n_rows, sd, d_coeffs, d_flags);
-    else if (sd.bias)
-        hipLaunchKernelGGL((grouped_stream_kernel<T, LPS, true, true, false>), dim3((unsigned)nb), dim3(64), lds, ctx->stream,
-                           dc.d_ptrs, n_feat, d_offsets, n_groups, n_rows, sd, d_coeffs, d_flags);
-    else if (n_feat == LPS)
-        hipLaunchKernelGGL((grouped_stream_kernel<T, LPS, true, false, true>), dim3((unsigned)nb), dim3(64), lds, ctx->stream,
-                           dc.d_ptrs, n_feat, d_offsets, n_groups, n_rows, sd, d_coeffs, d_flags);
-    else
-        hipLaunchKernelGGL((grouped_stream_kernel<T, LPS, true, false, false>), dim3((unsigned)nb), dim3(64), lds, ctx->stream,
-                           dc.d_ptrs, n_feat, d_offsets, n_groups, n_rows, sd, d_coeffs, d_flags);
+    // the feature count is a compile-time constant of the kernel where that variant exists: every f64 count of this kernel
+    // size, and p == LPS for f32 (a run-time count costs a scalar compare + branch per column and tile: 6 features ran
+    // slower than 8, 3 slower than 4)
+    auto go = [&](auto bias_c, auto pc_c) {
+        hipLaunchKernelGGL((grouped_stream_kernel<T, LPS, true, decltype(bias_c)::value, decltype(pc_c)::value>), dim3((unsigned)nb),
+                           dim3(64), lds, ctx->stream, dc.d_ptrs, n_feat, d_offsets, n_groups, n_rows, sd, d_coeffs, d_flags);
+    };
+    auto by_pc = [&](auto bias_c) {
+        using std::integral_constant;
+        constexpr int LO = LPS == 4 ? 1 : LPS / 2 + 1;  // feature counts served by this kernel size: LO .. LPS
+        if (n_feat == LPS) return go(bias_c, integral_constant<int, LPS>{});
+        if constexpr (sizeof(T) == 8) {
+            if (n_feat == LO) return go(bias_c, integral_constant<int, LO>{});
+            if constexpr (LPS >= 4) {
+                if (n_feat == LO + 1 && LO + 1 < LPS) return go(bias_c, integral_constant<int, (LO + 1 < LPS ? LO + 1 : LPS)>{});
+                if (n_feat == LO + 2 && LO + 2 < LPS) return go(bias_c, integral_constant<int, (LO + 2 < LPS ? LO + 2 : LPS)>{});
+            }
+            if constexpr (LPS == 16) {
+                if (n_feat == 12) return go(bias_c, integral_constant<int, 12>{});
+                if (n_feat == 13) return go(bias_c, integral_constant<int, 13>{});
+                if (n_feat == 14) return go(bias_c, integral_constant<int, 14>{});
+                if (n_feat == 15) return go(bias_c, integral_constant<int, 15>{});
+            }
+        }
+        return go(bias_c, integral_constant<int, 0>{});
+    };
+    if (sd.bias) by_pc(std::true_type{});
+    else by_pc(std::false_type{});
     PDS_HIP_CHECK(hipGetLastError());
     return PDS_OK;
 }
