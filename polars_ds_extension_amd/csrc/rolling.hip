@@ -90,19 +90,23 @@ __device__ __forceinline__ bool finish_row(bool in, const double (&z)[PP], doubl
     return in && fin;
 }
 
-// MODE (0 rolling, 1 expanding totals, 2 expanding main) and FULLP (p == PP, no bias column) are compile-time: the step
+// MODE (0 rolling, 1 expanding totals, 2 expanding main) and FULLP (1: p == PP without a bias column, 2: p == PP - 1 plus the bias column; 0: run time) are compile-time: the step
 // is VALU bound, but the wave-uniform branches on them (a dozen per row fetch, more in the phases) each cost a scalar
 // compare + branch bubble inside it.
-template <typename T, int PP, int MODE, bool FULLP>
+template <typename T, int PP, int MODE, int FULLP>
 __device__ __forceinline__ void rolling_body(const T* const* __restrict__ cols, const RollArgs& ra_in,
                                              double* __restrict__ tile_tot /*[tiles][NV]*/, T* __restrict__ coeffs,
                                              T* __restrict__ pred, uint8_t* __restrict__ valid) {
     RollArgs ra = ra_in;
     ra.mode = MODE;
-    if constexpr (FULLP) {
+    if constexpr (FULLP == 1) {
         ra.p = PP;
         ra.pp = PP;
         ra.bias = 0;
+    } else if constexpr (FULLP == 2) {
+        ra.p = PP - 1;
+        ra.pp = PP;
+        ra.bias = 1;
     }
     constexpr int NG = RollDims<PP>::NG, NV = RollDims<PP>::NV, NSET = RollDims<PP>::NSET, NH = RollDims<PP>::NH;
     static_assert(NH <= 32, "two lanes per moment of a pass");
@@ -333,19 +337,19 @@ __device__ __forceinline__ void rolling_body(const T* const* __restrict__ cols, 
 
 // p' <= 8 is compiled for two waves per SIMD (248 VGPRs, no spills): with the moments passing through LDS in halves
 // the CU then holds 8 waves.  p' >= 10 would spill at that budget (measured 2x slower) and keeps one wave per SIMD.
-template <typename T, int PP, int MODE, bool FULLP>
+template <typename T, int PP, int MODE, int FULLP>
 __global__ __launch_bounds__(kRollWaves * 64) __attribute__((amdgpu_waves_per_eu(PDS_ROLL_WPE))) void rolling_kernel(
     const T* const* __restrict__ cols, RollArgs ra, double* __restrict__ tile_tot, T* __restrict__ coeffs, T* __restrict__ pred,
     uint8_t* __restrict__ valid) {
     rolling_body<T, PP, MODE, FULLP>(cols, ra, tile_tot, coeffs, pred, valid);
 }
-template <typename T, int PP, int MODE, bool FULLP>
+template <typename T, int PP, int MODE, int FULLP>
 __global__ __launch_bounds__(kRollWaves * 64) void rolling_kernel_1w(const T* const* __restrict__ cols, RollArgs ra,
                                                                      double* __restrict__ tile_tot, T* __restrict__ coeffs,
                                                                      T* __restrict__ pred, uint8_t* __restrict__ valid) {
     rolling_body<T, PP, MODE, FULLP>(cols, ra, tile_tot, coeffs, pred, valid);
 }
-template <typename T, int PP, int MODE, bool FULLP>
+template <typename T, int PP, int MODE, int FULLP>
 static auto roll_kernel_ptr() {
     if constexpr (PP >= 10) return &rolling_kernel_1w<T, PP, MODE, FULLP>;
     else return &rolling_kernel<T, PP, MODE, FULLP>;
@@ -398,7 +402,7 @@ __global__ __launch_bounds__(kPrefixWaves * 64) void tile_prefix_kernel(double* 
     }
 }
 
-template <typename T, int PP, bool FULLP>
+template <typename T, int PP, int FULLP>
 static int launch_pp_f(pds_ctx* ctx, const DeviceCols<T>& dc, RollArgs ra, bool expanding, const double* seed_moments,
                        T* d_coeffs, T* d_pred, uint8_t* d_valid) {
     constexpr int NV = RollDims<PP>::NV;
@@ -453,8 +457,9 @@ static int launch_pp_f(pds_ctx* ctx, const DeviceCols<T>& dc, RollArgs ra, bool 
 template <typename T, int PP>
 static int launch_pp(pds_ctx* ctx, const DeviceCols<T>& dc, RollArgs ra, bool expanding, const double* seed_moments,
                      T* d_coeffs, T* d_pred, uint8_t* d_valid) {
-    if (ra.p == PP && !ra.bias) return launch_pp_f<T, PP, true>(ctx, dc, ra, expanding, seed_moments, d_coeffs, d_pred, d_valid);
-    return launch_pp_f<T, PP, false>(ctx, dc, ra, expanding, seed_moments, d_coeffs, d_pred, d_valid);
+    if (ra.p == PP && !ra.bias) return launch_pp_f<T, PP, 1>(ctx, dc, ra, expanding, seed_moments, d_coeffs, d_pred, d_valid);
+    if (ra.p == PP - 1 && ra.bias) return launch_pp_f<T, PP, 2>(ctx, dc, ra, expanding, seed_moments, d_coeffs, d_pred, d_valid);
+    return launch_pp_f<T, PP, 0>(ctx, dc, ra, expanding, seed_moments, d_coeffs, d_pred, d_valid);
 }
 
 template <typename T>
