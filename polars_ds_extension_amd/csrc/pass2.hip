@@ -27,8 +27,9 @@ struct V16<float> {
 
 constexpr int kP2Threads = 256;
 
-// P16: exactly 16 features, known at compile time (the per-column `c < p` scalar branches in the row loop fold away)
-template <typename T, bool WEIGHTED, int HC, bool P16>
+// PC: the feature count as a compile-time constant (16, 8, 4, 2, 1; 0 = run time): the per-column `c < p` scalar branches
+// in the row loop fold away
+template <typename T, bool WEIGHTED, int HC, int PC>
 __global__ __launch_bounds__(kP2Threads) void pass2_kernel(const T* const* __restrict__ cols, int p_arg, int bias,
                                                            int64_t n, const T* __restrict__ beta,
                                                            const T* __restrict__ inv, T* __restrict__ pred_out,
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(kP2Threads) void pass2_kernel(const T* const* __res
                                                            double* __restrict__ partials) {
     using V = typename V16<T>::type;
     constexpr int RPL = V16<T>::RPL;
-    const int p = P16 ? 16 : p_arg;
+    const int p = PC ? PC : p_arg;
     const int pp = p + bias;
     double sse = 0.0, wsse = 0.0;
     // loop-invariant, wave-uniform: column pointers and coefficients live in SGPRs
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(kP2Threads) void leverage_scale_wide_kernel(const T
     }
 }
 
-template <typename T, bool W, bool P16>
+template <typename T, bool W, int P16>
 static void launch_p2_w(int hc, dim3 g, hipStream_t st, const T* const* cols, int p, int bias, int64_t n, const T* beta,
                         const T* inv, T* pred, T* resid, T* s, double* partials) {
     switch (hc) {
@@ -254,8 +255,14 @@ static void launch_p2_w(int hc, dim3 g, hipStream_t st, const T* const* cols, in
 template <typename T, bool W>
 static void launch_p2(int hc, dim3 g, hipStream_t st, const T* const* cols, int p, int bias, int64_t n, const T* beta,
                       const T* inv, T* pred, T* resid, T* s, double* partials) {
-    if (p == 16) launch_p2_w<T, W, true>(hc, g, st, cols, p, bias, n, beta, inv, pred, resid, s, partials);
-    else launch_p2_w<T, W, false>(hc, g, st, cols, p, bias, n, beta, inv, pred, resid, s, partials);
+    switch (p) {
+        case 16: launch_p2_w<T, W, 16>(hc, g, st, cols, p, bias, n, beta, inv, pred, resid, s, partials); break;
+        case 8: launch_p2_w<T, W, 8>(hc, g, st, cols, p, bias, n, beta, inv, pred, resid, s, partials); break;
+        case 4: launch_p2_w<T, W, 4>(hc, g, st, cols, p, bias, n, beta, inv, pred, resid, s, partials); break;
+        case 2: launch_p2_w<T, W, 2>(hc, g, st, cols, p, bias, n, beta, inv, pred, resid, s, partials); break;
+        case 1: launch_p2_w<T, W, 1>(hc, g, st, cols, p, bias, n, beta, inv, pred, resid, s, partials); break;
+        default: launch_p2_w<T, W, 0>(hc, g, st, cols, p, bias, n, beta, inv, pred, resid, s, partials); break;
+    }
 }
 
 // d_meat: when hc_mode != 0 the caller passes a device buffer of n_rows T values in d_meat (reused as
