@@ -229,6 +229,71 @@ def test_pl_recursive_lr_null_policies(so, orc):
 
 
 @pytest.mark.gpu
+def test_borrowed_chunks_slices_and_bitmaps(so, orc):
+    """A single Float64 chunk is read in place (no marshalling copy): slices (offset != 0), validity bitmaps at bit offsets
+    that are not byte aligned, several chunks of odd lengths -- and a fill policy never writes into the caller's buffers."""
+    rng = np.random.default_rng(77)
+    n = 5000
+    X = rng.normal(size=(n + 11, 3))
+    y = X @ [1.0, -2.0, 0.5] + 0.1 * rng.normal(size=n + 11)
+    mask = rng.random(n + 11) < 0.03
+    for off in (3, 8, 11):  # bit offsets 3 and 11 take the bit loop, 8 the byte-copy path
+        ins = [("y", pa.array(y).slice(off, n)), ("x1", pa.array(X[:, 0], mask=mask).slice(off, n)),
+               ("x2", pa.array(X[:, 1]).slice(off, n)), ("x3", pa.array(X[:, 2]).slice(off, n))]
+        _, out = ph.call_plugin(so, "pl_lr", ins, dict(LR, null_policy="skip"))
+        m = ~mask[off:off + n]
+        ref = orc.pl_lr(X[off:off + n][m], y[off:off + n][m])
+        np.testing.assert_allclose(out[0].as_py(), ref, rtol=1e-10)
+        _, out = ph.call_plugin(so, "pl_lr_pred", ins, dict(LR, null_policy="skip"))
+        pred = out.field("pred").to_pylist()
+        assert [v is None for v in pred] == list(~m)
+        np.testing.assert_allclose(np.array([v for v in pred if v is not None]), X[off:off + n][m] @ ref, rtol=1e-9, atol=1e-11)
+    # chunks of 13 / 1001 / rest rows with nulls in every chunk
+    cuts = [0, 13, 1014, n]
+    xa = pa.array(X[:n, 0], mask=mask[:n])
+    ins = [("y", pa.chunked_array([pa.array(y[a:b]) for a, b in zip(cuts, cuts[1:])])),
+           ("x1", pa.chunked_array([xa.slice(a, b - a) for a, b in zip(cuts, cuts[1:])])),
+           ("x2", pa.array(X[:n, 1])), ("x3", pa.array(X[:n, 2]))]
+    _, out = ph.call_plugin(so, "pl_lr", ins, dict(LR, null_policy="skip"))
+    m = ~mask[:n]
+    np.testing.assert_allclose(out[0].as_py(), orc.pl_lr(X[:n][m], y[:n][m]), rtol=1e-10)
+    # fill policies rewrite a private copy: the engine's buffers are untouched
+    x1 = pa.array(X[:n, 0], mask=mask[:n])
+    raw_before = np.frombuffer(x1.buffers()[1], dtype=np.float64).copy()
+    ins = [("y", pa.array(y[:n])), ("x1", x1), ("x2", pa.array(X[:n, 1]))]
+    _, out = ph.call_plugin(so, "pl_rolling_lr", ins, {"null_policy": "zero", "n": 50, "bias": False, "lambda": 0.0, "min_size": 2})
+    assert len(out) == n
+    _, out = ph.call_plugin(so, "pl_recursive_lr", ins, {"null_policy": "1.5", "n": 50, "bias": False, "lambda": 0.0, "min_size": 0})
+    assert len(out) == n
+    assert np.array_equal(np.frombuffer(x1.buffers()[1], dtype=np.float64), raw_before)
+
+
+@pytest.mark.gpu
+def test_pl_lr_by_int64_keys_are_exact(so, orc):
+    # keys beyond 2^53 (not representable as f64) and negative keys keep their identity, in any row order
+    rng = np.random.default_rng(5)
+    base = np.array([(1 << 60) + 1, (1 << 60) + 2, (1 << 60) + 3, -(1 << 61), -5, 0, 9007199254740993], dtype=np.int64)
+    per = 40
+    key = np.repeat(base, per)
+    X = rng.normal(size=(len(key), 2))
+    y = X @ [2.0, -1.0] + 0.05 * rng.normal(size=len(key)) + np.repeat(np.arange(len(base)), per)
+    perm = rng.permutation(len(key))
+    for order in (np.arange(len(key)), perm):
+        _, out = ph.call_plugin(so, "pl_lr_by", [("key", pa.array(key[order]))] + _cols(X[order], y[order]), dict(LR, bias=True))
+        res = out.to_pylist()
+        want = sorted(base.tolist()) if order is perm else None
+        got = [r["key"] for r in res]
+        assert sorted(got) == sorted(base.tolist()) and (want is None or got == want)
+        for r in res:
+            m = key == r["key"]
+            np.testing.assert_allclose(r["coeffs"], orc.pl_lr(X[m], y[m], add_bias=True), rtol=1e-9, atol=1e-11)
+    # Int32 keys are widened
+    k32 = np.repeat(np.array([5, -7, 100], dtype=np.int32), per)
+    _, out = ph.call_plugin(so, "pl_lr_by", [("key", pa.array(k32))] + _cols(X[:3 * per], y[:3 * per]), LR)
+    assert [r["key"] for r in out.to_pylist()] == [-7, 5, 100] or [r["key"] for r in out.to_pylist()] == [5, -7, 100]
+
+
+@pytest.mark.gpu
 def test_pl_lr_by_matches_per_group_calls(so, orc):
     # tests/test_linear_exprs.py:918-953: the batched path == one pl_lr call per group
     rng = np.random.default_rng(0)

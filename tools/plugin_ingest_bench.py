@@ -1,0 +1,61 @@
+"""
+Host-frame ingestion through the plugin boundary: wall time of `_polars_plugin_pl_lr` on an N x p Float64 frame that
+lives in (pageable) host memory as single Arrow chunks -- what Polars hands over in select() context.  Separates the
+marshalling cost (reference: series_to_slice_inner's memcpy, src/utils/mod.rs:101-206) from the H2D copy and the kernels.
+
+  python tools/plugin_ingest_bench.py [n_rows] [n_feat] [path/to/lib.so]
+"""
+import ctypes as C
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import pyarrow as pa
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+import plugin_harness as ph  # noqa: E402
+
+
+def main():
+    n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 20_000_000
+    p = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    import torch  # noqa: F401  (one HIP runtime per process, see _lib.load)
+
+    lib = C.CDLL(sys.argv[3]) if len(sys.argv) > 3 else __import__("polars_ds_extension_amd._lib", fromlist=["load"]).load()
+    rng = np.random.default_rng(0)
+    X = rng.random((p, n))
+    y = X.T @ np.linspace(-1, 1, p) + 0.01 * rng.normal(size=n)
+    ins = [("y", pa.array(y))] + [(f"x{j}", pa.array(X[j])) for j in range(p)]
+    kw = {"bias": False, "null_policy": "raise", "l1_reg": 0.0, "l2_reg": 0.0, "solver": "qr", "tol": 1e-5, "max_iter": 200,
+          "weighted": False, "positive": False, "singular_x_tol": 1e-12}
+    gb = n * (p + 1) * 8 / 1e9
+    for policy in ("raise", "skip"):
+        kw["null_policy"] = policy
+        ph.call_plugin(lib, "pl_lr", ins, kw)
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            _, out = ph.call_plugin(lib, "pl_lr", ins, kw)
+            ts.append(time.perf_counter() - t0)
+        t = float(np.median(ts))
+        print(f"pl_lr host frame {n} x {p} f64 ({gb:.2f} GB) null_policy={policy}: {t * 1e3:.1f} ms  = {gb / t:.1f} GB/s end to end", flush=True)
+    # with a null in one column (bitmap import + device-side policy)
+    mask = np.zeros(n, dtype=bool)
+    mask[::1000] = True
+    ins2 = [ins[0], ("x0", pa.array(X[0], mask=mask))] + ins[2:]
+    kw["null_policy"] = "skip"
+    ph.call_plugin(lib, "pl_lr", ins2, kw)
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        ph.call_plugin(lib, "pl_lr", ins2, kw)
+        ts.append(time.perf_counter() - t0)
+    t = float(np.median(ts))
+    print(f"  with nulls in one column: {t * 1e3:.1f} ms = {gb / t:.1f} GB/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
