@@ -17,6 +17,7 @@ from .lstsq import (  # noqa: F401
     lin_reg_from_moments,
     lin_reg_report,
     lin_reg_w_rcond,
+    query_ar_coeffs,
     recursive_lin_reg,
     rolling_lin_reg,
 )

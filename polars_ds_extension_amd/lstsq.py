@@ -21,7 +21,7 @@ from . import _lib, config
 
 __all__ = [
     "Context", "default_context", "lin_reg", "lin_reg_report", "lin_reg_by", "rolling_lin_reg",
-    "recursive_lin_reg", "lin_reg_w_rcond", "gram_moments", "lin_reg_from_moments",
+    "recursive_lin_reg", "lin_reg_w_rcond", "gram_moments", "lin_reg_from_moments", "query_ar_coeffs",
 ]
 
 
@@ -328,6 +328,37 @@ def _lin_reg_multi(x, targets, add_bias, return_pred, l2_reg, solver, singular_x
             out[f"target_{i}_resid"] = resid[i]
         return out
     return {f"target_{i}": (None if is_null.value else coeffs[i]) for i in range(k)}
+
+
+def query_ar_coeffs(x, lag: int, add_bias: bool = True, null_policy: str = "raise", ctx: Context | None = None):
+    """
+    Autoregressive coefficients of order `lag` (python/polars_ds/exprs/ts_features.py:419-461): `lin_reg` of x[t] on
+    x[t-1] ... x[t-lag] over t = lag ... n-1, bias last.  The lagged features are *views* into the one series (the
+    reference builds them with shift + slice): numpy / torch slices and pyarrow slices carry only a pointer and a bit
+    offset, so no column is copied on the way to the Gram kernel, which reads element-aligned pointers.
+    """
+    if null_policy not in ("raise", "one", "zero"):
+        import math
+
+        try:
+            z = float(null_policy)
+            if not math.isfinite(z):
+                raise ValueError
+        except (TypeError, ValueError):
+            raise ValueError("`null_polocy` must be 'raise', 'one', 'zero' or any finite numeric string for AR coefficients.") from None
+    if lag <= 0:
+        raise ValueError("`lag` must be > 0.")
+    n = len(x)
+    m = max(n - lag, 0)
+    if _is_arrow(x):
+        import pyarrow as pa
+
+        if isinstance(x, pa.ChunkedArray):
+            x = x.combine_chunks() if x.num_chunks != 1 else x.chunk(0)
+        feats = [x.slice(lag - i, m) for i in range(1, lag + 1)]
+        return lin_reg(*feats, target=x.slice(lag, m), add_bias=add_bias, null_policy=null_policy, ctx=ctx)
+    feats = [x[lag - i : n - i] for i in range(1, lag + 1)]
+    return lin_reg(*feats, target=x[lag:], add_bias=add_bias, null_policy=null_policy, ctx=ctx)
 
 
 def lin_reg_w_rcond(*x, target, add_bias: bool = False, rcond: float = 0.0, l2_reg: float = 0.0, ctx: Context | None = None):

@@ -122,3 +122,21 @@ def recursive_lin_reg(*x, target, start_with: int, add_bias: bool = False, l2_re
     kwargs = {"null_policy": null_policy, "n": start_with, "bias": add_bias, "lambda": abs(l2_reg), "min_size": 0}
     cols = [_formula(target).cast(_dtype())] + [_formula(z) for z in x]
     return _plugin("pl_recursive_lr", cols, kwargs).alias("recursive_lin_reg")
+
+
+def query_ar_coeffs(x, lag: int, add_bias: bool = True, null_policy: str = "raise"):
+    """exprs/ts_features.py:419-461: AR(lag) coefficients = lin_reg on shifted slices of the one series, bias last."""
+    if null_policy not in ("raise", "one", "zero"):
+        import math
+
+        try:
+            if not math.isfinite(float(null_policy)):
+                raise ValueError
+        except (TypeError, ValueError):
+            raise ValueError("`null_polocy` must be 'raise', 'one', 'zero' or any finite numeric string for AR coefficients.") from None
+    if lag <= 0:
+        raise ValueError("`lag` must be > 0.")
+    pl = _pl()
+    xx = pl.col(x) if isinstance(x, str) else x
+    return lin_reg(*[xx.shift(i).slice(offset=lag).alias(str(i)) for i in range(1, lag + 1)], target=xx.slice(offset=lag),
+                   add_bias=add_bias, null_policy=null_policy)

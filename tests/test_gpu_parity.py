@@ -1128,3 +1128,92 @@ def test_wide_pred_and_report(pds, orc):
     ro = orc.lin_reg_report(np.c_[X, np.ones(n)], y)
     assert nrel(r["beta"], ro["beta"]) < F64_TOL and frel(r["std_err"], ro["std_err"], 1e-12) < F64_TOL
     assert frel(r["p>|t|"], ro["p"], 1e-12) < 1e-8 and abs(r["r2"][0] - ro["r2"]) < 1e-12
+
+
+def _ar_design(x, lag, bias):
+    n = len(x)
+    A = np.column_stack([x[lag - i : n - i] for i in range(1, lag + 1)] + ([np.ones(n - lag)] if bias else []))
+    return A, x[lag:]
+
+
+@pytest.mark.parametrize("lag,bias", [(1, True), (3, True), (5, False), (16, True)])
+def test_query_ar_coeffs(pds, lag, bias):
+    """exprs/ts_features.py:419-461 (SURVEY 8f rank 4 consumer): lin_reg on lagged views of ONE series -- the feature columns
+    are pointers 8 bytes apart into the same buffer, on the host and in HBM."""
+    rng = np.random.default_rng(40 + lag)
+    n = 200_003
+    phi = 0.5 ** np.arange(1, lag + 1) * (-1.0) ** np.arange(lag)
+    from scipy.signal import lfilter
+
+    x = lfilter([1.0], np.concatenate([[1.0], -phi]), 0.3 + rng.normal(size=n))  # AR(lag) process
+    A, b = _ar_design(x, lag, bias)
+    ref = np.linalg.lstsq(A, b, rcond=None)[0]
+    assert nrel(pds.query_ar_coeffs(x, lag, add_bias=bias), ref) < F64_TOL
+    assert nrel(pds.query_ar_coeffs(dev(x), lag, add_bias=bias), ref) < F64_TOL
+    with pytest.raises(ValueError, match="lag"):
+        pds.query_ar_coeffs(x, 0)
+    with pytest.raises(ValueError, match="null_polocy"):
+        pds.query_ar_coeffs(x, 2, null_policy="skip")
+
+
+def test_query_ar_coeffs_arrow_nulls(pds):
+    import pyarrow as pa
+
+    rng = np.random.default_rng(9)
+    n, lag = 50_000, 4
+    x = np.cumsum(rng.normal(size=n)) * 0.01 + rng.normal(size=n)
+    mask = rng.random(n) < 0.01
+    mask[:lag] = False
+    xa = pa.array(x, mask=mask)
+    with pytest.raises(Exception, match="Nulls found"):
+        pds.query_ar_coeffs(xa, lag)
+    # "zero": null features become 0, rows whose target is null are dropped (series_to_mat_for_lr :211-240)
+    xz = np.where(mask, 0.0, x)
+    A, b = _ar_design(xz, lag, True)
+    keep = ~mask[lag:]
+    ref = np.linalg.lstsq(A[keep], b[keep], rcond=None)[0]
+    assert nrel(pds.query_ar_coeffs(xa, lag, null_policy="zero"), ref) < F64_TOL
+
+
+def test_device_columns_at_element_alignment(pds, orc):
+    """Arrow slices put column starts at any multiple of the element size: every kernel takes 8-byte (f64) / 4-byte (f32)
+    aligned device pointers.  Results equal those on 256-byte aligned clones of the same data."""
+    import torch
+
+    rng = np.random.default_rng(123)
+    n, p = 70_001, 5
+    X, y, _ = make_xy(rng, n, p)
+    big = [torch.from_numpy(np.concatenate([np.zeros(j + 1), X[:, j]])).cuda() for j in range(p)]
+    xs_u = [b[j + 1 :] for j, b in enumerate(big)]           # starts 8, 16, 24 ... bytes past an allocation boundary
+    yb = torch.from_numpy(np.concatenate([np.zeros(3), y])).cuda()
+    y_u = yb[3:]
+    xs_a, y_a = cols_of(X), dev(y)
+    assert any(t.data_ptr() % 16 for t in xs_u) and y_u.data_ptr() % 16 == 8
+    for bias in (False, True):
+        assert nrel(pds.lin_reg(*xs_u, target=y_u, add_bias=bias), pds.lin_reg(*xs_a, target=y_a, add_bias=bias)) < 1e-13
+        pu, ru = pds.lin_reg(*xs_u, target=y_u, add_bias=bias, return_pred=True)
+        pa_, ra = pds.lin_reg(*xs_a, target=y_a, add_bias=bias, return_pred=True)
+        assert nrel(pu.cpu().numpy(), pa_.cpu().numpy()) < 1e-13 and nrel(ru.cpu().numpy(), ra.cpu().numpy()) < 1e-9
+    ru = pds.lin_reg_report(*xs_u, target=y_u, add_bias=True, std_err="hc1")
+    ra = pds.lin_reg_report(*xs_a, target=y_a, add_bias=True, std_err="hc1")
+    for k in ("beta", "hc1_se", "t"):
+        assert nrel(ru[k], ra[k]) < 1e-10
+    cu, pu, vu = pds.rolling_lin_reg(*xs_u, target=y_u, window_size=64, add_bias=True)
+    ca, pa2, va = pds.rolling_lin_reg(*xs_a, target=y_a, window_size=64, add_bias=True)
+    assert torch.equal(vu, va) and nrel(cu[63:].cpu().numpy(), ca[63:].cpu().numpy()) < 1e-12
+    off = np.arange(0, n, 97, dtype=np.int64)
+    off = np.concatenate([off, [n]]) if off[-1] != n else off
+    cu, nu = pds.lin_reg_by(*xs_u, target=y_u, group_offsets=off)
+    ca, na = pds.lin_reg_by(*xs_a, target=y_a, group_offsets=off)
+    assert torch.equal(nu, na) and nrel(cu.cpu().numpy(), ca.cpu().numpy()) < 1e-12
+    # f32: 4-byte aligned starts
+    pds.config.LIN_REG_EXPR_F64 = False
+    try:
+        big32 = [torch.from_numpy(np.concatenate([np.zeros(j + 1), X[:, j]]).astype(np.float32)).cuda() for j in range(p)]
+        xs32 = [b[j + 1 :] for j, b in enumerate(big32)]
+        y32 = torch.from_numpy(np.concatenate([np.zeros(1), y]).astype(np.float32)).cuda()[1:]
+        got = pds.lin_reg(*xs32, target=y32)
+        want = pds.lin_reg(*[t.clone() for t in xs32], target=y32.clone())
+        assert nrel(got, want) < 1e-6
+    finally:
+        pds.config.LIN_REG_EXPR_F64 = True
