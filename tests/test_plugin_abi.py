@@ -55,6 +55,81 @@ def test_coalescing_queue_fails_cleanly_without_a_device(so):
     so._polars_plugin_get_last_error_message.restype = C.c_char_p
 
 
+def _debug_import(so, arr, kind=0):
+    """Series import of csrc/plugin.cpp without a device: (values, valid, null_count, borrowed)."""
+    se, keep = ph._export_series("c", arr)
+    n = len(arr)
+    dt = {0: np.float64, 1: np.float32, 2: np.int64}[kind]
+    vals = np.full(n, -777, dtype=dt)
+    valid = np.full(n, 9, dtype=np.uint8)
+    nulls, borrowed = C.c_longlong(-1), C.c_int(-1)
+    so.pds_plugin_debug_import.restype = C.c_longlong
+    so.pds_plugin_debug_import.argtypes = [C.POINTER(ph.SeriesExport), C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_longlong),
+                                           C.POINTER(C.c_int)]
+    try:
+        got = so.pds_plugin_debug_import(C.byref(se), kind, vals.ctypes.data, valid.ctypes.data, C.byref(nulls), C.byref(borrowed))
+    finally:
+        ph._release_inputs([keep])
+    if got < 0:
+        so._polars_plugin_get_last_error_message.restype = C.c_char_p
+        raise ph.PluginFailure(so._polars_plugin_get_last_error_message().decode())
+    assert got == n
+    return vals, valid.astype(bool), nulls.value, bool(borrowed.value)
+
+
+def test_series_import_borrows_single_chunks_and_reads_bitmaps(so):
+    """Host logic of the ingestion (series_to_slice_inner's role, src/utils/mod.rs:101-206): one chunk of the working dtype
+    is borrowed, everything else gathered + cast; validity at any bit offset, across chunks of any length."""
+    rng = np.random.default_rng(11)
+    n = 1000
+    x = rng.normal(size=n + 70)
+    mask = rng.random(n + 70) < 0.2
+    full = pa.array(x, mask=mask)
+    for off in list(range(0, 18)) + [63, 64, 65]:
+        for ln in (0, 1, 7, 8, 9, 63, 64, 65, n):
+            a = full.slice(off, ln)
+            vals, valid, nulls, borrowed = _debug_import(so, a)
+            want_valid = ~mask[off:off + ln]
+            assert borrowed and np.array_equal(valid, want_valid) and nulls == int((~want_valid).sum())
+            assert np.array_equal(vals[valid], x[off:off + ln][want_valid])
+    # several chunks (odd lengths, with and without nulls, sliced) are gathered; bits land at their global positions
+    for _ in range(20):
+        cuts = np.sort(rng.integers(0, n, size=rng.integers(1, 6)))
+        cuts = np.concatenate([[0], cuts, [n]])
+        chunks = []
+        for a, b in zip(cuts, cuts[1:]):
+            ch = pa.array(x[a:b], mask=mask[a:b]) if rng.random() < 0.7 else pa.array(np.where(mask[a:b], 0.0, x[a:b]))
+            chunks.append((ch, a, b, ch.null_count > 0 or not mask[a:b].any()))
+        arr = pa.chunked_array([c[0] for c in chunks], type=pa.float64())
+        vals, valid, nulls, borrowed = _debug_import(so, arr)
+        want_valid = np.ones(n, dtype=bool)
+        want_vals = x[:n].copy()
+        for ch, a, b, _ in chunks:
+            if ch.null_count:
+                want_valid[a:b] = ~mask[a:b]
+            else:
+                want_vals[a:b] = ch.to_numpy(zero_copy_only=False)  # (masked values were written as 0.0 or kept as they are)
+        assert borrowed == (len(chunks) == 1) and np.array_equal(valid, want_valid) and nulls == int((~want_valid).sum())
+        assert np.array_equal(vals[valid], want_vals[want_valid])
+    # casts: every integer width and the other float width; f32 target; int64 keys stay exact and are borrowed
+    for dt in (np.int8, np.int16, np.int32, np.int64, np.uint8, np.uint16, np.uint32, np.uint64, np.float32):
+        v = rng.integers(0, 100, size=50).astype(dt)
+        vals, valid, nulls, borrowed = _debug_import(so, pa.array(v).slice(3, 40))
+        assert not borrowed and nulls == 0 and valid.all() and np.array_equal(vals, v[3:43].astype(np.float64))
+    v32 = rng.normal(size=64).astype(np.float32)
+    vals, _, _, borrowed = _debug_import(so, pa.array(v32).slice(5), kind=1)
+    assert borrowed and np.array_equal(vals, v32[5:])
+    vals, _, _, borrowed = _debug_import(so, pa.array(x[:64]), kind=1)
+    assert not borrowed and np.array_equal(vals, x[:64].astype(np.float32))
+    keys = np.array([(1 << 62) + 1, -(1 << 62) - 3, 9007199254740993, 0], dtype=np.int64)
+    vals, _, _, borrowed = _debug_import(so, pa.array(keys), kind=2)
+    assert borrowed and np.array_equal(vals, keys)
+    vals, _, _, borrowed = _debug_import(so, pa.array(keys.astype(np.int32) % 1000), kind=2)
+    assert not borrowed and np.array_equal(vals, (keys.astype(np.int32) % 1000).astype(np.int64))
+    with pytest.raises(ph.PluginFailure, match="non-numeric"):
+        _debug_import(so, pa.array(["a", "b"]))
+
+
 def test_kwargs_pickle_parser(so):
     # the exact dicts python/polars_ds/exprs/expr_linear.py builds (:237-248, :546-552)
     lr_kwargs = {"bias": True, "null_policy": "skip", "l1_reg": 0.0, "l2_reg": 0.25, "solver": "qr", "tol": 1e-5,
