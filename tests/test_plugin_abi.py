@@ -130,6 +130,36 @@ def test_series_import_borrows_single_chunks_and_reads_bitmaps(so):
         _debug_import(so, pa.array(["a", "b"]))
 
 
+def test_result_export_takes_over_device_written_rows(so):
+    """Rolling / recursive results: the n x p' block the device wrote becomes the List values buffer as it is -- leading
+    invalid rows are skipped by the buffer start, invalid rows in the middle closed up in place; validity bits packed 8 at a time."""
+    rng = np.random.default_rng(4)
+    for n, width, lead, holes in [(0, 3, 0, 0), (1, 2, 1, 0), (1, 2, 0, 0), (37, 3, 0, 0), (37, 3, 5, 0), (64, 1, 7, 9), (1001, 9, 255, 40),
+                                  (513, 4, 513, 0), (130, 2, 0, 130)]:
+        rows = rng.normal(size=(n, width))
+        flags = np.ones(n, dtype=np.uint8)
+        flags[:lead] = 0
+        if holes and n > lead:
+            flags[rng.choice(np.arange(lead, n), size=min(holes, n - lead), replace=False)] = 0
+        flags[flags > 0] = rng.choice([1, 2, 255], size=int((flags > 0).sum()))  # any non-zero byte means valid
+        ret = ph.SeriesExport()
+        so.pds_plugin_debug_export_rows.restype = None
+        so.pds_plugin_debug_export_rows.argtypes = [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.POINTER(ph.SeriesExport)]
+        so.pds_plugin_debug_export_rows(rows.ctypes.data, n, width, flags.ctypes.data, C.byref(ret))
+        assert ret.release
+        field = pa.Field._import_from_c(C.addressof(ret.field.contents))
+        out = pa.Array._import_from_c(C.addressof(ret.arrays[0].contents), field.type)
+        C.CFUNCTYPE(None, C.POINTER(ph.SeriesExport))(ret.release)(C.byref(ret))
+        out.validate(full=True)
+        got = out.to_pylist()
+        assert len(got) == n
+        for i in range(n):
+            if flags[i]:
+                assert got[i]["coeffs"] == rows[i].tolist() and got[i]["pred"] == rows[i, 0]
+            else:
+                assert got[i]["coeffs"] is None and got[i]["pred"] is None
+
+
 def test_kwargs_pickle_parser(so):
     # the exact dicts python/polars_ds/exprs/expr_linear.py builds (:237-248, :546-552)
     lr_kwargs = {"bias": True, "null_policy": "skip", "l1_reg": 0.0, "l2_reg": 0.25, "solver": "qr", "tol": 1e-5,

@@ -56,6 +56,22 @@ def main():
     t = float(np.median(ts))
     print(f"  with nulls in one column: {t * 1e3:.1f} ms = {gb / t:.1f} GB/s", flush=True)
 
+    # results as large as the inputs: rolling fit (N x p coefficients + pred back to the host) and pred / resid
+    nr = min(n, 10_000_000)
+    ins_r = [(nm, a.slice(0, nr)) for nm, a in ins]
+    kr = {"null_policy": "raise", "n": 256, "bias": False, "lambda": 0.0, "min_size": p}
+    gb_r = nr * ((p + 1) * 8 + (p + 1) * 8 + 8) / 1e9
+    for sym, kwargs, gbs in (("pl_rolling_lr", kr, gb_r), ("pl_lr_pred", dict(kw, null_policy="raise"), nr * (p + 3) * 8 / 1e9)):
+        ph.call_plugin(lib, sym, ins_r, kwargs)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            _, out = ph.call_plugin(lib, sym, ins_r, kwargs)
+            ts.append(time.perf_counter() - t0)
+            del out
+        t = float(np.median(ts))
+        print(f"{sym} host frame {nr} x {p}: {t * 1e3:.1f} ms = {gbs / t:.1f} GB/s (in + out bytes) end to end", flush=True)
+
 
 if __name__ == "__main__":
     main()
