@@ -351,7 +351,10 @@ _KEEP = []  # CFUNCTYPE objects must outlive the library
 
 def load():
     """Build (if stale) and load the mock plugin library with every entry point bound.  Returns the CDLL."""
-    lib = C.CDLL(str(_build.build()))
+    import os
+
+    # (PDS_MOCK_LIB: a sanitizer build of the same sources, see tests/mock_device/sanitize.sh)
+    lib = C.CDLL(os.environ.get("PDS_MOCK_LIB") or str(_build.build()))
     lib.mock_set_error.argtypes = [C.c_char_p]
     impl = {}
     impl.update(make_callbacks("f64"))
