@@ -182,6 +182,36 @@ def test_kwargs_pickle_parser(so):
                 assert got[k] == f"'{v}'"
 
 
+def test_kwargs_parser_rejects_garbage_without_crashing(so):
+    """Mutated / truncated / random byte strings: the parser answers 0 or an error code, never reads out of bounds
+    (tests/mock_device/sanitize.sh runs the same sources under ASan + UBSan)."""
+    import random
+
+    rnd = random.Random(7)
+    base = [pickle.dumps(d, protocol=pr) for pr in (2, 3, 4, 5) for d in (
+        {"bias": True, "null_policy": "skip", "l1_reg": 0.0, "l2_reg": 0.25, "solver": "qr", "tol": 1e-5, "max_iter": 200},
+        {"null_policy": "0.5", "n": 256, "bias": False, "lambda": 0.1, "min_size": 70000},
+        {"n": -3, "huge": 2**63 - 1, "neg": -2**63, "s": "x" * 300, "f": -1.5e300, "none": None}, {})]
+    out = C.create_string_buffer(1 << 14)
+    outcomes = set()
+    for _ in range(20_000):
+        b = bytearray(rnd.choice(base))
+        r = rnd.random()
+        if r < 0.4:
+            for _ in range(rnd.randint(1, 4)):
+                b[rnd.randrange(len(b))] = rnd.randrange(256)
+        elif r < 0.6:
+            b = b[: rnd.randrange(len(b) + 1)]
+        elif r < 0.8:
+            pos = rnd.randrange(len(b) + 1)
+            b[pos:pos] = bytes(rnd.randrange(256) for _ in range(rnd.randint(1, 8)))
+        else:
+            b = bytearray(rnd.randrange(256) for _ in range(rnd.randint(0, 64)))
+        buf = (C.c_uint8 * max(len(b), 1)).from_buffer_copy(bytes(b) or b"\0")
+        outcomes.add(so.pds_plugin_debug_parse_kwargs(buf, len(b), out, len(out)))
+    assert outcomes <= {0, -1, -2} and {0, -1} <= outcomes
+
+
 def test_output_fields(so):
     f = ph.output_field(so, "pl_lr")
     assert f.name == "coeffs" and f.type == pa.large_list(pa.field("item", pa.float64()))
