@@ -89,6 +89,9 @@ __global__ __launch_bounds__(kWThreads, 2) void moments_wide_kernel(const T* con
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* LI = reinterpret_cast<T*>(smem);
     T* LJ = LI + kWB * CS;
+#ifdef PDS_WIDE_DB
+    T* const lds_base = LI;  // two stage buffers of 2 * kWB * CS elements each, used alternately (one barrier per stage)
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     constexpr bool NARROW = MODE == 1, FUSE = MODE == 2;
@@ -214,6 +217,7 @@ __global__ __launch_bounds__(kWThreads, 2) void moments_wide_kernel(const T* con
                 for (int r = 0; r < 16; ++r) accf[m][nn][r] = 0.f;
     }
     const T* PJ = diag ? LI : LJ;
+    (void)PJ;
     const bool tailwave = FUSE && diag && wave == 2;
     auto mma_tail = [&]() __attribute__((always_inline)) {
         if constexpr (FUSE) {
@@ -278,9 +282,23 @@ __global__ __launch_bounds__(kWThreads, 2) void moments_wide_kernel(const T* con
     };
     if (r_begin < r_end) load_stage(r_begin);
     for (int64_t row0 = r_begin; row0 < r_end; row0 += KC) {
+#ifdef PDS_WIDE_DB
+        // EXPERIMENT (unmeasured): stage s parks its panel in buffer s & 1.  A wave that is still multiplying stage s - 1 reads
+        // the other buffer; nobody reads this one any more, because every wave passed stage s - 1's barrier only after it had
+        // finished stage s - 2.  One barrier per stage instead of two, for twice the LDS.
+        {
+            const int buf = (int)(((row0 - r_begin) / KC) & 1);
+            LI = lds_base + (size_t)buf * 2 * kWB * CS;
+            LJ = LI + kWB * CS;
+            PJ = diag ? LI : LJ;
+        }
+        store_stage();
+        __syncthreads();
+#else
         __syncthreads();  // previous stage's reads are done
         store_stage();
         __syncthreads();
+#endif
         if (row0 + KC < r_end) load_stage(row0 + KC);
         if constexpr (narrow) mma_stage(std::integral_constant<int, NMN>{}, std::integral_constant<int, 1>{});
         else if (tailwave) mma_tail();
@@ -381,7 +399,11 @@ static int launch_moments_wide_w(pds_ctx* ctx, const DeviceCols<T>& dc, int n_fe
     const size_t part_bytes = (size_t)nsplit * npairs * kWB * kWB * sizeof(T);
     T* partials = reinterpret_cast<T*>(ws_take(ctx, part_bytes));
     if (ctx->ws_used > ctx->ws.bytes) return fail(PDS_ERR_INVALID, "internal: workspace for the wide Gram build was not reserved");
+#ifdef PDS_WIDE_DB
+    const size_t lds = (size_t)4 * kWB * W::CS * sizeof(T);
+#else
     const size_t lds = (size_t)2 * kWB * W::CS * sizeof(T);
+#endif
     T* d_sw = nullptr;
     if constexpr (WEIGHTED) d_sw = reinterpret_cast<T*>(ws_take(ctx, (size_t)n_rows * sizeof(T)));
     if (ctx->ws_used > ctx->ws.bytes) return fail(PDS_ERR_INVALID, "internal: workspace for the wide Gram build was not reserved");
