@@ -1228,7 +1228,7 @@ int pds_ctx_create(int device, pds_ctx** out) {
     c->own_stream = true;
     const size_t pbytes = (size_t)c->num_cus * 8 * kPartStride * sizeof(double);
     if (hipMalloc(reinterpret_cast<void**>(&c->partials), pbytes) != hipSuccess) {
-        hipStreamDestroy(c->stream);
+        (void)hipStreamDestroy(c->stream);
         delete c;
         return fail(PDS_ERR_HIP, "hipMalloc(partials) failed");
     }
@@ -1238,21 +1238,21 @@ int pds_ctx_create(int device, pds_ctx** out) {
 
 void pds_ctx_destroy(pds_ctx* ctx) {
     if (!ctx) return;
-    hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
-    if (ctx->partials) hipFree(ctx->partials);
-    if (ctx->ws.ptr) hipFree(ctx->ws.ptr);
-    if (ctx->stage.ptr) hipFree(ctx->stage.ptr);
-    if (ctx->solve_ws.ptr) hipFree(ctx->solve_ws.ptr);
-    if (ctx->keyed.ptr) hipFree(ctx->keyed.ptr);
-    if (ctx->pinned) hipHostFree(ctx->pinned);
-    if (ctx->pinned_in) hipHostFree(ctx->pinned_in);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->partials) (void)hipFree(ctx->partials);
+    if (ctx->ws.ptr) (void)hipFree(ctx->ws.ptr);
+    if (ctx->stage.ptr) (void)hipFree(ctx->stage.ptr);
+    if (ctx->solve_ws.ptr) (void)hipFree(ctx->solve_ws.ptr);
+    if (ctx->keyed.ptr) (void)hipFree(ctx->keyed.ptr);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->pinned_in) (void)hipHostFree(ctx->pinned_in);
     for (auto& e : ctx->ev_pending) {
-        hipEventDestroy(e.a);
-        hipEventDestroy(e.b);
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
     }
-    for (auto e : ctx->ev_pool) hipEventDestroy(e);
-    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
@@ -1260,7 +1260,7 @@ int pds_ctx_set_stream(pds_ctx* ctx, void* hip_stream) {
     if (!ctx) return fail(PDS_ERR_INVALID, "null ctx");
     PDS_HIP_CHECK(hipSetDevice(ctx->device));
     PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     // NULL is a valid hipStream_t: the (legacy) default stream, which is what torch uses unless told otherwise
     ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
     ctx->own_stream = false;
