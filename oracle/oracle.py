@@ -11,7 +11,6 @@ Every function takes X as an (n, p) array (converted to column-major, the layout
 from __future__ import annotations
 
 import ctypes as C
-import os
 import subprocess
 from pathlib import Path
 

@@ -6,7 +6,6 @@ Pins the CPU oracle (oracle/pds_oracle.c) BEFORE it is trusted as the checker:
 No GPU needed.
 """
 import numpy as np
-import pytest
 from scipy import stats
 
 

@@ -1,5 +1,5 @@
 """Development aid: fused grouped kernel with an intercept (centred form) at 16 and 8 features."""
-import os, sys, time
+import sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import torch

@@ -2,7 +2,7 @@
 import os, sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-import numpy as np, torch
+import torch
 import polars_ds_extension_amd as pds
 G, R, P = 1_000_000, 100, int(os.environ.get("P", "16"))
 N = G * R

@@ -1,5 +1,5 @@
 """Development aid: single-system Gram build time vs number of features (is it HBM-bound at every p?)."""
-import sys, time
+import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import torch

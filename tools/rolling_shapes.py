@@ -1,4 +1,8 @@
-import sys, os, torch, numpy as np
+"""Rolling kernel across feature counts / bias (ms per launch, ns per row) -- run on the GPU box."""
+import sys
+
+import torch
+
 sys.path.insert(0,'.')
 import polars_ds_extension_amd as pds
 dev=torch.device('cuda',0); g=torch.Generator(device=dev); g.manual_seed(1)
