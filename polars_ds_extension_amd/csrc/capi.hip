@@ -165,7 +165,7 @@ static bool jacobi_svd(const std::vector<double>& a, int n, std::vector<double>&
                     be += u[r + (size_t)j * n] * u[r + (size_t)j * n];
                     ga += u[r + (size_t)i * n] * u[r + (size_t)j * n];
                 }
-                if (ga == 0.0 || std::fabs(ga) <= eps * std::sqrt(al * be)) continue;
+                if (ga == 0.0 || std::fabs(ga) <= eps * std::sqrt(al) * std::sqrt(be)) continue;  // (al * be may overflow)
                 conv = false;
                 const double zeta = (be - al) / (2 * ga);
                 const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1 + zeta * zeta));

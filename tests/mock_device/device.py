@@ -339,7 +339,35 @@ def make_callbacks(sfx):
         windowed(cols, n_feat, n, bias, lam, coeffs_p, pred_p, valid_p, int(start_with) - 1, (b, np.ones(len(b), dtype=bool)))
         return OK
 
-    return {f"pds_lr_{sfx}": lr, f"pds_lr_pred_{sfx}": lr_pred, f"pds_lr_nullable_{sfx}": lr_nullable, f"pds_lr_multi_{sfx}": multi,
+    def moments(ctx, cols_p, w_p, n_feat, n, space, out_p, out_space):
+        _check_shape(n_feat, n, 0)
+        cols = _columns(cols_p, n_feat + 1, n, dt)
+        Z = np.column_stack(cols[1:] + [np.ones(n, dtype=dt), cols[0]]).astype(np.float64)
+        A = (Z * _view(w_p, n, dt)[:, None]).T @ Z if w_p else Z.T @ Z
+        q = n_feat + 2
+        _view(out_p, q * q, dt)[:] = A.T.reshape(-1)  # column-major
+        return OK
+
+    def from_moments(ctx, mom_p, mom_space, n_feat, prm_p, coeffs_p, is_null_p):
+        prm = _prm(prm_p)
+        q, p, bias = n_feat + 2, n_feat, prm["add_bias"]
+        pp = p + bias
+        A = _view(mom_p, q * q, dt).reshape(q, q).T.astype(dt)
+        G = np.ascontiguousarray(A[:pp, :pp]).copy()
+        c = np.ascontiguousarray(A[:pp, p + 1]).copy()
+        meth = orc.lr_methods(prm["l1_reg"], prm["l2_reg"])
+        if meth in ("normal", "l2") and not prm["positive"]:
+            G[np.arange(p), np.arange(p)] += prm["l2_reg"]
+            b = orc.gated_solve_gram(G, c, prm["solver"], prm["singular_x_tol"]) if prm["singular_x_tol"] > 0 else orc.solve_gram(G, c, prm["solver"])
+        elif meth == "normal":
+            raise MockError(UNSUPPORTED, "mock: NNLS from moments is not modelled")
+        else:
+            b = orc.cd_from_gram(G, c, A[:p, p].copy(), float(A[p, p + 1]), float(A[p, p]), prm["l1_reg"], prm["l2_reg"], bias, prm["tol"],
+                                 2000 if f32 else prm["max_iter"], prm["positive"])[0]
+        put_fit(None if b is None else np.asarray(b).reshape(-1), pp, coeffs_p, is_null_p)
+        return OK
+
+    return {f"pds_moments_{sfx}": moments, f"pds_lr_from_moments_{sfx}": from_moments, f"pds_lr_{sfx}": lr, f"pds_lr_pred_{sfx}": lr_pred, f"pds_lr_nullable_{sfx}": lr_nullable, f"pds_lr_multi_{sfx}": multi,
             f"pds_lr_rcond_{sfx}": rcond, f"pds_lin_reg_report_{sfx}": report, f"pds_lin_reg_report_nullable_{sfx}": report_nullable,
             f"pds_lr_grouped_{sfx}": grouped, f"pds_lr_grouped_weighted_{sfx}": grouped_weighted,
             f"pds_lr_grouped_nullable_{sfx}": grouped_nullable, f"pds_lr_by_key_{sfx}": by_key, f"pds_rolling_lr_{sfx}": rolling,
@@ -380,4 +408,16 @@ def load():
         cb = proto(guarded)
         _KEEP.append(cb)
         getattr(lib, "mock_bind_" + name)(C.cast(cb, C.c_void_p))
+    return lib
+
+
+def load_for_package():
+    """The mock library with the return / argument types polars_ds_extension_amd/_lib.load() sets on the product library
+    (tests/test_oracle_reference_suite.py swaps it in to pin the oracle against the reference's own test-suite)."""
+    lib = load()
+    lib.pds_last_error.restype = C.c_char_p
+    lib.pds_version.restype = C.c_char_p
+    lib.pds_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    lib.pds_ctx_destroy.argtypes = [C.c_void_p]
+    lib.pds_ctx_destroy.restype = None
     return lib
