@@ -367,7 +367,23 @@ def make_callbacks(sfx):
         put_fit(None if b is None else np.asarray(b).reshape(-1), pp, coeffs_p, is_null_p)
         return OK
 
-    return {f"pds_moments_{sfx}": moments, f"pds_lr_from_moments_{sfx}": from_moments, f"pds_lr_{sfx}": lr, f"pds_lr_pred_{sfx}": lr_pred, f"pds_lr_nullable_{sfx}": lr_nullable, f"pds_lr_multi_{sfx}": multi,
+    def with_inv(ctx, cols_p, n_feat, n, space, bias, lam, coeffs_p, inv_p):
+        _check_shape(n_feat, n, bias)
+        cols = _columns(cols_p, n_feat + 1, n, dt)
+        X = X_of(cols)
+        Xb = np.asfortranarray(orc.with_bias(X) if bias else X, dtype=dt)
+        pp = Xb.shape[1]
+        inv = np.zeros((pp, pp), dtype=dt, order="F")
+        beta = np.zeros(pp, dtype=dt)
+        y = np.ascontiguousarray(cols[0], dtype=dt)
+        fn = getattr(orc.lib(), "orc_qr_lr_with_inv_" + sfx)
+        fn(Xb.ctypes.data_as(C.c_void_p), C.c_int64(n), y.ctypes.data_as(C.c_void_p), C.c_int64(n), C.c_int(pp), ct(lam), C.c_int(int(bool(bias))),
+           inv.ctypes.data_as(C.c_void_p), beta.ctypes.data_as(C.c_void_p))
+        _view(coeffs_p, pp, dt)[:] = beta
+        _view(inv_p, pp * pp, dt)[:] = inv.reshape(-1, order="F")
+        return OK
+
+    return {f"pds_lr_with_inv_{sfx}": with_inv, f"pds_moments_{sfx}": moments, f"pds_lr_from_moments_{sfx}": from_moments, f"pds_lr_{sfx}": lr, f"pds_lr_pred_{sfx}": lr_pred, f"pds_lr_nullable_{sfx}": lr_nullable, f"pds_lr_multi_{sfx}": multi,
             f"pds_lr_rcond_{sfx}": rcond, f"pds_lin_reg_report_{sfx}": report, f"pds_lin_reg_report_nullable_{sfx}": report_nullable,
             f"pds_lr_grouped_{sfx}": grouped, f"pds_lr_grouped_weighted_{sfx}": grouped_weighted,
             f"pds_lr_grouped_nullable_{sfx}": grouped_nullable, f"pds_lr_by_key_{sfx}": by_key, f"pds_rolling_lr_{sfx}": rolling,

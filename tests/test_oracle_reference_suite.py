@@ -13,9 +13,11 @@ import pytest
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "tests"))
+import test_linear_models as M  # noqa: E402
 import test_reference_suite as R  # noqa: E402
 
 TESTS = [n for n, f in vars(R).items() if n.startswith("test_") and callable(f)]
+MODEL_TESTS = ["test_lr", "test_online_lr", "test_elastic_net"]  # the reference's tests/test_linear_models.py, host (NumPy) data
 
 
 @pytest.fixture(scope="module")
@@ -48,8 +50,8 @@ def _params_of(fn):
 
 def _cases():
     out = []
-    for name in TESTS:
-        fn = getattr(R, name)
+    for name in TESTS + MODEL_TESTS:
+        fn = getattr(R, name, None) or getattr(M, name)
         sig = list(inspect.signature(fn).parameters)
         grids = [[{}]]
         for mk in _params_of(fn):
@@ -71,7 +73,7 @@ def _cases():
 @pytest.mark.parametrize("name,kwargs", _cases())
 def test_reference_suite_on_the_oracle(name, kwargs, oracle_backed_package):
     m = oracle_backed_package
-    fn = getattr(R, name)
+    fn = getattr(R, name, None) or getattr(M, name)
     kw = dict(kwargs)
     if "lin_reg_dtype" in kw:
         m.config.LIN_REG_EXPR_F64 = kw["lin_reg_dtype"] == "f64"
