@@ -71,6 +71,9 @@ int pds_ctx_set_stream(pds_ctx* ctx, void* hip_stream);
 int pds_ctx_synchronize(pds_ctx* ctx);
 /* Number of compute units of the context's device (256 on MI355X). */
 int pds_ctx_num_cus(const pds_ctx* ctx);
+/* Diagnostics: how many call-local workspace slices had to be allocated outside the per-call reservation since the context
+ * was created (0 unless an entry point under-estimated its bound; the slices are still valid, never out of bounds). */
+long long pds_ctx_workspace_spills(const pds_ctx* ctx);
 /*
  * Measurement hooks (bench.py): with timing enabled every kernel class is bracketed by a HIP event
  * pair recorded on the context's stream.  pds_ctx_get_timing synchronises and returns, per class,
@@ -88,7 +91,7 @@ typedef struct {
     double tol;            /* kwargs.tol (CD / NNLS convergence; rcond for pds_lr_rcond) */
     int solver;            /* pds_solver, from kwargs.solver */
     int positive;          /* kwargs.positive */
-    int max_iter;          /* kwargs.max_iter (the f32 twin ignores it: 2000 CD / 200 NNLS) */
+    int max_iter;          /* kwargs.max_iter (the f32 twin ignores it: 2000 CD; NNLS 200 in pl_lr_f32, 2000 in pl_lr_pred_f32) */
     double singular_x_tol; /* kwargs.singular_x_tol: > 0 enables the log-det rank gate */
 } pds_lr_params;
 
@@ -118,6 +121,18 @@ int pds_lr_pred_f64(pds_ctx* ctx, const double* const* cols, const double* weigh
 int pds_lr_pred_f32(pds_ctx* ctx, const float* const* cols, const float* weights, int n_feat,
                     int64_t n_rows, pds_space space, const pds_lr_params* prm, float* coeffs,
                     int* is_null, float* pred, float* resid);
+
+/*
+ * pds_elastic_net_*: ElasticNet::fit_unchecked of the model-class route (src/linear/lr/lr_solvers.rs:139-164, reached from
+ * PyElasticNet.fit src/pymodels/py_lr.rs:112): ALWAYS faer_coordinate_descent with (l1_reg, l2_reg, add_bias, tol, max_iter,
+ * positive = false) -- also when l1_reg <= 0, where `pl_lr`'s dispatch would take the closed-form ridge instead (the two
+ * differ: coordinate descent penalises with n_rows * l2_reg, :478-480).  max_iter is honoured in both precisions (the 2000
+ * of the f32 expression twin is the plugin function's, not the solver's).  Only an empty frame is rejected (lr/mod.rs:114-125).
+ */
+int pds_elastic_net_f64(pds_ctx* ctx, const double* const* cols, int n_feat, int64_t n_rows, pds_space space,
+                        const pds_lr_params* prm, double* coeffs);
+int pds_elastic_net_f32(pds_ctx* ctx, const float* const* cols, int n_feat, int64_t n_rows, pds_space space,
+                        const pds_lr_params* prm, float* coeffs);
 
 /*
  * pds_lr_nullable_*: `pl_lr` / `pl_lr_pred` on columns that carry Arrow validity bitmaps, i.e. the null handling of
@@ -161,6 +176,10 @@ int pds_lr_multi_f32(pds_ctx* ctx, const float* const* cols, int n_targets, int 
 int pds_lr_rcond_f64(pds_ctx* ctx, const double* const* cols, int n_feat, int64_t n_rows,
                      pds_space space, int add_bias, double l2_reg, double rcond, double* coeffs,
                      double* singular_values);
+/* pl_lr_w_rcond_f32 (linear_regression_f32.rs:515-566): rcond = max(tol as f32, f32::EPSILON * max(n, p')). */
+int pds_lr_rcond_f32(pds_ctx* ctx, const float* const* cols, int n_feat, int64_t n_rows,
+                     pds_space space, int add_bias, float l2_reg, float rcond, float* coeffs,
+                     float* singular_values);
 
 /*
  * pds_lin_reg_report_*: the arithmetic of `pl_lin_reg_report` (linear_regression.rs:822-980) and, with

@@ -68,10 +68,22 @@ int ensure_pinned(pds_ctx* ctx, size_t bytes) {
 
 int ws_reserve(pds_ctx* ctx, size_t total_bytes) {
     ctx->ws_used = 0;
+    for (void* q : ctx->ws_spill) (void)hipFree(q);  // (hipFree waits for the device: the previous call's kernels are done)
+    ctx->ws_spill.clear();
     return ensure_ws(ctx, ctx->ws, total_bytes + 4096);
 }
 void* ws_take(pds_ctx* ctx, size_t bytes) {
     const size_t off = (ctx->ws_used + 255) & ~(size_t)255;
+    if (off + bytes > ctx->ws.bytes) {
+        // An entry point under-estimated its ws_reserve() bound.  Handing out memory past the workspace would corrupt
+        // whatever lives behind it without any error, so the slice comes from its own allocation instead (released by the
+        // next ws_reserve) and the event is counted: tests assert the counter stays at zero.
+        void* q = nullptr;
+        ++ctx->ws_spill_count;
+        if (hipMalloc(&q, bytes + 256) != hipSuccess) return nullptr;  // (a null slice faults loudly in the kernel)
+        ctx->ws_spill.push_back(q);
+        return q;
+    }
     ctx->ws_used = off + bytes;
     return static_cast<char*>(ctx->ws.ptr) + off;
 }
@@ -238,10 +250,13 @@ static Method pick_method(const pds_lr_params* prm) {
     return {Method::CD, prm->l1_reg, l2 ? prm->l2_reg : 0.0, m.positive};
 }
 
-// Device moments -> coefficients on the host.  `is_f32_path` applies the f32 twin's iteration caps.
+// Device moments -> coefficients on the host.  The f32 twin's iteration caps apply when T = float: coordinate descent 2000
+// everywhere, NNLS 200 in `pl_lr_f32` (linear_regression_f32.rs:343) but 2000 in `pl_lr_pred_f32` (:620) -- `pred_path`.
+// `force_cd`: ElasticNet::fit_unchecked (lr_solvers.rs:139-164) always runs faer_coordinate_descent, also for l1_reg <= 0.
 template <typename T>
 static int lr_from_device_moments(pds_ctx* ctx, const T* d_mom, int p, const pds_lr_params* prm, bool weighted,
-                                  T* coeffs, int* is_null, T* d_coeffs_keep /*nullable device copy*/) {
+                                  T* coeffs, int* is_null, T* d_coeffs_keep /*nullable device copy*/, bool pred_path = false,
+                                  bool force_cd = false) {
     const int bias = prm->add_bias ? 1 : 0, pp = p + bias, q = p + 2;
     if (is_null) *is_null = 0;
     // coefficients and the null flag sit in one block so that they come back in one copy
@@ -252,6 +267,7 @@ static int lr_from_device_moments(pds_ctx* ctx, const T* d_mom, int p, const pds
     int* d_info = reinterpret_cast<int*>(ws_take(ctx, 16));
     if (int rc = ensure_pinned(ctx, 4096 + sizeof(T) * (size_t)(q * q + pp))) return rc;
     Method m = weighted ? Method{Method::OLS, 0.0, 0.0, 0} : pick_method(prm);
+    if (force_cd) m = Method{Method::CD, prm->l1_reg > 0.0 ? prm->l1_reg : 0.0, prm->l2_reg > 0.0 ? prm->l2_reg : 0.0, prm->positive ? 1 : 0};
     const bool f32 = sizeof(T) == 4;
     if (m.kind == Method::OLS && prm->solver == PDS_SOLVER_SVD) {
         // svd: small host solve on the moments
@@ -307,10 +323,10 @@ static int lr_from_device_moments(pds_ctx* ctx, const T* d_mom, int p, const pds
         SolveParams sp{p, bias, prm->solver, weighted ? 0.0 : m.l2, weighted ? 0.0 : prm->singular_x_tol, 0};
         if (int rc = launch_solve<T>(ctx, d_mom, 1, sp, d_coeffs, d_flag, nullptr, nullptr)) return rc;
     } else if (m.kind == Method::NNLS) {
-        if (int rc = launch_nnls<T>(ctx, d_mom, p, bias, prm->tol, f32 ? 200 : prm->max_iter, d_coeffs)) return rc;
+        if (int rc = launch_nnls<T>(ctx, d_mom, p, bias, prm->tol, f32 ? (pred_path ? 2000 : 200) : prm->max_iter, d_coeffs)) return rc;
         PDS_HIP_CHECK(hipMemsetAsync(d_flag, 0, 1, ctx->stream));
     } else {
-        if (int rc = launch_cd<T>(ctx, d_mom, p, bias, m.l1, m.l2, prm->tol, f32 ? 2000 : prm->max_iter, m.positive,
+        if (int rc = launch_cd<T>(ctx, d_mom, p, bias, m.l1, m.l2, prm->tol, (f32 && !force_cd) ? 2000 : prm->max_iter, m.positive,
                                   d_coeffs, d_info))
             return rc;
         PDS_HIP_CHECK(hipMemsetAsync(d_flag, 0, 1, ctx->stream));
@@ -341,9 +357,14 @@ static int check_shape(int n_feat, int64_t n_rows, int add_bias) {
 
 template <typename T>
 static int lr_impl(pds_ctx* ctx, const T* const* cols, const T* weights, int n_feat, int64_t n_rows, pds_space space,
-                   const pds_lr_params* prm, T* coeffs, int* is_null, T* pred, T* resid) {
+                   const pds_lr_params* prm, T* coeffs, int* is_null, T* pred, T* resid, bool force_cd = false) {
     if (!ctx || !cols || !prm || !coeffs) return fail(PDS_ERR_INVALID, "null argument");
-    if (int rc = check_shape(n_feat, n_rows, prm->add_bias)) return rc;
+    if (force_cd) {  // ElasticNet::fit (lr/mod.rs:114-125) only rejects an empty frame; fewer rows than columns is fine
+        if (n_feat < 1) return fail(PDS_ERR_INVALID, "need at least one feature column");
+        if (n_rows <= 0) return fail(PDS_ERR_EMPTY, "Empty data");
+    } else if (int rc = check_shape(n_feat, n_rows, prm->add_bias)) {
+        return rc;
+    }
     PDS_HIP_CHECK(hipSetDevice(ctx->device));
     const int q = n_feat + 2, pp = n_feat + (prm->add_bias ? 1 : 0);
     const bool want_pred = pred || resid;
@@ -359,7 +380,8 @@ static int lr_impl(pds_ctx* ctx, const T* const* cols, const T* weights, int n_f
     int null_flag = 0;
     // (a device copy of the coefficients is only kept for the residual pass: without it they come back with the null
     //  flag in one copy)
-    if (int rc = lr_from_device_moments<T>(ctx, d_mom, n_feat, prm, weights != nullptr, coeffs, &null_flag, want_pred ? d_coeffs : nullptr))
+    if (int rc = lr_from_device_moments<T>(ctx, d_mom, n_feat, prm, weights != nullptr, coeffs, &null_flag, want_pred ? d_coeffs : nullptr,
+                                           want_pred, force_cd))
         return rc;
     if (is_null) *is_null = null_flag;
     if (want_pred) {
@@ -439,7 +461,7 @@ static int lr_nullable_impl(pds_ctx* ctx, const T* const* cols, const uint8_t* c
     if (int rc = launch_moments<T>(ctx, dk, n_feat, prep.n_kept, false, d_mom)) return rc;
     T* d_coeffs = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * (pp + 2)));
     int null_flag = 0;
-    if (int rc = lr_from_device_moments<T>(ctx, d_mom, n_feat, prm, false, coeffs, &null_flag, want_pred ? d_coeffs : nullptr)) return rc;
+    if (int rc = lr_from_device_moments<T>(ctx, d_mom, n_feat, prm, false, coeffs, &null_flag, want_pred ? d_coeffs : nullptr, want_pred)) return rc;
     if (is_null) *is_null = null_flag;
     if (want_pred) {
         T* c_pred = reinterpret_cast<T*>(ws_take(ctx, (size_t)prep.n_kept * sizeof(T)));
@@ -610,6 +632,45 @@ static int from_moments_impl(pds_ctx* ctx, const T* moments, pds_space mom_space
 }
 
 // ---------------------------------------------------------------------------------------------
+// pl_lr_w_rcond(_f32) -> faer_solve_lr_rcond (lr_solvers.rs:216-258): SVD of X'X (+ lambda), singular values of X =
+// sqrt of its eigenvalues, pseudo-inverse with the reference's cut-off rule (eigenvalue compared with rcond * s_max, as
+// written at :226-240).  The Gram build is the device pass; the p' x p' decomposition is a host Jacobi SVD in f64 for
+// both precisions (the f32 twin's moments are f32 -- what its matrix-core tiles produce -- the decomposition of the 2 KB
+// matrix is not where its error comes from).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+static int lr_rcond_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t n_rows, pds_space space, int add_bias,
+                         double l2_reg, double rcond, T* coeffs, T* singular_values) {
+    if (!ctx || !cols || !coeffs || !singular_values) return fail(PDS_ERR_INVALID, "null argument");
+    if (int rc = check_shape(n_feat, n_rows, add_bias)) return rc;
+    const int bias = add_bias ? 1 : 0, pp = n_feat + bias, q = n_feat + 2;
+    std::vector<T> M((size_t)q * q);
+    if (int rc = moments_impl<T>(ctx, cols, nullptr, n_feat, n_rows, space, M.data(), PDS_HOST)) return rc;
+    std::vector<double> G, c, u, s, v;
+    host_normal_eq(M, n_feat, bias, l2_reg, G, c);
+    if (!jacobi_svd(G, pp, u, s, v)) return fail(PDS_ERR_NUMERIC, "SVD failed.");
+    std::vector<double> sv(pp);
+    for (int i = 0; i < pp; ++i) {
+        sv[i] = std::sqrt(s[i]);
+        singular_values[i] = (T)sv[i];
+    }
+    const double thr = rcond * sv[0];  // lr_solvers.rs:230-240 (eigenvalue vs rcond * s_max, as written)
+    std::vector<double> z(pp);
+    for (int i = 0; i < pp; ++i) {
+        const double sinv = s[i] >= thr ? 1.0 / s[i] : 0.0;
+        double acc = 0;
+        for (int r = 0; r < pp; ++r) acc += u[r + (size_t)i * pp] * c[r];
+        z[i] = acc * sinv;
+    }
+    for (int r = 0; r < pp; ++r) {
+        double acc = 0;
+        for (int i = 0; i < pp; ++i) acc += v[r + (size_t)i * pp] * z[i];
+        coeffs[r] = (T)acc;
+    }
+    return PDS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // lin_reg_report / wls_report
 // ---------------------------------------------------------------------------------------------
 template <typename T, typename R>
@@ -697,8 +758,9 @@ static int report_impl(pds_ctx* ctx, const T* const* cols, const T* weights, int
         dc2.nc = p + 2;
         dc2.h_ptrs.assign(dc.h_ptrs.begin(), dc.h_ptrs.begin() + p + 1);
         dc2.h_ptrs.push_back(d_s);
-        dc2.d_ptrs = reinterpret_cast<const T**>(ws_take(ctx, sizeof(T*) * (p + 2)));
-        PDS_HIP_CHECK(hipMemcpyAsync(dc2.d_ptrs, dc2.h_ptrs.data(), sizeof(T*) * (p + 2), hipMemcpyHostToDevice, ctx->stream));
+        dc2.h_ptrs.resize(std::max(p + 2, 18), dc2.h_ptrs[0]);  // (the p <= 16 kernels fetch 18 entries with wide loads)
+        dc2.d_ptrs = reinterpret_cast<const T**>(ws_take(ctx, sizeof(T*) * dc2.h_ptrs.size()));
+        PDS_HIP_CHECK(hipMemcpyAsync(dc2.d_ptrs, dc2.h_ptrs.data(), sizeof(T*) * dc2.h_ptrs.size(), hipMemcpyHostToDevice, ctx->stream));
         if (int rc = launch_moments<T>(ctx, dc2, p, n_rows, true, d_mom2)) return rc;
         PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     }
@@ -1242,6 +1304,7 @@ void pds_ctx_destroy(pds_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->partials) (void)hipFree(ctx->partials);
     if (ctx->ws.ptr) (void)hipFree(ctx->ws.ptr);
+    for (void* q : ctx->ws_spill) (void)hipFree(q);
     if (ctx->stage.ptr) (void)hipFree(ctx->stage.ptr);
     if (ctx->solve_ws.ptr) (void)hipFree(ctx->solve_ws.ptr);
     if (ctx->keyed.ptr) (void)hipFree(ctx->keyed.ptr);
@@ -1274,6 +1337,8 @@ int pds_ctx_synchronize(pds_ctx* ctx) {
 }
 
 int pds_ctx_num_cus(const pds_ctx* ctx) { return ctx ? ctx->num_cus : 0; }
+
+long long pds_ctx_workspace_spills(const pds_ctx* ctx) { return ctx ? ctx->ws_spill_count : -1; }
 
 int pds_ctx_set_timing(pds_ctx* ctx, int enable) {
     if (!ctx) return fail(PDS_ERR_INVALID, "null ctx");
@@ -1326,6 +1391,15 @@ int pds_lr_pred_f32(pds_ctx* ctx, const float* const* cols, const float* weights
     return lr_impl<float>(ctx, cols, weights, n_feat, n_rows, space, prm, coeffs, is_null, pred, resid);
 }
 
+int pds_elastic_net_f64(pds_ctx* ctx, const double* const* cols, int n_feat, int64_t n_rows, pds_space space,
+                        const pds_lr_params* prm, double* coeffs) {
+    return lr_impl<double>(ctx, cols, nullptr, n_feat, n_rows, space, prm, coeffs, nullptr, nullptr, nullptr, true);
+}
+int pds_elastic_net_f32(pds_ctx* ctx, const float* const* cols, int n_feat, int64_t n_rows, pds_space space,
+                        const pds_lr_params* prm, float* coeffs) {
+    return lr_impl<float>(ctx, cols, nullptr, n_feat, n_rows, space, prm, coeffs, nullptr, nullptr, nullptr, true);
+}
+
 int pds_lr_nullable_f64(pds_ctx* ctx, const double* const* cols, const uint8_t* const* validity, const int64_t* bit_offsets,
                         int n_feat, int64_t n_rows, pds_space space, int null_policy, double fill_value,
                         const pds_lr_params* prm, double* coeffs, int* is_null, double* pred, double* resid,
@@ -1356,29 +1430,12 @@ int pds_lr_multi_f32(pds_ctx* ctx, const float* const* cols, int n_targets, int 
 
 int pds_lr_rcond_f64(pds_ctx* ctx, const double* const* cols, int n_feat, int64_t n_rows, pds_space space,
                      int add_bias, double l2_reg, double rcond, double* coeffs, double* singular_values) {
-    if (!ctx || !cols || !coeffs || !singular_values) return fail(PDS_ERR_INVALID, "null argument");
-    if (int rc = check_shape(n_feat, n_rows, add_bias)) return rc;
-    const int bias = add_bias ? 1 : 0, pp = n_feat + bias, q = n_feat + 2;
-    std::vector<double> M((size_t)q * q);
-    if (int rc = moments_impl<double>(ctx, cols, nullptr, n_feat, n_rows, space, M.data(), PDS_HOST)) return rc;
-    std::vector<double> G, c, u, s, v;
-    host_normal_eq(M, n_feat, bias, l2_reg, G, c);
-    if (!jacobi_svd(G, pp, u, s, v)) return fail(PDS_ERR_NUMERIC, "SVD failed.");
-    for (int i = 0; i < pp; ++i) singular_values[i] = std::sqrt(s[i]);
-    const double thr = rcond * singular_values[0];  // lr_solvers.rs:230-240 (eigenvalue vs rcond * s_max, as written)
-    std::vector<double> z(pp);
-    for (int i = 0; i < pp; ++i) {
-        const double sinv = s[i] >= thr ? 1.0 / s[i] : 0.0;
-        double acc = 0;
-        for (int r = 0; r < pp; ++r) acc += u[r + (size_t)i * pp] * c[r];
-        z[i] = acc * sinv;
-    }
-    for (int r = 0; r < pp; ++r) {
-        double acc = 0;
-        for (int i = 0; i < pp; ++i) acc += v[r + (size_t)i * pp] * z[i];
-        coeffs[r] = acc;
-    }
-    return PDS_OK;
+    return pds::lr_rcond_impl<double>(ctx, cols, n_feat, n_rows, space, add_bias, l2_reg, rcond, coeffs, singular_values);
+}
+int pds_lr_rcond_f32(pds_ctx* ctx, const float* const* cols, int n_feat, int64_t n_rows, pds_space space,
+                     int add_bias, float l2_reg, float rcond, float* coeffs, float* singular_values) {
+    return pds::lr_rcond_impl<float>(ctx, cols, n_feat, n_rows, space, add_bias, (double)l2_reg, (double)rcond, coeffs,
+                                     singular_values);
 }
 
 int pds_lin_reg_report_f64(pds_ctx* ctx, const double* const* cols, const double* weights, int n_feat,

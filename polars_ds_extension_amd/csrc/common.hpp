@@ -81,6 +81,8 @@ struct pds_ctx {
     double* partials = nullptr; // per-block partial records (num_cus * 8 blocks * kPartStride doubles)
     pds::Workspace ws;       // HBM scratch for call-local arrays (bump allocated per call)
     size_t ws_used = 0;
+    std::vector<void*> ws_spill;     // slices ws_take() had to allocate on their own (an under-estimated ws_reserve bound)
+    long long ws_spill_count = 0;    // ... counted since the context was created (pds_ctx_workspace_spills)
     pds::Workspace stage;    // HBM staging of PDS_HOST column buffers
     pds::Workspace solve_ws; // factor workspace of the p' > 64 solver (solve_big.hip)
     pds::Workspace keyed;    // pds_lr_by_key_*: staged / sorted keys, permutation, gathered columns, run-length results
@@ -113,7 +115,8 @@ struct KernelTimer {
 int ensure_ws(pds_ctx* ctx, Workspace& w, size_t bytes);
 int ensure_pinned(pds_ctx* ctx, size_t bytes);
 // call-local bump allocation inside ctx->ws: ws_reserve() once per API call with an upper bound, then
-// ws_take() hands out 256-byte aligned slices (never fails after a successful reserve).
+// ws_take() hands out 256-byte aligned slices; a request past the reserved bound is served from its own allocation and
+// counted (never silently out of bounds).
 int ws_reserve(pds_ctx* ctx, size_t total_bytes);
 void* ws_take(pds_ctx* ctx, size_t bytes);
 

@@ -239,9 +239,10 @@ class ElasticNet(_Fitted):
         X, y = _handle_nans_in_np(X, y, null_policy)
         if int(X.shape[0]) == 0:
             raise ValueError("Not enough data.")  # (fewer rows than columns is fine here, lr_solvers.rs:167-175)
-        # a pure ridge penalty (l1_reg <= 0) takes the closed form here; the reference iterates it to `tol`
-        b = lstsq.lin_reg(*_columns(X), target=y, add_bias=self._has_bias, l1_reg=max(self.l1_reg, 0.0), l2_reg=max(self.l2_reg, 0.0),
-                          tol=self.tol, max_iter=self.max_iter, singular_x_tol=0.0, null_policy="ignore")
+        # always coordinate descent, like ElasticNet::fit_unchecked -- also for a pure ridge penalty (l1_reg <= 0), whose
+        # coordinate-descent objective penalises with n_rows * l2_reg (lr_solvers.rs:478-480), not the closed form's l2_reg
+        b = lstsq.elastic_net_fit(*_columns(X), target=y, add_bias=self._has_bias, l1_reg=self.l1_reg, l2_reg=self.l2_reg,
+                                  tol=self.tol, max_iter=self.max_iter)
         self._take(b)
         return self
 

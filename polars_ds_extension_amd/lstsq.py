@@ -21,7 +21,7 @@ from . import _lib, config
 
 __all__ = [
     "Context", "default_context", "lin_reg", "lin_reg_report", "lin_reg_by", "rolling_lin_reg",
-    "recursive_lin_reg", "lin_reg_w_rcond", "gram_moments", "lin_reg_from_moments", "query_ar_coeffs",
+    "recursive_lin_reg", "lin_reg_w_rcond", "elastic_net_fit", "gram_moments", "lin_reg_from_moments", "query_ar_coeffs",
 ]
 
 
@@ -362,20 +362,40 @@ def query_ar_coeffs(x, lag: int, add_bias: bool = True, null_policy: str = "rais
 
 
 def lin_reg_w_rcond(*x, target, add_bias: bool = False, rcond: float = 0.0, l2_reg: float = 0.0, ctx: Context | None = None):
-    """pds.lin_reg_w_rcond (pl_lr_w_rcond): returns (coeffs, singular_values).  f64 only."""
-    if not config.LIN_REG_EXPR_F64:
-        raise NotImplementedError("lin_reg_w_rcond is f64 only here")
+    """pds.lin_reg_w_rcond (pl_lr_w_rcond / pl_lr_w_rcond_f32): returns (coeffs, singular_values)."""
     ctx = ctx or default_context()
     cols = _Cols(target, x)
     _follow(ctx, cols)
+    dt = _dtype()
+    real = C.c_double if dt == np.float64 else C.c_float
     pp = cols.n_feat + int(bool(add_bias))
-    rc = max(float(rcond), np.finfo(np.float64).eps * max(cols.n_rows, pp))  # linear_regression.rs:651-702
-    coeffs = np.empty(pp)
-    sv = np.empty(pp)
-    _lib.check(ctx._lib.pds_lr_rcond_f64(ctx._h, cols.cols, cols.n_feat, C.c_int64(cols.n_rows), cols.space,
-                                         int(bool(add_bias)), C.c_double(l2_reg), C.c_double(rc),
-                                         C.c_void_p(coeffs.ctypes.data), C.c_void_p(sv.ctypes.data)))
+    # (kwargs.tol as T).max(T::EPSILON * max(nrows, p'))   linear_regression.rs:651-702, linear_regression_f32.rs:515-566
+    rc = max(dt(rcond), np.finfo(dt).eps * dt(max(cols.n_rows, pp)))
+    coeffs = np.empty(pp, dtype=dt)
+    sv = np.empty(pp, dtype=dt)
+    fn = ctx._lib.pds_lr_rcond_f64 if dt == np.float64 else ctx._lib.pds_lr_rcond_f32
+    _lib.check(fn(ctx._h, cols.cols, cols.n_feat, C.c_int64(cols.n_rows), cols.space, int(bool(add_bias)), real(l2_reg), real(rc),
+                  C.c_void_p(coeffs.ctypes.data), C.c_void_p(sv.ctypes.data)))
     return coeffs, sv
+
+
+def elastic_net_fit(*x, target, l1_reg: float, l2_reg: float, add_bias: bool = False, tol: float = 1e-5, max_iter: int = 2000,
+                    ctx: Context | None = None):
+    """
+    ElasticNet::fit_unchecked (src/linear/lr/lr_solvers.rs:139-164): always faer_coordinate_descent, also for l1_reg <= 0
+    (pl_lr's dispatch would take the closed-form ridge there, which penalises with l2_reg where coordinate descent uses
+    n_rows * l2_reg).  Returns the coefficients (bias last).
+    """
+    ctx = ctx or default_context()
+    cols = _Cols(target, x)
+    _follow(ctx, cols)
+    dt = _dtype()
+    prm = _lib.LRParams(int(bool(add_bias)), float(l1_reg), float(l2_reg), float(tol), 0, 0, int(max_iter), 0.0)
+    pp = cols.n_feat + int(bool(add_bias))
+    coeffs = np.empty(pp, dtype=dt)
+    fn = ctx._lib.pds_elastic_net_f64 if dt == np.float64 else ctx._lib.pds_elastic_net_f32
+    _lib.check(fn(ctx._h, cols.cols, cols.n_feat, C.c_int64(cols.n_rows), cols.space, C.byref(prm), C.c_void_p(coeffs.ctypes.data)))
+    return coeffs
 
 
 def lin_reg_report(*x, target, add_bias: bool = False, weights=None, std_err: str = "se", y_var: float | None = None,

@@ -133,6 +133,18 @@ def make_callbacks(sfx):
                 _view(resid_p, n, dt)[:] = y - pr
         return OK
 
+    def elastic_net(ctx, cols_p, n_feat, n, space, prm_p, coeffs_p):
+        prm = _prm(prm_p)
+        if n == 0:
+            raise MockError(EMPTY, "Empty data")
+        cols = _columns(cols_p, n_feat + 1, n, dt)
+        X = X_of(cols)
+        Xb = orc.with_bias(X) if prm["add_bias"] else X
+        b = orc.coordinate_descent(Xb, cols[0], max(prm["l1_reg"], 0.0), max(prm["l2_reg"], 0.0), bool(prm["add_bias"]), prm["tol"],
+                                   prm["max_iter"], False)
+        _view(coeffs_p, n_feat + prm["add_bias"], dt)[:] = b
+        return OK
+
     def lr_pred(ctx, cols_p, w_p, n_feat, n, space, prm_p, coeffs_p, is_null_p, pred_p, resid_p):
         return lr(ctx, cols_p, w_p, n_feat, n, space, prm_p, coeffs_p, is_null_p, pred_p, resid_p)
 
@@ -384,7 +396,7 @@ def make_callbacks(sfx):
         return OK
 
     return {f"pds_lr_with_inv_{sfx}": with_inv, f"pds_moments_{sfx}": moments, f"pds_lr_from_moments_{sfx}": from_moments, f"pds_lr_{sfx}": lr, f"pds_lr_pred_{sfx}": lr_pred, f"pds_lr_nullable_{sfx}": lr_nullable, f"pds_lr_multi_{sfx}": multi,
-            f"pds_lr_rcond_{sfx}": rcond, f"pds_lin_reg_report_{sfx}": report, f"pds_lin_reg_report_nullable_{sfx}": report_nullable,
+            f"pds_lr_rcond_{sfx}": rcond, f"pds_elastic_net_{sfx}": elastic_net, f"pds_lin_reg_report_{sfx}": report, f"pds_lin_reg_report_nullable_{sfx}": report_nullable,
             f"pds_lr_grouped_{sfx}": grouped, f"pds_lr_grouped_weighted_{sfx}": grouped_weighted,
             f"pds_lr_grouped_nullable_{sfx}": grouped_nullable, f"pds_lr_by_key_{sfx}": by_key, f"pds_rolling_lr_{sfx}": rolling,
             f"pds_recursive_lr_{sfx}": recursive}

@@ -18,6 +18,10 @@ sys.path.insert(0, str(ROOT / "tests"))
 import plugin_harness as ph  # noqa: E402
 
 SYMBOLS = ["pl_lr", "pl_lr_pred", "pl_lin_reg_report", "pl_wls_report", "pl_rolling_lr", "pl_recursive_lr", "pl_lr_by", "pl_lr_multi", "pl_lr_multi_pred"]
+# every `#[polars_expr] fn` of /root/reference/src/num_ext/linear_regression.rs (:419,517,587,651,704,822,982,1121,1206) and of
+# linear_regression_f32.rs (:289,386,456,515,568,687,846,986,1072) -- the names `polars_ds.exprs.expr_linear` registers
+REFERENCE_EXPRS = ["pl_lr", "pl_lr_multi", "pl_lr_multi_pred", "pl_lr_w_rcond", "pl_lr_pred", "pl_lin_reg_report", "pl_wls_report",
+                   "pl_recursive_lr", "pl_rolling_lr"]
 
 
 @pytest.fixture(scope="module")
@@ -38,6 +42,22 @@ def test_plugin_symbols_and_version(so):
     assert so._polars_plugin_get_version() == 1  # (major 0 << 16) | minor 1
     so._polars_plugin_get_last_error_message.restype = C.c_char_p
     assert isinstance(so._polars_plugin_get_last_error_message(), bytes)
+
+
+def test_every_reference_expression_symbol_is_exported(so):
+    """All 18 `#[polars_expr]` names of the reference's two lstsq files (9 + their _f32 twins), entry point and field function."""
+    names = [n + sfx for n in REFERENCE_EXPRS for sfx in ("", "_f32")]
+    assert len(names) == 18
+    missing = [n for n in names if not (hasattr(so, f"_polars_plugin_{n}") and hasattr(so, f"_polars_plugin_field_{n}"))]
+    assert not missing, f"reference expressions without a plugin symbol: {missing}"
+    ref = Path("/root/reference/src/num_ext")
+    if ref.exists():  # (this container only: the list above is what the reference declares)
+        import re
+
+        declared = []
+        for f in ("linear_regression.rs", "linear_regression_f32.rs"):
+            declared += re.findall(r"#\[polars_expr\([^\]]*\)\][^\n]*\n\s*fn\s+(\w+)", (ref / f).read_text())
+        assert sorted(declared) == sorted(names)
 
 
 def test_coalescing_queue_fails_cleanly_without_a_device(so):
@@ -549,3 +569,26 @@ def test_pl_lr_multi_and_rcond(so, orc):
     ref, _, _, sv = np.linalg.lstsq(X, Y[:, 0], rcond=0.3)
     np.testing.assert_allclose(r["coeffs"], ref, atol=1e-10)
     np.testing.assert_allclose(r["singular_values"], sv, rtol=1e-10)
+    # the f32 twin (linear_regression_f32.rs:515-566): List<f32> fields, rcond = max(tol as f32, f32::EPSILON * max(n, p'))
+    f32_ins = [("y", pa.array(Y[:, 0].astype(np.float32)))] + [(f"x{j}", pa.array(X[:, j].astype(np.float32))) for j in range(3)]
+    field, out = ph.call_plugin(so, "pl_lr_w_rcond_f32", f32_ins, dict(LR, tol=0.3))
+    r32 = out.to_pylist()[0]
+    assert out.type.field("coeffs").type == pa.large_list(pa.float32()) and list(r32) == ["coeffs", "singular_values"]
+    bo, svo = orc.solve_lr_rcond(X.astype(np.float32), Y[:, 0].astype(np.float32), rcond=np.float32(0.3))
+    np.testing.assert_allclose(r32["coeffs"], ref, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(r32["coeffs"], bo, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(r32["singular_values"], sv, rtol=1e-5)
+    # null policies reach pl_lr_w_rcond too (series_to_mat_for_lr is called at :660): skip == the fit on the complete rows
+    x0 = X[:, 0].copy()
+    mask = np.zeros(n, dtype=bool)
+    mask[::17] = True
+    nul_ins = [("y", pa.array(Y[:, 0])), ("x0", pa.array(x0, mask=mask))] + ins[3:]
+    with pytest.raises(ph.PluginFailure, match="Nulls found in data"):
+        ph.call_plugin(so, "pl_lr_w_rcond", nul_ins, dict(LR, tol=0.3, null_policy="raise"))
+    _, out = ph.call_plugin(so, "pl_lr_w_rcond", nul_ins, dict(LR, tol=0.3, null_policy="skip"))
+    ref_s, _, _, sv_s = np.linalg.lstsq(X[~mask], Y[~mask, 0], rcond=0.3)
+    np.testing.assert_allclose(out.to_pylist()[0]["coeffs"], ref_s, atol=1e-10)
+    _, out = ph.call_plugin(so, "pl_lr_w_rcond", nul_ins, dict(LR, tol=0.3, null_policy="zero"))
+    Xz = X.copy()
+    Xz[mask, 0] = 0.0
+    np.testing.assert_allclose(out.to_pylist()[0]["coeffs"], np.linalg.lstsq(Xz, Y[:, 0], rcond=0.3)[0], atol=1e-10)
