@@ -899,6 +899,7 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
     int64_t chunk = std::max<int64_t>(big ? 64 : 4096, (int64_t)(128ll << 20) / (int64_t)(sizeof(T) * q * q));
     chunk = std::min(chunk, n_groups);
     size_t need = 131072 + sizeof(T) * (size_t)chunk * q * q;
+    need += (size_t)n_groups * 4 + (size_t)chunk * (pp * sizeof(T) + 1) + 4096;  // the fused path's pivoted-QR pass: list, results
     if (big) need += (size_t)n_groups * (n_feat + 1) * sizeof(T*) + moments_wide_workspace(ctx->num_cus, n_feat, n_rows) + 8192;
     if (space == PDS_HOST) need += (size_t)(n_groups + 1) * 8 + (size_t)n_groups * (pp * sizeof(T) + 1) + 4096;
     if (nullable) {
@@ -1004,7 +1005,7 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
                 return rc;
         }
     } else if (n_feat <= 16 && !want_piv && !(unfused_env && unfused_env[0] == '1') && n_groups < (1ll << 31)) {
-        if (int rc = launch_grouped_fused<T>(ctx, dc, n_feat, n_rows, d_off, n_groups, sp, d_coeffs, d_null)) return rc;
+        if (int rc = launch_grouped_fused<T>(ctx, dc, n_feat, n_rows, d_off, n_groups, sp, d_coeffs, d_null, d_mom, chunk)) return rc;
     } else {
         for (int64_t g0 = 0; g0 < n_groups; g0 += chunk) {
             const int64_t gc = std::min(chunk, n_groups - g0);

@@ -145,16 +145,20 @@ template <typename T>
 int launch_moments_wide(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, bool weighted, T* d_moments);
 size_t moments_wide_workspace(int num_cus, int n_feat, int64_t n_rows, bool weighted = false);
 
-// segmented (per-group) moments: d_moments [n_groups][(p+2)^2]
+// segmented (per-group) moments: d_moments [n_groups][(p+2)^2].  d_group_index (p <= 16 only): record g belongs to group
+// d_group_index[g] of the offsets array instead of group g.
 template <typename T>
 int launch_grouped_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, const int64_t* d_offsets,
-                           int64_t n_groups, T* d_moments);
+                           int64_t n_groups, T* d_moments, const int32_t* d_group_index = nullptr);
 
 struct SolveParams;
-// grouped_fused.hip: per-group Gram + pivoted-QR solve in one kernel (p' <= 16, OLS / ridge)
+// grouped_fused.hip: per-group Gram + gated Cholesky in one streaming kernel (p <= 16, OLS / ridge); unless the caller asked
+// for "choleskey", groups next to the gate go through a second, pivoted-QR pass (d_mom_scratch: room for `scratch_groups`
+// moment records of (p+2)^2 values; the pass is chunked by it)
 template <typename T>
 int launch_grouped_fused(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, const int64_t* d_offsets,
-                         int64_t n_groups, const SolveParams& sp, T* d_coeffs, uint8_t* d_flags);
+                         int64_t n_groups, const SolveParams& sp, T* d_coeffs, uint8_t* d_flags, T* d_mom_scratch,
+                         int64_t scratch_groups);
 
 // ---- solve.hip ----
 struct SolveParams {

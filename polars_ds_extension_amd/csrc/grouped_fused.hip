@@ -283,7 +283,9 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
         const bool colv = j < pp;
         const int64_t sys = gbase + sub;
         const bool live = sub < npend;
+        const bool few = null_p;  // fewer rows than coefficients: null whatever the solver says
         bool is_null = null_p;
+        bool suspect = false;
         double zj = 0.0;
         int pj = j;
         PDS_T0();
@@ -292,7 +294,10 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
             spk.pp = p;  // (a compile-time constant under PC != 0: the per-step `K < p'` branches fold away)
             spk.p = spk.pp;
             spk.gate_on = 1;           // this kernel only exists for the gated Cholesky (launch_stream_lps)
-            chol_core<LPS>(a_p, dj_p, j, spk, is_null, zj);
+            chol_core<LPS>(a_p, dj_p, j, spk, is_null, zj, &suspect);
+            // marginal / gated / broken-down systems are left to the pivoted-QR pass behind this kernel (flag 2)
+            suspect = suspect && !few;
+            is_null = is_null || suspect;
         } else {
             solve_core<LPS>(a_p, b_p, dj_p, j, lane, sp, is_null, pj, zj);
         }
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
             const double b0 = (ys_p - sb) / n_p;
             if (live && j == 0) coeffs[sys * (int64_t)pout + p] = is_null ? (T)__builtin_nan("") : (T)b0;
         }
-        if (live && j == 0 && flags) flags[sys] = is_null ? 1 : 0;
+        if (live && j == 0 && flags) flags[sys] = suspect ? 2 : (is_null ? 1 : 0);
         PDS_T1(3);
         gbase += npend;
         npend = 0;
@@ -567,10 +572,37 @@ static int launch_stream_lps(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, 
     return PDS_OK;
 }
 
+// ---- second pass: the groups the streaming kernel marked (flag 2) go through the reference's default factorisation
+__global__ void collect_marked_kernel(const uint8_t* __restrict__ flags, int64_t n_groups, int32_t* __restrict__ list,
+                                      unsigned* __restrict__ count) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool hit = g < n_groups && flags[g] == 2;
+    // one atomic per wave: the marked groups of a wave take consecutive slots
+    const unsigned long long m = __ballot(hit);
+    if (m == 0ull) return;
+    const int lane = threadIdx.x & 63;
+    unsigned base = 0;
+    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(count, (unsigned)__popcll(m));
+    base = __shfl(base, __ffsll((long long)m) - 1);
+    if (hit) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)g;
+}
+template <typename T>
+__global__ void scatter_marked_kernel(const T* __restrict__ co_c, const uint8_t* __restrict__ fl_c, const int32_t* __restrict__ list,
+                                      int64_t n, int pp, T* __restrict__ coeffs, uint8_t* __restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * pp) return;
+    const int64_t k = i / pp;
+    const int c = (int)(i - k * pp);
+    const int64_t g = list[k];
+    coeffs[g * pp + c] = co_c[i];
+    if (c == 0) flags[g] = fl_c[k] ? 1 : 0;
+}
+
 // OLS / ridge, p <= 16 features (+ intercept)
 template <typename T>
 int launch_grouped_fused(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, const int64_t* d_offsets,
-                         int64_t n_groups, const SolveParams& sp, T* d_coeffs, uint8_t* d_flags) {
+                         int64_t n_groups, const SolveParams& sp, T* d_coeffs, uint8_t* d_flags, T* d_mom_scratch,
+                         int64_t scratch_groups) {
     SolveRegDev sd;
     sd.p = sp.p;
     sd.bias = sp.add_bias ? 1 : 0;
@@ -584,10 +616,46 @@ int launch_grouped_fused(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int6
     if (n_groups >= (1ll << 31)) return fail(PDS_ERR_INVALID, "internal: fused grouped kernel counts groups per wave in 32 bits");
     const char* piv = std::getenv("PDS_GROUPED_PIVOTED");
     const bool chol = sd.gate_on && !(piv && piv[0] == '1');
+    // solver = "choleskey" IS this kernel's factorisation (llt + the 2 sum ln L_ii gate, lr_solvers.rs:369-380); for "qr"
+    // (default) and "svd" the kernel answers the clear cases and leaves the rest to the pivoted QR below
+    const bool second_pass = chol && sp.solver != PDS_SOLVER_CHOLESKEY && d_flags && d_mom_scratch && scratch_groups > 0;
+    sd.sus_tol = second_pass ? std::sqrt(sd.inv_tol) : 0.0;
     // (the intercept takes no solver lane: the kernel size follows the feature count)
-    if (sd.p <= 4) return launch_stream_lps<T, 4>(ctx, dc, n_feat, d_offsets, n_groups, n_rows, sd, chol, d_coeffs, d_flags);
-    if (sd.p <= 8) return launch_stream_lps<T, 8>(ctx, dc, n_feat, d_offsets, n_groups, n_rows, sd, chol, d_coeffs, d_flags);
-    return launch_stream_lps<T, 16>(ctx, dc, n_feat, d_offsets, n_groups, n_rows, sd, chol, d_coeffs, d_flags);
+    int rc;
+    if (sd.p <= 4) rc = launch_stream_lps<T, 4>(ctx, dc, n_feat, d_offsets, n_groups, n_rows, sd, chol, d_coeffs, d_flags);
+    else if (sd.p <= 8) rc = launch_stream_lps<T, 8>(ctx, dc, n_feat, d_offsets, n_groups, n_rows, sd, chol, d_coeffs, d_flags);
+    else rc = launch_stream_lps<T, 16>(ctx, dc, n_feat, d_offsets, n_groups, n_rows, sd, chol, d_coeffs, d_flags);
+    if (rc || !second_pass) return rc;
+    // ---- marked groups: Gram records (indexed grouped build) -> pivoted Householder QR with the log-det gate -> scatter
+    int32_t* d_list = reinterpret_cast<int32_t*>(ws_take(ctx, (size_t)n_groups * sizeof(int32_t)));
+    unsigned* d_count = reinterpret_cast<unsigned*>(ws_take(ctx, 256));
+    if (!d_list || !d_count) return fail(PDS_ERR_HIP, "workspace allocation failed");
+    PDS_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(unsigned), ctx->stream));
+    hipLaunchKernelGGL(collect_marked_kernel, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, ctx->stream, d_flags, n_groups,
+                       d_list, d_count);
+    PDS_HIP_CHECK(hipGetLastError());
+    if (int rc2 = ensure_pinned(ctx, 4096)) return rc2;
+    unsigned* h_count = reinterpret_cast<unsigned*>(static_cast<char*>(ctx->pinned) + 3072);
+    PDS_HIP_CHECK(hipMemcpyAsync(h_count, d_count, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const int64_t marked = (int64_t)*h_count;
+    if (marked == 0) return PDS_OK;
+    const int pp = sd.pp;
+    const int64_t chunk = std::min<int64_t>(scratch_groups, marked);
+    T* co_c = reinterpret_cast<T*>(ws_take(ctx, (size_t)chunk * pp * sizeof(T)));
+    uint8_t* fl_c = reinterpret_cast<uint8_t*>(ws_take(ctx, (size_t)chunk));
+    if (!co_c || !fl_c) return fail(PDS_ERR_HIP, "workspace allocation failed");
+    SolveParams sq = sp;
+    sq.solver = PDS_SOLVER_QR;
+    for (int64_t k0 = 0; k0 < marked; k0 += chunk) {
+        const int64_t kc = std::min(chunk, marked - k0);
+        if (int rc2 = launch_grouped_moments<T>(ctx, dc, n_feat, d_offsets, kc, d_mom_scratch, d_list + k0)) return rc2;
+        if (int rc2 = launch_solve<T>(ctx, d_mom_scratch, kc, sq, co_c, fl_c, nullptr, nullptr)) return rc2;
+        hipLaunchKernelGGL((scatter_marked_kernel<T>), dim3((unsigned)((kc * pp + 255) / 256)), dim3(256), 0, ctx->stream, co_c, fl_c,
+                           d_list + k0, kc, pp, d_coeffs, d_flags);
+        PDS_HIP_CHECK(hipGetLastError());
+    }
+    return PDS_OK;
 }
 
 #ifdef PDS_PROFILE_PHASES
@@ -600,8 +668,8 @@ extern "C" int pds_debug_phase_cycles(unsigned long long* out, int reset) {
 #endif
 
 template int launch_grouped_fused<double>(pds_ctx*, const DeviceCols<double>&, int, int64_t, const int64_t*, int64_t,
-                                          const SolveParams&, double*, uint8_t*);
+                                          const SolveParams&, double*, uint8_t*, double*, int64_t);
 template int launch_grouped_fused<float>(pds_ctx*, const DeviceCols<float>&, int, int64_t, const int64_t*, int64_t,
-                                         const SolveParams&, float*, uint8_t*);
+                                         const SolveParams&, float*, uint8_t*, float*, int64_t);
 
 }  // namespace pds

@@ -148,7 +148,8 @@ __global__ __launch_bounds__(64) void moments_finalize_kernel(const double* __re
 template <typename T>
 __global__ __launch_bounds__(256, 2) void grouped_moments_kernel(const T* const* __restrict__ cols, int p,
                                                                  const int64_t* __restrict__ offsets,
-                                                                 int64_t n_groups, T* __restrict__ out) {
+                                                                 int64_t n_groups, T* __restrict__ out,
+                                                                 const int32_t* __restrict__ gidx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     char* wl = smem + wave * kWaveLds;
@@ -160,9 +161,15 @@ __global__ __launch_bounds__(256, 2) void grouped_moments_kernel(const T* const*
     fetch_col_ptrs<T, false>(cols, p, cp);
     int64_t g = wid;
     int64_t r0 = 0, rend = 0;
+    // gidx != null: record g is the Gram matrix of group gidx[g] (the pivoted-QR pass over the groups the fused kernel
+    // marked: a sparse subset of the frame's groups, records compact)
+    auto bounds = [&](int64_t k) __attribute__((always_inline)) {
+        const int64_t gg = gidx ? (int64_t)gidx[k] : k;
+        r0 = offsets[gg];
+        rend = offsets[gg + 1];
+    };
     if (g < n_groups) {
-        r0 = offsets[g];
-        rend = offsets[g + 1];
+        bounds(g);
         load_group_tile<T>(cp, p, r0, rend, lane, regs);
     }
     for (; g < n_groups; g += nw) {
@@ -175,8 +182,7 @@ __global__ __launch_bounds__(256, 2) void grouped_moments_kernel(const T* const*
         const int64_t ng = grend - gr0;
         const int64_t gn = g + nw;
         if (ng <= 128 && gn < n_groups) {  // prefetch the next group's first tile
-            r0 = offsets[gn];
-            rend = offsets[gn + 1];
+            bounds(gn);
             load_group_tile<T>(cp, p, r0, rend, lane, regs);
         }
         {
@@ -191,8 +197,7 @@ __global__ __launch_bounds__(256, 2) void grouped_moments_kernel(const T* const*
             consume_tile<T, false>(wl, lane, (rows + 3) >> 2, acc);
             done += 128;
             if (done >= ng && gn < n_groups) {
-                r0 = offsets[gn];
-                rend = offsets[gn + 1];
+                bounds(gn);
                 load_group_tile<T>(cp, p, r0, rend, lane, regs);
             }
         }
@@ -342,10 +347,11 @@ static void launch_mid_nb(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, con
 
 template <typename T>
 int launch_grouped_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, const int64_t* d_offsets,
-                           int64_t n_groups, T* d_moments) {
+                           int64_t n_groups, T* d_moments, const int32_t* d_group_index) {
     if (n_feat < 1 || n_feat > kMaxFeatWide)
         return fail(PDS_ERR_UNSUPPORTED, "grouped regressions: 1..64 features supported");
     if (n_groups <= 0) return PDS_OK;
+    if (d_group_index && n_feat > kMaxFeatSmall) return fail(PDS_ERR_INVALID, "internal: indexed grouped Gram build is the p <= 16 kernel's");
     if (n_feat > kMaxFeatSmall) {
         const int nb = (n_feat + 2 + 15) / 16;  // 2 .. 5
         KernelTimer timer(ctx, kKindGroupedMoments);
@@ -363,7 +369,7 @@ int launch_grouped_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, co
     size_t lds = (size_t)kWaves * kWaveLds;
     KernelTimer timer(ctx, kKindGroupedMoments);
     hipLaunchKernelGGL((grouped_moments_kernel<T>), dim3(nblocks), dim3(256), lds, ctx->stream, dc.d_ptrs, n_feat,
-                       d_offsets, n_groups, d_moments);
+                       d_offsets, n_groups, d_moments, d_group_index);
     PDS_HIP_CHECK(hipGetLastError());
     return PDS_OK;
 }
@@ -371,8 +377,8 @@ int launch_grouped_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, co
 template int launch_moments<double>(pds_ctx*, const DeviceCols<double>&, int, int64_t, bool, double*);
 template int launch_moments<float>(pds_ctx*, const DeviceCols<float>&, int, int64_t, bool, float*);
 template int launch_grouped_moments<double>(pds_ctx*, const DeviceCols<double>&, int, const int64_t*, int64_t,
-                                            double*);
+                                            double*, const int32_t*);
 template int launch_grouped_moments<float>(pds_ctx*, const DeviceCols<float>&, int, const int64_t*, int64_t,
-                                           float*);
+                                           float*, const int32_t*);
 
 }  // namespace pds

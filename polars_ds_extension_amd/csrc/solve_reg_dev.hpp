@@ -9,6 +9,11 @@ struct SolveRegDev {
     int p, pp, bias, lambda_on_bias, gate_on;
     double lambda, ln_tol;
     double inv_tol;  // 1 / gate_tol (the Cholesky gate compares a product of pivot ratios)
+    // Fused grouped kernel with solver = "qr" (the reference's default col_piv_qr): a system whose pivot-ratio product
+    // reaches sus_tol = sqrt(1 / gate_tol) -- rel. determinant within [tol, sqrt(tol)], every gated one, every breakdown --
+    // is not answered by the Cholesky at all but marked for the pivoted-QR kernel, so that the null decision next to the
+    // threshold and the coefficients of marginal systems come from the reference's own factorisation.  0 = off.
+    double sus_tol = 0.0;
 };
 
 // Cross-lane moves of a double.  The f64 overload of update_dpp matters: with row_newbcast it is ONE v_mov_b64_dpp
@@ -342,7 +347,7 @@ __device__ __forceinline__ double grp_prod<4>(double v) {
 // a[0..LPS) = column j of G (+lambda), a[LPS] = c_j, dj = G_jj.  beta_j is the coefficient of column j.
 template <int LPS>
 __device__ __forceinline__ void chol_core(double (&a)[LPS + 1], double dj, int j, const SolveRegDev& sp, bool& is_null,
-                                          double& beta) {
+                                          double& beta, bool* suspect = nullptr) {
     const int pp = sp.pp;
     const bool colv = j < pp;
     if (sp.gate_on) {
@@ -357,6 +362,7 @@ __device__ __forceinline__ void chol_core(double (&a)[LPS + 1], double dj, int j
     if (sp.gate_on) {
         const double grow = grp_prod<LPS>(colv ? dj * invd : 1.0);  // prod G_kk / L_kk^2
         if (grow >= sp.inv_tol) is_null = true;
+        if (suspect) *suspect = sp.sus_tol > 0.0 && (!ok || !(grow < sp.sus_tol));
     }
     double c[LPS];
 #pragma unroll

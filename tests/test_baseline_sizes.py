@@ -1,0 +1,162 @@
+"""
+BASELINE.json's configs at their configured sizes, against the ORACLE (not only through size-independent properties): the
+frames are SURVEY.md 8(d)'s synthetic inputs (tools/synth.py, seeded, generated on the GPU); the HIP path runs on the whole
+frame, and a prefix / sample large enough to be meaningful and small enough for the CPU restatement to finish in seconds is
+brought to the host and compared.  Tolerances are the contract's: 1e-10 (f64) normwise, 1e-4 (f32).
+"""
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "tools"))
+
+pytestmark = pytest.mark.gpu
+
+F64_TOL = 1e-10
+F32_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def pds():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import polars_ds_extension_amd as m
+
+    m.config.LIN_REG_EXPR_F64 = True
+    return m
+
+
+def _threads(orc):
+    return max(1, min(64, orc.max_threads()))
+
+
+def _rowrel(a, b):
+    return np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64), axis=1) / np.linalg.norm(np.asarray(b, np.float64), axis=1)
+
+
+# ------------------------------------------------------------------------------------------ configs[2]: grouped, 8(d) C3 spec
+def test_c3_spec_sorted_and_shuffled_keys_against_oracle(pds, orc):
+    """
+    1e6 groups, Poisson(100) sizes clipped to [16, 256], 8 features, 0.1 % collinear groups, int64 keys -- sorted and
+    shuffled.  Null flags of ALL groups of the sample equal the oracle's; coefficients of every non-null group within 1e-10.
+    """
+    import torch
+
+    import synth
+
+    G, p, S = 1_000_000, 8, 200_000
+    fr = synth.c3_frame(G, p, seed=2)
+    xs, y, off = fr["xs"], fr["y"], fr["offsets"]
+    assert 0.95e8 < fr["n_rows"] < 1.05e8 and int(fr["sizes"].min()) >= 16 and int(fr["sizes"].max()) <= 256
+    co, nu = pds.lin_reg_by(*xs, target=y, group_offsets=off)
+    # the gate fires exactly on the collinear groups (and nowhere else: every group has >= 16 rows for 8 features)
+    assert bool((nu.bool() == fr["collinear"]).all()) and int(nu.sum().item()) == int(fr["collinear"].sum().item()) >= 900
+    # ---- oracle on the first S groups (their rows are a prefix of the frame)
+    n_s = int(off[S].item())
+    host = [y[:n_s].cpu().numpy()] + [x[:n_s].cpu().numpy() for x in xs]
+    off_h = off[: S + 1].cpu().numpy()
+    co_o, nu_o = orc.grouped_lr(host, off_h, nthreads=_threads(orc))
+    assert np.array_equal(nu[:S].cpu().numpy().astype(bool), nu_o)
+    ok = ~nu_o
+    err = _rowrel(co[:S].cpu().numpy()[ok], co_o[ok])
+    print(f"C3 spec, sorted keys: {S} groups vs oracle, max normwise rel {err.max():.2e}, nulls {int(nu_o.sum())}")
+    assert err.max() < F64_TOL
+    assert bool(torch.isnan(co[nu.bool()]).all())
+    # ---- the same frame with shuffled rows, grouped by the key column on the device
+    perm = torch.randperm(fr["n_rows"], device="cuda", generator=torch.Generator(device="cuda").manual_seed(22))
+    keys_s = fr["keys"][perm] * 3 - 1_000_000  # (keys need not be 0..G-1)
+    xs_s = [x[perm] for x in xs]
+    y_s = y[perm]
+    del perm
+    k2, co2, nu2 = pds.lin_reg_by_key(*xs_s, target=y_s, key=keys_s)
+    assert k2.shape[0] == G and bool((k2 == torch.arange(G, device="cuda") * 3 - 1_000_000).all())
+    assert bool((nu2 == nu).all())
+    okd = ~nu.bool()
+    d = (co2[okd] - co[okd]).norm(dim=1) / co[okd].norm(dim=1)  # same groups, rows summed in another order
+    print(f"C3 spec, shuffled keys vs sorted: max normwise rel {float(d.max()):.2e}")
+    assert float(d.max()) < F64_TOL
+    err2 = _rowrel(co2[:S].cpu().numpy()[ok], co_o[ok])
+    assert err2.max() < F64_TOL
+
+
+# ------------------------------------------------------------------------------------------ configs[3]: rolling, w = 256
+@pytest.mark.parametrize("lam", [0.0, 0.1])
+def test_c4_full_frame_prefix_against_the_reference_chain(pds, orc, lam):
+    """1e8 rows x 8 features, window 256: the first 1e6 output rows against faer_rolling_lr's Woodbury chain (oracle)."""
+    import synth
+
+    n, p, w, m = 100_000_000, 8, 256, 1_000_000
+    fr = synth.c4_frame(n, p, seed=3)
+    co, pr, va = pds.rolling_lin_reg(*fr["xs"], target=fr["y"], window_size=w, l2_reg=lam)
+    assert not bool(va[: w - 1].any()) and bool(va[w - 1:].all())
+    Xh = np.stack([x[:m].cpu().numpy() for x in fr["xs"]], axis=1)
+    yh = fr["y"][:m].cpu().numpy()
+    ref = orc.rolling_lr(Xh, yh, w, l2_reg=lam)  # rows w-1 .. m-1
+    got = co[w - 1: m].cpu().numpy()
+    err = _rowrel(got, ref)
+    print(f"C4 lambda={lam}: 1e6-row prefix vs the reference chain, max normwise rel {err.max():.2e}")
+    assert err.max() < F64_TOL
+    pred_ref = np.einsum("ij,ij->i", Xh[w - 1:], ref)
+    assert np.max(np.abs(pr[w - 1: m].cpu().numpy() - pred_ref) / np.maximum(np.abs(pred_ref), 1e-3)) < F64_TOL
+    # far end of the frame: direct window solves (the chain would have to run 1e8 steps on the host to get there)
+    for i in (n - 1, n - 123_457, n // 2):
+        A = np.stack([x[i - w + 1: i + 1].cpu().numpy() for x in fr["xs"]], axis=1)
+        b = fr["y"][i - w + 1: i + 1].cpu().numpy()
+        direct = np.linalg.solve(A.T @ A + lam * np.eye(p), A.T @ b)
+        assert np.linalg.norm(co[i].cpu().numpy() - direct) / np.linalg.norm(direct) < 1e-9
+
+
+# ------------------------------------------------------------------------------------------ configs[1]: single OLS + report
+def test_c2_prefix_against_oracle(pds, orc):
+    """C2 data (U(0,1) features, two zero coefficients): 1e7-row prefix, lin_reg and lin_reg_report(SE) against the oracle."""
+    import synth
+
+    n, p = 10_000_000, 16
+    fr = synth.c2_frame(n, p, seed=1)
+    Xh = np.stack([x.cpu().numpy() for x in fr["xs"]], axis=1)
+    yh = fr["y"].cpu().numpy()
+    b = pds.lin_reg(*fr["xs"], target=fr["y"], add_bias=True)
+    bo = orc.pl_lr(Xh, yh, add_bias=True)
+    assert np.linalg.norm(b - bo) / np.linalg.norm(bo) < F64_TOL
+    r = pds.lin_reg_report(*fr["xs"], target=fr["y"], add_bias=True)
+    ro = orc.lin_reg_report(np.c_[Xh, np.ones(n)], yh)
+    assert np.linalg.norm(r["beta"] - ro["beta"]) / np.linalg.norm(ro["beta"]) < F64_TOL
+    assert np.max(np.abs(r["std_err"] - ro["std_err"]) / ro["std_err"]) < F64_TOL
+    # t = beta / se: relative to |t| floored at 1 (beta_3 = beta_11 = 0 make two t-values O(1) sums of rounding-size parts)
+    assert np.max(np.abs(r["t"] - ro["t"]) / np.maximum(np.abs(ro["t"]), 1.0)) < 1e-9
+    assert abs(np.ravel(r["r2"])[0] - ro["r2"]) < 1e-12
+
+
+# ------------------------------------------------------------------------------------------ configs[4]: elastic net, f32, p = 512
+def test_c5_one_million_rows_against_oracle_f32_and_f64(pds, orc):
+    """
+    1e6 x 512 f32, AR(0.5) columns, l1 = l2 = 0.01, tol = 1e-5: against the oracle's all-f32 path (what "matches the
+    reference f32 path" means) and against the f64 truth -- both distances printed.
+    """
+    import synth
+
+    n, p = 1_000_000, 512
+    fr = synth.c5_frame(n, p, seed=4)
+    X, y = fr["X"], fr["y"]
+    pds.config.LIN_REG_EXPR_F64 = False
+    try:
+        b = pds.lin_reg(*[X[j] for j in range(p)], target=y, l1_reg=0.01, l2_reg=0.01, tol=1e-5)
+    finally:
+        pds.config.LIN_REG_EXPR_F64 = True
+    assert b.dtype == np.float32
+    Xh = np.asfortranarray(X.cpu().numpy().T)
+    yh = y.cpu().numpy()
+    nt = _threads(orc)
+    o32 = orc.coordinate_descent(Xh, yh, 0.01, 0.01, False, 1e-5, 2000, False, nthreads=nt)
+    truth = orc.coordinate_descent(Xh.astype(np.float64), yh.astype(np.float64), 0.01, 0.01, False, 1e-9, 2000, False, nthreads=nt)
+    nrm = np.linalg.norm(truth)
+    d_gpu, d_orc, d_go = np.linalg.norm(b - truth) / nrm, np.linalg.norm(o32 - truth) / nrm, np.linalg.norm(b - o32) / nrm
+    print(f"C5 1e6 x 512: gpu-truth {d_gpu:.2e}  oracle_f32-truth {d_orc:.2e}  gpu-oracle_f32 {d_go:.2e}")
+    assert d_gpu < F32_TOL
+    assert d_gpu <= max(d_orc, 2e-6)  # never further from the truth than the reference's own f32 arithmetic
+    assert np.array_equal(np.abs(b) > 1e-6, np.abs(truth) > 1e-6)  # same support
