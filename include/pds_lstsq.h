@@ -215,6 +215,30 @@ int pds_lin_reg_report_f32(pds_ctx* ctx, const float* const* cols, const float* 
                            float y_var, pds_report_f32* out);
 
 /*
+ * Row-sharded `pl_lin_reg_report` / `pl_wls_report` (one process per GPU): the stages of
+ * pds_lin_reg_report_* as separate calls, the two exchange steps between them left to the caller.
+ *   1. every rank: pds_moments_* on its rows                     -> all-reduce(SUM) of the (p+2)^2 block
+ *   2. pds_report_fit_from_moments_*: X'X -> col_piv_qr -> inverse, beta (linear_regression.rs:854-858) -- replicated,
+ *      deterministic, so every rank holds the same beta / inv without a broadcast.  moments / beta / inv are HOST buffers
+ *      (beta: p' values; inv: p'^2, column-major).
+ *   3. every rank: pds_report_partials_* on its rows: the residual pass (:863-909)
+ *      partials[0] = sum e^2, partials[1] = sum w e^2 (WLS), partials[2 ..] = the (p+2)^2 block whose leading p' x p' part is
+ *      the HC meat X' diag(s) X (zeros for plain standard errors); 2 + (p+2)^2 doubles, HOST -> all-reduce(SUM)
+ *   4. pds_report_finish_*: the O(p'^2) epilogue (:861-939) on the summed partials; n_rows_total = rows of the whole frame;
+ *      y_var as in pds_lin_reg_report_* (of the whole target).  No device work.
+ */
+int pds_report_fit_from_moments_f64(pds_ctx* ctx, const double* moments, int n_feat, int add_bias, double* beta, double* inv);
+int pds_report_fit_from_moments_f32(pds_ctx* ctx, const float* moments, int n_feat, int add_bias, float* beta, float* inv);
+int pds_report_partials_f64(pds_ctx* ctx, const double* const* cols, const double* weights, int n_feat, int64_t n_rows,
+                            pds_space space, int add_bias, int se_type, const double* beta, const double* inv, double* partials);
+int pds_report_partials_f32(pds_ctx* ctx, const float* const* cols, const float* weights, int n_feat, int64_t n_rows,
+                            pds_space space, int add_bias, int se_type, const float* beta, const float* inv, double* partials);
+int pds_report_finish_f64(int n_feat, int add_bias, int se_type, int weighted, int64_t n_rows_total, double y_var,
+                          const double* beta, const double* inv, const double* partials, pds_report_f64* out);
+int pds_report_finish_f32(int n_feat, int add_bias, int se_type, int weighted, int64_t n_rows_total, float y_var,
+                          const float* beta, const float* inv, const double* partials, pds_report_f32* out);
+
+/*
  * pds_lin_reg_report_nullable_*: `pl_lin_reg_report` on columns with Arrow validity bitmaps: the null policy of
  * series_to_mat_for_lr (linear_regression.rs:151-267, called at :846) on the device, then the same report on the rows
  * that survive it (dof, r2 use that row count).  Arguments as pds_lr_nullable_*; `y_var` stays what Polars computed

@@ -673,6 +673,73 @@ static int lr_rcond_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t
 // ---------------------------------------------------------------------------------------------
 // lin_reg_report / wls_report
 // ---------------------------------------------------------------------------------------------
+// second pass over the frame: residuals (sum e^2, sum w e^2) and, for the HC estimators, the per-row weights s_i followed by
+// one more *weighted* Gram build = the meat X' diag(s) X (d_mom2: (p+2)^2 moment layout; untouched for plain standard errors)
+template <typename T>
+static int report_second_pass(pds_ctx* ctx, const DeviceCols<T>& dc, int p, int64_t n_rows, int bias, bool weighted, int se_type,
+                              const T* d_beta, const T* d_inv, double* d_sums, T* d_mom2) {
+    const int hc = (se_type == PDS_SE) ? 0 : (se_type == PDS_HC2 ? 2 : (se_type == PDS_HC3 ? 3 : 1));
+    T* d_s = hc ? reinterpret_cast<T*>(ws_take(ctx, (size_t)n_rows * sizeof(T))) : nullptr;
+    if (int rc = launch_pass2<T>(ctx, dc, p, n_rows, bias, weighted, d_beta, d_inv, hc, nullptr, nullptr, d_sums,
+                                 reinterpret_cast<double*>(d_s)))
+        return rc;
+    if (hc) {
+        // meat = X' diag(s) X : one more weighted Gram build with w = s
+        DeviceCols<T> dc2;
+        dc2.nc = p + 2;
+        dc2.h_ptrs.assign(dc.h_ptrs.begin(), dc.h_ptrs.begin() + p + 1);
+        dc2.h_ptrs.push_back(d_s);
+        dc2.h_ptrs.resize(std::max(p + 2, 18), dc2.h_ptrs[0]);  // (the p <= 16 kernels fetch 18 entries with wide loads)
+        dc2.d_ptrs = reinterpret_cast<const T**>(ws_take(ctx, sizeof(T*) * dc2.h_ptrs.size()));
+        PDS_HIP_CHECK(hipMemcpyAsync(dc2.d_ptrs, dc2.h_ptrs.data(), sizeof(T*) * dc2.h_ptrs.size(), hipMemcpyHostToDevice, ctx->stream));
+        if (int rc = launch_moments<T>(ctx, dc2, p, n_rows, true, d_mom2)) return rc;
+        PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // (dc2.h_ptrs is the source of the async table copy)
+    }
+    return PDS_OK;
+}
+
+// ---- O(p'^2) host epilogue (linear_regression.rs:861-939): r2 / adj_r2, standard errors, t, p, confidence interval
+template <typename T, typename R>
+static void report_epilogue(int64_t n_rows, int p, int bias, int se_type, bool weighted, T y_var, const T* beta, const T* inv,
+                            const T* meat /*(p+2)^2 moment layout, HC only*/, const double* sums, R* out) {
+    const int pp = p + bias, q = p + 2;
+    const T dof = (T)n_rows - (T)pp;
+    const T nf = (T)n_rows;
+    const T ssr = (T)sums[0];
+    const T ratio = ssr / (y_var * nf);
+    out->r2 = (T)1 - ratio;
+    out->adj_r2 = (T)1 - ratio * (((T)(n_rows - 1)) / (dof - (T)1));
+    std::vector<T> se(pp);
+    if (se_type == PDS_SE) {
+        const T mse = (weighted ? (T)sums[1] : ssr) / dof;
+        for (int i = 0; i < pp; ++i) se[i] = (T)std::sqrt((double)(mse * inv[i + (size_t)i * pp]));
+    } else {
+        // var_hc_ii = inv_i . meat . inv_i ; meat is the (p+bias) leading block of the weighted moments
+        const T factor = (se_type == PDS_HC1) ? nf / (T)(n_rows - pp) : (T)1;
+        for (int i = 0; i < pp; ++i) {
+            double acc = 0.0;
+            for (int a = 0; a < pp; ++a) {
+                double t = 0.0;
+                for (int b = 0; b < pp; ++b) t += (double)meat[a + (size_t)b * q] * (double)inv[b + (size_t)i * pp];
+                acc += (double)inv[a + (size_t)i * pp] * t;
+            }
+            se[i] = (T)std::sqrt((double)((T)acc * factor));
+        }
+    }
+    const double t_alpha = student_t_ppf(0.975, (double)dof);
+    for (int i = 0; i < pp; ++i) {
+        out->beta[i] = beta[i];
+        out->std_err[i] = se[i];
+        const T tv = beta[i] / se[i];
+        out->t[i] = tv;
+        bool err = false;
+        const double sf = student_t_sf(std::fabs((double)tv), (double)dof, &err);
+        out->p[i] = err ? (T)NAN : (T)(2.0 * sf);
+        out->ci_lower[i] = (T)((double)beta[i] - t_alpha * (double)se[i]);
+        out->ci_upper[i] = (T)((double)beta[i] + t_alpha * (double)se[i]);
+    }
+}
+
 template <typename T, typename R>
 static int report_impl(pds_ctx* ctx, const T* const* cols, const T* weights, int n_feat, int64_t n_rows,
                        pds_space space, int add_bias, int se_type, T y_var, R* out,
@@ -747,23 +814,8 @@ static int report_impl(pds_ctx* ctx, const T* const* cols, const T* weights, int
     // xtx.col_piv_qr() -> inverse() and the solve (:855-858, 1028-1030)
     SolveParams sp{p, bias, PDS_SOLVER_QR, 0.0, 0.0, 0};
     if (int rc = launch_solve<T>(ctx, d_mom, 1, sp, d_beta, d_flag, d_inv, nullptr)) return rc;
-    const int hc = (se_type == PDS_SE) ? 0 : (se_type == PDS_HC2 ? 2 : (se_type == PDS_HC3 ? 3 : 1));
-    T* d_s = hc ? reinterpret_cast<T*>(ws_take(ctx, (size_t)n_rows * sizeof(T))) : nullptr;
-    if (int rc = launch_pass2<T>(ctx, dc, p, n_rows, bias, weighted, d_beta, d_inv, hc, nullptr, nullptr, d_sums,
-                                 reinterpret_cast<double*>(d_s)))
-        return rc;
-    if (hc) {
-        // meat = X' diag(s) X : one more weighted Gram build with w = s
-        DeviceCols<T> dc2;
-        dc2.nc = p + 2;
-        dc2.h_ptrs.assign(dc.h_ptrs.begin(), dc.h_ptrs.begin() + p + 1);
-        dc2.h_ptrs.push_back(d_s);
-        dc2.h_ptrs.resize(std::max(p + 2, 18), dc2.h_ptrs[0]);  // (the p <= 16 kernels fetch 18 entries with wide loads)
-        dc2.d_ptrs = reinterpret_cast<const T**>(ws_take(ctx, sizeof(T*) * dc2.h_ptrs.size()));
-        PDS_HIP_CHECK(hipMemcpyAsync(dc2.d_ptrs, dc2.h_ptrs.data(), sizeof(T*) * dc2.h_ptrs.size(), hipMemcpyHostToDevice, ctx->stream));
-        if (int rc = launch_moments<T>(ctx, dc2, p, n_rows, true, d_mom2)) return rc;
-        PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    }
+    if (int rc = report_second_pass<T>(ctx, dc, p, n_rows, bias, weighted, se_type, d_beta, d_inv, d_sums, d_mom2)) return rc;
+    const bool hc = se_type != PDS_SE;
     std::vector<T> beta(pp), inv((size_t)pp * pp), meat((size_t)q * q);
     double sums[2] = {0, 0};
     PDS_HIP_CHECK(hipMemcpyAsync(beta.data(), d_beta, sizeof(T) * pp, hipMemcpyDeviceToHost, ctx->stream));
@@ -771,43 +823,74 @@ static int report_impl(pds_ctx* ctx, const T* const* cols, const T* weights, int
     PDS_HIP_CHECK(hipMemcpyAsync(sums, d_sums, sizeof(sums), hipMemcpyDeviceToHost, ctx->stream));
     if (hc) PDS_HIP_CHECK(hipMemcpyAsync(meat.data(), d_mom2, sizeof(T) * q * q, hipMemcpyDeviceToHost, ctx->stream));
     PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    report_epilogue<T, R>(n_rows, p, bias, se_type, weighted, y_var, beta.data(), inv.data(), meat.data(), sums, out);
+    return PDS_OK;
+}
 
-    // ---- O(p'^2) host epilogue (linear_regression.rs:861-939)
-    const T dof = (T)n_rows - (T)pp;
-    const T nf = (T)n_rows;
-    const T ssr = (T)sums[0];
-    const T ratio = ssr / (y_var * nf);
-    out->r2 = (T)1 - ratio;
-    out->adj_r2 = (T)1 - ratio * (((T)(n_rows - 1)) / (dof - (T)1));
-    std::vector<T> se(pp);
-    if (se_type == PDS_SE) {
-        const T mse = (weighted ? (T)sums[1] : ssr) / dof;
-        for (int i = 0; i < pp; ++i) se[i] = (T)std::sqrt((double)(mse * inv[i + (size_t)i * pp]));
-    } else {
-        // var_hc_ii = inv_i . meat . inv_i ; meat is the (p+bias) leading block of the weighted moments
-        const T factor = (se_type == PDS_HC1) ? nf / (T)(n_rows - pp) : (T)1;
-        for (int i = 0; i < pp; ++i) {
-            double acc = 0.0;
-            for (int a = 0; a < pp; ++a) {
-                double t = 0.0;
-                for (int b = 0; b < pp; ++b) t += (double)meat[a + (size_t)b * q] * (double)inv[b + (size_t)i * pp];
-                acc += (double)inv[a + (size_t)i * pp] * t;
-            }
-            se[i] = (T)std::sqrt((double)((T)acc * factor));
-        }
-    }
-    const double t_alpha = student_t_ppf(0.975, (double)dof);
-    for (int i = 0; i < pp; ++i) {
-        out->beta[i] = beta[i];
-        out->std_err[i] = se[i];
-        const T tv = beta[i] / se[i];
-        out->t[i] = tv;
-        bool err = false;
-        const double sf = student_t_sf(std::fabs((double)tv), (double)dof, &err);
-        out->p[i] = err ? (T)NAN : (T)(2.0 * sf);
-        out->ci_lower[i] = (T)((double)beta[i] - t_alpha * (double)se[i]);
-        out->ci_upper[i] = (T)((double)beta[i] + t_alpha * (double)se[i]);
-    }
+// ---------------------------------------------------------------------------------------------
+// Row-sharded lin_reg_report: the stages of report_impl as separate entry points, the two exchange
+// steps between them (all-reduce of the moment block, all-reduce of [sum e^2 | sum w e^2 | meat]) left to the caller.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+static int report_fit_impl(pds_ctx* ctx, const T* moments, int n_feat, int add_bias, T* beta, T* inv) {
+    if (!ctx || !moments || !beta || !inv) return fail(PDS_ERR_INVALID, "null argument");
+    if (n_feat < 1) return fail(PDS_ERR_INVALID, "need at least one feature column");
+    PDS_HIP_CHECK(hipSetDevice(ctx->device));
+    const int p = n_feat, bias = add_bias ? 1 : 0, pp = p + bias, q = p + 2;
+    if (int rc = ws_reserve(ctx, 131072 + sizeof(T) * (size_t)(q * q + pp * pp + pp + 8))) return rc;
+    T* d_mom = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * q * q));
+    T* d_beta = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * (pp + 2)));
+    T* d_inv = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * pp * pp));
+    uint8_t* d_flag = reinterpret_cast<uint8_t*>(ws_take(ctx, 16));
+    PDS_HIP_CHECK(hipMemcpyAsync(d_mom, moments, sizeof(T) * q * q, hipMemcpyHostToDevice, ctx->stream));
+    SolveParams sp{p, bias, PDS_SOLVER_QR, 0.0, 0.0, 0};
+    if (int rc = launch_solve<T>(ctx, d_mom, 1, sp, d_beta, d_flag, d_inv, nullptr)) return rc;
+    PDS_HIP_CHECK(hipMemcpyAsync(beta, d_beta, sizeof(T) * pp, hipMemcpyDeviceToHost, ctx->stream));
+    PDS_HIP_CHECK(hipMemcpyAsync(inv, d_inv, sizeof(T) * pp * pp, hipMemcpyDeviceToHost, ctx->stream));
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PDS_OK;
+}
+
+template <typename T>
+static int report_partials_impl(pds_ctx* ctx, const T* const* cols, const T* weights, int n_feat, int64_t n_rows, pds_space space,
+                                int add_bias, int se_type, const T* beta, const T* inv, double* partials) {
+    if (!ctx || !cols || !beta || !inv || !partials) return fail(PDS_ERR_INVALID, "null argument");
+    if (n_feat < 1) return fail(PDS_ERR_INVALID, "need at least one feature column");
+    if (n_rows <= 0) return fail(PDS_ERR_EMPTY, "Empty data");
+    if (weights && se_type != PDS_SE) se_type = PDS_SE;
+    PDS_HIP_CHECK(hipSetDevice(ctx->device));
+    const int p = n_feat, bias = add_bias ? 1 : 0, pp = p + bias, q = p + 2;
+    size_t need = 131072 + sizeof(T) * (size_t)(q * q + pp * pp + pp + 8) + sizeof(T*) * (size_t)(p + 64);
+    if (p > kMaxFeatSmall) need += moments_wide_workspace(ctx->num_cus, p, n_rows, true);
+    if (se_type != PDS_SE) need += (size_t)n_rows * sizeof(T) + 512;
+    if (int rc = ws_reserve(ctx, need)) return rc;
+    DeviceCols<T> dc;
+    if (int rc = make_device_cols<T>(ctx, cols, weights, p, n_rows, space, dc)) return rc;
+    T* d_mom2 = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * q * q));
+    T* d_beta = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * (pp + 2)));
+    T* d_inv = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * pp * pp));
+    double* d_sums = reinterpret_cast<double*>(ws_take(ctx, 64));
+    PDS_HIP_CHECK(hipMemcpyAsync(d_beta, beta, sizeof(T) * pp, hipMemcpyHostToDevice, ctx->stream));
+    PDS_HIP_CHECK(hipMemcpyAsync(d_inv, inv, sizeof(T) * pp * pp, hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = report_second_pass<T>(ctx, dc, p, n_rows, bias, weights != nullptr, se_type, d_beta, d_inv, d_sums, d_mom2)) return rc;
+    std::vector<T> meat((size_t)q * q, T(0));
+    PDS_HIP_CHECK(hipMemcpyAsync(partials, d_sums, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (se_type != PDS_SE) PDS_HIP_CHECK(hipMemcpyAsync(meat.data(), d_mom2, sizeof(T) * q * q, hipMemcpyDeviceToHost, ctx->stream));
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < q * q; ++i) partials[2 + i] = (double)meat[i];
+    return PDS_OK;
+}
+
+template <typename T, typename R>
+static int report_finish_impl(int n_feat, int add_bias, int se_type, int weighted, int64_t n_rows_total, T y_var, const T* beta,
+                              const T* inv, const double* partials, R* out) {
+    if (!beta || !inv || !partials || !out) return fail(PDS_ERR_INVALID, "null argument");
+    if (n_feat < 1) return fail(PDS_ERR_INVALID, "need at least one feature column");
+    if (weighted && se_type != PDS_SE) se_type = PDS_SE;
+    const int q = n_feat + 2;
+    std::vector<T> meat((size_t)q * q);
+    for (int i = 0; i < q * q; ++i) meat[i] = (T)partials[2 + i];
+    report_epilogue<T, R>(n_rows_total, n_feat, add_bias ? 1 : 0, se_type, weighted != 0, y_var, beta, inv, meat.data(), partials, out);
     return PDS_OK;
 }
 
@@ -1447,6 +1530,29 @@ int pds_lin_reg_report_f64(pds_ctx* ctx, const double* const* cols, const double
 int pds_lin_reg_report_f32(pds_ctx* ctx, const float* const* cols, const float* weights, int n_feat, int64_t n_rows,
                            pds_space space, int add_bias, int se_type, float y_var, pds_report_f32* out) {
     return report_impl<float, pds_report_f32>(ctx, cols, weights, n_feat, n_rows, space, add_bias, se_type, y_var, out);
+}
+
+int pds_report_fit_from_moments_f64(pds_ctx* ctx, const double* moments, int n_feat, int add_bias, double* beta, double* inv) {
+    return report_fit_impl<double>(ctx, moments, n_feat, add_bias, beta, inv);
+}
+int pds_report_fit_from_moments_f32(pds_ctx* ctx, const float* moments, int n_feat, int add_bias, float* beta, float* inv) {
+    return report_fit_impl<float>(ctx, moments, n_feat, add_bias, beta, inv);
+}
+int pds_report_partials_f64(pds_ctx* ctx, const double* const* cols, const double* weights, int n_feat, int64_t n_rows,
+                            pds_space space, int add_bias, int se_type, const double* beta, const double* inv, double* partials) {
+    return report_partials_impl<double>(ctx, cols, weights, n_feat, n_rows, space, add_bias, se_type, beta, inv, partials);
+}
+int pds_report_partials_f32(pds_ctx* ctx, const float* const* cols, const float* weights, int n_feat, int64_t n_rows,
+                            pds_space space, int add_bias, int se_type, const float* beta, const float* inv, double* partials) {
+    return report_partials_impl<float>(ctx, cols, weights, n_feat, n_rows, space, add_bias, se_type, beta, inv, partials);
+}
+int pds_report_finish_f64(int n_feat, int add_bias, int se_type, int weighted, int64_t n_rows_total, double y_var,
+                          const double* beta, const double* inv, const double* partials, pds_report_f64* out) {
+    return report_finish_impl<double, pds_report_f64>(n_feat, add_bias, se_type, weighted, n_rows_total, y_var, beta, inv, partials, out);
+}
+int pds_report_finish_f32(int n_feat, int add_bias, int se_type, int weighted, int64_t n_rows_total, float y_var,
+                          const float* beta, const float* inv, const double* partials, pds_report_f32* out) {
+    return report_finish_impl<float, pds_report_f32>(n_feat, add_bias, se_type, weighted, n_rows_total, y_var, beta, inv, partials, out);
 }
 
 int pds_lin_reg_report_nullable_f64(pds_ctx* ctx, const double* const* cols, const uint8_t* const* validity,

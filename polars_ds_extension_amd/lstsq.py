@@ -21,7 +21,7 @@ from . import _lib, config
 
 __all__ = [
     "Context", "default_context", "lin_reg", "lin_reg_report", "lin_reg_by", "rolling_lin_reg",
-    "recursive_lin_reg", "lin_reg_w_rcond", "elastic_net_fit", "gram_moments", "lin_reg_from_moments", "query_ar_coeffs",
+    "recursive_lin_reg", "lin_reg_w_rcond", "elastic_net_fit", "report_fit_from_moments", "report_partials", "report_finish", "gram_moments", "lin_reg_from_moments", "query_ar_coeffs",
 ]
 
 
@@ -456,6 +456,60 @@ def lin_reg_report(*x, target, add_bias: bool = False, weights=None, std_err: st
                                             cols.space, int(bool(add_bias)), _lib.SE_TYPES.get(std_err, 0), yv,
                                             C.byref(rep)))
     return _report_dict(outs, rep, cols.n_feat, add_bias, std_err, weights is not None, feature_names, dt)
+
+
+# ---- the stages of lin_reg_report as separate calls (row-sharded multi-GPU form: parallel.lin_reg_report_row_sharded)
+def report_fit_from_moments(moments, *, add_bias: bool = False, ctx: Context | None = None):
+    """Stage 2: (all-reduced) moment matrix -> (beta [p'], inv [p' x p'] = (X'X)^-1 by column-pivoted QR).  Host arrays."""
+    ctx = ctx or default_context()
+    dt = _dtype()
+    if _is_torch(moments):
+        moments = moments.detach().cpu().numpy()
+    m = np.asfortranarray(np.asarray(moments, dtype=dt))
+    q = int(m.shape[0])
+    p = q - 2
+    pp = p + int(bool(add_bias))
+    beta = np.empty(pp, dtype=dt)
+    inv = np.empty((pp, pp), dtype=dt, order="F")
+    _lib.check(ctx.fn("pds_report_fit_from_moments")(ctx._h, C.c_void_p(m.ctypes.data), p, int(bool(add_bias)),
+                                                     C.c_void_p(beta.ctypes.data), C.c_void_p(inv.ctypes.data)))
+    return beta, inv
+
+
+def report_partials(*x, target, beta, inv, add_bias: bool = False, weights=None, std_err: str = "se", ctx: Context | None = None):
+    """Stage 3 on this rank's rows: [sum e^2, sum w e^2, meat block ((p+2)^2)] as one float64 vector (the all-reduce payload)."""
+    ctx = ctx or default_context()
+    cols = _Cols(target, x, weights)
+    _follow(ctx, cols)
+    dt = _dtype()
+    q = cols.n_feat + 2
+    beta = np.ascontiguousarray(beta, dtype=dt)
+    inv = np.asfortranarray(np.asarray(inv, dtype=dt))
+    out = np.zeros(2 + q * q, dtype=np.float64)
+    _lib.check(ctx.fn("pds_report_partials")(ctx._h, cols.cols, cols.weights, cols.n_feat, C.c_int64(cols.n_rows), cols.space,
+                                             int(bool(add_bias)), _lib.SE_TYPES.get(std_err, 0), C.c_void_p(beta.ctypes.data),
+                                             C.c_void_p(inv.ctypes.data), C.c_void_p(out.ctypes.data)))
+    return out
+
+
+def report_finish(beta, inv, partials, *, n_rows_total: int, y_var: float, add_bias: bool = False, weighted: bool = False,
+                  std_err: str = "se", feature_names: Sequence[str] | None = None) -> dict:
+    """Stage 4: the O(p'^2) epilogue on the summed partials (no device work)."""
+    lib = _lib.load()
+    dt = _dtype()
+    beta = np.ascontiguousarray(beta, dtype=dt)
+    inv = np.asfortranarray(np.asarray(inv, dtype=dt))
+    partials = np.ascontiguousarray(partials, dtype=np.float64)
+    pp = int(beta.shape[0])
+    n_feat = pp - int(bool(add_bias))
+    outs = {k: np.empty(pp, dtype=dt) for k in ("beta", "std_err", "t", "p", "ci_lower", "ci_upper")}
+    R = _lib.ReportF64 if config.LIN_REG_EXPR_F64 else _lib.ReportF32
+    rep = R(*[C.c_void_p(outs[k].ctypes.data) for k in ("beta", "std_err", "t", "p", "ci_lower", "ci_upper")], 0.0, 0.0)
+    yv = C.c_double(y_var) if config.LIN_REG_EXPR_F64 else C.c_float(y_var)
+    fn = getattr(lib, "pds_report_finish" + _suffix())
+    _lib.check(fn(n_feat, int(bool(add_bias)), _lib.SE_TYPES.get(std_err, 0), int(bool(weighted)), C.c_int64(int(n_rows_total)), yv,
+                  C.c_void_p(beta.ctypes.data), C.c_void_p(inv.ctypes.data), C.c_void_p(partials.ctypes.data), C.byref(rep)))
+    return _report_dict(outs, rep, n_feat, add_bias, std_err, weighted, feature_names, dt)
 
 
 def _report_dict(outs, rep, n_feat, add_bias, std_err, weighted, feature_names, dt):

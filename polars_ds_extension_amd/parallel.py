@@ -4,12 +4,13 @@ Multi-GPU host logic (one process per GPU, torch.distributed; backend "nccl" == 
 The reference has no distributed layer at all; what shards is the data:
 
   * group_by-partitioned regressions (the headline path) shard BY GROUP KEY: every rank owns a contiguous
-    range of groups and runs the grouped kernels on it.  There is no data-path collective; only the
-    results (n_groups x p' coefficients + null flags) are gathered when a caller wants them on one rank.
+    range of groups and runs the grouped kernels on it.  A frame that lives on one rank is SCATTERED first (grouped
+    point-to-point sends, root -> every peer over its own xGMI link); the results (n_groups x p' coefficients + null
+    flags) are GATHERED to the requesting rank the same way, piece by piece while the next piece is computed.
   * a single big regression shards BY ROW RANGE: every rank builds the moment matrix of its rows and ONE
     all-reduce(SUM) of that (p+2)^2 block (2.6 KB at p = 16 -- latency bound, any algorithm) makes the
     normal equations global; the O(p^3) solve is replicated.  lin_reg_report adds one more all-reduce of
-    (sum e^2, sum w e^2) after the residual pass.
+    [sum e^2 | sum w e^2 | HC meat] after the residual pass (lin_reg_report_row_sharded).
   * rolling regressions shard BY ROW RANGE with a halo: rank r also reads the window-1 rows in front of its range
     (its windows reach back into them) and drops their outputs; no collective.  Expanding ("recursive")
     regressions need what came before: every rank builds the moment matrix of its rows, ONE all-gather of
@@ -97,63 +98,234 @@ def lin_reg_row_sharded(xs_local: Sequence, y_local, *, weights_local=None, mome
     return solve_fn(m, **lin_reg_kwargs)
 
 
+def _hip_grouped_out(xs, y, offsets, **kw):
+    from . import lstsq
+
+    return lstsq.lin_reg_by(*xs, target=y, group_offsets=offsets, **kw)
+
+
+def chunk_bounds(n_groups: int, chunks: int) -> list[tuple[int, int]]:
+    """`chunks` consecutive ranges of equal group COUNT (a function of the count alone: the gathering rank can reproduce it)."""
+    chunks = max(1, min(int(chunks), max(int(n_groups), 1)))
+    return [shard_bounds(n_groups, chunks, c) for c in range(chunks)]
+
+
+def lin_reg_by_group_local_shard(xs_loc, y_loc, loc_off, parts, *, rank: int, gather_to: int | None = 0, chunks: int = 1,
+                                 grouped_fn: Callable | None = None, group=None, **lin_reg_kwargs):
+    """
+    The compute + gather leg of the group-sharded regression on a rank that already HOLDS its shard (rows of groups
+    parts[rank] = [g_lo, g_hi), `loc_off` rebased to the shard).  The shard is fitted in `chunks` pieces; a peer hands every
+    finished piece to the gathering rank at once (isend on RCCL's stream while the next piece is being computed), the
+    gathering rank posts all receives up front, straight into the rows of the assembled result -- no staging copy, and every
+    peer's traffic rides its own xGMI link into the root (results are n_groups x p' values + one flag byte per group:
+    16 MB per peer at 1e6 groups x 16 features on 8 GPUs).
+    Returns (coeffs_local, is_null_local) and, on the gathering rank, additionally the assembled (coeffs, is_null).
+    """
+    import torch
+
+    dist = _dist()
+    grouped_fn = grouped_fn or _hip_grouped_out
+    world = len(parts)
+    g_lo, g_hi = parts[rank]
+    ng = g_hi - g_lo
+    pp = len(xs_loc) + int(bool(lin_reg_kwargs.get("add_bias", False)))
+    is_t = isinstance(y_loc, torch.Tensor)  # (NumPy 2 arrays have a .device too)
+    dev = y_loc.device if is_t else torch.device("cpu")
+    cdt = y_loc.dtype if is_t else torch.from_numpy(np.asarray(y_loc)[:0]).dtype
+    off = loc_off
+    off_h = np.asarray(loc_off.cpu() if hasattr(loc_off, "cpu") else loc_off, dtype=np.int64)  # (row bounds of the pieces: host)
+    root = gather_to
+    co_all = nu_all = None
+    reqs = []
+    if root is not None and rank == root:
+        total = parts[-1][1]
+        co_all = torch.empty((total, pp), dtype=cdt, device=dev)
+        nu_all = torch.empty((total,), dtype=torch.uint8, device=dev)
+        ops = []
+        for r in range(world):
+            if r == rank:
+                continue
+            for c_lo, c_hi in chunk_bounds(parts[r][1] - parts[r][0], chunks):
+                if c_hi > c_lo:
+                    lo, hi = parts[r][0] + c_lo, parts[r][0] + c_hi
+                    ops.append(dist.P2POp(dist.irecv, co_all[lo:hi], r, group))
+                    ops.append(dist.P2POp(dist.irecv, nu_all[lo:hi], r, group))
+        if ops:
+            reqs = dist.batch_isend_irecv(ops)
+    keep = []
+    co_parts, nu_parts = [], []
+    for c_lo, c_hi in chunk_bounds(ng, chunks) if ng > 0 else []:
+        if c_hi <= c_lo:
+            continue
+        r0, r1 = int(off_h[c_lo]), int(off_h[c_hi])
+        sub_off = off[c_lo: c_hi + 1] - r0
+        co, nu = grouped_fn([x[r0:r1] for x in xs_loc], y_loc[r0:r1], sub_off, **lin_reg_kwargs)
+        co = co if isinstance(co, torch.Tensor) else torch.as_tensor(np.asarray(co))
+        nu = (nu if isinstance(nu, torch.Tensor) else torch.as_tensor(np.asarray(nu))).to(torch.uint8)
+        co_parts.append(co)
+        nu_parts.append(nu)
+        if root is None:
+            continue
+        if rank == root:
+            co_all[g_lo + c_lo: g_lo + c_hi].copy_(co)
+            nu_all[g_lo + c_lo: g_lo + c_hi].copy_(nu)
+        else:
+            co, nu = co.contiguous(), nu.contiguous()
+            keep += [co, nu]
+            reqs.append(dist.isend(co, dst=root, group=group))
+            reqs.append(dist.isend(nu, dst=root, group=group))
+    for q in reqs:
+        q.wait()
+    co_loc = torch.cat(co_parts, 0) if co_parts else torch.empty((0, pp), dtype=cdt, device=dev)
+    nu_loc = torch.cat(nu_parts, 0) if nu_parts else torch.empty((0,), dtype=torch.uint8, device=dev)
+    if root is not None and rank == root:
+        return co_loc, nu_loc, co_all, nu_all
+    return co_loc, nu_loc
+
+
+def scatter_frame_by_groups(xs, y, group_offsets, *, root: int = 0, group=None, device=None):
+    """
+    The scatter leg for a frame that is resident on ONE rank ("device-resident frame on GPU0: RCCL scatter"):
+    `root` passes the whole columns and the n_groups + 1 row offsets, every other rank passes None.  The groups are range-
+    partitioned balanced in rows; the root sends every peer the row range of every column (views of the resident columns: no
+    staging copy) plus the peer's rebased offsets as ONE grouped point-to-point launch -- root -> 7 peers uses all 7 xGMI
+    links at once, 1/8 of the frame per link -- and every peer receives straight into fresh tensors.
+    Returns (xs_local, y_local, offsets_local (int64, rebased to the shard), parts) on every rank.
+    """
+    import torch
+
+    dist = _dist()
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    meta = [None]
+    if rank == root:
+        off = np.asarray(group_offsets.cpu() if hasattr(group_offsets, "cpu") else group_offsets, dtype=np.int64)
+        parts = shard_groups_by_rows(off, world)
+        rows = [(int(off[lo]), int(off[hi])) for lo, hi in parts]
+        meta = [dict(parts=parts, rows=rows, n_cols=len(xs), dtype=str(y.dtype).replace("torch.", ""))]
+    dist.broadcast_object_list(meta, src=root, group=group)
+    m = meta[0]
+    parts, rows, nc = m["parts"], m["rows"], m["n_cols"]
+    dt = getattr(torch, m["dtype"])
+    if rank == root:
+        dev = y.device
+        off_t = torch.as_tensor(off, device=dev)
+        ops, keep = [], []
+        for r in range(world):
+            if r == root or parts[r][1] <= parts[r][0]:
+                continue
+            r0, r1 = rows[r]
+            for col in (*xs, y):
+                ops.append(dist.P2POp(dist.isend, col[r0:r1], r, group))
+            lo, hi = parts[r]
+            o = (off_t[lo: hi + 1] - r0).contiguous()
+            keep.append(o)
+            ops.append(dist.P2POp(dist.isend, o, r, group))
+        for q in (dist.batch_isend_irecv(ops) if ops else []):
+            q.wait()
+        r0, r1 = rows[root]
+        lo, hi = parts[root]
+        return [x[r0:r1] for x in xs], y[r0:r1], off_t[lo: hi + 1] - r0, parts
+    dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu"))
+    r0, r1 = rows[rank]
+    lo, hi = parts[rank]
+    n = r1 - r0
+    xs_l = [torch.empty(n, dtype=dt, device=dev) for _ in range(nc)]
+    y_l = torch.empty(n, dtype=dt, device=dev)
+    off_l = torch.zeros(hi - lo + 1, dtype=torch.int64, device=dev)
+    if hi > lo:
+        ops = [dist.P2POp(dist.irecv, t, root, group) for t in (*xs_l, y_l, off_l)]
+        for q in dist.batch_isend_irecv(ops):
+            q.wait()
+    return xs_l, y_l, off_l, parts
+
+
 def lin_reg_by_group_sharded(xs, y, group_offsets, *, rank: int | None = None, world: int | None = None,
-                             grouped_fn: Callable | None = None, gather_to: int | None = None, group=None,
+                             grouped_fn: Callable | None = None, gather_to: int | None = None, chunks: int = 1, group=None,
                              **lin_reg_kwargs):
     """
     group_by(key).agg(pds.lin_reg(...)) sharded by group key.  `xs`, `y`, `group_offsets` describe the whole
     frame as visible to this rank (e.g. a host-resident Arrow table every rank can slice, or each rank's
     own copy); the rank extracts ITS groups' rows, runs the grouped kernels, and returns
     (g_lo, g_hi, coeffs_local, is_null_local).  With gather_to = r the per-rank results are gathered on
-    rank r, which additionally returns the assembled (coeffs, is_null) for all groups.
+    rank r (lin_reg_by_group_local_shard), which additionally returns the assembled (coeffs, is_null) for all groups.
+    A frame resident on one rank only goes through scatter_frame_by_groups first.
     """
-    import torch
-
     dist = _dist()
     rank = dist.get_rank(group) if rank is None else rank
     world = dist.get_world_size(group) if world is None else world
-    grouped_fn = grouped_fn or _hip_grouped
     off = np.asarray(group_offsets.cpu() if hasattr(group_offsets, "cpu") else group_offsets, dtype=np.int64)
     parts = shard_groups_by_rows(off, world)
     g_lo, g_hi = parts[rank]
     r_lo, r_hi = int(off[g_lo]), int(off[g_hi])
-    loc_off = off[g_lo : g_hi + 1] - r_lo
-    xs_loc = [x[r_lo:r_hi] for x in xs]
-    y_loc = y[r_lo:r_hi]
-    if g_hi > g_lo:
-        co, nu = grouped_fn(xs_loc, y_loc, loc_off, **lin_reg_kwargs)
-    else:
+    loc_off = off[g_lo: g_hi + 1] - r_lo
+    res = lin_reg_by_group_local_shard([x[r_lo:r_hi] for x in xs], y[r_lo:r_hi], loc_off, parts, rank=rank, gather_to=gather_to,
+                                       chunks=chunks, grouped_fn=grouped_fn, group=group, **lin_reg_kwargs)
+    if gather_to is not None and rank == gather_to:
+        return g_lo, g_hi, res[2], res[3]
+    co, nu = res[0], res[1]
+    if g_hi <= g_lo:
         co, nu = None, None
-    if gather_to is None:
-        return g_lo, g_hi, co, nu
-    # results only: n_groups_r x p' values + flags per rank (8 MB per rank at config 3) -> gather
-    pp = len(xs) + int(bool(lin_reg_kwargs.get("add_bias", False)))
-    def to_t(a, shape, dtype):
-        if a is None:
-            return torch.zeros(shape, dtype=dtype)
-        return a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a))
-    co_t = to_t(co, (0, pp), torch.float64)
-    nu_t = to_t(nu, (0,), torch.uint8).to(torch.uint8)
-    sizes = [parts[r][1] - parts[r][0] for r in range(world)]
-    dev = co_t.device
-    if rank == gather_to:
-        co_list = [torch.empty((sizes[r], pp), dtype=co_t.dtype, device=dev) for r in range(world)]
-        nu_list = [torch.empty((sizes[r],), dtype=torch.uint8, device=dev) for r in range(world)]
-    else:
-        co_list = nu_list = None
-    # gather with unequal sizes: point-to-point to the root (every peer uses its own xGMI link to the root)
-    if rank == gather_to:
-        co_list[rank].copy_(co_t)
-        nu_list[rank].copy_(nu_t)
-        for r in range(world):
-            if r != rank and sizes[r] > 0:
-                dist.recv(co_list[r], src=r, group=group)
-                dist.recv(nu_list[r], src=r, group=group)
-        return g_lo, g_hi, torch.cat(co_list, 0), torch.cat(nu_list, 0)
-    if sizes[rank] > 0:
-        dist.send(co_t.contiguous(), dst=gather_to, group=group)
-        dist.send(nu_t.contiguous(), dst=gather_to, group=group)
     return g_lo, g_hi, co, nu
+
+
+def _hip_report_fit(moments, **kw):
+    from . import lstsq
+
+    return lstsq.report_fit_from_moments(moments, **kw)
+
+
+def _hip_report_partials(xs, y, weights, beta, inv, **kw):
+    from . import lstsq
+
+    return lstsq.report_partials(*xs, target=y, weights=weights, beta=beta, inv=inv, **kw)
+
+
+def _hip_report_finish(beta, inv, partials, **kw):
+    from . import lstsq
+
+    return lstsq.report_finish(beta, inv, partials, **kw)
+
+
+def lin_reg_report_row_sharded(xs_local: Sequence, y_local, *, add_bias: bool = False, std_err: str = "se", weights_local=None,
+                               y_var: float | None = None, moments_fn: Callable | None = None, fit_fn: Callable | None = None,
+                               partials_fn: Callable | None = None, finish_fn: Callable | None = None, group=None):
+    """
+    pds.lin_reg_report (and the WLS report with `weights_local`) over row-sharded columns: the reference's arithmetic
+    (linear_regression.rs:854-909) with its two passes over X turned into two exchange steps --
+      1. local moment block -> all-reduce(SUM)                     ((p+2)^2 values: 2.6 KB at p = 16)
+      2. (X'X)^-1 and beta from the summed block, replicated on every rank (deterministic: no broadcast needed)
+      3. local residual pass with that beta / inverse: [sum e^2 | sum w e^2 | meat] -> all-reduce(SUM)   (2 + (p+2)^2 values)
+      4. the O(p'^2) epilogue (SE / HC0-3, t, p, CI, r2), replicated.
+    `y_var` defaults to the ddof = 1 variance of the whole target, taken from the summed moments.  Every rank returns the report.
+    """
+    import torch
+
+    dist = _dist()
+    moments_fn = moments_fn or _hip_moments
+    fit_fn = fit_fn or _hip_report_fit
+    partials_fn = partials_fn or _hip_report_partials
+    finish_fn = finish_fn or _hip_report_finish
+    m = moments_fn(xs_local, y_local, weights_local)
+    if not isinstance(m, torch.Tensor):
+        m = torch.as_tensor(np.asarray(m))
+    m = m.contiguous()
+    dist.all_reduce(m, op=dist.ReduceOp.SUM, group=group)  # exchange step 1
+    n_local = torch.tensor([len(y_local)], dtype=torch.int64, device=m.device)
+    dist.all_reduce(n_local, op=dist.ReduceOp.SUM, group=group)  # (row count: the weighted block carries sum(w) instead of n)
+    n_total = int(n_local.item())
+    mh = m.detach().cpu().numpy()
+    q = mh.shape[0]
+    if y_var is None:
+        if weights_local is not None:
+            raise ValueError("y_var (the unweighted ddof = 1 variance of the whole target) must be given for the weighted report")
+        sy, syy = float(mh[q - 2, q - 1]), float(mh[q - 1, q - 1])
+        y_var = (syy - sy * sy / n_total) / (n_total - 1.0)
+    beta, inv = fit_fn(mh, add_bias=add_bias)
+    part = partials_fn(xs_local, y_local, weights_local, beta, inv, add_bias=add_bias, std_err=std_err)
+    pt = torch.as_tensor(np.asarray(part, dtype=np.float64)).to(m.device)
+    dist.all_reduce(pt, op=dist.ReduceOp.SUM, group=group)  # exchange step 2
+    return finish_fn(beta, inv, pt.cpu().numpy(), n_rows_total=n_total, y_var=y_var, add_bias=add_bias,
+                     weighted=weights_local is not None, std_err=std_err)
 
 
 def _hip_rolling(xs, y, **kw):

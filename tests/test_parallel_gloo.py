@@ -65,6 +65,70 @@ def _worker(rank, world, port, q):
 
         g_lo, g_hi, co, nu = par.lin_reg_by_group_sharded([X[:, j] for j in range(p)], y, off, grouped_fn=grouped_fn,
                                                           gather_to=0, add_bias=False)
+        # ---- the frame lives on rank 0 only: scatter leg (grouped point-to-point), then compute + gather in 3 pieces per rank,
+        #      gathered on rank 1 this time (the root of the scatter and the root of the gather need not coincide)
+        n_used = int(off[-1])
+        if rank == 0:
+            xs_t = [torch.from_numpy(np.ascontiguousarray(X[:n_used, j])) for j in range(p)]
+            sc = par.scatter_frame_by_groups(xs_t, torch.from_numpy(y[:n_used].copy()), off, root=0)
+        else:
+            sc = par.scatter_frame_by_groups(None, None, None, root=0, device=torch.device("cpu"))
+        xs_l, y_l, off_l, parts = sc
+
+        def grouped_fn_t(xs, yy, loc_off, add_bias=False, **kw):
+            return grouped_fn([np.asarray(x) for x in xs], np.asarray(yy), np.asarray(loc_off), add_bias=add_bias)
+
+        res = par.lin_reg_by_group_local_shard(xs_l, y_l, off_l, parts, rank=rank, gather_to=1, chunks=3, grouped_fn=grouped_fn_t,
+                                               add_bias=True)
+        sc_rows_ok = bool(int(off_l[-1]) == len(y_l) and int(off_l[0]) == 0 and
+                          np.array_equal(np.asarray(y_l), y[int(off[parts[rank][0]]): int(off[parts[rank][1]])]))
+        # ---- lin_reg_report, row-sharded: two all-reduces (moment block; [sum e^2 | sum w e^2 | meat])
+        def rep_moments_fn(xs, yy, w):
+            Z = np.c_[np.stack(xs, axis=1), np.ones(len(yy)), yy]
+            return torch.from_numpy(np.ascontiguousarray(Z.T @ (Z if w is None else Z * np.asarray(w)[:, None])))
+
+        def rep_fit_fn(M, add_bias=False):
+            pp_ = p + int(add_bias)
+            G = np.ascontiguousarray(M[:pp_, :pp_])
+            inv = orc.qr_inverse(G)
+            return inv @ M[:pp_, p + 1], inv
+
+        def rep_partials_fn(xs, yy, w, beta, inv, add_bias=False, std_err="se"):
+            Xl = np.stack(xs, axis=1)
+            if add_bias:
+                Xl = np.c_[Xl, np.ones(len(yy))]
+            e = yy - Xl @ beta
+            h = np.einsum("ij,jk,ik->i", Xl, inv, Xl)
+            s2 = {"se": np.zeros_like(e), "hc0": e * e, "hc1": e * e, "hc2": e * e / (1 - h), "hc3": e * e / (1 - h) ** 2}[std_err]
+            q_ = p + 2
+            meat = np.zeros((q_, q_))
+            idx = list(range(p)) + ([p] if add_bias else [])
+            meat[np.ix_(idx, idx)] = Xl.T @ (Xl * s2[:, None])
+            ww = np.ones_like(e) if w is None else np.asarray(w)
+            return np.r_[e @ e, (ww * e) @ e, meat.reshape(-1, order="F")]
+
+        def rep_finish_fn(beta, inv, part, n_rows_total, y_var, add_bias=False, weighted=False, std_err="se"):
+            pp_ = len(beta)
+            q_ = p + 2
+            dof = n_rows_total - pp_
+            if std_err == "se":
+                se = np.sqrt(part[0] / dof * np.diag(inv))
+            else:
+                meat = part[2:].reshape(q_, q_, order="F")
+                idx = list(range(p)) + ([p] if add_bias else [])
+                V = inv @ meat[np.ix_(idx, idx)] @ inv
+                se = np.sqrt(np.diag(V) * (n_rows_total / dof if std_err == "hc1" else 1.0))
+            return {"beta": beta, "se": se, "r2": 1 - part[0] / (y_var * n_rows_total)}
+
+        rep_err = {}
+        Xb_full = np.c_[X, np.ones(n)]
+        for se_kind in ("se", "hc1", "hc3"):
+            rep = par.lin_reg_report_row_sharded([X[lo:hi, j] for j in range(p)], y[lo:hi], add_bias=True, std_err=se_kind,
+                                                 moments_fn=rep_moments_fn, fit_fn=rep_fit_fn, partials_fn=rep_partials_fn,
+                                                 finish_fn=rep_finish_fn)
+            ro = orc.lin_reg_report(Xb_full, y, std_err=se_kind)
+            rep_err[se_kind] = (float(np.max(np.abs(rep["se"] - ro["std_err"]) / ro["std_err"])),
+                                float(np.linalg.norm(rep["beta"] - ro["beta"]) / np.linalg.norm(ro["beta"])), abs(rep["r2"] - ro["r2"]))
         # ---- rolling, row-sharded with a (window - 1)-row halo; compute step = the sequential oracle
         win = 37
 
@@ -120,7 +184,13 @@ def _worker(rank, world, port, q):
         err_rec = float(np.max(np.abs(eco[first - e_lo :] - ref_rec[first - (n0 - 1) : e_hi - (n0 - 1)])))
         rec_valid_ok = bool(np.all(eva[first - e_lo :] == 1) and np.all(eva[: first - e_lo] == 0))
         out = {"rank": rank, "err_rows": err_rows, "range": (g_lo, g_hi), "err_roll": err_roll, "roll_valid_ok": roll_valid_ok,
-               "err_rec": err_rec, "rec_valid_ok": rec_valid_ok}
+               "err_rec": err_rec, "rec_valid_ok": rec_valid_ok, "sc_rows_ok": sc_rows_ok, "rep_err": rep_err,
+               "sc_local_groups": int(res[0].shape[0]), "parts": parts}
+        if rank == 1:
+            ref_co_b, ref_nu_b = orc.grouped_lr([y[:n_used]] + [X[:n_used, j] for j in range(p)], off, add_bias=True)
+            out["sc_gathered"] = tuple(res[2].shape)
+            out["sc_err"] = float(np.max(np.abs(res[2].numpy() - ref_co_b)))
+            out["sc_null_equal"] = bool(np.array_equal(res[3].numpy().astype(bool), ref_nu_b))
         if rank == 0:
             ref_co, ref_nu = orc.grouped_lr([y] + [X[:, j] for j in range(p)], off)
             out["groups"] = ng
@@ -169,3 +239,12 @@ def test_world2_gloo():
     # so it differs from the reference's never re-anchored chain by that chain's own round-off only)
     assert all(o["err_roll"] < 1e-8 and o["roll_valid_ok"] for o in outs)
     assert all(o["err_rec"] < 1e-8 and o["rec_valid_ok"] for o in outs)
+    # scatter from rank 0, three pieces per rank, gathered on rank 1: every rank got exactly its rows, rank 1 holds all groups
+    assert all(o["sc_rows_ok"] for o in outs)
+    parts = outs[0]["parts"]
+    assert [o["sc_local_groups"] for o in outs] == [hi - lo for lo, hi in parts]
+    assert outs[1]["sc_gathered"][0] == outs[0]["groups"] and outs[1]["sc_err"] < 1e-12 and outs[1]["sc_null_equal"]
+    # row-sharded report == the single-frame report (both all-reduces), on every rank
+    for o in outs:
+        for kind, (e_se, e_beta, e_r2) in o["rep_err"].items():
+            assert e_se < 1e-10 and e_beta < 1e-11 and e_r2 < 1e-12, (kind, e_se, e_beta, e_r2)

@@ -62,6 +62,23 @@ def test_sharded_paths_on_rccl(world1):
     assert (g_lo, g_hi) == (0, len(off) - 1)
     assert torch.allclose(co_all.to(ref_co.device), ref_co, rtol=0, atol=0, equal_nan=True)
     assert torch.equal(nu_all.to(ref_nu.device), ref_nu)
+    # the same through the scatter leg + compute / gather in pieces (rank 0 of 1: the grouped send / recv lists are empty, the
+    # partition, piece bounds and result assembly are the real ones)
+    xs_l, y_l, off_l, parts = par.scatter_frame_by_groups(xs, yt[: int(off[-1])], off, root=0)
+    co_l, nu_l, co_g, nu_g = par.lin_reg_by_group_local_shard(xs_l, y_l, off_l, parts, rank=0, gather_to=0, chunks=4, add_bias=False)
+    assert parts == [(0, len(off) - 1)] and torch.allclose(co_g, ref_co, rtol=0, atol=0, equal_nan=True) and torch.equal(nu_g, ref_nu)
+    # row-sharded report: moments -> all-reduce -> fit -> residual pass -> all-reduce -> epilogue == the single-frame report
+    for kind in ("se", "hc0", "hc1", "hc2", "hc3"):
+        rs = par.lin_reg_report_row_sharded(xs, yt, add_bias=True, std_err=kind)
+        r0 = pds.lin_reg_report(*xs, target=yt, add_bias=True, std_err=kind)
+        for k in r0:
+            if k != "features":
+                assert np.allclose(rs[k], r0[k], rtol=1e-13, atol=0), (kind, k)
+    w = torch.from_numpy(rng.random(n) + 0.5).cuda()
+    yv = float(np.var(y, ddof=1))
+    rs = par.lin_reg_report_row_sharded(xs, yt, add_bias=True, weights_local=w, y_var=yv)
+    r0 = pds.lin_reg_report(*xs, target=yt, add_bias=True, weights=w, y_var=yv)
+    assert all(np.allclose(rs[k], r0[k], rtol=1e-13, atol=0) for k in r0 if k != "features")
     # rolling with halo / expanding with an all-gathered prefix
     lo, hi, rc, rp, rv = par.rolling_lin_reg_row_sharded(xs, yt, 64, add_bias=True)
     c0, p0, v0 = pds.rolling_lin_reg(*xs, target=yt, window_size=64, add_bias=True)
