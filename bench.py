@@ -9,14 +9,23 @@ feats").  `value` = regressions/s over the whole job (all ranks), wall clock bra
 synchronize, max over ranks.  The same frame is then fed as ONE regression (config 2, single OLS) to
 measure the Gram build GB/s, reported under "gram_build".
 
-  roofline      dominant kernel of the step (the per-group Gram build): algorithmic bytes per launch /
-                average launch duration measured with HIP events on the launch stream (library hooks
+  roofline      dominant kernel of the step (the fused per-group Gram + solve kernel): algorithmic bytes per
+                launch / average launch duration measured with HIP events on the launch stream (library hooks
                 pds_ctx_set_timing / pds_ctx_get_timing), against the 8 TB/s HBM3E peak.
   cpu_baseline  the CPU restatement of the reference (oracle/, kind "port": the Rust crate cannot be
-                built here) timed on the host cores of this box on a bounded sample of the same frame.
+                built here) timed on the host cores of this box on a bounded sample of the same frame
+                (p = 16, and p = 8 beside `grouped_p8`).
+  end_to_end    the SAME workload when the frame starts in HOST memory as Arrow buffers and goes through the plugin
+                boundary (`_polars_plugin_pl_lr_by`, `_polars_plugin_pl_lr`): wall clock, bytes over PCIe, fraction of the
+                measured pinned-copy PCIe rate.  This is the rate a Polars user sees; `value` is the HBM-resident rate.
+  grouped_c3spec  SURVEY.md 8(d)'s C3 data (Poisson(100) sizes in [16, 256], 0.1 % collinear groups -> the rank gate fires,
+                8 features), keys sorted and shuffled.
 
-Multi-GPU (--gpus N, launched by torch.distributed.run): groups shard by key across ranks, no data-path
-collective (weak scaling: every rank owns 1e6 groups); see DESIGN.md "multi-GPU".
+Multi-GPU (--gpus N, launched by torch.distributed.run): STRONG scaling by default -- the 1e6 groups of the fixed 1e8-row
+frame are sharded by group key, every rank holds its shard in HBM, and the GATHER of the coefficients and null flags to rank
+0 (RCCL point-to-point, piece by piece behind the compute) is inside the timed region.  `--scaling weak` keeps 1e6 groups
+per rank (no collective).  `scatter` reports, outside the timed region, what it costs to distribute a frame that is
+resident on rank 0 only.  See DESIGN.md "multi-GPU".
 """
 from __future__ import annotations
 
@@ -33,6 +42,22 @@ sys.path.insert(0, str(ROOT))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+PROFILE_TAG = "r02"     # profiles/<tag>_traffic.json: HBM bytes per launch from the rocprofv3 PMC passes
+
+
+def _gen_frame(torch, dev, seed, G, R, P):
+    """x ~ N(0,1), per-group beta ~ N(0,1), noise 0.1; fixed R rows per group (the headline frame)."""
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    N = G * R
+    xs = [torch.randn(N, dtype=torch.float64, device=dev, generator=gen) for _ in range(P)]
+    y = torch.zeros(N, dtype=torch.float64, device=dev)
+    for j in range(P):
+        bj = torch.randn(G, dtype=torch.float64, device=dev, generator=gen)
+        y.add_(xs[j] * bj.repeat_interleave(R))
+        del bj
+    y.add_(torch.randn(N, dtype=torch.float64, device=dev, generator=gen), alpha=0.1)
+    return xs, y
 
 
 def main() -> int:
@@ -40,11 +65,14 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--groups", type=int, default=1_000_000, help="groups per rank")
+    ap.add_argument("--groups", type=int, default=1_000_000, help="groups of the frame (strong) / per rank (weak)")
     ap.add_argument("--rows-per-group", type=int, default=100)
     ap.add_argument("--feats", type=int, default=16)
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--gather-chunks", type=int, default=2, help="pieces per rank: results of a piece travel while the next is computed")
     ap.add_argument("--cpu-sample-groups", type=int, default=200_000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip end_to_end / grouped_c3spec / scatter (A/B runs)")
     args = ap.parse_args()
 
     import numpy as np
@@ -57,7 +85,7 @@ def main() -> int:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # PDS_BENCH_FORCE_DIST=1 runs the RCCL init / barrier / all-reduce code path at world_size 1 (single-GPU smoke of the N > 1 path)
+    # PDS_BENCH_FORCE_DIST=1 runs the RCCL init / barrier / gather code path at world_size 1 (single-GPU smoke of the N > 1 path)
     use_dist = world > 1 or os.environ.get("PDS_BENCH_FORCE_DIST") == "1"
     if use_dist:
         import torch.distributed as dist
@@ -67,26 +95,46 @@ def main() -> int:
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     import polars_ds_extension_amd as pds
+    from polars_ds_extension_amd import parallel as par
 
-    G, R, P = args.groups, args.rows_per_group, args.feats
+    R, P = args.rows_per_group, args.feats
+    strong = args.scaling == "strong"
+    G_total = args.groups if strong else args.groups * world
+    # group-key range partition (fixed group size: balanced in rows == balanced in groups)
+    parts = [par.shard_bounds(G_total, world, r) for r in range(world)]
+    g_lo, g_hi = parts[rank]
+    G = g_hi - g_lo
     N = G * R
     ctx = pds.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream(dev))
 
-    # ---- synthetic frame, generated in HBM (seeded per rank): x ~ N(0,1), per-group beta, noise 0.1
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + rank)
-    xs = [torch.randn(N, dtype=torch.float64, device=dev, generator=gen) for _ in range(P)]
-    y = torch.zeros(N, dtype=torch.float64, device=dev)
-    for j in range(P):
-        bj = torch.randn(G, dtype=torch.float64, device=dev, generator=gen)
-        y.add_(xs[j] * bj.repeat_interleave(R))
-        del bj
-    y.add_(torch.randn(N, dtype=torch.float64, device=dev, generator=gen), alpha=0.1)
+    # ---- this rank's shard of the synthetic frame, generated in HBM (seeded per rank)
+    xs, y = _gen_frame(torch, dev, 1234 + rank, G, R, P)
     offsets = torch.arange(0, N + 1, R, dtype=torch.int64, device=dev)
+    off_host = np.arange(0, N + 1, R, dtype=np.int64)
     torch.cuda.synchronize(dev)
+    gather = use_dist and strong
+    chunks = max(1, args.gather_chunks) if gather and world > 1 else 1
+
+    def grouped_fn(xs_c, y_c, off_c, **kw):
+        return pds.lin_reg_by(*xs_c, target=y_c, group_offsets=off_c, add_bias=False, ctx=ctx)
+
+    class _Off:  # device offsets for the kernels, host offsets for the piece bounds (no device read-back inside the step)
+        def __init__(self, d, h):
+            self.d, self.h = d, h
+
+        def cpu(self):
+            return self.h
+
+        def __getitem__(self, s):
+            return self.d[s]
+
+    off_pair = _Off(offsets, torch.from_numpy(off_host))
 
     def step():
+        if gather:
+            res = par.lin_reg_by_group_local_shard(xs, y, off_pair, parts, rank=rank, gather_to=0, chunks=chunks, grouped_fn=grouped_fn)
+            return (res[2], res[3]) if rank == 0 else (res[0], res[1])
         return pds.lin_reg_by(*xs, target=y, group_offsets=offsets, add_bias=False, ctx=ctx)
 
     def barrier():
@@ -111,9 +159,9 @@ def main() -> int:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
-    value = world * G / (elapsed / args.steps)
+    value = G_total / (elapsed / args.steps)
 
-    # ---- roofline of the dominant kernel (grouped Gram build), rank 0's launches
+    # ---- roofline of the dominant kernel (fused grouped Gram + solve), rank 0's launches
     q = P + 2
     gm_ms, gm_cnt = timing["grouped_moments"]
     sv_ms, sv_cnt = timing["solve"]
@@ -126,16 +174,18 @@ def main() -> int:
     alg_bytes = groups_per_launch * bytes_per_group
     avg_ms = gm_ms / max(gm_cnt, 1)
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    # HBM bytes per launch measured offline with rocprofv3 PMC passes (profiles/r01_traffic.json, committed)
+    # HBM bytes per launch measured offline with rocprofv3 PMC passes (profiles/<tag>_traffic.json, committed)
     traffic = None
-    try:
-        tj = json.loads((ROOT / "profiles" / "r01_traffic.json").read_text())["kernels"]
-        want = "pds::grouped_stream_kernel<double, 16," if fused else "pds::grouped_moments_kernel<double>"
-        hit = [v for k, v in tj.items() if k.startswith(want)]
-        if hit and G == 1_000_000 and R == 100 and P == 16:
-            traffic = int(hit[0]["hbm_bytes_per_launch"])
-    except Exception:
-        traffic = None
+    for tag in (PROFILE_TAG, "r01"):
+        try:
+            tj = json.loads((ROOT / "profiles" / f"{tag}_traffic.json").read_text())["kernels"]
+            want = "pds::grouped_stream_kernel<double, 16," if fused else "pds::grouped_moments_kernel<double>"
+            hit = [v for k, v in tj.items() if k.startswith(want)]
+            if hit and G == 1_000_000 and R == 100 and P == 16 and launches_per_step == 1:
+                traffic = int(hit[0]["hbm_bytes_per_launch"])
+                break
+        except Exception:
+            continue
     roofline = {
         "bound": "hbm", "kernel": "grouped_stream_kernel<double,16,cholesky> (Gram + solve fused)" if fused else "grouped_moments_kernel<double>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
@@ -170,19 +220,25 @@ def main() -> int:
             pds.lin_reg_by(*xs[:8], target=y, group_offsets=offsets, add_bias=False, ctx=ctx)
         torch.cuda.synchronize(dev)
         reps = 5
+        ctx.get_timing(reset=True)
+        ctx.set_timing(True)
         t8 = time.perf_counter()
         for _ in range(reps):
             pds.lin_reg_by(*xs[:8], target=y, group_offsets=offsets, add_bias=False, ctx=ctx)
         torch.cuda.synchronize(dev)
         t8 = (time.perf_counter() - t8) / reps
+        ctx.set_timing(False)
+        k8_ms, k8_cnt = ctx.get_timing(reset=True)["grouped_moments"]
         b8 = G * (R * 9 * 8 + 16 + 8 * 8 + 1)
+        k8 = k8_ms / max(k8_cnt, 1)
         p8 = {"workload": f"{G} groups x {R} rows x 8 f64 feats", "regressions_per_s": round(G / t8, 1),
-              "ms_per_step": round(t8 * 1e3, 4), "algorithmic_GBps": round(b8 / t8 / 1e9, 1),
-              "frac_of_hbm_peak": round(b8 / t8 / 1e9 / HBM_PEAK_GBPS, 4)}
+              "ms_per_step": round(t8 * 1e3, 4), "kernel_ms": round(k8, 4), "algorithmic_GBps": round(b8 / (k8 * 1e-3) / 1e9, 1),
+              "frac_of_hbm_peak": round(b8 / (k8 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
 
     # ---- CPU baseline + parity spot check on a bounded sample (rank 0, N = 1 only)
     cpu = None
     parity = None
+    host_cols = None
     if rank == 0 and world == 1 and not args.no_cpu:
         from oracle import oracle as orc
 
@@ -200,6 +256,13 @@ def main() -> int:
                "sample": f"{gs} groups x {R} rows x {P} f64 feats (first {ns} rows of the same frame), OpenMP over groups, "
                          f"{t_cpu:.2f} s; per-group copy + X'X + gated col-piv QR as Polars drives pl_lr",
                "nproc": os.cpu_count()}
+        # the same sample on the first 8 feature columns: the CPU figure beside `grouped_p8`
+        if P >= 8:
+            t1 = time.perf_counter()
+            orc.grouped_lr(host_cols[:9], off_h, add_bias=False, tol=1e-12, nthreads=nthreads)
+            t_cpu8 = time.perf_counter() - t1
+            cpu["p8_value"] = round(gs / t_cpu8, 1)
+            cpu["p8_sample"] = f"{gs} groups x {R} rows x 8 f64 feats, {nthreads} threads, {t_cpu8:.2f} s"
         # the Gram build of the single regression on the same sample, all host cores
         t2 = time.perf_counter()
         orc.gram_cols(host_cols, nthreads=nthreads)
@@ -212,22 +275,168 @@ def main() -> int:
         parity = {"groups_checked": int(gs), "max_normwise_rel_err": float(np.max(num / den)),
                   "null_mismatches": int(np.sum(nulls[:gs].cpu().numpy().astype(bool) != nu_cpu))}
 
+    # ---- the same workload from HOST Arrow buffers through the plugin boundary (rank 0, N = 1): the rate a Polars user sees
+    end_to_end = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        try:
+            end_to_end = _end_to_end(torch, np, pds, dev, xs, y, G, R, P, cpu)
+        except Exception as e:  # pyarrow / harness trouble must not cost the headline line
+            end_to_end = {"error": f"{type(e).__name__}: {e}"}
+
+    # ---- SURVEY.md 8(d) C3 data: Poisson sizes, collinear groups (the gate fires inside the timed run), sorted and shuffled keys
+    c3 = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        try:
+            del xs, y
+            torch.cuda.empty_cache()
+            c3 = _c3_spec(torch, pds, ctx, dev)
+        except Exception as e:
+            c3 = {"error": f"{type(e).__name__}: {e}"}
+
+    # ---- scatter leg (outside the timed region): what distributing a rank-0-resident frame of this size costs
+    scatter = None
+    if use_dist and strong and not args.no_extras:
+        try:
+            scatter = _scatter_leg(torch, dist, par, dev, rank, world, G_total, R, P)
+        except Exception as e:
+            scatter = {"error": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
+        per = "of the frame" if strong else "per GPU"
         line = {
             "metric": "grouped lstsq regressions/sec (1e8 rows x 16 f64 feats; Gram-build GB/s under gram_build)",
             "value": round(value, 1), "unit": "regressions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"group_by(key).agg(lin_reg): {G} groups x {R} rows x {P} f64 feats per GPU "
-                                   f"({N:.0e} rows), OLS with rank gate (pl_lr default path), inputs resident in HBM",
-                       "groups_per_gpu": G, "rows_per_group": R, "features": P, "parallelism": f"group-sharded x{world}"},
+            "config": {"workload": f"group_by(key).agg(lin_reg): {args.groups} groups x {R} rows x {P} f64 feats {per} "
+                                   f"({args.groups * R:.0e} rows), OLS with rank gate (pl_lr default path), inputs resident in HBM"
+                                   + (", coefficients + null flags gathered to rank 0 inside the timed region" if gather else ""),
+                       "groups_total": G_total, "groups_per_gpu": G, "rows_per_group": R, "features": P,
+                       "parallelism": f"group-sharded x{world}", "gather_chunks": chunks if gather else None},
             "roofline": roofline, "gram_build": gram, "grouped_p8": p8, "cpu_baseline": cpu, "parity_spot_check": parity,
+            "end_to_end": end_to_end, "grouped_c3spec": c3, "scatter": scatter,
         }
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     return 0
+
+
+def _end_to_end(torch, np, pds, dev, xs, y, G, R, P, cpu):
+    """Host Arrow buffers -> `_polars_plugin_pl_lr_by` / `_polars_plugin_pl_lr` -> Arrow result; wall clock."""
+    import ctypes as C
+
+    import pyarrow as pa
+
+    sys.path.insert(0, str(ROOT / "tests"))
+    import plugin_harness as ph  # pyarrow + ctypes in the role of the Polars engine (test infrastructure)
+    from polars_ds_extension_amd import _lib
+
+    lib = _lib.load()
+    N = G * R
+    # measured PCIe rate of this box: pinned host -> HBM, 1 GiB
+    pin = torch.empty(1 << 27, dtype=torch.float64).pin_memory()
+    dst = torch.empty(1 << 27, dtype=torch.float64, device=dev)
+    dst.copy_(pin, non_blocking=True)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        dst.copy_(pin, non_blocking=True)
+    torch.cuda.synchronize(dev)
+    pcie = 3 * (1 << 30) / (time.perf_counter() - t0) / 1e9
+    del pin, dst
+    host = [("y", pa.array(y.cpu().numpy()))] + [(f"x{j + 1}", pa.array(xs[j].cpu().numpy())) for j in range(P)]
+    key = ("key", pa.array(np.repeat(np.arange(G, dtype=np.int64), R)))
+    kw = {"bias": False, "null_policy": "raise", "l1_reg": 0.0, "l2_reg": 0.0, "solver": "qr", "tol": 1e-5, "max_iter": 200,
+          "weighted": False, "positive": False, "singular_x_tol": 1e-12}
+    out = {"pcie_pinned_h2d_GBps": round(pcie, 1)}
+
+    def timed(sym, ins, reps=3):
+        ph.call_plugin(lib, sym, ins, kw)
+        ts = []
+        for _ in range(reps):
+            t1 = time.perf_counter()
+            _, res = ph.call_plugin(lib, sym, ins, kw)
+            ts.append(time.perf_counter() - t1)
+        return float(np.median(ts)), res
+
+    t_by, res = timed("pl_lr_by", [key] + host)
+    assert len(res) == G
+    gb_by = (N * (P + 2) * 8 + G * (P * 8 + 8 + 1)) / 1e9  # keys + y + features up, keys + coefficients + validity down
+    out["pl_lr_by"] = {"workload": f"host Arrow frame, {G} groups x {R} rows x {P} f64 feats + int64 keys", "wall_ms": round(t_by * 1e3, 1),
+                       "regressions_per_s": round(G / t_by, 1), "pcie_GB": round(gb_by, 2), "GBps": round(gb_by / t_by, 1),
+                       "frac_of_pcie_rate": round(gb_by / t_by / pcie, 3)}
+    t_lr, _ = timed("pl_lr", host)
+    gb_lr = N * (P + 1) * 8 / 1e9
+    out["pl_lr"] = {"workload": f"host Arrow frame, single OLS {N:.0e} rows x {P} f64 feats", "wall_ms": round(t_lr * 1e3, 1),
+                    "pcie_GB": round(gb_lr, 2), "GBps": round(gb_lr / t_lr, 1), "frac_of_pcie_rate": round(gb_lr / t_lr / pcie, 3)}
+    if cpu:
+        out["gpu_over_cpu_host_resident"] = round(G / t_by / cpu["value"], 1)
+        out["note"] = ("host-resident frames are PCIe bound: this ratio, not the HBM-resident one, is what an unchanged Polars "
+                       "query sees on one GPU")
+    return out
+
+
+def _c3_spec(torch, pds, ctx, dev):
+    sys.path.insert(0, str(ROOT / "tools"))
+    import synth
+
+    G, p = 1_000_000, 8
+    fr = synth.c3_frame(G, p, seed=2, device=dev)
+    xs, y, off = fr["xs"], fr["y"], fr["offsets"]
+
+    def bench(fn, reps=5):
+        fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            r = fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / reps, r
+
+    t_sorted, (co, nu) = bench(lambda: pds.lin_reg_by(*xs, target=y, group_offsets=off, ctx=ctx))
+    nulls = int(nu.sum().item())
+    t_keyed, _ = bench(lambda: pds.lin_reg_by_key(*xs, target=y, key=fr["keys"], ctx=ctx, max_groups=G))
+    perm = torch.randperm(fr["n_rows"], device=dev, generator=torch.Generator(device=dev).manual_seed(22))
+    ks = fr["keys"][perm]
+    xs_s = [x[perm] for x in xs]
+    y_s = y[perm]
+    del perm
+    t_shuf, (k2, co2, nu2) = bench(lambda: pds.lin_reg_by_key(*xs_s, target=y_s, key=ks, ctx=ctx, max_groups=G), reps=3)
+    alg = fr["n_rows"] * (p + 1) * 8 + G * (p * 8 + 17)
+    return {"workload": f"{G} groups, Poisson(100) rows in [16, 256] ({fr['n_rows']} rows), {p} f64 feats, 0.1 % collinear groups",
+            "gated_groups": nulls, "collinear_groups": int(fr["collinear"].sum().item()),
+            "sorted_offsets_ms": round(t_sorted * 1e3, 3), "sorted_keys_ms": round(t_keyed * 1e3, 3), "shuffled_keys_ms": round(t_shuf * 1e3, 3),
+            "regressions_per_s_sorted": round(G / t_sorted, 1), "regressions_per_s_shuffled": round(G / t_shuf, 1),
+            "sorted_frac_of_hbm_peak": round(alg / t_sorted / 1e9 / HBM_PEAK_GBPS, 4),
+            "shuffled_equals_sorted_nulls": bool((nu2 == nu).all().item())}
+
+
+def _scatter_leg(torch, dist, par, dev, rank, world, G_total, R, P):
+    """Rank 0 holds the whole frame; time scatter_frame_by_groups (grouped point-to-point, one launch)."""
+    if rank == 0:
+        xs_f, y_f = _gen_frame(torch, dev, 99, G_total, R, P)
+        off_f = torch.arange(0, G_total * R + 1, R, dtype=torch.int64).numpy()
+        args = (xs_f, y_f, off_f)
+    else:
+        args = (None, None, None)
+    ts = []
+    for _ in range(2):
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        t0 = time.perf_counter()
+        got = par.scatter_frame_by_groups(*args, root=0, device=dev)
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        ts.append(time.perf_counter() - t0)
+        del got
+    t = torch.tensor([ts[-1]], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    sent = G_total * R * (P + 1) * 8 * (world - 1) / max(world, 1)
+    return {"ms": round(float(t.item()) * 1e3, 2), "GB_sent_by_root": round(sent / 1e9, 2),
+            "GBps_per_link": round(sent / max(world - 1, 1) / float(t.item()) / 1e9, 1) if world > 1 else None,
+            "note": "frame resident on rank 0 only -> every rank holds its group range; not part of `value`"}
 
 
 if __name__ == "__main__":

@@ -1392,6 +1392,8 @@ void pds_ctx_destroy(pds_ctx* ctx) {
     if (ctx->stage.ptr) (void)hipFree(ctx->stage.ptr);
     if (ctx->solve_ws.ptr) (void)hipFree(ctx->solve_ws.ptr);
     if (ctx->keyed.ptr) (void)hipFree(ctx->keyed.ptr);
+    if (ctx->mark_count) (void)hipFree(ctx->mark_count);
+    if (ctx->mark_host) (void)hipHostFree(ctx->mark_host);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pinned_in) (void)hipHostFree(ctx->pinned_in);
     for (auto& e : ctx->ev_pending) {

@@ -86,6 +86,11 @@ struct pds_ctx {
     pds::Workspace stage;    // HBM staging of PDS_HOST column buffers
     pds::Workspace solve_ws; // factor workspace of the p' > 64 solver (solve_big.hip)
     pds::Workspace keyed;    // pds_lr_by_key_*: staged / sorted keys, permutation, gathered columns, run-length results
+    // fused grouped kernel -> pivoted-QR pass hand-over: device counter of marked groups, and a host-mapped word the kernel
+    // raises when it marks its first group (the only thing the host reads in the common case)
+    unsigned* mark_count = nullptr;
+    unsigned* mark_host = nullptr;      // host address
+    unsigned* mark_host_dev = nullptr;  // the same word as the device sees it
     void* pinned = nullptr;  // pinned host scratch (small results, pointer arrays)
     size_t pinned_bytes = 0;
     void* pinned_in = nullptr;  // pinned staging of small PDS_HOST frames: all columns + pointer table, ONE H2D copy

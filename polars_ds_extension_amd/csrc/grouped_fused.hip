@@ -223,7 +223,8 @@ template <typename T, int LPS, bool CHOL, bool BIAS, int PC>
 __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __restrict__ cols, int p_arg,
                                                             const int64_t* __restrict__ offsets, int64_t n_groups,
                                                             int64_t n_rows, SolveRegDev sp, T* __restrict__ coeffs,
-                                                            uint8_t* __restrict__ flags) {
+                                                            uint8_t* __restrict__ flags, int32_t* __restrict__ mark_list,
+                                                            unsigned* __restrict__ mark_count, unsigned* __restrict__ mark_host_flag) {
     constexpr int SPW = 64 / LPS;
     constexpr int RPL = Tile<T>::RPL;
     constexpr int TR = 64 * RPL;
@@ -308,6 +309,23 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
             if (live && j == 0) coeffs[sys * (int64_t)pout + p] = is_null ? (T)__builtin_nan("") : (T)b0;
         }
         if (live && j == 0 && flags) flags[sys] = suspect ? 2 : (is_null ? 1 : 0);
+        if constexpr (CHOL) {
+            // systems left to the pivoted-QR pass are appended to a list (one atomic per wave and batch of solves -- and none
+            // at all in the common case of no marked system); the first marking wave also raises a word in host-mapped
+            // memory, which is all the host looks at after the kernel: no counter read-back, no extra launch unless needed
+            const bool mk = suspect && live && j == 0;
+            const unsigned long long mm = __ballot(mk);
+            if (mm != 0ull && mark_list) {
+                const int leader = __ffsll((long long)mm) - 1;
+                unsigned slot = 0;
+                if (lane == leader) {
+                    slot = atomicAdd(mark_count, (unsigned)__popcll(mm));
+                    __hip_atomic_store(mark_host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                slot = __shfl(slot, leader);
+                if (mk) mark_list[slot + __popcll(mm & ((1ull << lane) - 1ull))] = (int32_t)sys;
+            }
+        }
         PDS_T1(3);
         gbase += npend;
         npend = 0;
@@ -532,7 +550,7 @@ __global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __re
 template <typename T, int LPS>
 static int launch_stream_lps(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, const int64_t* d_offsets,
                              int64_t n_groups, int64_t n_rows, const SolveRegDev& sd, bool chol, T* d_coeffs,
-                             uint8_t* d_flags) {
+                             uint8_t* d_flags, int32_t* d_mark_list, unsigned* d_mark_count, unsigned* d_mark_host) {
     const size_t lds = (size_t)kFWaveLds;
     const int per_cu = std::max(1, (int)((160 * 1024) / lds));
     int64_t nb = std::min<int64_t>(std::max<int64_t>(n_groups / (64 / LPS), 1), (int64_t)ctx->num_cus * per_cu);
@@ -545,7 +563,8 @@ static int launch_stream_lps(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, 
     // slower than 8, 3 slower than 4)
     auto go = [&](auto bias_c, auto pc_c) {
         hipLaunchKernelGGL((grouped_stream_kernel<T, LPS, true, decltype(bias_c)::value, decltype(pc_c)::value>), dim3((unsigned)nb),
-                           dim3(64), lds, ctx->stream, dc.d_ptrs, n_feat, d_offsets, n_groups, n_rows, sd, d_coeffs, d_flags);
+                           dim3(64), lds, ctx->stream, dc.d_ptrs, n_feat, d_offsets, n_groups, n_rows, sd, d_coeffs, d_flags, d_mark_list,
+                           d_mark_count, d_mark_host);
     };
     auto by_pc = [&](auto bias_c) {
         using std::integral_constant;
@@ -573,19 +592,16 @@ static int launch_stream_lps(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, 
 }
 
 // ---- second pass: the groups the streaming kernel marked (flag 2) go through the reference's default factorisation
-__global__ void collect_marked_kernel(const uint8_t* __restrict__ flags, int64_t n_groups, int32_t* __restrict__ list,
-                                      unsigned* __restrict__ count) {
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool hit = g < n_groups && flags[g] == 2;
-    // one atomic per wave: the marked groups of a wave take consecutive slots
-    const unsigned long long m = __ballot(hit);
-    if (m == 0ull) return;
-    const int lane = threadIdx.x & 63;
-    unsigned base = 0;
-    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(count, (unsigned)__popcll(m));
-    base = __shfl(base, __ffsll((long long)m) - 1);
-    if (hit) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)g;
+static int ensure_mark_state(pds_ctx* ctx) {
+    if (ctx->mark_count) return PDS_OK;
+    PDS_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ctx->mark_count), 256));
+    PDS_HIP_CHECK(hipMemset(ctx->mark_count, 0, 256));
+    PDS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ctx->mark_host), 64, hipHostMallocMapped | hipHostMallocCoherent));
+    *ctx->mark_host = 0u;
+    PDS_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->mark_host_dev), ctx->mark_host, 0));
+    return PDS_OK;
 }
+
 template <typename T>
 __global__ void scatter_marked_kernel(const T* __restrict__ co_c, const uint8_t* __restrict__ fl_c, const int32_t* __restrict__ list,
                                       int64_t n, int pp, T* __restrict__ coeffs, uint8_t* __restrict__ flags) {
@@ -621,24 +637,32 @@ int launch_grouped_fused(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int6
     const bool second_pass = chol && sp.solver != PDS_SOLVER_CHOLESKEY && d_flags && d_mom_scratch && scratch_groups > 0;
     sd.sus_tol = second_pass ? std::sqrt(sd.inv_tol) : 0.0;
     // (the intercept takes no solver lane: the kernel size follows the feature count)
+    int32_t* d_list = nullptr;
+    unsigned* d_count = nullptr;
+    unsigned* d_host = nullptr;
+    if (second_pass) {
+        if (int rc0 = ensure_mark_state(ctx)) return rc0;
+        d_list = reinterpret_cast<int32_t*>(ws_take(ctx, (size_t)n_groups * sizeof(int32_t)));
+        if (!d_list) return fail(PDS_ERR_HIP, "workspace allocation failed");
+        d_count = ctx->mark_count;
+        d_host = ctx->mark_host_dev;
+        *ctx->mark_host = 0u;  // (host-mapped word; the previous call synchronised before it returned)
+    }
     int rc;
-    if (sd.p <= 4) rc = launch_stream_lps<T, 4>(ctx, dc, n_feat, d_offsets, n_groups, n_rows, sd, chol, d_coeffs, d_flags);
-    else if (sd.p <= 8) rc = launch_stream_lps<T, 8>(ctx, dc, n_feat, d_offsets, n_groups, n_rows, sd, chol, d_coeffs, d_flags);
-    else rc = launch_stream_lps<T, 16>(ctx, dc, n_feat, d_offsets, n_groups, n_rows, sd, chol, d_coeffs, d_flags);
+    if (sd.p <= 4) rc = launch_stream_lps<T, 4>(ctx, dc, n_feat, d_offsets, n_groups, n_rows, sd, chol, d_coeffs, d_flags, d_list, d_count, d_host);
+    else if (sd.p <= 8) rc = launch_stream_lps<T, 8>(ctx, dc, n_feat, d_offsets, n_groups, n_rows, sd, chol, d_coeffs, d_flags, d_list, d_count, d_host);
+    else rc = launch_stream_lps<T, 16>(ctx, dc, n_feat, d_offsets, n_groups, n_rows, sd, chol, d_coeffs, d_flags, d_list, d_count, d_host);
     if (rc || !second_pass) return rc;
-    // ---- marked groups: Gram records (indexed grouped build) -> pivoted Householder QR with the log-det gate -> scatter
-    int32_t* d_list = reinterpret_cast<int32_t*>(ws_take(ctx, (size_t)n_groups * sizeof(int32_t)));
-    unsigned* d_count = reinterpret_cast<unsigned*>(ws_take(ctx, 256));
-    if (!d_list || !d_count) return fail(PDS_ERR_HIP, "workspace allocation failed");
-    PDS_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(unsigned), ctx->stream));
-    hipLaunchKernelGGL(collect_marked_kernel, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, ctx->stream, d_flags, n_groups,
-                       d_list, d_count);
-    PDS_HIP_CHECK(hipGetLastError());
-    if (int rc2 = ensure_pinned(ctx, 4096)) return rc2;
-    unsigned* h_count = reinterpret_cast<unsigned*>(static_cast<char*>(ctx->pinned) + 3072);
-    PDS_HIP_CHECK(hipMemcpyAsync(h_count, d_count, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    // ---- marked groups: Gram records (indexed grouped build) -> pivoted Householder QR with the log-det gate -> scatter.
+    // Whether there are any is read from the host-mapped word after the kernel has finished (the entry points synchronise
+    // before they return anyway); the common case -- none -- costs no launch, no copy and no counter read-back.
     PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    const int64_t marked = (int64_t)*h_count;
+    if (__atomic_load_n(ctx->mark_host, __ATOMIC_ACQUIRE) == 0u) return PDS_OK;
+    unsigned h_count = 0;
+    PDS_HIP_CHECK(hipMemcpyAsync(&h_count, d_count, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    PDS_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(unsigned), ctx->stream));  // ready for the next call
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const int64_t marked = (int64_t)h_count;
     if (marked == 0) return PDS_OK;
     const int pp = sd.pp;
     const int64_t chunk = std::min<int64_t>(scratch_groups, marked);

@@ -19,6 +19,8 @@
 // min_size > 0, counted for the skipping variant's validity rule (faer_rolling_skipping_lr :218-301).
 // HBM traffic: every input element read twice (as "new" and as "old", the second read served by
 // L2/Infinity Cache for w = 256), every output element written once.
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace pds {
@@ -65,6 +67,10 @@ struct RollArgs {
     int64_t tile_rows;
 };
 
+}  // namespace pds
+#include "rolling_seg_dev.hpp"  // (needs RollArgs)
+namespace pds {
+
 // fetch_row: raw z (PP entries, padding = 0, bias entry = 1) and y of row r (zeros when r is out of range) -- only
 // issues the loads, so the next step's rows can be in flight while the current step is scanned and solved;
 // finish_row: the finiteness rule (a non-finite row is left out, OnlineLR::update lr_online_solvers.rs:85-89).
@@ -110,7 +116,8 @@ __device__ __forceinline__ void rolling_body(const T* const* __restrict__ cols, 
     }
     constexpr int NG = RollDims<PP>::NG, NV = RollDims<PP>::NV, NSET = RollDims<PP>::NSET, NH = RollDims<PP>::NH;
     static_assert(NH <= 32, "two lanes per moment of a pass");
-    extern __shared__ __attribute__((aligned(16))) double sm[];
+    extern __shared__ __attribute__((aligned(16))) double seg_lds[];
+    double* sm = seg_lds;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double* D = sm + (size_t)wave * NH * kLdsStride;
     const int64_t T_ = ra.tile_rows;
@@ -419,11 +426,27 @@ static int launch_pp_f(pds_ctx* ctx, const DeviceCols<T>& dc, RollArgs ra, bool 
     if (lds > 64 * 1024)
         for (const void* k : {reinterpret_cast<const void*>(kern0), reinterpret_cast<const void*>(kern1), reinterpret_cast<const void*>(kern2)})
             PDS_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // up to 8 coefficients: lane = 4 consecutive rows, running moments in registers (rolling_seg_dev.hpp); PDS_ROLLING_V1=1
+    // keeps the lane = row kernel (development A/B).  The totals pass of the expanding fit stays with the first kernel.
+    static const bool v1 = [] { const char* e = std::getenv("PDS_ROLLING_V1"); return e && e[0] == '1'; }();
+    bool seg = false;
+    if constexpr (PP <= 8) seg = !v1;
+    [[maybe_unused]] auto launch_seg = [&](auto mode_c, const double* tot) {
+        if constexpr (PP <= 8) {
+            constexpr int M = decltype(mode_c)::value;
+            using SD = SegDims<T, PP>;
+            const int64_t sb = std::min<int64_t>(std::max<int64_t>(ntiles, 1), (int64_t)ctx->num_cus * 4);
+            hipLaunchKernelGGL((rolling_seg_kernel<T, PP, M, FULLP>), dim3((unsigned)sb), dim3(64), (size_t)SD::LDS_BYTES, ctx->stream,
+                               dc.d_ptrs, ra, tot, d_coeffs, d_pred, d_valid);
+        }
+    };
     KernelTimer timer(ctx, kKindRolling);
     if (!expanding) {
         ra.mode = 0;
-        hipLaunchKernelGGL(kern0, dim3((unsigned)nb), dim3(kRollWaves * 64), lds, ctx->stream,
-                           dc.d_ptrs, ra, (double*)nullptr, d_coeffs, d_pred, d_valid);
+        if (seg) launch_seg(std::integral_constant<int, 0>{}, (const double*)nullptr);
+        else
+            hipLaunchKernelGGL(kern0, dim3((unsigned)nb), dim3(kRollWaves * 64), lds, ctx->stream,
+                               dc.d_ptrs, ra, (double*)nullptr, d_coeffs, d_pred, d_valid);
     } else {
         double* tot = reinterpret_cast<double*>(ws_take(ctx, (size_t)ntiles * NV * sizeof(double)));
         double* d_seed = nullptr;
@@ -447,8 +470,10 @@ static int launch_pp_f(pds_ctx* ctx, const DeviceCols<T>& dc, RollArgs ra, bool 
                            dc.d_ptrs, ra, tot, d_coeffs, d_pred, d_valid);
         hipLaunchKernelGGL(tile_prefix_kernel, dim3(1), dim3(kPrefixWaves * 64), 0, ctx->stream, tot, ntiles, NV, d_seed);
         ra.mode = 2;
-        hipLaunchKernelGGL(kern2, dim3((unsigned)nb), dim3(kRollWaves * 64), lds, ctx->stream,
-                           dc.d_ptrs, ra, tot, d_coeffs, d_pred, d_valid);
+        if (seg) launch_seg(std::integral_constant<int, 2>{}, (const double*)tot);
+        else
+            hipLaunchKernelGGL(kern2, dim3((unsigned)nb), dim3(kRollWaves * 64), lds, ctx->stream,
+                               dc.d_ptrs, ra, tot, d_coeffs, d_pred, d_valid);
     }
     PDS_HIP_CHECK(hipGetLastError());
     return PDS_OK;

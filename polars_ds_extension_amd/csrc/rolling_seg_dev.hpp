@@ -1,0 +1,416 @@
+// rolling_seg_dev.hpp -- rolling / expanding fits with up to 8 coefficients: lane = K CONSECUTIVE rows.
+//
+// rolling.hip's first kernel makes lane = one row of a 64-row step and sends the NV = p'(p'+1)/2 + p' + 1 running moments
+// on a round trip through LDS every step (increments out, a scan by lane = moment, window sums back): ~270 LDS
+// instructions of ~1000 per 64 rows, at two waves per SIMD -- an LDS- and issue-bound step at 0.33 of the HBM roofline.
+// Here a lane owns K = 4 consecutive rows of a 256-row stage and the running moments stay in its registers:
+//   pass 1   S_l  = sum over the lane's K rows of  m(r) - m(r - w)                       2 NV FMAs per row
+//   scan     P_l  = carry + exclusive prefix of S over the lanes -- ONE trip through LDS per STAGE: 45 values out, lane =
+//                   moment runs the 64-long prefix in place, 45 values back (the round trip is amortised over K rows)
+//   pass 2   S = P_l; per row: S += m(r) - m(r - w); L D L' of (S + lambda I) in a work copy; beta; pred; stores
+// with m(r) = [upper triangle of z z', z y, 1] of row r (zeros for a non-finite row: OnlineLR::update lr_online_solvers.rs:85-89).
+// The lane's K rows of a column are K * 8 contiguous bytes and lanes are contiguous, so a stage reads whole lines and a lane
+// writes its K coefficient rows as K * p' * 8 contiguous bytes.
+// One wave per SIMD (the running sums, the work copy and 2 K rows need ~400 registers); what hides the HBM latency is a
+// register-staged prefetch THROUGH LDS: while pass 2 computes, the next stage's rows are loaded 16 bytes per lane (fully
+// coalesced 1 KiB pieces, a quarter of them in front of every row of pass 2) and parked in the wave's LDS region, from
+// where the lanes pick up their own K rows at the start of the next stage.  The same region carries the scan (the rows are
+// in registers by then): 36 KB per wave, four waves per CU.
+// Tiles of kSegTile rows are anchored exactly as in rolling.hip (window in front of the tile summed cooperatively; expanding:
+// exclusive prefix over per-tile totals), so round-off never accumulates over more than one tile.
+#pragma once
+#include <type_traits>
+
+#include "common.hpp"
+#include "moments_dev.hpp"
+
+namespace pds {
+
+constexpr int kSegK = 4;                  // consecutive rows per lane
+constexpr int kSegStage = 64 * kSegK;     // rows per stage
+constexpr int kSegTile = 4096;            // rows per tile (== rolling.hip's kTileRows: the expanding pass shares its tile totals)
+constexpr int kSegStride = 65;            // doubles per moment row of the scan area
+
+template <typename T, int PP>
+struct SegDims {
+    static constexpr int NG = PP * (PP + 1) / 2;
+    static constexpr int NV = NG + PP + 1;
+    static constexpr int E16 = 16 / (int)sizeof(T);                 // elements per 16-byte lane load
+    static constexpr int PIECES = kSegK / E16;                      // 1 KiB pieces per stream and stage
+    static constexpr int STREAM_BYTES = kSegStage * (int)sizeof(T);
+    static constexpr int NSTREAM = 2 * (PP + 1);                    // new + old rows of [features.., y]
+    static constexpr int STAGE_BYTES = NSTREAM * STREAM_BYTES;
+    static constexpr int SCAN_BYTES = NV * kSegStride * 8;
+    static constexpr int LDS_BYTES = STAGE_BYTES > SCAN_BYTES ? STAGE_BYTES : SCAN_BYTES;
+};
+
+template <int PP>
+struct SegRow {
+    double z[PP], y;
+};
+
+// S += m(row) (SIGN = +1) or S -= m(row): Gram upper triangle (a <= b, row-major), then z y, then the finite-row count.
+// (the negation rides on the FMA's source modifier: no extra instruction)
+template <int PP, int NV, int SIGN>
+__device__ __forceinline__ void seg_accumulate(double (&S)[NV], const SegRow<PP>& r, bool ok) {
+    int v = 0;
+#pragma unroll
+    for (int a = 0; a < PP; ++a) {
+        const double sa = SIGN > 0 ? r.z[a] : -r.z[a];
+#pragma unroll
+        for (int b = a; b < PP; ++b) {
+            S[v] = fma(sa, r.z[b], S[v]);
+            ++v;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < PP; ++a) {
+        S[v] = fma(SIGN > 0 ? r.z[a] : -r.z[a], r.y, S[v]);
+        ++v;
+    }
+    S[v] += ok ? (double)SIGN : 0.0;
+}
+
+template <int PP>
+__device__ __forceinline__ bool seg_finite(const SegRow<PP>& r) {
+    bool fin = isfinite(r.y);
+#pragma unroll
+    for (int a = 0; a < PP; ++a) fin = fin && isfinite(r.z[a]);
+    return fin;
+}
+template <int PP>
+__device__ __forceinline__ void seg_zero(SegRow<PP>& r) {
+#pragma unroll
+    for (int a = 0; a < PP; ++a) r.z[a] = 0.0;
+    r.y = 0.0;
+}
+
+// MODE 0: rolling window.  MODE 2: expanding, main pass (tile_tot holds the exclusive prefix over the tiles' totals, written
+// by rolling.hip's totals pass + tile_prefix_kernel).  FULLP as in rolling.hip (1: p == PP, no bias; 2: p == PP - 1 + bias).
+template <typename T, int PP, int MODE, int FULLP>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void rolling_seg_kernel(
+    const T* const* __restrict__ cols, RollArgs ra_in, const double* __restrict__ tile_tot, T* __restrict__ coeffs,
+    T* __restrict__ pred, uint8_t* __restrict__ valid) {
+    using SD = SegDims<T, PP>;
+    constexpr int K = kSegK, NG = SD::NG, NV = SD::NV, E16 = SD::E16, PIECES = SD::PIECES;
+    static_assert(NV <= 64, "one lane per moment in the scan");
+    static_assert(MODE == 0 || MODE == 2, "rolling or the main pass of the expanding fit");
+    using V16 = typename Tile<T>::vec;  // 16 bytes, element aligned (d2u / f4u)
+    RollArgs ra = ra_in;
+    if constexpr (FULLP == 1) {
+        ra.p = PP;
+        ra.pp = PP;
+        ra.bias = 0;
+    } else if constexpr (FULLP == 2) {
+        ra.p = PP - 1;
+        ra.pp = PP;
+        ra.bias = 1;
+    }
+    const int p = ra.p;                       // feature columns; column p of the table is y
+    constexpr int NWHICH = MODE == 0 ? 2 : 1; // new rows (+ the rows leaving the window)
+    constexpr int NLOAD = NWHICH * (PP + 1) * PIECES;       // 16-byte loads per lane and stage (columns beyond p are skipped)
+    constexpr int PER_BATCH = (NLOAD + K - 1) / K;          // ... issued in K batches, one in front of every row of pass 2
+    extern __shared__ __attribute__((aligned(16))) double seg_lds[];  // (one name / type per translation unit)
+    char* sm = reinterpret_cast<char*>(seg_lds);
+    double* D = seg_lds;
+    const int lane = threadIdx.x & 63;
+    const int64_t n = ra.n, w = ra.window;
+    const int64_t ntiles = (n + kSegTile - 1) / kSegTile;
+    const double lambda = ra.lambda;
+
+    // ---- one 16-byte piece of the next stage: global -> register (issue) -> LDS (commit)
+    auto piece_row = [&](int idx, int64_t base) __attribute__((always_inline)) {
+        const int piece = idx % PIECES, which = idx / (PIECES * (PP + 1));
+        return base + (int64_t)piece * (64 * E16) + (int64_t)lane * E16 - (which ? w : 0);
+    };
+    auto issue = [&](int idx, int64_t base, V16& v) __attribute__((always_inline)) {
+        const int c = (idx / PIECES) % (PP + 1);
+        if (c > p) return;  // (unused column slot)
+        const int64_t r = piece_row(idx, base);
+        gptr<T> col = as_global(cols[c]);
+        if (r >= 0 && r + E16 <= n) {
+            v = *reinterpret_cast<gptr<V16>>(col + r);
+        } else {
+#pragma unroll
+            for (int e = 0; e < E16; ++e) v[e] = (r + e >= 0 && r + e < n) ? col[r + e] : T(0);
+        }
+    };
+    auto commit = [&](int idx, const V16& v) __attribute__((always_inline)) {
+        const int c = (idx / PIECES) % (PP + 1), piece = idx % PIECES, which = idx / (PIECES * (PP + 1));
+        if (c > p) return;
+        *reinterpret_cast<V16*>(sm + (which * (PP + 1) + c) * SD::STREAM_BYTES + piece * 1024 + lane * 16) = v;
+    };
+    // the lane's K rows of stream (which, c) out of the LDS image
+    auto pick = [&](int which, int c, double (&out)[K]) __attribute__((always_inline)) {
+        const char* src = sm + (which * (PP + 1) + c) * SD::STREAM_BYTES + lane * (K * (int)sizeof(T));
+#pragma unroll
+        for (int j = 0; j < PIECES; ++j) {
+            const V16 v = *reinterpret_cast<const V16*>(src + 16 * j);
+#pragma unroll
+            for (int e = 0; e < E16; ++e) out[j * E16 + e] = (double)v[e];
+        }
+    };
+
+#ifdef PDS_PROFILE_ROLLING
+    unsigned long long rprof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        RT0();
+        const int64_t t0 = t * kSegTile, t1 = (t0 + kSegTile < n) ? t0 + kSegTile : n;
+        // ---- anchor: lane v < NV carries moment v of the window that ends at row t0 - 1
+        double carry = 0.0;
+        if constexpr (MODE == 2) {
+            if (lane < NV) carry = tile_tot[t * NV + lane];
+        } else {
+            double A[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) A[v] = 0.0;
+            const int64_t a0 = t0 - w;
+            for (int64_t r = a0 + lane; r < t0; r += 64) {
+                SegRow<PP> row;
+                const bool in = r >= 0;
+#pragma unroll
+                for (int c = 0; c < PP; ++c) {
+                    double x = 0.0;
+                    if (c < p) x = in ? (double)as_global(cols[c])[r] : 0.0;
+                    else if (c == p && ra.bias) x = 1.0;
+                    row.z[c] = x;
+                }
+                row.y = in ? (double)as_global(cols[p])[r] : 0.0;
+                const bool ok = in && seg_finite<PP>(row);
+                if (!ok) seg_zero<PP>(row);
+                seg_accumulate<PP, NV, 1>(A, row, ok);
+            }
+#pragma unroll
+            for (int v = 0; v < NV; ++v) D[v * kSegStride + lane] = A[v];
+            PDS_WAVE_LDS_SYNC();
+            if (lane < NV) {
+                const double* rowp = D + lane * kSegStride;
+                double s = 0.0;
+#pragma unroll 16
+                for (int i = 0; i < 64; ++i) s += rowp[i];
+                carry = s;
+            }
+            PDS_WAVE_LDS_SYNC();
+        }
+        // ---- first stage of the tile: straight through (issue everything, commit everything)
+        {
+            V16 tmp[NLOAD];
+#pragma unroll
+            for (int i = 0; i < NLOAD; ++i) issue(i, t0, tmp[i]);
+#pragma unroll
+            for (int i = 0; i < NLOAD; ++i) commit(i, tmp[i]);
+        }
+        RT1(0);  // anchor + first stage straight through
+        for (int64_t base = t0; base < t1; base += kSegStage) {
+            RTA();
+            PDS_WAVE_LDS_SYNC();  // the stage image is complete
+            const int64_t r0 = base + (int64_t)K * lane;
+            // ---- the lane's rows: LDS -> registers
+            SegRow<PP> rn[K], ro[K];
+            bool okn[K], oko[K];
+#pragma unroll
+            for (int c = 0; c < PP; ++c) {
+                double a[K], b[K];
+                const bool feat = c < p;
+                if (feat) {
+                    pick(0, c, a);
+                    if constexpr (MODE == 0) pick(1, c, b);
+                }
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    const double one = (c == p && ra.bias) ? 1.0 : 0.0;
+                    rn[i].z[c] = feat ? a[i] : one;
+                    ro[i].z[c] = (MODE == 0) ? (feat ? b[i] : one) : 0.0;
+                }
+            }
+            {
+                double a[K], b[K];
+                pick(0, p, a);
+                if constexpr (MODE == 0) pick(1, p, b);
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    rn[i].y = a[i];
+                    ro[i].y = (MODE == 0) ? b[i] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const int64_t r = r0 + i;
+                okn[i] = (r < t1) && seg_finite<PP>(rn[i]);
+                if (!okn[i]) seg_zero<PP>(rn[i]);
+                if constexpr (MODE == 0) {
+                    oko[i] = (r < t1) && (r - w >= 0) && seg_finite<PP>(ro[i]);
+                    if (!oko[i]) seg_zero<PP>(ro[i]);
+                } else {
+                    oko[i] = false;
+                }
+            }
+#ifdef PDS_PROFILE_ROLLING
+            asm volatile("" :: "v"(rn[0].z[0]), "v"(rn[K - 1].y));
+#endif
+            RT1(1);  // rows LDS -> registers, finiteness
+            RTA();
+            // ---- pass 1: the lane's own increments
+            double S[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) S[v] = 0.0;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                seg_accumulate<PP, NV, 1>(S, rn[i], okn[i]);
+                if constexpr (MODE == 0) seg_accumulate<PP, NV, -1>(S, ro[i], oko[i]);
+            }
+#ifdef PDS_PROFILE_ROLLING
+            asm volatile("" :: "v"(S[0]), "v"(S[NV - 1]));
+#endif
+            RT1(2);  // pass 1
+            RTA();
+            // ---- scan over the lanes through LDS (every lane holds its rows in registers: the region is free)
+            PDS_WAVE_LDS_SYNC();
+#pragma unroll
+            for (int v = 0; v < NV; ++v) D[v * kSegStride + lane] = S[v];
+            PDS_WAVE_LDS_SYNC();
+            if (lane < NV) {
+                double* rowp = D + lane * kSegStride;
+                double run = carry;
+#pragma unroll
+                for (int i0 = 0; i0 < 64; i0 += 16) {
+                    double x[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) x[i] = rowp[i0 + i];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const double inc = x[i];
+                        x[i] = run;  // exclusive prefix, carry included
+                        run += inc;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) rowp[i0 + i] = x[i];
+                }
+                carry = run;
+            }
+            PDS_WAVE_LDS_SYNC();
+#pragma unroll
+            for (int v = 0; v < NV; ++v) S[v] = D[v * kSegStride + lane];
+            PDS_WAVE_LDS_SYNC();  // the region is free again: the next stage's pieces may land
+            RT1(3);  // scan
+            RTA();
+            // ---- pass 2: row by row; a quarter of the next stage's pieces goes in flight in front of every row
+            const int64_t nb = base + kSegStage;
+            const bool more = nb < t1;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                V16 tmp[PER_BATCH];
+                if (more) {
+#pragma unroll
+                    for (int j = 0; j < PER_BATCH; ++j)
+                        if (i * PER_BATCH + j < NLOAD) issue(i * PER_BATCH + j, nb, tmp[j]);
+                }
+                seg_accumulate<PP, NV, 1>(S, rn[i], okn[i]);
+                if constexpr (MODE == 0) seg_accumulate<PP, NV, -1>(S, ro[i], oko[i]);
+                const int64_t r = r0 + i;
+                // L D L' of (G + lambda I) in a work copy; idx(a, b), a <= b -> a * PP - a (a - 1) / 2 + (b - a).
+                // Padding dimensions (a >= p') have zero rows and a unit diagonal: beta_pad = 0.
+                double g[NG], c[PP], rd[PP];
+#pragma unroll
+                for (int a = 0; a < PP; ++a) c[a] = S[NG + a];
+#define GI(a, b) g[(a) * PP - ((a) * ((a)-1)) / 2 + ((b) - (a))]
+#define SI(a, b) S[(a) * PP - ((a) * ((a)-1)) / 2 + ((b) - (a))]
+                auto diag_add = [&](int a) __attribute__((always_inline)) { return (a < ra.pp) ? lambda : 1.0; };
+                bool okc = true;
+                {   // step 0 reads the running sums and writes the work copy: no register copy of the NG values
+                    const double d = SI(0, 0) + diag_add(0);
+                    okc = d > 0.0;
+                    double x = __builtin_amdgcn_rcp(d);
+                    x = x * fma(-d, x, 2.0);
+                    x = x * fma(-d, x, 2.0);
+                    rd[0] = x;
+#pragma unroll
+                    for (int a = 1; a < PP; ++a) {
+                        const double tka = SI(0, a) * x;
+#pragma unroll
+                        for (int b = a; b < PP; ++b) GI(a, b) = fma(-tka, SI(0, b), SI(a, b) + ((a == b) ? diag_add(a) : 0.0));
+                        GI(0, a) = tka;
+                    }
+                }
+#pragma unroll
+                for (int k = 1; k < PP; ++k) {
+                    const double d = GI(k, k);
+                    okc = okc && (d > 0.0);
+                    double x = __builtin_amdgcn_rcp(d);
+                    x = x * fma(-d, x, 2.0);
+                    x = x * fma(-d, x, 2.0);
+                    rd[k] = x;
+#pragma unroll
+                    for (int a = k + 1; a < PP; ++a) {
+                        const double tka = GI(k, a) * x;  // l_ak
+#pragma unroll
+                        for (int b = a; b < PP; ++b) GI(a, b) = fma(-tka, GI(k, b), GI(a, b));
+                        GI(k, a) = tka;
+                    }
+                }
+#undef SI
+                // L u = c, D v = u, L' beta = v
+#pragma unroll
+                for (int a = 1; a < PP; ++a)
+#pragma unroll
+                    for (int k = 0; k < a; ++k) c[a] = fma(-GI(k, a), c[k], c[a]);
+#pragma unroll
+                for (int a = 0; a < PP; ++a) c[a] *= rd[a];
+#pragma unroll
+                for (int a = PP - 2; a >= 0; --a)
+#pragma unroll
+                    for (int k = a + 1; k < PP; ++k) c[a] = fma(-GI(a, k), c[k], c[a]);
+#undef GI
+                if (r < t1) {
+                    const T nanv = (T)__builtin_nan("");
+                    bool v_ok = r >= w - 1;
+                    if (ra.min_size > 0) v_ok = v_ok && (S[NV - 1] >= (double)ra.min_size);
+                    double pr = 0.0;
+#pragma unroll
+                    for (int a = 0; a < PP; ++a) pr = fma(rn[i].z[a], c[a], pr);
+                    const bool good = v_ok && okc;
+                    T* out = coeffs + r * (int64_t)ra.pp;
+                    if constexpr (FULLP != 0 && PP % E16 == 0) {
+                        // p' == PP: the row is PP contiguous values -> 16-byte stores (element-aligned vector type)
+#pragma unroll
+                        for (int a = 0; a < PP; a += E16) {
+                            V16 o;
+#pragma unroll
+                            for (int e = 0; e < E16; ++e) o[e] = good ? (T)c[a + e] : nanv;
+                            *reinterpret_cast<V16*>(out + a) = o;
+                        }
+                    } else {
+#pragma unroll
+                        for (int a = 0; a < PP; ++a)
+                            if (a < ra.pp) out[a] = good ? (T)c[a] : nanv;
+                    }
+                    pred[r] = (good && okn[i]) ? (T)pr : nanv;  // (a non-finite row: x_r . beta is NaN in the reference too)
+                    valid[r] = v_ok ? 1 : 0;
+                }
+                if (more) {
+#ifdef PDS_PROFILE_ROLLING
+                    const unsigned long long _tc = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll
+                    for (int j = 0; j < PER_BATCH; ++j)
+                        if (i * PER_BATCH + j < NLOAD) commit(i * PER_BATCH + j, tmp[j]);
+#ifdef PDS_PROFILE_ROLLING
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    rprof[5] += __builtin_amdgcn_s_memtime() - _tc;
+#endif
+                }
+            }
+            RT1(4);  // pass 2 (incl. the commits counted in [5])
+        }
+        PDS_WAVE_LDS_SYNC();  // the next tile's anchor writes the region
+    }
+#ifdef PDS_PROFILE_ROLLING
+    rprof[7] = __builtin_amdgcn_s_memtime() - t_begin;
+    if (lane == 0)
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_roll_cycles[k], rprof[k]);
+#endif
+}
+
+}  // namespace pds

@@ -66,7 +66,9 @@ def test_sharded_paths_on_rccl(world1):
     # partition, piece bounds and result assembly are the real ones)
     xs_l, y_l, off_l, parts = par.scatter_frame_by_groups(xs, yt[: int(off[-1])], off, root=0)
     co_l, nu_l, co_g, nu_g = par.lin_reg_by_group_local_shard(xs_l, y_l, off_l, parts, rank=0, gather_to=0, chunks=4, add_bias=False)
-    assert parts == [(0, len(off) - 1)] and torch.allclose(co_g, ref_co, rtol=0, atol=0, equal_nan=True) and torch.equal(nu_g, ref_nu)
+    # (pieces start at other rows than the frame, so a group's rows meet the kernel's 128-row tiles differently: same sums in
+    #  another order -- equal to rounding, not bitwise)
+    assert parts == [(0, len(off) - 1)] and torch.allclose(co_g, ref_co, rtol=1e-12, atol=1e-14, equal_nan=True) and torch.equal(nu_g, ref_nu)
     # row-sharded report: moments -> all-reduce -> fit -> residual pass -> all-reduce -> epilogue == the single-frame report
     for kind in ("se", "hc0", "hc1", "hc2", "hc3"):
         rs = par.lin_reg_report_row_sharded(xs, yt, add_bias=True, std_err=kind)
