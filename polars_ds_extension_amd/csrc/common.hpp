@@ -142,7 +142,10 @@ int make_device_cols(pds_ctx* ctx, const T* const* cols /*[y,x1..xp]*/, const T*
 // ---- kernels' host launchers (moments.hip) ----
 template <typename T>
 int launch_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, bool weighted,
-                   T* d_moments /*device, (p+2)^2*/);
+                   T* d_moments /*device, (p+2)^2*/,
+                   // p <= 16, unweighted frames only: weight of row i = (y_i - x_i . beta [- beta_p])^2 formed inside the pass
+                   // (the HC0 / HC1 meat of lin_reg_report); d_sums_resid[0] receives sum of the weights = sum e^2
+                   const T* d_beta_resid = nullptr, int bias_resid = 0, double* d_sums_resid = nullptr);
 
 // moments_wide.hip: p > 16 (tiled MFMA SYRK with split-K); partials come out of ctx->ws (reserve
 // moments_wide_workspace() bytes on top of the call's other needs)

@@ -23,10 +23,17 @@ namespace pds {
 // =============================================================================================
 // P16: exactly 16 features, known at compile time -- the per-column `c < p` scalar branches of the tile load / store fold away
 // P2 (0 = off): p <= P2 <= 8 features, 16 / P2 row slabs per matrix instruction (consume_tile_pack)
-template <typename T, bool WEIGHTED, bool P16, int P2>
+// WM: 0 = unweighted, 1 = a weight column, 2 = the weight of a row is its squared residual under `beta` (the HC0 / HC1
+// "meat" X' diag(e^2) X of pl_lin_reg_report, linear_regression.rs:880-892, in the SAME pass that forms the residuals: the
+// lane that loaded a row holds all of its features, so e_i = y_i - x_i . beta costs p FMAs before the tile goes to LDS, the
+// per-row weight vector never reaches HBM, and sum(w) of the record is the residual sum of squares)
+template <typename T, int WM, bool P16, int P2>
 __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* __restrict__ cols, int p_arg,
-                                                               int64_t n, double* __restrict__ partials) {
+                                                               int64_t n, double* __restrict__ partials,
+                                                               const T* __restrict__ beta, int bias) {
     static_assert(!(P16 && P2), "one or the other");
+    constexpr bool WEIGHTED = WM != 0;   // the LDS tile carries a weight column
+    constexpr bool LOADW = WM == 1;      // ... that comes from memory
     const int p = P16 ? 16 : p_arg;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int RPL = Tile<T>::RPL;
@@ -49,7 +56,28 @@ __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* _
     const int64_t wid = (int64_t)blockIdx.x * kWaves + wave, nw = (int64_t)gridDim.x * kWaves;
     TileRegs<T> regs;
     ColPtrs<T> cp;
-    fetch_col_ptrs<T, WEIGHTED>(cols, p, cp);
+    fetch_col_ptrs<T, LOADW>(cols, p, cp);
+    // WM == 2: coefficients are wave uniform (scalar registers); rows at or beyond n_lim get weight 0
+    T bx[16];
+    T b0 = T(0);
+    if constexpr (WM == 2) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) bx[c] = (c < p) ? beta[c] : T(0);
+        b0 = bias ? beta[p] : T(0);
+    }
+    auto resid_weights = [&](int64_t row, int64_t n_lim) __attribute__((always_inline)) {
+        if constexpr (WM == 2) {
+#pragma unroll
+            for (int e = 0; e < RPL; ++e) {
+                T acc1 = b0;  // same order as pass2_kernel: bias first, then the features in column order
+#pragma unroll
+                for (int c = 0; c < 16; ++c)
+                    if (c < p) acc1 += regs.x[c][e] * bx[c];
+                const T r = regs.y[e] - acc1;
+                regs.w[e] = (row + e < n_lim) ? r * r : T(0);
+            }
+        }
+    };
     // Wave w streams the CONTIGUOUS tile range [nfull w / W, nfull (w+1) / W) of every column (consecutive 1 KiB pieces of a
     // column stay with one wave: 6.1 TB/s for the bare access pattern against 5.5 TB/s grid-strided, tools/membw.hip).
     // -DPDS_GRAM_STRIDED keeps the grid-strided walk (A/B).
@@ -60,16 +88,18 @@ __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* _
     int64_t t = (int64_t)(((__int128)nfull * wid) / nw);
     const int64_t t_end = (int64_t)(((__int128)nfull * (wid + 1)) / nw), t_step = 1;
 #endif
-    if (t < t_end) load_full_tile<T, WEIGHTED>(cp, p, t * TR + lane * RPL, regs);
+    if (t < t_end) load_full_tile<T, LOADW>(cp, p, t * TR + lane * RPL, regs);
     for (; t < t_end; t += t_step) {
+        resid_weights(0, 1 << 30);  // (full tiles: every row counts)
         store_tile_lds<T, WEIGHTED>(wl, p, lane, regs);
         const int64_t tn = t + t_step;
-        if (tn < t_end) load_full_tile<T, WEIGHTED>(cp, p, tn * TR + lane * RPL, regs);
+        if (tn < t_end) load_full_tile<T, LOADW>(cp, p, tn * TR + lane * RPL, regs);
         if constexpr (P2 != 0) consume_tile_pack<T, WEIGHTED, P2>(wl, lane, acc);
         else consume_tile<T, WEIGHTED>(wl, lane, TR / 4, acc);
     }
     if (nfull * TR < n && wid == nw - 1) {  // ragged tail: exactly one wave
-        load_tail_tile<T, WEIGHTED>(cp, p, nfull * TR + lane * RPL, n, regs);
+        load_tail_tile<T, LOADW>(cp, p, nfull * TR + lane * RPL, n, regs);
+        resid_weights(nfull * TR + lane * RPL, n);
         store_tile_lds<T, WEIGHTED>(wl, p, lane, regs);
         if constexpr (P2 != 0) consume_tile_pack<T, WEIGHTED, P2>(wl, lane, acc);
         else consume_tile<T, WEIGHTED>(wl, lane, TR / 4, acc);
@@ -97,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* _
 template <typename T>
 __global__ __launch_bounds__(64) void moments_finalize_kernel(const double* __restrict__ partials, int nblocks,
                                                               int p, double n_rows, int weighted, int p2,
-                                                              T* __restrict__ out) {
+                                                              T* __restrict__ out, double* __restrict__ sums_out) {
     const int e = blockIdx.x;  // element of the partial record, 0 .. kPartSW
     auto blocksum = [&](int el) {
         double v = 0.0;
@@ -147,6 +177,10 @@ __global__ __launch_bounds__(64) void moments_finalize_kernel(const double* __re
         out[(p + 1) + p * q] = (T)s;
     } else if (e == kPartSW) {
         out[p + p * q] = (T)(weighted ? s : n_rows);
+        if (sums_out) {  // residual-weighted build: sum(w) IS the residual sum of squares (report_second_pass reads it here)
+            sums_out[0] = s;
+            sums_out[1] = 0.0;
+        }
     }
 }
 
@@ -230,10 +264,12 @@ __global__ __launch_bounds__(256, 2) void grouped_moments_kernel(const T* const*
 // =============================================================================================
 template <typename T>
 int launch_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, bool weighted,
-                   T* d_moments) {
+                   T* d_moments, const T* d_beta_resid, int bias_resid, double* d_sums_resid) {
     if (n_feat > kMaxFeatSmall) {
+        if (d_beta_resid) return fail(PDS_ERR_INVALID, "internal: the residual-weighted Gram build is the p <= 16 kernel's");
         return launch_moments_wide<T>(ctx, dc, n_feat, n_rows, weighted, d_moments);
     }
+    if (d_beta_resid && weighted) return fail(PDS_ERR_INVALID, "internal: residual weights replace the weight column");
     if (n_feat < 1) return fail(PDS_ERR_INVALID, "need at least one feature column");
     constexpr int TR = 64 * Tile<T>::RPL;
     int64_t ntiles = (n_rows + TR - 1) / TR;
@@ -245,7 +281,7 @@ int launch_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_
     const int p2 = n_feat > 8 ? 0 : (n_feat > 4 ? 8 : (n_feat > 2 ? 4 : (n_feat > 1 ? 2 : 1)));
     auto launch = [&](auto w_c, auto p16_c, auto p2_c) {
         hipLaunchKernelGGL((moments_small_kernel<T, decltype(w_c)::value, decltype(p16_c)::value, decltype(p2_c)::value>), dim3(nblocks),
-                           dim3(256), lds, ctx->stream, dc.d_ptrs, n_feat, n_rows, partials);
+                           dim3(256), lds, ctx->stream, dc.d_ptrs, n_feat, n_rows, partials, d_beta_resid, bias_resid);
     };
     auto by_p2 = [&](auto w_c) {
         using std::integral_constant;
@@ -257,10 +293,11 @@ int launch_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_
         else if (p2 == 1) launch(w_c, false_type{}, integral_constant<int, 1>{});
         else launch(w_c, false_type{}, integral_constant<int, 0>{});
     };
-    if (weighted) by_p2(std::true_type{});
-    else by_p2(std::false_type{});
+    if (d_beta_resid) by_p2(std::integral_constant<int, 2>{});
+    else if (weighted) by_p2(std::integral_constant<int, 1>{});
+    else by_p2(std::integral_constant<int, 0>{});
     hipLaunchKernelGGL((moments_finalize_kernel<T>), dim3(kPartSW + 1), dim3(64), 0, ctx->stream, partials, nblocks, n_feat,
-                       (double)n_rows, weighted ? 1 : 0, p2, d_moments);
+                       (double)n_rows, (weighted || d_beta_resid) ? 1 : 0, p2, d_moments, d_beta_resid ? d_sums_resid : nullptr);
     PDS_HIP_CHECK(hipGetLastError());
     return PDS_OK;
 }
@@ -383,8 +420,8 @@ int launch_grouped_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, co
     return PDS_OK;
 }
 
-template int launch_moments<double>(pds_ctx*, const DeviceCols<double>&, int, int64_t, bool, double*);
-template int launch_moments<float>(pds_ctx*, const DeviceCols<float>&, int, int64_t, bool, float*);
+template int launch_moments<double>(pds_ctx*, const DeviceCols<double>&, int, int64_t, bool, double*, const double*, int, double*);
+template int launch_moments<float>(pds_ctx*, const DeviceCols<float>&, int, int64_t, bool, float*, const float*, int, double*);
 template int launch_grouped_moments<double>(pds_ctx*, const DeviceCols<double>&, int, const int64_t*, int64_t,
                                             double*, const int32_t*);
 template int launch_grouped_moments<float>(pds_ctx*, const DeviceCols<float>&, int, const int64_t*, int64_t,

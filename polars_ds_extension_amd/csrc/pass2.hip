@@ -30,7 +30,7 @@ constexpr int kP2Threads = 256;
 // PC: the feature count as a compile-time constant (16, 8, 4, 2, 1; 0 = run time): the per-column `c < p` scalar branches
 // in the row loop fold away
 template <typename T, bool WEIGHTED, int HC, int PC>
-__global__ __launch_bounds__(kP2Threads) void pass2_kernel(const T* const* __restrict__ cols, int p_arg, int bias,
+__global__ __launch_bounds__(kP2Threads, 2) void pass2_kernel(const T* const* __restrict__ cols, int p_arg, int bias,
                                                            int64_t n, const T* __restrict__ beta,
                                                            const T* __restrict__ inv, T* __restrict__ pred_out,
                                                            T* __restrict__ resid_out, T* __restrict__ s_out,
@@ -51,32 +51,25 @@ __global__ __launch_bounds__(kP2Threads) void pass2_kernel(const T* const* __res
     const gptr<T> cy = as_global(cols[p]);
     const gptr<T> cw = as_global(WEIGHTED ? cols[p + 1] : cols[p]);
     const T b0 = bias ? beta[p] : T(0);
-    const int64_t nvec = (n + RPL - 1) / RPL;
-    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = v * RPL;
-        const bool full = row + RPL <= n;
-        V x[16];
-        V yv, wv;
-        if (full) {
+    // Wave w owns the CONTIGUOUS chunk range [nchunk w / W, nchunk (w+1) / W) (a chunk = 64 RPL rows = 1 KiB of every column):
+    // consecutive pieces of a column stay with one wave, the loads are non-temporal (every element is read once) and the next
+    // chunk is in flight in a second register set while this one is computed -- the recipe of the Gram kernel (moments.hip),
+    // which took this kernel's access pattern from 0.60 to 0.8 of the HBM peak.  The ragged last chunk belongs to the last wave.
+    constexpr int CH = 64 * RPL;
+    const int lane = threadIdx.x & 63;
+    const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t nfull = n / CH;
+    int64_t t = (int64_t)(((__int128)nfull * wid) / nw);
+    const int64_t t_end = (int64_t)(((__int128)nfull * (wid + 1)) / nw);
+    V xa[16], ya, wa;
+    auto load_full = [&](int64_t row, V (&x)[16], V& yv, V& wv) __attribute__((always_inline)) {
 #pragma unroll
-            for (int c = 0; c < 16; ++c)
-                if (c < p) x[c] = *reinterpret_cast<gptr<V>>(cx[c] + row);
-            yv = *reinterpret_cast<gptr<V>>(cy + row);
-            if (WEIGHTED) wv = *reinterpret_cast<gptr<V>>(cw + row);
-        } else {
-#pragma unroll
-            for (int c = 0; c < 16; ++c)
-                if (c < p) {
-#pragma unroll
-                    for (int e = 0; e < RPL; ++e) x[c][e] = (row + e < n) ? cx[c][row + e] : T(0);
-                }
-#pragma unroll
-            for (int e = 0; e < RPL; ++e) yv[e] = (row + e < n) ? cy[row + e] : T(0);
-            if (WEIGHTED) {
-#pragma unroll
-                for (int e = 0; e < RPL; ++e) wv[e] = (row + e < n) ? cw[row + e] : T(0);
-            }
-        }
+        for (int c = 0; c < 16; ++c)
+            if (c < p) x[c] = __builtin_nontemporal_load(reinterpret_cast<gptr<V>>(cx[c] + row));
+        yv = __builtin_nontemporal_load(reinterpret_cast<gptr<V>>(cy + row));
+        if (WEIGHTED) wv = __builtin_nontemporal_load(reinterpret_cast<gptr<V>>(cw + row));
+    };
+    auto compute = [&](int64_t row, const V (&x)[16], const V& yv, const V& wv, bool full) __attribute__((always_inline)) {
         V pr, rs, sv;
 #pragma unroll
         for (int e = 0; e < RPL; ++e) {
@@ -87,7 +80,7 @@ __global__ __launch_bounds__(kP2Threads) void pass2_kernel(const T* const* __res
             pr[e] = acc;
             const T r = yv[e] - acc;
             rs[e] = r;
-            const bool in = row + e < n;
+            const bool in = full || row + e < n;
             const double rd = in ? (double)r : 0.0;
             sse = fma(rd, rd, sse);
             if (WEIGHTED) wsse = fma((double)wv[e], rd * rd, wsse);
@@ -98,18 +91,18 @@ __global__ __launch_bounds__(kP2Threads) void pass2_kernel(const T* const* __res
 #pragma unroll
                     for (int a = 0; a < 16; ++a)
                         if (a < p) {
-                            T t = bias ? inv[a + p * pp] : T(0);
+                            T tt = bias ? inv[a + p * pp] : T(0);
 #pragma unroll
                             for (int b = 0; b < 16; ++b)
-                                if (b < p) t += inv[a + b * pp] * x[b][e];
-                            h += x[a][e] * t;
+                                if (b < p) tt += inv[a + b * pp] * x[b][e];
+                            h += x[a][e] * tt;
                         }
                     if (bias) {
-                        T t = inv[p + p * pp];
+                        T tt = inv[p + p * pp];
 #pragma unroll
                         for (int b = 0; b < 16; ++b)
-                            if (b < p) t += inv[p + b * pp] * x[b][e];
-                        h += t;
+                            if (b < p) tt += inv[p + b * pp] * x[b][e];
+                        h += tt;
                     }
                     const T om = T(1) - h;
                     s = (HC == 2) ? s * (T(1) / om) : s * (T(1) / (om * om));
@@ -118,9 +111,9 @@ __global__ __launch_bounds__(kP2Threads) void pass2_kernel(const T* const* __res
             }
         }
         if (full) {
-            if (pred_out) *reinterpret_cast<V*>(pred_out + row) = pr;
-            if (resid_out) *reinterpret_cast<V*>(resid_out + row) = rs;
-            if (HC) *reinterpret_cast<V*>(s_out + row) = sv;
+            if (pred_out) __builtin_nontemporal_store(pr, reinterpret_cast<V*>(pred_out + row));
+            if (resid_out) __builtin_nontemporal_store(rs, reinterpret_cast<V*>(resid_out + row));
+            if (HC) *reinterpret_cast<V*>(s_out + row) = sv;  // (re-read by the weighted Gram build right behind this kernel)
         } else {
 #pragma unroll
             for (int e = 0; e < RPL; ++e)
@@ -130,6 +123,32 @@ __global__ __launch_bounds__(kP2Threads) void pass2_kernel(const T* const* __res
                     if (HC) s_out[row + e] = sv[e];
                 }
         }
+    };
+    if (t < t_end) load_full(t * CH + lane * RPL, xa, ya, wa);
+    for (; t < t_end; ++t) {
+        V xb[16], yb, wb;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) xb[c] = xa[c];
+        yb = ya;
+        wb = wa;
+        if (t + 1 < t_end) load_full((t + 1) * CH + lane * RPL, xa, ya, wa);
+        compute(t * CH + lane * RPL, xb, yb, wb, true);
+    }
+    if (nfull * CH < n && wid == nw - 1) {  // ragged tail: exactly one wave
+        const int64_t row = nfull * CH + lane * RPL;
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (c < p) {
+#pragma unroll
+                for (int e = 0; e < RPL; ++e) xa[c][e] = (row + e < n) ? cx[c][row + e] : T(0);
+            }
+#pragma unroll
+        for (int e = 0; e < RPL; ++e) ya[e] = (row + e < n) ? cy[row + e] : T(0);
+        if (WEIGHTED) {
+#pragma unroll
+            for (int e = 0; e < RPL; ++e) wa[e] = (row + e < n) ? cw[row + e] : T(0);
+        }
+        compute(row, xa, ya, wa, false);
     }
     // block reduction (fixed order) -> one partial pair per block
     __shared__ double red[2][kP2Threads / 64];
@@ -138,7 +157,7 @@ __global__ __launch_bounds__(kP2Threads) void pass2_kernel(const T* const* __res
         sse += __shfl_xor(sse, o);
         wsse += __shfl_xor(wsse, o);
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wave = threadIdx.x >> 6;
     if (lane == 0) {
         red[0][wave] = sse;
         red[1][wave] = wsse;
@@ -293,7 +312,8 @@ int launch_pass2(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_ro
     constexpr int RPL = V16<T>::RPL;
     const int64_t nvec = (n_rows + RPL - 1) / RPL;
     int64_t want = (nvec + kP2Threads - 1) / kP2Threads;
-    const int nblocks = (int)std::min<int64_t>(std::max<int64_t>(want, 1), (int64_t)ctx->num_cus * 8);
+    // two resident blocks per CU (8 waves, like the Gram kernel): every wave streams one contiguous range, all of them at once
+    const int nblocks = (int)std::min<int64_t>(std::max<int64_t>(want, 1), (int64_t)ctx->num_cus * 2);
     double* partials = ctx->partials;
     T* s_rows = reinterpret_cast<T*>(d_s_rows);
     KernelTimer timer(ctx, kKindPass2);

@@ -210,9 +210,38 @@ def test_lin_reg_report(pds, orc, se, bias):
     assert frel(r[key], ro["std_err"], 1e-12) < F64_TOL
     assert frel(r["t"], ro["t"], 1e-2) < 1e-9
     assert frel(r["p>|t|"], ro["p"], 1e-12) < 1e-8  # p = 2 sf(|t|): relative error of t amplified by ~|t|
+    # ... and ALL of that slack is t's: the p-value the library reports is bit for bit the reference's special function of
+    # the library's own t (stats.cpp restates beta.rs / gamma.rs operation by operation), so p meets the 1e-10 contract as a
+    # function and differs from the oracle's p only through the 1e-12-level difference of the two t values
+    dof = float(n - Xb.shape[1])
+    p_of_own_t = np.array([2.0 * orc.student_t_sf(abs(float(tv)), dof) for tv in np.asarray(r["t"], np.float64)])
+    assert np.array_equal(np.asarray(r["p>|t|"], np.float64), p_of_own_t)
     assert np.any((ro["p"] > 1e-6) & (ro["p"] < 0.999))
     assert frel(r["0.025"], ro["ci_lo"], 1e-3) < 1e-9 and frel(r["0.975"], ro["ci_hi"], 1e-3) < 1e-9
     assert abs(r["r2"][0] - ro["r2"]) < 1e-12 and abs(r["adj_r2"][0] - ro["adj_r2"]) < 1e-12
+
+
+@pytest.mark.parametrize("p", [1, 2, 3, 5, 8, 11, 16])
+def test_report_and_pred_shapes(pds, orc, p):
+    """Ragged row counts and every Gram-kernel packing (1 / 2 / 4 / 8 feature slots, 16): HC0 / HC1 form the residuals and the
+    meat X' diag(e^2) X in ONE pass (moments_small_kernel WM = 2), SE / pred go through the streaming residual pass."""
+    rng = np.random.default_rng(40 + p)
+    for n in (130 + p, 128 * 37, 12_345 + p):
+        X, y, _ = make_xy(rng, n, p, noise=0.0)
+        y = y + 0.25 + 0.2 * rng.normal(size=n) * (0.5 + X[:, 0])
+        for bias in (False, True):
+            Xb = np.c_[X, np.ones(n)] if bias else X
+            for se in ("se", "hc0", "hc1"):
+                r = pds.lin_reg_report(*cols_of(X), target=dev(y), add_bias=bias, std_err=se)
+                ro = orc.lin_reg_report(Xb, y, std_err=se)
+                key = {"se": "std_err"}.get(se, f"{se}_se")
+                assert nrel(r["beta"], ro["beta"]) < F64_TOL, (n, bias, se)
+                assert frel(r[key], ro["std_err"], 1e-12) < F64_TOL, (n, bias, se)
+                assert abs(r["r2"][0] - ro["r2"]) < 1e-11
+            pred, resid = pds.lin_reg(*cols_of(X), target=dev(y), add_bias=bias, return_pred=True)
+            bo = orc.pl_lr(X, y, add_bias=bias)
+            po = Xb @ bo
+            assert nrel(pred.cpu().numpy(), po) < F64_TOL and nrel(resid.cpu().numpy(), y - po) < 1e-8
 
 
 def test_wls_report(pds, orc):

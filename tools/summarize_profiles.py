@@ -44,6 +44,29 @@ extra = json.loads((SRC / "bench_extra.json").read_text())
 (OUT / f"{rnd}_bench_extra.json").write_text(json.dumps(extra, indent=1) + "\n")
 
 fetch, write = pmc(SRC / "pmc_FETCH_SIZE.csv"), pmc(SRC / "pmc_WRITE_SIZE.csv")
+for extra_pmc in ("roll",):  # rolling kernel at C4 (tools/rolling_bench.py c4), same two counters
+    fp, wp = SRC / f"pmc_{extra_pmc}_FETCH_SIZE.csv", SRC / f"pmc_{extra_pmc}_WRITE_SIZE.csv"
+    if fp.exists() and wp.exists():
+        for k, v in pmc(fp).items():
+            fetch.setdefault(k, v)
+        for k, v in pmc(wp).items():
+            write.setdefault(k, v)
+
+
+def steady(path, warm_launches):
+    """Per-kernel duration statistics from the kernel TRACE with the first `warm_launches` launches of every kernel dropped
+    (the --stats table averages the warm-ups in: round 1's CSV and bench line disagreed by 7 % for that reason)."""
+    per = defaultdict(list)
+    rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
+    for r in rows:
+        n = short(r["Kernel_Name"])
+        if n.startswith("pds::"):
+            per[n].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    out = {}
+    for n, v in per.items():
+        w = v[warm_launches:] if len(v) > warm_launches + 2 else v
+        out[n] = {"launches": len(w), "avg_us": sum(w) / len(w), "min_us": min(w), "max_us": max(w), "dropped_warmup": len(v) - len(w)}
+    return out
 traffic = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) on `python bench.py --steps 2 "
                    "--warmup 1 --no-cpu`; read bytes = 2 x FETCH_SIZE x 1024 (gfx950 correction, MI355X_MICROARCH.md HBM section), "
                    "write bytes = WRITE_SIZE x 1024", "kernels": {}}
@@ -56,7 +79,7 @@ for k in fetch:
 
 md = [f"# profiles/{rnd} -- one MI355X (gfx950), ROCm 7.2", "",
       f"* `{rnd}_bench_line.json` -- the `python bench.py` JSON line.",
-      f"* `{rnd}_bench_kernel_stats.csv` -- `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 5 --warmup 2 --no-cpu`.",
+      f"* `{rnd}_bench_kernel_stats.csv` -- `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 10 --warmup 3 --no-cpu --no-extras`.",
       f"* `{rnd}_traffic.json` -- HBM bytes per launch from `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (two separate passes).",
       f"* `{rnd}_bench_extra.json` / `{rnd}_extra_kernel_stats.csv` -- `python tools/bench_extra.py`: the other BASELINE configs (single OLS + "
       "report, rolling, recursive, elastic net) and the host-buffer rate, and the rocprofv3 kernel stats of that run.",
@@ -65,6 +88,14 @@ md = [f"# profiles/{rnd} -- one MI355X (gfx950), ROCm 7.2", "",
 for n, c, us, pct in stats(SRC / "bench_kernel_stats.csv"):
     md.append(f"| `{n}` | {c} | {us:.1f} | {pct:.2f} |")
 rf = line["roofline"]
+trace = SRC / "bench_kernel_trace.csv"
+if trace.exists():
+    st = steady(trace, 3)
+    (OUT / f"{rnd}_bench_kernel_steady.json").write_text(json.dumps(st, indent=1) + "\n")
+    md += ["", "Same run, from the kernel trace, warm-up launches (the first 3 of each kernel) dropped -- the figure to hold "
+           f"against the bench line (`{rnd}_bench_kernel_steady.json`):", "", "| kernel | launches | avg us | min | max |", "|---|---|---|---|---|"]
+    for n, v in sorted(st.items(), key=lambda kv: -kv[1]["avg_us"] * kv[1]["launches"]):
+        md.append(f"| `{n}` | {v['launches']} | {v['avg_us']:.1f} | {v['min_us']:.1f} | {v['max_us']:.1f} |")
 md += ["", f"HIP-event timing inside bench.py for the same kernels: grouped fused {rf['avg_launch_ms']:.4f} ms per launch "
        f"({rf['achieved']:.0f} GB/s algorithmic, frac {rf['frac']:.3f} of 8 TB/s); single-OLS Gram "
        f"{line['gram_build']['avg_launch_ms']:.4f} ms ({line['gram_build']['achieved_GBps']:.0f} GB/s, frac {line['gram_build']['frac_of_hbm_peak']:.3f}).", "",
