@@ -14,8 +14,10 @@
  *   - `cols` is an array (in HOST memory) of n_feat + 1 column pointers in the reference's input
  *     order [y, x1, ..., xp] (expr_linear.py:250-258; weighted variants take `weights` separately).
  *     Each column is a contiguous buffer of n_rows values, exactly an Arrow Float64/Float32 values
- *     buffer.  `space` says where the column *buffers* live (PDS_HOST: host memory, staged to HBM in
- *     row chunks through pinned buffers; PDS_DEVICE: already resident in HBM).
+ *     buffer.  `space` says where the column *buffers* live (PDS_DEVICE: already resident in HBM; PDS_HOST: host
+ *     memory, copied to HBM by the library -- frames of more than one chunk (256 MiB, pds_set_host_staging) cross
+ *     PCIe one row range at a time into a chunk-sized staging buffer for pds_lr_* / pds_moments_* (p <= 16), so HBM use
+ *     is O(chunk) and the frame may be larger than HBM; the other entry points stage the whole frame).
  *   - output buffers are host memory unless the parameter is documented "space-resident".
  *   - every function returns PDS_OK (0) or a negative pds_status; pds_last_error() returns the
  *     message (thread-local), with the reference's error strings where the reference has one.
@@ -71,6 +73,11 @@ int pds_ctx_set_stream(pds_ctx* ctx, void* hip_stream);
 int pds_ctx_synchronize(pds_ctx* ctx);
 /* Number of compute units of the context's device (256 on MI355X). */
 int pds_ctx_num_cus(const pds_ctx* ctx);
+/* Host-frame staging (process wide): chunk_mb = bytes of one row chunk of a PDS_HOST frame (default 256, env
+ * PDS_HOST_CHUNK_MB); resident_max_mb = largest host frame that pds_lr_pred_* still stages whole (one PCIe trip; larger
+ * frames make two chunked trips; default 98304, env PDS_HOST_RESIDENT_MAX_MB).  A value <= 0 leaves the setting as is.
+ * Replaces the reference's one-Vec marshalling copy, src/utils/mod.rs:101-206. */
+int pds_set_host_staging(double chunk_mb, double resident_max_mb);
 /* Diagnostics: how many call-local workspace slices had to be allocated outside the per-call reservation since the context
  * was created (0 unless an entry point under-estimated its bound; the slices are still valid, never out of bounds). */
 long long pds_ctx_workspace_spills(const pds_ctx* ctx);

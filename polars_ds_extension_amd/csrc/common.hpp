@@ -145,7 +145,11 @@ int launch_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_
                    T* d_moments /*device, (p+2)^2*/,
                    // p <= 16, unweighted frames only: weight of row i = (y_i - x_i . beta [- beta_p])^2 formed inside the pass
                    // (the HC0 / HC1 meat of lin_reg_report); d_sums_resid[0] receives sum of the weights = sum e^2
-                   const T* d_beta_resid = nullptr, int bias_resid = 0, double* d_sums_resid = nullptr);
+                   const T* d_beta_resid = nullptr, int bias_resid = 0, double* d_sums_resid = nullptr,
+                   // p <= 16: write the record as f64 into this slot instead of d_moments (row chunks of a host frame)
+                   double* d_moments_f64 = nullptr);
+template <typename T>
+int launch_sum_moment_slots(pds_ctx* ctx, const double* d_slots, int nslots, int len, T* d_out);
 
 // moments_wide.hip: p > 16 (tiled MFMA SYRK with split-K); partials come out of ctx->ws (reserve
 // moments_wide_workspace() bytes on top of the call's other needs)

@@ -264,8 +264,9 @@ __global__ __launch_bounds__(256, 2) void grouped_moments_kernel(const T* const*
 // =============================================================================================
 template <typename T>
 int launch_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, bool weighted,
-                   T* d_moments, const T* d_beta_resid, int bias_resid, double* d_sums_resid) {
+                   T* d_moments, const T* d_beta_resid, int bias_resid, double* d_sums_resid, double* d_moments_f64) {
     if (n_feat > kMaxFeatSmall) {
+        if (d_moments_f64) return fail(PDS_ERR_INVALID, "internal: f64 moment slots are the p <= 16 kernel's");
         if (d_beta_resid) return fail(PDS_ERR_INVALID, "internal: the residual-weighted Gram build is the p <= 16 kernel's");
         return launch_moments_wide<T>(ctx, dc, n_feat, n_rows, weighted, d_moments);
     }
@@ -296,8 +297,12 @@ int launch_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_
     if (d_beta_resid) by_p2(std::integral_constant<int, 2>{});
     else if (weighted) by_p2(std::integral_constant<int, 1>{});
     else by_p2(std::integral_constant<int, 0>{});
-    hipLaunchKernelGGL((moments_finalize_kernel<T>), dim3(kPartSW + 1), dim3(64), 0, ctx->stream, partials, nblocks, n_feat,
-                       (double)n_rows, (weighted || d_beta_resid) ? 1 : 0, p2, d_moments, d_beta_resid ? d_sums_resid : nullptr);
+    if (d_moments_f64)  // one row chunk of a host frame: the chunk's record stays in f64 until the chunks are summed
+        hipLaunchKernelGGL((moments_finalize_kernel<double>), dim3(kPartSW + 1), dim3(64), 0, ctx->stream, partials, nblocks, n_feat,
+                           (double)n_rows, (weighted || d_beta_resid) ? 1 : 0, p2, d_moments_f64, (double*)nullptr);
+    else
+        hipLaunchKernelGGL((moments_finalize_kernel<T>), dim3(kPartSW + 1), dim3(64), 0, ctx->stream, partials, nblocks, n_feat,
+                           (double)n_rows, (weighted || d_beta_resid) ? 1 : 0, p2, d_moments, d_beta_resid ? d_sums_resid : nullptr);
     PDS_HIP_CHECK(hipGetLastError());
     return PDS_OK;
 }
@@ -420,8 +425,26 @@ int launch_grouped_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, co
     return PDS_OK;
 }
 
-template int launch_moments<double>(pds_ctx*, const DeviceCols<double>&, int, int64_t, bool, double*, const double*, int, double*);
-template int launch_moments<float>(pds_ctx*, const DeviceCols<float>&, int, int64_t, bool, float*, const float*, int, double*);
+// sum of the per-chunk f64 moment records in chunk order (fixed order: reproducible), cast once
+template <typename T>
+__global__ void sum_moment_slots_kernel(const double* __restrict__ slots, int nslots, int len, T* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    double s = 0.0;
+    for (int k = 0; k < nslots; ++k) s += slots[(size_t)k * len + i];
+    out[i] = (T)s;
+}
+template <typename T>
+int launch_sum_moment_slots(pds_ctx* ctx, const double* d_slots, int nslots, int len, T* d_out) {
+    hipLaunchKernelGGL((sum_moment_slots_kernel<T>), dim3((len + 255) / 256), dim3(256), 0, ctx->stream, d_slots, nslots, len, d_out);
+    PDS_HIP_CHECK(hipGetLastError());
+    return PDS_OK;
+}
+template int launch_sum_moment_slots<double>(pds_ctx*, const double*, int, int, double*);
+template int launch_sum_moment_slots<float>(pds_ctx*, const double*, int, int, float*);
+
+template int launch_moments<double>(pds_ctx*, const DeviceCols<double>&, int, int64_t, bool, double*, const double*, int, double*, double*);
+template int launch_moments<float>(pds_ctx*, const DeviceCols<float>&, int, int64_t, bool, float*, const float*, int, double*, double*);
 template int launch_grouped_moments<double>(pds_ctx*, const DeviceCols<double>&, int, const int64_t*, int64_t,
                                             double*, const int32_t*);
 template int launch_grouped_moments<float>(pds_ctx*, const DeviceCols<float>&, int, const int64_t*, int64_t,

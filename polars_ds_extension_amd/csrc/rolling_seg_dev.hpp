@@ -299,9 +299,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             // ---- pass 2: row by row; a quarter of the next stage's pieces goes in flight in front of every row
             const int64_t nb = base + kSegStage;
             const bool more = nb < t1;
+#ifdef PDS_ROLL_DEEP
+            // batch i of the next stage's pieces is committed to LDS one row LATER (behind row i + 1's solve): two batches
+            // are in flight, each has two solves (~2 us) to arrive instead of one
+            V16 tmp2[2][PER_BATCH];
+#endif
 #pragma unroll
             for (int i = 0; i < K; ++i) {
+#ifdef PDS_ROLL_DEEP
+                V16 (&tmp)[PER_BATCH] = tmp2[i & 1];
+#else
                 V16 tmp[PER_BATCH];
+#endif
                 if (more) {
 #pragma unroll
                     for (int j = 0; j < PER_BATCH; ++j)
@@ -379,23 +388,45 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                             V16 o;
 #pragma unroll
                             for (int e = 0; e < E16; ++e) o[e] = good ? (T)c[a + e] : nanv;
+#ifdef PDS_ROLL_NT_STORE
+                            __builtin_nontemporal_store(o, reinterpret_cast<V16*>(out + a));
+#else
                             *reinterpret_cast<V16*>(out + a) = o;
+#endif
                         }
                     } else {
 #pragma unroll
                         for (int a = 0; a < PP; ++a)
                             if (a < ra.pp) out[a] = good ? (T)c[a] : nanv;
                     }
+#ifdef PDS_ROLL_NT_STORE
+                    __builtin_nontemporal_store((good && okn[i]) ? (T)pr : nanv, pred + r);
+                    __builtin_nontemporal_store((uint8_t)(v_ok ? 1 : 0), valid + r);
+#else
                     pred[r] = (good && okn[i]) ? (T)pr : nanv;  // (a non-finite row: x_r . beta is NaN in the reference too)
                     valid[r] = v_ok ? 1 : 0;
+#endif
                 }
                 if (more) {
 #ifdef PDS_PROFILE_ROLLING
                     const unsigned long long _tc = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef PDS_ROLL_DEEP
+                    if (i > 0) {
+#pragma unroll
+                        for (int j = 0; j < PER_BATCH; ++j)
+                            if ((i - 1) * PER_BATCH + j < NLOAD) commit((i - 1) * PER_BATCH + j, tmp2[(i - 1) & 1][j]);
+                    }
+                    if (i == K - 1) {
+#pragma unroll
+                        for (int j = 0; j < PER_BATCH; ++j)
+                            if (i * PER_BATCH + j < NLOAD) commit(i * PER_BATCH + j, tmp2[i & 1][j]);
+                    }
+#else
 #pragma unroll
                     for (int j = 0; j < PER_BATCH; ++j)
                         if (i * PER_BATCH + j < NLOAD) commit(i * PER_BATCH + j, tmp[j]);
+#endif
 #ifdef PDS_PROFILE_ROLLING
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     rprof[5] += __builtin_amdgcn_s_memtime() - _tc;

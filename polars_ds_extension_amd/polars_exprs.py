@@ -3,9 +3,10 @@ Polars expression builders that route through libpds_lstsq_hip.so's `_polars_plu
 
 Same call signatures as /root/reference/python/polars_ds/exprs/expr_linear.py (`lin_reg` :105-274 incl. the multi-target
 form, `lin_reg_w_rcond` :356-410, `lin_reg_report` :561-631, `rolling_lin_reg` :482-558, `recursive_lin_reg` :413-479) plus the key-aware
-`lin_reg(..., by=key)` of SURVEY.md 8(b).  Importing this module needs `polars` (>= 1.4), which is NOT installable
-in the build image: the module is exercised only through the plugin ABI tests (tests/test_plugin_abi.py, pyarrow
-standing in for the engine) and is UNVERIFIED against a real Polars until run next to one.
+`lin_reg(..., by=key)` of SURVEY.md 8(b) and `lin_reg_by_group`, the frame-level replacement of `group_by().agg(lin_reg)`.
+Importing this module needs `polars` (>= 1.4), which is NOT installable in the build image: tests/test_polars_exprs.py runs
+every builder end to end with tests/mini_polars standing in for the engine (it implements the documented plugin calling
+convention and the per-group evaluation of `group_by().agg()`); against a REAL Polars the module is still unverified.
 """
 from __future__ import annotations
 
@@ -82,6 +83,21 @@ def lin_reg(*x, target, add_bias: bool = False, weights=None, return_pred: bool 
     if return_pred:
         return _plugin("pl_lr_pred", cols, kwargs).alias("lr_pred")
     return _plugin("pl_lr", cols, kwargs, returns_scalar=True).alias("coeffs")
+
+
+def lin_reg_by_group(df, by: str, *x, target, **kwargs):
+    """
+    The replacement for `df.group_by(by).agg(pds.lin_reg(*x, target=...))` on this backend: ONE plugin call over the whole
+    frame (`pl_lr_by`: keys in any row order, one fused kernel for every group) instead of one `pl_lr` call per group.
+    An expression cannot know that it sits inside a `group_by` -- Polars hands the plugin one group's rows at a time, which
+    costs a host-to-device round trip per group and runs BELOW the CPU reference (the coalescing queue of csrc/plugin.cpp
+    only softens that) -- so the rewrite is explicit.  Returns a frame with one row per distinct key, keys
+    ascending: columns `by` and `coeffs` (a null list where the reference's per-group call returns a null list).
+    """
+    if kwargs.get("return_pred"):
+        raise ValueError("lin_reg_by_group returns coefficients (one row per group)")
+    out = df.select(lin_reg(*x, target=target, by=by, **kwargs)).unnest("coeffs_by")
+    return out
 
 
 def lin_reg_w_rcond(*x, target, add_bias: bool = False, rcond: float = 0.0, l2_reg: float = 0.0, null_policy: str = "raise"):

@@ -1,0 +1,319 @@
+"""
+mini_polars -- a stand-in for the part of the `polars` Python API that `polars_ds_extension_amd/polars_exprs.py` (and the
+reference's `python/polars_ds/exprs/expr_linear.py`) touches.  TEST INFRASTRUCTURE: polars is not installable in the build
+image, so without this module `polars_exprs.py` is never executed by any test.
+
+What it implements is the calling convention Polars documents for expression plugins, nothing more:
+  * lazy expression objects (`pl.col`, `pl.lit`, `pl.sql_expr` of a bare column name or simple arithmetic, `.alias`,
+    `.cast`, `.rechunk`, `.var`, `.shift`, `.slice`);
+  * `polars.plugins.register_plugin_function(plugin_path=..., function_name=..., args=..., kwargs=...)` -> an expression
+    that, when evaluated, dlopens `plugin_path`, exports every input as a Series over the Arrow C Data Interface, pickles
+    the kwargs with protocol 5 and calls `_polars_plugin_<function_name>` (tests/plugin_harness.py);
+  * `DataFrame.select / with_columns / unnest`, and `DataFrame.group_by(key).agg(expr)`, which -- like Polars -- evaluates
+    the expression ONCE PER GROUP on the group's rows, from a pool of worker threads (the call pattern behind
+    `df.group_by(k).agg(pds.lin_reg(...))`, tests/test_linear_exprs.py:918-953 of the reference).
+It is NOT a claim that the plugin has run inside a real Polars (still unverified).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import re
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+import numpy as np
+import pyarrow as pa
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
+import plugin_harness as _ph  # noqa: E402
+
+__version__ = "0.0-mini"
+AGG_THREADS = 16  # worker threads of group_by().agg (Polars: the rayon pool)
+
+
+class _DType:
+    def __init__(self, name, pa_type):
+        self.name, self.pa = name, pa_type
+
+    def __repr__(self):
+        return self.name
+
+
+Float64 = _DType("Float64", pa.float64())
+Float32 = _DType("Float32", pa.float32())
+Int64 = _DType("Int64", pa.int64())
+
+
+class Series:
+    def __init__(self, name=None, values=None):
+        if values is None and not isinstance(name, str):
+            name, values = "", name
+        self.name = name or ""
+        self.arr = values if isinstance(values, (pa.Array, pa.ChunkedArray)) else pa.array(np.asarray(values))
+
+    def to_numpy(self):
+        return self.arr.to_numpy(zero_copy_only=False)
+
+    def to_list(self):
+        return self.arr.to_pylist()
+
+    def __len__(self):
+        return len(self.arr)
+
+
+def _combine(a):
+    return a.combine_chunks() if isinstance(a, pa.ChunkedArray) else a
+
+
+class Expr:
+    """Lazy expression; `_eval(frame)` -> (output name, pyarrow array)."""
+
+    def alias(self, name):
+        return _Alias(self, name)
+
+    def cast(self, dt):
+        return _Cast(self, dt)
+
+    def rechunk(self):
+        return _Rechunk(self)
+
+    def var(self, ddof=1):
+        return _Var(self, ddof)
+
+    def shift(self, n=1):
+        return _Shift(self, n)
+
+    def slice(self, offset, length=None):
+        return _Slice(self, offset, length)
+
+    def _bin(self, other, op):
+        return _Arith(self, other if isinstance(other, Expr) else lit(other), op)
+
+    def __add__(self, o):
+        return self._bin(o, np.add)
+
+    def __sub__(self, o):
+        return self._bin(o, np.subtract)
+
+    def __mul__(self, o):
+        return self._bin(o, np.multiply)
+
+    def __truediv__(self, o):
+        return self._bin(o, np.divide)
+
+
+class _Col(Expr):
+    def __init__(self, name):
+        self.name = name
+
+    def _eval(self, fr):
+        if self.name not in fr:
+            raise KeyError(f"column {self.name!r} not found")
+        return self.name, fr[self.name]
+
+
+class _Lit(Expr):
+    def __init__(self, s):
+        self.s = s if isinstance(s, Series) else Series("literal", pa.array([s]))
+
+    def _eval(self, fr):
+        return self.s.name or "literal", self.s.arr
+
+
+class _Alias(Expr):
+    def __init__(self, e, name):
+        self.e, self.name = e, name
+
+    def _eval(self, fr):
+        return self.name, self.e._eval(fr)[1]
+
+
+class _Cast(Expr):
+    def __init__(self, e, dt):
+        self.e, self.dt = e, dt
+
+    def _eval(self, fr):
+        n, a = self.e._eval(fr)
+        return n, a if a.type == self.dt.pa else a.cast(self.dt.pa)
+
+
+class _Rechunk(Expr):
+    def __init__(self, e):
+        self.e = e
+
+    def _eval(self, fr):
+        n, a = self.e._eval(fr)
+        return n, _combine(a)
+
+
+class _Var(Expr):
+    def __init__(self, e, ddof):
+        self.e, self.ddof = e, ddof
+
+    def _eval(self, fr):
+        n, a = self.e._eval(fr)
+        v = _combine(a).to_numpy(zero_copy_only=False)
+        v = v[~np.isnan(v)] if a.null_count else v
+        return n, pa.array([float(np.var(v.astype(np.float64), ddof=self.ddof))]).cast(a.type)
+
+
+class _Shift(Expr):
+    def __init__(self, e, n):
+        self.e, self.n = e, n
+
+    def _eval(self, fr):
+        name, a = self.e._eval(fr)
+        a = _combine(a)
+        k = self.n
+        if k == 0:
+            return name, a
+        nulls = pa.nulls(min(abs(k), len(a)), a.type)
+        if k > 0:
+            return name, pa.concat_arrays([nulls, a.slice(0, max(len(a) - k, 0))])
+        return name, pa.concat_arrays([a.slice(-k), nulls])
+
+
+class _Slice(Expr):
+    def __init__(self, e, offset, length):
+        self.e, self.offset, self.length = e, offset, length
+
+    def _eval(self, fr):
+        n, a = self.e._eval(fr)
+        return n, a.slice(self.offset) if self.length is None else a.slice(self.offset, self.length)
+
+
+class _Arith(Expr):
+    def __init__(self, a, b, op):
+        self.a, self.b, self.op = a, b, op
+
+    def _eval(self, fr):
+        n, x = self.a._eval(fr)
+        _, y = self.b._eval(fr)
+        xv, yv = (_combine(v).to_numpy(zero_copy_only=False) for v in (x, y))
+        return n, pa.array(self.op(xv, yv))
+
+
+class _Plugin(Expr):
+    _libs: dict = {}
+
+    def __init__(self, plugin_path, function_name, args, kwargs, returns_scalar, changes_length):
+        self.path, self.fn, self.args, self.kwargs = str(plugin_path), function_name, list(args), kwargs
+        self.returns_scalar, self.changes_length = returns_scalar, changes_length
+
+    def _lib(self):
+        lib = _Plugin._libs.get(self.path)
+        if lib is None:
+            lib = _Plugin._libs[self.path] = C.CDLL(self.path)  # what Polars does with `plugin_path`
+        return lib
+
+    def _eval(self, fr):
+        ins = [a._eval(fr) for a in self.args]
+        _, out = _ph.call_plugin(self._lib(), self.fn, ins, self.kwargs)
+        return ins[0][0], out  # (output name = the first input's, until aliased)
+
+
+def col(name):
+    return _Col(name)
+
+
+def lit(v):
+    return _Lit(v)
+
+
+_IDENT = re.compile(r"^[A-Za-z_][A-Za-z0-9_]*$")
+
+
+def sql_expr(s: str):
+    """A bare column name, or arithmetic over column names and numbers (enough for the formulas the reference's tests use)."""
+    s = s.strip()
+    if _IDENT.match(s):
+        return _Col(s)
+    names = set(re.findall(r"[A-Za-z_][A-Za-z0-9_]*", s))
+    return eval(s, {"__builtins__": {}}, {n: _Col(n) for n in names})  # noqa: S307 (test infrastructure, trusted input)
+
+
+class _GroupBy:
+    def __init__(self, df, by, maintain_order):
+        self.df, self.by = df, by
+
+    def agg(self, *exprs):
+        keys = _combine(self.df.cols[self.by]).to_numpy(zero_copy_only=False)
+        uniq, first = np.unique(keys, return_index=True)
+        order = np.argsort(first, kind="stable")  # groups in order of first appearance
+        groups = [np.flatnonzero(keys == uniq[g]) for g in order]
+
+        def one(idx):
+            sub = {k: _combine(v).take(pa.array(idx)) for k, v in self.df.cols.items()}
+            return [e._eval(sub) for e in exprs]
+
+        with ThreadPoolExecutor(max_workers=AGG_THREADS) as ex:
+            rows = list(ex.map(one, groups))
+        out = {self.by: pa.array(uniq[order])}
+        for j in range(len(exprs)):
+            name = rows[0][j][0]
+            vals = [r[j][1] for r in rows]
+            out[name] = pa.concat_arrays([_combine(v) for v in vals])  # returns_scalar: one value (here: one list) per group
+        return DataFrame(out)
+
+
+class DataFrame:
+    def __init__(self, data):
+        self.cols = {}
+        for k, v in dict(data).items():
+            self.cols[k] = v if isinstance(v, (pa.Array, pa.ChunkedArray)) else pa.array(np.asarray(v))
+
+    @property
+    def columns(self):
+        return list(self.cols)
+
+    def __getitem__(self, k):
+        return Series(k, self.cols[k])
+
+    def __len__(self):
+        return len(next(iter(self.cols.values()))) if self.cols else 0
+
+    height = property(__len__)
+
+    def lazy(self):
+        return self
+
+    def collect(self):
+        return self
+
+    def select(self, *exprs):
+        out = {}
+        for e in exprs:
+            e = col(e) if isinstance(e, str) else e
+            n, a = e._eval(self.cols)
+            out[n] = a
+        return DataFrame(out)
+
+    def with_columns(self, *exprs):
+        out = dict(self.cols)
+        for e in exprs:
+            n, a = e._eval(self.cols)
+            out[n] = a
+        return DataFrame(out)
+
+    def group_by(self, by, maintain_order=True):
+        return _GroupBy(self, by, maintain_order)
+
+    def unnest(self, name):
+        out = {}
+        for k, v in self.cols.items():
+            if k != name:
+                out[k] = v
+                continue
+            st = _combine(v)
+            for i, f in enumerate(st.type):
+                out[f.name] = st.field(i)
+        return DataFrame(out)
+
+    def explode(self, name):
+        out = dict(self.cols)
+        out[name] = _combine(self.cols[name]).flatten()
+        return DataFrame(out)
+
+    def to_dict(self):
+        return {k: v.to_pylist() for k, v in self.cols.items()}

@@ -55,6 +55,15 @@ def frel(a, b, floor):
     return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor)))
 
 
+def hold_f32(name, gpu, o32, truth, d=None, slack=1.25):
+    """The f32 contract (tests/test_f32_contract.py): within 1e-4 of the f64 truth, or -- where the reference's own all-f32
+    arithmetic is further than that from the truth -- no further than the reference's f32 path is."""
+    d = d or nrel
+    dg, do = d(gpu, truth), d(o32, truth)
+    print(f"{name}: gpu-truth {dg:.2e}  orc32-truth {do:.2e}  gpu-orc32 {d(gpu, o32):.2e}")
+    assert dg <= F32_TOL or (do > F32_TOL and dg <= do * slack), f"{name}: gpu-truth {dg:.2e}, orc32-truth {do:.2e}"
+
+
 def make_xy(rng, n, p, noise=0.01, zero_coefs=()):
     X = rng.random((n, p))
     beta = np.array([(-1.0) ** j * (0.05 + 0.03 * j) for j in range(p)])
@@ -242,6 +251,49 @@ def test_report_and_pred_shapes(pds, orc, p):
             bo = orc.pl_lr(X, y, add_bias=bias)
             po = Xb @ bo
             assert nrel(pred.cpu().numpy(), po) < F64_TOL and nrel(resid.cpu().numpy(), y - po) < 1e-8
+
+
+def test_host_frames_in_row_chunks(pds, orc):
+    """PDS_HOST frames of more than one chunk go through a chunk-sized staging buffer (capi.hip, moments_from_host_chunked /
+    pred_from_host_chunked): same answers as the whole-frame path, O(chunk) HBM.  The chunk is shrunk to 1024 rows here."""
+    from polars_ds_extension_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(77)
+    n, p = 30_001, 5
+    X, y, _ = make_xy(rng, n, p, noise=0.05)
+    y = y + 0.2
+    w = rng.random(n) + 0.1
+    hc = [np.ascontiguousarray(X[:, j]) for j in range(p)]
+    whole = pds.lin_reg(*hc, target=y, add_bias=True)
+    whole_m = pds.gram_moments(*hc, target=y)
+    stage_before = pds.default_context()
+    try:
+        lib.pds_set_host_staging(0.05, 0.0)  # 30 chunks of 1024 rows
+        b = pds.lin_reg(*hc, target=y, add_bias=True)
+        assert nrel(b, orc.pl_lr(X, y, add_bias=True)) < F64_TOL and nrel(b, whole) < 1e-12
+        assert np.array_equal(b, pds.lin_reg(*hc, target=y, add_bias=True))  # chunk records summed in a fixed order
+        assert nrel(pds.gram_moments(*hc, target=y), whole_m) < 1e-13
+        bw = pds.lin_reg(*hc, target=y, add_bias=True, weights=w)
+        assert nrel(bw, orc.pl_lr(X, y, add_bias=True, weights=w)) < F64_TOL
+        bl = pds.lin_reg(*hc, target=y, l1_reg=0.01, tol=1e-9, max_iter=2000)
+        assert nrel(bl, orc.pl_lr(X, y, l1_reg=0.01, tol=1e-9, max_iter=2000)) < 1e-8
+        # pred: resident (one PCIe trip) while the frame is under the limit, two chunked trips above it
+        pr1, rs1 = pds.lin_reg(*hc, target=y, add_bias=True, return_pred=True)
+        lib.pds_set_host_staging(0.05, 0.01)
+        pr2, rs2 = pds.lin_reg(*hc, target=y, add_bias=True, return_pred=True)
+        po = np.c_[X, np.ones(n)] @ orc.pl_lr(X, y, add_bias=True)
+        for pr, rs in ((pr1, rs1), (pr2, rs2)):
+            assert nrel(np.asarray(pr), po) < F64_TOL and nrel(np.asarray(rs), y - po) < 1e-8
+        # f32 twin: chunk records stay in f64 until they are summed
+        pds.config.LIN_REG_EXPR_F64 = False
+        X32, y32 = X.astype(np.float32), y.astype(np.float32)
+        b32 = pds.lin_reg(*[np.ascontiguousarray(X32[:, j]) for j in range(p)], target=y32, add_bias=True)
+        assert b32.dtype == np.float32 and nrel(b32, orc.pl_lr(X32.astype(np.float64), y32.astype(np.float64), add_bias=True)) < F32_TOL
+    finally:
+        pds.config.LIN_REG_EXPR_F64 = True
+        lib.pds_set_host_staging(256.0, 98304.0)
+    assert stage_before is pds.default_context()
 
 
 def test_wls_report(pds, orc):
@@ -713,7 +765,7 @@ def test_new_paths_f32(pds, orc, f32):
     Xb = np.c_[X.astype(np.float64), np.ones(n)]
     for i in (w - 1, 1500, n - 1):
         direct = np.linalg.lstsq(Xb[i - w + 1 : i + 1], y[i - w + 1 : i + 1].astype(np.float64), rcond=None)[0]
-        assert nrel(co[i], direct) < 5e-3  # f32 normal equations of a 21-column window
+        assert nrel(co[i], direct) < F32_TOL  # (measured 4e-6: tools/f32_distances.py)
     # keyed grouping, shuffled rows
     G, per, q = 300, 60, 4
     key = np.repeat(np.arange(G) * 7 - 100, per)
@@ -725,22 +777,22 @@ def test_new_paths_f32(pds, orc, f32):
     cg = cg.cpu().numpy()
     for g in (0, 123, G - 1):
         m = key == g * 7 - 100
-        assert nrel(cg[g], np.linalg.lstsq(Xg[m].astype(np.float64), yg[m].astype(np.float64), rcond=None)[0]) < F32_TOL * 10
+        assert nrel(cg[g], np.linalg.lstsq(Xg[m].astype(np.float64), yg[m].astype(np.float64), rcond=None)[0]) < F32_TOL
     # grouped lasso
     off = np.arange(0, G * per + 1, per)
     cl, _ = pds.lin_reg_by(*cols_of(Xg), target=dev(yg), group_offsets=off, l1_reg=0.01, tol=1e-7)
     bo = orc.pl_lr(Xg[:per].astype(np.float64), yg[:per].astype(np.float64), l1_reg=0.01, tol=1e-10, max_iter=2000)
-    assert nrel(cl.cpu().numpy()[0], bo) < 1e-3
+    assert nrel(cl.cpu().numpy()[0], bo) < F32_TOL
     # grouped with more than 64 features, HC3 with more than 16
     pw = 70
     Xw = rng.normal(size=(900, pw)).astype(np.float32)
     yw = (Xw @ rng.normal(size=pw) + 0.1 * rng.normal(size=900)).astype(np.float32)
     cw, nw = pds.lin_reg_by(*cols_of(Xw), target=dev(yw), group_offsets=np.array([0, 400, 900]))
     assert not nw.cpu().numpy().any()
-    assert nrel(cw.cpu().numpy()[1], np.linalg.lstsq(Xw[400:].astype(np.float64), yw[400:].astype(np.float64), rcond=None)[0]) < 1e-3
+    assert nrel(cw.cpu().numpy()[1], np.linalg.lstsq(Xw[400:].astype(np.float64), yw[400:].astype(np.float64), rcond=None)[0]) < F32_TOL
     r = pds.lin_reg_report(*cols_of(Xw[:, :20]), target=dev(yw), std_err="hc3")
     ro = orc.lin_reg_report(Xw[:, :20].astype(np.float64), yw.astype(np.float64), std_err="hc3")
-    assert frel(r["hc3_se"], ro["std_err"], 1e-9) < 2e-3
+    assert frel(r["hc3_se"], ro["std_err"], 1e-9) < F32_TOL
 
 
 # ------------------------------------------------------------------------------------------ f32 twin
@@ -754,16 +806,16 @@ def test_f32_path(pds, orc, f32):
     bo = orc.pl_lr(X32, y32, add_bias=True, singular_x_tol=1e-6)  # the reference's all-f32 arithmetic
     assert nrel(b, truth) <= nrel(bo, truth) * 1.5 + 1e-6  # never worse than the f32 reference vs the f64 truth
     b = pds.lin_reg(*cols_of(X32), target=dev(y32), l1_reg=0.001, l2_reg=0.001, tol=1e-7)
-    assert nrel(b, orc.pl_lr(X32.astype(np.float64), y32.astype(np.float64), l1_reg=0.001, l2_reg=0.001, tol=1e-9, max_iter=2000)) < 1e-3
+    assert nrel(b, orc.pl_lr(X32.astype(np.float64), y32.astype(np.float64), l1_reg=0.001, l2_reg=0.001, tol=1e-9, max_iter=2000)) < F32_TOL
     r = pds.lin_reg_report(*cols_of(X32), target=dev(y32), add_bias=True)
     ro = orc.lin_reg_report(np.c_[X32.astype(np.float64), np.ones(len(y))], y32.astype(np.float64))
-    assert frel(r["std_err"], ro["std_err"], 1e-9) < 1e-3
+    assert frel(r["std_err"], ro["std_err"], 1e-9) < F32_TOL
     co, nu = pds.lin_reg_by(*cols_of(X32), target=dev(y32), group_offsets=np.arange(0, 400_001, 1000), add_bias=False)
     co_o, _ = orc.grouped_lr([y32.astype(np.float64)] + [X32[:, j].astype(np.float64) for j in range(8)], np.arange(0, 400_001, 1000))
-    assert np.max(np.linalg.norm(co.cpu().numpy() - co_o, axis=1) / np.linalg.norm(co_o, axis=1)) < 1e-3
+    assert np.max(np.linalg.norm(co.cpu().numpy() - co_o, axis=1) / np.linalg.norm(co_o, axis=1)) < F32_TOL
     co, pr, va = pds.rolling_lin_reg(*cols_of(X32[:50_000, :3]), target=dev(y32[:50_000]), window_size=64)
     ref = orc.rolling_lr(X32[:50_000, :3].astype(np.float64), y32[:50_000].astype(np.float64), 64)
-    assert np.max(np.linalg.norm(co.cpu().numpy()[63:] - ref, axis=1) / np.linalg.norm(ref, axis=1)) < 1e-3
+    assert np.max(np.linalg.norm(co.cpu().numpy()[63:] - ref, axis=1) / np.linalg.norm(ref, axis=1)) < F32_TOL
 
 
 @pytest.mark.parametrize("p,bias", [(17, True), (30, False), (31, True), (47, True), (63, True), (64, False)])
@@ -955,8 +1007,10 @@ def test_config5_elastic_net_f32_wide(pds, orc, f32):
     Z = np.c_[X.astype(np.float64), np.ones(n), y.astype(np.float64)]
     assert nrel(M, Z.T @ Z) < 3e-7
     b = pds.lin_reg(*cols_of(X), target=dev(y), l1_reg=0.01, l2_reg=0.01, tol=1e-5)
-    truth = orc.pl_lr(X.astype(np.float64), y.astype(np.float64), l1_reg=0.01, l2_reg=0.01, tol=1e-7, max_iter=2000)
-    assert b.dtype == np.float32 and nrel(b, truth) < 1e-3
+    truth = orc.pl_lr(X.astype(np.float64), y.astype(np.float64), l1_reg=0.01, l2_reg=0.01, tol=1e-9, max_iter=2000)
+    o32 = orc.pl_lr(X, y, l1_reg=0.01, l2_reg=0.01, tol=1e-5, max_iter=2000)  # the reference's all-f32 sweeps, same stopping rule
+    assert b.dtype == np.float32
+    hold_f32("config 5 at 6e4 x 512", b, o32, truth)  # (the configured 1e7 / 1e6 rows: tests/test_baseline_sizes.py)
     assert np.sum(np.abs(b) > 1e-6) < 200  # sparse solution
 
 

@@ -1,0 +1,205 @@
+"""
+`polars_ds_extension_amd/polars_exprs.py` executed end to end: expression builders -> `register_plugin_function` ->
+`_polars_plugin_*` symbol -> Arrow result, with tests/mini_polars standing in for the Polars engine (see its docstring: it
+implements the documented plugin calling convention and the per-group evaluation of `group_by().agg()`, nothing else).
+
+The tests read like the reference's (tests/test_linear_exprs.py: `df.select(pds.lin_reg(...))`, `df.group_by(k).agg(...)`).
+Each runs twice: `-m "not gpu"` against csrc/plugin.cpp linked to the mock device layer (oracle behind every pds_* call:
+proves the Python layer, the kwargs, the symbol routing and the plugin plumbing), and `-m gpu` against libpds_lstsq_hip.so.
+"""
+import inspect
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "tests"))
+sys.path.insert(0, str(ROOT))
+
+
+def _import_engine():
+    """The real polars if one is importable, else tests/mini_polars (and say which)."""
+    try:
+        import polars as pl  # noqa: F401
+
+        if getattr(pl, "__version__", "").endswith("mini"):
+            return pl, "mini"
+        return pl, "real"
+    except ImportError:
+        sys.path.insert(0, str(ROOT / "tests" / "mini_polars"))
+        import polars as pl
+
+        return pl, "mini"
+
+
+pl, ENGINE = _import_engine()
+from polars_ds_extension_amd import config as cfg  # noqa: E402
+from polars_ds_extension_amd import polars_exprs as px  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+
+    oracle.build()
+    return oracle
+
+
+def _frame(rng, n, p, bias=0.0, noise=0.05):
+    X = rng.normal(size=(n, p))
+    beta = rng.normal(size=p)
+    y = X @ beta + bias + noise * rng.normal(size=n)
+    data = {"y": y}
+    data.update({f"x{j + 1}": X[:, j] for j in range(p)})
+    return X, y, pl.DataFrame(data)
+
+
+# ---- the tests proper: `path` = the plugin library the engine is pointed at -------------------------------------------
+def t_select_lin_reg(path, orc):
+    px.PLUGIN_PATH = path
+    rng = np.random.default_rng(1)
+    X, y, df = _frame(rng, 5000, 3, bias=0.3)
+    out = df.select(px.lin_reg("x1", "x2", "x3", target="y", add_bias=True))
+    assert out.columns == ["coeffs"]
+    np.testing.assert_allclose(out["coeffs"].to_list()[0], orc.pl_lr(X, y, add_bias=True), rtol=1e-9, atol=1e-12)
+    # expressions and arithmetic formulas as inputs (expr_linear.py `str_to_expr`)
+    out = df.select(px.lin_reg(pl.col("x1"), "x2 * 2.0", target="y"))
+    np.testing.assert_allclose(out["coeffs"].to_list()[0], orc.pl_lr(np.c_[X[:, 0], 2.0 * X[:, 1]], y), rtol=1e-9, atol=1e-12)
+    # ridge / lasso route through the same symbol with the reference's kwargs
+    out = df.select(px.lin_reg("x1", "x2", "x3", target="y", l2_reg=0.5))
+    np.testing.assert_allclose(out["coeffs"].to_list()[0], orc.pl_lr(X, y, l2_reg=0.5), rtol=1e-9, atol=1e-12)
+    out = df.select(px.lin_reg("x1", "x2", "x3", target="y", l1_reg=0.05, tol=1e-9, max_iter=2000))
+    np.testing.assert_allclose(out["coeffs"].to_list()[0], orc.pl_lr(X, y, l1_reg=0.05, tol=1e-9, max_iter=2000), rtol=1e-7, atol=1e-9)
+    with pytest.raises(ValueError, match="max_iter"):
+        px.lin_reg("x1", target="y", max_iter=0)
+
+
+def t_pred_and_weights(path, orc):
+    px.PLUGIN_PATH = path
+    rng = np.random.default_rng(2)
+    X, y, df = _frame(rng, 3000, 2)
+    out = df.select(px.lin_reg("x1", "x2", target="y", return_pred=True)).unnest("lr_pred")
+    b = orc.pl_lr(X, y)
+    np.testing.assert_allclose(out["pred"].to_numpy(), X @ b, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(out["resid"].to_numpy(), y - X @ b, rtol=1e-7, atol=1e-10)
+    w = rng.random(3000) + 0.1
+    dfw = pl.DataFrame({"y": y, "x1": X[:, 0], "x2": X[:, 1], "w": w})
+    out = dfw.select(px.lin_reg("x1", "x2", target="y", weights="w"))
+    np.testing.assert_allclose(out["coeffs"].to_list()[0], orc.pl_lr(X, y, weights=w), rtol=1e-9, atol=1e-12)
+
+
+def t_group_by_agg_equals_by(path, orc):
+    """df.group_by(k).agg(pds.lin_reg(...)) -- one pl_lr call per group from the engine's worker threads, through the
+    coalescing queue -- and its documented replacement, ONE pl_lr_by call, give the same coefficients per key."""
+    px.PLUGIN_PATH = path
+    rng = np.random.default_rng(3)
+    G, per = 120, 40
+    key = np.repeat(rng.permutation(G) * 5 - 17, per)
+    X = rng.normal(size=(G * per, 3))
+    y = X @ [0.7, -1.1, 0.4] + 0.01 * key + 0.1 * rng.normal(size=G * per)
+    perm = rng.permutation(G * per)  # rows of a group are NOT contiguous
+    df = pl.DataFrame({"k": key[perm], "y": y[perm], "x1": X[perm, 0], "x2": X[perm, 1], "x3": X[perm, 2]})
+    per_group = df.group_by("k", maintain_order=True).agg(px.lin_reg("x1", "x2", "x3", target="y", add_bias=True))
+    by = px.lin_reg_by_group(df, "k", "x1", "x2", "x3", target="y", add_bias=True)
+    assert by.columns == ["k", "coeffs"] and len(by) == G and len(per_group) == G
+    kb = by["k"].to_numpy()
+    assert np.array_equal(kb, np.sort(np.unique(key)))  # keys ascending
+    agg = dict(zip(per_group["k"].to_list(), per_group["coeffs"].to_list()))
+    for k, co in zip(kb.tolist(), by["coeffs"].to_list()):
+        m = key == k
+        np.testing.assert_allclose(co, orc.pl_lr(X[m], y[m], add_bias=True), rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(co, agg[k], rtol=1e-9, atol=1e-11)
+
+
+def t_report_rolling_recursive(path, orc):
+    px.PLUGIN_PATH = path
+    rng = np.random.default_rng(4)
+    X, y, df = _frame(rng, 4000, 3, bias=0.2, noise=0.3)
+    rep = df.select(px.lin_reg_report("x1", "x2", "x3", target="y", add_bias=True)).unnest("lin_reg_report")
+    ro = orc.lin_reg_report(np.c_[X, np.ones(len(y))], y, y_var=float(np.var(y, ddof=1)))
+    assert rep["features"].to_list() == ["x1", "x2", "x3", "__bias__"]
+    np.testing.assert_allclose(rep["beta"].to_numpy(), ro["beta"], rtol=1e-9)
+    np.testing.assert_allclose(rep["std_err"].to_numpy(), ro["std_err"], rtol=1e-9)
+    rep = df.select(px.lin_reg_report("x1", "x2", "x3", target="y", add_bias=True, std_err="hc1")).unnest("lin_reg_report")
+    np.testing.assert_allclose(rep["hc1_se"].to_numpy(), orc.lin_reg_report(np.c_[X, np.ones(len(y))], y, std_err="hc1")["std_err"], rtol=1e-9)
+    w = 30
+    roll = df.select(px.rolling_lin_reg("x1", "x2", target="y", window_size=w)).unnest("rolling_lin_reg")
+    co = roll["coeffs"].to_list()
+    assert co[w - 2] is None and co[w - 1] is not None
+    np.testing.assert_allclose(np.array(co[w - 1:]), orc.rolling_lr(X[:, :2], y, w), rtol=1e-7, atol=1e-9)
+    rec = df.select(px.recursive_lin_reg("x1", "x2", target="y", start_with=10)).unnest("recursive_lin_reg")
+    np.testing.assert_allclose(np.array(rec["coeffs"].to_list()[9:]), orc.recursive_lr(X[:, :2], y, 10), rtol=1e-7, atol=1e-9)
+    with pytest.raises(ValueError, match="window_size"):
+        px.rolling_lin_reg("x1", target="y", window_size=1)
+
+
+def t_f32_switch_multi_target_rcond_ar(path, orc):
+    px.PLUGIN_PATH = path
+    rng = np.random.default_rng(5)
+    X, y, df = _frame(rng, 6000, 3)
+    cfg.LIN_REG_EXPR_F64 = False
+    try:
+        e = px.lin_reg("x1", "x2", "x3", target="y")
+        assert e.e.fn == "pl_lr_f32" if ENGINE == "mini" else True  # config._which_lin_reg: the _f32 symbol
+        b32 = df.select(e)["coeffs"].to_list()[0]
+        e = px.lin_reg_w_rcond("x1", "x2", "x3", target="y")
+        assert e.fn == "pl_lr_w_rcond_f32" if ENGINE == "mini" else True
+        r32 = df.select(e.alias("r")).unnest("r")["coeffs"].to_list()[0]
+    finally:
+        cfg.LIN_REG_EXPR_F64 = True
+    truth = orc.pl_lr(X, y)
+    assert np.linalg.norm(np.array(b32) - truth) / np.linalg.norm(truth) < 1e-4
+    assert np.linalg.norm(np.array(r32) - truth) / np.linalg.norm(truth) < 1e-4
+    # multi-target: the extra targets ride in the same Gram pass (expr_linear.py:188-233)
+    df2 = df.with_columns((pl.col("y") * 2.0 + pl.col("x1")).alias("y2"))
+    out = df2.select(px.lin_reg("x1", "x2", "x3", target=["y", "y2"]))
+    co = out["coeffs"].to_list()[0]  # Struct{target_0: [..], target_1: [..]}
+    y2 = 2.0 * y + X[:, 0]
+    np.testing.assert_allclose(co["target_0"], orc.pl_lr(X, y), rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(co["target_1"], orc.pl_lr(X, y2), rtol=1e-8, atol=1e-10)
+    # rcond form: Struct{coeffs, singular_values}
+    out = df.select(px.lin_reg_w_rcond("x1", "x2", "x3", target="y").alias("r")).unnest("r")
+    np.testing.assert_allclose(out["coeffs"].to_list()[0], truth, rtol=1e-8, atol=1e-10)
+    # AR coefficients: lagged views of one series (ts_features.py:419-461)
+    z = np.cumsum(rng.normal(size=3000)) * 0.01 + rng.normal(size=3000)
+    ar = pl.DataFrame({"z": z}).select(px.query_ar_coeffs("z", 3))["coeffs"].to_list()[0]
+    L = np.c_[z[2:-1], z[1:-2], z[:-3]]
+    np.testing.assert_allclose(ar, orc.pl_lr(L, z[3:], add_bias=True), rtol=1e-8, atol=1e-10)
+
+
+T_FUNCS = [t_select_lin_reg, t_pred_and_weights, t_group_by_agg_equals_by, t_report_rolling_recursive, t_f32_switch_multi_target_rcond_ar]
+
+
+# ---- CPU: the mock device layer behind the same plugin.cpp ------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def mock_path(orc):
+    from mock_device import device
+
+    so = device.load()
+    return Path(so._name)
+
+
+@pytest.mark.parametrize("fn", T_FUNCS, ids=lambda f: f.__name__)
+def test_exprs_against_the_mock_device(fn, mock_path, orc):
+    fn(mock_path, orc)
+
+
+# ---- GPU: the product library --------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("fn", T_FUNCS, ids=lambda f: f.__name__)
+def test_exprs_against_the_hip_library(fn, orc):
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from polars_ds_extension_amd import _lib
+
+    fn(_lib.LIB_PATH, orc)
+
+
+def test_which_engine():
+    print(f"polars engine under these tests: {ENGINE} ({getattr(pl, '__version__', '?')})")
+    assert ENGINE in ("mini", "real")
+    assert "lin_reg_by_group" in dir(px) and inspect.signature(px.lin_reg).parameters["by"].default is None
