@@ -78,6 +78,15 @@ int pds_ctx_num_cus(const pds_ctx* ctx);
  * frames make two chunked trips; default 98304, env PDS_HOST_RESIDENT_MAX_MB).  A value <= 0 leaves the setting as is.
  * Replaces the reference's one-Vec marshalling copy, src/utils/mod.rs:101-206. */
 int pds_set_host_staging(double chunk_mb, double resident_max_mb);
+
+/* Row-major matrix -> the contiguous column buffers every entry point takes (the pyclass route: the NumPy X of LR /
+ * ElasticNet / OnlineLR, which the reference reads through a strided faer MatRef, src/pymodels/numpy_faer.rs:10-66).
+ * X: n_rows x n_cols values with row stride ld (elements), resident in `space`.  out_cols: DEVICE buffer; column c is
+ * written to out_cols + c * col_stride (col_stride >= n_rows).  Host matrices cross PCIe as contiguous row chunks. */
+int pds_rows_to_cols_f64(pds_ctx* ctx, const double* X, int64_t ld, int64_t n_rows, int n_cols, pds_space space, double* out_cols,
+                         int64_t col_stride);
+int pds_rows_to_cols_f32(pds_ctx* ctx, const float* X, int64_t ld, int64_t n_rows, int n_cols, pds_space space, float* out_cols,
+                         int64_t col_stride);
 /* Diagnostics: how many call-local workspace slices had to be allocated outside the per-call reservation since the context
  * was created (0 unless an entry point under-estimated its bound; the slices are still valid, never out of bounds). */
 long long pds_ctx_workspace_spills(const pds_ctx* ctx);

@@ -264,6 +264,38 @@ static int pred_from_host_chunked(pds_ctx* ctx, const T* const* cols, int n_feat
 }
 
 // ---------------------------------------------------------------------------------------------
+// Row-major matrices (the pyclass route: NumPy X of LR / ElasticNet / OnlineLR, numpy_faer.rs:10-66) -> column buffers in HBM
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+static int rows_to_cols_impl(pds_ctx* ctx, const T* X, int64_t ld, int64_t n_rows, int n_cols, pds_space space, T* out_cols,
+                             int64_t col_stride) {
+    if (!ctx || !X || !out_cols) return fail(PDS_ERR_INVALID, "null argument");
+    if (n_rows <= 0 || n_cols <= 0) return fail(PDS_ERR_EMPTY, "Empty data");
+    if (ld < n_cols || col_stride < n_rows) return fail(PDS_ERR_INVALID, "row stride < columns or column stride < rows");
+    PDS_HIP_CHECK(hipSetDevice(ctx->device));
+    if (space == PDS_DEVICE) {
+        if (int rc = launch_rows_to_cols<T>(ctx, X, ld, n_rows, n_cols, out_cols, col_stride, 0)) return rc;
+        PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        return PDS_OK;
+    }
+    // host matrix: contiguous row chunks through one staging buffer (one copy per chunk; the kernel behind it is ~100x faster
+    // than the link, so the single stream loses nothing)
+    int64_t rows_per = (int64_t)(host_chunk_bytes() / ((size_t)ld * sizeof(T)));
+    rows_per = std::min<int64_t>(std::max<int64_t>(rows_per & ~(int64_t)63, 64), n_rows);
+    if (int rc = ensure_ws(ctx, ctx->stage, (size_t)rows_per * ld * sizeof(T) + 256)) return rc;
+    T* d_stage = reinterpret_cast<T*>(ctx->stage.ptr);
+    for (int64_t r0 = 0; r0 < n_rows; r0 += rows_per) {
+        const int64_t rows = std::min(rows_per, n_rows - r0);
+        // (the last row may be shorter than ld in the caller's allocation: copy rows - 1 full strides + n_cols values)
+        const size_t bytes = ((size_t)(rows - 1) * ld + n_cols) * sizeof(T);
+        PDS_HIP_CHECK(hipMemcpyAsync(d_stage, X + r0 * ld, bytes, hipMemcpyHostToDevice, ctx->stream));
+        if (int rc = launch_rows_to_cols<T>(ctx, d_stage, ld, rows, n_cols, out_cols, col_stride, r0)) return rc;
+    }
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PDS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // host-side p' x p' SVD solve (solver = "svd", rcond path): one-sided Jacobi on the Gram matrix.
 // O(p'^3) on a 2 KB matrix -- not worth a kernel; only reached for single systems.
 // ---------------------------------------------------------------------------------------------
@@ -1376,7 +1408,7 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
     const size_t temp_bytes = keyed_temp_bytes(n_rows);
     size_t need = temp_bytes + 3 * up((size_t)(n_rows + 1) * 8) + 4096;  // unique keys, counts, offsets (at most one per row)
     if (space == PDS_HOST) need += col_bytes * nc + up((size_t)cap * pp * sizeof(T)) + up((size_t)cap);
-    if (!sorted) need += 2 * key_bytes + 2 * idx_bytes + col_bytes * nc + 256;
+    if (!sorted) need += 2 * key_bytes + 2 * idx_bytes + col_bytes * nc + up((size_t)n_rows * nc * sizeof(T)) + up(2 * (size_t)nc * sizeof(T*)) + 1024;
     if (int rc = ensure_ws(ctx, ctx->keyed, need)) return rc;
     char* w = static_cast<char*>(ctx->keyed.ptr);
     auto take = [&](size_t b) { char* r = w; w += up(b); return r; };
@@ -1402,10 +1434,28 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
         int64_t* mm = reinterpret_cast<int64_t*>(take(256));
         if (int rc = keyed_sort(ctx, d_keys, n_rows, idx_in, sk, perm, d_temp, temp_bytes, sk2, mm)) return rc;
         d_sorted_keys = sk;
-        for (int c = 0; c < nc; ++c) {
-            T* d = reinterpret_cast<T*>(take((size_t)n_rows * sizeof(T)));
-            if (int rc = launch_gather_rows<T>(ctx, src[c], perm, n_rows, d)) return rc;
-            src[c] = d;
+        static const bool by_column = [] { const char* e = std::getenv("PDS_KEYED_GATHER_BY_COLUMN"); return e && e[0] == '1'; }();
+        if (by_column) {  // (A/B: one random 8-byte read per element)
+            for (int c = 0; c < nc; ++c) {
+                T* d = reinterpret_cast<T*>(take((size_t)n_rows * sizeof(T)));
+                if (int rc = launch_gather_rows<T>(ctx, src[c], perm, n_rows, d)) return rc;
+                src[c] = d;
+            }
+        } else {
+            // transpose to row-major records, then one random access per ROW (keyed.hip)
+            std::vector<const T*> tbl(2 * (size_t)nc);
+            for (int c = 0; c < nc; ++c) tbl[c] = src[c];
+            for (int c = 0; c < nc; ++c) {
+                T* d = reinterpret_cast<T*>(take((size_t)n_rows * sizeof(T)));
+                tbl[nc + c] = d;
+                src[c] = d;
+            }
+            T* records = reinterpret_cast<T*>(take((size_t)n_rows * nc * sizeof(T)));
+            const T** d_tbl = reinterpret_cast<const T**>(take(2 * (size_t)nc * sizeof(T*)));
+            PDS_HIP_CHECK(hipMemcpyAsync(d_tbl, tbl.data(), 2 * (size_t)nc * sizeof(T*), hipMemcpyHostToDevice, ctx->stream));
+            if (int rc = launch_gather_frame<T>(ctx, d_tbl, perm, nc, n_rows, records, (T* const*)(d_tbl + nc)))
+                return rc;
+            PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // (tbl: source of the table copy)
         }
     }
     int64_t ng = 0;
@@ -1558,6 +1608,15 @@ int pds_ctx_synchronize(pds_ctx* ctx) {
 }
 
 int pds_ctx_num_cus(const pds_ctx* ctx) { return ctx ? ctx->num_cus : 0; }
+
+int pds_rows_to_cols_f64(pds_ctx* ctx, const double* X, int64_t ld, int64_t n_rows, int n_cols, pds_space space, double* out_cols,
+                         int64_t col_stride) {
+    return pds::rows_to_cols_impl<double>(ctx, X, ld, n_rows, n_cols, space, out_cols, col_stride);
+}
+int pds_rows_to_cols_f32(pds_ctx* ctx, const float* X, int64_t ld, int64_t n_rows, int n_cols, pds_space space, float* out_cols,
+                         int64_t col_stride) {
+    return pds::rows_to_cols_impl<float>(ctx, X, ld, n_rows, n_cols, space, out_cols, col_stride);
+}
 
 int pds_set_host_staging(double chunk_mb, double resident_max_mb) {
     if (chunk_mb > 0.0) pds::g_host_chunk_mb = std::max(chunk_mb, 0.001);

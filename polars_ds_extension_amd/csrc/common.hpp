@@ -255,6 +255,12 @@ int keyed_runs(pds_ctx* ctx, const int64_t* d_sorted_keys, int64_t n, int64_t* d
                int64_t* d_nruns, void* d_temp, size_t temp_bytes, int64_t* n_groups);
 template <typename T>
 int launch_gather_rows(pds_ctx* ctx, const T* d_src, const uint32_t* d_perm, int64_t n, T* d_dst);
+// layout.hip: rows [0, n_rows) of a row-major device matrix (row stride ld) -> out[c * col_stride + out_row0 + r]
+template <typename T>
+int launch_rows_to_cols(pds_ctx* ctx, const T* d_X, int64_t ld, int64_t n_rows, int n_cols, T* d_out, int64_t col_stride, int64_t out_row0);
+// keyed.hip: the whole frame through the permutation by way of row-major records (one random access per row, not per element)
+template <typename T>
+int launch_gather_frame(pds_ctx* ctx, const T* const* d_src, const uint32_t* d_perm, int nc, int64_t n, T* d_records, T* const* d_dst);
 template <typename T>
 int launch_scale_sqrt_w(pds_ctx* ctx, const T* d_src /*nullable: ones*/, const T* d_w, int64_t n, T* d_dst);
 

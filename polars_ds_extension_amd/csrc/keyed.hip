@@ -3,11 +3,14 @@
 // tests/test_linear_exprs.py:435-474, 918-953), done on the device for the key-aware symbol `pl_lr_by`.
 //   1. one pass decides whether the keys are already non-decreasing (a frame sorted by its key needs no data movement);
 //   2. otherwise a radix sort of (key, row index) pairs (hipCUB; stable, so rows keep their order inside a group) and a
-//      gather of every column through the permutation -- the only part that moves the frame (8-byte reads at random
-//      rows: one 64-byte sector per element, a scan of the frame at 1/8 efficiency);
+//      gather of the frame through the permutation.  Gathering column by column reads one 64-byte sector per 8-byte
+//      element (19 of the 25 ms of a shuffled 1e8-row x 9-column frame, profiles/r02_keyed_kernel_stats_before.csv), so the
+//      frame is first transposed to row-major records (one streaming pass, LDS tiles) and the permutation then fetches
+//      whole ROWS: 72 contiguous bytes per random access instead of nine sectors;
 //   3. run-length encoding of the sorted keys gives the distinct keys and the group sizes, an exclusive sum the offsets.
 // Groups come out in ascending key order.
 #include <hipcub/hipcub.hpp>
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -29,6 +32,51 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ 
                                                           T* __restrict__ dst) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         dst[i] = src[perm[i]];
+}
+
+// ---- columns -> row-major records: block = 256 rows, transposed through LDS (both sides coalesced)
+constexpr int kAosRows = 256;
+template <typename T>
+__global__ __launch_bounds__(256) void cols_to_rows_kernel(const T* const* __restrict__ cols, int nc, int64_t n, T* __restrict__ rows) {
+    extern __shared__ __attribute__((aligned(16))) char aos_lds[];
+    T* tile = reinterpret_cast<T*>(aos_lds);
+    const int ncp = nc | 1;  // odd stride: conflict-free column writes
+    const int64_t nblk = (n + kAosRows - 1) / kAosRows;
+    for (int64_t b = blockIdx.x; b < nblk; b += gridDim.x) {
+        const int64_t r0 = b * kAosRows;
+        const int rows_here = (int)((n - r0 < kAosRows) ? n - r0 : kAosRows);
+        for (int c = 0; c < nc; ++c) {
+            const gptr<T> col = as_global(cols[c]);
+            if ((int)threadIdx.x < rows_here) tile[threadIdx.x * ncp + c] = __builtin_nontemporal_load(col + r0 + threadIdx.x);
+        }
+        __syncthreads();
+        T* out = rows + r0 * nc;
+        const int total = rows_here * nc;
+        for (int e = threadIdx.x; e < total; e += 256) {
+            const int r = e / nc, c = e - r * nc;
+            out[e] = tile[r * ncp + c];
+        }
+        __syncthreads();
+    }
+}
+
+// ---- dst_c[i] = rows[perm[i]][c]: one random access per ROW (nc contiguous values), writes coalesced per column
+template <typename T>
+__global__ __launch_bounds__(256) void gather_records_kernel(const T* __restrict__ rows, const uint32_t* __restrict__ perm, int nc,
+                                                             int64_t n, T* const* __restrict__ dst) {
+    constexpr int E = 16 / (int)sizeof(T);  // elements per 16-byte load (records are only element aligned)
+    using V = typename std::conditional<sizeof(T) == 8, double __attribute__((ext_vector_type(2), aligned(8))),
+                                        float __attribute__((ext_vector_type(4), aligned(4)))>::type;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const T* src = rows + (int64_t)perm[i] * nc;
+        int c = 0;
+        for (; c + E <= nc; c += E) {
+            const V v = *reinterpret_cast<const V*>(src + c);
+#pragma unroll
+            for (int e = 0; e < E; ++e) dst[c + e][i] = v[e];
+        }
+        for (; c < nc; ++c) dst[c][i] = src[c];
+    }
 }
 
 __global__ void close_offsets_kernel(int64_t* __restrict__ off, const int64_t* __restrict__ n_runs, int64_t n) {
@@ -56,6 +104,10 @@ size_t keyed_temp_bytes(int64_t n) {
     (void)hipcub::DeviceRunLengthEncode::Encode(nullptr, b, (const int64_t*)nullptr, (int64_t*)nullptr, (int64_t*)nullptr,
                                                 (int64_t*)nullptr, (int)std::min<int64_t>(n, INT32_MAX));
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, c, (const int64_t*)nullptr, (int64_t*)nullptr, (int)std::min<int64_t>(n, INT32_MAX));
+    size_t a32 = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a32, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
+                                             (uint32_t*)nullptr, (int)std::min<int64_t>(n, INT32_MAX));
+    a = std::max(a, a32);
     size_t d = 0;
     (void)hipcub::DeviceReduce::Min(nullptr, d, (const int64_t*)nullptr, (int64_t*)nullptr, (int)std::min<int64_t>(n, INT32_MAX));
     return up256(std::max(std::max(a, d), std::max(b, c))) + 256;
@@ -67,6 +119,20 @@ __global__ __launch_bounds__(256) void rebase_keys_kernel(const int64_t* __restr
     const uint64_t base = (uint64_t)*kmin;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         out[i] = (int64_t)(sign > 0 ? (uint64_t)in[i] - base : (uint64_t)in[i] + base);
+}
+
+// key ranges below 2^32 (the usual case: group ids) sort as 32-bit numbers -- 8 bytes per (key, row) pair and pass, not 12
+__global__ __launch_bounds__(256) void rebase_keys_u32_kernel(const int64_t* __restrict__ in, int64_t n, const int64_t* __restrict__ kmin,
+                                                              uint32_t* __restrict__ out) {
+    const uint64_t base = (uint64_t)*kmin;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (uint32_t)((uint64_t)in[i] - base);
+}
+__global__ __launch_bounds__(256) void widen_keys_kernel(const uint32_t* __restrict__ in, int64_t n, const int64_t* __restrict__ kmin,
+                                                         int64_t* __restrict__ out) {
+    const uint64_t base = (uint64_t)*kmin;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (int64_t)((uint64_t)in[i] + base);
 }
 
 // (key, row) radix sort: d_sorted_keys / d_perm out; d_idx_in is scratch of n uint32; d_scratch_keys n int64; d_minmax 2 int64
@@ -83,6 +149,16 @@ int keyed_sort(pds_ctx* ctx, const int64_t* d_keys, int64_t n, uint32_t* d_idx_i
     const uint64_t range = (uint64_t)mm[1] - (uint64_t)mm[0];
     int bits = 1;
     while (bits < 64 && (range >> bits) != 0) ++bits;
+    if (bits <= 32) {
+        uint32_t* k32_in = reinterpret_cast<uint32_t*>(d_scratch_keys);   // the scratch holds n int64 = 2 n uint32
+        uint32_t* k32_out = k32_in + n;
+        hipLaunchKernelGGL(rebase_keys_u32_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_keys, n, d_minmax, k32_in);
+        PDS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, (const uint32_t*)k32_in, k32_out, (const uint32_t*)d_idx_in,
+                                                         d_perm, (int)n, 0, bits, ctx->stream));
+        hipLaunchKernelGGL(widen_keys_kernel, dim3(nb), dim3(256), 0, ctx->stream, (const uint32_t*)k32_out, n, d_minmax, d_sorted_keys);
+        PDS_HIP_CHECK(hipGetLastError());
+        return PDS_OK;
+    }
     hipLaunchKernelGGL(rebase_keys_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_keys, n, d_minmax, 1, d_scratch_keys);
     // (as unsigned numbers in [0, range]: the signed sort order of int64 agrees below bit 63, and bit 63 is only
     //  walked when the range needs it, where the unsigned key type below sorts it correctly)
@@ -115,6 +191,21 @@ int launch_gather_rows(pds_ctx* ctx, const T* d_src, const uint32_t* d_perm, int
     PDS_HIP_CHECK(hipGetLastError());
     return PDS_OK;
 }
+
+// the whole frame through the permutation: d_src / d_dst are DEVICE tables of nc column pointers, d_records n * nc elements
+template <typename T>
+int launch_gather_frame(pds_ctx* ctx, const T* const* d_src, const uint32_t* d_perm, int nc, int64_t n, T* d_records, T* const* d_dst) {
+    const size_t lds = (size_t)kAosRows * (size_t)(nc | 1) * sizeof(T);
+    const int64_t nblk = (n + kAosRows - 1) / kAosRows;
+    const int nb1 = (int)std::min<int64_t>(std::max<int64_t>(nblk, 1), (int64_t)ctx->num_cus * 8);
+    hipLaunchKernelGGL((cols_to_rows_kernel<T>), dim3(nb1), dim3(256), lds, ctx->stream, d_src, nc, n, d_records);
+    const int nb2 = (int)std::min<int64_t>(std::max<int64_t>((n + 255) / 256, 1), (int64_t)ctx->num_cus * 32);
+    hipLaunchKernelGGL((gather_records_kernel<T>), dim3(nb2), dim3(256), 0, ctx->stream, (const T*)d_records, d_perm, nc, n, d_dst);
+    PDS_HIP_CHECK(hipGetLastError());
+    return PDS_OK;
+}
+template int launch_gather_frame<double>(pds_ctx*, const double* const*, const uint32_t*, int, int64_t, double*, double* const*);
+template int launch_gather_frame<float>(pds_ctx*, const float* const*, const uint32_t*, int, int64_t, float*, float* const*);
 
 // weighted groups: x_c * sqrt(w) (and sqrt(w) itself as the bias column) turn X' W X into a plain Gram matrix
 template <typename T>

@@ -3,9 +3,9 @@ Model classes over NumPy / torch data -- the mirror of the reference's pyclass r
 `LR`, `ElasticNet`, `OnlineLR` of /root/reference/python/polars_ds/linear_models.py:134-700, whose `PyLR` /
 `PyElasticNet` / `PyOnlineLR` (src/pymodels/py_lr.rs:21-224) call the same solvers as the expressions.  Same
 constructor arguments, method names and error behaviour; the fits run on the MI355X through the C ABI
-(`lstsq.py`): the feature matrix is handed over column by column (a row-major NumPy matrix is copied into
-contiguous columns first -- the reference reads it through a strided `MatRef`; a CUDA tensor is transposed on the
-device).  The O(p'^2) state arithmetic of `OnlineLR.update` (one `woodbury_step`, lr_online_solvers.rs:307-332) and
+(`lstsq.py`): the row-major feature matrix is transposed once on the device into the column buffers the kernels
+stream (`pds_rows_to_cols_*`; a NumPy matrix crosses PCIe as contiguous row chunks, a CUDA tensor stays in HBM --
+the reference reads the NumPy buffer through a strided `MatRef`, numpy_faer.rs:10-66).  The O(p'^2) state arithmetic of `OnlineLR.update` (one `woodbury_step`, lr_online_solvers.rs:307-332) and
 `predict` (one matrix-vector product) stay where the data is.
 `fit_df` / `predict_df` need polars (absent in this image) and are written against its public API.
 """
@@ -37,7 +37,40 @@ def _as_matrix(X):
 
 
 def _columns(X) -> list:
-    """The p contiguous columns of an n x p matrix."""
+    """
+    The p contiguous columns of an n x p matrix.  With a GPU the row-major matrix is transposed ONCE on the device
+    (`pds_rows_to_cols_*`, csrc/layout.hip): a NumPy matrix crosses PCIe as contiguous row chunks -- one copy, not p strided
+    host gathers -- and a row-major CUDA tensor never leaves HBM.  The reference reads the NumPy buffer through a strided
+    faer MatRef (src/pymodels/numpy_faer.rs:10-66).  Without a device (the CPU test-suite on the mock library) the columns
+    are cut on the host.
+    """
+    try:
+        import torch
+
+        have_gpu = torch.cuda.is_available()
+    except ImportError:
+        have_gpu = False
+    if have_gpu:
+        f64 = bool(config.LIN_REG_EXPR_F64)
+        tdt, ndt = (torch.float64, np.float64) if f64 else (torch.float32, np.float32)
+        n, p = int(X.shape[0]), int(X.shape[1])
+        if n > 0 and p > 0:
+            ctx = lstsq.default_context()
+            if _is_torch(X):
+                Xs = X if X.is_cuda else X.cuda()
+                Xs = Xs.to(tdt)
+                if Xs.stride(1) != 1:
+                    Xs = Xs.contiguous()
+                ptr, ld, space, dev = int(Xs.data_ptr()), int(Xs.stride(0)), _lib.PDS_DEVICE, Xs.device
+            else:
+                Xs = np.ascontiguousarray(X, dtype=ndt)
+                ptr, ld, space, dev = int(Xs.ctypes.data), p, _lib.PDS_HOST, torch.device("cuda", ctx.device)
+            out = torch.empty((p, n), dtype=tdt, device=dev)
+            ctx.follow_torch_stream(dev)
+            _lib.check(ctx.fn("pds_rows_to_cols")(ctx._h, C.c_void_p(ptr), C.c_int64(ld), C.c_int64(n), C.c_int(p), C.c_int(space),
+                                                  C.c_void_p(int(out.data_ptr())), C.c_int64(n)))
+            del Xs
+            return [out[j] for j in range(p)]
     if _is_torch(X):
         Xt = X.t().contiguous()
         return [Xt[j] for j in range(Xt.shape[0])]

@@ -253,6 +253,39 @@ def test_report_and_pred_shapes(pds, orc, p):
             assert nrel(pred.cpu().numpy(), po) < F64_TOL and nrel(resid.cpu().numpy(), y - po) < 1e-8
 
 
+def test_rows_to_cols(pds):
+    """pds_rows_to_cols_*: row-major matrix (row stride >= columns, host or HBM) -> contiguous columns in HBM, exact."""
+    import ctypes as C
+
+    import torch
+
+    from polars_ds_extension_amd import _lib
+
+    lib = _lib.load()
+    ctx = pds.default_context()
+    rng = np.random.default_rng(5)
+    try:
+        for chunk_mb in (256.0, 0.02):  # the second setting cuts host matrices into many row chunks
+            lib.pds_set_host_staging(chunk_mb, 0.0)
+            for n, p, ld in ((1, 1, 1), (63, 5, 5), (1000, 33, 40), (70_001, 17, 17), (257, 100, 100), (4096, 512, 512)):
+                for dt, tdt, suf in ((np.float64, torch.float64, "_f64"), (np.float32, torch.float32, "_f32")):
+                    A = rng.normal(size=(n, ld)).astype(dt)
+                    fn = getattr(lib, "pds_rows_to_cols" + suf)
+                    for space in (_lib.PDS_HOST, _lib.PDS_DEVICE):
+                        src = A if space == _lib.PDS_HOST else torch.from_numpy(A).cuda()
+                        ptr = src.ctypes.data if space == _lib.PDS_HOST else src.data_ptr()
+                        stride = n + 3
+                        out = torch.full((p, stride), -7.0, dtype=tdt, device="cuda")
+                        ctx.follow_torch_stream(out.device)
+                        _lib.check(fn(ctx._h, C.c_void_p(ptr), C.c_int64(ld), C.c_int64(n), C.c_int(p), C.c_int(space),
+                                      C.c_void_p(out.data_ptr()), C.c_int64(stride)))
+                        got = out.cpu().numpy()
+                        assert np.array_equal(got[:, :n], A[:, :p].T), (n, p, ld, suf, space)
+                        assert np.all(got[:, n:] == -7.0)
+    finally:
+        lib.pds_set_host_staging(256.0, 98304.0)
+
+
 def test_host_frames_in_row_chunks(pds, orc):
     """PDS_HOST frames of more than one chunk go through a chunk-sized staging buffer (capi.hip, moments_from_host_chunked /
     pred_from_host_chunked): same answers as the whole-frame path, O(chunk) HBM.  The chunk is shrunk to 1024 rows here."""
