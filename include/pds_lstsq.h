@@ -79,6 +79,17 @@ int pds_ctx_num_cus(const pds_ctx* ctx);
  * Replaces the reference's one-Vec marshalling copy, src/utils/mod.rs:101-206. */
 int pds_set_host_staging(double chunk_mb, double resident_max_mb);
 
+/* GLM by iteratively re-weighted least squares -- faer_irls (src/linear/glm/glm_solvers.rs:249-368) as GLM::fit_unchecked
+ * drives it (:216-240: weighted least squares by pivoted QR, a ones column for add_bias).  link: 0 identity, 1 log, 2 logit,
+ * 3 inverse; variance: 0 gaussian, 1 poisson, 2 binomial, 3 gamma (link_functions.rs:5-77; GLMFamily::link_function /
+ * variance_function glm_solvers.rs:24-41).  coeffs: n_feat + add_bias values, bias last; *n_iter (nullable): iterations run.
+ * Stops when max |beta_new - beta| < tol or after max_iter iterations (the reference does not report non-convergence).
+ * Up to 16 feature columns.  Each iteration is one pass over the frame. */
+int pds_glm_irls_f64(pds_ctx* ctx, const double* const* cols, int n_feat, int64_t n_rows, pds_space space, int add_bias, int link,
+                     int variance, double tol, int max_iter, double* coeffs, int* n_iter);
+int pds_glm_irls_f32(pds_ctx* ctx, const float* const* cols, int n_feat, int64_t n_rows, pds_space space, int add_bias, int link,
+                     int variance, float tol, int max_iter, float* coeffs, int* n_iter);
+
 /* Row-major matrix -> the contiguous column buffers every entry point takes (the pyclass route: the NumPy X of LR /
  * ElasticNet / OnlineLR, which the reference reads through a strided faer MatRef, src/pymodels/numpy_faer.rs:10-66).
  * X: n_rows x n_cols values with row stride ld (elements), resident in `space`.  out_cols: DEVICE buffer; column c is

@@ -229,6 +229,22 @@ def weighted_lr(X, y, w, solver="qr") -> np.ndarray:
     return beta
 
 
+GLM_FAMILIES = {"gaussian": (0, 0), "normal": (0, 0), "poisson": (1, 1), "binomial": (2, 2), "logistic": (2, 2), "gamma": (3, 3)}
+
+
+def glm_irls(X, y, family="gaussian", add_bias=False, tol=1e-8, max_iter=100):
+    """faer_irls (glm_solvers.rs:249-368) behind GLM::fit_unchecked (:216-240): returns (coefficients incl. bias last, iterations)."""
+    Xf, yf, dt = _prep(with_bias(np.asarray(X)) if add_bias else X, y)
+    link, var = GLM_FAMILIES.get(str(family).lower(), (0, 0))  # GLMFamily::from: anything else is Gaussian (:43-57)
+    n, p = Xf.shape
+    beta = np.zeros(p, dtype=dt)
+    fn = getattr(lib(), "orc_glm_irls" + _suf(dt))
+    fn.restype = C.c_int
+    R = _real(dt)
+    it = fn(_p(Xf), _p(yf), C.c_int64(n), C.c_int(p), C.c_int(link), C.c_int(var), R(tol), C.c_int(int(max_iter)), _p(beta))
+    return beta, int(it)
+
+
 def coordinate_descent(X, y, l1_reg, l2_reg, add_bias=False, tol=1e-5, max_iter=200, positive=False,
                        nthreads=1, return_info=False):
     Xf, yf, dt = _prep(X, y)

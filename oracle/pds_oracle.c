@@ -222,6 +222,7 @@ double orc_student_t_ppf(double x, double df) {
 #define REAL_EPS DBL_EPSILON
 #define RSQRT sqrt
 #define RLOG log
+#define REXP exp
 #define RISFINITE(v) isfinite(v)
 #define RSIGNBIT(v) signbit(v)
 #include "pds_oracle_impl.inc"
@@ -230,6 +231,7 @@ double orc_student_t_ppf(double x, double df) {
 #undef REAL_EPS
 #undef RSQRT
 #undef RLOG
+#undef REXP
 #undef RISFINITE
 #undef RSIGNBIT
 
@@ -238,6 +240,7 @@ double orc_student_t_ppf(double x, double df) {
 #define REAL_EPS FLT_EPSILON
 #define RSQRT sqrtf
 #define RLOG logf
+#define REXP expf
 #define RISFINITE(v) isfinite(v)
 #define RSIGNBIT(v) signbit(v)
 #include "pds_oracle_impl.inc"
@@ -246,6 +249,7 @@ double orc_student_t_ppf(double x, double df) {
 #undef REAL_EPS
 #undef RSQRT
 #undef RLOG
+#undef REXP
 #undef RISFINITE
 #undef RSIGNBIT
 

@@ -54,6 +54,8 @@ int orc_max_threads(void);
                            unsigned char* flags, int nthreads);                                    \
     void orc_weighted_lr##S(const REAL* x, const REAL* y, const REAL* w, int64_t n, int p,        \
                             int solver, REAL* beta);                                               \
+    int orc_glm_irls##S(const REAL* x, const REAL* y, int64_t n, int p, int link, int variance,   \
+                        REAL tol, int max_iter, REAL* beta);                                       \
     int orc_cd_from_gram##S(const REAL* g, const REAL* xty, const REAL* col_sums, REAL y_sum,     \
                             REAL m, int p, REAL l1_reg, REAL l2_reg, int add_bias, REAL tol,      \
                             int max_iter, int positive, REAL* beta, int* converged);              \

@@ -832,6 +832,62 @@ static int lr_rcond_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t
 }
 
 // ---------------------------------------------------------------------------------------------
+// GLM by iteratively re-weighted least squares: the caller of faer_weighted_lr (faer_irls, glm_solvers.rs:249-368;
+// GLM::fit_unchecked :216-240).  One IRLS iteration = ONE pass over the frame (moments.hip WM = 3 forms the weights and the
+// working response from the previous coefficients while the row is in registers) + a p' x p' pivoted-QR solve; the state
+// between iterations is the coefficient vector, not four n-long vectors.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+static int glm_irls_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t n_rows, pds_space space, int add_bias, int link,
+                         int variance, T tol, int max_iter, T* coeffs, int* n_iter) {
+    if (!ctx || !cols || !coeffs) return fail(PDS_ERR_INVALID, "null argument");
+    if (n_feat < 1) return fail(PDS_ERR_INVALID, "need at least one feature column");
+    if (n_feat > kMaxFeatSmall) return fail(PDS_ERR_UNSUPPORTED, "GLM (IRLS): up to 16 feature columns");
+    if (n_rows <= 0) return fail(PDS_ERR_EMPTY, "Empty data");
+    if (max_iter < 1) return fail(PDS_ERR_INVALID, "`max_iter` must be > 1.");  // linear_models.py:756-757
+    if (link < 0 || link > 3 || variance < 0 || variance > 3) return fail(PDS_ERR_INVALID, "unknown link / variance function");
+    PDS_HIP_CHECK(hipSetDevice(ctx->device));
+    const int p = n_feat, bias = add_bias ? 1 : 0, pp = p + bias, q = p + 2;
+    if (int rc = ws_reserve(ctx, 262144 + (size_t)max_iter * 1024 + sizeof(T) * (size_t)(2 * q * q + 2 * pp + 16) + sizeof(T*) * 64)) return rc;
+    DeviceCols<T> dc;
+    if (int rc = make_device_cols<T>(ctx, cols, (const T*)nullptr, p, n_rows, space, dc)) return rc;
+    T* d_mom = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * q * q));
+    T* d_beta = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * (pp + 2)));
+    IrlsArgs ia;
+    ia.link = link;
+    ia.variance = variance;
+    ia.init = 1;
+    if (variance != 2) {  // mean of y for the starting mu (:272-279): sum(y) is an entry of the plain moment matrix
+        if (int rc = launch_moments<T>(ctx, dc, p, n_rows, false, d_mom)) return rc;
+        T sy = T(0);
+        PDS_HIP_CHECK(hipMemcpyAsync(&sy, d_mom + p + (size_t)(p + 1) * q, sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+        PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        ia.y_mean = (double)sy / (double)n_rows;
+    }
+    pds_lr_params prm{};
+    prm.add_bias = bias;
+    prm.solver = PDS_SOLVER_QR;  // GLM::fit_unchecked passes LRSolverMethods::QR (:226, :236)
+    prm.max_iter = 1;
+    std::vector<T> beta(pp, T(0)), bnew(pp, T(0));
+    int it = 0;
+    while (it < max_iter) {
+        ++it;
+        if (int rc = launch_moments<T>(ctx, dc, p, n_rows, false, d_mom, d_beta, bias, nullptr, nullptr, &ia)) return rc;
+        int null_flag = 0;
+        if (int rc = lr_from_device_moments<T>(ctx, d_mom, p, &prm, /*weighted=*/true, bnew.data(), &null_flag, d_beta)) return rc;
+        ia.init = 0;
+        T max_diff = T(0);
+        for (int j = 0; j < pp; ++j) max_diff = std::max(max_diff, (T)std::fabs(beta[j] - bnew[j]));
+        beta = bnew;
+        if (max_diff < tol) break;  // (a NaN difference never converges, as in the reference: :339-350)
+    }
+    for (int j = 0; j < pp; ++j) coeffs[j] = beta[j];
+    if (n_iter) *n_iter = it;
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PDS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // lin_reg_report / wls_report
 // ---------------------------------------------------------------------------------------------
 // second pass over the frame: residuals (sum e^2, sum w e^2) and, for the HC estimators, the per-row weights s_i followed by
@@ -1608,6 +1664,15 @@ int pds_ctx_synchronize(pds_ctx* ctx) {
 }
 
 int pds_ctx_num_cus(const pds_ctx* ctx) { return ctx ? ctx->num_cus : 0; }
+
+int pds_glm_irls_f64(pds_ctx* ctx, const double* const* cols, int n_feat, int64_t n_rows, pds_space space, int add_bias, int link,
+                     int variance, double tol, int max_iter, double* coeffs, int* n_iter) {
+    return pds::glm_irls_impl<double>(ctx, cols, n_feat, n_rows, space, add_bias, link, variance, tol, max_iter, coeffs, n_iter);
+}
+int pds_glm_irls_f32(pds_ctx* ctx, const float* const* cols, int n_feat, int64_t n_rows, pds_space space, int add_bias, int link,
+                     int variance, float tol, int max_iter, float* coeffs, int* n_iter) {
+    return pds::glm_irls_impl<float>(ctx, cols, n_feat, n_rows, space, add_bias, link, variance, tol, max_iter, coeffs, n_iter);
+}
 
 int pds_rows_to_cols_f64(pds_ctx* ctx, const double* X, int64_t ld, int64_t n_rows, int n_cols, pds_space space, double* out_cols,
                          int64_t col_stride) {

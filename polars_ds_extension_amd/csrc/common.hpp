@@ -139,6 +139,12 @@ template <typename T>
 int make_device_cols(pds_ctx* ctx, const T* const* cols /*[y,x1..xp]*/, const T* weights, int n_feat,
                      int64_t n_rows, pds_space space, DeviceCols<T>& out);
 
+// one IRLS step folded into the Gram pass (moments.hip WM = 3): link / variance ids as in pds_lstsq.h, init = first iteration
+struct IrlsArgs {
+    int link = 0, variance = 0, init = 0;
+    double y_mean = 0.0;
+};
+
 // ---- kernels' host launchers (moments.hip) ----
 template <typename T>
 int launch_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, bool weighted,
@@ -147,7 +153,9 @@ int launch_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_
                    // (the HC0 / HC1 meat of lin_reg_report); d_sums_resid[0] receives sum of the weights = sum e^2
                    const T* d_beta_resid = nullptr, int bias_resid = 0, double* d_sums_resid = nullptr,
                    // p <= 16: write the record as f64 into this slot instead of d_moments (row chunks of a host frame)
-                   double* d_moments_f64 = nullptr);
+                   double* d_moments_f64 = nullptr,
+                   // p <= 16: weights and working response of one IRLS step from d_beta_resid (moments = X'WX | X'Wz)
+                   const IrlsArgs* irls = nullptr);
 template <typename T>
 int launch_sum_moment_slots(pds_ctx* ctx, const double* d_slots, int nslots, int len, T* d_out);
 

@@ -17,12 +17,56 @@
 
 namespace pds {
 
+// link / variance functions of the GLM (link_functions.rs:5-77): 0 identity / gaussian, 1 log / poisson, 2 logit / binomial,
+// 3 inverse / gamma -- evaluated in T, like the reference's `T: RealField + Float`
+template <typename T>
+__device__ __forceinline__ T glm_link(int link, T mu) {
+    switch (link) {
+        case 1: return (T)log(mu);
+        case 2: return (T)log(mu / (T(1) - mu));
+        case 3: return T(1) / mu;
+        default: return mu;
+    }
+}
+template <typename T>
+__device__ __forceinline__ T glm_inv(int link, T eta) {
+    switch (link) {
+        case 1: return (T)exp(eta);
+        case 2: { const T e = (T)exp(eta); return e / (T(1) + e); }
+        case 3: return T(1) / eta;
+        default: return eta;
+    }
+}
+template <typename T>
+__device__ __forceinline__ T glm_deriv(int link, T mu) {
+    switch (link) {
+        case 1: return T(1) / mu;
+        case 2: return T(1) / (mu * (T(1) - mu));
+        case 3: { const T r = T(1) / mu; return -(r * r); }
+        default: return T(1);
+    }
+}
+template <typename T>
+__device__ __forceinline__ T glm_var(int variance, T mu) {
+    switch (variance) {
+        case 1: return mu;
+        case 2: return mu * (T(1) - mu);
+        case 3: return mu * mu;
+        default: return T(1);
+    }
+}
+
 // =============================================================================================
 // single big system: grid-stride over 128-row (f64) / 256-row (f32) tiles, register prefetch of the
 // next tile while the matrix core chews the current one.
 // =============================================================================================
 // P16: exactly 16 features, known at compile time -- the per-column `c < p` scalar branches of the tile load / store fold away
 // P2 (0 = off): p <= P2 <= 8 features, 16 / P2 row slabs per matrix instruction (consume_tile_pack)
+// WM = 3: one step of iteratively re-weighted least squares (faer_irls, glm_solvers.rs:293-316) as ONE Gram pass: from the
+// row it has just loaded the lane forms eta = x . beta_prev, mu = g^-1(eta), the weight 1 / (g'(mu)^2 V(mu)) and the working
+// response z = eta + g'(mu) (y - mu), which REPLACES y in the tile -- the reference's n-long mu / eta / weights / d_mu vectors
+// never exist, an IRLS iteration reads X and y once and writes nothing.  ia.init: the first iteration starts from
+// mu0 = (y + mean) / 2 (binomial: (y + 0.5) / 2), eta0 = g(mu0) (:263-290).
 // WM: 0 = unweighted, 1 = a weight column, 2 = the weight of a row is its squared residual under `beta` (the HC0 / HC1
 // "meat" X' diag(e^2) X of pl_lin_reg_report, linear_regression.rs:880-892, in the SAME pass that forms the residuals: the
 // lane that loaded a row holds all of its features, so e_i = y_i - x_i . beta costs p FMAs before the tile goes to LDS, the
@@ -30,7 +74,7 @@ namespace pds {
 template <typename T, int WM, bool P16, int P2>
 __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* __restrict__ cols, int p_arg,
                                                                int64_t n, double* __restrict__ partials,
-                                                               const T* __restrict__ beta, int bias) {
+                                                               const T* __restrict__ beta, int bias, IrlsArgs ia) {
     static_assert(!(P16 && P2), "one or the other");
     constexpr bool WEIGHTED = WM != 0;   // the LDS tile carries a weight column
     constexpr bool LOADW = WM == 1;      // ... that comes from memory
@@ -60,10 +104,15 @@ __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* _
     // WM == 2: coefficients are wave uniform (scalar registers); rows at or beyond n_lim get weight 0
     T bx[16];
     T b0 = T(0);
-    if constexpr (WM == 2) {
+    if constexpr (WM >= 2) {
+        if (WM == 2 || !ia.init) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) bx[c] = (c < p) ? beta[c] : T(0);
-        b0 = bias ? beta[p] : T(0);
+            for (int c = 0; c < 16; ++c) bx[c] = (c < p) ? beta[c] : T(0);
+            b0 = bias ? beta[p] : T(0);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) bx[c] = T(0);
+        }
     }
     auto resid_weights = [&](int64_t row, int64_t n_lim) __attribute__((always_inline)) {
         if constexpr (WM == 2) {
@@ -75,6 +124,31 @@ __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* _
                     if (c < p) acc1 += regs.x[c][e] * bx[c];
                 const T r = regs.y[e] - acc1;
                 regs.w[e] = (row + e < n_lim) ? r * r : T(0);
+            }
+        }
+        if constexpr (WM == 3) {
+            const T ymean = (T)ia.y_mean;
+#pragma unroll
+            for (int e = 0; e < RPL; ++e) {
+                const T yv = regs.y[e];
+                T eta, mu;
+                if (ia.init) {
+                    mu = (ia.variance == 2) ? (yv + T(0.5)) * T(0.5) : (yv + ymean) * T(0.5);
+                    eta = glm_link<T>(ia.link, mu);
+                } else {
+                    T acc1 = b0;
+#pragma unroll
+                    for (int c = 0; c < 16; ++c)
+                        if (c < p) acc1 += regs.x[c][e] * bx[c];
+                    eta = acc1;
+                    mu = glm_inv<T>(ia.link, eta);
+                }
+                const T d = glm_deriv<T>(ia.link, mu);
+                const T wv = T(1) / (d * d * glm_var<T>(ia.variance, mu));
+                const T z = eta + d * (yv - mu);
+                const bool in = row + e < n_lim;
+                regs.w[e] = in ? wv : T(0);
+                regs.y[e] = in ? z : T(0);
             }
         }
     };
@@ -264,13 +338,16 @@ __global__ __launch_bounds__(256, 2) void grouped_moments_kernel(const T* const*
 // =============================================================================================
 template <typename T>
 int launch_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, bool weighted,
-                   T* d_moments, const T* d_beta_resid, int bias_resid, double* d_sums_resid, double* d_moments_f64) {
+                   T* d_moments, const T* d_beta_resid, int bias_resid, double* d_sums_resid, double* d_moments_f64,
+                   const IrlsArgs* irls) {
     if (n_feat > kMaxFeatSmall) {
         if (d_moments_f64) return fail(PDS_ERR_INVALID, "internal: f64 moment slots are the p <= 16 kernel's");
         if (d_beta_resid) return fail(PDS_ERR_INVALID, "internal: the residual-weighted Gram build is the p <= 16 kernel's");
         return launch_moments_wide<T>(ctx, dc, n_feat, n_rows, weighted, d_moments);
     }
-    if (d_beta_resid && weighted) return fail(PDS_ERR_INVALID, "internal: residual weights replace the weight column");
+    if ((d_beta_resid || irls) && weighted) return fail(PDS_ERR_INVALID, "internal: residual / IRLS weights replace the weight column");
+    if (irls && n_feat > kMaxFeatSmall) return fail(PDS_ERR_UNSUPPORTED, "GLM (IRLS): up to 16 feature columns");
+    const IrlsArgs ia = irls ? *irls : IrlsArgs{};
     if (n_feat < 1) return fail(PDS_ERR_INVALID, "need at least one feature column");
     constexpr int TR = 64 * Tile<T>::RPL;
     int64_t ntiles = (n_rows + TR - 1) / TR;
@@ -282,7 +359,7 @@ int launch_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_
     const int p2 = n_feat > 8 ? 0 : (n_feat > 4 ? 8 : (n_feat > 2 ? 4 : (n_feat > 1 ? 2 : 1)));
     auto launch = [&](auto w_c, auto p16_c, auto p2_c) {
         hipLaunchKernelGGL((moments_small_kernel<T, decltype(w_c)::value, decltype(p16_c)::value, decltype(p2_c)::value>), dim3(nblocks),
-                           dim3(256), lds, ctx->stream, dc.d_ptrs, n_feat, n_rows, partials, d_beta_resid, bias_resid);
+                           dim3(256), lds, ctx->stream, dc.d_ptrs, n_feat, n_rows, partials, d_beta_resid, bias_resid, ia);
     };
     auto by_p2 = [&](auto w_c) {
         using std::integral_constant;
@@ -294,15 +371,16 @@ int launch_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_
         else if (p2 == 1) launch(w_c, false_type{}, integral_constant<int, 1>{});
         else launch(w_c, false_type{}, integral_constant<int, 0>{});
     };
-    if (d_beta_resid) by_p2(std::integral_constant<int, 2>{});
+    if (irls) by_p2(std::integral_constant<int, 3>{});
+    else if (d_beta_resid) by_p2(std::integral_constant<int, 2>{});
     else if (weighted) by_p2(std::integral_constant<int, 1>{});
     else by_p2(std::integral_constant<int, 0>{});
     if (d_moments_f64)  // one row chunk of a host frame: the chunk's record stays in f64 until the chunks are summed
         hipLaunchKernelGGL((moments_finalize_kernel<double>), dim3(kPartSW + 1), dim3(64), 0, ctx->stream, partials, nblocks, n_feat,
-                           (double)n_rows, (weighted || d_beta_resid) ? 1 : 0, p2, d_moments_f64, (double*)nullptr);
+                           (double)n_rows, (weighted || d_beta_resid || irls) ? 1 : 0, p2, d_moments_f64, (double*)nullptr);
     else
         hipLaunchKernelGGL((moments_finalize_kernel<T>), dim3(kPartSW + 1), dim3(64), 0, ctx->stream, partials, nblocks, n_feat,
-                           (double)n_rows, (weighted || d_beta_resid) ? 1 : 0, p2, d_moments, d_beta_resid ? d_sums_resid : nullptr);
+                           (double)n_rows, (weighted || d_beta_resid || irls) ? 1 : 0, p2, d_moments, (d_beta_resid && !irls) ? d_sums_resid : nullptr);
     PDS_HIP_CHECK(hipGetLastError());
     return PDS_OK;
 }
@@ -443,8 +521,10 @@ int launch_sum_moment_slots(pds_ctx* ctx, const double* d_slots, int nslots, int
 template int launch_sum_moment_slots<double>(pds_ctx*, const double*, int, int, double*);
 template int launch_sum_moment_slots<float>(pds_ctx*, const double*, int, int, float*);
 
-template int launch_moments<double>(pds_ctx*, const DeviceCols<double>&, int, int64_t, bool, double*, const double*, int, double*, double*);
-template int launch_moments<float>(pds_ctx*, const DeviceCols<float>&, int, int64_t, bool, float*, const float*, int, double*, double*);
+template int launch_moments<double>(pds_ctx*, const DeviceCols<double>&, int, int64_t, bool, double*, const double*, int, double*, double*,
+                                    const IrlsArgs*);
+template int launch_moments<float>(pds_ctx*, const DeviceCols<float>&, int, int64_t, bool, float*, const float*, int, double*, double*,
+                                   const IrlsArgs*);
 template int launch_grouped_moments<double>(pds_ctx*, const DeviceCols<double>&, int, const int64_t*, int64_t,
                                             double*, const int32_t*);
 template int launch_grouped_moments<float>(pds_ctx*, const DeviceCols<float>&, int, const int64_t*, int64_t,

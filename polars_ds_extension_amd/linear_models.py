@@ -18,7 +18,7 @@ import numpy as np
 
 from . import _lib, config, lstsq
 
-__all__ = ["LR", "ElasticNet", "OnlineLR"]
+__all__ = ["LR", "ElasticNet", "OnlineLR", "GLM"]
 
 
 def _is_torch(a) -> bool:
@@ -50,6 +50,8 @@ def _columns(X) -> list:
         have_gpu = torch.cuda.is_available()
     except ImportError:
         have_gpu = False
+    if have_gpu and str(getattr(_lib.load(), "_name", "")) != str(_lib.LIB_PATH):
+        have_gpu = False  # (the CPU test-suite's mock library stands in for the product library: columns are cut on the host)
     if have_gpu:
         f64 = bool(config.LIN_REG_EXPR_F64)
         tdt, ndt = (torch.float64, np.float64) if f64 else (torch.float32, np.float32)
@@ -362,3 +364,99 @@ class OnlineLR(_Fitted):
         self._all = self._all + u * (z * (yv - float(x @ self._all)))
         self._take(self._all)
         return self
+
+
+GLM_FAMILIES = {"gaussian": (0, 0), "normal": (0, 0), "poisson": (1, 1), "binomial": (2, 2), "logistic": (2, 2), "gamma": (3, 3)}
+"""family -> (link, variance) ids of include/pds_lstsq.h: canonical links, GLMFamily::link_function / variance_function
+(src/linear/glm/glm_solvers.rs:24-41)."""
+
+
+class GLM:
+    """
+    Generalized linear models by iteratively re-weighted least squares (linear_models.py:705-923 of the reference; PyGLM,
+    src/pymodels/py_glm.rs:14-101; faer_irls, src/linear/glm/glm_solvers.rs:249-368 -- the caller of faer_weighted_lr).
+    Families and their canonical links: gaussian / normal (identity), poisson (log), binomial / logistic (logit), gamma
+    (inverse).  On the MI355X one IRLS iteration is ONE pass over the frame (`pds_glm_irls_*`): weights and working response
+    are formed from the previous coefficients while a row sits in registers; up to 16 features.
+    """
+
+    def __init__(self, add_bias: bool = False, solver: str = "irls", family: str = "normal", max_iter: int = 100, tol: float = 1e-8,
+                 feature_names_in_: List[str] | None = None):
+        if solver not in ["irls"]:
+            raise NotImplementedError
+        if max_iter < 1:
+            raise ValueError("`max_iter` must be > 1.")
+        if family not in ["gaussian", "normal", "poisson", "binomial", "logistic", "gamma"]:
+            raise NotImplementedError
+        self.add_bias, self.family, self.solver = bool(add_bias), family, solver
+        self.max_iter, self.tol = int(max_iter), abs(float(tol))
+        self.feature_names_in_: List[str] = [] if feature_names_in_ is None else list(feature_names_in_)
+        self._coeffs: np.ndarray | None = None
+        self._bias = 0.0
+        self.n_iter_ = 0
+
+    def __repr__(self) -> str:
+        link = {0: "Identity", 1: "Log", 2: "Logit", 3: "Inverse"}[GLM_FAMILIES[self.family][0]]
+        var = {0: "Gaussian", 1: "Poisson", 2: "Binomial", 3: "Gamma"}[GLM_FAMILIES[self.family][1]]
+        return f"GLM:\nLink: {link}\nVariance: {var}"  # GLM::to_string, glm_solvers.rs:98-102
+
+    def is_fit(self) -> bool:
+        return self._coeffs is not None
+
+    def set_input_features(self, features: List[str]):
+        self.feature_names_in_ = list(features)
+        return self
+
+    def coeffs(self) -> np.ndarray:
+        if self._coeffs is None:
+            raise ValueError("Matrix is not learned yet.")
+        return self._coeffs.copy()
+
+    def bias(self) -> float:
+        return float(self._bias)
+
+    def fit(self, X, y, null_policy: str = "ignore"):
+        X = _as_matrix(X)
+        y = _target(y, int(X.shape[0]))
+        X, y = _handle_nans_in_np(X, y, null_policy)
+        n, p = int(X.shape[0]), int(X.shape[1])
+        if n < p or n == 0:
+            raise ValueError("Not enough data.")  # LinearModel::fit, src/linear/lr/mod.rs:114-125
+        ctx = lstsq.default_context()
+        cols = lstsq._Cols(y, _columns(X))
+        lstsq._follow(ctx, cols)
+        pp = p + int(self.add_bias)
+        f64 = bool(config.LIN_REG_EXPR_F64)
+        co = np.empty(pp, dtype=np.float64 if f64 else np.float32)
+        link, var = GLM_FAMILIES[self.family]
+        n_iter = C.c_int(0)
+        tol = C.c_double(self.tol) if f64 else C.c_float(self.tol)
+        _lib.check(ctx.fn("pds_glm_irls")(ctx._h, cols.cols, cols.n_feat, C.c_int64(cols.n_rows), cols.space, int(self.add_bias),
+                                          C.c_int(link), C.c_int(var), tol, C.c_int(self.max_iter), C.c_void_p(co.ctypes.data),
+                                          C.byref(n_iter)))
+        co = co.astype(np.float64)
+        self._coeffs, self._bias = (co[:-1].copy(), float(co[-1])) if self.add_bias else (co.copy(), 0.0)
+        self.n_iter_ = int(n_iter.value)
+        return self
+
+    def fit_df(self, df, features: List[str], target: str, null_policy: str = "skip", show_report: bool = False):
+        X, y = _Fitted._frame_to_numpy(self, df, features, target, null_policy)
+        self.feature_names_in_ = list(features)
+        return self.fit(X, y, null_policy="ignore")
+
+    def predict(self, X, linear: bool = False):
+        """E[Y | X] = g^-1(X beta + bias), or the linear predictor eta when `linear` (glm_predict, glm_solvers.rs:243-250)."""
+        if not self.is_fit():
+            raise ValueError("Matrix is not learned yet.")
+        eta = _predict(X, self._coeffs, self._bias)
+        if linear:
+            return eta
+        link = GLM_FAMILIES[self.family][0]
+        if _is_torch(eta):
+            import torch
+
+            return {0: lambda e: e, 1: torch.exp, 2: torch.sigmoid, 3: torch.reciprocal}[link](eta)
+        if link == 2:
+            e = np.exp(eta)
+            return e / (1.0 + e)
+        return {0: lambda e: e, 1: np.exp, 3: lambda e: 1.0 / e}[link](eta)

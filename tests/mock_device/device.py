@@ -395,7 +395,27 @@ def make_callbacks(sfx):
         _view(inv_p, pp * pp, dt)[:] = inv.reshape(-1, order="F")
         return OK
 
-    return {f"pds_lr_with_inv_{sfx}": with_inv, f"pds_moments_{sfx}": moments, f"pds_lr_from_moments_{sfx}": from_moments, f"pds_lr_{sfx}": lr, f"pds_lr_pred_{sfx}": lr_pred, f"pds_lr_nullable_{sfx}": lr_nullable, f"pds_lr_multi_{sfx}": multi,
+    def glm_irls(ctx, cols_p, n_feat, n, space, bias, link, variance, tol, max_iter, coeffs_p, n_iter_p):
+        if n_feat < 1 or n_feat > 16:
+            raise MockError(UNSUPPORTED if n_feat > 16 else INVALID, "GLM (IRLS): up to 16 feature columns")
+        if n <= 0:
+            raise MockError(EMPTY, "Empty data")
+        cols = _columns(cols_p, n_feat + 1, n, dt)
+        X = X_of(cols)
+        Xb = np.asfortranarray(orc.with_bias(X) if bias else X, dtype=dt)
+        pp = Xb.shape[1]
+        beta = np.zeros(pp, dtype=dt)
+        y = np.ascontiguousarray(cols[0], dtype=dt)
+        fn = getattr(orc.lib(), "orc_glm_irls_" + sfx)
+        fn.restype = C.c_int
+        it = fn(Xb.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), C.c_int64(n), C.c_int(pp), C.c_int(link), C.c_int(variance),
+                ct(tol), C.c_int(max_iter), beta.ctypes.data_as(C.c_void_p))
+        _view(coeffs_p, pp, dt)[:] = beta
+        if n_iter_p:
+            _view(n_iter_p, 1, np.int32)[0] = it
+        return OK
+
+    return {f"pds_glm_irls_{sfx}": glm_irls, f"pds_lr_with_inv_{sfx}": with_inv, f"pds_moments_{sfx}": moments, f"pds_lr_from_moments_{sfx}": from_moments, f"pds_lr_{sfx}": lr, f"pds_lr_pred_{sfx}": lr_pred, f"pds_lr_nullable_{sfx}": lr_nullable, f"pds_lr_multi_{sfx}": multi,
             f"pds_lr_rcond_{sfx}": rcond, f"pds_elastic_net_{sfx}": elastic_net, f"pds_lin_reg_report_{sfx}": report, f"pds_lin_reg_report_nullable_{sfx}": report_nullable,
             f"pds_lr_grouped_{sfx}": grouped, f"pds_lr_grouped_weighted_{sfx}": grouped_weighted,
             f"pds_lr_grouped_nullable_{sfx}": grouped_nullable, f"pds_lr_by_key_{sfx}": by_key, f"pds_rolling_lr_{sfx}": rolling,

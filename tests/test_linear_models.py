@@ -1,7 +1,8 @@
 """
 The model classes (polars_ds_extension_amd/linear_models.py), mirroring /root/reference/tests/test_linear_models.py:
 `_handle_nans_in_np` (:9-50), LR against scikit-learn for every solver string (:53-75), OnlineLR fit + updates against
-refits (:78-122), ElasticNet against scikit-learn with and without intercept (:125-158) -- same tolerances.
+refits (:78-122), ElasticNet against scikit-learn with and without intercept (:125-158), GLM for its four families
+(:199-257; scikit-learn's unpenalised GLMs in the place of statsmodels, which this image does not have) -- same tolerances.
 """
 import numpy as np
 import pytest
@@ -162,3 +163,111 @@ def test_elastic_net_pure_ridge_penalty_runs_coordinate_descent(add_bias, orc):
     assert np.linalg.norm(got - np.linalg.solve(G, Xb.T @ y)) / np.linalg.norm(ref) < 1e-7
     G1 = Xb.T @ Xb + np.diag([0.1] * 3 + ([0.0] if add_bias else []))
     assert np.linalg.norm(got - np.linalg.solve(G1, Xb.T @ y)) / np.linalg.norm(ref) > 1e-2
+
+
+# ------------------------------------------------------------------------------------------ GLM (IRLS)
+def _glm_family_data(family, rng, n=500, p=4):
+    """tests/test_linear_models.py:199-232 of the reference: the four y generators."""
+    X = rng.randn(n, p)
+    if family == "gaussian":
+        y = X @ np.array([1.0, -0.5, 0.3, 0.8]) + rng.randn(n) * 0.1
+    elif family == "binomial":
+        y = rng.binomial(1, 1.0 / (1.0 + np.exp(-(X @ np.array([1.0, -0.5, 0.3, 0.8]))))).astype(float)
+    elif family == "poisson":
+        y = rng.poisson(np.exp(np.clip(X @ np.array([0.5, -0.25, 0.15, 0.4]), -2.0, 2.0))).astype(float)
+    else:
+        y = rng.gamma(shape=2.0, scale=np.exp(np.clip(X @ np.array([0.3, -0.15, 0.09, 0.24]), -2.0, 2.0)) / 2.0)
+    return X, y
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family", ["gaussian", "binomial", "poisson", "gamma"])
+def test_glm_family(family):
+    """All four families against an independent maximum-likelihood fit (the reference compares with statsmodels at atol 1e-2)."""
+    from scipy.optimize import minimize
+
+    from polars_ds_extension_amd.linear_models import GLM
+
+    rng = np.random.RandomState(42)
+    X, y = _glm_family_data(family, rng)
+    glm = GLM(solver="irls", add_bias=True, family=family, max_iter=200, tol=1e-8)
+    glm.fit(X, y.reshape(-1, 1))
+    b = np.r_[glm.coeffs(), glm.bias()]
+    Xb = np.c_[X, np.ones(len(y))]
+    # negative log-likelihood with the canonical link (up to constants): the IRLS fixed point is its stationary point
+    nll = {
+        "gaussian": lambda t: 0.5 * np.sum((y - Xb @ t) ** 2),
+        "binomial": lambda t: np.sum(np.logaddexp(0.0, Xb @ t) - y * (Xb @ t)),
+        "poisson": lambda t: np.sum(np.exp(Xb @ t) - y * (Xb @ t)),
+        "gamma": lambda t: np.sum(y * (Xb @ t) - np.log(np.maximum(Xb @ t, 1e-300))),  # inverse link: mu = 1 / eta
+    }[family]
+    res = minimize(nll, b + 0.01, method="Nelder-Mead", options={"xatol": 1e-10, "fatol": 1e-14, "maxiter": 20000, "maxfev": 20000})
+    np.testing.assert_allclose(b, res.x, atol=1e-2, err_msg=f"GLM family={family!r}")
+    # the gradient of the likelihood vanishes at the fit: X' (y - mu) = 0 for a canonical link (gamma: with the sign of -1/mu)
+    mu = glm.predict(X).reshape(-1)
+    score = Xb.T @ (y - mu)
+    assert np.max(np.abs(score)) < 1e-5 * len(y), score
+    assert glm.predict(X, linear=True).shape == (len(y), 1) and 1 <= glm.n_iter_ <= 200
+    if family == "binomial":  # and scikit-learn's unpenalised logistic regression agrees
+        from sklearn.linear_model import LogisticRegression
+
+        m = LogisticRegression(penalty=None, tol=1e-12, max_iter=1000).fit(X, y)
+        np.testing.assert_allclose(b, np.r_[m.coef_.reshape(-1), m.intercept_], atol=1e-4)
+    if family == "poisson":
+        from sklearn.linear_model import PoissonRegressor
+
+        m = PoissonRegressor(alpha=0, tol=1e-12, max_iter=1000).fit(X, y)
+        np.testing.assert_allclose(b, np.r_[m.coef_.reshape(-1), m.intercept_], atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_glm_convergence_failure():
+    """GLM with max_iter=1 and tight tol does not crash; returns finite coeffs (:260-276)."""
+    from polars_ds_extension_amd.linear_models import GLM
+
+    rng = np.random.RandomState(0)
+    n, p = 200, 5
+    X = rng.randn(n, p)
+    y = (np.exp(np.clip(X @ np.ones(p) * 0.2, -2, 2)) + rng.exponential(0.5, n)).reshape(-1, 1)
+    glm = GLM(solver="irls", add_bias=False, family="poisson", max_iter=1, tol=1e-12)
+    glm.fit(X, y)
+    assert glm.coeffs() is not None and np.all(np.isfinite(glm.coeffs())) and glm.n_iter_ == 1
+    with pytest.raises(NotImplementedError):
+        GLM(solver="lbfgs")
+    with pytest.raises(NotImplementedError):
+        GLM(family="tweedie")
+    with pytest.raises(ValueError, match="max_iter"):
+        GLM(max_iter=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family", ["gaussian", "binomial", "poisson", "gamma"])
+@pytest.mark.parametrize("add_bias", [False, True])
+def test_glm_matches_the_oracle(family, add_bias, orc):
+    """pds_glm_irls_* (one Gram pass per IRLS iteration) against the restated faer_irls, f64 and f32, host and device data."""
+    import torch
+
+    import polars_ds_extension_amd as pds
+    from polars_ds_extension_amd.linear_models import GLM
+
+    rng = np.random.RandomState(7)
+    X, y = _glm_family_data(family, rng, n=20_001, p=4)
+    if family == "gamma" and not add_bias:
+        y = rng.gamma(shape=2.0, scale=1.0 / np.maximum(0.5 + X @ np.array([0.1, -0.05, 0.03, 0.08]), 0.1) / 2.0)
+    bo, it_o = orc.glm_irls(X, y, family, add_bias=add_bias, tol=1e-10, max_iter=100)
+    for data in ((X, y), (torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda())):
+        glm = GLM(add_bias=add_bias, family=family, max_iter=100, tol=1e-10).fit(*data)
+        b = np.r_[glm.coeffs(), glm.bias()] if add_bias else glm.coeffs()
+        assert np.linalg.norm(b - bo) / np.linalg.norm(bo) < 1e-9, (family, add_bias, b, bo)
+        assert abs(glm.n_iter_ - it_o) <= 1
+    pds.config.LIN_REG_EXPR_F64 = False
+    try:
+        glm = GLM(add_bias=add_bias, family=family, max_iter=100, tol=1e-6).fit(X, y)
+        b32 = np.r_[glm.coeffs(), glm.bias()] if add_bias else glm.coeffs()
+        o32, _ = orc.glm_irls(X.astype(np.float32), y.astype(np.float32), family, add_bias=add_bias, tol=1e-6, max_iter=100)
+        d_gpu = np.linalg.norm(b32 - bo) / np.linalg.norm(bo)
+        d_orc = np.linalg.norm(o32 - bo) / np.linalg.norm(bo)
+        print(f"glm f32 {family} bias={add_bias}: gpu-truth {d_gpu:.2e}  orc32-truth {d_orc:.2e}")
+        assert d_gpu < 1e-4 or d_gpu <= 1.25 * d_orc
+    finally:
+        pds.config.LIN_REG_EXPR_F64 = True

@@ -17,7 +17,7 @@ import test_linear_models as M  # noqa: E402
 import test_reference_suite as R  # noqa: E402
 
 TESTS = [n for n, f in vars(R).items() if n.startswith("test_") and callable(f)]
-MODEL_TESTS = ["test_lr", "test_online_lr", "test_elastic_net"]  # the reference's tests/test_linear_models.py, host (NumPy) data
+MODEL_TESTS = ["test_lr", "test_online_lr", "test_elastic_net", "test_glm_family", "test_glm_convergence_failure"]  # the reference's tests/test_linear_models.py, host (NumPy) data
 
 
 @pytest.fixture(scope="module")
