@@ -364,8 +364,9 @@ int pds_lr_by_key_f32(pds_ctx* ctx, const float* const* cols, const int64_t* key
  *           `space`-resident; rows [0, n-1) are unspecified and marked invalid.
  *   pred    out, n_rows, `space`-resident.
  *   valid   out, n_rows bytes (1 = row has a result), `space`-resident.
- * Up to 64 coefficients (n_feat + add_bias): <= 12 in the one-kernel lane-per-row form, 13 .. 64 through per-row moment
- * records and the batched solver.
+ * Coefficients (n_feat + add_bias): <= 8 lane = 4 rows, 9 .. 12 lane = row (one kernel each), 13 .. 64 through per-row
+ * moment records and the batched pivoted QR, 65 .. 255 (n_feat <= 254) through a 1024-thread record kernel and the big-system
+ * solver (coverage path: the reference's drivers have no limit).
  * min_size > 0 selects the skipping variant (faer_rolling_skipping_lr :218-301): rows holding a
  * non-finite value are left out of the window and a window with fewer than min_size rows is invalid.
  */

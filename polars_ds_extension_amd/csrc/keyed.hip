@@ -67,8 +67,32 @@ __global__ __launch_bounds__(256) void gather_records_kernel(const T* __restrict
     constexpr int E = 16 / (int)sizeof(T);  // elements per 16-byte load (records are only element aligned)
     using V = typename std::conditional<sizeof(T) == 8, double __attribute__((ext_vector_type(2), aligned(8))),
                                         float __attribute__((ext_vector_type(4), aligned(4)))>::type;
+    constexpr int MAXV = 10;  // records of up to 10 vectors (20 f64 / 40 f32 values) are fetched whole before anything is stored
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const T* src = rows + (int64_t)perm[i] * nc;
+        const int nv = nc / E;
+        if (nv <= MAXV) {
+            // every load of the record is in flight before the first store (a load -> store -> load chain per lane cost
+            // 7.3 ms for 1e8 records of 9 doubles)
+            V v[MAXV];
+            T tl[E];
+#pragma unroll
+            for (int k = 0; k < MAXV; ++k)
+                if (k < nv) v[k] = *reinterpret_cast<const V*>(src + k * E);
+#pragma unroll
+            for (int e = 0; e < E - 1; ++e)
+                if (nv * E + e < nc) tl[e] = src[nv * E + e];
+#pragma unroll
+            for (int k = 0; k < MAXV; ++k)
+                if (k < nv) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) dst[k * E + e][i] = v[k][e];
+                }
+#pragma unroll
+            for (int e = 0; e < E - 1; ++e)
+                if (nv * E + e < nc) dst[nv * E + e][i] = tl[e];
+            continue;
+        }
         int c = 0;
         for (; c + E <= nc; c += E) {
             const V v = *reinterpret_cast<const V*>(src + c);

@@ -111,6 +111,113 @@ __global__ __launch_bounds__(64) void rolling_wide_kernel(const T* const* __rest
     }
 }
 
+// ---- more than 64 coefficients (the reference's drivers have no limit, lr_online_solvers.rs:148-301): the running moment
+// matrix no longer fits the registers of one wavefront, so a segment belongs to a 1024-thread workgroup laid out 32 x 32:
+// thread (ti, tj) owns the entries (ti + 32 a, tj + 32 b), a, b < QB = ceil(q / 32) -- per row of the window QB + QB LDS
+// reads feed QB^2 FMAs -- and the rows come through 16-row LDS tiles.  Records are solved by the big-system path of
+// launch_solve (solve_big.hip: one workgroup per system).  Coverage path: every row costs a (p+2)^2 record and a p'^3 / 3
+// factorisation, where the reference drags a p' x p' inverse along at O(p'^2) per row.
+constexpr int kBigStep = 16;
+constexpr int kBigZStride = kBigStep + 1;
+
+template <typename T, int QB>
+__global__ __launch_bounds__(1024) void rolling_big_kernel(const T* const* __restrict__ cols, RollWideArgs ra, int64_t c0,
+                                                           int64_t c1, double* __restrict__ seg_tot, T* __restrict__ mom) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int tid = threadIdx.x, ti = tid & 31, tj = tid >> 5;
+    const int p = ra.p, q = ra.q, qq = q * q;
+    double* Zn = sm;
+    double* Zo = sm + q * kBigZStride;
+    int* fin = reinterpret_cast<int*>(sm + 2 * q * kBigZStride);  // [0..15] new rows finite, [16..31] old rows finite
+    const int64_t s = c0 / kSegRows + blockIdx.x;
+    const int64_t r0 = s * kSegRows;
+    if (r0 >= c1) return;
+    const int64_t r1 = (r0 + kSegRows < c1) ? r0 + kSegRows : c1;
+    const int64_t w = ra.window;
+    double W[QB][QB];
+#pragma unroll
+    for (int a = 0; a < QB; ++a)
+#pragma unroll
+        for (int b = 0; b < QB; ++b) {
+            const int i = ti + 32 * a, j = tj + 32 * b;
+            W[a][b] = (ra.mode == 2 && i < q && j < q) ? seg_tot[s * qq + i + (int64_t)j * q] : 0.0;
+        }
+    int64_t r_begin = r0;
+    if (ra.mode == 0) r_begin = r0 - ((w + kBigStep - 1) / kBigStep) * kBigStep;
+    for (int64_t base = r_begin; base < r1; base += kBigStep) {
+        const bool warm = base < r0;
+        // ---- stage kBigStep rows (and the rows leaving the window): thread = (column c, row t)
+        if (tid < 32) fin[tid] = 1;
+        __syncthreads();
+        for (int e = tid; e < (p + 1) * kBigStep; e += 1024) {
+            const int c = e / kBigStep, t = e % kBigStep;
+            const int slot = c < p ? c : p + 1;
+            const int64_t r = base + t;
+            const bool in = r >= 0 && r < ra.n && (warm ? r >= r0 - w : r < r1);
+            const double v = in ? (double)as_global(cols[c])[r] : 0.0;
+            Zn[slot * kBigZStride + t] = v;
+            if (!in || !isfinite(v)) fin[t] = 0;  // (benign race: every writer stores 0)
+            if (ra.mode == 0 && !warm) {
+                const int64_t ro = r - w;
+                const bool ino = ro >= 0 && r < r1;
+                const double vo = ino ? (double)as_global(cols[c])[ro] : 0.0;
+                Zo[slot * kBigZStride + t] = vo;
+                if (!ino || !isfinite(vo)) fin[16 + t] = 0;
+            }
+        }
+        if (tid < kBigStep) {
+            Zn[p * kBigZStride + tid] = 1.0;
+            Zo[p * kBigZStride + tid] = 1.0;
+        }
+        __syncthreads();
+        const int steps = (int)((r1 - base < kBigStep) ? r1 - base : kBigStep);
+        for (int t = 0; t < steps; ++t) {
+            if (fin[t]) {
+                double xi[QB], xj[QB];
+#pragma unroll
+                for (int a = 0; a < QB; ++a) xi[a] = (ti + 32 * a < q) ? Zn[(ti + 32 * a) * kBigZStride + t] : 0.0;
+#pragma unroll
+                for (int b = 0; b < QB; ++b) xj[b] = (tj + 32 * b < q) ? Zn[(tj + 32 * b) * kBigZStride + t] : 0.0;
+#pragma unroll
+                for (int a = 0; a < QB; ++a)
+#pragma unroll
+                    for (int b = 0; b < QB; ++b) W[a][b] = fma(xi[a], xj[b], W[a][b]);
+            }
+            if (ra.mode == 0 && !warm && fin[16 + t]) {
+                double xi[QB], xj[QB];
+#pragma unroll
+                for (int a = 0; a < QB; ++a) xi[a] = (ti + 32 * a < q) ? Zo[(ti + 32 * a) * kBigZStride + t] : 0.0;
+#pragma unroll
+                for (int b = 0; b < QB; ++b) xj[b] = (tj + 32 * b < q) ? Zo[(tj + 32 * b) * kBigZStride + t] : 0.0;
+#pragma unroll
+                for (int a = 0; a < QB; ++a)
+#pragma unroll
+                    for (int b = 0; b < QB; ++b) W[a][b] = fma(-xi[a], xj[b], W[a][b]);
+            }
+            if (!warm && ra.mode != 1) {
+                T* rec = mom + (base + t - c0) * (int64_t)qq;
+#pragma unroll
+                for (int a = 0; a < QB; ++a)
+#pragma unroll
+                    for (int b = 0; b < QB; ++b) {
+                        const int i = ti + 32 * a, j = tj + 32 * b;
+                        if (i < q && j < q) rec[i + (int64_t)j * q] = (T)W[a][b];
+                    }
+            }
+        }
+        __syncthreads();
+    }
+    if (ra.mode == 1) {
+#pragma unroll
+        for (int a = 0; a < QB; ++a)
+#pragma unroll
+            for (int b = 0; b < QB; ++b) {
+                const int i = ti + 32 * a, j = tj + 32 * b;
+                if (i < q && j < q) seg_tot[s * qq + i + (int64_t)j * q] = W[a][b];
+            }
+    }
+}
+
 // exclusive prefix over the per-segment totals, thread = matrix entry (fixed order: results do not depend on scheduling)
 __global__ __launch_bounds__(256) void seg_prefix_kernel(double* __restrict__ tot, int64_t nseg, int qq,
                                                          const double* __restrict__ seed) {
@@ -160,7 +267,8 @@ size_t rolling_wide_workspace(int n_feat, int64_t n_rows, size_t elem) {
     return (size_t)c * q * q * elem + (size_t)c + (size_t)nseg * q * q * sizeof(double) + (size_t)q * q * sizeof(double) + 8192;
 }
 
-template <typename T, int KMAX>
+// KMAX > 0: the one-wavefront kernel (q <= 66); QB > 0: the 1024-thread kernel
+template <typename T, int KMAX, int QB>
 static int launch_wide_k(pds_ctx* ctx, const DeviceCols<T>& dc, RollWideArgs ra, double lambda, bool expanding,
                          const double* seed_moments, T* d_coeffs, T* d_pred, uint8_t* d_valid) {
     const int q = ra.q, qq = q * q;
@@ -168,10 +276,19 @@ static int launch_wide_k(pds_ctx* ctx, const DeviceCols<T>& dc, RollWideArgs ra,
     const int64_t nseg = (ra.n + kSegRows - 1) / kSegRows;
     T* d_mom = reinterpret_cast<T*>(ws_take(ctx, (size_t)chunk * qq * sizeof(T)));
     uint8_t* d_flags = reinterpret_cast<uint8_t*>(ws_take(ctx, (size_t)chunk));
-    const size_t lds = (size_t)2 * q * kZStride * sizeof(double);
-    auto kern = &rolling_wide_kernel<T, KMAX>;
-    if (lds > 64 * 1024)
-        PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (!d_mom || !d_flags) return fail(PDS_ERR_HIP, "workspace allocation failed");
+    constexpr bool BIG = QB > 0;
+    const size_t lds = BIG ? (size_t)2 * q * kBigZStride * sizeof(double) + 256 : (size_t)2 * q * kZStride * sizeof(double);
+    const void* kptr;
+    if constexpr (BIG) kptr = reinterpret_cast<const void*>(&rolling_big_kernel<T, QB>);
+    else kptr = reinterpret_cast<const void*>(&rolling_wide_kernel<T, KMAX>);
+    if (lds > 64 * 1024) PDS_HIP_CHECK(hipFuncSetAttribute(kptr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    auto run = [&](unsigned nblocks, int64_t c0, int64_t c1, double* tot, T* mom) {
+        if constexpr (BIG)
+            hipLaunchKernelGGL((rolling_big_kernel<T, QB>), dim3(nblocks), dim3(1024), lds, ctx->stream, dc.d_ptrs, ra, c0, c1, tot, mom);
+        else
+            hipLaunchKernelGGL((rolling_wide_kernel<T, KMAX>), dim3(nblocks), dim3(64), lds, ctx->stream, dc.d_ptrs, ra, c0, c1, tot, mom);
+    };
     double* d_tot = nullptr;
     if (expanding) {
         d_tot = reinterpret_cast<double*>(ws_take(ctx, (size_t)nseg * qq * sizeof(double)));
@@ -183,8 +300,7 @@ static int launch_wide_k(pds_ctx* ctx, const DeviceCols<T>& dc, RollWideArgs ra,
         }
         KernelTimer timer(ctx, kKindRolling);
         ra.mode = 1;
-        hipLaunchKernelGGL(kern, dim3((unsigned)nseg), dim3(64), lds, ctx->stream, dc.d_ptrs, ra, (int64_t)0, ra.n, d_tot,
-                           (T*)nullptr);
+        run((unsigned)nseg, (int64_t)0, ra.n, d_tot, (T*)nullptr);
         hipLaunchKernelGGL(seg_prefix_kernel, dim3((qq + 255) / 256), dim3(256), 0, ctx->stream, d_tot, nseg, qq, d_seed);
         PDS_HIP_CHECK(hipGetLastError());
     }
@@ -194,8 +310,7 @@ static int launch_wide_k(pds_ctx* ctx, const DeviceCols<T>& dc, RollWideArgs ra,
         const int64_t c1 = std::min(ra.n, c0 + chunk);
         {
             KernelTimer timer(ctx, kKindRolling);
-            hipLaunchKernelGGL(kern, dim3((unsigned)((c1 - c0 + kSegRows - 1) / kSegRows)), dim3(64), lds, ctx->stream, dc.d_ptrs,
-                               ra, c0, c1, d_tot, d_mom);
+            run((unsigned)((c1 - c0 + kSegRows - 1) / kSegRows), c0, c1, d_tot, d_mom);
             PDS_HIP_CHECK(hipGetLastError());
         }
         if (int rc = launch_solve<T>(ctx, d_mom, c1 - c0, sp, d_coeffs + c0 * ra.pp, d_flags, nullptr, nullptr)) return rc;
@@ -222,11 +337,20 @@ int launch_rolling_wide(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64
     ra.mode = 0;
     const double lam = lambda > 0.0 ? lambda : 0.0;
     const int qq = ra.q * ra.q;
-    if (ra.pp > 64 || n_feat > 64)
-        return fail(PDS_ERR_UNSUPPORTED, "rolling / recursive: at most 64 coefficients (features + bias) in this build");
-    if (qq <= 64 * 6) return launch_wide_k<T, 6>(ctx, dc, ra, lam, expanding, seed_moments, d_coeffs, d_pred, d_valid);
-    if (qq <= 64 * 19) return launch_wide_k<T, 19>(ctx, dc, ra, lam, expanding, seed_moments, d_coeffs, d_pred, d_valid);
-    return launch_wide_k<T, 69>(ctx, dc, ra, lam, expanding, seed_moments, d_coeffs, d_pred, d_valid);
+    if (n_feat > 254)
+        return fail(PDS_ERR_UNSUPPORTED, "rolling / recursive: at most 254 feature columns in this build");
+    if (qq <= 64 * 6) return launch_wide_k<T, 6, 0>(ctx, dc, ra, lam, expanding, seed_moments, d_coeffs, d_pred, d_valid);
+    if (qq <= 64 * 19) return launch_wide_k<T, 19, 0>(ctx, dc, ra, lam, expanding, seed_moments, d_coeffs, d_pred, d_valid);
+    if (ra.q <= 66) return launch_wide_k<T, 69, 0>(ctx, dc, ra, lam, expanding, seed_moments, d_coeffs, d_pred, d_valid);
+    const int qb = (ra.q + 31) / 32;  // 3 .. 8
+    switch (qb) {
+        case 3: return launch_wide_k<T, 0, 3>(ctx, dc, ra, lam, expanding, seed_moments, d_coeffs, d_pred, d_valid);
+        case 4: return launch_wide_k<T, 0, 4>(ctx, dc, ra, lam, expanding, seed_moments, d_coeffs, d_pred, d_valid);
+        case 5: return launch_wide_k<T, 0, 5>(ctx, dc, ra, lam, expanding, seed_moments, d_coeffs, d_pred, d_valid);
+        case 6: return launch_wide_k<T, 0, 6>(ctx, dc, ra, lam, expanding, seed_moments, d_coeffs, d_pred, d_valid);
+        case 7: return launch_wide_k<T, 0, 7>(ctx, dc, ra, lam, expanding, seed_moments, d_coeffs, d_pred, d_valid);
+        default: return launch_wide_k<T, 0, 8>(ctx, dc, ra, lam, expanding, seed_moments, d_coeffs, d_pred, d_valid);
+    }
 }
 
 template int launch_rolling_wide<double>(pds_ctx*, const DeviceCols<double>&, int, int64_t, int, int64_t, int64_t, double, bool,

@@ -746,6 +746,54 @@ def test_rolling_recursive_13_to_64_coefficients(pds, orc, p, bias, w):
             assert nrel(co4[i], direct) < 1e-8
 
 
+@pytest.mark.parametrize("p,bias,w", [(65, False, 150), (70, True, 200), (127, True, 300), (130, False, 400)])
+def test_rolling_recursive_beyond_64_coefficients(pds, orc, p, bias, w):
+    """p' > 64 (the reference's drivers have no limit, lr_online_solvers.rs:148-301): 1024-thread record kernel + the
+    big-system solver; crosses segment (256 rows) and record-chunk borders; rolling, skipping, expanding, seeded."""
+    rng = np.random.default_rng(900 + p)
+    n, n0 = 1500, 2 * p + 30
+    X = rng.random((n, p))
+    y = X @ rng.normal(size=p) + 0.3 + 0.05 * rng.normal(size=n)
+    Xb = np.c_[X, np.ones(n)] if bias else X
+    for lam in (0.0, 0.05):
+        co, pr, va = pds.rolling_lin_reg(*cols_of(X), target=dev(y), window_size=w, add_bias=bias, l2_reg=lam)
+        co, va = co.cpu().numpy(), va.cpu().numpy().astype(bool)
+        assert va[w - 1 :].all() and not va[: w - 1].any() and np.isnan(co[: w - 1]).all()
+        for i in list(range(w - 1, n, 173)) + [255 + w, 256 + w, n - 1]:
+            Z, t = Xb[i - w + 1 : i + 1], y[i - w + 1 : i + 1]
+            direct = np.linalg.solve(Z.T @ Z + lam * np.eye(Z.shape[1]), Z.T @ t)
+            assert nrel(co[i], direct) < 1e-7, (i, lam)
+            assert abs(float(pr[i]) - Xb[i] @ direct) < 1e-7
+    co2, pr2, va2 = pds.recursive_lin_reg(*cols_of(X), target=dev(y), start_with=n0, add_bias=bias)
+    co2, va2 = co2.cpu().numpy(), va2.cpu().numpy().astype(bool)
+    assert va2[n0 - 1 :].all() and not va2[: n0 - 1].any()
+    for i in (n0 + 50, 511, 512, 513, 1000, n - 1):
+        direct = np.linalg.lstsq(Xb[: i + 1], y[: i + 1], rcond=None)[0]
+        assert nrel(co2[i], direct) < 1e-7
+    ref = orc.recursive_lr(Xb, y, n0)  # the reference's Woodbury chain from its initial fit
+    assert np.max(np.linalg.norm(co2[n0 - 1 :] - ref, axis=1) / np.linalg.norm(ref, axis=1)) < 1e-6
+    h = 777
+    M = pds.gram_moments(*cols_of(X[:h]), target=dev(y[:h]))
+    co3, _, va3 = pds.recursive_lin_reg(*cols_of(X[h:]), target=dev(y[h:]), start_with=n0, add_bias=bias, seed_moments=M)
+    assert va3.cpu().numpy().all()
+    assert np.max(np.linalg.norm(co3.cpu().numpy() - co2[h:], axis=1) / np.linalg.norm(co2[h:], axis=1)) < 1e-8
+    Xn = X.copy()
+    bad = rng.choice(n, size=40, replace=False)
+    Xn[bad, 1] = np.nan
+    m = w - 3
+    co4, _, va4 = pds.rolling_lin_reg(*cols_of(Xn), target=dev(y), window_size=w, add_bias=bias, skip_non_finite=True,
+                                      min_valid_rows=m)
+    co4, va4 = co4.cpu().numpy(), va4.cpu().numpy().astype(bool)
+    fin = np.isfinite(Xn).all(axis=1)
+    cnt = np.convolve(fin.astype(int), np.ones(w, dtype=int))[w - 1 : n]
+    assert np.array_equal(va4[w - 1 :], cnt >= m) and not va4[: w - 1].any()
+    for i in np.flatnonzero(va4)[::301]:
+        rows = np.arange(i - w + 1, i + 1)[fin[i - w + 1 : i + 1]]
+        direct = np.linalg.lstsq(Xb[rows], y[rows], rcond=None)[0]
+        if fin[i]:
+            assert nrel(co4[i], direct) < 1e-7
+
+
 def test_rolling_wide_many_chunks(pds):
     """rolling_wide.hip streams its per-row moment records in chunks sized for the Infinity Cache: cross the chunk borders."""
     rng = np.random.default_rng(5)
