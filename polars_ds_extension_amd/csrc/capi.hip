@@ -1557,7 +1557,8 @@ static int rolling_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
         return fail(PDS_ERR_INVALID, "window / start_with must be in [1, n_rows]");
     }
     PDS_HIP_CHECK(hipSetDevice(ctx->device));
-    size_t need = 131072 + ((size_t)(n_rows / 4096) + 2) * 96 * sizeof(double);  // + per-tile totals (expanding)
+    size_t need = 131072 + ((size_t)(n_rows / 4096) + 2) * 96 * sizeof(double)  // + per-tile totals (expanding)
+                  + ((size_t)(n_rows / 4096 / 32) + 2) * 128 * sizeof(double);   // + their chunk sums (tile prefix)
     if (space == PDS_HOST) need += (size_t)n_rows * ((pp + 1) * sizeof(T) + 1) + 4096;
     if (pp > 12) need += rolling_wide_workspace(n_feat, n_rows, sizeof(T));
     if (int rc = ws_reserve(ctx, need)) return rc;

@@ -362,51 +362,67 @@ static auto roll_kernel_ptr() {
     else return &rolling_kernel<T, PP, MODE, FULLP>;
 }
 
-// exclusive prefix over the per-tile totals (expanding window): one block of kPrefixWaves waves, lane = moment,
-// wave = a contiguous chunk of tiles.  Pass 1 sums each chunk, the chunk bases are formed in LDS in chunk order, pass 2
-// writes the running prefix -- a fixed summation order, so results do not depend on scheduling.
+// exclusive prefix over the per-tile totals (expanding window) in three small launches: chunk sums (one wave per chunk of
+// kPrefixChunk tiles, lane = moment), the running bases of the chunks (one wave, chunk order), the prefixes inside every chunk.
+// A fixed summation order -- chunk by chunk, tile by tile -- so results do not depend on scheduling.  (One 16-wave block
+// walking all 24 414 tiles of a 1e8-row frame twice took 0.62 ms.)
 // (`seed`: moments of rows that precede this frame -- the row-sharded multi-GPU expanding fit -- or nullptr)
-constexpr int kPrefixWaves = 16;
-__global__ __launch_bounds__(kPrefixWaves * 64) void tile_prefix_kernel(double* __restrict__ tot, int64_t ntiles, int nv,
-                                                                        const double* __restrict__ seed) {
-    __shared__ double base[kPrefixWaves][128];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t per = (ntiles + kPrefixWaves - 1) / kPrefixWaves;
-    const int64_t t0 = wave * per, t1 = (t0 + per < ntiles) ? t0 + per : ntiles;
-    for (int v = lane; v < nv; v += 64) {  // nv <= 91 (p' = 12): at most two moments per lane
+constexpr int kPrefixChunk = 32;
+__global__ __launch_bounds__(64) void tile_chunk_sum_kernel(const double* __restrict__ tot, int64_t ntiles, int nv,
+                                                            double* __restrict__ chunk_sum) {
+    const int64_t c = blockIdx.x;
+    const int64_t t0 = c * kPrefixChunk, t1 = (t0 + kPrefixChunk < ntiles) ? t0 + kPrefixChunk : ntiles;
+    for (int v = threadIdx.x; v < nv; v += 64) {
         double sum = 0.0;
-        int64_t t = t0;
-        for (; t + 8 <= t1; t += 8) {
-            double x[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) x[k] = tot[(t + k) * nv + v];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) sum += x[k];
-        }
-        for (; t < t1; ++t) sum += tot[t * nv + v];
-        base[wave][v] = sum;
+        for (int64_t t = t0; t < t1; ++t) sum += tot[t * nv + v];
+        chunk_sum[c * nv + v] = sum;
     }
-    __syncthreads();
-    for (int v = lane; v < nv; v += 64) {
-        double run = seed ? seed[v] : 0.0;
-        for (int w = 0; w < wave; ++w) run += base[w][v];
-        int64_t t = t0;
-        for (; t + 8 <= t1; t += 8) {
-            double x[8];
+}
+__global__ __launch_bounds__(128) void chunk_prefix_kernel(double* __restrict__ chunk_sum, int64_t nchunks, int nv,
+                                                           const double* __restrict__ seed) {
+    const int v = threadIdx.x;
+    if (v >= nv) return;
+    double run = seed ? seed[v] : 0.0;
+    int64_t c = 0;
+    for (; c + 8 <= nchunks; c += 8) {
+        double x[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) x[k] = tot[(t + k) * nv + v];
+        for (int k = 0; k < 8; ++k) x[k] = chunk_sum[(c + k) * nv + v];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                tot[(t + k) * nv + v] = run;
-                run += x[k];
-            }
+        for (int k = 0; k < 8; ++k) {
+            chunk_sum[(c + k) * nv + v] = run;
+            run += x[k];
         }
-        for (; t < t1; ++t) {
+    }
+    for (; c < nchunks; ++c) {
+        const double x = chunk_sum[c * nv + v];
+        chunk_sum[c * nv + v] = run;
+        run += x;
+    }
+}
+__global__ __launch_bounds__(64) void tile_prefix_write_kernel(double* __restrict__ tot, int64_t ntiles, int nv,
+                                                               const double* __restrict__ chunk_base) {
+    const int64_t c = blockIdx.x;
+    const int64_t t0 = c * kPrefixChunk, t1 = (t0 + kPrefixChunk < ntiles) ? t0 + kPrefixChunk : ntiles;
+    for (int v = threadIdx.x; v < nv; v += 64) {
+        double run = chunk_base[c * nv + v];
+        for (int64_t t = t0; t < t1; ++t) {
             const double x = tot[t * nv + v];
             tot[t * nv + v] = run;
             run += x;
         }
     }
+}
+static int launch_tile_prefix(pds_ctx* ctx, double* tot, int64_t ntiles, int nv, const double* d_seed) {
+    if (nv > 128) return fail(PDS_ERR_INVALID, "internal: tile prefix handles up to 128 moments");
+    const int64_t nchunks = (ntiles + kPrefixChunk - 1) / kPrefixChunk;
+    double* chunk = reinterpret_cast<double*>(ws_take(ctx, (size_t)nchunks * nv * sizeof(double)));
+    if (!chunk) return fail(PDS_ERR_HIP, "workspace allocation failed");
+    hipLaunchKernelGGL(tile_chunk_sum_kernel, dim3((unsigned)nchunks), dim3(64), 0, ctx->stream, (const double*)tot, ntiles, nv, chunk);
+    hipLaunchKernelGGL(chunk_prefix_kernel, dim3(1), dim3(128), 0, ctx->stream, chunk, nchunks, nv, d_seed);
+    hipLaunchKernelGGL(tile_prefix_write_kernel, dim3((unsigned)nchunks), dim3(64), 0, ctx->stream, tot, ntiles, nv, (const double*)chunk);
+    PDS_HIP_CHECK(hipGetLastError());
+    return PDS_OK;
 }
 
 template <typename T, int PP, int FULLP>
@@ -466,9 +482,20 @@ static int launch_pp_f(pds_ctx* ctx, const DeviceCols<T>& dc, RollArgs ra, bool 
             PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // h is on this stack frame
         }
         ra.mode = 1;
-        hipLaunchKernelGGL(kern1, dim3((unsigned)nb), dim3(kRollWaves * 64), lds, ctx->stream,
-                           dc.d_ptrs, ra, tot, d_coeffs, d_pred, d_valid);
-        hipLaunchKernelGGL(tile_prefix_kernel, dim3(1), dim3(kPrefixWaves * 64), 0, ctx->stream, tot, ntiles, NV, d_seed);
+        bool totals_done = false;
+        if constexpr (PP <= 8) {
+            if (seg) {  // streaming totals (rolling_seg_dev.hpp): HBM bound instead of a full pass of the rolling kernel
+                using SD = SegDims<T, PP>;
+                const int64_t tb = std::min<int64_t>(std::max<int64_t>(ntiles, 1), (int64_t)ctx->num_cus * 8);
+                hipLaunchKernelGGL((rolling_totals_kernel<T, PP, FULLP>), dim3((unsigned)tb), dim3(64),
+                                   (size_t)SD::NV * kSegStride * sizeof(double), ctx->stream, dc.d_ptrs, ra, tot);
+                totals_done = true;
+            }
+        }
+        if (!totals_done)
+            hipLaunchKernelGGL(kern1, dim3((unsigned)nb), dim3(kRollWaves * 64), lds, ctx->stream,
+                               dc.d_ptrs, ra, tot, d_coeffs, d_pred, d_valid);
+        if (int rc = launch_tile_prefix(ctx, tot, ntiles, NV, d_seed)) return rc;
         ra.mode = 2;
         if (seg) launch_seg(std::integral_constant<int, 2>{}, (const double*)tot);
         else

@@ -24,6 +24,12 @@
 #include "common.hpp"
 #include "moments_dev.hpp"
 
+// The next stage's rows go global -> LDS directly (below); -DPDS_ROLL_NO_LDS_DIRECT keeps the register-staged prefetch (A/B:
+// 5.31 -> 4.54 ms at C4, profiles/r02_rolling_variants_ab.txt)
+#ifndef PDS_ROLL_NO_LDS_DIRECT
+#define PDS_ROLL_LDS_DIRECT 1
+#endif
+
 namespace pds {
 
 constexpr int kSegK = 4;                  // consecutive rows per lane
@@ -140,6 +146,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         if (c > p) return;
         *reinterpret_cast<V16*>(sm + (which * (PP + 1) + c) * SD::STREAM_BYTES + piece * 1024 + lane * 16) = v;
     };
+#ifdef PDS_ROLL_LDS_DIRECT
+    // gfx950: global_load_lds_dwordx4 -- the 16 bytes of lane L land at (wave-uniform LDS base) + 16 L without passing
+    // through a register: the next stage's image is fetched by ONE burst of asynchronous loads at the start of pass 2 and is
+    // complete long before the next stage reads it (no staging registers, no ds_write commits, no wait behind every row)
+    auto issue_direct = [&](int idx, int64_t base) __attribute__((always_inline)) {
+        const int c = (idx / PIECES) % (PP + 1), piece = idx % PIECES, which = idx / (PIECES * (PP + 1));
+        if (c > p) return;
+        const int64_t r = piece_row(idx, base);
+        gptr<T> col = as_global(cols[c]);
+        typedef __attribute__((address_space(3))) void* lds_ptr;
+        typedef const __attribute__((address_space(1))) void* glb_ptr;
+        __builtin_amdgcn_global_load_lds((glb_ptr)(col + r), (lds_ptr)(sm + (which * (PP + 1) + c) * SD::STREAM_BYTES + piece * 1024),
+                                         16, 0, 0);
+    };
+#endif
     // the lane's K rows of stream (which, c) out of the LDS image
     auto pick = [&](int which, int c, double (&out)[K]) __attribute__((always_inline)) {
         const char* src = sm + (which * (PP + 1) + c) * SD::STREAM_BYTES + lane * (K * (int)sizeof(T));
@@ -238,11 +259,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
             for (int i = 0; i < K; ++i) {
                 const int64_t r = r0 + i;
+                // (a row that does not count -- outside the tile, in front of the frame, holding a non-finite value -- is
+                //  skipped by an exec-mask branch around its accumulation: 18 selects per row saved over zeroing its values)
                 okn[i] = (r < t1) && seg_finite<PP>(rn[i]);
-                if (!okn[i]) seg_zero<PP>(rn[i]);
                 if constexpr (MODE == 0) {
                     oko[i] = (r < t1) && (r - w >= 0) && seg_finite<PP>(ro[i]);
-                    if (!oko[i]) seg_zero<PP>(ro[i]);
                 } else {
                     oko[i] = false;
                 }
@@ -258,8 +279,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             for (int v = 0; v < NV; ++v) S[v] = 0.0;
 #pragma unroll
             for (int i = 0; i < K; ++i) {
-                seg_accumulate<PP, NV, 1>(S, rn[i], okn[i]);
-                if constexpr (MODE == 0) seg_accumulate<PP, NV, -1>(S, ro[i], oko[i]);
+                if (okn[i]) seg_accumulate<PP, NV, 1>(S, rn[i], true);
+                if constexpr (MODE == 0) {
+                    if (oko[i]) seg_accumulate<PP, NV, -1>(S, ro[i], true);
+                }
             }
 #ifdef PDS_PROFILE_ROLLING
             asm volatile("" :: "v"(S[0]), "v"(S[NV - 1]));
@@ -298,7 +321,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             RTA();
             // ---- pass 2: row by row; a quarter of the next stage's pieces goes in flight in front of every row
             const int64_t nb = base + kSegStage;
+#ifdef PDS_ROLL_LDS_DIRECT
+            // interior stages (every piece of both streams inside the frame): the asynchronous burst; frame edges keep the
+            // guarded register path below
+            const bool direct = (nb < t1) && (nb + kSegStage <= n) && (MODE != 0 || nb - w >= 0);
+            const bool edge = (nb < t1) && !direct;  // (fetched behind the rows, in small batches: rare and allowed to wait)
+            const bool more = false;
+            if (direct) {
+#pragma unroll
+                for (int idx = 0; idx < NLOAD; ++idx) issue_direct(idx, nb);
+            }
+#else
             const bool more = nb < t1;
+#endif
 #ifdef PDS_ROLL_DEEP
             // batch i of the next stage's pieces is committed to LDS one row LATER (behind row i + 1's solve): two batches
             // are in flight, each has two solves (~2 us) to arrive instead of one
@@ -316,8 +351,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     for (int j = 0; j < PER_BATCH; ++j)
                         if (i * PER_BATCH + j < NLOAD) issue(i * PER_BATCH + j, nb, tmp[j]);
                 }
-                seg_accumulate<PP, NV, 1>(S, rn[i], okn[i]);
-                if constexpr (MODE == 0) seg_accumulate<PP, NV, -1>(S, ro[i], oko[i]);
+#ifdef PDS_ROLL_LDS_DIRECT
+                // The compiler does not order LDS reads behind global_load_lds (its ISA for this kernel has no vmcnt wait in
+                // front of the next stage's ds_reads), so the wave waits itself: in front of the LAST row -- the burst was
+                // issued three rows (~10 000 clk) ago, and the stores of this row then stay in flight across the loop edge.
+                if (i == K - 1 && direct) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                if (okn[i]) seg_accumulate<PP, NV, 1>(S, rn[i], true);
+                if constexpr (MODE == 0) {
+                    if (oko[i]) seg_accumulate<PP, NV, -1>(S, ro[i], true);
+                }
                 const int64_t r = r0 + i;
                 // L D L' of (G + lambda I) in a work copy; idx(a, b), a <= b -> a * PP - a (a - 1) / 2 + (b - a).
                 // Padding dimensions (a >= p') have zero rows and a unit diagonal: beta_pad = 0.
@@ -433,6 +476,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #endif
                 }
             }
+#ifdef PDS_ROLL_LDS_DIRECT
+            if (edge) {
+#pragma unroll 1
+                for (int b = 0; b < K; ++b) {
+                    V16 tmpe[PER_BATCH];
+#pragma unroll
+                    for (int j = 0; j < PER_BATCH; ++j)
+                        if (b * PER_BATCH + j < NLOAD) issue(b * PER_BATCH + j, nb, tmpe[j]);
+#pragma unroll
+                    for (int j = 0; j < PER_BATCH; ++j)
+                        if (b * PER_BATCH + j < NLOAD) commit(b * PER_BATCH + j, tmpe[j]);
+                }
+            }
+#endif
             RT1(4);  // pass 2 (incl. the commits counted in [5])
         }
         PDS_WAVE_LDS_SYNC();  // the next tile's anchor writes the region
@@ -442,6 +499,88 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     if (lane == 0)
         for (int k = 0; k < 8; ++k) atomicAdd(&g_roll_cycles[k], rprof[k]);
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Expanding fit, pass 1: the moment totals of every 4096-row tile -- a pure streaming reduction (45 FMAs per row at p' = 8
+// against 72 bytes: HBM bound), so it reads like the Gram kernels: 16 bytes per lane straight down each column (1 KiB
+// coalesced per instruction, non-temporal), the next 128-row step in flight in a second register set, moments in registers,
+// one cross-lane reduction per tile.  (It was the lane = row rolling kernel in its totals mode: 3.06 ms for the 7.2 GB of
+// C4's frame.)  Same moment order and non-finite rule as rolling_seg_kernel (seg_accumulate).
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, int PP, int FULLP>
+__global__ __launch_bounds__(64) void rolling_totals_kernel(const T* const* __restrict__ cols, RollArgs ra_in,
+                                                            double* __restrict__ tile_tot) {
+    using SD = SegDims<T, PP>;
+    constexpr int NV = SD::NV, E16 = SD::E16;
+    constexpr int STEP = 64 * E16;  // rows per load step
+    using V16 = typename Tile<T>::vec;
+    RollArgs ra = ra_in;
+    if constexpr (FULLP == 1) {
+        ra.p = PP;
+        ra.pp = PP;
+        ra.bias = 0;
+    } else if constexpr (FULLP == 2) {
+        ra.p = PP - 1;
+        ra.pp = PP;
+        ra.bias = 1;
+    }
+    const int p = ra.p;
+    extern __shared__ __attribute__((aligned(16))) double tot_lds[];
+    const int lane = threadIdx.x & 63;
+    const int64_t n = ra.n;
+    const int64_t ntiles = (n + kSegTile - 1) / kSegTile;
+    auto load_step = [&](int64_t row, V16 (&v)[PP + 1]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c <= PP; ++c) {
+            if (c > p) continue;
+            gptr<T> col = as_global(cols[c]);
+            if (row + E16 <= n) {
+                v[c] = __builtin_nontemporal_load(reinterpret_cast<gptr<V16>>(col + row));
+            } else {
+#pragma unroll
+                for (int e = 0; e < E16; ++e) v[c][e] = (row + e < n) ? col[row + e] : T(0);
+            }
+        }
+    };
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int64_t t0 = t * kSegTile, t1 = (t0 + kSegTile < n) ? t0 + kSegTile : n;
+        double S[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) S[v] = 0.0;
+        V16 cur[PP + 1], nxt[PP + 1];
+        load_step(t0 + (int64_t)lane * E16, cur);
+        for (int64_t base = t0; base < t1; base += STEP) {
+            const bool more = base + STEP < t1;
+            if (more) load_step(base + STEP + (int64_t)lane * E16, nxt);
+#pragma unroll
+            for (int e = 0; e < E16; ++e) {
+                SegRow<PP> row;
+#pragma unroll
+                for (int c = 0; c < PP; ++c) row.z[c] = (c < p) ? (double)cur[c][e] : ((c == p && ra.bias) ? 1.0 : 0.0);
+                row.y = (double)cur[p][e];
+                const bool ok = (base + (int64_t)lane * E16 + e < t1) && seg_finite<PP>(row);
+                if (!ok) seg_zero<PP>(row);
+                seg_accumulate<PP, NV, 1>(S, row, ok);
+            }
+            if (more) {
+#pragma unroll
+                for (int c = 0; c <= PP; ++c) cur[c] = nxt[c];
+            }
+        }
+        // ---- the tile's totals: sum over the lanes in lane order (fixed order: reproducible)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) tot_lds[v * kSegStride + lane] = S[v];
+        PDS_WAVE_LDS_SYNC();
+        if (lane < NV) {
+            const double* rowp = tot_lds + lane * kSegStride;
+            double s = 0.0;
+#pragma unroll 16
+            for (int i = 0; i < 64; ++i) s += rowp[i];
+            tile_tot[t * NV + lane] = s;
+        }
+        PDS_WAVE_LDS_SYNC();
+    }
 }
 
 }  // namespace pds
