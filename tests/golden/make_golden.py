@@ -49,6 +49,17 @@ def main():
         if src.lstrip().startswith("# Linear Regression\n"):
             m = re.search(r"\[(-?[\d.]+), (-?[\d.]+)\]", txt)
             gold["lin_reg_full_frame_coeffs"] = [float(m.group(1)), float(m.group(2))]
+        if "lin_reg_report" in src and "ln(x1+1)" in src:
+            # the printed report table (f64 cell, then the f32 cell): features | beta | std_err | t | ... | 0.025 | 0.975 | r2 | adj_r2
+            # (polars elides the middle columns with an ellipsis); 10 000 rows, 3 features + bias -> dof = 9 996
+            r = [x for x in rows(txt) if len(x) == 9 and x[0] not in ("features",)]
+            key = "report_f32" if "LIN_REG_EXPR_F64 = False" in src else "report_f64"
+            gold[key] = [{"feature": x[0], "beta": float(x[1]), "std_err": float(x[2]), "t": float(x[3]), "ci_lo": float(x[5]),
+                          "ci_hi": float(x[6]), "r2": float(x[7]), "adj_r2": float(x[8])} for x in r]
+            gold["report_rows"], gold["report_dof"] = 10_000, 9_996
+        if "target=[pl.col(\"y\"), pl.col(\"y2\")]" in src and "LIN_REG_EXPR_F64" not in src:
+            m = re.findall(r"\[(-?[\d.]+), (-?[\d.]+)\]", txt)
+            gold["multi_target_coeffs"] = [[float(a), float(b)] for a, b in m]
         if "rolling_lin_reg" in src and "window_size=5" in src:
             r = [x for x in rows(txt) if len(x) == 5 and x[0] not in ("y", "…")]
             parsed = []

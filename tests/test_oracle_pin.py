@@ -34,6 +34,26 @@ def test_golden_rolling_window5(orc, golden):
 
 
 # ------------------------------------------------------------------ (2) literal frames of the reference tests
+def test_golden_report_table(orc, golden):
+    """The report table the reference's notebook prints (10 000 rows, 3 features + bias: dof 9 996), f64 and f32 cells: the
+    columns are tied together by the epilogue arithmetic this repo restates (linear_regression.rs:861-939) -- t = beta / se,
+    CI = beta -/+ t_ppf(0.975, dof) se with the reference's own Student-t quantile, adj_r2 = 1 - (1 - r2)(n - 1)/(dof - 1)."""
+    n, dof = golden["report_rows"], golden["report_dof"]
+    tq = orc.student_t_ppf(0.975, float(dof))
+    assert abs(tq - 1.96020) < 2e-4  # (the reference's bisection stops early: 6e-5 relative, DESIGN.md 7)
+    for key, tol in (("report_f64", 1.6e-6), ("report_f32", 2.6e-6)):
+        rows_ = golden[key]
+        assert [r["feature"] for r in rows_] == ["ln(x1+1)", "exp(x2)", "sin(x3)", "__bias__"]
+        for r in rows_:
+            se = r["beta"] / r["t"]  # t carries nine digits, std_err only four: the implied std_err is the sharper one
+            assert abs(se - r["std_err"]) < 6e-7 + 2e-6 * abs(se)
+            assert abs(r["beta"] - tq * abs(se) - r["ci_lo"]) < tol and abs(r["beta"] + tq * abs(se) - r["ci_hi"]) < tol
+            adj = 1.0 - (1.0 - r["r2"]) * ((n - 1) / (dof - 1.0))  # `dof - 1`, as the reference computes it (:874-878)
+            assert abs(adj - r["adj_r2"]) < 1.6e-6
+    # the multi-target cell repeats the single-target coefficients for target_0
+    assert golden["multi_target_coeffs"][0] == golden["lin_reg_full_frame_coeffs"]
+
+
 def test_literal_skip_null_frame(orc):
     # tests/test_linear_exprs.py:411-432 -- y = x1 + x2 + 3.5... wait: literal frame, row 0 has a null
     # x1 = [None,2,3,4,5], x2 = [1,...], y = x1 + x2 ... the test pins pred [None,9.5,10.5,11.5,12.5].
