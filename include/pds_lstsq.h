@@ -79,25 +79,6 @@ int pds_ctx_num_cus(const pds_ctx* ctx);
  * Replaces the reference's one-Vec marshalling copy, src/utils/mod.rs:101-206. */
 int pds_set_host_staging(double chunk_mb, double resident_max_mb);
 
-/* GLM by iteratively re-weighted least squares -- faer_irls (src/linear/glm/glm_solvers.rs:249-368) as GLM::fit_unchecked
- * drives it (:216-240: weighted least squares by pivoted QR, a ones column for add_bias).  link: 0 identity, 1 log, 2 logit,
- * 3 inverse; variance: 0 gaussian, 1 poisson, 2 binomial, 3 gamma (link_functions.rs:5-77; GLMFamily::link_function /
- * variance_function glm_solvers.rs:24-41).  coeffs: n_feat + add_bias values, bias last; *n_iter (nullable): iterations run.
- * Stops when max |beta_new - beta| < tol or after max_iter iterations (the reference does not report non-convergence).
- * Up to 16 feature columns.  Each iteration is one pass over the frame. */
-int pds_glm_irls_f64(pds_ctx* ctx, const double* const* cols, int n_feat, int64_t n_rows, pds_space space, int add_bias, int link,
-                     int variance, double tol, int max_iter, double* coeffs, int* n_iter);
-int pds_glm_irls_f32(pds_ctx* ctx, const float* const* cols, int n_feat, int64_t n_rows, pds_space space, int add_bias, int link,
-                     int variance, float tol, int max_iter, float* coeffs, int* n_iter);
-
-/* Row-major matrix -> the contiguous column buffers every entry point takes (the pyclass route: the NumPy X of LR /
- * ElasticNet / OnlineLR, which the reference reads through a strided faer MatRef, src/pymodels/numpy_faer.rs:10-66).
- * X: n_rows x n_cols values with row stride ld (elements), resident in `space`.  out_cols: DEVICE buffer; column c is
- * written to out_cols + c * col_stride (col_stride >= n_rows).  Host matrices cross PCIe as contiguous row chunks. */
-int pds_rows_to_cols_f64(pds_ctx* ctx, const double* X, int64_t ld, int64_t n_rows, int n_cols, pds_space space, double* out_cols,
-                         int64_t col_stride);
-int pds_rows_to_cols_f32(pds_ctx* ctx, const float* X, int64_t ld, int64_t n_rows, int n_cols, pds_space space, float* out_cols,
-                         int64_t col_stride);
 /* Diagnostics: how many call-local workspace slices had to be allocated outside the per-call reservation since the context
  * was created (0 unless an entry point under-estimated its bound; the slices are still valid, never out of bounds). */
 long long pds_ctx_workspace_spills(const pds_ctx* ctx);
@@ -424,6 +405,43 @@ int pds_lr_from_moments_f32(pds_ctx* ctx, const float* moments, pds_space mom_sp
 /* Bit-faithful host restatements of src/stats_utils (beta.rs:24-37, 365-377) used by the report. */
 double pds_student_t_sf(double x, double df);
 double pds_student_t_ppf(double q, double df);
+
+/* ------------------------------------------------------------------------------------------------
+ * The pyclass route (src/pymodels): GLM, fits from row-major matrices
+ * ---------------------------------------------------------------------------------------------- */
+/* GLM by iteratively re-weighted least squares -- faer_irls (src/linear/glm/glm_solvers.rs:249-368) as GLM::fit_unchecked
+ * drives it (:216-240: weighted least squares by pivoted QR, a ones column for add_bias).  link: 0 identity, 1 log, 2 logit,
+ * 3 inverse; variance: 0 gaussian, 1 poisson, 2 binomial, 3 gamma (link_functions.rs:5-77; GLMFamily::link_function /
+ * variance_function glm_solvers.rs:24-41).  coeffs: n_feat + add_bias values, bias last; *n_iter (nullable): iterations run.
+ * Stops when max |beta_new - beta| < tol or after max_iter iterations (the reference does not report non-convergence).
+ * Up to 16 feature columns.  Each iteration is one pass over the frame. */
+int pds_glm_irls_f64(pds_ctx* ctx, const double* const* cols, int n_feat, int64_t n_rows, pds_space space, int add_bias, int link,
+                     int variance, double tol, int max_iter, double* coeffs, int* n_iter);
+int pds_glm_irls_f32(pds_ctx* ctx, const float* const* cols, int n_feat, int64_t n_rows, pds_space space, int add_bias, int link,
+                     int variance, float tol, int max_iter, float* coeffs, int* n_iter);
+
+/* Fits straight from a ROW-MAJOR matrix -- the pyclass route (PyLR / PyElasticNet / PyOnlineLR, src/pymodels/py_lr.rs:21-224,
+ * whose NumPy X the reference reads through a strided faer MatRef, src/pymodels/numpy_faer.rs:10-66).
+ * X: n_rows x n_feat values, row stride ld (elements); y: n_rows values; both resident in `space`.
+ * mode 0: LR::fit -- the pl_lr dispatch of `prm` (faer_solve_lr, lr_solvers.rs:65-73; pass singular_x_tol = 0 for the model class);
+ * mode 1: ElasticNet::fit -- always faer_coordinate_descent with prm's l1_reg / l2_reg / tol / max_iter (lr_solvers.rs:139-164);
+ * mode 2: OnlineLR::fit -- faer_qr_lr_with_inv (lr_online_solvers.rs:120-143): coeffs and inv = (X'X + lambda I)^-1 with
+ *         lambda = prm->l2_reg on the feature diagonals, (n_feat + add_bias)^2 values column-major (inv required).
+ * Up to 16 features the matrix core reads the rows as they lie (one pass, no transposition; host matrices as contiguous row
+ * chunks); wider matrices are transposed once on the device.  coeffs: n_feat + add_bias values, bias last. */
+int pds_lr_rowmajor_f64(pds_ctx* ctx, const double* X, int64_t ld, const double* y, int64_t n_rows, int n_feat, pds_space space,
+                        const pds_lr_params* prm, int mode, double* coeffs, int* is_null, double* inv);
+int pds_lr_rowmajor_f32(pds_ctx* ctx, const float* X, int64_t ld, const float* y, int64_t n_rows, int n_feat, pds_space space,
+                        const pds_lr_params* prm, int mode, float* coeffs, int* is_null, float* inv);
+
+/* Row-major matrix -> the contiguous column buffers every entry point takes (the pyclass route: the NumPy X of LR /
+ * ElasticNet / OnlineLR, which the reference reads through a strided faer MatRef, src/pymodels/numpy_faer.rs:10-66).
+ * X: n_rows x n_cols values with row stride ld (elements), resident in `space`.  out_cols: DEVICE buffer; column c is
+ * written to out_cols + c * col_stride (col_stride >= n_rows).  Host matrices cross PCIe as contiguous row chunks. */
+int pds_rows_to_cols_f64(pds_ctx* ctx, const double* X, int64_t ld, int64_t n_rows, int n_cols, pds_space space, double* out_cols,
+                         int64_t col_stride);
+int pds_rows_to_cols_f32(pds_ctx* ctx, const float* X, int64_t ld, int64_t n_rows, int n_cols, pds_space space, float* out_cols,
+                         int64_t col_stride);
 
 #ifdef __cplusplus
 }

@@ -195,6 +195,102 @@ __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* _
     }
 }
 
+// =============================================================================================
+// Row-major frames (the pyclass route: a NumPy / torch matrix X[n][ld], y[n]; numpy_faer.rs:10-66 reads it through a
+// strided MatRef).  Row-major IS the matrix core's operand layout: lane (f = lane & 15, q = lane >> 4) of a 16x16x4 step
+// holds feature f of row 4 s + q, i.e. the 64 lanes of one load instruction read four consecutive rows of 16 features
+// -- 512 contiguous bytes at ld = 16 -- and the value goes into the MFMA as it arrives: no LDS tile, no transposition pass.
+// Each wave streams a contiguous row range, eight 4-row steps (32 rows) per iteration with the next iteration's sixteen
+// loads in flight in a second register set.  Same partial records and finalize kernel as moments_small_kernel.
+// =============================================================================================
+template <typename T>
+__global__ __launch_bounds__(256, 2) void moments_rowmajor_kernel(const T* __restrict__ X, int64_t ld, const T* __restrict__ y,
+                                                                  int p, int64_t n, double* __restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int U = 8;  // 4-row steps per iteration
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int f = lane & 15, q = lane >> 4;
+    const bool feat = f < p;
+    const gptr<T> Xg = as_global(X);
+    const gptr<T> yg = as_global(y);
+    const int64_t wid = (int64_t)blockIdx.x * kWaves + wave, nw = (int64_t)gridDim.x * kWaves;
+    const int64_t nit = (n + 4 * U - 1) / (4 * U);  // iterations of 32 rows; the last one may be ragged
+    int64_t it = (int64_t)(((__int128)nit * wid) / nw);
+    const int64_t it_end = (int64_t)(((__int128)nit * (wid + 1)) / nw);
+    using Acc = typename Tile<T>::acc;
+    WaveAcc acc;
+    zero_acc(acc);
+    T xa[U], ya[U];
+    auto load_iter = [&](int64_t i, T (&xv)[U], T (&yv)[U]) __attribute__((always_inline)) {
+        const int64_t r0 = i * (4 * U) + q;
+        if (r0 + 4 * (U - 1) < n - 3 + q) {  // every row of the iteration exists (rows r0 + 4 u <= n - 1 for all q)
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t r = r0 + 4 * u;
+                xv[u] = feat ? __builtin_nontemporal_load(Xg + r * ld + f) : T(0);
+                yv[u] = __builtin_nontemporal_load(yg + r);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t r = r0 + 4 * u;
+                const bool in = r < n;
+                xv[u] = (in && feat) ? Xg[r * ld + f] : T(0);
+                yv[u] = in ? yg[r] : T(0);
+            }
+        }
+    };
+    if (it < it_end) load_iter(it, xa, ya);
+    for (; it < it_end; ++it) {
+        T xb[U], yb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            xb[u] = xa[u];
+            yb[u] = ya[u];
+        }
+        if (it + 1 < it_end) load_iter(it + 1, xa, ya);
+        if constexpr (sizeof(T) == 8) {
+            Acc a = Acc{acc.d[0], acc.d[1], acc.d[2], acc.d[3]};
+            double xy = acc.xy, cs = acc.cs, yy = acc.yy, ys = acc.ys;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                a = Tile<T>::mfma(xb[u], xb[u], a);
+                xy = fma(xb[u], yb[u], xy);
+                cs += xb[u];
+                yy = fma(yb[u], yb[u], yy);
+                ys += yb[u];
+            }
+            acc.d[0] = a[0]; acc.d[1] = a[1]; acc.d[2] = a[2]; acc.d[3] = a[3];
+            acc.xy = xy; acc.cs = cs; acc.yy = yy; acc.ys = ys;
+        } else {  // f32: one iteration's products in f32 on the matrix core, folded into f64 accumulators (like the tile kernel)
+            Acc a = Acc{0, 0, 0, 0};
+            float xy = 0.f, cs = 0.f, yy = 0.f, ys = 0.f;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                a = Tile<T>::mfma(xb[u], xb[u], a);
+                xy = fmaf(xb[u], yb[u], xy);
+                cs += xb[u];
+                yy = fmaf(yb[u], yb[u], yy);
+                ys += yb[u];
+            }
+            acc.d[0] += (double)a[0]; acc.d[1] += (double)a[1]; acc.d[2] += (double)a[2]; acc.d[3] += (double)a[3];
+            acc.xy += (double)xy; acc.cs += (double)cs; acc.yy += (double)yy; acc.ys += (double)ys;
+        }
+    }
+    __syncthreads();
+    double* recs = reinterpret_cast<double*>(smem);
+    wave_record<T>(acc, lane, recs + wave * kPartStride);
+    __syncthreads();
+    for (int e = threadIdx.x; e < kPartStride; e += blockDim.x) {
+        double sum = 0.0;
+        if (e <= kPartSW) {
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) sum += recs[w * kPartStride + e];
+        }
+        partials[(int64_t)blockIdx.x * kPartStride + e] = sum;
+    }
+}
+
 // fixed-order reduction of the per-block partials and assembly of the (p+2)x(p+2) moment matrix.
 // One 64-lane block per record element: lane l sums blocks l, l+64, ... in order, then a fixed
 // butterfly combines the lanes -- deterministic, and ~2 us instead of a 512-long dependent load chain.
@@ -502,6 +598,28 @@ int launch_grouped_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, co
     PDS_HIP_CHECK(hipGetLastError());
     return PDS_OK;
 }
+
+template <typename T>
+int launch_moments_rowmajor(pds_ctx* ctx, const T* d_X, int64_t ld, const T* d_y, int n_feat, int64_t n_rows, T* d_moments,
+                            double* d_moments_f64) {
+    if (n_feat < 1 || n_feat > kMaxFeatSmall) return fail(PDS_ERR_INVALID, "internal: the row-major Gram kernel takes 1..16 features");
+    const int64_t nit = (n_rows + 31) / 32;
+    const int nblocks = (int)std::min<int64_t>(std::max<int64_t>((nit + kWaves - 1) / kWaves, 1), (int64_t)ctx->num_cus * 2);
+    double* partials = ctx->partials;
+    KernelTimer timer(ctx, kKindMoments);
+    hipLaunchKernelGGL((moments_rowmajor_kernel<T>), dim3(nblocks), dim3(256), (size_t)kWaves * kPartStride * sizeof(double), ctx->stream,
+                       d_X, ld, d_y, n_feat, n_rows, partials);
+    if (d_moments_f64)
+        hipLaunchKernelGGL((moments_finalize_kernel<double>), dim3(kPartSW + 1), dim3(64), 0, ctx->stream, partials, nblocks, n_feat,
+                           (double)n_rows, 0, 0, d_moments_f64, (double*)nullptr);
+    else
+        hipLaunchKernelGGL((moments_finalize_kernel<T>), dim3(kPartSW + 1), dim3(64), 0, ctx->stream, partials, nblocks, n_feat,
+                           (double)n_rows, 0, 0, d_moments, (double*)nullptr);
+    PDS_HIP_CHECK(hipGetLastError());
+    return PDS_OK;
+}
+template int launch_moments_rowmajor<double>(pds_ctx*, const double*, int64_t, const double*, int, int64_t, double*, double*);
+template int launch_moments_rowmajor<float>(pds_ctx*, const float*, int64_t, const float*, int, int64_t, float*, double*);
 
 // sum of the per-chunk f64 moment records in chunk order (fixed order: reproducible), cast once
 template <typename T>

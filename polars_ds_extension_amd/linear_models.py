@@ -79,6 +79,44 @@ def _columns(X) -> list:
     return [np.ascontiguousarray(X[:, j]) for j in range(X.shape[1])]
 
 
+def _fit_rowmajor(X, y, prm, mode: int, pp: int):
+    """
+    LR / ElasticNet / OnlineLR fits straight from the row-major matrix (`pds_lr_rowmajor_*`): up to 16 features the matrix
+    core reads the rows as they lie -- one pass over X, nothing transposed, a NumPy matrix crossing PCIe as contiguous row
+    chunks.  Returns (coeffs, is_null, inv) or None when this route does not apply (no GPU / the CPU suite's mock library),
+    in which case the caller cuts columns.
+    """
+    try:
+        import torch
+
+        if not torch.cuda.is_available() or str(getattr(_lib.load(), "_name", "")) != str(_lib.LIB_PATH):
+            return None
+    except ImportError:
+        return None
+    f64 = bool(config.LIN_REG_EXPR_F64)
+    tdt, ndt = (torch.float64, np.float64) if f64 else (torch.float32, np.float32)
+    n, p = int(X.shape[0]), int(X.shape[1])
+    ctx = lstsq.default_context()
+    if _is_torch(X):
+        Xs = (X if X.is_cuda else X.cuda()).to(tdt)
+        if Xs.stride(1) != 1:
+            Xs = Xs.contiguous()
+        ys = torch.as_tensor(y).to(device=Xs.device, dtype=tdt).reshape(-1).contiguous()
+        xp, yp, ld, space = int(Xs.data_ptr()), int(ys.data_ptr()), int(Xs.stride(0)), _lib.PDS_DEVICE
+        ctx.follow_torch_stream(Xs.device)
+    else:
+        Xs = np.ascontiguousarray(X, dtype=ndt)
+        ys = np.ascontiguousarray(np.asarray(y.cpu() if _is_torch(y) else y).reshape(-1), dtype=ndt)
+        xp, yp, ld, space = int(Xs.ctypes.data), int(ys.ctypes.data), p, _lib.PDS_HOST
+    co = np.empty(pp, dtype=ndt)
+    inv = np.empty((pp, pp), dtype=ndt) if mode == 2 else None
+    is_null = C.c_int(0)
+    _lib.check(ctx.fn("pds_lr_rowmajor")(ctx._h, C.c_void_p(xp), C.c_int64(ld), C.c_void_p(yp), C.c_int64(n), C.c_int(p), C.c_int(space),
+                                         C.byref(prm), C.c_int(mode), C.c_void_p(co.ctypes.data), C.byref(is_null),
+                                         C.c_void_p(inv.ctypes.data) if inv is not None else C.c_void_p(None)))
+    return co, bool(is_null.value), inv
+
+
 def _target(y, n: int):
     if _is_torch(y):
         y = y.reshape(-1)
@@ -226,6 +264,11 @@ class LR(_Fitted):
         if n < p or n == 0:
             raise ValueError("Not enough data.")  # LinalgErrors::NotEnoughData (src/linear/lr/mod.rs:119-121)
         # faer_solve_lr: no rank gate, lambda on the feature diagonals only
+        prm = lstsq._params(self._has_bias, 0.0, self.lambda_, 1e-5, self.solver, False, 200, 0.0)
+        rm = _fit_rowmajor(X, y, prm, 0, p + int(self._has_bias))
+        if rm is not None:
+            self._take(rm[0])
+            return self
         b = lstsq.lin_reg(*_columns(X), target=y, add_bias=self._has_bias, l2_reg=self.lambda_, solver=self.solver,
                           singular_x_tol=0.0, null_policy="ignore")
         self._take(b)
@@ -276,6 +319,11 @@ class ElasticNet(_Fitted):
             raise ValueError("Not enough data.")  # (fewer rows than columns is fine here, lr_solvers.rs:167-175)
         # always coordinate descent, like ElasticNet::fit_unchecked -- also for a pure ridge penalty (l1_reg <= 0), whose
         # coordinate-descent objective penalises with n_rows * l2_reg (lr_solvers.rs:478-480), not the closed form's l2_reg
+        prm = lstsq._params(self._has_bias, self.l1_reg, self.l2_reg, self.tol, "qr", False, self.max_iter, 0.0)
+        rm = _fit_rowmajor(X, y, prm, 1, int(X.shape[1]) + int(self._has_bias))
+        if rm is not None:
+            self._take(rm[0])
+            return self
         b = lstsq.elastic_net_fit(*_columns(X), target=y, add_bias=self._has_bias, l1_reg=self.l1_reg, l2_reg=self.l2_reg,
                                   tol=self.tol, max_iter=self.max_iter)
         self._take(b)
@@ -332,10 +380,17 @@ class OnlineLR(_Fitted):
         n, p = int(X.shape[0]), int(X.shape[1])
         if n < p or n == 0:
             raise ValueError("Not enough data.")
+        pp = p + int(self._has_bias)
+        prm = lstsq._params(self._has_bias, 0.0, self.lambda_, 1e-5, "qr", False, 200, 0.0)
+        rm = _fit_rowmajor(X, y, prm, 2, pp)
+        if rm is not None:
+            self._all = rm[0].astype(np.float64)
+            self._inv = rm[2].astype(np.float64).reshape(pp, pp, order="F")
+            self._take(self._all)
+            return self
         ctx = lstsq.default_context()
         cols = lstsq._Cols(y, _columns(X))
         lstsq._follow(ctx, cols)
-        pp = p + int(self._has_bias)
         dt = np.float64 if config.LIN_REG_EXPR_F64 else np.float32
         co, inv = np.empty(pp, dtype=dt), np.empty((pp, pp), dtype=dt)
         lam = C.c_double(self.lambda_) if config.LIN_REG_EXPR_F64 else C.c_float(self.lambda_)

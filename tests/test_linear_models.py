@@ -165,6 +165,63 @@ def test_elastic_net_pure_ridge_penalty_runs_coordinate_descent(add_bias, orc):
     assert np.linalg.norm(got - np.linalg.solve(G1, Xb.T @ y)) / np.linalg.norm(ref) > 1e-2
 
 
+# ------------------------------------------------------------------------------------------ fits from a row-major matrix
+@pytest.mark.gpu
+@pytest.mark.parametrize("p", [1, 3, 8, 16, 20])
+def test_fits_from_row_major_matrices(p, orc):
+    """pds_lr_rowmajor_* (the pyclass route): p <= 16 reads the rows as they lie (moments_rowmajor_kernel), wider matrices are
+    transposed on the device; NumPy (host, contiguous row chunks) and CUDA tensors with a row stride > p; ragged row counts."""
+    import torch
+
+    import polars_ds_extension_amd as pds
+    from polars_ds_extension_amd import _lib
+    from polars_ds_extension_amd.linear_models import LR, ElasticNet, OnlineLR
+
+    lib = _lib.load()
+    rng = np.random.default_rng(50 + p)
+    try:
+        for n, chunk_mb in ((2 * p + 3, 256.0), (4099, 256.0), (60_001, 0.05)):
+            lib.pds_set_host_staging(chunk_mb, 0.0)
+            X = rng.normal(size=(n, p))
+            y = X @ rng.normal(size=p) + 0.4 + 0.1 * rng.normal(size=n)
+            wide = torch.zeros((n, p + 5), dtype=torch.float64, device="cuda")
+            wide[:, :p] = torch.from_numpy(X).cuda()
+            Xd = wide[:, :p]  # row stride p + 5
+            assert Xd.stride(0) == p + 5 and Xd.stride(1) == 1
+            for bias in (False, True):
+                bo = orc.pl_lr(X, y, add_bias=bias, singular_x_tol=0.0)
+                for data in (X, Xd):
+                    lr = LR(has_bias=bias).fit(data, y)
+                    b = np.r_[lr.coeffs(), lr.bias()] if bias else lr.coeffs()
+                    assert np.linalg.norm(b - bo) / np.linalg.norm(bo) < 1e-9, (n, p, bias)
+                    lr = LR(has_bias=bias, lambda_=0.3).fit(data, y)
+                    b = np.r_[lr.coeffs(), lr.bias()] if bias else lr.coeffs()
+                    br = orc.pl_lr(X, y, add_bias=bias, l2_reg=0.3, singular_x_tol=0.0)
+                    assert np.linalg.norm(b - br) / np.linalg.norm(br) < 1e-9
+                    en = ElasticNet(l1_reg=0.01, l2_reg=0.02, has_bias=bias, tol=1e-9, max_iter=5000).fit(data, y)
+                    b = np.r_[en.coeffs(), en.bias()] if bias else en.coeffs()
+                    be = orc.coordinate_descent(X, y, 0.01, 0.02, bias, 1e-9, 5000)
+                    assert np.linalg.norm(b - be) / np.linalg.norm(be) < 1e-7
+                    ol = OnlineLR(has_bias=bias, lambda_=0.1).fit(data, y)
+                    Xb = np.c_[X, np.ones(n)] if bias else X
+                    G = Xb.T @ Xb
+                    G[np.arange(p), np.arange(p)] += 0.1  # lambda on the feature diagonals
+                    assert np.linalg.norm(ol.inv() - np.linalg.inv(G)) / np.linalg.norm(np.linalg.inv(G)) < 1e-8
+                    bi = np.linalg.solve(G, Xb.T @ y)
+                    b = np.r_[ol.coeffs(), ol.bias()] if bias else ol.coeffs()
+                    assert np.linalg.norm(b - bi) / np.linalg.norm(bi) < 1e-8
+        # f32 twin
+        pds.config.LIN_REG_EXPR_F64 = False
+        X = rng.normal(size=(30_001, p))
+        y = X @ rng.normal(size=p) + 0.4 + 0.1 * rng.normal(size=30_001)
+        lr = LR(has_bias=True).fit(X, y)
+        bo = orc.pl_lr(X.astype(np.float32).astype(np.float64), y.astype(np.float32).astype(np.float64), add_bias=True, singular_x_tol=0.0)
+        assert np.linalg.norm(np.r_[lr.coeffs(), lr.bias()] - bo) / np.linalg.norm(bo) < 1e-4
+    finally:
+        pds.config.LIN_REG_EXPR_F64 = True
+        lib.pds_set_host_staging(256.0, 98304.0)
+
+
 # ------------------------------------------------------------------------------------------ GLM (IRLS)
 def _glm_family_data(family, rng, n=500, p=4):
     """tests/test_linear_models.py:199-232 of the reference: the four y generators."""
