@@ -18,6 +18,8 @@ measure the Gram build GB/s, reported under "gram_build".
   end_to_end    the SAME workload when the frame starts in HOST memory as Arrow buffers and goes through the plugin
                 boundary (`_polars_plugin_pl_lr_by`, `_polars_plugin_pl_lr`): wall clock, bytes over PCIe, fraction of the
                 measured pinned-copy PCIe rate.  This is the rate a Polars user sees; `value` is the HBM-resident rate.
+  other_configs   the other BASELINE.json configs on the same box (HBM resident): lin_reg_report at C2 (SE and HC1, wall clock of
+                the whole call), rolling / expanding fits at C4 (1e8 x 8, window 256; kernel time by HIP events).
   grouped_c3spec  SURVEY.md 8(d)'s C3 data (Poisson(100) sizes in [16, 256], 0.1 % collinear groups -> the rank gate fires,
                 8 features), keys sorted and shuffled.
 
@@ -283,6 +285,14 @@ def main() -> int:
         except Exception as e:  # pyarrow / harness trouble must not cost the headline line
             end_to_end = {"error": f"{type(e).__name__}: {e}"}
 
+    # ---- the other BASELINE configs, on the headline frame where they share it (C2) and on a C4 frame
+    other = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        try:
+            other = _other_configs(torch, pds, ctx, dev, xs, y, N, P)
+        except Exception as e:
+            other = {"error": f"{type(e).__name__}: {e}"}
+
     # ---- SURVEY.md 8(d) C3 data: Poisson sizes, collinear groups (the gate fires inside the timed run), sorted and shuffled keys
     c3 = None
     if rank == 0 and world == 1 and not args.no_extras:
@@ -314,7 +324,7 @@ def main() -> int:
                        "groups_total": G_total, "groups_per_gpu": G, "rows_per_group": R, "features": P,
                        "parallelism": f"group-sharded x{world}", "gather_chunks": chunks if gather else None},
             "roofline": roofline, "gram_build": gram, "grouped_p8": p8, "cpu_baseline": cpu, "parity_spot_check": parity,
-            "end_to_end": end_to_end, "grouped_c3spec": c3, "scatter": scatter,
+            "end_to_end": end_to_end, "other_configs": other, "grouped_c3spec": c3, "scatter": scatter,
         }
         print(json.dumps(line), flush=True)
     if use_dist:
@@ -375,6 +385,45 @@ def _end_to_end(torch, np, pds, dev, xs, y, G, R, P, cpu):
         out["gpu_over_cpu_host_resident"] = round(G / t_by / cpu["value"], 1)
         out["note"] = ("host-resident frames are PCIe bound: this ratio, not the HBM-resident one, is what an unchanged Polars "
                        "query sees on one GPU")
+    return out
+
+
+def _other_configs(torch, pds, ctx, dev, xs, y, N, P):
+    out = {}
+
+    def wall(fn, reps=3):
+        fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    gb = N * (P + 1) * 8 / 1e9
+    for se in ("se", "hc1"):
+        ms = wall(lambda: pds.lin_reg_report(*xs, target=y, add_bias=True, std_err=se, ctx=ctx))
+        streams = 2  # Gram + one more pass (residual pass, or the fused residual + meat pass)
+        out[f"report_c2_{se}"] = {"wall_ms": round(ms, 3), "streams_over_the_frame": streams,
+                                  "frac_of_hbm_peak": round(streams * gb / ms * 1e3 / HBM_PEAK_GBPS, 4)}
+    n, p, w = 100_000_000, 8, 256
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(3)
+    rx = [torch.rand(n, dtype=torch.float64, device=dev, generator=gen) for _ in range(p)]
+    ry = sum(rx[j] * (0.1 * (j + 1)) for j in range(p)) + 1e-3 * torch.randn(n, dtype=torch.float64, device=dev, generator=gen)
+    alg = n * ((p + 1) * 8 + (p + 1) * 8 + 8) / 1e9  # 152 B per row at p' = 8
+    for name, fn in (("rolling_c4", lambda: pds.rolling_lin_reg(*rx, target=ry, window_size=w, ctx=ctx)),
+                     ("expanding_1e8x8", lambda: pds.recursive_lin_reg(*rx, target=ry, start_with=w, ctx=ctx))):
+        fn()
+        ctx.get_timing(reset=True)
+        ctx.set_timing(True)
+        for _ in range(3):
+            fn()
+        ctx.set_timing(False)
+        t = ctx.get_timing(reset=True)["rolling"]
+        ms = t[0] / 3  # (the expanding fit is several launches per call)
+        out[name] = {"rows": n, "coefficients": p, "window": w, "kernel_ms": round(ms, 3), "rows_per_s": round(n / ms * 1e3, 1),
+                     "algorithmic_GBps": round(alg / ms * 1e3, 1), "frac_of_hbm_peak": round(alg / ms * 1e3 / HBM_PEAK_GBPS, 4)}
     return out
 
 

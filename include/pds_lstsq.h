@@ -192,7 +192,8 @@ int pds_lr_rcond_f32(pds_ctx* ctx, const float* const* cols, int n_feat, int64_t
 /*
  * pds_lin_reg_report_*: the arithmetic of `pl_lin_reg_report` (linear_regression.rs:822-980) and, with
  * weights != NULL, `pl_wls_report` (:982-1117).  y_var is inputs[0][0] of the expression
- * (`target.var()`, ddof = 1, computed by Polars; expr_linear.py:614-617).  Each output has
+ * (`target.var()`, ddof = 1, computed by Polars; expr_linear.py:614-617); pass NaN (unweighted form) and the library takes
+ * it from the Gram pass the report makes anyway (sum y and sum y^2 are entries of the moment matrix).  Each output has
  * n_feat + add_bias entries; r2 / adj_r2 are scalars (the reference broadcasts them).
  */
 typedef struct {

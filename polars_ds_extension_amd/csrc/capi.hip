@@ -1045,7 +1045,19 @@ static int report_impl(pds_ctx* ctx, const T* const* cols, const T* weights, int
     PDS_HIP_CHECK(hipMemcpyAsync(inv.data(), d_inv, sizeof(T) * pp * pp, hipMemcpyDeviceToHost, ctx->stream));
     PDS_HIP_CHECK(hipMemcpyAsync(sums, d_sums, sizeof(sums), hipMemcpyDeviceToHost, ctx->stream));
     if (hc) PDS_HIP_CHECK(hipMemcpyAsync(meat.data(), d_mom2, sizeof(T) * q * q, hipMemcpyDeviceToHost, ctx->stream));
+    // y_var = NaN: take the target's sample variance (ddof = 1, what Polars evaluates as `target.var()` and hands over as input
+    // 0, expr_linear.py:614-617) from the Gram pass this call has just made -- sum y and sum y^2 are entries of the moment matrix
+    T mom_y[2] = {T(0), T(0)};
+    const bool derive_var = !(y_var == y_var) && !weighted;
+    if (derive_var) {
+        PDS_HIP_CHECK(hipMemcpyAsync(&mom_y[0], d_mom + p + (size_t)(p + 1) * q, sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+        PDS_HIP_CHECK(hipMemcpyAsync(&mom_y[1], d_mom + (p + 1) + (size_t)(p + 1) * q, sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+    }
     PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (derive_var) {
+        const double nn = (double)n_rows, sy = (double)mom_y[0], syy = (double)mom_y[1];
+        y_var = (T)((syy - sy * sy / nn) / (nn - 1.0));
+    }
     report_epilogue<T, R>(n_rows, p, bias, se_type, weighted, y_var, beta.data(), inv.data(), meat.data(), sums, out);
     return PDS_OK;
 }

@@ -599,16 +599,157 @@ int launch_grouped_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, co
     return PDS_OK;
 }
 
+// f64, 16 bytes per lane: lane L loads the feature PAIR (2 f', 2 f' + 1), f' = L & 7, of row slot L >> 3 -- the 64 lanes of
+// one instruction read 8 consecutive rows of 16 features = 1 KiB contiguous at ld = 16, like the column kernels' loads.
+// As an MFMA operand, lane (i = L & 15, k = L >> 4) then carries feature 2 (i & 7) [.x] / 2 (i & 7) + 1 [.y] of row
+// 2 k + (i >> 3): three matrix instructions per 8 rows -- x.x, x.y, y.y -- whose two diagonal 8 x 8 blocks (rows 2 k and
+// rows 2 k + 1) sum to the even-even, even-odd and odd-odd blocks of the Gram matrix (the off-diagonal blocks are cross terms
+// of different rows nobody reads).  1.5x the matrix work of the column kernel (1.5 ms of pipe per 1e8 rows, still under the
+// HBM time) for loads that are as wide as the link likes them: 8 B per lane ran at 0.39 of the HBM peak.
+#ifndef PDS_ROWMAJOR_U
+#define PDS_ROWMAJOR_U 4
+#endif
+#ifndef PDS_ROWMAJOR_BLOCKS
+#define PDS_ROWMAJOR_BLOCKS 4
+#endif
+__global__ __launch_bounds__(256, PDS_ROWMAJOR_BLOCKS) void moments_rowmajor_f64_kernel(const double* __restrict__ X, int64_t ld,
+                                                                      const double* __restrict__ y, int p, int64_t n,
+                                                                      double* __restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int U = PDS_ROWMAJOR_U;  // 8-row steps per iteration.  Measured at 1e8 x 16 (profiles/r02_rowmajor_ab.txt): U = 4 with
+    // four resident blocks (16 waves per CU) 2.77 ms, U = 8 x 3 blocks 3.24, U = 16 x 2 blocks 4.89: many waves with short bursts beat
+    // few waves with deep ones here (the y loads are 8-fold redundant per instruction, the matrix pipe runs 1.5x the column kernel's work)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fp = lane & 7, rs = lane >> 3;
+    const int f0 = 2 * fp;
+    const bool has0 = f0 < p, has1 = f0 + 1 < p;
+    const gptr<double> Xg = as_global(X);
+    const gptr<double> yg = as_global(y);
+    const int64_t wid = (int64_t)blockIdx.x * kWaves + wave, nw = (int64_t)gridDim.x * kWaves;
+    const int64_t nit = (n + 8 * U - 1) / (8 * U);
+    int64_t it = (int64_t)(((__int128)nit * wid) / nw);
+    const int64_t it_end = (int64_t)(((__int128)nit * (wid + 1)) / nw);
+    d4 ee = {0, 0, 0, 0}, eo = {0, 0, 0, 0}, oo = {0, 0, 0, 0};
+    double xy0 = 0, xy1 = 0, cs0 = 0, cs1 = 0, yy = 0, ys = 0;
+    d2u xa[U];
+    double ya[U];
+    auto load_iter = [&](int64_t i, d2u (&xv)[U], double (&yv)[U]) __attribute__((always_inline)) {
+        const int64_t r0 = i * (8 * U) + rs;
+        const bool full = (i + 1) * (8 * U) <= n;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t r = r0 + 8 * u;
+            const bool in = full || r < n;
+            d2u v = {0.0, 0.0};
+            if (in && has1) v = __builtin_nontemporal_load(reinterpret_cast<gptr<d2u>>(Xg + r * ld + f0));
+            else if (in && has0) v[0] = Xg[r * ld + f0];
+            xv[u] = v;
+            yv[u] = in ? __builtin_nontemporal_load(yg + r) : 0.0;
+        }
+    };
+    if (it < it_end) load_iter(it, xa, ya);
+    for (; it < it_end; ++it) {
+        d2u xb[U];
+        double yb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            xb[u] = xa[u];
+            yb[u] = ya[u];
+        }
+        if (it + 1 < it_end) load_iter(it + 1, xa, ya);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const double a = xb[u][0], b = xb[u][1], t = yb[u];
+            ee = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, ee, 0, 0, 0);
+            eo = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, eo, 0, 0, 0);
+            oo = __builtin_amdgcn_mfma_f64_16x16x4f64(b, b, oo, 0, 0, 0);
+            xy0 = fma(a, t, xy0);
+            xy1 = fma(b, t, xy1);
+            cs0 += a;
+            cs1 += b;
+            yy = fma(t, t, yy);
+            ys += t;
+        }
+    }
+    // ---- wave record in the layout of moments_small_kernel (D tile 16 x 16, xy, cs, yy, ys)
+    __syncthreads();
+    double* raw = reinterpret_cast<double*>(smem) + kWaves * kPartStride + wave * 768;  // three raw 16 x 16 product tiles
+    double* rec = reinterpret_cast<double*>(smem) + wave * kPartStride;
+    {
+        const int j = lane & 15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = (lane >> 4) + 4 * r;  // D layout of v_mfma_f64_16x16x4: col = lane & 15, row = (lane >> 4) + 4 reg
+            raw[i + 16 * j] = ee[r];
+            raw[256 + i + 16 * j] = eo[r];
+            raw[512 + i + 16 * j] = oo[r];
+        }
+    }
+    // per-feature sums: over the 8 row slots (lane bits 3..5)
+#pragma unroll
+    for (int o = 8; o <= 32; o <<= 1) {
+        xy0 += __shfl_xor(xy0, o);
+        xy1 += __shfl_xor(xy1, o);
+        cs0 += __shfl_xor(cs0, o);
+        cs1 += __shfl_xor(cs1, o);
+        yy += __shfl_xor(yy, o);
+        ys += __shfl_xor(ys, o);
+    }
+    PDS_WAVE_LDS_SYNC();
+    for (int e = lane; e < 256; e += 64) {
+        const int a = e & 15, b = e >> 4;  // features
+        const int ia = a >> 1, ib = b >> 1;
+        double v;
+        if (!(a & 1) && !(b & 1)) v = raw[ia + 16 * ib] + raw[(ia + 8) + 16 * (ib + 8)];
+        else if (!(a & 1) && (b & 1)) v = raw[256 + ia + 16 * ib] + raw[256 + (ia + 8) + 16 * (ib + 8)];
+        else if ((a & 1) && !(b & 1)) v = raw[256 + ib + 16 * ia] + raw[256 + (ib + 8) + 16 * (ia + 8)];
+        else v = raw[512 + ia + 16 * ib] + raw[512 + (ia + 8) + 16 * (ib + 8)];
+        rec[kPartD + a + 16 * b] = v;
+    }
+    if (lane < 8) {
+        rec[kPartXY + 2 * lane] = xy0;
+        rec[kPartXY + 2 * lane + 1] = xy1;
+        rec[kPartCS + 2 * lane] = cs0;
+        rec[kPartCS + 2 * lane + 1] = cs1;
+    }
+    if (lane == 0) {
+        rec[kPartYY] = yy;
+        rec[kPartYS] = ys;
+        rec[kPartSW] = 0.0;
+    }
+    __syncthreads();
+    const double* recs = reinterpret_cast<const double*>(smem);
+    for (int e = threadIdx.x; e < kPartStride; e += blockDim.x) {
+        double sum = 0.0;
+        if (e <= kPartSW) {
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) sum += recs[w * kPartStride + e];
+        }
+        partials[(int64_t)blockIdx.x * kPartStride + e] = sum;
+    }
+}
+
 template <typename T>
 int launch_moments_rowmajor(pds_ctx* ctx, const T* d_X, int64_t ld, const T* d_y, int n_feat, int64_t n_rows, T* d_moments,
                             double* d_moments_f64) {
     if (n_feat < 1 || n_feat > kMaxFeatSmall) return fail(PDS_ERR_INVALID, "internal: the row-major Gram kernel takes 1..16 features");
     const int64_t nit = (n_rows + 31) / 32;
-    const int nblocks = (int)std::min<int64_t>(std::max<int64_t>((nit + kWaves - 1) / kWaves, 1), (int64_t)ctx->num_cus * 2);
+    const int per_cu = sizeof(T) == 8 ? PDS_ROWMAJOR_BLOCKS : 2;
+    const int nblocks = (int)std::min<int64_t>(std::max<int64_t>((nit + kWaves - 1) / kWaves, 1), (int64_t)ctx->num_cus * per_cu);
     double* partials = ctx->partials;
     KernelTimer timer(ctx, kKindMoments);
-    hipLaunchKernelGGL((moments_rowmajor_kernel<T>), dim3(nblocks), dim3(256), (size_t)kWaves * kPartStride * sizeof(double), ctx->stream,
-                       d_X, ld, d_y, n_feat, n_rows, partials);
+    if constexpr (sizeof(T) == 8) {
+        static const bool narrow = [] { const char* e = std::getenv("PDS_ROWMAJOR_NARROW"); return e && e[0] == '1'; }();  // (A/B)
+        if (!narrow)
+            hipLaunchKernelGGL(moments_rowmajor_f64_kernel, dim3(nblocks), dim3(256), (size_t)kWaves * (kPartStride + 768) * sizeof(double),
+                               ctx->stream, d_X, ld, d_y, n_feat, n_rows, partials);
+        else
+            hipLaunchKernelGGL((moments_rowmajor_kernel<T>), dim3(nblocks), dim3(256), (size_t)kWaves * kPartStride * sizeof(double),
+                               ctx->stream, d_X, ld, d_y, n_feat, n_rows, partials);
+    } else {
+        hipLaunchKernelGGL((moments_rowmajor_kernel<T>), dim3(nblocks), dim3(256), (size_t)kWaves * kPartStride * sizeof(double), ctx->stream,
+                           d_X, ld, d_y, n_feat, n_rows, partials);
+    }
     if (d_moments_f64)
         hipLaunchKernelGGL((moments_finalize_kernel<double>), dim3(kPartSW + 1), dim3(64), 0, ctx->stream, partials, nblocks, n_feat,
                            (double)n_rows, 0, 0, d_moments_f64, (double*)nullptr);

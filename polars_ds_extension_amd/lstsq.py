@@ -442,11 +442,14 @@ def lin_reg_report(*x, target, add_bias: bool = False, weights=None, std_err: st
     _follow(ctx, cols)
     pp = cols.n_feat + int(bool(add_bias))
     if y_var is None:
-        M = gram_moments(*x, target=target, ctx=ctx)
-        q = cols.n_feat + 2
-        n = float(cols.n_rows)
-        sy, syy = float(M[q - 2, q - 1]), float(M[q - 1, q - 1])
-        y_var = (syy - sy * sy / n) / (n - 1.0)
+        if weights is None:
+            y_var = float("nan")  # the library derives it from the Gram pass the report makes anyway (sum y, sum y^2)
+        else:
+            M = gram_moments(*x, target=target, ctx=ctx)
+            q = cols.n_feat + 2
+            n = float(cols.n_rows)
+            sy, syy = float(M[q - 2, q - 1]), float(M[q - 1, q - 1])
+            y_var = (syy - sy * sy / n) / (n - 1.0)
     dt = _dtype()
     outs = {k: np.empty(pp, dtype=dt) for k in ("beta", "std_err", "t", "p", "ci_lower", "ci_upper")}
     R = _lib.ReportF64 if config.LIN_REG_EXPR_F64 else _lib.ReportF32

@@ -233,6 +233,8 @@ def make_callbacks(sfx):
     def report(ctx, cols_p, w_p, n_feat, n, space, bias, se_type, y_var, out_p):
         _check_shape(n_feat, n, bias)
         cols = _columns(cols_p, n_feat + 1, n, dt)
+        if y_var != y_var and not w_p:  # NaN: the library derives target.var() (ddof = 1) from its own Gram pass
+            y_var = float(np.var(np.asarray(cols[0], dtype=np.float64), ddof=1))
         run_report(X_of(cols), cols[0], _view(w_p, n, dt) if w_p else None, bool(bias), se_type, y_var, out_p)
         return OK
 

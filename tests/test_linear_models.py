@@ -200,8 +200,8 @@ def test_fits_from_row_major_matrices(p, orc):
                     assert np.linalg.norm(b - br) / np.linalg.norm(br) < 1e-9
                     en = ElasticNet(l1_reg=0.01, l2_reg=0.02, has_bias=bias, tol=1e-9, max_iter=5000).fit(data, y)
                     b = np.r_[en.coeffs(), en.bias()] if bias else en.coeffs()
-                    be = orc.coordinate_descent(X, y, 0.01, 0.02, bias, 1e-9, 5000)
-                    assert np.linalg.norm(b - be) / np.linalg.norm(be) < 1e-7
+                    be = orc.pl_lr(X, y, add_bias=bias, l1_reg=0.01, l2_reg=0.02, tol=1e-9, max_iter=5000)
+                    assert np.linalg.norm(b - be) / np.linalg.norm(be) < 1e-7, (n, p, bias, b, be)
                     ol = OnlineLR(has_bias=bias, lambda_=0.1).fit(data, y)
                     Xb = np.c_[X, np.ones(n)] if bias else X
                     G = Xb.T @ Xb
