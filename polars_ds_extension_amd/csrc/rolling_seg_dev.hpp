@@ -334,91 +334,60 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #else
             const bool more = nb < t1;
 #endif
-#ifdef PDS_ROLL_DEEP
-            // batch i of the next stage's pieces is committed to LDS one row LATER (behind row i + 1's solve): two batches
-            // are in flight, each has two solves (~2 us) to arrive instead of one
-            V16 tmp2[2][PER_BATCH];
-#endif
-#pragma unroll
-            for (int i = 0; i < K; ++i) {
-#ifdef PDS_ROLL_DEEP
-                V16 (&tmp)[PER_BATCH] = tmp2[i & 1];
-#else
-                V16 tmp[PER_BATCH];
-#endif
-                if (more) {
-#pragma unroll
-                    for (int j = 0; j < PER_BATCH; ++j)
-                        if (i * PER_BATCH + j < NLOAD) issue(i * PER_BATCH + j, nb, tmp[j]);
-                }
-#ifdef PDS_ROLL_LDS_DIRECT
-                // The compiler does not order LDS reads behind global_load_lds (its ISA for this kernel has no vmcnt wait in
-                // front of the next stage's ds_reads), so the wave waits itself: in front of the LAST row -- the burst was
-                // issued three rows (~10 000 clk) ago, and the stores of this row then stay in flight across the loop edge.
-                if (i == K - 1 && direct) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-                if (okn[i]) seg_accumulate<PP, NV, 1>(S, rn[i], true);
-                if constexpr (MODE == 0) {
-                    if (oko[i]) seg_accumulate<PP, NV, -1>(S, ro[i], true);
-                }
-                const int64_t r = r0 + i;
-                // L D L' of (G + lambda I) in a work copy; idx(a, b), a <= b -> a * PP - a (a - 1) / 2 + (b - a).
-                // Padding dimensions (a >= p') have zero rows and a unit diagonal: beta_pad = 0.
-                double g[NG], c[PP], rd[PP];
+            auto diag_add = [&](int a) __attribute__((always_inline)) { return (a < ra.pp) ? lambda : 1.0; };
+#define GI(g, a, b) g[(a) * PP - ((a) * ((a)-1)) / 2 + ((b) - (a))]
+            // step 0 of the L D L' of (G + lambda I) reads the running sums and writes the work copy (no register copy of the NG
+            // values); idx(a, b), a <= b -> a * PP - a (a - 1) / 2 + (b - a).  Padding dimensions (a >= p') have zero rows
+            // and a unit diagonal: beta_pad = 0.
+            auto fact_first = [&](double (&g)[NG], double (&c)[PP], double (&rd)[PP], bool& okc) __attribute__((always_inline)) {
 #pragma unroll
                 for (int a = 0; a < PP; ++a) c[a] = S[NG + a];
-#define GI(a, b) g[(a) * PP - ((a) * ((a)-1)) / 2 + ((b) - (a))]
-#define SI(a, b) S[(a) * PP - ((a) * ((a)-1)) / 2 + ((b) - (a))]
-                auto diag_add = [&](int a) __attribute__((always_inline)) { return (a < ra.pp) ? lambda : 1.0; };
-                bool okc = true;
-                {   // step 0 reads the running sums and writes the work copy: no register copy of the NG values
-                    const double d = SI(0, 0) + diag_add(0);
-                    okc = d > 0.0;
-                    double x = __builtin_amdgcn_rcp(d);
-                    x = x * fma(-d, x, 2.0);
-                    x = x * fma(-d, x, 2.0);
-                    rd[0] = x;
+                const double d = GI(S, 0, 0) + diag_add(0);
+                okc = d > 0.0;
+                double x = __builtin_amdgcn_rcp(d);
+                x = x * fma(-d, x, 2.0);
+                x = x * fma(-d, x, 2.0);
+                rd[0] = x;
 #pragma unroll
-                    for (int a = 1; a < PP; ++a) {
-                        const double tka = SI(0, a) * x;
+                for (int a = 1; a < PP; ++a) {
+                    const double tka = GI(S, 0, a) * x;
 #pragma unroll
-                        for (int b = a; b < PP; ++b) GI(a, b) = fma(-tka, SI(0, b), SI(a, b) + ((a == b) ? diag_add(a) : 0.0));
-                        GI(0, a) = tka;
-                    }
+                    for (int b = a; b < PP; ++b) GI(g, a, b) = fma(-tka, GI(S, 0, b), GI(S, a, b) + ((a == b) ? diag_add(a) : 0.0));
+                    GI(g, 0, a) = tka;
                 }
+            };
+            auto fact_step = [&](int k, double (&g)[NG], double (&rd)[PP], bool& okc) __attribute__((always_inline)) {
+                const double d = GI(g, k, k);
+                okc = okc && (d > 0.0);
+                double x = __builtin_amdgcn_rcp(d);
+                x = x * fma(-d, x, 2.0);
+                x = x * fma(-d, x, 2.0);
+                rd[k] = x;
 #pragma unroll
-                for (int k = 1; k < PP; ++k) {
-                    const double d = GI(k, k);
-                    okc = okc && (d > 0.0);
-                    double x = __builtin_amdgcn_rcp(d);
-                    x = x * fma(-d, x, 2.0);
-                    x = x * fma(-d, x, 2.0);
-                    rd[k] = x;
+                for (int a = k + 1; a < PP; ++a) {
+                    const double tka = GI(g, k, a) * x;  // l_ak
 #pragma unroll
-                    for (int a = k + 1; a < PP; ++a) {
-                        const double tka = GI(k, a) * x;  // l_ak
-#pragma unroll
-                        for (int b = a; b < PP; ++b) GI(a, b) = fma(-tka, GI(k, b), GI(a, b));
-                        GI(k, a) = tka;
-                    }
+                    for (int b = a; b < PP; ++b) GI(g, a, b) = fma(-tka, GI(g, k, b), GI(g, a, b));
+                    GI(g, k, a) = tka;
                 }
-#undef SI
-                // L u = c, D v = u, L' beta = v
+            };
+            // L u = c, D v = u, L' beta = v -- one substitution step at a time, so that two systems can be walked in lockstep
+            auto fwd_step = [&](int a, const double (&g)[NG], double (&c)[PP]) __attribute__((always_inline)) {
 #pragma unroll
-                for (int a = 1; a < PP; ++a)
+                for (int k = 0; k < PP; ++k)
+                    if (k < a) c[a] = fma(-GI(g, k, a), c[k], c[a]);
+            };
+            auto bwd_step = [&](int a, const double (&g)[NG], double (&c)[PP]) __attribute__((always_inline)) {
 #pragma unroll
-                    for (int k = 0; k < a; ++k) c[a] = fma(-GI(k, a), c[k], c[a]);
-#pragma unroll
-                for (int a = 0; a < PP; ++a) c[a] *= rd[a];
-#pragma unroll
-                for (int a = PP - 2; a >= 0; --a)
-#pragma unroll
-                    for (int k = a + 1; k < PP; ++k) c[a] = fma(-GI(a, k), c[k], c[a]);
-#undef GI
+                for (int k = 0; k < PP; ++k)
+                    if (k > a) c[a] = fma(-GI(g, a, k), c[k], c[a]);
+            };
+            auto emit = [&](int i, const double (&c)[PP], bool okc, double cnt) __attribute__((always_inline)) {
+                const int64_t r = r0 + i;
                 if (r < t1) {
                     const T nanv = (T)__builtin_nan("");
                     bool v_ok = r >= w - 1;
-                    if (ra.min_size > 0) v_ok = v_ok && (S[NV - 1] >= (double)ra.min_size);
+                    if (ra.min_size > 0) v_ok = v_ok && (cnt >= (double)ra.min_size);
                     double pr = 0.0;
 #pragma unroll
                     for (int a = 0; a < PP; ++a) pr = fma(rn[i].z[a], c[a], pr);
@@ -431,51 +400,108 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                             V16 o;
 #pragma unroll
                             for (int e = 0; e < E16; ++e) o[e] = good ? (T)c[a + e] : nanv;
-#ifdef PDS_ROLL_NT_STORE
-                            __builtin_nontemporal_store(o, reinterpret_cast<V16*>(out + a));
-#else
                             *reinterpret_cast<V16*>(out + a) = o;
-#endif
                         }
                     } else {
 #pragma unroll
                         for (int a = 0; a < PP; ++a)
                             if (a < ra.pp) out[a] = good ? (T)c[a] : nanv;
                     }
-#ifdef PDS_ROLL_NT_STORE
-                    __builtin_nontemporal_store((good && okn[i]) ? (T)pr : nanv, pred + r);
-                    __builtin_nontemporal_store((uint8_t)(v_ok ? 1 : 0), valid + r);
-#else
                     pred[r] = (good && okn[i]) ? (T)pr : nanv;  // (a non-finite row: x_r . beta is NaN in the reference too)
                     valid[r] = v_ok ? 1 : 0;
-#endif
                 }
+            };
+            auto advance = [&](int i) __attribute__((always_inline)) {  // the window moves on by row i of the lane
+                if (okn[i]) seg_accumulate<PP, NV, 1>(S, rn[i], true);
+                if constexpr (MODE == 0) {
+                    if (oko[i]) seg_accumulate<PP, NV, -1>(S, ro[i], true);
+                }
+            };
+#ifdef PDS_ROLL_PAIR
+            // Two rows' factorisations in lockstep: the dependent chains of one (pivot reciprocal + two Newton steps, the
+            // substitution recurrences) fill the latency slots of the other.  Measured: 4.79 vs 4.80 ms at C4 -- the scheduler
+            // already overlaps what can be overlapped; kept behind the flag for the record (profiles/r02_rolling_variants_ab.txt).
+            static_assert(K % 2 == 0, "rows are walked in pairs");
+#pragma unroll
+            for (int i = 0; i < K; i += 2) {
+#ifdef PDS_ROLL_LDS_DIRECT
+                if (i == K - 2 && direct) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (see the single-row form below)
+#endif
+                double g0[NG], g1[NG], c0[PP], c1[PP], rd0[PP], rd1[PP];
+                bool ok0 = true, ok1 = true;
+                advance(i);
+                const double cnt0 = S[NV - 1];
+                fact_first(g0, c0, rd0, ok0);
+                advance(i + 1);
+                const double cnt1 = S[NV - 1];
+                fact_first(g1, c1, rd1, ok1);
+#pragma unroll
+                for (int k = 1; k < PP; ++k) {
+                    fact_step(k, g0, rd0, ok0);
+                    fact_step(k, g1, rd1, ok1);
+                }
+#pragma unroll
+                for (int a = 1; a < PP; ++a) {
+                    fwd_step(a, g0, c0);
+                    fwd_step(a, g1, c1);
+                }
+#pragma unroll
+                for (int a = 0; a < PP; ++a) {
+                    c0[a] *= rd0[a];
+                    c1[a] *= rd1[a];
+                }
+#pragma unroll
+                for (int a = PP - 2; a >= 0; --a) {
+                    bwd_step(a, g0, c0);
+                    bwd_step(a, g1, c1);
+                }
+                emit(i, c0, ok0, cnt0);
+                emit(i + 1, c1, ok1, cnt1);
+            }
+            (void)more;
+#else
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                V16 tmp[PER_BATCH];
+                if (more) {
+#pragma unroll
+                    for (int j = 0; j < PER_BATCH; ++j)
+                        if (i * PER_BATCH + j < NLOAD) issue(i * PER_BATCH + j, nb, tmp[j]);
+                }
+#ifdef PDS_ROLL_LDS_DIRECT
+                // The compiler does not order LDS reads behind global_load_lds (its ISA for this kernel has no vmcnt wait in
+                // front of the next stage's ds_reads), so the wave waits itself: in front of the LAST row -- the burst was
+                // issued three rows (~10 000 clk) ago, and the stores of this row then stay in flight across the loop edge.
+                if (i == K - 1 && direct) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                advance(i);
+                double g[NG], c[PP], rd[PP];
+                bool okc = true;
+                fact_first(g, c, rd, okc);
+#pragma unroll
+                for (int k = 1; k < PP; ++k) fact_step(k, g, rd, okc);
+#pragma unroll
+                for (int a = 1; a < PP; ++a) fwd_step(a, g, c);
+#pragma unroll
+                for (int a = 0; a < PP; ++a) c[a] *= rd[a];
+#pragma unroll
+                for (int a = PP - 2; a >= 0; --a) bwd_step(a, g, c);
+                emit(i, c, okc, S[NV - 1]);
                 if (more) {
 #ifdef PDS_PROFILE_ROLLING
                     const unsigned long long _tc = __builtin_amdgcn_s_memtime();
 #endif
-#ifdef PDS_ROLL_DEEP
-                    if (i > 0) {
-#pragma unroll
-                        for (int j = 0; j < PER_BATCH; ++j)
-                            if ((i - 1) * PER_BATCH + j < NLOAD) commit((i - 1) * PER_BATCH + j, tmp2[(i - 1) & 1][j]);
-                    }
-                    if (i == K - 1) {
-#pragma unroll
-                        for (int j = 0; j < PER_BATCH; ++j)
-                            if (i * PER_BATCH + j < NLOAD) commit(i * PER_BATCH + j, tmp2[i & 1][j]);
-                    }
-#else
 #pragma unroll
                     for (int j = 0; j < PER_BATCH; ++j)
                         if (i * PER_BATCH + j < NLOAD) commit(i * PER_BATCH + j, tmp[j]);
-#endif
 #ifdef PDS_PROFILE_ROLLING
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     rprof[5] += __builtin_amdgcn_s_memtime() - _tc;
 #endif
                 }
             }
+#endif
+#undef GI
 #ifdef PDS_ROLL_LDS_DIRECT
             if (edge) {
 #pragma unroll 1
