@@ -222,6 +222,57 @@ def test_fits_from_row_major_matrices(p, orc):
         lib.pds_set_host_staging(256.0, 98304.0)
 
 
+@pytest.mark.gpu
+def test_new_entry_points_reject_bad_arguments():
+    """pds_lr_rowmajor_* / pds_glm_irls_* / pds_rows_to_cols_*: argument errors come back as codes + messages, nothing runs."""
+    import ctypes as C
+
+    import torch
+
+    from polars_ds_extension_amd import _lib, lstsq
+
+    lib = _lib.load()
+    ctx = lstsq.default_context()
+    X = np.ascontiguousarray(np.random.default_rng(0).normal(size=(50, 3)))
+    y = np.ascontiguousarray(X @ [1.0, 2.0, 3.0])
+    co = np.zeros(4)
+    prm = lstsq._params(True, 0.0, 0.0, 1e-5, "qr", False, 200, 0.0)
+    null = C.c_int(0)
+
+    def rowmajor(ld=3, n=50, p=3, mode=0, inv=None):
+        return lib.pds_lr_rowmajor_f64(ctx._h, C.c_void_p(X.ctypes.data), C.c_int64(ld), C.c_void_p(y.ctypes.data), C.c_int64(n), C.c_int(p),
+                                       C.c_int(_lib.PDS_HOST), C.byref(prm), C.c_int(mode), C.c_void_p(co.ctypes.data), C.byref(null),
+                                       C.c_void_p(inv))
+
+    assert rowmajor() == 0 and np.allclose(co[:3], [1.0, 2.0, 3.0], atol=1e-9)
+    assert rowmajor(ld=2) != 0 and b"stride" in lib.pds_last_error()
+    assert rowmajor(mode=2) != 0 and b"inv" in lib.pds_last_error()  # OnlineLR mode needs the inverse buffer
+    assert rowmajor(mode=7) != 0
+    assert rowmajor(n=0) != 0 and b"Empty" in lib.pds_last_error()
+    assert rowmajor(n=2) != 0 and b"#Data < #features" in lib.pds_last_error()
+    keep = [np.ascontiguousarray(X[:, j]) for j in range(3)]
+    cols = (C.c_void_p * 4)(y.ctypes.data, *[k.ctypes.data for k in keep])
+    it = C.c_int(0)
+
+    def glm(link=0, var=0, max_iter=10, p=3, n=50):
+        return lib.pds_glm_irls_f64(ctx._h, cols, C.c_int(p), C.c_int64(n), C.c_int(_lib.PDS_HOST), 1, C.c_int(link), C.c_int(var),
+                                    C.c_double(1e-8), C.c_int(max_iter), C.c_void_p(co.ctypes.data), C.byref(it))
+
+    assert glm() == 0 and it.value >= 1 and np.allclose(co[:3], [1.0, 2.0, 3.0], atol=1e-7)
+    assert glm(link=4) != 0 and glm(var=-1) != 0
+    assert glm(max_iter=0) != 0 and b"max_iter" in lib.pds_last_error()
+    assert glm(p=17) != 0 and b"16" in lib.pds_last_error()
+    assert glm(n=0) != 0 and b"Empty" in lib.pds_last_error()
+    out = torch.empty((3, 50), dtype=torch.float64, device="cuda")
+
+    def r2c(ld=3, stride=50, n=50):
+        return lib.pds_rows_to_cols_f64(ctx._h, C.c_void_p(X.ctypes.data), C.c_int64(ld), C.c_int64(n), C.c_int(3), C.c_int(_lib.PDS_HOST),
+                                        C.c_void_p(out.data_ptr()), C.c_int64(stride))
+
+    assert r2c() == 0 and np.array_equal(out.cpu().numpy(), X.T)
+    assert r2c(ld=2) != 0 and r2c(stride=49) != 0 and r2c(n=0) != 0
+
+
 # ------------------------------------------------------------------------------------------ GLM (IRLS)
 def _glm_family_data(family, rng, n=500, p=4):
     """tests/test_linear_models.py:199-232 of the reference: the four y generators."""
