@@ -1,0 +1,395 @@
+// capi_grouped.hpp -- grouped regressions: contiguous groups, weighted groups, int64 keys in any row order
+// Part of the one translation unit capi.hip (included there, inside namespace pds, in dependency order): the entry-point
+// pipelines are templates with internal linkage, split by concern, not by compilation unit.
+#pragma once
+
+// ---------------------------------------------------------------------------------------------
+// grouped
+// ---------------------------------------------------------------------------------------------
+// Groups with more than 64 features (coverage path): every group's Gram matrix comes from the tiled matrix-core SYRK of the
+// single-regression path (moments_wide.hip) on that group's row range, the records of a chunk of groups are then solved
+// together (solve_big.hip: Cholesky on an L2-resident workspace, one workgroup per system; CD / NNLS: one wavefront each).
+__global__ void mark_small_groups_kernel(const int64_t* __restrict__ off, int64_t n_groups, int pp, uint8_t* __restrict__ flags) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n_groups && off[g + 1] - off[g] < pp) flags[g] = 1;
+}
+template <typename T>
+__global__ void nan_flagged_kernel(const uint8_t* __restrict__ flags, int64_t n_groups, int pp, T* __restrict__ coeffs) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_groups * pp && flags[i / pp]) coeffs[i] = (T)__builtin_nan("");
+}
+
+template <typename T>
+static int grouped_big(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, const int64_t* d_off, int64_t n_groups, int64_t chunk,
+                       const Method& method, const pds_lr_params* prm, const SolveParams& sp, T* d_mom, T* d_coeffs,
+                       uint8_t* d_null) {
+    const int bias = prm->add_bias ? 1 : 0, pp = n_feat + bias, q = n_feat + 2, nc = n_feat + 1;
+    std::vector<int64_t> off((size_t)n_groups + 1);
+    PDS_HIP_CHECK(hipMemcpyAsync(off.data(), d_off, off.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    // one pointer table per group: the column bases moved to the group's first row
+    std::vector<const T*> tables((size_t)n_groups * nc);
+    for (int64_t g = 0; g < n_groups; ++g)
+        for (int c = 0; c < nc; ++c) tables[(size_t)g * nc + c] = dc.h_ptrs[c] + off[g];
+    const T** d_tables = reinterpret_cast<const T**>(ws_take(ctx, tables.size() * sizeof(T*)));
+    PDS_HIP_CHECK(hipMemcpyAsync(d_tables, tables.data(), tables.size() * sizeof(T*), hipMemcpyHostToDevice, ctx->stream));
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const bool f32 = sizeof(T) == 4;
+    for (int64_t g0 = 0; g0 < n_groups; g0 += chunk) {
+        const int64_t gc = std::min(chunk, n_groups - g0);
+        for (int64_t g = g0; g < g0 + gc; ++g) {
+            T* rec = d_mom + (size_t)(g - g0) * q * q;
+            const int64_t ng = off[g + 1] - off[g];
+            if (ng <= 0) {
+                PDS_HIP_CHECK(hipMemsetAsync(rec, 0, sizeof(T) * (size_t)q * q, ctx->stream));
+                continue;
+            }
+            DeviceCols<T> dg;
+            dg.nc = nc;
+            dg.d_ptrs = d_tables + (size_t)g * nc;
+            dg.h_ptrs.assign(tables.begin() + (size_t)g * nc, tables.begin() + (size_t)(g + 1) * nc);
+            const size_t mark = ctx->ws_used;  // the SYRK partials are call-local: stream order makes the reuse safe
+            const int rc = launch_moments_wide<T>(ctx, dg, n_feat, ng, false, rec);
+            ctx->ws_used = mark;
+            if (rc) return rc;
+        }
+        T* co = d_coeffs + g0 * pp;
+        uint8_t* fl = d_null + g0;
+        if (method.kind == Method::OLS) {
+            if (int rc = launch_solve<T>(ctx, d_mom, gc, sp, co, fl, nullptr, nullptr)) return rc;
+            // per-group pl_lr rejects "#Data < #features": null
+            hipLaunchKernelGGL(mark_small_groups_kernel, dim3((unsigned)((gc + 255) / 256)), dim3(256), 0, ctx->stream, d_off + g0, gc,
+                               pp, fl);
+            hipLaunchKernelGGL((nan_flagged_kernel<T>), dim3((unsigned)((gc * pp + 255) / 256)), dim3(256), 0, ctx->stream, fl, gc, pp,
+                               co);
+            PDS_HIP_CHECK(hipGetLastError());
+        } else if (method.kind == Method::NNLS) {
+            if (int rc = launch_nnls<T>(ctx, d_mom, n_feat, bias, prm->tol, f32 ? 200 : prm->max_iter, co, gc, fl, d_off + g0)) return rc;
+        } else if (int rc = launch_cd<T>(ctx, d_mom, n_feat, bias, method.l1, method.l2, prm->tol, f32 ? 2000 : prm->max_iter,
+                                         method.positive, co, nullptr, gc, fl, d_off + g0))
+            return rc;
+    }
+    return PDS_OK;
+}
+
+template <typename T>
+static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t n_rows, const int64_t* offsets,
+                        int64_t n_groups, pds_space space, const pds_lr_params* prm, T* coeffs, uint8_t* is_null,
+                        // nullable form: Arrow validity per column [y, x1..xp]; every group is fitted on the rows of it that
+                        // survive the policy, like Polars calling pl_lr(null_policy=...) per group
+                        bool nullable = false, const uint8_t* const* validity = nullptr, const int64_t* bit_offsets = nullptr,
+                        int policy = PDS_NULL_RAISE, T fill_value = T(0)) {
+    if (!ctx || !cols || !offsets || !prm || !coeffs) return fail(PDS_ERR_INVALID, "null argument");
+    if (n_feat < 1) return fail(PDS_ERR_INVALID, "need at least one feature column");
+    if (n_groups <= 0 || n_rows <= 0) return fail(PDS_ERR_EMPTY, "Empty data");
+    const Method method = pick_method(prm);  // per group what pl_lr does per call: linear_regression.rs:447-497
+    PDS_HIP_CHECK(hipSetDevice(ctx->device));
+    const int bias = prm->add_bias ? 1 : 0, pp = n_feat + bias, q = n_feat + 2;
+    // chunk the groups so one chunk's moment records (q*q values per group) stay inside the 256 MiB
+    // Infinity Cache between the Gram kernel that writes them and the solve kernel that reads them
+    const bool big = n_feat > kMaxFeatWide;  // > 64 features: one tiled-SYRK Gram build per group + solve_big
+    int64_t chunk = std::max<int64_t>(big ? 64 : 4096, (int64_t)(128ll << 20) / (int64_t)(sizeof(T) * q * q));
+    chunk = std::min(chunk, n_groups);
+    size_t need = 131072 + sizeof(T) * (size_t)chunk * q * q;
+    need += (size_t)n_groups * 4 + (size_t)chunk * (pp * sizeof(T) + 1) + 4096;  // the fused path's pivoted-QR pass: list, results
+    if (big) need += (size_t)n_groups * (n_feat + 1) * sizeof(T*) + moments_wide_workspace(ctx->num_cus, n_feat, n_rows) + 8192;
+    if (space == PDS_HOST) need += (size_t)(n_groups + 1) * 8 + (size_t)n_groups * (pp * sizeof(T) + 1) + 4096;
+    if (nullable) {
+        if (policy < PDS_NULL_RAISE || policy > PDS_NULL_IGNORE) return fail(PDS_ERR_INVALID, "Invalid NullPolicy.");
+        need += (1 << 20) + null_policy_workspace(n_feat + 1, n_rows, sizeof(T)) + (size_t)(n_groups + 1) * 8 + 4096;
+        if (space == PDS_HOST) need += (size_t)(n_feat + 1) * ((size_t)n_rows / 8 + 4096);
+    }
+    if (int rc = ws_reserve(ctx, need)) return rc;
+    DeviceCols<T> dc;
+    if (int rc = make_device_cols<T>(ctx, cols, (const T*)nullptr, n_feat, n_rows, space, dc)) return rc;
+    const int64_t* d_off = offsets;
+    T* d_coeffs = coeffs;
+    uint8_t* d_null = is_null;
+    // small host batches (the plugin layer's coalesced per-group calls): offsets go up through pinned memory, coefficients
+    // and null flags come back in ONE copy -- every pageable hipMemcpyAsync is 5-10 us of a ~60 us call
+    const size_t co_bytes = ((size_t)n_groups * pp * sizeof(T) + 255) & ~(size_t)255;
+    const bool small_out = space == PDS_HOST && co_bytes + (size_t)n_groups + (size_t)(n_groups + 1) * 8 <= ((size_t)48 << 10);
+    if (space == PDS_HOST) {
+        int64_t* t = reinterpret_cast<int64_t*>(ws_take(ctx, (size_t)(n_groups + 1) * 8));
+        if (small_out) {
+            if (int rc = ensure_pinned(ctx, (size_t)128 << 10)) return rc;
+            char* pin_off = static_cast<char*>(ctx->pinned) + ((size_t)64 << 10);
+            std::memcpy(pin_off, offsets, (size_t)(n_groups + 1) * 8);
+            PDS_HIP_CHECK(hipMemcpyAsync(t, pin_off, (size_t)(n_groups + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        } else {
+            PDS_HIP_CHECK(hipMemcpyAsync(t, offsets, (size_t)(n_groups + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        }
+        d_off = t;
+        char* blk = reinterpret_cast<char*>(ws_take(ctx, co_bytes + (size_t)n_groups));
+        d_coeffs = reinterpret_cast<T*>(blk);
+        d_null = reinterpret_cast<uint8_t*>(blk + co_bytes);
+    } else if (!d_null) {
+        d_null = reinterpret_cast<uint8_t*>(ws_take(ctx, (size_t)n_groups));
+    }
+    if (nullable) {
+        const int nc = n_feat + 1;
+        std::vector<const T*> ref_order(nc);
+        ref_order[0] = dc.h_ptrs[n_feat];
+        for (int c = 0; c < n_feat; ++c) ref_order[c + 1] = dc.h_ptrs[c];
+        std::vector<const uint8_t*> bms(nc, nullptr);
+        std::vector<int64_t> boff(nc, 0);
+        for (int c = 0; c < nc; ++c) {
+            boff[c] = bit_offsets ? bit_offsets[c] : 0;
+            const uint8_t* b = validity ? validity[c] : nullptr;
+            if (b && space == PDS_HOST) {
+                const size_t bytes = (size_t)((boff[c] + n_rows + 7) / 8);
+                uint8_t* d = reinterpret_cast<uint8_t*>(ws_take(ctx, bytes));
+                PDS_HIP_CHECK(hipMemcpyAsync(d, b, bytes, hipMemcpyHostToDevice, ctx->stream));
+                b = d;
+            }
+            bms[c] = b;
+        }
+        NullPrepared<T> prep;
+        if (int rc = apply_null_policy<T>(ctx, ref_order, bms, boff, n_rows, policy, fill_value, prep)) return rc;
+        if (prep.dropped) {
+            int64_t* off2 = reinterpret_cast<int64_t*>(ws_take(ctx, (size_t)(n_groups + 1) * 8));
+            if (int rc = remap_group_offsets(ctx, d_off, n_groups, prep.d_rank, n_rows, prep.n_kept, off2)) return rc;
+            d_off = off2;
+        }
+        DeviceCols<T> dk;
+        dk.nc = nc;
+        dk.h_ptrs.resize(nc);
+        for (int c = 0; c < n_feat; ++c) dk.h_ptrs[c] = prep.cols[c + 1];
+        dk.h_ptrs[n_feat] = prep.cols[0];
+        dk.h_ptrs.resize(std::max(nc, 18), dk.h_ptrs[0]);
+        dk.d_ptrs = reinterpret_cast<const T**>(ws_take(ctx, sizeof(T*) * dk.h_ptrs.size()));
+        PDS_HIP_CHECK(hipMemcpyAsync(dk.d_ptrs, dk.h_ptrs.data(), sizeof(T*) * dk.h_ptrs.size(), hipMemcpyHostToDevice, ctx->stream));
+        PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        dc = dk;
+        n_rows = prep.n_kept;
+        if (n_rows == 0) return fail(PDS_ERR_EMPTY, "Empty data");
+    }
+    T* d_mom = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * (size_t)chunk * q * q));
+    SolveParams sp{n_feat, bias, prm->solver == PDS_SOLVER_SVD ? PDS_SOLVER_QR : prm->solver, prm->l2_reg,
+                   prm->singular_x_tol, 0};
+    {
+        const char* piv0 = std::getenv("PDS_GROUPED_PIVOTED");
+        if (piv0 && piv0[0] == '1' && sp.solver == PDS_SOLVER_CHOLESKEY) sp.solver = PDS_SOLVER_QR;
+    }
+    // Default (rank gate on): ONE streaming kernel, Gram + in-register Cholesky, no moment records in HBM.
+    // Gate off (singular_x_tol = 0) needs the pivoted QR to reproduce the reference's answers on rank-deficient
+    // groups; that solver is register hungry and runs faster as its own kernel behind the grouped Gram build.
+    // PDS_GROUPED_UNFUSED=1 / PDS_GROUPED_PIVOTED=1 force the two-kernel pipeline / the pivoted QR (development).
+    const char* unfused_env = std::getenv("PDS_GROUPED_UNFUSED");
+    const char* piv_env = std::getenv("PDS_GROUPED_PIVOTED");
+    const bool want_piv = !(sp.gate_tol > 0.0) || (piv_env && piv_env[0] == '1');
+    if (big) {
+        if (int rc = grouped_big<T>(ctx, dc, n_feat, d_off, n_groups, chunk, method, prm, sp, d_mom, d_coeffs, d_null)) return rc;
+    } else if (method.kind != Method::OLS) {
+        // lasso / elastic net / positive fits per group: grouped Gram build, then one wavefront per group runs the
+        // reference's coordinate descent (faer_coordinate_descent / faer_nn_lr) on that group's moment record
+        const bool f32 = sizeof(T) == 4;
+        for (int64_t g0 = 0; g0 < n_groups; g0 += chunk) {
+            const int64_t gc = std::min(chunk, n_groups - g0);
+            if (int rc = launch_grouped_moments<T>(ctx, dc, n_feat, d_off + g0, gc, d_mom)) return rc;
+            if (method.kind == Method::NNLS) {
+                if (int rc = launch_nnls<T>(ctx, d_mom, n_feat, bias, prm->tol, f32 ? 200 : prm->max_iter, d_coeffs + g0 * pp, gc,
+                                            d_null + g0, d_off + g0))
+                    return rc;
+            } else if (int rc = launch_cd<T>(ctx, d_mom, n_feat, bias, method.l1, method.l2, prm->tol,
+                                             f32 ? 2000 : prm->max_iter, method.positive, d_coeffs + g0 * pp, nullptr, gc,
+                                             d_null + g0, d_off + g0))
+                return rc;
+        }
+    } else if (n_feat <= 16 && !want_piv && !(unfused_env && unfused_env[0] == '1') && n_groups < (1ll << 31)) {
+        if (int rc = launch_grouped_fused<T>(ctx, dc, n_feat, n_rows, d_off, n_groups, sp, d_coeffs, d_null, d_mom, chunk)) return rc;
+    } else {
+        for (int64_t g0 = 0; g0 < n_groups; g0 += chunk) {
+            const int64_t gc = std::min(chunk, n_groups - g0);
+            if (int rc = launch_grouped_moments<T>(ctx, dc, n_feat, d_off + g0, gc, d_mom)) return rc;
+            if (int rc = launch_solve<T>(ctx, d_mom, gc, sp, d_coeffs + g0 * pp, d_null + g0, nullptr, d_off + g0)) return rc;
+        }
+    }
+    if (small_out) {
+        char* pin = static_cast<char*>(ctx->pinned);
+        PDS_HIP_CHECK(hipMemcpyAsync(pin, d_coeffs, co_bytes + (size_t)n_groups, hipMemcpyDeviceToHost, ctx->stream));
+        PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        std::memcpy(coeffs, pin, (size_t)n_groups * pp * sizeof(T));
+        if (is_null) std::memcpy(is_null, pin + co_bytes, (size_t)n_groups);
+        return PDS_OK;
+    }
+    if (space == PDS_HOST) {
+        PDS_HIP_CHECK(hipMemcpyAsync(coeffs, d_coeffs, (size_t)n_groups * pp * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+        if (is_null) PDS_HIP_CHECK(hipMemcpyAsync(is_null, d_null, (size_t)n_groups, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PDS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weighted groups: per group faer_weighted_lr (lr_solvers.rs:386-409) -- X' W X = (sqrt(W) X)' (sqrt(W) X), so the frame
+// is scaled once on the device (the bias becomes an explicit sqrt(w) column) and takes the unweighted, ungated grouped path
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+static int grouped_weighted_impl(pds_ctx* ctx, const T* const* cols, const T* weights, int n_feat, int64_t n_rows,
+                                 const int64_t* offsets, int64_t n_groups, pds_space space, const pds_lr_params* prm, T* coeffs,
+                                 uint8_t* is_null) {
+    if (!ctx || !cols || !weights || !offsets || !prm || !coeffs) return fail(PDS_ERR_INVALID, "null argument");
+    if (n_feat < 1) return fail(PDS_ERR_INVALID, "need at least one feature column");
+    if (n_groups <= 0 || n_rows <= 0) return fail(PDS_ERR_EMPTY, "Empty data");
+    PDS_HIP_CHECK(hipSetDevice(ctx->device));
+    const int bias = prm->add_bias ? 1 : 0, pf = n_feat + bias, nc_in = n_feat + 1;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t col_bytes = up((size_t)n_rows * sizeof(T));
+    size_t need = col_bytes * (pf + 1) + 4096;
+    if (space == PDS_HOST) need += col_bytes * (nc_in + 1) + up((size_t)(n_groups + 1) * 8) + up((size_t)n_groups * pf * sizeof(T)) + up((size_t)n_groups);
+    if (int rc = ensure_ws(ctx, ctx->keyed, need)) return rc;
+    char* w = static_cast<char*>(ctx->keyed.ptr);
+    auto take = [&](size_t b) { char* r = w; w += up(b); return r; };
+    std::vector<const T*> src(nc_in);
+    const T* d_w = weights;
+    const int64_t* d_off = offsets;
+    T* d_co = coeffs;
+    uint8_t* d_nu = is_null;
+    if (space == PDS_HOST) {
+        for (int c = 0; c < nc_in; ++c) {
+            T* d = reinterpret_cast<T*>(take((size_t)n_rows * sizeof(T)));
+            PDS_HIP_CHECK(hipMemcpyAsync(d, cols[c], (size_t)n_rows * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+            src[c] = d;
+        }
+        T* dw = reinterpret_cast<T*>(take((size_t)n_rows * sizeof(T)));
+        PDS_HIP_CHECK(hipMemcpyAsync(dw, weights, (size_t)n_rows * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+        d_w = dw;
+        int64_t* doff = reinterpret_cast<int64_t*>(take((size_t)(n_groups + 1) * 8));
+        PDS_HIP_CHECK(hipMemcpyAsync(doff, offsets, (size_t)(n_groups + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        d_off = doff;
+        d_co = reinterpret_cast<T*>(take((size_t)n_groups * pf * sizeof(T)));
+        d_nu = reinterpret_cast<uint8_t*>(take((size_t)n_groups));
+    } else {
+        for (int c = 0; c < nc_in; ++c) src[c] = cols[c];
+    }
+    // scaled frame in reference order [y, x1..xp, (sqrt w)]
+    std::vector<const T*> scaled(pf + 1);
+    for (int c = 0; c < nc_in; ++c) {
+        T* d = reinterpret_cast<T*>(take((size_t)n_rows * sizeof(T)));
+        if (int rc = launch_scale_sqrt_w<T>(ctx, src[c], d_w, n_rows, d)) return rc;
+        scaled[c] = d;
+    }
+    if (bias) {
+        T* d = reinterpret_cast<T*>(take((size_t)n_rows * sizeof(T)));
+        if (int rc = launch_scale_sqrt_w<T>(ctx, (const T*)nullptr, d_w, n_rows, d)) return rc;
+        scaled[nc_in] = d;
+    }
+    pds_lr_params p2 = *prm;  // faer_weighted_lr: plain solve with `solver`, no gate, no penalties
+    p2.add_bias = 0;
+    p2.l1_reg = 0.0;
+    p2.l2_reg = 0.0;
+    p2.positive = 0;
+    p2.singular_x_tol = 0.0;
+    if (int rc = grouped_impl<T>(ctx, scaled.data(), pf, n_rows, d_off, n_groups, PDS_DEVICE, &p2, d_co, d_nu)) return rc;
+    if (space == PDS_HOST) {
+        PDS_HIP_CHECK(hipMemcpyAsync(coeffs, d_co, (size_t)n_groups * pf * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+        if (is_null) PDS_HIP_CHECK(hipMemcpyAsync(is_null, d_nu, (size_t)n_groups, hipMemcpyDeviceToHost, ctx->stream));
+        PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    return PDS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// grouped by an int64 key column in any row order (keyed.hip brings the frame into key order on the device)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* keys, int n_feat, int64_t n_rows, pds_space space,
+                          const pds_lr_params* prm, int64_t max_groups, int64_t* out_keys, T* coeffs, uint8_t* is_null,
+                          int64_t* n_groups) {
+    if (!ctx || !cols || !keys || !prm || !out_keys || !coeffs || !n_groups) return fail(PDS_ERR_INVALID, "null argument");
+    if (n_feat < 1) return fail(PDS_ERR_INVALID, "need at least one feature column");
+    if (n_rows <= 0) return fail(PDS_ERR_EMPTY, "Empty data");
+    if (n_rows >= (1ll << 31)) return fail(PDS_ERR_UNSUPPORTED, "keyed grouping: fewer than 2^31 rows per call");
+    if (max_groups < 1) return fail(PDS_ERR_INVALID, "max_groups must be positive");
+    PDS_HIP_CHECK(hipSetDevice(ctx->device));
+    const int nc = n_feat + 1, pp = n_feat + (prm->add_bias ? 1 : 0);
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t key_bytes = up((size_t)n_rows * 8), col_bytes = up((size_t)n_rows * sizeof(T)), idx_bytes = up((size_t)n_rows * 4);
+    // ---- keys on the device, and are they already in order?
+    const int64_t* d_keys = keys;
+    if (space == PDS_HOST) {
+        if (int rc = ensure_ws(ctx, ctx->stage, key_bytes + 256)) return rc;
+        PDS_HIP_CHECK(hipMemcpyAsync(ctx->stage.ptr, keys, (size_t)n_rows * 8, hipMemcpyHostToDevice, ctx->stream));
+        d_keys = static_cast<const int64_t*>(ctx->stage.ptr);
+    }
+    if (int rc = ensure_pinned(ctx, 4096)) return rc;
+    if (int rc = ensure_ws(ctx, ctx->solve_ws, 4096)) return rc;  // a flag word that outlives the workspace sizing below
+    bool sorted = false;
+    if (int rc = keys_nondecreasing(ctx, d_keys, n_rows, static_cast<unsigned*>(ctx->solve_ws.ptr), &sorted)) return rc;
+    // ---- workspace: [raw columns (host frames)] [sorted keys, index in/out, gathered columns (unsorted frames)] runs, temp
+    const int64_t cap = std::min<int64_t>(max_groups, n_rows);
+    const size_t temp_bytes = keyed_temp_bytes(n_rows);
+    size_t need = temp_bytes + 3 * up((size_t)(n_rows + 1) * 8) + 4096;  // unique keys, counts, offsets (at most one per row)
+    if (space == PDS_HOST) need += col_bytes * nc + up((size_t)cap * pp * sizeof(T)) + up((size_t)cap);
+    if (!sorted) need += 2 * key_bytes + 2 * idx_bytes + col_bytes * nc + up((size_t)n_rows * nc * sizeof(T)) + up(2 * (size_t)nc * sizeof(T*)) + 1024;
+    if (int rc = ensure_ws(ctx, ctx->keyed, need)) return rc;
+    char* w = static_cast<char*>(ctx->keyed.ptr);
+    auto take = [&](size_t b) { char* r = w; w += up(b); return r; };
+    void* d_temp = take(temp_bytes);
+    int64_t* d_unique = reinterpret_cast<int64_t*>(take((size_t)(n_rows + 1) * 8));
+    int64_t* d_counts = reinterpret_cast<int64_t*>(take((size_t)(n_rows + 1) * 8));
+    int64_t* d_offsets = reinterpret_cast<int64_t*>(take((size_t)(n_rows + 1) * 8));
+    int64_t* d_nruns = reinterpret_cast<int64_t*>(take(256));
+    std::vector<const T*> src(nc);  // reference order [y, x1..xp], device resident
+    for (int c = 0; c < nc; ++c) src[c] = cols[c];
+    if (space == PDS_HOST)
+        for (int c = 0; c < nc; ++c) {
+            T* d = reinterpret_cast<T*>(take((size_t)n_rows * sizeof(T)));
+            PDS_HIP_CHECK(hipMemcpyAsync(d, cols[c], (size_t)n_rows * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+            src[c] = d;
+        }
+    const int64_t* d_sorted_keys = d_keys;
+    if (!sorted) {
+        int64_t* sk = reinterpret_cast<int64_t*>(take((size_t)n_rows * 8));
+        uint32_t* idx_in = reinterpret_cast<uint32_t*>(take((size_t)n_rows * 4));
+        uint32_t* perm = reinterpret_cast<uint32_t*>(take((size_t)n_rows * 4));
+        int64_t* sk2 = reinterpret_cast<int64_t*>(take((size_t)n_rows * 8));
+        int64_t* mm = reinterpret_cast<int64_t*>(take(256));
+        if (int rc = keyed_sort(ctx, d_keys, n_rows, idx_in, sk, perm, d_temp, temp_bytes, sk2, mm)) return rc;
+        d_sorted_keys = sk;
+        static const bool by_column = [] { const char* e = std::getenv("PDS_KEYED_GATHER_BY_COLUMN"); return e && e[0] == '1'; }();
+        if (by_column) {  // (A/B: one random 8-byte read per element)
+            for (int c = 0; c < nc; ++c) {
+                T* d = reinterpret_cast<T*>(take((size_t)n_rows * sizeof(T)));
+                if (int rc = launch_gather_rows<T>(ctx, src[c], perm, n_rows, d)) return rc;
+                src[c] = d;
+            }
+        } else {
+            // transpose to row-major records, then one random access per ROW (keyed.hip)
+            std::vector<const T*> tbl(2 * (size_t)nc);
+            for (int c = 0; c < nc; ++c) tbl[c] = src[c];
+            for (int c = 0; c < nc; ++c) {
+                T* d = reinterpret_cast<T*>(take((size_t)n_rows * sizeof(T)));
+                tbl[nc + c] = d;
+                src[c] = d;
+            }
+            T* records = reinterpret_cast<T*>(take((size_t)n_rows * nc * sizeof(T)));
+            const T** d_tbl = reinterpret_cast<const T**>(take(2 * (size_t)nc * sizeof(T*)));
+            PDS_HIP_CHECK(hipMemcpyAsync(d_tbl, tbl.data(), 2 * (size_t)nc * sizeof(T*), hipMemcpyHostToDevice, ctx->stream));
+            if (int rc = launch_gather_frame<T>(ctx, d_tbl, perm, nc, n_rows, records, (T* const*)(d_tbl + nc)))
+                return rc;
+            PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // (tbl: source of the table copy)
+        }
+    }
+    int64_t ng = 0;
+    if (int rc = keyed_runs(ctx, d_sorted_keys, n_rows, d_unique, d_counts, d_offsets, d_nruns, d_temp, temp_bytes, &ng)) return rc;
+    *n_groups = ng;
+    if (ng > max_groups) return fail(PDS_ERR_INVALID, "more distinct keys than max_groups");
+    T* d_co = coeffs;
+    uint8_t* d_nu = is_null;
+    if (space == PDS_HOST) {
+        d_co = reinterpret_cast<T*>(take((size_t)cap * pp * sizeof(T)));
+        d_nu = reinterpret_cast<uint8_t*>(take((size_t)cap));
+    }
+    if (int rc = grouped_impl<T>(ctx, src.data(), n_feat, n_rows, d_offsets, ng, PDS_DEVICE, prm, d_co, d_nu)) return rc;
+    if (space == PDS_HOST) {
+        PDS_HIP_CHECK(hipMemcpyAsync(coeffs, d_co, (size_t)ng * pp * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+        if (is_null) PDS_HIP_CHECK(hipMemcpyAsync(is_null, d_nu, (size_t)ng, hipMemcpyDeviceToHost, ctx->stream));
+        PDS_HIP_CHECK(hipMemcpyAsync(out_keys, d_unique, (size_t)ng * 8, hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        PDS_HIP_CHECK(hipMemcpyAsync(out_keys, d_unique, (size_t)ng * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PDS_OK;
+}

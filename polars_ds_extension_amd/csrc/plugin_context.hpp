@@ -1,0 +1,73 @@
+// plugin_context.hpp -- per-thread pds_ctx and the f64 / f32 entry-point table (Api<T>)
+// Part of the one translation unit plugin.cpp (included there, inside its anonymous namespace, in dependency order).
+#pragma once
+
+// ------------------------------------------------------------------------------------------------- context
+pds_ctx* thread_ctx() {
+    // Polars calls plugin symbols from many rayon threads: one context (stream + workspace) per thread
+    thread_local pds_ctx* ctx = nullptr;
+    if (!ctx) {
+        const char* dev = std::getenv("PDS_DEVICE");
+        if (pds_ctx_create(dev ? std::atoi(dev) : 0, &ctx) != PDS_OK) raise(pds_last_error());
+    }
+    return ctx;
+}
+void check(int rc) {
+    if (rc != PDS_OK) raise(pds_last_error());
+}
+
+template <typename T> struct Api;
+template <> struct Api<double> {
+    using Report = pds_report_f64;
+    static constexpr auto lr_nullable = pds_lr_nullable_f64;
+    static constexpr auto lr = pds_lr_f64;
+    static constexpr auto lr_pred = pds_lr_pred_f64;
+    static constexpr auto report = pds_lin_reg_report_f64;
+    static constexpr auto report_nullable = pds_lin_reg_report_nullable_f64;
+    static constexpr auto rolling = pds_rolling_lr_f64;
+    static constexpr auto recursive = pds_recursive_lr_f64;
+    static constexpr auto by_key = pds_lr_by_key_f64;
+    static constexpr auto grouped = pds_lr_grouped_f64;
+    static constexpr auto grouped_weighted = pds_lr_grouped_weighted_f64;
+    static constexpr auto grouped_nullable = pds_lr_grouped_nullable_f64;
+    static constexpr auto multi = pds_lr_multi_f64;
+    static constexpr auto rcond = pds_lr_rcond_f64;
+};
+template <> struct Api<float> {
+    using Report = pds_report_f32;
+    static constexpr auto lr_nullable = pds_lr_nullable_f32;
+    static constexpr auto lr = pds_lr_f32;
+    static constexpr auto lr_pred = pds_lr_pred_f32;
+    static constexpr auto report = pds_lin_reg_report_f32;
+    static constexpr auto report_nullable = pds_lin_reg_report_nullable_f32;
+    static constexpr auto rolling = pds_rolling_lr_f32;
+    static constexpr auto recursive = pds_recursive_lr_f32;
+    static constexpr auto by_key = pds_lr_by_key_f32;
+    static constexpr auto grouped = pds_lr_grouped_f32;
+    static constexpr auto grouped_weighted = pds_lr_grouped_weighted_f32;
+    static constexpr auto grouped_nullable = pds_lr_grouped_nullable_f32;
+    static constexpr auto multi = pds_lr_multi_f32;
+    static constexpr auto rcond = pds_lr_rcond_f32;
+};
+
+pds_lr_params lr_params(const Kwargs& kw) {  // LRKwargs :27-45 (serde defaults for the optional fields)
+    pds_lr_params p;
+    p.add_bias = kw_bool(kw, "bias");
+    p.l1_reg = kw_f64(kw, "l1_reg");
+    p.l2_reg = kw_f64(kw, "l2_reg");
+    p.tol = kw_f64(kw, "tol");
+    const std::string s = kw_str(kw, "solver", "qr");
+    p.solver = s == "svd" ? PDS_SOLVER_SVD : (s == "choleskey" ? PDS_SOLVER_CHOLESKEY : PDS_SOLVER_QR);
+    p.positive = kw_bool(kw, "positive");
+    p.max_iter = (int)kw_i64(kw, "max_iter");
+    p.singular_x_tol = kw_f64(kw, "singular_x_tol");
+    return p;
+}
+
+template <typename T>
+std::vector<Column<T>> import_all(SeriesExport* in, size_t n) {
+    std::vector<Column<T>> cols;
+    cols.reserve(n);
+    for (size_t i = 0; i < n; ++i) cols.push_back(import_series<T>(in[i]));
+    return cols;
+}
