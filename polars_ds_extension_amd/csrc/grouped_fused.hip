@@ -35,25 +35,17 @@ __device__ unsigned long long g_phase_cycles[8];
 
 constexpr int kFQ = 18;                  // LDS scratch moment matrix: indices 0..15 features, 16 bias, 17 y
 constexpr int kFM = kFQ * kFQ;           // doubles
-// -DPDS_HALF_TILE: the LDS tile holds HALF of the 128-row (f64) register tile at a time (lanes 0-31 park their rows, the
-// matrix core consumes them, then lanes 32-63 do): 11.3 KB of LDS per wave instead of 20.3, so the CU takes three waves per
-// SIMD instead of two while every load instruction still moves a full 1 KiB.
-#ifdef PDS_HALF_TILE
-constexpr int kFStride = kColStride / 2 + 8;  // 528 B: 132 dwords = 4 mod 64, the same conflict-free operand fetch as 1040
-#else
-constexpr int kFStride = kColStride;
-#endif
-constexpr int kFTile = 17 * kFStride;  // 16 feature slots + y
+constexpr int kFTile = 17 * kColStride;  // 16 feature slots + y
 constexpr int kFWaveLds = kFTile + kFM * 8;
 
 // consume rows [rel0, rel1) of the tile (relative row indices, 0 <= rel0 < rel1 <= TR) into `a`
 // BIAS = false drops the column sums / sum y (only the bias row of the normal equations needs them); y'y is never
 // needed by the solve.  These side sums are VALU work per 4-row step, and the fused kernel is VALU-issue bound.
-template <typename T, bool BIAS, typename PF>
-__device__ __forceinline__ void consume_range(const char* wl, int lane, int rel0, int rel1, WaveAcc& a, PF&& pf) {
+template <typename T, bool BIAS>
+__device__ __forceinline__ void consume_range(const char* wl, int lane, int rel0, int rel1, WaveAcc& a) {
     const int f = lane & 15, q = lane >> 4;
-    const T* xcol = reinterpret_cast<const T*>(wl + f * kFStride) + q;
-    const T* ycol = reinterpret_cast<const T*>(wl + kSlotY * kFStride) + q;
+    const T* xcol = reinterpret_cast<const T*>(wl + f * kColStride) + q;
+    const T* ycol = reinterpret_cast<const T*>(wl + kSlotY * kColStride) + q;
     int s0 = rel0 >> 2;
     const int s1 = (rel1 + 3) >> 2;  // exclusive
     using Acc = typename Tile<T>::acc;
@@ -127,7 +119,6 @@ __device__ __forceinline__ void consume_range(const char* wl, int lane, int rel0
         step_v(x1, y1);
         step_v(x2, y2);
         step_v(x3, y3);
-        pf();
     }
     // (fetching the next iteration's operands ahead of these matrix instructions was measured slower with a register
     //  rotation -- sixteen moves per iteration -- and no faster with two ping-pong operand sets: 2.43 ms either way)
@@ -147,12 +138,12 @@ __device__ __forceinline__ void consume_range(const char* wl, int lane, int rel0
 // the same features of rows 8s+4+q; the product's two diagonal 8 x 8 blocks are the Gram contributions of the two
 // slabs (the off-diagonal blocks are cross terms nobody reads), folded together at flush time.  Half the MFMAs per
 // row -- at 8 features the f64 matrix pipe (86 clk per 16x16x4) is as scarce as HBM bandwidth.
-template <typename T, bool BIAS, typename PF>
-__device__ __forceinline__ void consume_range_pack(const char* wl, int lane, int rel0, int rel1, WaveAcc& a, PF&& pf) {
+template <typename T, bool BIAS>
+__device__ __forceinline__ void consume_range_pack(const char* wl, int lane, int rel0, int rel1, WaveAcc& a) {
     const int f = lane & 15, q = lane >> 4;
     const int roff = q + 4 * (f >> 3);  // this lane's row inside an 8-row step
-    const T* xcol = reinterpret_cast<const T*>(wl + (f & 7) * kFStride) + roff;
-    const T* ycol = reinterpret_cast<const T*>(wl + kSlotY * kFStride) + roff;
+    const T* xcol = reinterpret_cast<const T*>(wl + (f & 7) * kColStride) + roff;
+    const T* ycol = reinterpret_cast<const T*>(wl + kSlotY * kColStride) + roff;
     int s0 = rel0 >> 3;
     const int s1 = (rel1 + 7) >> 3;  // exclusive
     using Acc = typename Tile<T>::acc;
@@ -202,7 +193,6 @@ __device__ __forceinline__ void consume_range_pack(const char* wl, int lane, int
         step_v(x1, y1);
         step_v(x2, y2);
         step_v(x3, y3);
-        pf();
     }
     for (; s < sfull; ++s) step_v(xcol[8 * s], ycol[8 * s]);
     if ((rel1 & 7) && sfull >= s0 && sfull < s1) step_m(sfull);
@@ -229,13 +219,8 @@ __device__ __forceinline__ int64_t lower_bound_i64(const int64_t* __restrict__ a
 // 15 / 7 / 3 features + bias): the per-column `c < p` branches of the tile load / store (17 scalar compares + branches per
 // tile, each re-reading a spilled SGPR) and the solver's per-step `K < p'` branches fold away -- 2.86 -> 2.63 ms at 16
 // features, 1.89 -> 1.52 ms at 8
-#ifdef PDS_HALF_TILE
-#define PDS_FUSED_OCC __attribute__((amdgpu_waves_per_eu(3, 3)))
-#else
-#define PDS_FUSED_OCC
-#endif
 template <typename T, int LPS, bool CHOL, bool BIAS, int PC>
-__global__ __launch_bounds__(64) PDS_FUSED_OCC void grouped_stream_kernel(const T* const* __restrict__ cols, int p_arg,
+__global__ __launch_bounds__(64) void grouped_stream_kernel(const T* const* __restrict__ cols, int p_arg,
                                                             const int64_t* __restrict__ offsets, int64_t n_groups,
                                                             int64_t n_rows, SolveRegDev sp, T* __restrict__ coeffs,
                                                             uint8_t* __restrict__ flags, int32_t* __restrict__ mark_list,
@@ -276,10 +261,7 @@ __global__ __launch_bounds__(64) PDS_FUSED_OCC void grouped_stream_kernel(const 
         typename Tile<T>::vec z;
 #pragma unroll
         for (int e = 0; e < RPL; ++e) z[e] = T(0);
-#ifdef PDS_HALF_TILE
-        if (lane < 32)
-#endif
-        for (int c = p; c < 16; ++c) *reinterpret_cast<typename Tile<T>::vec*>(wl + c * kFStride + lane * 16) = z;
+        for (int c = p; c < 16; ++c) *reinterpret_cast<typename Tile<T>::vec*>(wl + c * kColStride + lane * 16) = z;
     }
 #ifdef PDS_PROFILE_PHASES
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -497,92 +479,20 @@ __global__ __launch_bounds__(64) PDS_FUSED_OCC void grouped_stream_kernel(const 
         if ((t + 1) * TR <= n_rows) load_full_tile<T, false>(cp, p, row, regs);
         else load_tail_tile<T, false>(cp, p, row, n_rows, regs);
     };
+    // (Round 2, measured on one box against 2.465 ms as is -- profiles/r02_grouped_variants_ab.txt, source kept as
+    //  tools/experiments/grouped_fused_r02_spread_issue_and_half_tile.patch: the LDS tile holding HALF of the register tile at a
+    //  time (11.3 KB per wave, three waves per SIMD) 2.61 ms; the next tile's 17 loads issued in four slices from inside the
+    //  consume loop instead of one burst 4.3 ms.  The SIMD's issue slots -- matrix pipe + the solve's DPP arithmetic -- are the
+    //  bound, not memory-level parallelism: DESIGN.md 4.2.)
     // (Tried and measured slower: a half-size tile (8 B per lane per column, 11.6 KB of LDS per wave) -- 3.47 ms per
     //  1e6-group step at 2 waves/SIMD and 3.59 ms squeezed into 168 VGPRs for 3 waves/SIMD, against 3.12 ms as is.)
     // (A flat state machine with flush / solve instantiated once each was tried: 4.7k instead of 10.9k static
     //  instructions but 255 live VGPRs and 8 % slower than this nested form at 219.)
-#ifdef PDS_PF_SPREAD
-    // The next tile's 17 loads are not issued in one burst behind the LDS store (the phase profile charged that burst 1 960
-    // clk per group at 16 features: the wave sits in the issue queue instead of feeding the matrix core) but in four
-    // slices: the first at once, the others every PDS_PF_SPREAD four-step iterations of the consume loop.
-    int pf_chunk = 4;          // 4 = nothing pending
-    int64_t pf_row = 0;
-    int pf_iters = 0;
-    auto pf_issue = [&](int k) __attribute__((always_inline)) {
-        using V = typename Tile<T>::vec;
-        constexpr int CH = 5;  // columns per slice: x0-4 | x5-9 | x10-14 | x15, y
-        switch (k) {
-            case 0:
-#pragma unroll
-                for (int c = 0; c < CH; ++c)
-                    if (c < p) regs.x[c] = PDS_STREAM_LOAD(reinterpret_cast<gptr<V>>(as_global(cols[c]) + pf_row));
-                break;
-            case 1:
-#pragma unroll
-                for (int c = CH; c < 2 * CH; ++c)
-                    if (c < p) regs.x[c] = PDS_STREAM_LOAD(reinterpret_cast<gptr<V>>(as_global(cols[c]) + pf_row));
-                break;
-            case 2:
-#pragma unroll
-                for (int c = 2 * CH; c < 3 * CH; ++c)
-                    if (c < p) regs.x[c] = PDS_STREAM_LOAD(reinterpret_cast<gptr<V>>(as_global(cols[c]) + pf_row));
-                break;
-            default:
-#pragma unroll
-                for (int c = 3 * CH; c < 16; ++c)
-                    if (c < p) regs.x[c] = PDS_STREAM_LOAD(reinterpret_cast<gptr<V>>(as_global(cols[c]) + pf_row));
-                regs.y = PDS_STREAM_LOAD(reinterpret_cast<gptr<V>>(as_global(cols[p]) + pf_row));
-                break;
-        }
-    };
-    auto pf = [&]() __attribute__((always_inline)) {
-        if (pf_chunk < 4) {
-            if (++pf_iters >= PDS_PF_SPREAD) {
-                pf_iters = 0;
-                pf_issue(pf_chunk++);
-            }
-        }
-    };
-#else
-    auto pf = []() __attribute__((always_inline)) {};
-#endif
     if (t_first <= t_last) load_tile(t_first);
     // One flush site: a group is flushed as soon as its last row has been consumed (the loop condition also holds while
     // the current group is complete), so groups that end exactly at rhi and trailing empty groups are handled by the last
     // pass; a wave whose groups are all empty makes one pass without a tile.  (Two inlined copies of flush + solve were
     // 5 KB of code for nothing.)
-#ifdef PDS_HALF_TILE
-    // the loop walks 64-row (f64) SUB-tiles: sub-tile k = half (k & 1) of register tile k >> 1
-    constexpr int TRL = TR / 2;
-    const int64_t k_first = rlo / TRL, k_last = (rhi > rlo) ? (rhi - 1) / TRL : k_first - 1;
-    for (int64_t t = k_first;; ++t) {
-        const bool have_tile = t <= k_last;
-        if (have_tile) {
-            {
-                PDS_T0();
-                using V = typename Tile<T>::vec;
-                const int h = (int)(t & 1);
-                if ((lane >> 5) == h) {  // this half's lanes park their RPL rows of every column
-                    char* dst = wl + (lane & 31) * 16;
-#pragma unroll
-                    for (int c = 0; c < 16; ++c)
-                        if (c < p) *reinterpret_cast<V*>(dst + c * kFStride) = regs.x[c];
-                    *reinterpret_cast<V*>(dst + kSlotY * kFStride) = regs.y;
-                }
-#ifdef PDS_PROFILE_PHASES
-                PDS_WAVE_LDS_SYNC();
-#endif
-                PDS_T1(0);
-            }
-            PDS_T0();
-            // the registers are free once the second half is parked (or the first, when it is the wave's last sub-tile of
-            // this register tile anyway): the next register tile goes in flight
-            if ((t & 1) == 1 && t < k_last) load_tile((t >> 1) + 1);
-            PDS_T1(1);
-        }
-#define PDS_LOOP_TR TRL
-#define PDS_LOOP_LAST k_last
-#else
     for (int64_t t = t_first;; ++t) {
         const bool have_tile = t <= t_last;
         if (have_tile) {
@@ -595,31 +505,15 @@ __global__ __launch_bounds__(64) PDS_FUSED_OCC void grouped_stream_kernel(const 
                 PDS_T1(0);
             }
             PDS_T0();
-#ifdef PDS_PF_SPREAD
-            if (t + 1 <= t_last) {
-                if ((t + 2) * TR <= n_rows) {
-                    pf_row = (t + 1) * TR + lane * RPL;
-                    pf_iters = 0;
-                    pf_chunk = 1;
-                    pf_issue(0);
-                } else {
-                    load_tile(t + 1);  // ragged last tile of the frame: guarded loads, one burst
-                }
-            }
-#else
             if (t + 1 <= t_last) load_tile(t + 1);
-#endif
             PDS_T1(1);
         }
-#define PDS_LOOP_TR TR
-#define PDS_LOOP_LAST t_last
-#endif
-        const int64_t row0 = t * PDS_LOOP_TR;
+        const int64_t row0 = t * TR;
         // rows of this tile that belong to the wave, relative to row0 (no tile: nothing to consume, flushes only)
         uint32_t rel_end = 0, pos_rel = 0;
         if (have_tile) {
             const uint64_t left = (uint64_t)(rhi - row0);
-            rel_end = ((uint32_t)(left >> 32) != 0u || (uint32_t)left > (uint32_t)PDS_LOOP_TR) ? (uint32_t)PDS_LOOP_TR : (uint32_t)left;
+            rel_end = ((uint32_t)(left >> 32) != 0u || (uint32_t)left > (uint32_t)TR) ? (uint32_t)TR : (uint32_t)left;
             pos_rel = (uint32_t)(pos - row0);
         }
         // end of the current group relative to row0, saturated (ge >= pos >= row0 whenever a tile is present)
@@ -641,20 +535,15 @@ __global__ __launch_bounds__(64) PDS_FUSED_OCC void grouped_stream_kernel(const 
             }
             const uint32_t seg_end = (ge_rel < rel_end) ? ge_rel : rel_end;
             PDS_T0();
-            if constexpr (PACK) consume_range_pack<T, BIAS>(wl, lane, (int)pos_rel, (int)seg_end, acc, pf);
-            else consume_range<T, BIAS>(wl, lane, (int)pos_rel, (int)seg_end, acc, pf);
+            if constexpr (PACK) consume_range_pack<T, BIAS>(wl, lane, (int)pos_rel, (int)seg_end, acc);
+            else consume_range<T, BIAS>(wl, lane, (int)pos_rel, (int)seg_end, acc);
             PDS_T1(4);
             pos_rel = seg_end;
         }
         if (have_tile) pos = row0 + pos_rel;
-#ifdef PDS_PF_SPREAD
-        while (pf_chunk < 4) pf_issue(pf_chunk++);  // slices the consume loop did not reach (short tiles, empty groups)
-#endif
-        if (t >= PDS_LOOP_LAST) break;
+        if (t >= t_last) break;
         PDS_WAVE_LDS_SYNC();
     }
-#undef PDS_LOOP_TR
-#undef PDS_LOOP_LAST
     if (npend > 0) solve_pending();
 #ifdef PDS_PROFILE_PHASES
     prof[7] = __builtin_amdgcn_s_memtime() - t_begin;
@@ -668,11 +557,7 @@ static int launch_stream_lps(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, 
                              int64_t n_groups, int64_t n_rows, const SolveRegDev& sd, bool chol, T* d_coeffs,
                              uint8_t* d_flags, int32_t* d_mark_list, unsigned* d_mark_count, unsigned* d_mark_host) {
     const size_t lds = (size_t)kFWaveLds;
-#ifdef PDS_HALF_TILE
-    const int per_cu = std::max(1, std::min(12, (int)((160 * 1024) / lds)));  // three waves per SIMD (register budget 168)
-#else
     const int per_cu = std::max(1, (int)((160 * 1024) / lds));
-#endif
     int64_t nb = std::min<int64_t>(std::max<int64_t>(n_groups / (64 / LPS), 1), (int64_t)ctx->num_cus * per_cu);
     KernelTimer timer(ctx, kKindGroupedMoments);
     // (the pivoted-QR variant of this kernel measured slower than the two-kernel pipeline and is not instantiated;
