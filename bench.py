@@ -196,6 +196,21 @@ def main() -> int:
         "solve_ms_per_step": round(sv_ms / max(args.steps, 1), 4), "gram_ms_per_step": round(gm_ms / max(args.steps, 1), 4),
     }
 
+    # ---- what this box's HBM delivers to a plain streaming copy (quote the spec peak AND a measured figure)
+    if rank == 0:
+        a = torch.empty(1 << 27, dtype=torch.float64, device=dev)  # 1 GiB
+        b = torch.empty_like(a)
+        b.copy_(a)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            b.copy_(a)
+        torch.cuda.synchronize(dev)
+        copy_gbps = 5 * 2 * (1 << 30) / (time.perf_counter() - t0) / 1e9
+        roofline["measured_copy_GBps"] = round(copy_gbps, 1)  # read + write bytes of a 1 GiB device-to-device copy
+        roofline["frac_of_measured_copy"] = round(achieved / copy_gbps, 4)
+        del a, b
+
     # ---- config 2 on the same frame: single OLS Gram build (pds_moments), HBM GB/s
     gram = None
     if rank == 0:
@@ -289,7 +304,7 @@ def main() -> int:
     other = None
     if rank == 0 and world == 1 and not args.no_extras:
         try:
-            other = _other_configs(torch, pds, ctx, dev, xs, y, N, P)
+            other = _other_configs(torch, pds, ctx, dev, xs, y, N, P, with_cpu=not args.no_cpu)
         except Exception as e:
             other = {"error": f"{type(e).__name__}: {e}"}
 
@@ -388,7 +403,7 @@ def _end_to_end(torch, np, pds, dev, xs, y, G, R, P, cpu):
     return out
 
 
-def _other_configs(torch, pds, ctx, dev, xs, y, N, P):
+def _other_configs(torch, pds, ctx, dev, xs, y, N, P, with_cpu=True):
     out = {}
 
     def wall(fn, reps=3):
@@ -424,6 +439,19 @@ def _other_configs(torch, pds, ctx, dev, xs, y, N, P):
         ms = t[0] / 3  # (the expanding fit is several launches per call)
         out[name] = {"rows": n, "coefficients": p, "window": w, "kernel_ms": round(ms, 3), "rows_per_s": round(n / ms * 1e3, 1),
                      "algorithmic_GBps": round(alg / ms * 1e3, 1), "frac_of_hbm_peak": round(alg / ms * 1e3 / HBM_PEAK_GBPS, 4)}
+    if with_cpu:  # the reference's rolling driver is one sequential Woodbury chain: single thread, bounded sample of the same frame
+        import numpy as np
+
+        from oracle import oracle as orc
+
+        ns = 2_000_000
+        Xh = np.stack([x[:ns].cpu().numpy() for x in rx], axis=1)
+        yh = ry[:ns].cpu().numpy()
+        t0 = time.perf_counter()
+        orc.rolling_lr(Xh, yh, w)
+        tc = time.perf_counter() - t0
+        out["rolling_c4"]["cpu_rows_per_s"] = round(ns / tc, 1)
+        out["rolling_c4"]["cpu_sample"] = f"{ns} rows of the same frame, the reference's sequential Woodbury chain (oracle port), 1 thread, {tc:.2f} s"
     return out
 
 
