@@ -607,7 +607,7 @@ int launch_grouped_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, co
 // of different rows nobody reads).  1.5x the matrix work of the column kernel (1.5 ms of pipe per 1e8 rows, still under the
 // HBM time) for loads that are as wide as the link likes them: 8 B per lane ran at 0.39 of the HBM peak.
 #ifndef PDS_ROWMAJOR_U
-#define PDS_ROWMAJOR_U 4
+#define PDS_ROWMAJOR_U 3
 #endif
 #ifndef PDS_ROWMAJOR_BLOCKS
 #define PDS_ROWMAJOR_BLOCKS 4
@@ -616,8 +616,8 @@ __global__ __launch_bounds__(256, PDS_ROWMAJOR_BLOCKS) void moments_rowmajor_f64
                                                                       const double* __restrict__ y, int p, int64_t n,
                                                                       double* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int U = PDS_ROWMAJOR_U;  // 8-row steps per iteration.  Measured at 1e8 x 16 (profiles/r02_rowmajor_ab.txt): U = 4 with
-    // four resident blocks (16 waves per CU) 2.77 ms, U = 8 x 3 blocks 3.24, U = 16 x 2 blocks 4.89: many waves with short bursts beat
+    constexpr int U = PDS_ROWMAJOR_U;  // 8-row steps per iteration.  Measured at 1e8 x 16 (profiles/r02_rowmajor_ab.txt): four resident blocks (16
+    // waves per CU) with U = 2 / 3 / 4 / 6: 2.93 / 2.64 / 2.83 / 3.51 ms; U = 8 x 3 blocks 3.24, U = 16 x 2 blocks 4.89: many waves with short bursts beat
     // few waves with deep ones here (the y loads are 8-fold redundant per instruction, the matrix pipe runs 1.5x the column kernel's work)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fp = lane & 7, rs = lane >> 3;
