@@ -486,7 +486,7 @@ static int launch_pp_f(pds_ctx* ctx, const DeviceCols<T>& dc, RollArgs ra, bool 
         if constexpr (PP <= 8) {
             if (seg) {  // streaming totals (rolling_seg_dev.hpp): HBM bound instead of a full pass of the rolling kernel
                 using SD = SegDims<T, PP>;
-                const int64_t tb = std::min<int64_t>(std::max<int64_t>(ntiles, 1), (int64_t)ctx->num_cus * 8);
+                const int64_t tb = std::min<int64_t>(std::max<int64_t>(ntiles, 1), (int64_t)ctx->num_cus * 12);
                 hipLaunchKernelGGL((rolling_totals_kernel<T, PP, FULLP>), dim3((unsigned)tb), dim3(64),
                                    (size_t)SD::NV * kSegStride * sizeof(double), ctx->stream, dc.d_ptrs, ra, tot);
                 totals_done = true;

@@ -530,7 +530,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 // ---------------------------------------------------------------------------------------------------------------------
 // Expanding fit, pass 1: the moment totals of every 4096-row tile -- a pure streaming reduction (45 FMAs per row at p' = 8
 // against 72 bytes: HBM bound), so it reads like the Gram kernels: 16 bytes per lane straight down each column (1 KiB
-// coalesced per instruction, non-temporal), the next 128-row step in flight in a second register set, moments in registers,
+// coalesced per instruction, non-temporal), moments in registers, three waves per SIMD,
 // one cross-lane reduction per tile.  (It was the lane = row rolling kernel in its totals mode: 3.06 ms for the 7.2 GB of
 // C4's frame.)  Same moment order and non-finite rule as rolling_seg_kernel (seg_accumulate).
 // ---------------------------------------------------------------------------------------------------------------------
@@ -574,11 +574,12 @@ __global__ __launch_bounds__(64) void rolling_totals_kernel(const T* const* __re
         double S[NV];
 #pragma unroll
         for (int v = 0; v < NV; ++v) S[v] = 0.0;
-        V16 cur[PP + 1], nxt[PP + 1];
-        load_step(t0 + (int64_t)lane * E16, cur);
+        // One register set, three waves per SIMD (142 VGPRs), the next step's loads issued after this step's math: A/B against
+        // a register double buffer at two waves per SIMD (212 VGPRs) 1.12 vs 1.36 ms for C4's 7.2 GB = 0.80 vs 0.66 of the HBM
+        // peak -- more resident waves hide the latency better than a deeper burst per wave.
+        V16 cur[PP + 1];
         for (int64_t base = t0; base < t1; base += STEP) {
-            const bool more = base + STEP < t1;
-            if (more) load_step(base + STEP + (int64_t)lane * E16, nxt);
+            load_step(base + (int64_t)lane * E16, cur);
 #pragma unroll
             for (int e = 0; e < E16; ++e) {
                 SegRow<PP> row;
@@ -588,10 +589,6 @@ __global__ __launch_bounds__(64) void rolling_totals_kernel(const T* const* __re
                 const bool ok = (base + (int64_t)lane * E16 + e < t1) && seg_finite<PP>(row);
                 if (!ok) seg_zero<PP>(row);
                 seg_accumulate<PP, NV, 1>(S, row, ok);
-            }
-            if (more) {
-#pragma unroll
-                for (int c = 0; c <= PP; ++c) cur[c] = nxt[c];
             }
         }
         // ---- the tile's totals: sum over the lanes in lane order (fixed order: reproducible)
