@@ -1,6 +1,8 @@
 // capi.hip -- the extern "C" surface declared in include/pds_lstsq.h: context management, host <-> HBM
 // staging, and the per-expression pipelines that string the kernels together.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 

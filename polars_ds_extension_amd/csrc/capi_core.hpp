@@ -4,6 +4,27 @@
 #pragma once
 
 static thread_local std::string g_err;
+
+// PDS_TRACE=1: wall-clock stage marks of the host-frame pipelines on stderr (each mark synchronises the stream: a diagnostic,
+// it serialises what would otherwise overlap)
+struct StageTrace {
+    pds_ctx* ctx;
+    const char* what;
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    StageTrace(pds_ctx* c, const char* w) : ctx(c), what(w) {
+        static const bool env = [] { const char* e = std::getenv("PDS_TRACE"); return e && e[0] == '1'; }();
+        on = env;
+        if (on) t0 = std::chrono::steady_clock::now();
+    }
+    void mark(const char* stage) {
+        if (!on) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[pds trace] %s: %-28s %8.2f ms\n", what, stage, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
 void set_error(const std::string& msg) { g_err = msg; }
 int fail(int code, const std::string& msg) {
     g_err = msg;

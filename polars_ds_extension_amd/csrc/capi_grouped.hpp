@@ -306,6 +306,7 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
     const int nc = n_feat + 1, pp = n_feat + (prm->add_bias ? 1 : 0);
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t key_bytes = up((size_t)n_rows * 8), col_bytes = up((size_t)n_rows * sizeof(T)), idx_bytes = up((size_t)n_rows * 4);
+    StageTrace tr(ctx, "pds_lr_by_key");
     // ---- keys on the device, and are they already in order?
     const int64_t* d_keys = keys;
     if (space == PDS_HOST) {
@@ -317,6 +318,7 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
     if (int rc = ensure_ws(ctx, ctx->solve_ws, 4096)) return rc;  // a flag word that outlives the workspace sizing below
     bool sorted = false;
     if (int rc = keys_nondecreasing(ctx, d_keys, n_rows, static_cast<unsigned*>(ctx->solve_ws.ptr), &sorted)) return rc;
+    tr.mark("keys H2D + order check");
     // ---- workspace: [raw columns (host frames)] [sorted keys, index in/out, gathered columns (unsorted frames)] runs, temp
     const int64_t cap = std::min<int64_t>(max_groups, n_rows);
     const size_t temp_bytes = keyed_temp_bytes(n_rows);
@@ -324,6 +326,7 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
     if (space == PDS_HOST) need += col_bytes * nc + up((size_t)cap * pp * sizeof(T)) + up((size_t)cap);
     if (!sorted) need += 2 * key_bytes + 2 * idx_bytes + col_bytes * nc + up((size_t)n_rows * nc * sizeof(T)) + up(2 * (size_t)nc * sizeof(T*)) + 1024;
     if (int rc = ensure_ws(ctx, ctx->keyed, need)) return rc;
+    tr.mark("workspace");
     char* w = static_cast<char*>(ctx->keyed.ptr);
     auto take = [&](size_t b) { char* r = w; w += up(b); return r; };
     void* d_temp = take(temp_bytes);
@@ -339,6 +342,7 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
             PDS_HIP_CHECK(hipMemcpyAsync(d, cols[c], (size_t)n_rows * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
             src[c] = d;
         }
+    tr.mark("columns H2D");
     const int64_t* d_sorted_keys = d_keys;
     if (!sorted) {
         int64_t* sk = reinterpret_cast<int64_t*>(take((size_t)n_rows * 8));
@@ -372,8 +376,10 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
             PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // (tbl: source of the table copy)
         }
     }
+    tr.mark("sort + gather");
     int64_t ng = 0;
     if (int rc = keyed_runs(ctx, d_sorted_keys, n_rows, d_unique, d_counts, d_offsets, d_nruns, d_temp, temp_bytes, &ng)) return rc;
+    tr.mark("run lengths + offsets");
     *n_groups = ng;
     if (ng > max_groups) return fail(PDS_ERR_INVALID, "more distinct keys than max_groups");
     T* d_co = coeffs;
@@ -383,6 +389,7 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
         d_nu = reinterpret_cast<uint8_t*>(take((size_t)cap));
     }
     if (int rc = grouped_impl<T>(ctx, src.data(), n_feat, n_rows, d_offsets, ng, PDS_DEVICE, prm, d_co, d_nu)) return rc;
+    tr.mark("grouped fit");
     if (space == PDS_HOST) {
         PDS_HIP_CHECK(hipMemcpyAsync(coeffs, d_co, (size_t)ng * pp * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
         if (is_null) PDS_HIP_CHECK(hipMemcpyAsync(is_null, d_nu, (size_t)ng, hipMemcpyDeviceToHost, ctx->stream));
@@ -391,5 +398,6 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
         PDS_HIP_CHECK(hipMemcpyAsync(out_keys, d_unique, (size_t)ng * 8, hipMemcpyDeviceToDevice, ctx->stream));
     }
     PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    tr.mark("results D2H");
     return PDS_OK;
 }
