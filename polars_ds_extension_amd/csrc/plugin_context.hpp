@@ -15,6 +15,16 @@ pds_ctx* thread_ctx() {
 void check(int rc) {
     if (rc != PDS_OK) raise(pds_last_error());
 }
+// PDS_REFERENCE_QUIRKS=1 (read per call): answer the two places where the reference's outputs are accidents of its
+// result assembly exactly as it does instead of the way DESIGN.md section 7 argues for --
+//   pl_lr_pred, null_policy "ignore", nulls present: ONE row {pred: null, resid: null} (the dummy mask of
+//     series_to_mat_for_lr has length 1 and is false, linear_regression.rs:194-197, and :790-806 builds from the mask);
+//   pl_recursive_lr, skip / fill, nulls present: pred of the j-th fitted row is formed from compacted row j, not from the
+//     row the coefficients belong to (:1158-1166 reads x.get(i..i+1) where the null-free branch reads row m + i).
+bool reference_quirks() {
+    const char* e = std::getenv("PDS_REFERENCE_QUIRKS");
+    return e && e[0] == '1';
+}
 
 template <typename T> struct Api;
 template <> struct Api<double> {

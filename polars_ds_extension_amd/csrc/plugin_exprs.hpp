@@ -22,6 +22,19 @@ void do_pl_lr(SeriesExport* in, size_t n_in, const Kwargs& kw, SeriesExport* out
     std::vector<uint8_t> valid;
     bool any_null = false;
     for (auto& c : cols) any_null |= c.null_count > 0;
+    if (want_pred && !weighted && any_null && pol.kind == Policy::IGNORE && reference_quirks()) {
+        // the reference's answer (see reference_quirks()): one all-null row, whatever the frame holds
+        const uint8_t none = 0;
+        const T zero = 0;
+        std::vector<std::unique_ptr<ArrowArray>> kids;
+        kids.push_back(prim_array<T>(&zero, 1, &none));
+        kids.push_back(prim_array<T>(&zero, 1, &none));
+        std::vector<std::unique_ptr<ArrowSchema>> sk;
+        sk.push_back(make_schema(fmt_of<T>(), "pred"));
+        sk.push_back(make_schema(fmt_of<T>(), "resid"));
+        export_series(out, make_schema("+s", "", std::move(sk)), struct_array(1, std::move(kids)));
+        return;
+    }
     // small null-free coefficient fits (the per-group calls of group_by().agg()): leave together with whatever else is queued
     if (!weighted && !want_pred && !any_null && n >= pp && n > 0 && (size_t)n * (n_feat + 1) * sizeof(T) <= ((size_t)256 << 10) &&
         n_feat <= 64 && prm.solver != PDS_SOLVER_SVD && coalescing_enabled()) {
@@ -222,6 +235,13 @@ void do_windowed(SeriesExport* in, size_t n_in, const Kwargs& kw, SeriesExport* 
             std::vector<T> cc((size_t)nk * pp), pc(nk);
             std::vector<uint8_t> vc(nk);
             check(Api<T>::recursive(thread_ctx(), ptrs.data(), n_feat, nk, PDS_HOST, bias, nwin, (T)lambda, cc.data(), pc.data(), vc.data()));
+            if (reference_quirks())  // pred of fitted row j from compacted row j - (n - 1)
+                for (int64_t j = nwin - 1; j < nk; ++j) {
+                    const int64_t r = j - (nwin - 1);
+                    T acc = bias ? cc[(size_t)j * pp + n_feat] : (T)0;
+                    for (int k = 0; k < n_feat; ++k) acc += ptrs[1 + k][r] * cc[(size_t)j * pp + k];
+                    pc[j] = acc;
+                }
             int64_t j = 0;
             for (int64_t i = 0; i < n; ++i) {
                 if (!keep[i]) continue;

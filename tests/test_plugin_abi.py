@@ -384,6 +384,48 @@ def test_pl_recursive_lr_null_policies(so, orc):
 
 
 @pytest.mark.gpu
+def test_reference_quirks_switch(so, orc):
+    """PDS_REFERENCE_QUIRKS=1 reproduces the two accidents of the reference's result assembly that the default build
+    does not (DESIGN.md section 7): pl_lr_pred + ignore + nulls -> ONE null row (linear_regression.rs:194-197, :790-806);
+    pl_recursive_lr + skip / fill + nulls -> pred from compacted row j (:1158-1166)."""
+    import os
+
+    rng = np.random.default_rng(5)
+    n, n0 = 400, 5
+    X = rng.random((n, 2))
+    y = X @ [2.0, -1.0] + 0.5 + 0.01 * rng.random(n)
+    mx = rng.random(n) < 0.1
+    ins = [("y", pa.array(y)), ("x1", pa.array(X[:, 0], mask=mx)), ("x2", pa.array(X[:, 1]))]
+    kw_rec = {"null_policy": "skip", "n": n0, "bias": True, "lambda": 0.0, "min_size": 0}
+    _, plain = ph.call_plugin(so, "pl_recursive_lr", ins, kw_rec)
+    _, pred_plain = ph.call_plugin(so, "pl_lr_pred", ins, dict(LR, bias=True, null_policy="ignore"))
+    assert len(pred_plain) == n
+    os.environ["PDS_REFERENCE_QUIRKS"] = "1"
+    try:
+        _, pred_q = ph.call_plugin(so, "pl_lr_pred", ins, dict(LR, bias=True, null_policy="ignore"))
+        _, rec_q = ph.call_plugin(so, "pl_recursive_lr", ins, kw_rec)
+        # no nulls: nothing changes
+        clean = [("y", pa.array(y)), ("x1", pa.array(X[:, 0])), ("x2", pa.array(X[:, 1]))]
+        _, pred_clean = ph.call_plugin(so, "pl_lr_pred", clean, dict(LR, bias=True, null_policy="ignore"))
+    finally:
+        del os.environ["PDS_REFERENCE_QUIRKS"]
+    assert pred_q.to_pylist() == [{"pred": None, "resid": None}]
+    assert len(pred_clean) == n and pred_clean.null_count == 0
+    plain, rec_q = plain.to_pylist(), rec_q.to_pylist()
+    idx = np.flatnonzero(~mx)
+    for j, i in enumerate(idx):
+        if j < n0 - 1:
+            assert rec_q[i] == {"coeffs": None, "pred": None}
+            continue
+        assert rec_q[i]["coeffs"] == plain[i]["coeffs"]  # the coefficients are the same rows either way
+        r = idx[j - (n0 - 1)]  # compacted row j - (n - 1) of the reference's x
+        np.testing.assert_allclose(rec_q[i]["pred"], np.r_[X[r], 1.0] @ np.array(plain[i]["coeffs"]), rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(plain[i]["pred"], np.r_[X[i], 1.0] @ np.array(plain[i]["coeffs"]), rtol=1e-10, atol=1e-12)
+    for i in np.flatnonzero(mx):
+        assert rec_q[i] == {"coeffs": None, "pred": None}
+
+
+@pytest.mark.gpu
 def test_borrowed_chunks_slices_and_bitmaps(so, orc):
     """A single Float64 chunk is read in place (no marshalling copy): slices (offset != 0), validity bitmaps at bit offsets
     that are not byte aligned, several chunks of odd lengths -- and a fill policy never writes into the caller's buffers."""
