@@ -22,6 +22,11 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float f4w __attribute__((ext_vector_type(4), aligned(4)));
 typedef double d4w __attribute__((ext_vector_type(4)));
 typedef double d2w __attribute__((ext_vector_type(2), aligned(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f2w __attribute__((ext_vector_type(2)));
+typedef unsigned u4w __attribute__((ext_vector_type(4)));
+typedef unsigned u2w __attribute__((ext_vector_type(2)));
 
 constexpr int kWB = 128;     // block tile edge (columns of Z)
 constexpr int kWThreads = 256;
@@ -42,6 +47,35 @@ struct Wide<float> {
     using vec = f4w;
     static constexpr int VL = 4;
 };
+// f32 on the bf16 matrix-core path (SPLIT): x = h + m + l exactly, three bf16 planes (round to nearest, so the remainders
+// carry random signs); LDS holds each plane k-contiguous per column, 16 pad bytes per column keep the 16-byte operand reads
+// (8 lanes = 8 columns, 20 dwords apart) on distinct banks
+#ifndef PDS_WIDE_SPLIT_KC
+#define PDS_WIDE_SPLIT_KC 32
+#endif
+constexpr int kSplitKC = PDS_WIDE_SPLIT_KC;          // rows per stage of the SPLIT arithmetic
+constexpr int kSplitCSD = kSplitKC / 2 + 4;          // dwords per column and plane
+constexpr int kSplitPlane = 128 * kSplitCSD;         // dwords per plane of one panel
+// one packed pair of bf16 (round to nearest even) out of two floats; the floats keep the remainders
+__device__ __forceinline__ unsigned split_pair(float& a, float& b) {
+    const f2w v = {a, b};
+    const unsigned bits = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    a -= __builtin_bit_cast(float, bits << 16);
+    b -= __builtin_bit_cast(float, bits & 0xffff0000u);
+    return bits;
+}
+// c += a b with a = ah + am + al, b = bh + bm + bl: the six products down to 2^-24 of |a||b| (the three left out are below
+// the rounding of the f32 accumulator), smallest first
+__device__ __forceinline__ f16v mfma_split(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f16v c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+    return c;
+}
+
 template <>
 struct Wide<double> {
     static constexpr int KC = 16;
@@ -78,20 +112,22 @@ __host__ __device__ inline int ij_to_pair(int I, int J, int nb) { return I * nb 
 // WEIGHTED: A = Z' diag(w) Z (faer_weighted_lr, lr_solvers.rs:386-409) as the plain Gram of sqrt(w) * Z: every value is
 // scaled by sqrt(w_row) on its way into LDS (`sw`, precomputed once per call), which keeps the product symmetric, so
 // the diagonal-block and tail shortcuts apply unchanged.
-template <typename T, int MODE, bool WEIGHTED>
-__global__ __launch_bounds__(kWThreads, 2) void moments_wide_kernel(const T* const* __restrict__ cols, int p, int64_t n,
+// SPLIT (f32 only): the products run on the bf16 matrix cores as three-plane splits (see mfma_split) -- 6 instructions of
+// 32 cycles per 16 rows instead of 8 of 64 on v_mfma_f32_32x32x2_f32, f32 accumulation either way.
+template <typename T, int MODE, bool WEIGHTED, bool SPLIT = false>
+__global__ __launch_bounds__(kWThreads, (SPLIT && kSplitKC == 16) ? 3 : 2) void moments_wide_kernel(const T* const* __restrict__ cols, int p, int64_t n,
                                                                  int nb, int nb_main, int i_first, int64_t rows_per_split,
                                                                  const T* __restrict__ sw, T* __restrict__ partials) {
     using W = Wide<T>;
-    constexpr int KC = W::KC, CS = W::CS, MT = W::MT, NT = W::NT, VL = W::VL;
+    constexpr int KC = SPLIT ? kSplitKC : W::KC, CS = W::CS, MT = W::MT, NT = W::NT, VL = W::VL;
     constexpr int PPC = KC / VL;                  // 16-byte pieces per column and stage
     constexpr int NCH = kWB * PPC / kWThreads;    // chunks per thread and panel
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(!SPLIT || (sizeof(T) == 4 && KC % 16 == 0), "the split path is the f32 Gram on bf16 matrix cores");
     T* LI = reinterpret_cast<T*>(smem);
     T* LJ = LI + kWB * CS;
-#ifdef PDS_WIDE_DB
-    T* const lds_base = LI;  // two stage buffers of 2 * kWB * CS elements each, used alternately (one barrier per stage)
-#endif
+    unsigned* const SI = reinterpret_cast<unsigned*>(smem);  // SPLIT: planes h, m, l of the I panel, then of the J panel
+    unsigned* const SJ = SI + 3 * kSplitPlane;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     constexpr bool NARROW = MODE == 1, FUSE = MODE == 2;
@@ -130,20 +166,23 @@ __global__ __launch_bounds__(kWThreads, 2) void moments_wide_kernel(const T* con
     // this thread's 4 chunks per panel: chunk id = tid + 256 u  ->  column id/8, 16-byte piece id%8
     gptr<T> ptrI[NCH];
     gptr<T> ptrJ[NCH];
-    int kindI[NCH], kindJ[NCH];  // 0 data column, 1 ones column, 2 zero padding
+    unsigned kinds = 0;  // 2 bits per chunk, I panel then J panel: 0 data column, 1 ones column, 2 zero padding
 #pragma unroll
     for (int u = 0; u < NCH; ++u) {
         const int id = tid + kWThreads * u;
         const int cI = I * kWB + (id / PPC), cJ = ((FUSE && diag) ? nb - 1 : J) * kWB + (id / PPC);
-        kindI[u] = (cI < p || cI == p + 1) ? 0 : (cI == p ? 1 : 2);
-        kindJ[u] = (cJ < p || cJ == p + 1) ? 0 : (cJ == p ? 1 : 2);
+        kinds |= (unsigned)((cI < p || cI == p + 1) ? 0 : (cI == p ? 1 : 2)) << (2 * u);
+        kinds |= (unsigned)((cJ < p || cJ == p + 1) ? 0 : (cJ == p ? 1 : 2)) << (2 * (NCH + u));
         ptrI[u] = as_global(cols[cI < p ? cI : p]);  // index p is y in the device table
         ptrJ[u] = as_global(cols[cJ < p ? cJ : p]);
     }
     (void)q;
+    // block-uniform: every column of the panel is a data column (no ones column, no y, no padding)
+    const bool plainI = (I + 1) * kWB <= p, plainJ = (J + 1) * kWB <= p;
 
-    typename W::vec rI[NCH], rJ[NCH];
-    auto load_stage = [&](int64_t row0) __attribute__((always_inline)) {
+    typename W::vec rI[1][NCH], rJ[1][NCH];
+    auto load_stage = [&](auto set_c, int64_t row0) __attribute__((always_inline)) {
+        constexpr int SET = decltype(set_c)::value;
         typename W::vec swv;  // sqrt(w) of this thread's VL rows (the same rows for all of its chunks)
         if constexpr (WEIGHTED) {
             const int64_t r = row0 + (tid % PPC) * VL;
@@ -154,14 +193,33 @@ __global__ __launch_bounds__(kWThreads, 2) void moments_wide_kernel(const T* con
                 for (int e = 0; e < VL; ++e) swv[e] = (r + e < r_end) ? sw[r + e] : T(0);
             }
         }
+        // the common stage -- all KC rows inside the split, every column of the panel a data column -- is straight 16-byte
+        // loads behind wave-uniform tests; the per-lane kind / range selects of the general path cost a wave ~2 000 cycles
+        // of scalar branches per stage, which the short matrix-core phase of the SPLIT arithmetic no longer covers
+        const bool full = row0 + KC <= r_end;
 #pragma unroll
-        for (int u = 0; u < NCH; ++u) {
-            const int id = tid + kWThreads * u;
-            const int64_t r = row0 + (id % PPC) * VL;
+        for (int pnl = 0; pnl < 2; ++pnl) {
+            if (pnl == 1 && diag && !FUSE) continue;  // diagonal: J half unused
+            if (full && (pnl ? (plainJ && !diag) : plainI)) {
 #pragma unroll
-            for (int pnl = 0; pnl < 2; ++pnl) {
-                if (pnl == 1 && diag && !(FUSE && (tid + kWThreads * u) / PPC < 32)) continue;  // diagonal: J half unused, or the tail tile
-                const int kind = pnl ? kindJ[u] : kindI[u];
+                for (int u = 0; u < NCH; ++u) {
+                    const int64_t r = row0 + ((tid + kWThreads * u) % PPC) * VL;
+                    typename W::vec v = *reinterpret_cast<gptr<typename W::vec>>((pnl ? ptrJ[u] : ptrI[u]) + r);
+                    if constexpr (WEIGHTED) {
+#pragma unroll
+                        for (int e = 0; e < VL; ++e) v[e] *= swv[e];
+                    }
+                    if (pnl) rJ[SET][u] = v;
+                    else rI[SET][u] = v;
+                }
+                continue;
+            }
+#pragma unroll
+            for (int u = 0; u < NCH; ++u) {
+                const int id = tid + kWThreads * u;
+                const int64_t r = row0 + (id % PPC) * VL;
+                if (pnl == 1 && diag && !(FUSE && id / PPC < 32)) continue;  // diagonal: only the tail tile
+                const int kind = (kinds >> (2 * (pnl * NCH + u))) & 3;
                 const gptr<T> ptr = pnl ? ptrJ[u] : ptrI[u];
                 typename W::vec v;
                 if (kind == 0 && r + VL <= r_end) {
@@ -177,20 +235,38 @@ __global__ __launch_bounds__(kWThreads, 2) void moments_wide_kernel(const T* con
 #pragma unroll
                     for (int e = 0; e < VL; ++e) v[e] *= swv[e];
                 }
-                if (pnl) rJ[u] = v;
-                else rI[u] = v;
+                if (pnl) rJ[SET][u] = v;
+                else rI[SET][u] = v;
             }
         }
     };
-    auto store_stage = [&]() __attribute__((always_inline)) {
+    auto store_stage = [&](auto set_c) __attribute__((always_inline)) {
+        constexpr int SET = decltype(set_c)::value;
 #pragma unroll
         for (int u = 0; u < NCH; ++u) {
             const int id = tid + kWThreads * u;
             const int c = id / PPC, k0 = (id % PPC) * VL;
+            if constexpr (SPLIT) {
 #pragma unroll
-            for (int e = 0; e < VL; ++e) {
-                LI[c * CS + k0 + e] = rI[u][e];
-                if (!diag || (FUSE && c < 32)) LJ[c * CS + k0 + e] = rJ[u][e];
+                for (int pnl = 0; pnl < 2; ++pnl) {
+                    if (pnl == 1 && diag && !(FUSE && c < 32)) continue;
+                    float v0 = pnl ? rJ[SET][u][0] : rI[SET][u][0], v1 = pnl ? rJ[SET][u][1] : rI[SET][u][1];
+                    float v2 = pnl ? rJ[SET][u][2] : rI[SET][u][2], v3 = pnl ? rJ[SET][u][3] : rI[SET][u][3];
+                    unsigned* dst = (pnl ? SJ : SI) + c * kSplitCSD + k0 / 2;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        u2w w;
+                        w[0] = split_pair(v0, v1);
+                        w[1] = split_pair(v2, v3);
+                        *reinterpret_cast<u2w*>(dst + pl * kSplitPlane) = w;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < VL; ++e) {
+                    LI[c * CS + k0 + e] = rI[SET][u][e];
+                    if (!diag || (FUSE && c < 32)) LJ[c * CS + k0 + e] = rJ[SET][u][e];
+                }
             }
         }
     };
@@ -220,7 +296,24 @@ __global__ __launch_bounds__(kWThreads, 2) void moments_wide_kernel(const T* con
     (void)PJ;
     const bool tailwave = FUSE && diag && wave == 2;
     auto mma_tail = [&]() __attribute__((always_inline)) {
-        if constexpr (FUSE) {
+        if constexpr (FUSE && SPLIT) {
+            const int li = lane & 31, kq = lane >> 5;
+#pragma unroll
+            for (int ks = 0; ks < KC / 16; ++ks) {
+                bf16x8 b[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    b[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4w*>(SJ + pl * kSplitPlane + li * kSplitCSD + ks * 8 + kq * 4));
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    bf16x8 a[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        a[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4w*>(SI + pl * kSplitPlane + (t * 32 + li) * kSplitCSD + ks * 8 + kq * 4));
+                    accf[t >> 1][t & 1] = mfma_split(a, b, accf[t >> 1][t & 1]);
+                }
+            }
+        } else if constexpr (FUSE) {
             const int li = lane & 31, kq = lane >> 5;
 #pragma unroll
             for (int ks = 0; ks < W::KS; ++ks) {
@@ -240,7 +333,28 @@ __global__ __launch_bounds__(kWThreads, 2) void moments_wide_kernel(const T* con
     constexpr int NMN = 32 / MT;  // m-tiles per wave in narrow mode
     auto mma_stage = [&](auto nm_c, auto nn_c) __attribute__((always_inline)) {
         constexpr int NM = decltype(nm_c)::value, NN = decltype(nn_c)::value;
-        if constexpr (sizeof(T) == 4) {
+        if constexpr (SPLIT) {
+            const int li = lane & 31, kq = lane >> 5;
+            const unsigned* const SB = diag ? SI : SJ;
+#pragma unroll
+            for (int ks = 0; ks < KC / 16; ++ks) {
+                bf16x8 a[NM][3];
+#pragma unroll
+                for (int m = 0; m < NM; ++m)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        a[m][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4w*>(SI + pl * kSplitPlane + (rb + m * 32 + li) * kSplitCSD + ks * 8 + kq * 4));
+#pragma unroll
+                for (int nn = 0; nn < NN; ++nn) {  // one B tile at a time: 12 operand registers instead of 24
+                    bf16x8 b[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        b[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4w*>(SB + pl * kSplitPlane + (cb + nn * 32 + li) * kSplitCSD + ks * 8 + kq * 4));
+#pragma unroll
+                    for (int m = 0; m < NM; ++m) accf[m][nn] = mfma_split(a[m], b, accf[m][nn]);
+                }
+            }
+        } else if constexpr (sizeof(T) == 4) {
             const int li = lane & 31, kq = lane >> 5;
 #pragma unroll
             for (int ks = 0; ks < W::KS; ++ks) {
@@ -280,40 +394,34 @@ __global__ __launch_bounds__(kWThreads, 2) void moments_wide_kernel(const T* con
             }
         }
     };
-    if (r_begin < r_end) load_stage(r_begin);
+    auto mma_any = [&]() __attribute__((always_inline)) {
+        if constexpr (narrow) mma_stage(std::integral_constant<int, NMN>{}, std::integral_constant<int, 1>{});
+        else if (tailwave) mma_tail();
+        else mma_stage(std::integral_constant<int, NT>{}, std::integral_constant<int, NT>{});
+    };
+    using set0 = std::integral_constant<int, 0>;
+    // ---- the partial tile: P[split][pair][i * 128 + j] (narrow: only the first MFMA tile column)
+    T* P = partials + ((int64_t)by * npairs + pair) * (kWB * kWB);
+    if constexpr (FUSE) {
+        if (tailwave) P = partials + ((int64_t)by * npairs + ij_to_pair(I, nb - 1, nb)) * (kWB * kWB);  // pair (I, nb-1), first tile column
+    }
+    if (r_begin < r_end) load_stage(set0{}, r_begin);
     for (int64_t row0 = r_begin; row0 < r_end; row0 += KC) {
-#ifdef PDS_WIDE_DB
-        // EXPERIMENT (unmeasured): stage s parks its panel in buffer s & 1.  A wave that is still multiplying stage s - 1 reads
-        // the other buffer; nobody reads this one any more, because every wave passed stage s - 1's barrier only after it had
-        // finished stage s - 2.  One barrier per stage instead of two, for twice the LDS.
-        {
-            const int buf = (int)(((row0 - r_begin) / KC) & 1);
-            LI = lds_base + (size_t)buf * 2 * kWB * CS;
-            LJ = LI + kWB * CS;
-            PJ = diag ? LI : LJ;
-        }
-        store_stage();
-        __syncthreads();
-#else
         __syncthreads();  // previous stage's reads are done
-        store_stage();
+        store_stage(set0{});
         __syncthreads();
-#endif
-        if (row0 + KC < r_end) load_stage(row0 + KC);
+        if (row0 + KC < r_end) load_stage(set0{}, row0 + KC);
         if constexpr (narrow) mma_stage(std::integral_constant<int, NMN>{}, std::integral_constant<int, 1>{});
         else if (tailwave) mma_tail();
         else mma_stage(std::integral_constant<int, NT>{}, std::integral_constant<int, NT>{});
     }
-    // ---- write the partial tile: P[split][pair][i * 128 + j] (narrow: only the first MFMA tile column)
-    T* P = partials + ((int64_t)by * npairs + pair) * (kWB * kWB);
     if constexpr (FUSE) {
         if (tailwave) {  // rows t * 32.. of pair (I, nb-1), first tile column
-            T* PT = partials + ((int64_t)by * npairs + ij_to_pair(I, nb - 1, nb)) * (kWB * kWB);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) PT[(t * 32 + row) * kWB + col] = accf[t >> 1][t & 1][r];
+                for (int t = 0; t < 4; ++t) P[(t * 32 + row) * kWB + col] = accf[t >> 1][t & 1][r];
             }
             return;
         }
@@ -387,7 +495,7 @@ static void wide_split(int num_cus, int npairs, int64_t n_rows, int& nsplit, int
     nsplit = (int)((n_rows + rows_per_split - 1) / rows_per_split);
 }
 
-template <typename T, bool WEIGHTED>
+template <typename T, bool WEIGHTED, bool SPLIT>
 static int launch_moments_wide_w(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, T* d_moments) {
     using W = Wide<T>;
     const int q = n_feat + 2;
@@ -399,19 +507,15 @@ static int launch_moments_wide_w(pds_ctx* ctx, const DeviceCols<T>& dc, int n_fe
     const size_t part_bytes = (size_t)nsplit * npairs * kWB * kWB * sizeof(T);
     T* partials = reinterpret_cast<T*>(ws_take(ctx, part_bytes));
     if (ctx->ws_used > ctx->ws.bytes) return fail(PDS_ERR_INVALID, "internal: workspace for the wide Gram build was not reserved");
-#ifdef PDS_WIDE_DB
-    const size_t lds = (size_t)4 * kWB * W::CS * sizeof(T);
-#else
-    const size_t lds = (size_t)2 * kWB * W::CS * sizeof(T);
-#endif
+    const size_t lds = SPLIT ? (size_t)6 * kSplitPlane * sizeof(unsigned) : (size_t)2 * kWB * W::CS * sizeof(T);
     T* d_sw = nullptr;
     if constexpr (WEIGHTED) d_sw = reinterpret_cast<T*>(ws_take(ctx, (size_t)n_rows * sizeof(T)));
     if (ctx->ws_used > ctx->ws.bytes) return fail(PDS_ERR_INVALID, "internal: workspace for the wide Gram build was not reserved");
     if (lds > 64 * 1024) {
-        PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_wide_kernel<T, 0, WEIGHTED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_wide_kernel<T, 1, WEIGHTED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_wide_kernel<T, 0, WEIGHTED, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_wide_kernel<T, 1, WEIGHTED, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if constexpr (sizeof(T) == 4)
-            PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_wide_kernel<T, 2, WEIGHTED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_wide_kernel<T, 2, WEIGHTED, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     KernelTimer timer(ctx, kKindMoments);
     if constexpr (WEIGHTED)
@@ -424,19 +528,19 @@ static int launch_moments_wide_w(pds_ctx* ctx, const DeviceCols<T>& dc, int n_fe
     if constexpr (sizeof(T) == 4) {
         if (tail_narrow && nb_main > 0) {
             fused = true;
-            hipLaunchKernelGGL((moments_wide_kernel<T, 2, WEIGHTED>), grid_main, dim3(kWThreads), lds, ctx->stream, dc.d_ptrs, n_feat,
-                               n_rows, nb, nb_main, 0, rows_per_split, d_sw, partials);
-            hipLaunchKernelGGL((moments_wide_kernel<T, 1, WEIGHTED>), dim3(1, nsplit), dim3(kWThreads), lds, ctx->stream, dc.d_ptrs,
-                               n_feat, n_rows, nb, nb_main, nb - 1, rows_per_split, d_sw, partials);
+            hipLaunchKernelGGL((moments_wide_kernel<T, 2, WEIGHTED, SPLIT>), grid_main, dim3(kWThreads), lds, ctx->stream, dc.d_ptrs,
+                               n_feat, n_rows, nb, nb_main, 0, rows_per_split, d_sw, partials);
+            hipLaunchKernelGGL((moments_wide_kernel<T, 1, WEIGHTED, SPLIT>), dim3(1, nsplit), dim3(kWThreads), lds, ctx->stream,
+                               dc.d_ptrs, n_feat, n_rows, nb, nb_main, nb - 1, rows_per_split, d_sw, partials);
         }
     }
     if (!fused) {
         if (nb_main > 0)
-            hipLaunchKernelGGL((moments_wide_kernel<T, 0, WEIGHTED>), grid_main, dim3(kWThreads), lds, ctx->stream, dc.d_ptrs, n_feat,
-                               n_rows, nb, nb_main, 0, rows_per_split, d_sw, partials);
-        if (tail_narrow)
-            hipLaunchKernelGGL((moments_wide_kernel<T, 1, WEIGHTED>), dim3(nb, nsplit), dim3(kWThreads), lds, ctx->stream, dc.d_ptrs,
+            hipLaunchKernelGGL((moments_wide_kernel<T, 0, WEIGHTED, SPLIT>), grid_main, dim3(kWThreads), lds, ctx->stream, dc.d_ptrs,
                                n_feat, n_rows, nb, nb_main, 0, rows_per_split, d_sw, partials);
+        if (tail_narrow)
+            hipLaunchKernelGGL((moments_wide_kernel<T, 1, WEIGHTED, SPLIT>), dim3(nb, nsplit), dim3(kWThreads), lds, ctx->stream,
+                               dc.d_ptrs, n_feat, n_rows, nb, nb_main, 0, rows_per_split, d_sw, partials);
     }
     hipLaunchKernelGGL((moments_wide_reduce_kernel<T>), dim3(npairs, 64), dim3(256), 0, ctx->stream, partials, nsplit,
                        npairs, nb, n_feat, d_moments);
@@ -446,8 +550,16 @@ static int launch_moments_wide_w(pds_ctx* ctx, const DeviceCols<T>& dc, int n_fe
 
 template <typename T>
 int launch_moments_wide(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, bool weighted, T* d_moments) {
-    return weighted ? launch_moments_wide_w<T, true>(ctx, dc, n_feat, n_rows, d_moments)
-                    : launch_moments_wide_w<T, false>(ctx, dc, n_feat, n_rows, d_moments);
+    if constexpr (sizeof(T) == 4) {
+        // f32: products on the bf16 matrix cores as three-plane splits (2.7x the f32 matrix-core rate at f32 accuracy);
+        // PDS_WIDE_F32_NATIVE=1 keeps v_mfma_f32_32x32x2_f32 (A/B, and the exact-fmaf-chain arithmetic)
+        const char* e = std::getenv("PDS_WIDE_F32_NATIVE");  // read per call: the parity tests run both arithmetics
+        if (!(e && e[0] == '1'))
+            return weighted ? launch_moments_wide_w<T, true, true>(ctx, dc, n_feat, n_rows, d_moments)
+                            : launch_moments_wide_w<T, false, true>(ctx, dc, n_feat, n_rows, d_moments);
+    }
+    return weighted ? launch_moments_wide_w<T, true, false>(ctx, dc, n_feat, n_rows, d_moments)
+                    : launch_moments_wide_w<T, false, false>(ctx, dc, n_feat, n_rows, d_moments);
 }
 
 size_t moments_wide_workspace(int num_cus, int n_feat, int64_t n_rows, bool weighted) {

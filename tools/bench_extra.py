@@ -95,7 +95,13 @@ if "en" in which:
     out["elastic_net_c5"] = {"rows": n, "p": p, "dtype": "f32", "wall_ms": round(wall * 1e3, 2), "gram_ms": round(gms, 3),
                              "gram_TFLOPs_full_square": round(flops / (gms * 1e-3) / 1e12, 1),
                              "gram_TFLOPs_upper_triangle": round(flops / 2 / (gms * 1e-3) / 1e12, 1),
-                             "cd_ms": round(t.get("iterative", (0, 0))[0], 3), "nonzero": int((abs(b) > 1e-6).sum())}
+                             "cd_ms": round(t.get("iterative", (0, 0))[0], 3), "nonzero": int((abs(b) > 1e-6).sum()),
+                             "arithmetic": "f32 products as three-plane bf16 splits on the bf16 matrix cores (default)"}
+    import os
+    os.environ["PDS_WIDE_F32_NATIVE"] = "1"
+    wall2, t2, _ = timed(lambda: pds.lin_reg(*xs, target=y, l1_reg=0.01, l2_reg=0.01, tol=1e-5, ctx=ctx), reps=3, warm=1)
+    del os.environ["PDS_WIDE_F32_NATIVE"]
+    out["elastic_net_c5"]["native_f32_mfma"] = {"wall_ms": round(wall2 * 1e3, 2), "gram_ms": round(t2["moments"][0], 3)}
     pds.config.LIN_REG_EXPR_F64 = True
 if "c1" in which:
     # configs[0]: pds.lin_reg(x1..x4, target=y, add_bias=False) on a 100k-row f64 frame (benchmarks/test_linear_regression.py:9-31)
