@@ -415,7 +415,8 @@ double pds_student_t_ppf(double q, double df);
  * 3 inverse; variance: 0 gaussian, 1 poisson, 2 binomial, 3 gamma (link_functions.rs:5-77; GLMFamily::link_function /
  * variance_function glm_solvers.rs:24-41).  coeffs: n_feat + add_bias values, bias last; *n_iter (nullable): iterations run.
  * Stops when max |beta_new - beta| < tol or after max_iter iterations (the reference does not report non-convergence).
- * Up to 16 feature columns.  Each iteration is one pass over the frame. */
+ * Up to 16 feature columns an iteration is ONE pass over the frame (weights and working response formed inside the Gram
+ * kernel); wider frames write them as two columns and run the weighted wide Gram build on them. */
 int pds_glm_irls_f64(pds_ctx* ctx, const double* const* cols, int n_feat, int64_t n_rows, pds_space space, int add_bias, int link,
                      int variance, double tol, int max_iter, double* coeffs, int* n_iter);
 int pds_glm_irls_f32(pds_ctx* ctx, const float* const* cols, int n_feat, int64_t n_rows, pds_space space, int add_bias, int link,

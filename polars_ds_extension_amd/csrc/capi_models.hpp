@@ -14,13 +14,16 @@ static int glm_irls_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t
                          int variance, T tol, int max_iter, T* coeffs, int* n_iter) {
     if (!ctx || !cols || !coeffs) return fail(PDS_ERR_INVALID, "null argument");
     if (n_feat < 1) return fail(PDS_ERR_INVALID, "need at least one feature column");
-    if (n_feat > kMaxFeatSmall) return fail(PDS_ERR_UNSUPPORTED, "GLM (IRLS): up to 16 feature columns");
     if (n_rows <= 0) return fail(PDS_ERR_EMPTY, "Empty data");
     if (max_iter < 1) return fail(PDS_ERR_INVALID, "`max_iter` must be > 1.");  // linear_models.py:756-757
     if (link < 0 || link > 3 || variance < 0 || variance > 3) return fail(PDS_ERR_INVALID, "unknown link / variance function");
     PDS_HIP_CHECK(hipSetDevice(ctx->device));
     const int p = n_feat, bias = add_bias ? 1 : 0, pp = p + bias, q = p + 2;
-    if (int rc = ws_reserve(ctx, 262144 + (size_t)max_iter * 1024 + sizeof(T) * (size_t)(2 * q * q + 2 * pp + 16) + sizeof(T*) * 64)) return rc;
+    const bool wide = p > kMaxFeatSmall;  // weights / working response as columns of their own + the wide weighted Gram build
+    const size_t row_bytes = ((size_t)n_rows * sizeof(T) + 255) & ~(size_t)255;
+    if (int rc = ws_reserve(ctx, 262144 + (size_t)max_iter * 1024 + sizeof(T) * (size_t)(2 * q * q + 2 * pp + 16) + sizeof(T*) * (2 * (size_t)p + 64) +
+                                     (wide ? 2 * row_bytes + moments_wide_workspace(ctx->num_cus, p, n_rows, true) : 0)))
+        return rc;
     DeviceCols<T> dc;
     if (int rc = make_device_cols<T>(ctx, cols, (const T*)nullptr, p, n_rows, space, dc)) return rc;
     T* d_mom = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * q * q));
@@ -29,12 +32,30 @@ static int glm_irls_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t
     ia.link = link;
     ia.variance = variance;
     ia.init = 1;
-    if (variance != 2) {  // mean of y for the starting mu (:272-279): sum(y) is an entry of the plain moment matrix
-        if (int rc = launch_moments<T>(ctx, dc, p, n_rows, false, d_mom)) return rc;
+    if (variance != 2) {  // mean of y for the starting mu (:272-279): sum(y) is an entry of a plain moment matrix
         T sy = T(0);
-        PDS_HIP_CHECK(hipMemcpyAsync(&sy, d_mom + p + (size_t)(p + 1) * q, sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+        if (!wide) {
+            if (int rc = launch_moments<T>(ctx, dc, p, n_rows, false, d_mom)) return rc;
+            PDS_HIP_CHECK(hipMemcpyAsync(&sy, d_mom + p + (size_t)(p + 1) * q, sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+        } else {  // ... of the one-feature frame [y | y]: a streaming pass over y instead of a (p + 2)^2 Gram build
+            const T* yy[2] = {dc.h_ptrs[p], dc.h_ptrs[p]};
+            DeviceCols<T> dy;
+            if (int rc = make_device_cols<T>(ctx, yy, (const T*)nullptr, 1, n_rows, PDS_DEVICE, dy)) return rc;
+            if (int rc = launch_moments<T>(ctx, dy, 1, n_rows, false, d_mom)) return rc;
+            PDS_HIP_CHECK(hipMemcpyAsync(&sy, d_mom + 1, sizeof(T), hipMemcpyDeviceToHost, ctx->stream));  // Z = [y | 1 | y]: (1, 0)
+        }
         PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         ia.y_mean = (double)sy / (double)n_rows;
+    }
+    DeviceCols<T> dcw;  // wide: [z | x1..xp] with the weight column w
+    T *d_w = nullptr, *d_z = nullptr;
+    if (wide) {
+        d_w = reinterpret_cast<T*>(ws_take(ctx, row_bytes));
+        d_z = reinterpret_cast<T*>(ws_take(ctx, row_bytes));
+        std::vector<const T*> cw(p + 1);
+        cw[0] = d_z;
+        for (int c = 0; c < p; ++c) cw[c + 1] = dc.h_ptrs[c];
+        if (int rc = make_device_cols<T>(ctx, cw.data(), d_w, p, n_rows, PDS_DEVICE, dcw)) return rc;
     }
     pds_lr_params prm{};
     prm.add_bias = bias;
@@ -44,9 +65,16 @@ static int glm_irls_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t
     int it = 0;
     while (it < max_iter) {
         ++it;
-        if (int rc = launch_moments<T>(ctx, dc, p, n_rows, false, d_mom, d_beta, bias, nullptr, nullptr, &ia)) return rc;
+        const size_t ws_mark = ctx->ws_used;
+        if (!wide) {
+            if (int rc = launch_moments<T>(ctx, dc, p, n_rows, false, d_mom, d_beta, bias, nullptr, nullptr, &ia)) return rc;
+        } else {
+            if (int rc = launch_irls_working_wide<T>(ctx, dc, p, n_rows, bias, d_beta, ia, d_w, d_z)) return rc;
+            if (int rc = launch_moments_wide<T>(ctx, dcw, p, n_rows, true, d_mom)) return rc;
+        }
         int null_flag = 0;
         if (int rc = lr_from_device_moments<T>(ctx, d_mom, p, &prm, /*weighted=*/true, bnew.data(), &null_flag, d_beta)) return rc;
+        if (wide) ctx->ws_used = ws_mark;  // the partial tiles of the wide build are per iteration (the solve has synchronised)
         ia.init = 0;
         T max_diff = T(0);
         for (int j = 0; j < pp; ++j) max_diff = std::max(max_diff, (T)std::fabs(beta[j] - bnew[j]));

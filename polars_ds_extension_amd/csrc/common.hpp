@@ -156,6 +156,10 @@ int launch_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_
                    double* d_moments_f64 = nullptr,
                    // p <= 16: weights and working response of one IRLS step from d_beta_resid (moments = X'WX | X'Wz)
                    const IrlsArgs* irls = nullptr);
+// moments.hip: weights and working response of one IRLS step for frames of more than 16 features (the wide Gram build reads them)
+template <typename T>
+int launch_irls_working_wide(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, int bias, const T* d_beta,
+                             const IrlsArgs& ia, T* d_w, T* d_z);
 // moments.hip: Gram build straight from a row-major device matrix (X[r * ld + c], y[r]), 1..16 features, unweighted
 template <typename T>
 int launch_moments_rowmajor(pds_ctx* ctx, const T* d_X, int64_t ld, const T* d_y, int n_feat, int64_t n_rows, T* d_moments,

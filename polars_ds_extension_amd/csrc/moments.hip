@@ -777,6 +777,47 @@ int launch_sum_moment_slots(pds_ctx* ctx, const double* d_slots, int nslots, int
     PDS_HIP_CHECK(hipGetLastError());
     return PDS_OK;
 }
+// More than 16 features: the IRLS step of the WM = 3 pass as a kernel of its own -- lane = row, run-time loop over the
+// columns (coefficients from the scalar cache), writes the row's weight and working response; the weighted wide Gram
+// build (moments_wide.hip) then reads them as its weight column and target.  Same arithmetic order as the fused pass.
+template <typename T>
+__global__ __launch_bounds__(256) void irls_working_wide_kernel(const T* const* __restrict__ cols, int p, int bias, int64_t n,
+                                                                const T* __restrict__ beta, IrlsArgs ia, T* __restrict__ w_out,
+                                                                T* __restrict__ z_out) {
+    const gptr<T> cy = as_global(cols[p]);
+    const T b0 = (bias && !ia.init) ? beta[p] : T(0);
+    const T ymean = (T)ia.y_mean;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+        const T yv = cy[r];
+        T eta, mu;
+        if (ia.init) {
+            mu = (ia.variance == 2) ? (yv + T(0.5)) * T(0.5) : (yv + ymean) * T(0.5);
+            eta = glm_link<T>(ia.link, mu);
+        } else {
+            T acc = b0;
+            for (int c = 0; c < p; ++c) acc += as_global(cols[c])[r] * beta[c];
+            eta = acc;
+            mu = glm_inv<T>(ia.link, eta);
+        }
+        const T d = glm_deriv<T>(ia.link, mu);
+        w_out[r] = T(1) / (d * d * glm_var<T>(ia.variance, mu));
+        z_out[r] = eta + d * (yv - mu);
+    }
+}
+
+template <typename T>
+int launch_irls_working_wide(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, int bias, const T* d_beta,
+                             const IrlsArgs& ia, T* d_w, T* d_z) {
+    const int nb = (int)std::min<int64_t>(std::max<int64_t>((n_rows + 255) / 256, 1), (int64_t)ctx->num_cus * 8);
+    KernelTimer timer(ctx, kKindPass2);
+    hipLaunchKernelGGL((irls_working_wide_kernel<T>), dim3(nb), dim3(256), 0, ctx->stream, dc.d_ptrs, n_feat, bias, n_rows, d_beta, ia,
+                       d_w, d_z);
+    PDS_HIP_CHECK(hipGetLastError());
+    return PDS_OK;
+}
+template int launch_irls_working_wide<double>(pds_ctx*, const DeviceCols<double>&, int, int64_t, int, const double*, const IrlsArgs&, double*, double*);
+template int launch_irls_working_wide<float>(pds_ctx*, const DeviceCols<float>&, int, int64_t, int, const float*, const IrlsArgs&, float*, float*);
+
 template int launch_sum_moment_slots<double>(pds_ctx*, const double*, int, int, double*);
 template int launch_sum_moment_slots<float>(pds_ctx*, const double*, int, int, float*);
 

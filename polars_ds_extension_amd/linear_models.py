@@ -432,7 +432,8 @@ class GLM:
     src/pymodels/py_glm.rs:14-101; faer_irls, src/linear/glm/glm_solvers.rs:249-368 -- the caller of faer_weighted_lr).
     Families and their canonical links: gaussian / normal (identity), poisson (log), binomial / logistic (logit), gamma
     (inverse).  On the MI355X one IRLS iteration is ONE pass over the frame (`pds_glm_irls_*`): weights and working response
-    are formed from the previous coefficients while a row sits in registers; up to 16 features.
+    are formed from the previous coefficients while a row sits in registers (up to 16 features; wider frames write them as two
+    columns in front of the weighted wide Gram build).
     """
 
     def __init__(self, add_bias: bool = False, solver: str = "irls", family: str = "normal", max_iter: int = 100, tol: float = 1e-8,
