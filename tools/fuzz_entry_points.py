@@ -1,0 +1,116 @@
+"""Development aid: random shapes through lin_reg (all methods), lin_reg_report, rolling / recursive fits and the keyed grouped
+path against the oracle -- run on the GPU box after kernel changes.  Usage: python tools/fuzz_entry_points.py [seed] [seconds]"""
+import sys, time
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import numpy as np, torch
+import polars_ds_extension_amd as pds
+from oracle import oracle as orc
+
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+t_end = time.time() + (float(sys.argv[2]) if len(sys.argv) > 2 else 60)
+dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+nrel = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - b) / max(np.linalg.norm(b), 1e-300))
+count = {}
+worst = {}
+def note(k, e):
+    count[k] = count.get(k, 0) + 1
+    worst[k] = max(worst.get(k, 0.0), e)
+
+while time.time() < t_end:
+    kind = rng.choice(["lr", "lr", "report", "rolling", "recursive", "keyed", "weighted", "multi"])
+    if kind in ("lr", "weighted", "multi"):
+        p = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 17, 24, 40, 70]))
+        n = int(rng.integers(max(3 * p, 40), 60_000))
+        bias = bool(rng.integers(0, 2))
+        X = rng.normal(size=(n, p)) + rng.normal(size=p) * float(rng.choice([0.0, 2.0]))
+        y = X @ rng.normal(size=p) + 0.3 + 0.1 * rng.normal(size=n)
+        cols = [dev(X[:, j]) for j in range(p)]
+        if kind == "weighted":
+            w = rng.random(n) + 0.1
+            b = pds.lin_reg(*cols, target=dev(y), add_bias=bias, weights=dev(w))
+            note("weighted", nrel(b, orc.pl_lr(X, y, add_bias=bias, weights=w)))
+            assert worst["weighted"] < 1e-9, (p, n, bias)
+            continue
+        if kind == "multi":
+            k = int(rng.integers(2, 5))
+            Y = np.c_[[y + 0.5 * j * X[:, 0] for j in range(k)]].T
+            B = pds.lin_reg(*cols, target=[dev(Y[:, j]) for j in range(k)], add_bias=bias)
+            for j in range(k):
+                bo = orc.pl_lr(X, Y[:, j], add_bias=bias)
+                if bo is None or B[f"target_{j}"] is None:   # the default gate (relative determinant 1e-12) refuses correlated wide frames
+                    assert bo is None and B[f"target_{j}"] is None, (p, n, bias, k)
+                    note("multi-null", 0.0)
+                    continue
+                note("multi", nrel(B[f"target_{j}"], bo))
+            assert worst.get("multi", 0.0) < 1e-9, (p, n, bias, k)
+            continue
+        method = rng.choice(["ols", "ridge", "lasso", "enet", "nnls", "gated"])
+        kw = {"ols": {}, "ridge": {"l2_reg": 0.3}, "lasso": {"l1_reg": 0.02, "tol": 1e-9, "max_iter": 5000},
+              "enet": {"l1_reg": 0.02, "l2_reg": 0.05, "tol": 1e-9, "max_iter": 5000}, "nnls": {"positive": True, "tol": 1e-10, "max_iter": 5000},
+              "gated": {"singular_x_tol": 1e-10}}[method]
+        b = pds.lin_reg(*cols, target=dev(y), add_bias=bias, **kw)
+        bo = orc.pl_lr(X, y, add_bias=bias, **kw)
+        if bo is None or b is None:   # the gate: both sides must refuse
+            assert bo is None and b is None, (method, p, n, bias)
+            note("lr/gated-null", 0.0)
+            continue
+        e = nrel(b, bo)
+        note("lr/" + method, e)
+        assert e < (1e-7 if method in ("lasso", "enet", "nnls") else 1e-9), (method, p, n, bias, e)
+    elif kind == "report":
+        p = int(rng.choice([1, 3, 8, 16, 20, 33]))
+        n = int(rng.integers(20 * p + 50, 80_000))
+        bias = bool(rng.integers(0, 2))
+        se = str(rng.choice(["se", "hc0", "hc1", "hc2", "hc3"]))
+        X = rng.normal(size=(n, p))
+        y = X @ rng.normal(size=p) + (0.4 if bias else 0.0) + 0.3 * rng.normal(size=n) * (0.5 + np.abs(X[:, 0]))
+        r = pds.lin_reg_report(*[dev(X[:, j]) for j in range(p)], target=dev(y), add_bias=bias, std_err=se)
+        ro = orc.lin_reg_report(np.c_[X, np.ones(n)] if bias else X, y, y_var=float(np.var(y, ddof=1)), std_err=se)
+        key = {"se": "std_err"}.get(se, f"{se}_se")
+        e = max(nrel(r["beta"], ro["beta"]), nrel(r[key], ro["std_err"]))
+        note("report/" + se, e)
+        assert e < 1e-9, (se, p, n, bias, e)
+    elif kind in ("rolling", "recursive"):
+        p = int(rng.choice([1, 2, 4, 7, 8, 10, 12, 14, 30]))
+        bias = bool(rng.integers(0, 2))
+        pp = p + bias
+        n = int(rng.integers(4 * pp + 300, 40_000))
+        w = int(rng.integers(max(2 * pp + 5, 20), 400))
+        X = rng.random((n, p))
+        y = X @ rng.normal(size=p) + 0.2 + 0.01 * rng.normal(size=n)
+        lam = float(rng.choice([0.0, 0.1]))
+        Xb = np.c_[X, np.ones(n)] if bias else X
+        cols = [dev(X[:, j]) for j in range(p)]
+        if kind == "rolling":
+            co, pr, va = pds.rolling_lin_reg(*cols, target=dev(y), window_size=w, add_bias=bias, l2_reg=lam)
+            ref = orc.rolling_lr(Xb, y, w, l2_reg=lam)
+        else:
+            co, pr, va = pds.recursive_lin_reg(*cols, target=dev(y), start_with=w, add_bias=bias, l2_reg=lam)
+            ref = orc.recursive_lr(Xb, y, w, l2_reg=lam)
+        co = co.cpu().numpy()[w - 1:]
+        e = float(np.max(np.linalg.norm(co - ref, axis=1) / np.linalg.norm(ref, axis=1)))
+        note(kind, e)
+        assert e < 1e-7, (kind, p, bias, n, w, lam, e)   # the reference's chain itself drifts ~1e-10 from the direct solves
+    else:
+        p = int(rng.choice([1, 4, 8, 16]))
+        G = int(rng.integers(2, 3000))
+        sizes = rng.integers(0, int(rng.choice([5, 60, 400])), size=G) + (p + 2)
+        keys = np.repeat(rng.permutation(G).astype(np.int64) * 7 - 1000, sizes)
+        N = len(keys)
+        perm = rng.permutation(N)
+        X = rng.normal(size=(N, p))
+        y = X @ rng.normal(size=p) + 0.5 + 0.1 * rng.normal(size=N)
+        bias = bool(rng.integers(0, 2))
+        k, co, nu = pds.lin_reg_by_key(*[dev(X[perm, j]) for j in range(p)], target=dev(y[perm]), key=dev(keys[perm]), add_bias=bias)
+        k, co, nu = k.cpu().numpy(), co.cpu().numpy(), nu.cpu().numpy().astype(bool)
+        uk = np.unique(keys)
+        assert np.array_equal(k, uk)
+        for g in rng.choice(len(uk), size=min(20, len(uk)), replace=False):
+            m = keys == uk[g]
+            if m.sum() >= 3 * (p + bias) + 5 and not nu[g]:
+                note("keyed", nrel(co[g], orc.pl_lr(X[m], y[m], add_bias=bias)))
+        assert worst.get("keyed", 0.0) < 1e-8, (p, G, bias)
+print("configurations per entry point and the worst normwise distance to the oracle:")
+for k in sorted(count):
+    print(f"  {k:14s} {count[k]:5d}   {worst[k]:.2e}")
