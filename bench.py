@@ -19,7 +19,8 @@ measure the Gram build GB/s, reported under "gram_build".
                 boundary (`_polars_plugin_pl_lr_by`, `_polars_plugin_pl_lr`): wall clock, bytes over PCIe, fraction of the
                 measured pinned-copy PCIe rate.  This is the rate a Polars user sees; `value` is the HBM-resident rate.
   other_configs   the other BASELINE.json configs on the same box (HBM resident): lin_reg_report at C2 (SE and HC1, wall clock of
-                the whole call), rolling / expanding fits at C4 (1e8 x 8, window 256; kernel time by HIP events).
+                the whole call), rolling / expanding fits at C4 (1e8 x 8, window 256; kernel time by HIP events), the elastic net
+                of C5 (1e7 x 512 f32; Gram build on the bf16 matrix cores and, for comparison, with the f32 instructions).
   grouped_c3spec  SURVEY.md 8(d)'s C3 data (Poisson(100) sizes in [16, 256], 0.1 % collinear groups -> the rank gate fires,
                 8 features), keys sorted and shuffled.
 
@@ -439,19 +440,71 @@ def _other_configs(torch, pds, ctx, dev, xs, y, N, P, with_cpu=True):
         ms = t[0] / 3  # (the expanding fit is several launches per call)
         out[name] = {"rows": n, "coefficients": p, "window": w, "kernel_ms": round(ms, 3), "rows_per_s": round(n / ms * 1e3, 1),
                      "algorithmic_GBps": round(alg / ms * 1e3, 1), "frac_of_hbm_peak": round(alg / ms * 1e3 / HBM_PEAK_GBPS, 4)}
+    ns = 2_000_000
+    rx_s = [x[:ns].cpu().numpy() for x in rx]
+    ry_s = ry[:ns].cpu().numpy()
+    del rx, ry
+    torch.cuda.empty_cache()
+    try:
+        out["elastic_net_c5"] = _c5(torch, pds, ctx, dev)
+    except Exception as e:
+        out["elastic_net_c5"] = {"error": f"{type(e).__name__}: {e}"}
     if with_cpu:  # the reference's rolling driver is one sequential Woodbury chain: single thread, bounded sample of the same frame
         import numpy as np
 
         from oracle import oracle as orc
 
-        ns = 2_000_000
-        Xh = np.stack([x[:ns].cpu().numpy() for x in rx], axis=1)
-        yh = ry[:ns].cpu().numpy()
+        Xh = np.stack(rx_s, axis=1)
+        yh = ry_s
         t0 = time.perf_counter()
         orc.rolling_lr(Xh, yh, w)
         tc = time.perf_counter() - t0
         out["rolling_c4"]["cpu_rows_per_s"] = round(ns / tc, 1)
         out["rolling_c4"]["cpu_sample"] = f"{ns} rows of the same frame, the reference's sequential Woodbury chain (oracle port), 1 thread, {tc:.2f} s"
+    return out
+
+
+def _c5(torch, pds, ctx, dev):
+    """configs[4]: elastic net (l1 = l2 = 0.01, tol 1e-5) on 1e7 rows x 512 f32 features, AR(0.5) columns, 32 true coefficients --
+    one Gram build (MFMA bound) + coordinate-descent sweeps on the 514 x 514 moment matrix.  Both f32 Gram arithmetics."""
+    n, p = 10_000_000, 512
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(3)
+    xs, prev = [], None
+    for j in range(p):
+        e = torch.randn(n, dtype=torch.float32, device=dev, generator=gen)
+        prev = e if prev is None else 0.5 * prev + (0.75 ** 0.5) * e
+        xs.append(prev)
+    idx = torch.randperm(p, generator=torch.Generator().manual_seed(4))[:32]
+    y = torch.zeros(n, dtype=torch.float32, device=dev)
+    cgen = torch.Generator().manual_seed(5)
+    for j in idx.tolist():
+        y.add_(xs[j], alpha=float(torch.randn(1, generator=cgen).item()))
+    y.add_(torch.randn(n, dtype=torch.float32, device=dev, generator=gen), alpha=0.5)
+    out = {"rows": n, "features": p, "dtype": "f32"}
+    pds.config.LIN_REG_EXPR_F64 = False
+    try:
+        for name, native in (("bf16x3_split_default", "0"), ("f32_mfma", "1")):
+            os.environ["PDS_WIDE_F32_NATIVE"] = native
+            fit = lambda: pds.lin_reg(*xs, target=y, l1_reg=0.01, l2_reg=0.01, tol=1e-5, ctx=ctx)
+            fit()
+            ctx.get_timing(reset=True)
+            ctx.set_timing(True)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                b = fit()
+            torch.cuda.synchronize(dev)
+            wall = (time.perf_counter() - t0) / 3 * 1e3
+            ctx.set_timing(False)
+            t = ctx.get_timing(reset=True)
+            gram = t["moments"][0] / max(t["moments"][1], 1)
+            useful = n * (p + 2) * (p + 3)  # flops of the upper triangle incl. the diagonal, 2 per multiply-add
+            out[name] = {"wall_ms": round(wall, 2), "gram_ms": round(gram, 3), "gram_useful_TFLOPs": round(useful / gram / 1e9, 1),
+                         "frac_of_f32_mfma_peak_157TF": round(useful / gram / 1e9 / 157.3, 3), "nonzero": int((abs(b) > 1e-6).sum())}
+    finally:
+        os.environ.pop("PDS_WIDE_F32_NATIVE", None)
+        pds.config.LIN_REG_EXPR_F64 = True
     return out
 
 
