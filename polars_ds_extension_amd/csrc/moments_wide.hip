@@ -447,6 +447,199 @@ __global__ __launch_bounds__(kWThreads, (SPLIT && kSplitKC == 16) ? 3 : 2) void 
         }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// SPLIT arithmetic, 256 x 256 tile per workgroup.  The 128 x 128 kernel above reads two 128-column panels per tile and stage;
+// with the products at the bf16 rate THAT is what bounds it: 84 GB go L2 -> L1 per call at config 5 and the CUs sustain
+// ~3.8 TB/s of it together (7 B/clk/CU).  Here one workgroup of eight waves owns a 256 x 256 tile (2 x 2 of
+// the 128-tiles; the partial tiles keep their layout): 512 columns per stage for four tiles -- half the bytes per flop.
+//   * wave (wr, wc) holds rows 64 wr.. of the I superpanel against columns 128 wc.. of the J superpanel: 2 x 4 MFMA tiles, 128
+//     accumulator registers, 96 matrix instructions per 32-row stage and wave;
+//   * whole 128-byte lines per column and stage (8 lanes x 16 B; 16-row stages with double-buffered planes were measured too:
+//     the half lines are fetched twice from L2 -- 512 columns x 128 B outlive the L1 -- and the gain was gone);
+//   * diagonal workgroups compute the 10 of their 16 wave tiles that the upper triangle needs; their two idle waves multiply
+//     all 256 rows with the [1 | y] tail tile, parked in the unused J half (as MODE 2 does).
+// Used when the block grid is even (p = 512, 768, ...) and the tail fits one MFMA tile; everything else stays with the kernel above.
+constexpr int kS2B = 256;                    // tile edge
+constexpr int kS2KC = 32;                    // rows per stage
+constexpr int kS2CSD = kS2KC / 2 + 4;        // dwords per column and plane (64 B of bf16 + 16 pad: conflict-free 16-byte reads)
+constexpr int kS2Plane = 2 * kS2B * kS2CSD;  // dwords per plane: I superpanel then J superpanel
+constexpr int kS2Stage = 3 * kS2Plane;       // dwords of the stage buffer (h, m, l): 120 KB, one workgroup per CU
+constexpr int kS2Threads = 512;
+
+template <bool WEIGHTED>
+__global__ __launch_bounds__(kS2Threads, 1) void moments_wide_split256_kernel(const float* const* __restrict__ cols, int p, int64_t n,
+                                                                           int nb, int nb_main, int64_t rows_per_split,
+                                                                           const float* __restrict__ sw, float* __restrict__ partials) {
+    constexpr int KC = kS2KC, NCH = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned* const S = reinterpret_cast<unsigned*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    int bx, by;
+    {
+        const int nx = gridDim.x, ns = gridDim.y;
+        const int L = blockIdx.x + nx * blockIdx.y;
+        const int ns_full = ns & ~7;
+        if (L < nx * ns_full) {
+            const int xcd = L & 7, slot = L >> 3;
+            bx = slot % nx;
+            by = (slot / nx) * 8 + xcd;
+        } else {
+            const int R = L - nx * ns_full;
+            bx = R % nx;
+            by = ns_full + R / nx;
+        }
+    }
+    int IS, JS;
+    pair_to_ij(bx, nb_main / 2, IS, JS);
+    const bool diag = IS == JS;
+    const int npairs = nb * (nb + 1) / 2;
+    const int64_t r_begin = (int64_t)by * rows_per_split;
+    const int64_t r_end = (r_begin + rows_per_split < n) ? r_begin + rows_per_split : n;
+
+    // this thread's eight 16-byte pieces per stage: chunk id = tid + 512 u -> column id / 8 of the 512 (I: u < 4; J: u >= 4),
+    // rows 4 (id % 8)..  On the diagonal the J half holds only the tail tile (32 columns of block column nb - 1)
+    gptr<float> ptr[NCH];
+    unsigned kinds = 0;     // 2 bits per chunk: 0 data column, 1 ones column, 2 zero padding, 3 not loaded
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+        const int c = (tid >> 3) + 64 * (u & 3);  // column inside the superpanel
+        int col, kind;
+        if (u < 4) col = IS * kS2B + c;
+        else if (!diag) col = JS * kS2B + c;
+        else col = (c < 32) ? (nb - 1) * kWB + c : -1;
+        if (col < 0) kind = 3;
+        else kind = (col < p || col == p + 1) ? 0 : (col == p ? 1 : 2);
+        kinds |= (unsigned)kind << (2 * u);
+        ptr[u] = as_global(cols[(col >= 0 && col < p) ? col : p]);  // index p is y in the device table
+    }
+    const int piece = tid & 7;
+    f4w regs[NCH];
+    auto load_stage = [&](int64_t row0) __attribute__((always_inline)) {
+        const int64_t r = row0 + piece * 4;
+        f4w swv;
+        if constexpr (WEIGHTED) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) swv[e] = (r + e < r_end) ? sw[r + e] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < NCH; ++u) {
+            const int kind = (kinds >> (2 * u)) & 3;
+            if (kind == 3) continue;
+            f4w v;
+            if (kind == 0 && r + 4 <= r_end) {
+                v = *reinterpret_cast<gptr<f4w>>(ptr[u] + r);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool in = r + e < r_end;
+                    v[e] = !in ? 0.f : (kind == 0 ? ptr[u][r + e] : (kind == 1 ? 1.f : 0.f));
+                }
+            }
+            if constexpr (WEIGHTED) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= swv[e];
+            }
+            regs[u] = v;
+        }
+    };
+    auto store_stage = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < NCH; ++u) {
+            if (((kinds >> (2 * u)) & 3) == 3) continue;
+            const int c = (tid >> 3) + 64 * (u & 3) + (u >= 4 ? kS2B : 0);  // column inside the 512
+            unsigned* dst = S + c * kS2CSD + piece * 2;
+            float v0 = regs[u][0], v1 = regs[u][1], v2 = regs[u][2], v3 = regs[u][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                u2w w;
+                w[0] = split_pair(v0, v1);
+                w[1] = split_pair(v2, v3);
+                *reinterpret_cast<u2w*>(dst + pl * kS2Plane) = w;
+            }
+        }
+    };
+
+    // which of this wave's two 64-column units the upper triangle needs (all of them off the diagonal)
+    const bool need0 = !diag || 2 * wc >= wr, need1 = !diag || 2 * wc + 1 >= wr;
+    const bool tailwave = diag && nb > nb_main && wc == 0 && wr >= 2;  // rows 128 (wr - 2).. x tail tile
+    f16v acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.f;
+    const int li = lane & 31, kq = lane >> 5;
+    const unsigned* const BI = S + (tailwave ? (wr - 2) * 128 : wr * 64) * kS2CSD;  // this wave's rows of the I superpanel
+    const unsigned* const BJ = S + (diag && !tailwave ? 0 : kS2B) * kS2CSD;        // J superpanel (diagonal: I again; tail: the J half)
+
+    load_stage(r_begin);
+    for (int64_t row0 = r_begin; row0 < r_end; row0 += KC) {
+        __syncthreads();  // previous stage's reads are done
+        store_stage();
+        __syncthreads();
+        if (row0 + KC < r_end) load_stage(row0 + KC);
+#pragma unroll
+        for (int ks = 0; ks < KC / 16; ++ks) {
+            const int ko = ks * 8 + kq * 4;
+            if (tailwave) {
+                bf16x8 b[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) b[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4w*>(BJ + pl * kS2Plane + li * kS2CSD + ko));
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    bf16x8 a[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        a[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4w*>(BI + pl * kS2Plane + (t * 32 + li) * kS2CSD + ko));
+                    acc[t >> 1][t & 1] = mfma_split(a, b, acc[t >> 1][t & 1]);
+                }
+            } else if (need0 || need1) {
+                bf16x8 a[2][3];
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        a[m][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4w*>(BI + pl * kS2Plane + (m * 32 + li) * kS2CSD + ko));
+#pragma unroll
+                for (int nn = 0; nn < 4; ++nn) {
+                    if (!((nn < 2) ? need0 : need1)) continue;
+                    bf16x8 b[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        b[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4w*>(BJ + pl * kS2Plane + (wc * 128 + nn * 32 + li) * kS2CSD + ko));
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) acc[m][nn] = mfma_split(a[m], b, acc[m][nn]);
+                }
+            }
+        }
+    }
+    // ---- partial tiles, P[split][pair of 128-blocks][i * 128 + j]
+    const int row0 = 4 * (lane >> 5), col0 = lane & 31;
+    if (tailwave) {  // rows t * 32.. of pair (2 IS + wr - 2, nb - 1), first tile column
+        float* P = partials + ((int64_t)by * npairs + ij_to_pair(2 * IS + wr - 2, nb - 1, nb)) * (kWB * kWB);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) P[(t * 32 + row0 + (r & 3) + 8 * (r >> 2)) * kWB + col0] = acc[t >> 1][t & 1][r];
+        return;
+    }
+    const int I128 = 2 * IS + (wr >> 1), J128 = 2 * JS + wc;
+    if (I128 > J128) return;  // below the diagonal of the block grid (diagonal workgroups only)
+    float* P = partials + ((int64_t)by * npairs + ij_to_pair(I128, J128, nb)) * (kWB * kWB);
+#pragma unroll
+    for (int nn = 0; nn < 4; ++nn) {
+        if (!((nn < 2) ? need0 : need1)) continue;  // the redundant lower-left quadrant of a diagonal 128-tile is never read
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                P[((wr & 1) * 64 + m * 32 + row0 + (r & 3) + 8 * (r >> 2)) * kWB + nn * 32 + col0] = acc[m][nn][r];
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void sqrt_weights_kernel(const T* __restrict__ w, int64_t n, T* __restrict__ sw) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -528,8 +721,18 @@ static int launch_moments_wide_w(pds_ctx* ctx, const DeviceCols<T>& dc, int n_fe
     if constexpr (sizeof(T) == 4) {
         if (tail_narrow && nb_main > 0) {
             fused = true;
-            hipLaunchKernelGGL((moments_wide_kernel<T, 2, WEIGHTED, SPLIT>), grid_main, dim3(kWThreads), lds, ctx->stream, dc.d_ptrs,
-                               n_feat, n_rows, nb, nb_main, 0, rows_per_split, d_sw, partials);
+            const char* e128 = std::getenv("PDS_WIDE_TILE128");  // A/B: keep the 128 x 128 tile
+            if (SPLIT && nb_main >= 2 && nb_main % 2 == 0 && !(e128 && e128[0] == '1')) {
+                constexpr int lds256 = kS2Stage * (int)sizeof(unsigned);
+                PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_wide_split256_kernel<WEIGHTED>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds256));
+                const int nbs = nb_main / 2;
+                hipLaunchKernelGGL((moments_wide_split256_kernel<WEIGHTED>), dim3(nbs * (nbs + 1) / 2, nsplit), dim3(kS2Threads), lds256,
+                                   ctx->stream, dc.d_ptrs, n_feat, n_rows, nb, nb_main, rows_per_split, d_sw, partials);
+            } else {
+                hipLaunchKernelGGL((moments_wide_kernel<T, 2, WEIGHTED, SPLIT>), grid_main, dim3(kWThreads), lds, ctx->stream, dc.d_ptrs,
+                                   n_feat, n_rows, nb, nb_main, 0, rows_per_split, d_sw, partials);
+            }
             hipLaunchKernelGGL((moments_wide_kernel<T, 1, WEIGHTED, SPLIT>), dim3(1, nsplit), dim3(kWThreads), lds, ctx->stream,
                                dc.d_ptrs, n_feat, n_rows, nb, nb_main, nb - 1, rows_per_split, d_sw, partials);
         }
