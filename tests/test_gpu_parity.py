@@ -1072,6 +1072,35 @@ def test_wide_moments_f32_split_k(pds, f32, n, p):
     assert np.array_equal(M, M.T)
 
 
+@pytest.mark.parametrize("n,p,weighted", [(20_011, 515, False), (9_001, 260, True), (40_000, 768, False), (16_390, 512, True)])
+def test_wide_moments_f32_256_tile(pds, f32, n, p, weighted):
+    """Even block grids (p = 255..286, 511..542, 767..798) take the 256 x 256 tile of the bf16-split arithmetic: diagonal and
+    off-diagonal workgroups, the fused [1 | y] tail, ragged last stage, the weight column -- against an f64 Gram and against
+    the 128 x 128 tile and the f32 instructions on the same frame."""
+    import os
+
+    rng = np.random.default_rng(n + p)
+    X = (rng.normal(size=(n, p)) + rng.normal(size=p)).astype(np.float32)
+    y = rng.normal(size=n).astype(np.float32)
+    w = (rng.random(n) + 0.25).astype(np.float32) if weighted else None
+    Z = np.c_[X.astype(np.float64), np.ones(n), y.astype(np.float64)]
+    G = Z.T @ (Z if w is None else w.astype(np.float64)[:, None] * Z)
+    sc = np.sqrt(np.outer(np.diag(G), np.diag(G)))
+    got = {}
+    for name, env in (("tile256", {}), ("tile128", {"PDS_WIDE_TILE128": "1"}), ("f32", {"PDS_WIDE_F32_NATIVE": "1"})):
+        os.environ.update(env)
+        try:
+            M = pds.gram_moments(*cols_of(X), target=dev(y), weights=None if w is None else dev(w))
+        finally:
+            for k in env:
+                del os.environ[k]
+        assert M.dtype == np.float32 and M.shape == G.shape and np.array_equal(M, M.T)
+        assert np.max(np.abs(M - G) / sc) < 3e-6, name
+        got[name] = M
+    # the two tiles of the split arithmetic add the same products in the same order: bit for bit the same Gram
+    assert np.array_equal(got["tile256"], got["tile128"])
+
+
 def test_config5_elastic_net_f32_wide(pds, orc, f32):
     # configs[4] at reduced N: elastic net, p = 512 f32, AR(0.5)-correlated columns, 32 non-zero coefficients
     rng = np.random.default_rng(4)
