@@ -529,7 +529,7 @@ __global__ __launch_bounds__(kS2Threads, 1) void moments_wide_split256_kernel(co
             if (kind == 3) continue;
             f4w v;
             if (kind == 0 && r + 4 <= r_end) {
-                v = *reinterpret_cast<gptr<f4w>>(ptr[u] + r);
+                v = *reinterpret_cast<gptr<f4w>>(ptr[u] + r);  // (non-temporal: 21.6 against 21.4 ms)
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
