@@ -287,6 +287,16 @@ def main() -> int:
         t_gram = time.perf_counter() - t2
         cpu["gram_build_GBps"] = round(ns * (P + 1) * 8 / t_gram / 1e9, 2)
         cpu["gram_build_sample"] = f"{ns} rows x {P + 1} f64 columns, blocked X'X | X'y restatement, {nthreads} threads, {t_gram:.2f} s"
+        # sanity bound: numpy / OpenBLAS X'X of the same sample, as many threads as it takes by default
+        try:
+            Zs = np.stack(host_cols[1:] + [host_cols[0]], axis=1)  # row-major copy, not timed
+            t3 = time.perf_counter()
+            Zs.T @ Zs
+            t_np = time.perf_counter() - t3
+            cpu["gram_build_numpy_GBps"] = round(ns * (P + 1) * 8 / t_np / 1e9, 2)
+            del Zs
+        except Exception:
+            pass
         co_gpu = coeffs[:gs].cpu().numpy()
         num = np.linalg.norm(co_gpu - co_cpu, axis=1)
         den = np.linalg.norm(co_cpu, axis=1)
