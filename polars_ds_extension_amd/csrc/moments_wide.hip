@@ -646,6 +646,52 @@ __global__ __launch_bounds__(256) void sqrt_weights_kernel(const T* __restrict__
         sw[i] = (T)sqrt((double)w[i]);
 }
 
+// The [1 | y] tail against itself -- n, sum y, sum y^2 (weighted: sum w, sum w y, sum w y^2) -- is three sums over one column: a
+// grid-stride reduction in f64 instead of the narrow launch of the tile kernel (1.2 ms of barriers at config 5 for 2 x 2 entries).
+constexpr int kTailBlocks = 1024;
+template <typename T, bool WEIGHTED>
+__global__ __launch_bounds__(256) void tail_sums_kernel(const T* __restrict__ y, const T* __restrict__ sw, int64_t n,
+                                                        double* __restrict__ partials) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double v = (double)y[i];
+        const double w = WEIGHTED ? (double)sw[i] * (double)sw[i] : 1.0;
+        s0 += w;
+        s1 = fma(w, v, s1);
+        s2 = fma(w * v, v, s2);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        s0 += __shfl_xor(s0, o);
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+    }
+    __shared__ double red[3][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[0][wave] = s0;
+        red[1][wave] = s1;
+        red[2][wave] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) partials[3 * blockIdx.x + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+}
+// fixed-order sum of the block partials, then the four entries of the moment matrix (columns p = ones, p + 1 = y)
+template <typename T>
+__global__ __launch_bounds__(64) void tail_sums_write_kernel(const double* __restrict__ partials, int nblocks, int p, T* __restrict__ out) {
+    const int k = threadIdx.x;
+    if (k >= 3) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partials[3 * b + k];
+    const int q = p + 2;
+    if (k == 0) out[p + (int64_t)p * q] = (T)s;
+    if (k == 1) {
+        out[p + (int64_t)(p + 1) * q] = (T)s;
+        out[(p + 1) + (int64_t)p * q] = (T)s;
+    }
+    if (k == 2) out[(p + 1) + (int64_t)(p + 1) * q] = (T)s;
+}
+
 // out (q x q column-major, symmetric) = sum over splits of the partial tiles, fixed order
 template <typename T>
 __global__ __launch_bounds__(256) void moments_wide_reduce_kernel(const T* __restrict__ partials, int nsplit,
@@ -717,7 +763,7 @@ static int launch_moments_wide_w(pds_ctx* ctx, const DeviceCols<T>& dc, int n_fe
     const bool tail_narrow = q - (nb - 1) * kWB <= W::MT;
     const int nb_main = tail_narrow ? nb - 1 : nb;
     const dim3 grid_main(nb_main * (nb_main + 1) / 2, nsplit);
-    bool fused = false;
+    bool fused = false, tail_by_sums = false;
     if constexpr (sizeof(T) == 4) {
         if (tail_narrow && nb_main > 0) {
             fused = true;
@@ -733,8 +779,10 @@ static int launch_moments_wide_w(pds_ctx* ctx, const DeviceCols<T>& dc, int n_fe
                 hipLaunchKernelGGL((moments_wide_kernel<T, 2, WEIGHTED, SPLIT>), grid_main, dim3(kWThreads), lds, ctx->stream, dc.d_ptrs,
                                    n_feat, n_rows, nb, nb_main, 0, rows_per_split, d_sw, partials);
             }
-            hipLaunchKernelGGL((moments_wide_kernel<T, 1, WEIGHTED, SPLIT>), dim3(1, nsplit), dim3(kWThreads), lds, ctx->stream,
-                               dc.d_ptrs, n_feat, n_rows, nb, nb_main, nb - 1, rows_per_split, d_sw, partials);
+            tail_by_sums = q - (nb - 1) * kWB == 2;  // the tail is exactly [1 | y] (p a multiple of 128)
+            if (!tail_by_sums)
+                hipLaunchKernelGGL((moments_wide_kernel<T, 1, WEIGHTED, SPLIT>), dim3(1, nsplit), dim3(kWThreads), lds, ctx->stream,
+                                   dc.d_ptrs, n_feat, n_rows, nb, nb_main, nb - 1, rows_per_split, d_sw, partials);
         }
     }
     if (!fused) {
@@ -747,6 +795,12 @@ static int launch_moments_wide_w(pds_ctx* ctx, const DeviceCols<T>& dc, int n_fe
     }
     hipLaunchKernelGGL((moments_wide_reduce_kernel<T>), dim3(npairs, 64), dim3(256), 0, ctx->stream, partials, nsplit,
                        npairs, nb, n_feat, d_moments);
+    if (tail_by_sums) {  // (the reduce kernel has just written the unset partials of pair (nb - 1, nb - 1) there: replaced)
+        double* tp = reinterpret_cast<double*>(partials);  // the partial tiles are consumed: reuse their head
+        const int nblk = (int)std::min<int64_t>(kTailBlocks, std::max<int64_t>(1, (n_rows + 255) / 256));
+        hipLaunchKernelGGL((tail_sums_kernel<T, WEIGHTED>), dim3(nblk), dim3(256), 0, ctx->stream, dc.h_ptrs[n_feat], d_sw, n_rows, tp);
+        hipLaunchKernelGGL((tail_sums_write_kernel<T>), dim3(1), dim3(64), 0, ctx->stream, tp, nblk, n_feat, d_moments);
+    }
     PDS_HIP_CHECK(hipGetLastError());
     return PDS_OK;
 }
