@@ -384,6 +384,11 @@ __global__ __launch_bounds__(64) void cd_kernel(const T* __restrict__ M, int p, 
         if (i < p) gd[i] = (double)M[i + i * q];
     }
     WSYNC();
+    constexpr int kCdPrefetch = 9;  // 64 x 9 >= 514 = the moment columns of config 5; wider systems read each column when it is due
+    T pf[kCdPrefetch];
+    int pf_col = -1;
+#pragma unroll
+    for (int u = 0; u < kCdPrefetch; ++u) pf[u] = T(0);
     int it = 0, conv = 0;
     for (it = 0; it < max_iter; ++it) {
         double max_change = 0.0;
@@ -415,7 +420,36 @@ __global__ __launch_bounds__(64) void cd_kernel(const T* __restrict__ M, int p, 
             WSYNC();
             if (lane == 0) beta[jc] = committed;
             const T* col = M + (int64_t)jc * q;
-            for (int k = lane; k < pp; k += 64) r[k] = fma(-delta, (double)col[k], r[k]);
+            // The column of a moving coordinate comes from L2 / HBM (~1 us) and the next coordinate cannot start before the
+            // residuals are updated: a sweep over a 512-feature elastic net costs (moving coordinates) x (that latency).  The
+            // next candidate is known now -- the next set bit of `moved`, unless this update changes its mind -- so its column is
+            // fetched into registers while this one is applied.
+            if (pp <= 64 * kCdPrefetch) {
+                T cur[kCdPrefetch];
+                const bool hit = pf_col == jc;
+#pragma unroll
+                for (int u = 0; u < kCdPrefetch; ++u) {
+                    const int k = lane + 64 * u;
+                    cur[u] = hit ? pf[u] : (k < pp ? col[k] : T(0));
+                }
+                const unsigned long long rest = moved & ~((2ull << f) - 1ull);  // candidates behind jc in this chunk
+                pf_col = rest ? j0 + (__ffsll((long long)rest) - 1) : -1;
+                if (pf_col >= 0) {
+                    const T* nxt = M + (int64_t)pf_col * q;
+#pragma unroll
+                    for (int u = 0; u < kCdPrefetch; ++u) {
+                        const int k = lane + 64 * u;
+                        pf[u] = k < pp ? nxt[k] : T(0);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kCdPrefetch; ++u) {
+                    const int k = lane + 64 * u;
+                    if (k < pp) r[k] = fma(-delta, (double)cur[u], r[k]);
+                }
+            } else {
+                for (int k = lane; k < pp; k += 64) r[k] = fma(-delta, (double)col[k], r[k]);
+            }
             WSYNC();
             const double d = fabs(delta);
             max_change = d > max_change ? d : max_change;
