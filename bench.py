@@ -18,7 +18,7 @@ measure the Gram build GB/s, reported under "gram_build".
   end_to_end    the SAME workload when the frame starts in HOST memory as Arrow buffers and goes through the plugin
                 boundary (`_polars_plugin_pl_lr_by`, `_polars_plugin_pl_lr`): wall clock, bytes over PCIe, fraction of the
                 measured pinned-copy PCIe rate.  This is the rate a Polars user sees; `value` is the HBM-resident rate.
-  other_configs   the other BASELINE.json configs on the same box (HBM resident): lin_reg_report at C2 (SE and HC1, wall clock of
+  other_configs   the other BASELINE.json configs on the same box (HBM resident): lin_reg_report at C2 (SE, HC1 and HC3, wall clock of
                 the whole call), rolling / expanding fits at C4 (1e8 x 8, window 256; kernel time by HIP events), the elastic net
                 of C5 (1e7 x 512 f32; Gram build on the bf16 matrix cores and, for comparison, with the f32 instructions).
   grouped_c3spec  SURVEY.md 8(d)'s C3 data (Poisson(100) sizes in [16, 256], 0.1 % collinear groups -> the rank gate fires,
@@ -427,7 +427,7 @@ def _other_configs(torch, pds, ctx, dev, xs, y, N, P, with_cpu=True):
         return (time.perf_counter() - t0) / reps * 1e3
 
     gb = N * (P + 1) * 8 / 1e9
-    for se in ("se", "hc1"):
+    for se in ("se", "hc1", "hc3"):
         ms = wall(lambda: pds.lin_reg_report(*xs, target=y, add_bias=True, std_err=se, ctx=ctx))
         streams = 2  # Gram + one more pass (residual pass, or the fused residual + meat pass)
         out[f"report_c2_{se}"] = {"wall_ms": round(ms, 3), "streams_over_the_frame": streams,

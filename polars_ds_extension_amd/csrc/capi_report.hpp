@@ -14,10 +14,17 @@ static int report_second_pass(pds_ctx* ctx, const DeviceCols<T>& dc, int p, int6
     const int hc = (se_type == PDS_SE) ? 0 : (se_type == PDS_HC2 ? 2 : (se_type == PDS_HC3 ? 3 : 1));
     // HC0 / HC1, p <= 16: the row weights are e_i^2, which the Gram kernel can form itself from the row it has just loaded --
     // residuals, sum e^2 and the meat in ONE pass over the frame (the report is two streams, not three, and the n-row
-    // weight vector never exists).  HC2 / HC3 need the leverages (O(p'^2) per row): pass2_kernel + a weighted Gram build.
+    // weight vector never exists).  HC2 / HC3 add the leverages (O(p'^2) per row, WM = 4).  Weighted frames and more than 16
+    // features: pass2_kernel + a weighted Gram build.
     static const bool no_fuse = [] { const char* e = std::getenv("PDS_REPORT_NO_FUSE"); return e && e[0] == '1'; }();
     if (hc == 1 && !weighted && p <= kMaxFeatSmall && !no_fuse)
         return launch_moments<T>(ctx, dc, p, n_rows, false, d_mom2, d_beta, bias, d_sums);
+    if (hc >= 2 && !weighted && p <= kMaxFeatSmall && !no_fuse && d_inv) {  // ... and the leverages too: O(p'^2) per row in the same pass
+        IrlsArgs ha;
+        ha.inv = d_inv;
+        ha.hc_pow = hc - 1;
+        return launch_moments<T>(ctx, dc, p, n_rows, false, d_mom2, d_beta, bias, d_sums, nullptr, &ha);
+    }
     T* d_s = hc ? reinterpret_cast<T*>(ws_take(ctx, (size_t)n_rows * sizeof(T))) : nullptr;
     if (int rc = launch_pass2<T>(ctx, dc, p, n_rows, bias, weighted, d_beta, d_inv, hc, nullptr, nullptr, d_sums,
                                  reinterpret_cast<double*>(d_s)))

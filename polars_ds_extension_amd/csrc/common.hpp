@@ -143,6 +143,10 @@ int make_device_cols(pds_ctx* ctx, const T* const* cols /*[y,x1..xp]*/, const T*
 struct IrlsArgs {
     int link = 0, variance = 0, init = 0;
     double y_mean = 0.0;
+    // WM = 4 (HC2 / HC3 meat in the residual pass): (X'X)^-1, p' x p' column-major in the kernel's T, and the power of
+    // 1 / (1 - h_i) that scales the squared residual (1: HC2, 2: HC3)
+    const void* inv = nullptr;
+    int hc_pow = 0;
 };
 
 // ---- kernels' host launchers (moments.hip) ----

@@ -94,6 +94,38 @@ __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* _
         for (int c = p; c < 16; ++c) *reinterpret_cast<typename Tile<T>::vec*>(wl + c * kColStride + lane * 16) = z;
     }
 
+    // WM == 4: (X'X)^-1, padded to 17 x 17 (unused rows / columns zero), spread over the lanes: entry i lives in lane i % 64,
+    // slot i / 64.  Every row needs all of its upper triangle with wave-uniform indices; v_readlane hands an entry to the
+    // scalar side in one instruction -- as scalar LOADS from memory the 289 entries cost 10 ms per pass at 1e8 x 16 (what
+    // pass2_kernel's HC2 / HC3 path still pays), as LDS broadcasts 50 ms.  Off-diagonal entries are stored doubled.
+    unsigned hc_lo[5], hc_hi[5];
+    if constexpr (WM == 4) {
+        const T* const inv_g = static_cast<const T*>(ia.inv);
+        const int pp = p + bias;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int i = lane + 64 * j, a = i % 17, b = i / 17;
+            T v = T(0);
+            if (i < 289 && a < pp && b < pp) v = inv_g[a + b * pp] * (a == b ? T(1) : T(2));
+            if constexpr (sizeof(T) == 8) {
+                const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+                hc_lo[j] = (unsigned)u;
+                hc_hi[j] = (unsigned)(u >> 32);
+            } else {
+                hc_lo[j] = __builtin_bit_cast(unsigned, v);
+                hc_hi[j] = 0;
+            }
+        }
+    }
+    auto hc_entry = [&](int i) __attribute__((always_inline)) -> T {  // i = a + 17 b, compile-time after unrolling
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)hc_lo[i / 64], i % 64);
+        if constexpr (sizeof(T) == 8) {
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)hc_hi[i / 64], i % 64);
+            return __builtin_bit_cast(T, ((unsigned long long)hi << 32) | lo);
+        } else {
+            return __builtin_bit_cast(T, lo);
+        }
+    };
     WaveAcc acc;
     zero_acc(acc);
     const int64_t nfull = n / TR;
@@ -105,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* _
     T bx[16];
     T b0 = T(0);
     if constexpr (WM >= 2) {
-        if (WM == 2 || !ia.init) {
+        if (WM == 2 || WM == 4 || !ia.init) {
 #pragma unroll
             for (int c = 0; c < 16; ++c) bx[c] = (c < p) ? beta[c] : T(0);
             b0 = bias ? beta[p] : T(0);
@@ -124,6 +156,39 @@ __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* _
                     if (c < p) acc1 += regs.x[c][e] * bx[c];
                 const T r = regs.y[e] - acc1;
                 regs.w[e] = (row + e < n_lim) ? r * r : T(0);
+            }
+        }
+        if constexpr (WM == 4) {
+            // HC2 / HC3: the weight of a row is e_i^2 / (1 - h_i)^k with the leverage h_i = z_i' (X'X)^-1 z_i (the arithmetic of
+            // pass2_kernel, operation by operation).  The y slot of the tile takes (1 - h_i)^k, so that the moment entry
+            // (ones, y) = sum w_i y'_i is the plain residual sum of squares the report needs beside the meat.
+#pragma unroll
+            for (int e = 0; e < RPL; ++e) {
+                T acc1 = b0;
+#pragma unroll
+                for (int c = 0; c < 16; ++c)
+                    if (c < p) acc1 += regs.x[c][e] * bx[c];
+                const T r = regs.y[e] - acc1;
+                // leverage h = z' A z over the upper triangle, z = [x_0 .. x_{p-1}, 1 (bias), 0 ..]: the padded entries of A are
+                // zero, so all 17 x 18 / 2 terms run without a test (slots c >= p of the tile registers are not zeros in the
+                // packed layouts: they are masked here)
+                T z[17];
+#pragma unroll
+                for (int c = 0; c < 17; ++c) z[c] = (c < 16 && c < p) ? regs.x[c < 16 ? c : 0][e] : ((bias && c == p) ? T(1) : T(0));
+                T h = T(0);
+#pragma unroll
+                for (int a = 0; a < 17; ++a) {
+                    T tt = hc_entry(a + 17 * a) * z[a];
+#pragma unroll
+                    for (int b = a + 1; b < 17; ++b) tt += hc_entry(a + 17 * b) * z[b];
+                    h += z[a] * tt;
+                }
+                const T om = T(1) - h;
+                const T s2 = r * r;
+                const T wv = (ia.hc_pow == 1) ? s2 * (T(1) / om) : s2 * (T(1) / (om * om));
+                const bool in = row + e < n_lim;
+                regs.w[e] = in ? wv : T(0);
+                regs.y[e] = in ? ((ia.hc_pow == 1) ? om : om * om) : T(0);
             }
         }
         if constexpr (WM == 3) {
@@ -297,7 +362,8 @@ __global__ __launch_bounds__(256, 2) void moments_rowmajor_kernel(const T* __res
 template <typename T>
 __global__ __launch_bounds__(64) void moments_finalize_kernel(const double* __restrict__ partials, int nblocks,
                                                               int p, double n_rows, int weighted, int p2,
-                                                              T* __restrict__ out, double* __restrict__ sums_out) {
+                                                              T* __restrict__ out, double* __restrict__ sums_out,
+                                                              int sums_from_ys = 0) {
     const int e = blockIdx.x;  // element of the partial record, 0 .. kPartSW
     auto blocksum = [&](int el) {
         double v = 0.0;
@@ -345,9 +411,13 @@ __global__ __launch_bounds__(64) void moments_finalize_kernel(const double* __re
     } else if (e == kPartYS) {
         out[p + (p + 1) * q] = (T)s;
         out[(p + 1) + p * q] = (T)s;
+        if (sums_out && sums_from_ys) {  // HC2 / HC3: the y slot carried e^2 / w, so sum(w y') is the residual sum of squares
+            sums_out[0] = s;
+            sums_out[1] = 0.0;
+        }
     } else if (e == kPartSW) {
         out[p + p * q] = (T)(weighted ? s : n_rows);
-        if (sums_out) {  // residual-weighted build: sum(w) IS the residual sum of squares (report_second_pass reads it here)
+        if (sums_out && !sums_from_ys) {  // residual-weighted build: sum(w) IS the residual sum of squares (report_second_pass reads it here)
             sums_out[0] = s;
             sums_out[1] = 0.0;
         }
@@ -467,16 +537,19 @@ int launch_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_
         else if (p2 == 1) launch(w_c, false_type{}, integral_constant<int, 1>{});
         else launch(w_c, false_type{}, integral_constant<int, 0>{});
     };
-    if (irls) by_p2(std::integral_constant<int, 3>{});
+    const bool hc23 = irls && irls->hc_pow > 0;  // residual weights scaled by the leverages (HC2 / HC3)
+    if (hc23) by_p2(std::integral_constant<int, 4>{});
+    else if (irls) by_p2(std::integral_constant<int, 3>{});
     else if (d_beta_resid) by_p2(std::integral_constant<int, 2>{});
     else if (weighted) by_p2(std::integral_constant<int, 1>{});
     else by_p2(std::integral_constant<int, 0>{});
     if (d_moments_f64)  // one row chunk of a host frame: the chunk's record stays in f64 until the chunks are summed
         hipLaunchKernelGGL((moments_finalize_kernel<double>), dim3(kPartSW + 1), dim3(64), 0, ctx->stream, partials, nblocks, n_feat,
-                           (double)n_rows, (weighted || d_beta_resid || irls) ? 1 : 0, p2, d_moments_f64, (double*)nullptr);
+                           (double)n_rows, (weighted || d_beta_resid || irls) ? 1 : 0, p2, d_moments_f64, (double*)nullptr, 0);
     else
         hipLaunchKernelGGL((moments_finalize_kernel<T>), dim3(kPartSW + 1), dim3(64), 0, ctx->stream, partials, nblocks, n_feat,
-                           (double)n_rows, (weighted || d_beta_resid || irls) ? 1 : 0, p2, d_moments, (d_beta_resid && !irls) ? d_sums_resid : nullptr);
+                           (double)n_rows, (weighted || d_beta_resid || irls) ? 1 : 0, p2, d_moments,
+                           (d_beta_resid && (!irls || hc23)) ? d_sums_resid : nullptr, hc23 ? 1 : 0);
     PDS_HIP_CHECK(hipGetLastError());
     return PDS_OK;
 }
