@@ -119,7 +119,9 @@ __global__ __launch_bounds__(kWThreads, (SPLIT && kSplitKC == 16) ? 3 : 2) void 
                                                                  int nb, int nb_main, int i_first, int64_t rows_per_split,
                                                                  const T* __restrict__ sw, T* __restrict__ partials) {
     using W = Wide<T>;
-    constexpr int KC = SPLIT ? kSplitKC : W::KC, CS = W::CS, MT = W::MT, NT = W::NT, VL = W::VL;
+    // (MODE 3, the compact f64 form: 32-row stages -- a 16-row stage is shorter than a trip to memory, and the four 16-byte
+    // loads a lane has in flight then bound the kernel)
+    constexpr int KC = SPLIT ? kSplitKC : (MODE == 3 ? 32 : W::KC), CS = MODE == 3 ? 33 : W::CS, MT = W::MT, NT = W::NT, VL = W::VL;
     constexpr int PPC = KC / VL;                  // 16-byte pieces per column and stage
     constexpr int NCH = kWB * PPC / kWThreads;    // chunks per thread and panel
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -131,6 +133,9 @@ __global__ __launch_bounds__(kWThreads, (SPLIT && kSplitKC == 16) ? 3 : 2) void 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     constexpr bool NARROW = MODE == 1, FUSE = MODE == 2;
+    constexpr bool compact = MODE == 3;  // f64, one block column: see mma_compact below (its own instantiation: sharing one
+                                         // with the 4 x 4 form costs 182 spilled registers)
+    static_assert(!compact || sizeof(T) == 8, "the compact form is the f64 tile grid");
     static_assert(!FUSE || (sizeof(T) == 4 && MT * 8 == kWThreads), "tail fusion is laid out for the f32 tile");
     // workgroups are handed to the 8 XCDs round-robin in launch order.  Remap so that all pairs of one row split run
     // on the same XCD back to back: they walk the same rows at the same pace, so each K-panel is pulled from HBM once
@@ -176,7 +181,6 @@ __global__ __launch_bounds__(kWThreads, (SPLIT && kSplitKC == 16) ? 3 : 2) void 
         ptrI[u] = as_global(cols[cI < p ? cI : p]);  // index p is y in the device table
         ptrJ[u] = as_global(cols[cJ < p ? cJ : p]);
     }
-    (void)q;
     // block-uniform: every column of the panel is a data column (no ones column, no y, no padding)
     const bool plainI = (I + 1) * kWB <= p, plainJ = (J + 1) * kWB <= p;
 
@@ -222,7 +226,13 @@ __global__ __launch_bounds__(kWThreads, (SPLIT && kSplitKC == 16) ? 3 : 2) void 
                 const int kind = (kinds >> (2 * (pnl * NCH + u))) & 3;
                 const gptr<T> ptr = pnl ? ptrJ[u] : ptrI[u];
                 typename W::vec v;
-                if (kind == 0 && r + VL <= r_end) {
+                if (full) {
+                    // a whole stage inside the split (every stage but a ragged last one): a column is a vector load, the ones
+                    // column or padding -- one select per chunk instead of the per-element tests below
+#pragma unroll
+                    for (int e = 0; e < VL; ++e) v[e] = kind == 1 ? T(1) : T(0);
+                    if (kind == 0) v = *reinterpret_cast<gptr<typename W::vec>>(ptr + r);
+                } else if (kind == 0 && r + VL <= r_end) {
                     v = *reinterpret_cast<gptr<typename W::vec>>(ptr + r);
                 } else {
 #pragma unroll
@@ -262,6 +272,9 @@ __global__ __launch_bounds__(kWThreads, (SPLIT && kSplitKC == 16) ? 3 : 2) void 
                     }
                 }
             } else {
+                if constexpr (compact) {
+                    if (((kinds >> (2 * u)) & 3) == 2) continue;  // padding columns were zeroed once, in front of the loop
+                }
 #pragma unroll
                 for (int e = 0; e < VL; ++e) {
                     LI[c * CS + k0 + e] = rI[SET][u][e];
@@ -394,9 +407,53 @@ __global__ __launch_bounds__(kWThreads, (SPLIT && kSplitKC == 16) ? 3 : 2) void 
             }
         }
     };
+    // f64, ONE block column (17 .. 126 features, the usual width of a hand-built regression): the 128 x 128 tile is mostly
+    // padding and all of its useful part sits in the quadrant of wave 0 -- 4.7e11 of 6.5e11 executed flops wasted at 64
+    // features and three idle waves.  Compact form (MODE 3): the T = ntile (ntile + 1) / 2 tiles of the upper triangle of the
+    // ceil(q / 16)^2 grid of 16 x 16 MFMA tiles are dealt round-robin to the four waves: tile t = wave + 4 s sits in slot s,
+    // accumulators accd[s >> 2][s & 3] (at most 9 slots).
+    const int ntile = (q + 15) / 16;
+    constexpr int kSlots = 9;
+    int slot_a[kSlots], slot_b[kSlots];  // LDS element offsets of the tile's row / column operand for this lane; -1: empty slot
+    if constexpr (compact) {
+        const int w0 = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+        for (int sidx = 0; sidx < kSlots; ++sidx) {
+            int t = w0 + 4 * sidx, r = 0;
+            while (r < ntile && t >= ntile - r) {  // row r of the triangle holds ntile - r tiles
+                t -= ntile - r;
+                ++r;
+            }
+            const bool ok = r < ntile;
+            slot_a[sidx] = ok ? (r * 16 + (lane & 15)) * CS : -1;
+            slot_b[sidx] = ok ? ((r + t) * 16 + (lane & 15)) * CS : -1;
+        }
+    }
+    auto mma_compact = [&]() __attribute__((always_inline)) {
+        if constexpr (compact) {
+            const int kq = lane >> 4;
+#pragma unroll
+            for (int ks = 0; ks < KC / 4; ++ks) {
+                const int k = 4 * ks + kq;
+#pragma unroll
+                for (int sidx = 0; sidx < kSlots; ++sidx) {
+                    if (__builtin_amdgcn_readfirstlane(slot_a[sidx]) < 0) continue;  // (wave-uniform: slots fill from the front)
+                    const double a = LI[slot_a[sidx] + k], b = LI[slot_b[sidx] + k];
+                    d4w c = {accd[sidx >> 2][sidx & 3][0], accd[sidx >> 2][sidx & 3][1], accd[sidx >> 2][sidx & 3][2],
+                             accd[sidx >> 2][sidx & 3][3]};
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+                    accd[sidx >> 2][sidx & 3][0] = c[0];
+                    accd[sidx >> 2][sidx & 3][1] = c[1];
+                    accd[sidx >> 2][sidx & 3][2] = c[2];
+                    accd[sidx >> 2][sidx & 3][3] = c[3];
+                }
+            }
+        }
+    };
     auto mma_any = [&]() __attribute__((always_inline)) {
         if constexpr (narrow) mma_stage(std::integral_constant<int, NMN>{}, std::integral_constant<int, 1>{});
         else if (tailwave) mma_tail();
+        else if constexpr (compact) mma_compact();
         else mma_stage(std::integral_constant<int, NT>{}, std::integral_constant<int, NT>{});
     };
     using set0 = std::integral_constant<int, 0>;
@@ -405,15 +462,16 @@ __global__ __launch_bounds__(kWThreads, (SPLIT && kSplitKC == 16) ? 3 : 2) void 
     if constexpr (FUSE) {
         if (tailwave) P = partials + ((int64_t)by * npairs + ij_to_pair(I, nb - 1, nb)) * (kWB * kWB);  // pair (I, nb-1), first tile column
     }
+    if constexpr (compact) {  // the padding columns of the panel: zero once
+        for (int i = tid; i < kWB * CS; i += kWThreads) LI[i] = T(0);
+    }
     if (r_begin < r_end) load_stage(set0{}, r_begin);
     for (int64_t row0 = r_begin; row0 < r_end; row0 += KC) {
         __syncthreads();  // previous stage's reads are done
         store_stage(set0{});
         __syncthreads();
         if (row0 + KC < r_end) load_stage(set0{}, row0 + KC);
-        if constexpr (narrow) mma_stage(std::integral_constant<int, NMN>{}, std::integral_constant<int, 1>{});
-        else if (tailwave) mma_tail();
-        else mma_stage(std::integral_constant<int, NT>{}, std::integral_constant<int, NT>{});
+        mma_any();
     }
     if constexpr (FUSE) {
         if (tailwave) {  // rows t * 32.. of pair (I, nb-1), first tile column
@@ -425,6 +483,18 @@ __global__ __launch_bounds__(kWThreads, (SPLIT && kSplitKC == 16) ? 3 : 2) void 
             }
             return;
         }
+    }
+    if constexpr (compact) {
+#pragma unroll
+        for (int sidx = 0; sidx < kSlots; ++sidx) {
+            if (slot_a[sidx] < 0) continue;
+            // offsets back to tile coordinates: slot_a = (16 r + li) CS, slot_b = (16 c + li) CS
+            const int tr = slot_a[sidx] / (16 * CS), tc = slot_b[sidx] / (16 * CS);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                P[(tr * 16 + (lane >> 4) + 4 * r) * kWB + tc * 16 + (lane & 15)] = accd[sidx >> 2][sidx & 3][r];
+        }
+        return;
     }
 #pragma unroll
     for (int m = 0; m < NT; ++m)
@@ -786,7 +856,15 @@ static int launch_moments_wide_w(pds_ctx* ctx, const DeviceCols<T>& dc, int n_fe
         }
     }
     if (!fused) {
-        if (nb_main > 0)
+        bool done = false;
+        if constexpr (sizeof(T) == 8) {
+            if (nb == 1) {  // 17 .. 126 features: the compact tile grid (MODE 3)
+                hipLaunchKernelGGL((moments_wide_kernel<T, 3, WEIGHTED, false>), grid_main, dim3(kWThreads), lds, ctx->stream, dc.d_ptrs,
+                                   n_feat, n_rows, nb, nb_main, 0, rows_per_split, d_sw, partials);
+                done = true;
+            }
+        }
+        if (nb_main > 0 && !done)
             hipLaunchKernelGGL((moments_wide_kernel<T, 0, WEIGHTED, SPLIT>), grid_main, dim3(kWThreads), lds, ctx->stream, dc.d_ptrs,
                                n_feat, n_rows, nb, nb_main, 0, rows_per_split, d_sw, partials);
         if (tail_narrow)
