@@ -746,13 +746,16 @@ __global__ __launch_bounds__(256) void tail_sums_kernel(const T* __restrict__ y,
     __syncthreads();
     if (threadIdx.x < 3) partials[3 * blockIdx.x + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
 }
-// fixed-order sum of the block partials, then the four entries of the moment matrix (columns p = ones, p + 1 = y)
+// fixed-order sum of the block partials (wave k sums component k: lane-strided, then a butterfly), then the four entries of
+// the moment matrix (columns p = ones, p + 1 = y)
 template <typename T>
-__global__ __launch_bounds__(64) void tail_sums_write_kernel(const double* __restrict__ partials, int nblocks, int p, T* __restrict__ out) {
-    const int k = threadIdx.x;
-    if (k >= 3) return;
+__global__ __launch_bounds__(192) void tail_sums_write_kernel(const double* __restrict__ partials, int nblocks, int p, T* __restrict__ out) {
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partials[3 * b + k];
+    for (int b = lane; b < nblocks; b += 64) s += partials[3 * b + k];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    if (lane != 0) return;
     const int q = p + 2;
     if (k == 0) out[p + (int64_t)p * q] = (T)s;
     if (k == 1) {
@@ -877,7 +880,7 @@ static int launch_moments_wide_w(pds_ctx* ctx, const DeviceCols<T>& dc, int n_fe
         double* tp = reinterpret_cast<double*>(partials);  // the partial tiles are consumed: reuse their head
         const int nblk = (int)std::min<int64_t>(kTailBlocks, std::max<int64_t>(1, (n_rows + 255) / 256));
         hipLaunchKernelGGL((tail_sums_kernel<T, WEIGHTED>), dim3(nblk), dim3(256), 0, ctx->stream, dc.h_ptrs[n_feat], d_sw, n_rows, tp);
-        hipLaunchKernelGGL((tail_sums_write_kernel<T>), dim3(1), dim3(64), 0, ctx->stream, tp, nblk, n_feat, d_moments);
+        hipLaunchKernelGGL((tail_sums_write_kernel<T>), dim3(1), dim3(192), 0, ctx->stream, tp, nblk, n_feat, d_moments);
     }
     PDS_HIP_CHECK(hipGetLastError());
     return PDS_OK;
