@@ -241,25 +241,61 @@ __global__ __launch_bounds__(kP2Threads) void pass2_wide_kernel(const T* const* 
 
 // p > 16, HC2 / HC3: the leverages h_i = z_i' (X'X)^-1 z_i (z = [x, (1)]; linear_regression.rs:893-909 takes them from
 // the diagonal of X (X'X)^-1 X') scale the squared residuals the wide pass left in s: s_i /= (1 - h_i) or (1 - h_i)^2.
-// lane = row; the p' x p' inverse is read with wave-uniform indices (scalar cache), the row's values p' times from
-// L1 / L2 -- O(p'^2) per row, a coverage path (HC0 / HC1 never come here).
-template <typename T>
+// lane = row.  LDS = true: the inverse sits in LDS (f64, rows padded to a multiple of 16) and the row's quadratic form runs in
+// chunks of 16 output coordinates -- per b one value of the row from memory and 16 LDS broadcasts feeding 16 independent
+// accumulators; every value of the row is read p' / 16 times.  (The first form -- inverse entries through the scalar cache,
+// one dependent chain per a, the row re-read p' times -- took 100 ms for 2e7 x 64; it stays for inverses beyond the LDS.)
+template <typename T, bool LDS>
 __global__ __launch_bounds__(kP2Threads) void leverage_scale_wide_kernel(const T* const* __restrict__ cols, int p, int bias,
                                                                          int64_t n, const T* __restrict__ inv, int hc,
                                                                          T* __restrict__ s_rows) {
     const int pp = p + bias;
-    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
-        double h = 0.0;
-        for (int a = 0; a < pp; ++a) {
-            double t = bias ? (double)inv[a + (size_t)p * pp] : 0.0;
-            const T* ia = inv + (size_t)a * pp;  // row a = column a (symmetric)
-            for (int b = 0; b < p; ++b) t = fma((double)ia[b], (double)as_global(cols[b])[r], t);
-            const double za = a < p ? (double)as_global(cols[a])[r] : 1.0;
-            h = fma(za, t, h);
+    if constexpr (LDS) {
+        extern __shared__ __attribute__((aligned(16))) double Al[];
+        const int ps = (pp + 15) & ~15;  // padded row: the chunks of 16 never test their tail
+        for (int i = threadIdx.x; i < pp * ps; i += blockDim.x) {
+            const int b = i / ps, a = i - b * ps;
+            Al[i] = a < pp ? (double)inv[a + (size_t)b * pp] : 0.0;
         }
-        const double om = 1.0 - h;
-        const double sc = (hc == 2) ? 1.0 / om : 1.0 / (om * om);
-        s_rows[r] = (T)((double)s_rows[r] * sc);
+        __syncthreads();
+        for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+            double h = 0.0;
+            for (int a0 = 0; a0 < pp; a0 += 16) {
+                double t[16];
+#pragma unroll
+                for (int a = 0; a < 16; ++a) t[a] = 0.0;
+                for (int b = 0; b < pp; ++b) {
+                    const double zb = b < p ? (double)as_global(cols[b])[r] : 1.0;
+                    const double* Ab = Al + b * ps + a0;
+#pragma unroll
+                    for (int a = 0; a < 16; ++a) t[a] = fma(Ab[a], zb, t[a]);
+                }
+#pragma unroll
+                for (int a = 0; a < 16; ++a) {
+                    if (a0 + a < pp) {
+                        const double za = a0 + a < p ? (double)as_global(cols[a0 + a])[r] : 1.0;
+                        h = fma(za, t[a], h);
+                    }
+                }
+            }
+            const double om = 1.0 - h;
+            const double sc = (hc == 2) ? 1.0 / om : 1.0 / (om * om);
+            s_rows[r] = (T)((double)s_rows[r] * sc);
+        }
+    } else {
+        for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+            double h = 0.0;
+            for (int a = 0; a < pp; ++a) {
+                double t = bias ? (double)inv[a + (size_t)p * pp] : 0.0;
+                const T* ia = inv + (size_t)a * pp;  // row a = column a (symmetric)
+                for (int b = 0; b < p; ++b) t = fma((double)ia[b], (double)as_global(cols[b])[r], t);
+                const double za = a < p ? (double)as_global(cols[a])[r] : 1.0;
+                h = fma(za, t, h);
+            }
+            const double om = 1.0 - h;
+            const double sc = (hc == 2) ? 1.0 / om : 1.0 / (om * om);
+            s_rows[r] = (T)((double)s_rows[r] * sc);
+        }
     }
 }
 
@@ -305,9 +341,20 @@ int launch_pass2(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_ro
             hipLaunchKernelGGL((pass2_wide_kernel<T, false>), dim3(nb), dim3(kP2Threads), 0, ctx->stream, dc.d_ptrs, n_feat,
                                add_bias ? 1 : 0, n_rows, d_beta, d_pred, d_resid, s_rows, ctx->partials);
         hipLaunchKernelGGL(pass2_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->partials, nb, d_sums);
-        if (hc_mode >= 2)
-            hipLaunchKernelGGL((leverage_scale_wide_kernel<T>), dim3(nb), dim3(kP2Threads), 0, ctx->stream, dc.d_ptrs, n_feat,
-                               add_bias ? 1 : 0, n_rows, d_inv, hc_mode, s_rows);
+        if (hc_mode >= 2) {
+            const int pp = n_feat + (add_bias ? 1 : 0);
+            const size_t lds = (size_t)pp * ((pp + 15) & ~15) * sizeof(double);
+            if (lds <= 150 * 1024) {
+                if (lds > 64 * 1024)
+                    PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&leverage_scale_wide_kernel<T, true>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL((leverage_scale_wide_kernel<T, true>), dim3(nb), dim3(kP2Threads), lds, ctx->stream, dc.d_ptrs, n_feat,
+                                   add_bias ? 1 : 0, n_rows, d_inv, hc_mode, s_rows);
+            } else {
+                hipLaunchKernelGGL((leverage_scale_wide_kernel<T, false>), dim3(nb), dim3(kP2Threads), 0, ctx->stream, dc.d_ptrs, n_feat,
+                                   add_bias ? 1 : 0, n_rows, d_inv, hc_mode, s_rows);
+            }
+        }
         PDS_HIP_CHECK(hipGetLastError());
         return PDS_OK;
     }
