@@ -10,6 +10,8 @@
 // elements, writes 0..3 N.
 #include "common.hpp"
 
+#include <type_traits>
+
 namespace pds {
 
 template <typename T>
@@ -245,6 +247,45 @@ __global__ __launch_bounds__(kP2Threads) void pass2_wide_kernel(const T* const* 
 // chunks of 16 output coordinates -- per b one value of the row from memory and 16 LDS broadcasts feeding 16 independent
 // accumulators; every value of the row is read p' / 16 times.  (The first form -- inverse entries through the scalar cache,
 // one dependent chain per a, the row re-read p' times -- took 100 ms for 2e7 x 64; it stays for inverses beyond the LDS.)
+// ... and for p' <= 80 all ceil(p' / 16) chunks at once: the row is read ONCE (one column pointer + one value per b), every
+// value feeds 16 NC independent accumulators (NC <= 5: 160 registers of f64)
+template <typename T, int NC>
+__global__ __launch_bounds__(kP2Threads) void leverage_scale_wide_regs_kernel(const T* const* __restrict__ cols, int p, int bias,
+                                                                              int64_t n, const T* __restrict__ inv, int hc,
+                                                                              T* __restrict__ s_rows) {
+    extern __shared__ __attribute__((aligned(16))) double Al[];
+    const int pp = p + bias;
+    constexpr int ps = NC * 16;
+    for (int i = threadIdx.x; i < pp * ps; i += blockDim.x) {
+        const int b = i / ps, a = i - b * ps;
+        Al[i] = a < pp ? (double)inv[a + (size_t)b * pp] : 0.0;
+    }
+    __syncthreads();
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+        double t[ps];
+#pragma unroll
+        for (int a = 0; a < ps; ++a) t[a] = 0.0;
+        double h = 0.0;
+        for (int b = 0; b < pp; ++b) {
+            const double zb = b < p ? (double)as_global(cols[b])[r] : 1.0;
+            const double* Ab = Al + b * ps;
+#pragma unroll
+            for (int a = 0; a < ps; ++a) t[a] = fma(Ab[a], zb, t[a]);
+        }
+        // h = z' t: a second trip over the row (L1 / L2 hits), fully unrolled so that t stays in registers
+#pragma unroll
+        for (int a = 0; a < ps; ++a) {
+            if (a < pp) {
+                const double za = a < p ? (double)as_global(cols[a])[r] : 1.0;
+                h = fma(za, t[a], h);
+            }
+        }
+        const double om = 1.0 - h;
+        const double sc = (hc == 2) ? 1.0 / om : 1.0 / (om * om);
+        s_rows[r] = (T)((double)s_rows[r] * sc);
+    }
+}
+
 template <typename T, bool LDS>
 __global__ __launch_bounds__(kP2Threads) void leverage_scale_wide_kernel(const T* const* __restrict__ cols, int p, int bias,
                                                                          int64_t n, const T* __restrict__ inv, int hc,
@@ -344,7 +385,20 @@ int launch_pass2(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_ro
         if (hc_mode >= 2) {
             const int pp = n_feat + (add_bias ? 1 : 0);
             const size_t lds = (size_t)pp * ((pp + 15) & ~15) * sizeof(double);
-            if (lds <= 150 * 1024) {
+            auto regs_form = [&](auto nc_c) {
+                constexpr int NC = decltype(nc_c)::value;
+                const size_t l2 = (size_t)pp * NC * 16 * sizeof(double);
+                if (l2 > 64 * 1024)
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&leverage_scale_wide_regs_kernel<T, NC>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+                hipLaunchKernelGGL((leverage_scale_wide_regs_kernel<T, NC>), dim3(nb), dim3(kP2Threads), l2, ctx->stream, dc.d_ptrs, n_feat,
+                                   add_bias ? 1 : 0, n_rows, d_inv, hc_mode, s_rows);
+            };
+            if (pp <= 32) regs_form(std::integral_constant<int, 2>{});
+            else if (pp <= 48) regs_form(std::integral_constant<int, 3>{});
+            else if (pp <= 64) regs_form(std::integral_constant<int, 4>{});
+            else if (pp <= 80) regs_form(std::integral_constant<int, 5>{});
+            else if (lds <= 150 * 1024) {
                 if (lds > 64 * 1024)
                     PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&leverage_scale_wide_kernel<T, true>),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
