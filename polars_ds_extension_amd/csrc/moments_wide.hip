@@ -119,11 +119,14 @@ __global__ __launch_bounds__(kWThreads, (SPLIT && kSplitKC == 16) ? 3 : 2) void 
                                                                  int nb, int nb_main, int i_first, int64_t rows_per_split,
                                                                  const T* __restrict__ sw, T* __restrict__ partials) {
     using W = Wide<T>;
-    // (MODE 3, the compact f64 form: 32-row stages -- a 16-row stage is shorter than a trip to memory, and the four 16-byte
-    // loads a lane has in flight then bound the kernel)
-    constexpr int KC = SPLIT ? kSplitKC : (MODE == 3 ? 32 : W::KC), CS = MODE == 3 ? 33 : W::CS, MT = W::MT, NT = W::NT, VL = W::VL;
+    // (MODE 3 / 4 / 5, the compact f64 forms for one block column of up to 128 / 64 / 32 columns: the LDS panel holds
+    // 4096 values whatever its shape, so the narrower the frame the more rows a stage takes -- 32 / 64 / 128.  A stage has to be
+    // worth a trip to memory: with 16 rows, or 32 rows of a 22-column frame (5.6 KB), the kernel ran at 0.85 TB/s)
+    constexpr int KC = SPLIT ? kSplitKC : (MODE == 3 ? 32 : MODE == 4 ? 64 : MODE == 5 ? 128 : W::KC);
+    constexpr int CS = MODE >= 3 ? KC + 1 : W::CS, MT = W::MT, NT = W::NT, VL = W::VL;
+    constexpr int NCOLS = MODE >= 3 ? 4096 / KC : kWB;  // columns of the LDS panel
     constexpr int PPC = KC / VL;                  // 16-byte pieces per column and stage
-    constexpr int NCH = kWB * PPC / kWThreads;    // chunks per thread and panel
+    constexpr int NCH = NCOLS * PPC / kWThreads;  // chunks per thread and panel
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert(!SPLIT || (sizeof(T) == 4 && KC % 16 == 0), "the split path is the f32 Gram on bf16 matrix cores");
     T* LI = reinterpret_cast<T*>(smem);
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(kWThreads, (SPLIT && kSplitKC == 16) ? 3 : 2) void 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     constexpr bool NARROW = MODE == 1, FUSE = MODE == 2;
-    constexpr bool compact = MODE == 3;  // f64, one block column: see mma_compact below (its own instantiation: sharing one
+    constexpr bool compact = MODE >= 3;  // f64, one block column: see mma_compact below (its own instantiation: sharing one
                                          // with the 4 x 4 form costs 182 spilled registers)
     static_assert(!compact || sizeof(T) == 8, "the compact form is the f64 tile grid");
     static_assert(!FUSE || (sizeof(T) == 4 && MT * 8 == kWThreads), "tail fusion is laid out for the f32 tile");
@@ -413,7 +416,7 @@ __global__ __launch_bounds__(kWThreads, (SPLIT && kSplitKC == 16) ? 3 : 2) void 
     // ceil(q / 16)^2 grid of 16 x 16 MFMA tiles are dealt round-robin to the four waves: tile t = wave + 4 s sits in slot s,
     // accumulators accd[s >> 2][s & 3] (at most 9 slots).
     const int ntile = (q + 15) / 16;
-    constexpr int kSlots = 9;
+    constexpr int kSlots = MODE == 5 ? 1 : (MODE == 4 ? 3 : 9);  // ceil(T / 4) for at most 2 / 4 / 8 tile rows
     int slot_a[kSlots], slot_b[kSlots];  // LDS element offsets of the tile's row / column operand for this lane; -1: empty slot
     if constexpr (compact) {
         const int w0 = __builtin_amdgcn_readfirstlane(wave);
@@ -463,7 +466,7 @@ __global__ __launch_bounds__(kWThreads, (SPLIT && kSplitKC == 16) ? 3 : 2) void 
         if (tailwave) P = partials + ((int64_t)by * npairs + ij_to_pair(I, nb - 1, nb)) * (kWB * kWB);  // pair (I, nb-1), first tile column
     }
     if constexpr (compact) {  // the padding columns of the panel: zero once
-        for (int i = tid; i < kWB * CS; i += kWThreads) LI[i] = T(0);
+        for (int i = tid; i < NCOLS * CS; i += kWThreads) LI[i] = T(0);
     }
     if (r_begin < r_end) load_stage(set0{}, r_begin);
     for (int64_t row0 = r_begin; row0 < r_end; row0 += KC) {
@@ -861,9 +864,16 @@ static int launch_moments_wide_w(pds_ctx* ctx, const DeviceCols<T>& dc, int n_fe
     if (!fused) {
         bool done = false;
         if constexpr (sizeof(T) == 8) {
-            if (nb == 1) {  // 17 .. 126 features: the compact tile grid (MODE 3)
-                hipLaunchKernelGGL((moments_wide_kernel<T, 3, WEIGHTED, false>), grid_main, dim3(kWThreads), lds, ctx->stream, dc.d_ptrs,
-                                   n_feat, n_rows, nb, nb_main, 0, rows_per_split, d_sw, partials);
+            if (nb == 1) {  // 17 .. 126 features: the compact tile grid, the more rows per stage the narrower the frame
+                if (q <= 32)
+                    hipLaunchKernelGGL((moments_wide_kernel<T, 5, WEIGHTED, false>), grid_main, dim3(kWThreads), lds, ctx->stream, dc.d_ptrs,
+                                       n_feat, n_rows, nb, nb_main, 0, rows_per_split, d_sw, partials);
+                else if (q <= 64)
+                    hipLaunchKernelGGL((moments_wide_kernel<T, 4, WEIGHTED, false>), grid_main, dim3(kWThreads), lds, ctx->stream, dc.d_ptrs,
+                                       n_feat, n_rows, nb, nb_main, 0, rows_per_split, d_sw, partials);
+                else
+                    hipLaunchKernelGGL((moments_wide_kernel<T, 3, WEIGHTED, false>), grid_main, dim3(kWThreads), lds, ctx->stream, dc.d_ptrs,
+                                       n_feat, n_rows, nb, nb_main, 0, rows_per_split, d_sw, partials);
                 done = true;
             }
         }
