@@ -138,7 +138,7 @@ __global__ __launch_bounds__(kWThreads, (SPLIT && kSplitKC == 16) ? 3 : 2) void 
     constexpr bool NARROW = MODE == 1, FUSE = MODE == 2;
     constexpr bool compact = MODE >= 3;  // f64, one block column: see mma_compact below (its own instantiation: sharing one
                                          // with the 4 x 4 form costs 182 spilled registers)
-    static_assert(!compact || sizeof(T) == 8, "the compact form is the f64 tile grid");
+    static_assert(!compact || sizeof(T) == 8 || (SPLIT && MODE == 3), "compact forms: the f64 tile grid, and the f32 split arithmetic (MODE 3)");
     static_assert(!FUSE || (sizeof(T) == 4 && MT * 8 == kWThreads), "tail fusion is laid out for the f32 tile");
     // workgroups are handed to the 8 XCDs round-robin in launch order.  Remap so that all pairs of one row split run
     // on the same XCD back to back: they walk the same rows at the same pace, so each K-panel is pulled from HBM once
@@ -263,6 +263,9 @@ __global__ __launch_bounds__(kWThreads, (SPLIT && kSplitKC == 16) ? 3 : 2) void 
 #pragma unroll
                 for (int pnl = 0; pnl < 2; ++pnl) {
                     if (pnl == 1 && diag && !(FUSE && c < 32)) continue;
+                    if constexpr (compact) {
+                        if (((kinds >> (2 * u)) & 3) == 2) continue;  // padding columns: planes zeroed once, in front of the loop
+                    }
                     float v0 = pnl ? rJ[SET][u][0] : rI[SET][u][0], v1 = pnl ? rJ[SET][u][1] : rI[SET][u][1];
                     float v2 = pnl ? rJ[SET][u][2] : rI[SET][u][2], v3 = pnl ? rJ[SET][u][3] : rI[SET][u][3];
                     unsigned* dst = (pnl ? SJ : SI) + c * kSplitCSD + k0 / 2;
@@ -415,8 +418,9 @@ __global__ __launch_bounds__(kWThreads, (SPLIT && kSplitKC == 16) ? 3 : 2) void 
     // features and three idle waves.  Compact form (MODE 3): the T = ntile (ntile + 1) / 2 tiles of the upper triangle of the
     // ceil(q / 16)^2 grid of 16 x 16 MFMA tiles are dealt round-robin to the four waves: tile t = wave + 4 s sits in slot s,
     // accumulators accd[s >> 2][s & 3] (at most 9 slots).
-    const int ntile = (q + 15) / 16;
-    constexpr int kSlots = MODE == 5 ? 1 : (MODE == 4 ? 3 : 9);  // ceil(T / 4) for at most 2 / 4 / 8 tile rows
+    constexpr int TE = sizeof(T) == 8 ? 16 : 32;  // MFMA tile edge (f32: the 32 x 32 tiles of the split arithmetic, 4 rows at most)
+    const int ntile = (q + TE - 1) / TE;
+    constexpr int kSlots = sizeof(T) == 4 ? 3 : (MODE == 5 ? 1 : (MODE == 4 ? 3 : 9));  // ceil(T / 4) for at most 2 / 4 / 8 tile rows
     int slot_a[kSlots], slot_b[kSlots];  // LDS element offsets of the tile's row / column operand for this lane; -1: empty slot
     if constexpr (compact) {
         const int w0 = __builtin_amdgcn_readfirstlane(wave);
@@ -428,12 +432,29 @@ __global__ __launch_bounds__(kWThreads, (SPLIT && kSplitKC == 16) ? 3 : 2) void 
                 ++r;
             }
             const bool ok = r < ntile;
-            slot_a[sidx] = ok ? (r * 16 + (lane & 15)) * CS : -1;
-            slot_b[sidx] = ok ? ((r + t) * 16 + (lane & 15)) * CS : -1;
+            constexpr int LD = SPLIT ? kSplitCSD : CS;  // elements (f32: dwords of a plane) between two columns of the panel
+            slot_a[sidx] = ok ? (r * TE + (lane & (TE - 1))) * LD : -1;
+            slot_b[sidx] = ok ? ((r + t) * TE + (lane & (TE - 1))) * LD : -1;
         }
     }
     auto mma_compact = [&]() __attribute__((always_inline)) {
-        if constexpr (compact) {
+        if constexpr (compact && SPLIT) {
+            const int kq = lane >> 5;
+#pragma unroll
+            for (int ks = 0; ks < KC / 16; ++ks) {
+#pragma unroll
+                for (int sidx = 0; sidx < kSlots; ++sidx) {
+                    if (__builtin_amdgcn_readfirstlane(slot_a[sidx]) < 0) continue;
+                    bf16x8 a[3], b[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        a[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4w*>(SI + pl * kSplitPlane + slot_a[sidx] + ks * 8 + kq * 4));
+                        b[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4w*>(SI + pl * kSplitPlane + slot_b[sidx] + ks * 8 + kq * 4));
+                    }
+                    accf[sidx >> 1][sidx & 1] = mfma_split(a, b, accf[sidx >> 1][sidx & 1]);
+                }
+            }
+        } else if constexpr (compact) {
             const int kq = lane >> 4;
 #pragma unroll
             for (int ks = 0; ks < KC / 4; ++ks) {
@@ -465,7 +486,9 @@ __global__ __launch_bounds__(kWThreads, (SPLIT && kSplitKC == 16) ? 3 : 2) void 
     if constexpr (FUSE) {
         if (tailwave) P = partials + ((int64_t)by * npairs + ij_to_pair(I, nb - 1, nb)) * (kWB * kWB);  // pair (I, nb-1), first tile column
     }
-    if constexpr (compact) {  // the padding columns of the panel: zero once
+    if constexpr (compact && SPLIT) {  // the padding columns of the panel: zero once (all three planes)
+        for (int i = tid; i < 3 * kSplitPlane; i += kWThreads) SI[i] = 0u;
+    } else if constexpr (compact) {
         for (int i = tid; i < NCOLS * CS; i += kWThreads) LI[i] = T(0);
     }
     if (r_begin < r_end) load_stage(set0{}, r_begin);
@@ -487,7 +510,19 @@ __global__ __launch_bounds__(kWThreads, (SPLIT && kSplitKC == 16) ? 3 : 2) void 
             return;
         }
     }
-    if constexpr (compact) {
+    if constexpr (compact && SPLIT) {
+#pragma unroll
+        for (int sidx = 0; sidx < kSlots; ++sidx) {
+            if (slot_a[sidx] < 0) continue;
+            const int tr = slot_a[sidx] / (32 * kSplitCSD), tc = slot_b[sidx] / (32 * kSplitCSD);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31;
+                P[(tr * 32 + row) * kWB + tc * 32 + col] = accf[sidx >> 1][sidx & 1][r];
+            }
+        }
+        return;
+    } else if constexpr (compact) {
 #pragma unroll
         for (int sidx = 0; sidx < kSlots; ++sidx) {
             if (slot_a[sidx] < 0) continue;
@@ -839,9 +874,16 @@ static int launch_moments_wide_w(pds_ctx* ctx, const DeviceCols<T>& dc, int n_fe
     const bool tail_narrow = q - (nb - 1) * kWB <= W::MT;
     const int nb_main = tail_narrow ? nb - 1 : nb;
     const dim3 grid_main(nb_main * (nb_main + 1) / 2, nsplit);
-    bool fused = false, tail_by_sums = false;
+    bool fused = false, tail_by_sums = false, done1 = false;
+    if constexpr (sizeof(T) == 4 && SPLIT) {
+        if (nb == 1) {  // 17 .. 126 features, split arithmetic: the compact 32 x 32 tile grid
+            hipLaunchKernelGGL((moments_wide_kernel<T, 3, WEIGHTED, true>), dim3(1, nsplit), dim3(kWThreads), lds, ctx->stream, dc.d_ptrs,
+                               n_feat, n_rows, nb, 1, 0, rows_per_split, d_sw, partials);
+            done1 = true;
+        }
+    }
     if constexpr (sizeof(T) == 4) {
-        if (tail_narrow && nb_main > 0) {
+        if (tail_narrow && nb_main > 0 && !done1) {
             fused = true;
             const char* e128 = std::getenv("PDS_WIDE_TILE128");  // A/B: keep the 128 x 128 tile
             if (SPLIT && nb_main >= 2 && nb_main % 2 == 0 && !(e128 && e128[0] == '1')) {
@@ -861,7 +903,7 @@ static int launch_moments_wide_w(pds_ctx* ctx, const DeviceCols<T>& dc, int n_fe
                                    dc.d_ptrs, n_feat, n_rows, nb, nb_main, nb - 1, rows_per_split, d_sw, partials);
         }
     }
-    if (!fused) {
+    if (!fused && !done1) {
         bool done = false;
         if constexpr (sizeof(T) == 8) {
             if (nb == 1) {  // 17 .. 126 features: the compact tile grid, the more rows per stage the narrower the frame
