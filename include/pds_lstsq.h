@@ -60,6 +60,10 @@ typedef enum { PDS_SOLVER_QR = 0, PDS_SOLVER_SVD = 1, PDS_SOLVER_CHOLESKEY = 2 }
 
 /* StandardError::from(String): linear_regression.rs:113-132 */
 typedef enum { PDS_SE = 0, PDS_HC0 = 1, PDS_HC1 = 2, PDS_HC2 = 3, PDS_HC3 = 4 } pds_se_type;
+/* OR-ed into the se_type argument of pds_lin_reg_report_* (unweighted form): ignore `y_var` and take the target's sample
+ * variance (ddof = 1) from the call's own pass over y (sums kept in f64 for both precisions).  Without the flag `y_var` is
+ * used as given -- a NaN (what a null `target.var()` becomes, linear_regression.rs:836) propagates into r2 / adj_r2. */
+#define PDS_REPORT_DERIVE_YVAR 0x100
 
 /* ---- library / context ------------------------------------------------------------------- */
 const char* pds_last_error(void);
@@ -90,6 +94,9 @@ long long pds_ctx_workspace_spills(const pds_ctx* ctx);
  */
 int pds_ctx_set_timing(pds_ctx* ctx, int enable);
 int pds_ctx_get_timing(pds_ctx* ctx, double* ms_sum, long long* counts, int n_kinds, int reset);
+/* The individual bracketed durations (ms) of one class, oldest first, at most `cap` (the newest are kept, up to 4096 per
+ * class): returns how many were written, -1 on a bad argument.  bench.py reports min / median / max of the timed launches. */
+int pds_ctx_get_timing_samples(pds_ctx* ctx, int kind, double* ms_out, int cap, int reset);
 
 /* ---- LRKwargs mirror (linear_regression.rs:27-45), minus the strings parsed by the host ---- */
 typedef struct {
@@ -192,8 +199,8 @@ int pds_lr_rcond_f32(pds_ctx* ctx, const float* const* cols, int n_feat, int64_t
 /*
  * pds_lin_reg_report_*: the arithmetic of `pl_lin_reg_report` (linear_regression.rs:822-980) and, with
  * weights != NULL, `pl_wls_report` (:982-1117).  y_var is inputs[0][0] of the expression
- * (`target.var()`, ddof = 1, computed by Polars; expr_linear.py:614-617); pass NaN (unweighted form) and the library takes
- * it from the Gram pass the report makes anyway (sum y and sum y^2 are entries of the moment matrix).  Each output has
+ * (`target.var()`, ddof = 1, computed by Polars; expr_linear.py:614-617); with se_type | PDS_REPORT_DERIVE_YVAR (unweighted
+ * form) the library computes it itself (sum y and sum y^2 in f64 from the rows the report works on).  Each output has
  * n_feat + add_bias entries; r2 / adj_r2 are scalars (the reference broadcasts them).
  */
 typedef struct {

@@ -31,6 +31,115 @@ def build(force: bool = False) -> Path:
     return _LIB_PATH
 
 
+def _host_signature() -> str:
+    """model name + ISA flags of this host: the perf build is -march=native, so it belongs to the box that compiled it"""
+    import hashlib
+
+    try:
+        txt = Path("/proc/cpuinfo").read_text()
+        keep = [ln for ln in txt.splitlines() if ln.startswith(("model name", "flags"))][:2]
+    except OSError:
+        keep = ["unknown"]
+    return hashlib.sha1("\n".join(keep).encode()).hexdigest()[:10]
+
+
+def build_perf(force: bool = False) -> Path:
+    """
+    The PERFORMANCE build of the restatement (pds_perf.c, `make perf`): -O3 -march=native, FMA and vectorised reductions
+    allowed, compiled on the box that runs the bench.  Only bench.py's cpu_baseline leg times it; the parity checker is
+    lib().  The file name carries a signature of the host CPU so that a build made elsewhere is never loaded.
+    """
+    out = _HERE / "_perf" / f"libpds_oracle_perf_{_host_signature()}.so"
+    src_m = max((_HERE / f).stat().st_mtime for f in ("pds_perf.c", "pds_oracle.c", "pds_oracle_impl.inc", "pds_oracle.h"))
+    if force or not out.exists() or out.stat().st_mtime < src_m:
+        subprocess.check_call(["make", "-C", str(_HERE), "-s", "perf"])
+        (_HERE / "_perf" / "libpds_oracle_perf.so").replace(out)
+    return out
+
+
+_perf = None
+
+
+def perf_lib() -> C.CDLL:
+    global _perf
+    if _perf is None:
+        _perf = C.CDLL(str(build_perf()))
+        _perf.perf_alloc.restype = C.c_void_p
+        _perf.perf_alloc.argtypes = [C.c_size_t]
+        _perf.perf_free.argtypes = [C.c_void_p]
+        _perf.perf_copy_first_touch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
+        _perf.perf_stream_triad.restype = C.c_double
+        _perf.perf_stream_triad.argtypes = [C.c_int64, C.c_int, C.c_int]
+        _perf.perf_gram_cols_f64.restype = C.c_double
+        _perf.perf_gram_cols_f64.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        _perf.perf_grouped_lr_f64.restype = C.c_double
+        _perf.perf_grouped_lr_f64.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_double,
+                                              C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        _perf.perf_num_procs.restype = C.c_int
+    return _perf
+
+
+class PerfFrame:
+    """
+    Column buffers [y, x1..xp] copied into 2 MiB-aligned storage whose pages are first touched by the OpenMP thread that
+    later reads them (perf_copy_first_touch): the frame a NUMA-aware engine would hold.  f64 only.
+    """
+
+    def __init__(self, cols, nthreads: int):
+        L = perf_lib()
+        self.n = int(len(cols[0]))
+        self.nthreads = int(nthreads)
+        self._ptrs = []
+        for c in cols:
+            c = np.ascontiguousarray(c, dtype=np.float64)
+            assert len(c) == self.n
+            ptr = L.perf_alloc(self.n * 8)
+            if not ptr:
+                raise MemoryError("perf_alloc")
+            L.perf_copy_first_touch(ptr, c.ctypes.data, self.n, self.nthreads)
+            self._ptrs.append(ptr)
+        self.table = (C.c_void_p * len(self._ptrs))(*self._ptrs)
+
+    def close(self):
+        L = perf_lib()
+        for p in self._ptrs:
+            L.perf_free(p)
+        self._ptrs = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def perf_stream_triad(n: int = 1 << 28, nthreads: int = 1, reps: int = 3) -> float:
+    """host STREAM triad, GB/s (best of reps)"""
+    return float(perf_lib().perf_stream_triad(int(n), int(nthreads), int(reps)))
+
+
+def perf_gram_cols(frame: "PerfFrame", reps: int = 3):
+    """[cols]'[cols] of the frame -> (q x q matrix, seconds of the best pass)"""
+    q = len(frame._ptrs)
+    out = np.zeros((q, q), dtype=np.float64, order="F")
+    t = perf_lib().perf_gram_cols_f64(frame.table, frame.n, q, out.ctypes.data, frame.nthreads, int(reps))
+    return out, float(t)
+
+
+def perf_grouped_lr(frame: "PerfFrame", group_offsets, n_features: int | None = None, add_bias=False, l2_reg=0.0, tol=1e-12,
+                    passes: int = 1):
+    """per-group copy + X'X + X'y + gated col-piv QR over contiguous groups -> (coeffs, null flags, seconds of all passes)"""
+    off = np.ascontiguousarray(group_offsets, dtype=np.int64)
+    p = (len(frame._ptrs) - 1) if n_features is None else int(n_features)
+    G = len(off) - 1
+    pp = p + (1 if add_bias else 0)
+    co = np.empty((G, pp), dtype=np.float64)
+    fl = np.zeros(G, dtype=np.uint8)
+    t = perf_lib().perf_grouped_lr_f64(frame.table, p, off.ctypes.data, G, int(add_bias), float(l2_reg), float(tol),
+                                       co.ctypes.data, fl.ctypes.data, frame.nthreads, int(passes))
+    return co, fl.astype(bool), float(t)
+
+
 _lib = None
 
 

@@ -16,10 +16,11 @@ LIB_PATH = _HERE / "csrc" / "libpds_lstsq_hip.so"
 PDS_HOST, PDS_DEVICE = 0, 1
 SOLVERS = {"qr": 0, "svd": 1, "choleskey": 2}  # any other string -> qr (src/linear/lr/mod.rs:17-26)
 SE_TYPES = {"se": 0, "hc0": 1, "hc1": 2, "hc2": 3, "hc3": 4}
+PDS_REPORT_DERIVE_YVAR = 0x100  # include/pds_lstsq.h
 
 EXPORTS = [
     "pds_last_error", "pds_version", "pds_ctx_create", "pds_ctx_destroy", "pds_ctx_set_stream",
-    "pds_ctx_synchronize", "pds_ctx_num_cus", "pds_set_host_staging", "pds_rows_to_cols_f64", "pds_rows_to_cols_f32", "pds_glm_irls_f64", "pds_glm_irls_f32", "pds_lr_rowmajor_f64", "pds_lr_rowmajor_f32", "pds_ctx_workspace_spills", "pds_ctx_set_timing", "pds_ctx_get_timing",
+    "pds_ctx_synchronize", "pds_ctx_num_cus", "pds_set_host_staging", "pds_rows_to_cols_f64", "pds_rows_to_cols_f32", "pds_glm_irls_f64", "pds_glm_irls_f32", "pds_lr_rowmajor_f64", "pds_lr_rowmajor_f32", "pds_ctx_workspace_spills", "pds_ctx_set_timing", "pds_ctx_get_timing", "pds_ctx_get_timing_samples",
     "pds_lr_f64", "pds_lr_f32", "pds_lr_pred_f64", "pds_lr_pred_f32", "pds_lr_rcond_f64", "pds_lr_rcond_f32", "pds_elastic_net_f64", "pds_elastic_net_f32", "pds_lr_nullable_f64", "pds_lr_nullable_f32", "pds_lr_multi_f64", "pds_lr_multi_f32",
     "pds_lin_reg_report_f64", "pds_lin_reg_report_f32",
     "pds_report_fit_from_moments_f64", "pds_report_fit_from_moments_f32", "pds_report_partials_f64", "pds_report_partials_f32",

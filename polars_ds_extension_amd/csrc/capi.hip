@@ -1,6 +1,7 @@
 // capi.hip -- the extern "C" surface declared in include/pds_lstsq.h: context management, host <-> HBM
 // staging, and the per-expression pipelines that string the kernels together.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -128,8 +129,8 @@ int pds_rows_to_cols_f32(pds_ctx* ctx, const float* X, int64_t ld, int64_t n_row
 }
 
 int pds_set_host_staging(double chunk_mb, double resident_max_mb) {
-    if (chunk_mb > 0.0) pds::g_host_chunk_mb = std::max(chunk_mb, 0.001);
-    if (resident_max_mb > 0.0) pds::g_host_resident_mb = std::max(resident_max_mb, 0.001);
+    if (chunk_mb > 0.0) pds::g_host_chunk_mb.store(std::max(chunk_mb, 0.001), std::memory_order_relaxed);
+    if (resident_max_mb > 0.0) pds::g_host_resident_mb.store(std::max(resident_max_mb, 0.001), std::memory_order_relaxed);
     return PDS_OK;
 }
 
@@ -149,6 +150,9 @@ int pds_ctx_get_timing(pds_ctx* ctx, double* ms_sum, long long* counts, int n_ki
         if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess && e.kind >= 0 && e.kind < 8) {
             ctx->kind_ms[e.kind] += ms;
             ctx->kind_count[e.kind] += 1;
+            auto& sm = ctx->kind_samples[e.kind];
+            if (sm.size() >= 4096) sm.erase(sm.begin(), sm.begin() + 2048);
+            sm.push_back(ms);
         }
         ctx->ev_pool.push_back(e.a);
         ctx->ev_pool.push_back(e.b);
@@ -164,6 +168,16 @@ int pds_ctx_get_timing(pds_ctx* ctx, double* ms_sum, long long* counts, int n_ki
             ctx->kind_count[k] = 0;
         }
     return PDS_OK;
+}
+
+int pds_ctx_get_timing_samples(pds_ctx* ctx, int kind, double* ms_out, int cap, int reset) {
+    if (!ctx || kind < 0 || kind >= 8) return -1;
+    if (pds_ctx_get_timing(ctx, nullptr, nullptr, 0, 0) != PDS_OK) return -1;  // drains the pending event pairs
+    auto& sm = ctx->kind_samples[kind];
+    const int n = (int)std::min<size_t>(sm.size(), (size_t)std::max(cap, 0));
+    for (int i = 0; i < n; ++i) ms_out[i] = sm[sm.size() - n + i];
+    if (reset) sm.clear();
+    return n;
 }
 
 int pds_lr_f64(pds_ctx* ctx, const double* const* cols, const double* weights, int n_feat, int64_t n_rows,

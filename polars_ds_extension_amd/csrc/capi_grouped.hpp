@@ -353,7 +353,8 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
         if (int rc = keyed_sort(ctx, d_keys, n_rows, idx_in, sk, perm, d_temp, temp_bytes, sk2, mm)) return rc;
         d_sorted_keys = sk;
         static const bool by_column = [] { const char* e = std::getenv("PDS_KEYED_GATHER_BY_COLUMN"); return e && e[0] == '1'; }();
-        if (by_column) {  // (A/B: one random 8-byte read per element)
+        // frames too wide for the 256-row transposition tile (32 f64 / 64 f32 columns and beyond) gather column by column
+        if (by_column || !gather_frame_fits<T>(nc)) {  // (one random 8-byte read per element; the env switch is the A/B)
             for (int c = 0; c < nc; ++c) {
                 T* d = reinterpret_cast<T*>(take((size_t)n_rows * sizeof(T)));
                 if (int rc = launch_gather_rows<T>(ctx, src[c], perm, n_rows, d)) return rc;

@@ -221,6 +221,7 @@ static int lr_impl(pds_ctx* ctx, const T* const* cols, const T* weights, int n_f
     // host frames of more than one chunk are streamed through a chunk-sized staging buffer; with a residual pass behind the
     // fit only when keeping the frame in HBM is not an option (then the rows cross PCIe twice)
     const int nc_host = n_feat + 1 + (weights ? 1 : 0);
+    StagingScope staging;  // one snapshot of the host-staging settings for the whole call
     bool chunked = space == PDS_HOST && host_frame_is_chunked<T>(n_feat, weights != nullptr, n_rows);
     if (chunked && want_pred && ((size_t)n_rows * nc_host * sizeof(T) <= host_resident_max_bytes() || weights)) chunked = false;
     size_t need = 65536 + sizeof(T) * (size_t)q * q + sizeof(T*) * (size_t)(n_feat + 32);
@@ -456,6 +457,7 @@ static int moments_impl(pds_ctx* ctx, const T* const* cols, const T* weights, in
     if (n_rows <= 0) return fail(PDS_ERR_EMPTY, "Empty data");
     PDS_HIP_CHECK(hipSetDevice(ctx->device));
     const int q = n_feat + 2;
+    StagingScope staging;  // one snapshot of the host-staging settings for the whole call
     size_t need = 65536 + sizeof(T) * (size_t)q * q + sizeof(T*) * (size_t)(n_feat + 32) +
                   (n_feat > kMaxFeatSmall ? moments_wide_workspace(ctx->num_cus, n_feat, n_rows, weights != nullptr) : 0);
     if (space == PDS_HOST && host_frame_is_chunked<T>(n_feat, weights != nullptr, n_rows))

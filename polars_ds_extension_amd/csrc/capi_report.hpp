@@ -101,10 +101,13 @@ static int report_impl(pds_ctx* ctx, const T* const* cols, const T* weights, int
     } else if (int rc = check_shape(n_feat, n_rows, add_bias)) {
         return rc;
     }
+    const bool derive_var = (se_type & PDS_REPORT_DERIVE_YVAR) != 0 && !weights;  // explicit request, never inferred from y_var
+    se_type &= ~PDS_REPORT_DERIVE_YVAR;
+    if (se_type < PDS_SE || se_type > PDS_HC3) return fail(PDS_ERR_INVALID, "unknown standard-error type");
     if (weights && se_type != PDS_SE) se_type = PDS_SE;  // pl_wls_report only knows "std_err"
     PDS_HIP_CHECK(hipSetDevice(ctx->device));
     const int p = n_feat, bias = add_bias ? 1 : 0, pp = p + bias, q = p + 2;
-    size_t need = 131072 + sizeof(T) * (size_t)(2 * q * q + pp * pp + pp) + sizeof(T*) * (size_t)(p + 64);
+    size_t need = 131072 + 65536 + sizeof(T) * (size_t)(2 * q * q + pp * pp + pp) + sizeof(T*) * (size_t)(p + 64);
     if (p > kMaxFeatSmall) need += (se_type != PDS_SE ? 2 : 1) * moments_wide_workspace(ctx->num_cus, p, n_rows, true);
     if (se_type != PDS_SE) need += (size_t)n_rows * sizeof(T) + 512;
     if (nullable) {
@@ -168,17 +171,23 @@ static int report_impl(pds_ctx* ctx, const T* const* cols, const T* weights, int
     PDS_HIP_CHECK(hipMemcpyAsync(inv.data(), d_inv, sizeof(T) * pp * pp, hipMemcpyDeviceToHost, ctx->stream));
     PDS_HIP_CHECK(hipMemcpyAsync(sums, d_sums, sizeof(sums), hipMemcpyDeviceToHost, ctx->stream));
     if (hc) PDS_HIP_CHECK(hipMemcpyAsync(meat.data(), d_mom2, sizeof(T) * q * q, hipMemcpyDeviceToHost, ctx->stream));
-    // y_var = NaN: take the target's sample variance (ddof = 1, what Polars evaluates as `target.var()` and hands over as input
-    // 0, expr_linear.py:614-617) from the Gram pass this call has just made -- sum y and sum y^2 are entries of the moment matrix
-    T mom_y[2] = {T(0), T(0)};
-    const bool derive_var = !(y_var == y_var) && !weighted;
+    // PDS_REPORT_DERIVE_YVAR: the target's sample variance (ddof = 1, what Polars evaluates as `target.var()` and hands over as
+    // input 0, expr_linear.py:614-617).  f64: sum y and sum y^2 are entries of the moment matrix this call has just built.  f32:
+    // those entries are rounded to f32 and syy - sy^2 / n would cancel for |mean| >> std, so y is summed once more in f64.
+    double mom_y[2] = {0.0, 0.0};
     if (derive_var) {
-        PDS_HIP_CHECK(hipMemcpyAsync(&mom_y[0], d_mom + p + (size_t)(p + 1) * q, sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
-        PDS_HIP_CHECK(hipMemcpyAsync(&mom_y[1], d_mom + (p + 1) + (size_t)(p + 1) * q, sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+        if constexpr (std::is_same<T, double>::value) {
+            PDS_HIP_CHECK(hipMemcpyAsync(&mom_y[0], d_mom + p + (size_t)(p + 1) * q, sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+            PDS_HIP_CHECK(hipMemcpyAsync(&mom_y[1], d_mom + (p + 1) + (size_t)(p + 1) * q, sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+        } else {
+            double* d_ys = reinterpret_cast<double*>(ws_take(ctx, 64));
+            if (int rc = launch_y_sums<T>(ctx, dc.h_ptrs[p], n_rows, d_ys)) return rc;
+            PDS_HIP_CHECK(hipMemcpyAsync(mom_y, d_ys, sizeof(mom_y), hipMemcpyDeviceToHost, ctx->stream));
+        }
     }
     PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (derive_var) {
-        const double nn = (double)n_rows, sy = (double)mom_y[0], syy = (double)mom_y[1];
+        const double nn = (double)n_rows, sy = mom_y[0], syy = mom_y[1];
         y_var = (T)((syy - sy * sy / nn) / (nn - 1.0));
     }
     report_epilogue<T, R>(n_rows, p, bias, se_type, weighted, y_var, beta.data(), inv.data(), meat.data(), sums, out);

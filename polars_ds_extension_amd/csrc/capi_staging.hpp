@@ -18,10 +18,34 @@ static double env_mb(const char* name, double dflt) {
 }
 // frames up to g_host_resident_mb keep the whole-frame staging when a second pass over the rows follows (pred / resid):
 // one trip over PCIe instead of two (default 96 GiB: a third of HBM).  pds_set_host_staging() changes both.
-double g_host_chunk_mb = env_mb("PDS_HOST_CHUNK_MB", 256.0);
-double g_host_resident_mb = env_mb("PDS_HOST_RESIDENT_MAX_MB", 98304.0);
-static size_t host_chunk_bytes() { return (size_t)(g_host_chunk_mb * 1048576.0); }
-static size_t host_resident_max_bytes() { return (size_t)(g_host_resident_mb * 1048576.0); }
+// Process-wide settings read by every calling thread (Polars' rayon threads each own a context) while pds_set_host_staging may
+// write them: atomics, and an entry point takes ONE snapshot (StagingScope) that all of its sizing and staging decisions use, so
+// the workspace bound it reserved and the buffers it then allocates cannot disagree.
+std::atomic<double> g_host_chunk_mb{env_mb("PDS_HOST_CHUNK_MB", 256.0)};
+std::atomic<double> g_host_resident_mb{env_mb("PDS_HOST_RESIDENT_MAX_MB", 98304.0)};
+struct StagingSnap {
+    size_t chunk_bytes, resident_bytes;
+};
+static thread_local const StagingSnap* t_staging = nullptr;
+struct StagingScope {
+    StagingSnap snap;
+    const StagingSnap* prev;
+    StagingScope() {
+        snap.chunk_bytes = (size_t)(g_host_chunk_mb.load(std::memory_order_relaxed) * 1048576.0);
+        snap.resident_bytes = (size_t)(g_host_resident_mb.load(std::memory_order_relaxed) * 1048576.0);
+        prev = t_staging;
+        if (!prev) t_staging = &snap;  // (the outermost scope of a call decides)
+    }
+    ~StagingScope() {
+        if (!prev) t_staging = nullptr;
+    }
+};
+static size_t host_chunk_bytes() {
+    return t_staging ? t_staging->chunk_bytes : (size_t)(g_host_chunk_mb.load(std::memory_order_relaxed) * 1048576.0);
+}
+static size_t host_resident_max_bytes() {
+    return t_staging ? t_staging->resident_bytes : (size_t)(g_host_resident_mb.load(std::memory_order_relaxed) * 1048576.0);
+}
 template <typename T>
 static int64_t host_chunk_rows(int nc, int64_t n_rows) {
     int64_t r = (int64_t)(host_chunk_bytes() / ((size_t)nc * sizeof(T)));

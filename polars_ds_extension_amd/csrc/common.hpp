@@ -91,6 +91,7 @@ struct pds_ctx {
     unsigned* mark_count = nullptr;
     unsigned* mark_host = nullptr;      // host address
     unsigned* mark_host_dev = nullptr;  // the same word as the device sees it
+    bool mark_dirty = false;            // a launch went out and mark_count has not been seen back at zero since (an error path)
     void* pinned = nullptr;  // pinned host scratch (small results, pointer arrays)
     size_t pinned_bytes = 0;
     void* pinned_in = nullptr;  // pinned staging of small PDS_HOST frames: all columns + pointer table, ONE H2D copy
@@ -102,6 +103,7 @@ struct pds_ctx {
     std::vector<EvPair> ev_pending;
     double kind_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long kind_count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<float> kind_samples[8];  // the individual bracketed durations (ms), newest kept up to 4096 per class
 };
 
 namespace pds {
@@ -226,6 +228,9 @@ int launch_nnls(pds_ctx* ctx, const T* d_moments, int p, int add_bias, double to
                 int64_t n_sys = 1, uint8_t* d_flags = nullptr, const int64_t* d_rows_per_sys = nullptr);
 
 // ---- pass2.hip ----
+// sum y and sum y^2 of one device column in f64 (fixed-order two-stage reduction): d_out[0..1]
+template <typename T>
+int launch_y_sums(pds_ctx* ctx, const T* d_y, int64_t n_rows, double* d_out);
 // streaming residual pass: pred/resid (nullable outputs), sums: [0]=sum e^2, [1]=sum w e^2,
 // meat (p' x p') = sum s_i x_i x_i' with s_i = e_i^2 * hc_scale(h_ii) when meat != null.
 template <typename T>
@@ -281,6 +286,11 @@ int launch_rows_to_cols(pds_ctx* ctx, const T* d_X, int64_t ld, int64_t n_rows, 
 // keyed.hip: the whole frame through the permutation by way of row-major records (one random access per row, not per element)
 template <typename T>
 int launch_gather_frame(pds_ctx* ctx, const T* const* d_src, const uint32_t* d_perm, int nc, int64_t n, T* d_records, T* const* d_dst);
+// the transposition tile of launch_gather_frame (256 rows x nc columns) must fit the 64 KB of LDS a launch gets without raising
+// the kernel's dynamic limit; wider frames take the column-by-column gather (launch_gather_rows), which has no width limit
+constexpr size_t kGatherFrameLdsLimit = 64 * 1024;
+template <typename T>
+inline bool gather_frame_fits(int nc) { return (size_t)256 * (size_t)(nc | 1) * sizeof(T) <= kGatherFrameLdsLimit; }
 template <typename T>
 int launch_scale_sqrt_w(pds_ctx* ctx, const T* d_src /*nullable: ones*/, const T* d_w, int64_t n, T* d_dst);
 

@@ -652,6 +652,11 @@ int launch_grouped_fused(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int6
         d_count = ctx->mark_count;
         d_host = ctx->mark_host_dev;
         *ctx->mark_host = 0u;  // (host-mapped word; the previous call synchronised before it returned)
+        // The counter is back at zero after every call that ran to its end (below).  A call that failed between its launch and
+        // that point leaves it wherever the kernel took it; the next launch would then append behind stale slots -- past the
+        // end of its list.  So such a context re-zeroes the counter first (costs nothing on the common path).
+        if (ctx->mark_dirty) PDS_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(unsigned), ctx->stream));
+        ctx->mark_dirty = true;
     }
     int rc;
     if (sd.p <= 4) rc = launch_stream_lps<T, 4>(ctx, dc, n_feat, d_offsets, n_groups, n_rows, sd, chol, d_coeffs, d_flags, d_list, d_count, d_host);
@@ -662,11 +667,15 @@ int launch_grouped_fused(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int6
     // Whether there are any is read from the host-mapped word after the kernel has finished (the entry points synchronise
     // before they return anyway); the common case -- none -- costs no launch, no copy and no counter read-back.
     PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    if (__atomic_load_n(ctx->mark_host, __ATOMIC_ACQUIRE) == 0u) return PDS_OK;
+    if (__atomic_load_n(ctx->mark_host, __ATOMIC_ACQUIRE) == 0u) {
+        ctx->mark_dirty = false;  // no wave marked a group: the counter was never touched
+        return PDS_OK;
+    }
     unsigned h_count = 0;
     PDS_HIP_CHECK(hipMemcpyAsync(&h_count, d_count, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
     PDS_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(unsigned), ctx->stream));  // ready for the next call
     PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->mark_dirty = false;
     const int64_t marked = (int64_t)h_count;
     if (marked == 0) return PDS_OK;
     const int pp = sd.pp;

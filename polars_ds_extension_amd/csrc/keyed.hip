@@ -219,7 +219,9 @@ int launch_gather_rows(pds_ctx* ctx, const T* d_src, const uint32_t* d_perm, int
 // the whole frame through the permutation: d_src / d_dst are DEVICE tables of nc column pointers, d_records n * nc elements
 template <typename T>
 int launch_gather_frame(pds_ctx* ctx, const T* const* d_src, const uint32_t* d_perm, int nc, int64_t n, T* d_records, T* const* d_dst) {
+    static_assert(kAosRows == 256, "gather_frame_fits() sizes the tile for 256 rows");
     const size_t lds = (size_t)kAosRows * (size_t)(nc | 1) * sizeof(T);
+    if (!gather_frame_fits<T>(nc)) return fail(PDS_ERR_UNSUPPORTED, "launch_gather_frame: the transposition tile exceeds the LDS of one launch");
     const int64_t nblk = (n + kAosRows - 1) / kAosRows;
     const int nb1 = (int)std::min<int64_t>(std::max<int64_t>(nblk, 1), (int64_t)ctx->num_cus * 8);
     hipLaunchKernelGGL((cols_to_rows_kernel<T>), dim3(nb1), dim3(256), lds, ctx->stream, d_src, nc, n, d_records);

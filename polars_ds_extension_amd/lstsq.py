@@ -123,6 +123,14 @@ class Context:
         _lib.check(self._lib.pds_ctx_get_timing(self._h, ms, cnt, 8, int(bool(reset))))
         return {k: (ms[i], int(cnt[i])) for i, k in enumerate(self.KINDS)}
 
+    def get_timing_samples(self, kind: str, reset: bool = True) -> list:
+        """The individual launch durations (ms) of one kernel class since the last reset, oldest first."""
+        buf = (C.c_double * 4096)()
+        n = int(self._lib.pds_ctx_get_timing_samples(self._h, self.KINDS.index(kind), buf, 4096, int(bool(reset))))
+        if n < 0:
+            raise ValueError(kind)
+        return [float(buf[i]) for i in range(n)]
+
     def close(self) -> None:
         if getattr(self, "_h", None) and self._h.value:
             self._lib.pds_ctx_destroy(self._h)
@@ -441,9 +449,11 @@ def lin_reg_report(*x, target, add_bias: bool = False, weights=None, std_err: st
     cols = _Cols(target, x, weights)
     _follow(ctx, cols)
     pp = cols.n_feat + int(bool(add_bias))
+    se_code = _lib.SE_TYPES.get(std_err, 0)
     if y_var is None:
         if weights is None:
-            y_var = float("nan")  # the library derives it from the Gram pass the report makes anyway (sum y, sum y^2)
+            y_var = 0.0
+            se_code |= _lib.PDS_REPORT_DERIVE_YVAR  # the library takes var(y) from its own pass over y (f64 sums)
         else:
             M = gram_moments(*x, target=target, ctx=ctx)
             q = cols.n_feat + 2
@@ -456,7 +466,7 @@ def lin_reg_report(*x, target, add_bias: bool = False, weights=None, std_err: st
     rep = R(*[C.c_void_p(outs[k].ctypes.data) for k in ("beta", "std_err", "t", "p", "ci_lower", "ci_upper")], 0.0, 0.0)
     yv = C.c_double(y_var) if config.LIN_REG_EXPR_F64 else C.c_float(y_var)
     _lib.check(ctx.fn("pds_lin_reg_report")(ctx._h, cols.cols, cols.weights, cols.n_feat, C.c_int64(cols.n_rows),
-                                            cols.space, int(bool(add_bias)), _lib.SE_TYPES.get(std_err, 0), yv,
+                                            cols.space, int(bool(add_bias)), se_code, yv,
                                             C.byref(rep)))
     return _report_dict(outs, rep, cols.n_feat, add_bias, std_err, weights is not None, feature_names, dt)
 

@@ -111,7 +111,7 @@ def chunk_bounds(n_groups: int, chunks: int) -> list[tuple[int, int]]:
 
 
 def lin_reg_by_group_local_shard(xs_loc, y_loc, loc_off, parts, *, rank: int, gather_to: int | None = 0, chunks: int = 1,
-                                 grouped_fn: Callable | None = None, group=None, **lin_reg_kwargs):
+                                 grouped_fn: Callable | None = None, group=None, result_dtype=None, **lin_reg_kwargs):
     """
     The compute + gather leg of the group-sharded regression on a rank that already HOLDS its shard (rows of groups
     parts[rank] = [g_lo, g_hi), `loc_off` rebased to the shard).  The shard is fitted in `chunks` pieces; a peer hands every
@@ -120,10 +120,14 @@ def lin_reg_by_group_local_shard(xs_loc, y_loc, loc_off, parts, *, rank: int, ga
     peer's traffic rides its own xGMI link into the root (results are n_groups x p' values + one flag byte per group:
     16 MB per peer at 1e6 groups x 16 features on 8 GPUs).
     Returns (coeffs_local, is_null_local) and, on the gathering rank, additionally the assembled (coeffs, is_null).
+    The dtype of the coefficients on the wire is `result_dtype`; by default what the library's grouped fit returns (the config
+    dtype: float64 under LIN_REG_EXPR_F64, whatever the inputs are) or, with an injected `grouped_fn`, the targets' dtype --
+    every rank casts to it before sending, so the receive buffers of the gathering rank always match the sends.
     """
     import torch
 
     dist = _dist()
+    default_fn = grouped_fn is None
     grouped_fn = grouped_fn or _hip_grouped_out
     world = len(parts)
     g_lo, g_hi = parts[rank]
@@ -131,7 +135,14 @@ def lin_reg_by_group_local_shard(xs_loc, y_loc, loc_off, parts, *, rank: int, ga
     pp = len(xs_loc) + int(bool(lin_reg_kwargs.get("add_bias", False)))
     is_t = isinstance(y_loc, torch.Tensor)  # (NumPy 2 arrays have a .device too)
     dev = y_loc.device if is_t else torch.device("cpu")
-    cdt = y_loc.dtype if is_t else torch.from_numpy(np.asarray(y_loc)[:0]).dtype
+    if result_dtype is not None:
+        cdt = result_dtype
+    elif default_fn:
+        from . import lstsq
+
+        cdt = torch.float64 if lstsq._dtype() == np.float64 else torch.float32
+    else:
+        cdt = y_loc.dtype if is_t else torch.from_numpy(np.asarray(y_loc)[:0]).dtype
     off = loc_off
     off_h = np.asarray(loc_off.cpu() if hasattr(loc_off, "cpu") else loc_off, dtype=np.int64)  # (row bounds of the pieces: host)
     root = gather_to
@@ -162,6 +173,9 @@ def lin_reg_by_group_local_shard(xs_loc, y_loc, loc_off, parts, *, rank: int, ga
         co, nu = grouped_fn([x[r0:r1] for x in xs_loc], y_loc[r0:r1], sub_off, **lin_reg_kwargs)
         co = co if isinstance(co, torch.Tensor) else torch.as_tensor(np.asarray(co))
         nu = (nu if isinstance(nu, torch.Tensor) else torch.as_tensor(np.asarray(nu))).to(torch.uint8)
+        if co.dtype != cdt or co.device != dev:
+            co = co.to(device=dev, dtype=cdt)  # (wire dtype / device: see the docstring)
+        nu = nu.to(dev)
         co_parts.append(co)
         nu_parts.append(nu)
         if root is None:

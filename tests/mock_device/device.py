@@ -226,15 +226,16 @@ def make_callbacks(sfx):
 
     def run_report(X, y, w, bias, se_type, y_var, out_p):
         Xb = orc.with_bias(X) if bias else X
-        yv = None if np.isnan(y_var) else y_var
+        yv = y_var  # (as given: a NaN propagates into r2 / adj_r2 like a null target.var() does in the reference)
         rep = orc.wls_report(Xb, y, w, y_var=yv) if w is not None else orc.lin_reg_report(Xb, y, y_var=yv, std_err=SE[se_type])
         put_report(out_p, rep, Xb.shape[1])
 
     def report(ctx, cols_p, w_p, n_feat, n, space, bias, se_type, y_var, out_p):
         _check_shape(n_feat, n, bias)
         cols = _columns(cols_p, n_feat + 1, n, dt)
-        if y_var != y_var and not w_p:  # NaN: the library derives target.var() (ddof = 1) from its own Gram pass
+        if (se_type & 0x100) and not w_p:  # PDS_REPORT_DERIVE_YVAR: the library takes target.var() (ddof = 1) from its own pass
             y_var = float(np.var(np.asarray(cols[0], dtype=np.float64), ddof=1))
+        se_type &= ~0x100
         run_report(X_of(cols), cols[0], _view(w_p, n, dt) if w_p else None, bool(bias), se_type, y_var, out_p)
         return OK
 

@@ -348,6 +348,30 @@ def test_report_y_var_from_moments(pds):
     assert abs(a["r2"][0] - b["r2"][0]) < 1e-10
 
 
+def test_report_y_var_given_is_used_as_given_and_nan_propagates(pds):
+    """A NaN var(y) handed over by the caller (a null `target.var()`, linear_regression.rs:836) is not silently replaced: r2 and
+    adj_r2 come back NaN, everything that does not depend on it is unchanged.  Deriving it is an explicit request (y_var=None)."""
+    rng = np.random.default_rng(41)
+    X, y, _ = make_xy(rng, 20_000, 3, noise=0.2)
+    a = pds.lin_reg_report(*cols_of(X), target=dev(y), add_bias=True)
+    b = pds.lin_reg_report(*cols_of(X), target=dev(y), add_bias=True, y_var=float("nan"))
+    assert np.isnan(b["r2"][0]) and np.isnan(b["adj_r2"][0]) and np.isfinite(a["r2"][0])
+    assert np.array_equal(a["beta"], b["beta"]) and np.array_equal(a["std_err"], b["std_err"])
+
+
+def test_report_f32_derived_variance_does_not_cancel(pds, f32):
+    """|mean(y)| >> std(y): var(y) formed from f32-rounded sum y, sum y^2 would lose every digit (1e-7 * (mean / std)^2 = 10
+    here); the library sums y in f64 for the f32 report, so r2 matches the one computed with numpy's centred variance."""
+    rng = np.random.default_rng(42)
+    n = 200_000
+    X = rng.normal(size=(n, 3)).astype(np.float32)
+    y = (1.0e4 + X @ np.array([0.5, -0.25, 0.125]) + 0.1 * rng.normal(size=n)).astype(np.float32)
+    yv = float(np.var(y.astype(np.float64), ddof=1))
+    a = pds.lin_reg_report(*cols_of(X), target=dev(y), add_bias=True)
+    b = pds.lin_reg_report(*cols_of(X), target=dev(y), add_bias=True, y_var=yv)
+    assert abs(float(a["r2"][0]) - float(b["r2"][0])) < 1e-5, (a["r2"], b["r2"])
+
+
 def test_default_context_is_per_thread(pds):
     """Python threads calling the functional API concurrently get their own context (stream, workspace, staging)."""
     from concurrent.futures import ThreadPoolExecutor
