@@ -49,18 +49,12 @@ PROFILE_TAG = "r02"     # profiles/<tag>_traffic.json: HBM bytes per launch from
 
 
 def _gen_frame(torch, dev, seed, G, R, P):
-    """x ~ N(0,1), per-group beta ~ N(0,1), noise 0.1; fixed R rows per group (the headline frame)."""
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(seed)
-    N = G * R
-    xs = [torch.randn(N, dtype=torch.float64, device=dev, generator=gen) for _ in range(P)]
-    y = torch.zeros(N, dtype=torch.float64, device=dev)
-    for j in range(P):
-        bj = torch.randn(G, dtype=torch.float64, device=dev, generator=gen)
-        y.add_(xs[j] * bj.repeat_interleave(R))
-        del bj
-    y.add_(torch.randn(N, dtype=torch.float64, device=dev, generator=gen), alpha=0.1)
-    return xs, y
+    """x ~ N(0,1), per-group beta ~ N(0,1), noise 0.1; fixed R rows per group (the headline frame; tools/synth.py, shared with
+    tests/test_baseline_sizes.py::test_headline_config_against_oracle)."""
+    sys.path.insert(0, str(ROOT / "tools"))
+    import synth
+
+    return synth.headline_frame(G, R, P, seed=seed, device=dev)
 
 
 def main() -> int:

@@ -344,6 +344,31 @@ int pds_lr_by_key_f32(pds_ctx* ctx, const float* const* cols, const int64_t* key
                       int64_t* n_groups);
 
 /*
+ * pds_lr_grouped_pred_* / pds_lr_by_key_pred_*: the grouped form of `pl_lr_pred` (linear_regression.rs:704-820) -- what
+ * `df.group_by(key).agg(pds.lin_reg(..., return_pred=True))` (tests/test_linear_exprs.py:435-474) and
+ * `pds.lin_reg(..., return_pred=True).over(key)` make Polars compute one group at a time: every group is fitted as
+ * pds_lr_grouped_* / pds_lr_by_key_* fit it, then ONE more pass over the frame (grouped_pred.hip) writes, for every row,
+ *   pred[r] = x_r . beta_g(r) (+ intercept),  resid[r] = y_r - pred[r],  row_null[r] = 1 when the row's group is null
+ * (pred / resid are NaN there; the reference returns an all-null struct for such a group, :745-750) -- IN THE FRAME'S OWN ROW
+ * ORDER, also when the keys are shuffled.  weights (nullable, n_rows values): per group faer_weighted_lr as in
+ * pds_lr_grouped_weighted_*, predictions from the unweighted rows.  pred / resid / row_null are `space`-resident and each may
+ * be NULL (at least one is not); coeffs / is_null (grouped) and out_keys / coeffs / is_null / n_groups (by key) may be NULL
+ * when only the per-row outputs are wanted (max_groups is then ignored).  Null-free frames only.
+ */
+int pds_lr_grouped_pred_f64(pds_ctx* ctx, const double* const* cols, const double* weights, int n_feat, int64_t n_rows,
+                            const int64_t* group_offsets, int64_t n_groups, pds_space space, const pds_lr_params* prm, double* coeffs,
+                            uint8_t* is_null, double* pred, double* resid, uint8_t* row_null);
+int pds_lr_grouped_pred_f32(pds_ctx* ctx, const float* const* cols, const float* weights, int n_feat, int64_t n_rows,
+                            const int64_t* group_offsets, int64_t n_groups, pds_space space, const pds_lr_params* prm, float* coeffs,
+                            uint8_t* is_null, float* pred, float* resid, uint8_t* row_null);
+int pds_lr_by_key_pred_f64(pds_ctx* ctx, const double* const* cols, const double* weights, const int64_t* keys, int n_feat,
+                           int64_t n_rows, pds_space space, const pds_lr_params* prm, int64_t max_groups, int64_t* out_keys,
+                           double* coeffs, uint8_t* is_null, int64_t* n_groups, double* pred, double* resid, uint8_t* row_null);
+int pds_lr_by_key_pred_f32(pds_ctx* ctx, const float* const* cols, const float* weights, const int64_t* keys, int n_feat, int64_t n_rows,
+                           pds_space space, const pds_lr_params* prm, int64_t max_groups, int64_t* out_keys, float* coeffs,
+                           uint8_t* is_null, int64_t* n_groups, float* pred, float* resid, uint8_t* row_null);
+
+/*
  * pds_rolling_lr_* / pds_recursive_lr_*: `pl_rolling_lr` (linear_regression.rs:1206-1283) and
  * `pl_recursive_lr` (:1121-1204) on null-free columns, i.e. faer_rolling_lr / faer_recursive_lr
  * (lr_online_solvers.rs:148-212) plus the plugin's pred_i = x_i . coeffs_i.  SWWLRKwargs: n = window

@@ -69,6 +69,7 @@ void pds_ctx_destroy(pds_ctx* ctx) {
     if (ctx->stage.ptr) (void)hipFree(ctx->stage.ptr);
     if (ctx->solve_ws.ptr) (void)hipFree(ctx->solve_ws.ptr);
     if (ctx->keyed.ptr) (void)hipFree(ctx->keyed.ptr);
+    if (ctx->wkeyed.ptr) (void)hipFree(ctx->wkeyed.ptr);
     if (ctx->mark_count) (void)hipFree(ctx->mark_count);
     if (ctx->mark_host) (void)hipHostFree(ctx->mark_host);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -339,6 +340,39 @@ int pds_lr_grouped_weighted_f32(pds_ctx* ctx, const float* const* cols, const fl
                                 const int64_t* group_offsets, int64_t n_groups, pds_space space, const pds_lr_params* prm,
                                 float* coeffs, uint8_t* is_null) {
     return pds::grouped_weighted_impl<float>(ctx, cols, weights, n_feat, n_rows, group_offsets, n_groups, space, prm, coeffs, is_null);
+}
+
+int pds_lr_grouped_pred_f64(pds_ctx* ctx, const double* const* cols, const double* weights, int n_feat, int64_t n_rows,
+                            const int64_t* group_offsets, int64_t n_groups, pds_space space, const pds_lr_params* prm, double* coeffs,
+                            uint8_t* is_null, double* pred, double* resid, uint8_t* row_null) {
+    if (!pred && !resid && !row_null) return pds::fail(PDS_ERR_INVALID, "pds_lr_grouped_pred: no per-row output requested");
+    if (weights)
+        return pds::grouped_weighted_impl<double>(ctx, cols, weights, n_feat, n_rows, group_offsets, n_groups, space, prm, coeffs, is_null,
+                                                  pred, resid, row_null, nullptr);
+    return pds::grouped_impl<double>(ctx, cols, n_feat, n_rows, group_offsets, n_groups, space, prm, coeffs, is_null, false, nullptr,
+                                     nullptr, PDS_NULL_RAISE, 0.0, pred, resid, row_null);
+}
+int pds_lr_grouped_pred_f32(pds_ctx* ctx, const float* const* cols, const float* weights, int n_feat, int64_t n_rows,
+                            const int64_t* group_offsets, int64_t n_groups, pds_space space, const pds_lr_params* prm, float* coeffs,
+                            uint8_t* is_null, float* pred, float* resid, uint8_t* row_null) {
+    if (!pred && !resid && !row_null) return pds::fail(PDS_ERR_INVALID, "pds_lr_grouped_pred: no per-row output requested");
+    if (weights)
+        return pds::grouped_weighted_impl<float>(ctx, cols, weights, n_feat, n_rows, group_offsets, n_groups, space, prm, coeffs, is_null,
+                                                 pred, resid, row_null, nullptr);
+    return pds::grouped_impl<float>(ctx, cols, n_feat, n_rows, group_offsets, n_groups, space, prm, coeffs, is_null, false, nullptr,
+                                    nullptr, PDS_NULL_RAISE, 0.0f, pred, resid, row_null);
+}
+int pds_lr_by_key_pred_f64(pds_ctx* ctx, const double* const* cols, const double* weights, const int64_t* keys, int n_feat,
+                           int64_t n_rows, pds_space space, const pds_lr_params* prm, int64_t max_groups, int64_t* out_keys,
+                           double* coeffs, uint8_t* is_null, int64_t* n_groups, double* pred, double* resid, uint8_t* row_null) {
+    return pds::lr_by_key_impl<double>(ctx, cols, keys, n_feat, n_rows, space, prm, max_groups, out_keys, coeffs, is_null, n_groups, weights,
+                                       pred, resid, row_null);
+}
+int pds_lr_by_key_pred_f32(pds_ctx* ctx, const float* const* cols, const float* weights, const int64_t* keys, int n_feat, int64_t n_rows,
+                           pds_space space, const pds_lr_params* prm, int64_t max_groups, int64_t* out_keys, float* coeffs,
+                           uint8_t* is_null, int64_t* n_groups, float* pred, float* resid, uint8_t* row_null) {
+    return pds::lr_by_key_impl<float>(ctx, cols, keys, n_feat, n_rows, space, prm, max_groups, out_keys, coeffs, is_null, n_groups, weights,
+                                      pred, resid, row_null);
 }
 
 int pds_lr_by_key_f64(pds_ctx* ctx, const double* const* cols, const int64_t* keys, int n_feat, int64_t n_rows, pds_space space,

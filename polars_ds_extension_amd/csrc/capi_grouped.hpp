@@ -78,8 +78,13 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
                         // nullable form: Arrow validity per column [y, x1..xp]; every group is fitted on the rows of it that
                         // survive the policy, like Polars calling pl_lr(null_policy=...) per group
                         bool nullable = false, const uint8_t* const* validity = nullptr, const int64_t* bit_offsets = nullptr,
-                        int policy = PDS_NULL_RAISE, T fill_value = T(0)) {
-    if (!ctx || !cols || !offsets || !prm || !coeffs) return fail(PDS_ERR_INVALID, "null argument");
+                        int policy = PDS_NULL_RAISE, T fill_value = T(0),
+                        // grouped pl_lr_pred (grouped_pred.hip): per-row outputs in the frame's row order, `space`-resident, each
+                        // nullable; `coeffs` may then be null as well.  Not with the nullable form (its rows are compacted).
+                        T* pred = nullptr, T* resid = nullptr, uint8_t* row_null = nullptr) {
+    const bool want_pred = pred || resid || row_null;
+    if (!ctx || !cols || !offsets || !prm || (!coeffs && !want_pred)) return fail(PDS_ERR_INVALID, "null argument");
+    if (want_pred && nullable) return fail(PDS_ERR_UNSUPPORTED, "grouped pred: null-free frames only");
     if (n_feat < 1) return fail(PDS_ERR_INVALID, "need at least one feature column");
     if (n_groups <= 0 || n_rows <= 0) return fail(PDS_ERR_EMPTY, "Empty data");
     const Method method = pick_method(prm);  // per group what pl_lr does per call: linear_regression.rs:447-497
@@ -93,7 +98,8 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
     size_t need = 131072 + sizeof(T) * (size_t)chunk * q * q;
     need += (size_t)n_groups * 4 + (size_t)chunk * (pp * sizeof(T) + 1) + 4096;  // the fused path's pivoted-QR pass: list, results
     if (big) need += (size_t)n_groups * (n_feat + 1) * sizeof(T*) + moments_wide_workspace(ctx->num_cus, n_feat, n_rows) + 8192;
-    if (space == PDS_HOST) need += (size_t)(n_groups + 1) * 8 + (size_t)n_groups * (pp * sizeof(T) + 1) + 4096;
+    if (space == PDS_HOST || !coeffs) need += (size_t)(n_groups + 1) * 8 + (size_t)n_groups * (pp * sizeof(T) + 1) + 4096;
+    if (want_pred && space == PDS_HOST) need += 2 * ((size_t)n_rows * sizeof(T) + 256) + (size_t)n_rows + 256;
     if (nullable) {
         if (policy < PDS_NULL_RAISE || policy > PDS_NULL_IGNORE) return fail(PDS_ERR_INVALID, "Invalid NullPolicy.");
         need += (1 << 20) + null_policy_workspace(n_feat + 1, n_rows, sizeof(T)) + (size_t)(n_groups + 1) * 8 + 4096;
@@ -108,7 +114,13 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
     // small host batches (the plugin layer's coalesced per-group calls): offsets go up through pinned memory, coefficients
     // and null flags come back in ONE copy -- every pageable hipMemcpyAsync is 5-10 us of a ~60 us call
     const size_t co_bytes = ((size_t)n_groups * pp * sizeof(T) + 255) & ~(size_t)255;
-    const bool small_out = space == PDS_HOST && co_bytes + (size_t)n_groups + (size_t)(n_groups + 1) * 8 <= ((size_t)48 << 10);
+    const bool small_out = space == PDS_HOST && coeffs && !want_pred &&
+                           co_bytes + (size_t)n_groups + (size_t)(n_groups + 1) * 8 <= ((size_t)48 << 10);
+    if (space == PDS_DEVICE && !coeffs) {  // (pred only: the coefficients live in the workspace)
+        char* blk = reinterpret_cast<char*>(ws_take(ctx, co_bytes + (size_t)n_groups));
+        d_coeffs = reinterpret_cast<T*>(blk);
+        if (!d_null) d_null = reinterpret_cast<uint8_t*>(blk + co_bytes);
+    }
     if (space == PDS_HOST) {
         int64_t* t = reinterpret_cast<int64_t*>(ws_take(ctx, (size_t)(n_groups + 1) * 8));
         if (small_out) {
@@ -205,6 +217,24 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
             if (int rc = launch_solve<T>(ctx, d_mom, gc, sp, d_coeffs + g0 * pp, d_null + g0, nullptr, d_off + g0)) return rc;
         }
     }
+    if (want_pred) {
+        T* d_pred = pred;
+        T* d_resid = resid;
+        uint8_t* d_rn = row_null;
+        if (space == PDS_HOST) {
+            if (pred) d_pred = reinterpret_cast<T*>(ws_take(ctx, (size_t)n_rows * sizeof(T)));
+            if (resid) d_resid = reinterpret_cast<T*>(ws_take(ctx, (size_t)n_rows * sizeof(T)));
+            if (row_null) d_rn = reinterpret_cast<uint8_t*>(ws_take(ctx, (size_t)n_rows));
+        }
+        if (int rc = launch_grouped_pred<T>(ctx, dc.d_ptrs, n_feat, bias, n_rows, d_off, n_groups, d_coeffs, d_null, nullptr, d_pred,
+                                            d_resid, d_rn))
+            return rc;
+        if (space == PDS_HOST) {
+            if (pred) PDS_HIP_CHECK(hipMemcpyAsync(pred, d_pred, (size_t)n_rows * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+            if (resid) PDS_HIP_CHECK(hipMemcpyAsync(resid, d_resid, (size_t)n_rows * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+            if (row_null) PDS_HIP_CHECK(hipMemcpyAsync(row_null, d_rn, (size_t)n_rows, hipMemcpyDeviceToHost, ctx->stream));
+        }
+    }
     if (small_out) {
         char* pin = static_cast<char*>(ctx->pinned);
         PDS_HIP_CHECK(hipMemcpyAsync(pin, d_coeffs, co_bytes + (size_t)n_groups, hipMemcpyDeviceToHost, ctx->stream));
@@ -214,7 +244,7 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
         return PDS_OK;
     }
     if (space == PDS_HOST) {
-        PDS_HIP_CHECK(hipMemcpyAsync(coeffs, d_coeffs, (size_t)n_groups * pp * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+        if (coeffs) PDS_HIP_CHECK(hipMemcpyAsync(coeffs, d_coeffs, (size_t)n_groups * pp * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
         if (is_null) PDS_HIP_CHECK(hipMemcpyAsync(is_null, d_null, (size_t)n_groups, hipMemcpyDeviceToHost, ctx->stream));
     }
     PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -228,18 +258,25 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
 template <typename T>
 static int grouped_weighted_impl(pds_ctx* ctx, const T* const* cols, const T* weights, int n_feat, int64_t n_rows,
                                  const int64_t* offsets, int64_t n_groups, pds_space space, const pds_lr_params* prm, T* coeffs,
-                                 uint8_t* is_null) {
-    if (!ctx || !cols || !weights || !offsets || !prm || !coeffs) return fail(PDS_ERR_INVALID, "null argument");
+                                 uint8_t* is_null,
+                                 // grouped pl_lr_pred with weights: pred = x . beta on the UNSCALED rows (linear_regression.rs:782-785),
+                                 // frame order (or through d_perm), `space`-resident, each nullable
+                                 T* pred = nullptr, T* resid = nullptr, uint8_t* row_null = nullptr, const uint32_t* d_perm = nullptr) {
+    const bool want_pred = pred || resid || row_null;
+    if (!ctx || !cols || !weights || !offsets || !prm || (!coeffs && !want_pred)) return fail(PDS_ERR_INVALID, "null argument");
     if (n_feat < 1) return fail(PDS_ERR_INVALID, "need at least one feature column");
     if (n_groups <= 0 || n_rows <= 0) return fail(PDS_ERR_EMPTY, "Empty data");
     PDS_HIP_CHECK(hipSetDevice(ctx->device));
     const int bias = prm->add_bias ? 1 : 0, pf = n_feat + bias, nc_in = n_feat + 1;
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t col_bytes = up((size_t)n_rows * sizeof(T));
-    size_t need = col_bytes * (pf + 1) + 4096;
-    if (space == PDS_HOST) need += col_bytes * (nc_in + 1) + up((size_t)(n_groups + 1) * 8) + up((size_t)n_groups * pf * sizeof(T)) + up((size_t)n_groups);
-    if (int rc = ensure_ws(ctx, ctx->keyed, need)) return rc;
-    char* w = static_cast<char*>(ctx->keyed.ptr);
+    size_t need = col_bytes * (pf + 1) + up(sizeof(T*) * (size_t)std::max(nc_in, 18)) + up((size_t)n_groups) + 4096;
+    if (space == PDS_HOST || !coeffs) need += up((size_t)n_groups * pf * sizeof(T));
+    if (space == PDS_HOST) need += col_bytes * (nc_in + 1) + up((size_t)(n_groups + 1) * 8);
+    if (want_pred && space == PDS_HOST) need += 2 * col_bytes + up((size_t)n_rows);
+    // (its own workspace: pds_lr_by_key_* calls this with its sorted frame living in ctx->keyed)
+    if (int rc = ensure_ws(ctx, ctx->wkeyed, need)) return rc;
+    char* w = static_cast<char*>(ctx->wkeyed.ptr);
     auto take = [&](size_t b) { char* r = w; w += up(b); return r; };
     std::vector<const T*> src(nc_in);
     const T* d_w = weights;
@@ -258,11 +295,11 @@ static int grouped_weighted_impl(pds_ctx* ctx, const T* const* cols, const T* we
         int64_t* doff = reinterpret_cast<int64_t*>(take((size_t)(n_groups + 1) * 8));
         PDS_HIP_CHECK(hipMemcpyAsync(doff, offsets, (size_t)(n_groups + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
         d_off = doff;
-        d_co = reinterpret_cast<T*>(take((size_t)n_groups * pf * sizeof(T)));
-        d_nu = reinterpret_cast<uint8_t*>(take((size_t)n_groups));
     } else {
         for (int c = 0; c < nc_in; ++c) src[c] = cols[c];
     }
+    if (space == PDS_HOST || !coeffs) d_co = reinterpret_cast<T*>(take((size_t)n_groups * pf * sizeof(T)));
+    if (space == PDS_HOST || !d_nu) d_nu = reinterpret_cast<uint8_t*>(take((size_t)n_groups));
     // scaled frame in reference order [y, x1..xp, (sqrt w)]
     std::vector<const T*> scaled(pf + 1);
     for (int c = 0; c < nc_in; ++c) {
@@ -282,8 +319,32 @@ static int grouped_weighted_impl(pds_ctx* ctx, const T* const* cols, const T* we
     p2.positive = 0;
     p2.singular_x_tol = 0.0;
     if (int rc = grouped_impl<T>(ctx, scaled.data(), pf, n_rows, d_off, n_groups, PDS_DEVICE, &p2, d_co, d_nu)) return rc;
+    if (want_pred) {
+        // device pointer table of the unscaled frame in kernel order (x_0 .. x_{p-1}, y)
+        std::vector<const T*> tbl((size_t)std::max(nc_in, 18), src[0]);
+        for (int c = 0; c < n_feat; ++c) tbl[c] = src[c + 1];
+        tbl[n_feat] = src[0];
+        const T** d_tbl = reinterpret_cast<const T**>(take(sizeof(T*) * tbl.size()));
+        PDS_HIP_CHECK(hipMemcpyAsync(d_tbl, tbl.data(), sizeof(T*) * tbl.size(), hipMemcpyHostToDevice, ctx->stream));
+        T* d_pred = pred;
+        T* d_resid = resid;
+        uint8_t* d_rn = row_null;
+        if (space == PDS_HOST) {
+            if (pred) d_pred = reinterpret_cast<T*>(take((size_t)n_rows * sizeof(T)));
+            if (resid) d_resid = reinterpret_cast<T*>(take((size_t)n_rows * sizeof(T)));
+            if (row_null) d_rn = reinterpret_cast<uint8_t*>(take((size_t)n_rows));
+        }
+        if (int rc = launch_grouped_pred<T>(ctx, d_tbl, n_feat, bias, n_rows, d_off, n_groups, d_co, d_nu, d_perm, d_pred, d_resid, d_rn))
+            return rc;
+        if (space == PDS_HOST) {
+            if (pred) PDS_HIP_CHECK(hipMemcpyAsync(pred, d_pred, (size_t)n_rows * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+            if (resid) PDS_HIP_CHECK(hipMemcpyAsync(resid, d_resid, (size_t)n_rows * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+            if (row_null) PDS_HIP_CHECK(hipMemcpyAsync(row_null, d_rn, (size_t)n_rows, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // (tbl: source of the table copy)
+    }
     if (space == PDS_HOST) {
-        PDS_HIP_CHECK(hipMemcpyAsync(coeffs, d_co, (size_t)n_groups * pf * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+        if (coeffs) PDS_HIP_CHECK(hipMemcpyAsync(coeffs, d_co, (size_t)n_groups * pf * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
         if (is_null) PDS_HIP_CHECK(hipMemcpyAsync(is_null, d_nu, (size_t)n_groups, hipMemcpyDeviceToHost, ctx->stream));
         PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     }
@@ -296,14 +357,22 @@ static int grouped_weighted_impl(pds_ctx* ctx, const T* const* cols, const T* we
 template <typename T>
 static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* keys, int n_feat, int64_t n_rows, pds_space space,
                           const pds_lr_params* prm, int64_t max_groups, int64_t* out_keys, T* coeffs, uint8_t* is_null,
-                          int64_t* n_groups) {
-    if (!ctx || !cols || !keys || !prm || !out_keys || !coeffs || !n_groups) return fail(PDS_ERR_INVALID, "null argument");
+                          int64_t* n_groups,
+                          // pds_lr_by_key_pred_*: optional weights (one more column through the ordering), per-row outputs in the
+                          // FRAME's row order; out_keys / coeffs / is_null / n_groups are then optional
+                          const T* weights = nullptr, T* pred = nullptr, T* resid = nullptr, uint8_t* row_null = nullptr) {
+    const bool want_pred = pred || resid || row_null;
+    const bool want_coef = out_keys || coeffs;
+    if (!ctx || !cols || !keys || !prm) return fail(PDS_ERR_INVALID, "null argument");
+    if (!want_pred && (!out_keys || !coeffs || !n_groups)) return fail(PDS_ERR_INVALID, "null argument");
+    if (want_coef && (!out_keys || !coeffs)) return fail(PDS_ERR_INVALID, "out_keys and coeffs come together");
     if (n_feat < 1) return fail(PDS_ERR_INVALID, "need at least one feature column");
     if (n_rows <= 0) return fail(PDS_ERR_EMPTY, "Empty data");
     if (n_rows >= (1ll << 31)) return fail(PDS_ERR_UNSUPPORTED, "keyed grouping: fewer than 2^31 rows per call");
+    if (!want_coef) max_groups = n_rows;
     if (max_groups < 1) return fail(PDS_ERR_INVALID, "max_groups must be positive");
     PDS_HIP_CHECK(hipSetDevice(ctx->device));
-    const int nc = n_feat + 1, pp = n_feat + (prm->add_bias ? 1 : 0);
+    const int nc = n_feat + 1 + (weights ? 1 : 0), pp = n_feat + (prm->add_bias ? 1 : 0);
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t key_bytes = up((size_t)n_rows * 8), col_bytes = up((size_t)n_rows * sizeof(T)), idx_bytes = up((size_t)n_rows * 4);
     StageTrace tr(ctx, "pds_lr_by_key");
@@ -322,9 +391,11 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
     // ---- workspace: [raw columns (host frames)] [sorted keys, index in/out, gathered columns (unsorted frames)] runs, temp
     const int64_t cap = std::min<int64_t>(max_groups, n_rows);
     const size_t temp_bytes = keyed_temp_bytes(n_rows);
-    size_t need = temp_bytes + 3 * up((size_t)(n_rows + 1) * 8) + 4096;  // unique keys, counts, offsets (at most one per row)
-    if (space == PDS_HOST) need += col_bytes * nc + up((size_t)cap * pp * sizeof(T)) + up((size_t)cap);
+    size_t need = temp_bytes + 3 * up((size_t)(n_rows + 1) * 8) + 8192;  // unique keys, counts, offsets (at most one per row)
+    if (space == PDS_HOST) need += col_bytes * nc;
+    if (space == PDS_HOST || !coeffs) need += up((size_t)cap * pp * sizeof(T)) + up((size_t)cap);
     if (!sorted) need += 2 * key_bytes + 2 * idx_bytes + col_bytes * nc + up((size_t)n_rows * nc * sizeof(T)) + up(2 * (size_t)nc * sizeof(T*)) + 1024;
+    if (want_pred) need += up(sizeof(T*) * (size_t)std::max(nc, 18)) + (space == PDS_HOST ? 2 * col_bytes + up((size_t)n_rows) : 0);
     if (int rc = ensure_ws(ctx, ctx->keyed, need)) return rc;
     tr.mark("workspace");
     char* w = static_cast<char*>(ctx->keyed.ptr);
@@ -334,16 +405,18 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
     int64_t* d_counts = reinterpret_cast<int64_t*>(take((size_t)(n_rows + 1) * 8));
     int64_t* d_offsets = reinterpret_cast<int64_t*>(take((size_t)(n_rows + 1) * 8));
     int64_t* d_nruns = reinterpret_cast<int64_t*>(take(256));
-    std::vector<const T*> src(nc);  // reference order [y, x1..xp], device resident
-    for (int c = 0; c < nc; ++c) src[c] = cols[c];
+    std::vector<const T*> src(nc);  // reference order [y, x1..xp, (w)], device resident
+    for (int c = 0; c < n_feat + 1; ++c) src[c] = cols[c];
+    if (weights) src[n_feat + 1] = weights;
     if (space == PDS_HOST)
         for (int c = 0; c < nc; ++c) {
             T* d = reinterpret_cast<T*>(take((size_t)n_rows * sizeof(T)));
-            PDS_HIP_CHECK(hipMemcpyAsync(d, cols[c], (size_t)n_rows * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+            PDS_HIP_CHECK(hipMemcpyAsync(d, src[c], (size_t)n_rows * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
             src[c] = d;
         }
     tr.mark("columns H2D");
     const int64_t* d_sorted_keys = d_keys;
+    const uint32_t* d_perm = nullptr;
     if (!sorted) {
         int64_t* sk = reinterpret_cast<int64_t*>(take((size_t)n_rows * 8));
         uint32_t* idx_in = reinterpret_cast<uint32_t*>(take((size_t)n_rows * 4));
@@ -352,6 +425,7 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
         int64_t* mm = reinterpret_cast<int64_t*>(take(256));
         if (int rc = keyed_sort(ctx, d_keys, n_rows, idx_in, sk, perm, d_temp, temp_bytes, sk2, mm)) return rc;
         d_sorted_keys = sk;
+        d_perm = perm;
         static const bool by_column = [] { const char* e = std::getenv("PDS_KEYED_GATHER_BY_COLUMN"); return e && e[0] == '1'; }();
         // frames too wide for the 256-row transposition tile (32 f64 / 64 f32 columns and beyond) gather column by column
         if (by_column || !gather_frame_fits<T>(nc)) {  // (one random 8-byte read per element; the env switch is the A/B)
@@ -381,21 +455,47 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
     int64_t ng = 0;
     if (int rc = keyed_runs(ctx, d_sorted_keys, n_rows, d_unique, d_counts, d_offsets, d_nruns, d_temp, temp_bytes, &ng)) return rc;
     tr.mark("run lengths + offsets");
-    *n_groups = ng;
+    if (n_groups) *n_groups = ng;
     if (ng > max_groups) return fail(PDS_ERR_INVALID, "more distinct keys than max_groups");
     T* d_co = coeffs;
     uint8_t* d_nu = is_null;
-    if (space == PDS_HOST) {
-        d_co = reinterpret_cast<T*>(take((size_t)cap * pp * sizeof(T)));
-        d_nu = reinterpret_cast<uint8_t*>(take((size_t)cap));
+    if (space == PDS_HOST || !coeffs) d_co = reinterpret_cast<T*>(take((size_t)cap * pp * sizeof(T)));
+    if (space == PDS_HOST || !is_null) d_nu = reinterpret_cast<uint8_t*>(take((size_t)cap));
+    T* d_pred = pred;
+    T* d_resid = resid;
+    uint8_t* d_rn = row_null;
+    if (want_pred && space == PDS_HOST) {
+        if (pred) d_pred = reinterpret_cast<T*>(take((size_t)n_rows * sizeof(T)));
+        if (resid) d_resid = reinterpret_cast<T*>(take((size_t)n_rows * sizeof(T)));
+        if (row_null) d_rn = reinterpret_cast<uint8_t*>(take((size_t)n_rows));
     }
-    if (int rc = grouped_impl<T>(ctx, src.data(), n_feat, n_rows, d_offsets, ng, PDS_DEVICE, prm, d_co, d_nu)) return rc;
+    if (weights) {
+        if (int rc = grouped_weighted_impl<T>(ctx, src.data(), src[n_feat + 1], n_feat, n_rows, d_offsets, ng, PDS_DEVICE, prm, d_co, d_nu,
+                                              d_pred, d_resid, d_rn, d_perm))
+            return rc;
+    } else {
+        if (int rc = grouped_impl<T>(ctx, src.data(), n_feat, n_rows, d_offsets, ng, PDS_DEVICE, prm, d_co, d_nu)) return rc;
+        if (want_pred) {
+            std::vector<const T*> tbl((size_t)std::max(nc, 18), src[0]);
+            for (int c = 0; c < n_feat; ++c) tbl[c] = src[c + 1];
+            tbl[n_feat] = src[0];
+            const T** d_tbl = reinterpret_cast<const T**>(take(sizeof(T*) * tbl.size()));
+            PDS_HIP_CHECK(hipMemcpyAsync(d_tbl, tbl.data(), sizeof(T*) * tbl.size(), hipMemcpyHostToDevice, ctx->stream));
+            if (int rc = launch_grouped_pred<T>(ctx, d_tbl, n_feat, prm->add_bias ? 1 : 0, n_rows, d_offsets, ng, d_co, d_nu, d_perm, d_pred,
+                                                d_resid, d_rn))
+                return rc;
+            PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // (tbl: source of the table copy)
+        }
+    }
     tr.mark("grouped fit");
     if (space == PDS_HOST) {
-        PDS_HIP_CHECK(hipMemcpyAsync(coeffs, d_co, (size_t)ng * pp * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
-        if (is_null) PDS_HIP_CHECK(hipMemcpyAsync(is_null, d_nu, (size_t)ng, hipMemcpyDeviceToHost, ctx->stream));
-        PDS_HIP_CHECK(hipMemcpyAsync(out_keys, d_unique, (size_t)ng * 8, hipMemcpyDeviceToHost, ctx->stream));
-    } else {
+        if (coeffs) PDS_HIP_CHECK(hipMemcpyAsync(coeffs, d_co, (size_t)ng * pp * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+        if (coeffs && is_null) PDS_HIP_CHECK(hipMemcpyAsync(is_null, d_nu, (size_t)ng, hipMemcpyDeviceToHost, ctx->stream));
+        if (out_keys) PDS_HIP_CHECK(hipMemcpyAsync(out_keys, d_unique, (size_t)ng * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (pred) PDS_HIP_CHECK(hipMemcpyAsync(pred, d_pred, (size_t)n_rows * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+        if (resid) PDS_HIP_CHECK(hipMemcpyAsync(resid, d_resid, (size_t)n_rows * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+        if (row_null) PDS_HIP_CHECK(hipMemcpyAsync(row_null, d_rn, (size_t)n_rows, hipMemcpyDeviceToHost, ctx->stream));
+    } else if (out_keys) {
         PDS_HIP_CHECK(hipMemcpyAsync(out_keys, d_unique, (size_t)ng * 8, hipMemcpyDeviceToDevice, ctx->stream));
     }
     PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));

@@ -86,6 +86,7 @@ struct pds_ctx {
     pds::Workspace stage;    // HBM staging of PDS_HOST column buffers
     pds::Workspace solve_ws; // factor workspace of the p' > 64 solver (solve_big.hip)
     pds::Workspace keyed;    // pds_lr_by_key_*: staged / sorted keys, permutation, gathered columns, run-length results
+    pds::Workspace wkeyed;   // pds_lr_grouped_weighted_*: staged + sqrt(w)-scaled frame (separate: by_key calls it with its frame in `keyed`)
     // fused grouped kernel -> pivoted-QR pass hand-over: device counter of marked groups, and a host-mapped word the kernel
     // raises when it marks its first group (the only thing the host reads in the common case)
     unsigned* mark_count = nullptr;
@@ -226,6 +227,12 @@ int launch_cd(pds_ctx* ctx, const T* d_moments, int p, int add_bias, double l1, 
 template <typename T>
 int launch_nnls(pds_ctx* ctx, const T* d_moments, int p, int add_bias, double tol, int max_iter, T* d_coeffs,
                 int64_t n_sys = 1, uint8_t* d_flags = nullptr, const int64_t* d_rows_per_sys = nullptr);
+
+// ---- grouped_pred.hip: per-row pred / resid of grouped fits (frame in group order; d_perm sends rows back to frame order) ----
+template <typename T>
+int launch_grouped_pred(pds_ctx* ctx, const T* const* d_cols, int n_feat, int bias, int64_t n_rows, const int64_t* d_off,
+                        int64_t n_groups, const T* d_coeffs, const uint8_t* d_flags, const uint32_t* d_perm, T* d_pred, T* d_resid,
+                        uint8_t* d_row_null);
 
 // ---- pass2.hip ----
 // sum y and sum y^2 of one device column in f64 (fixed-order two-stage reduction): d_out[0..1]

@@ -1,0 +1,218 @@
+// grouped_pred.hip -- per-row pred / resid of GROUPED fits: the second pass of `pl_lr_pred` (linear_regression.rs:782-806)
+// for every group of a frame at once -- what `df.group_by(key).agg(pds.lin_reg(..., return_pred=True))` and
+// `pds.lin_reg(..., return_pred=True).over(key)` make the reference do one group at a time
+// (tests/test_linear_exprs.py:435-474, examples/basics.ipynb cells 16 / 18).
+//
+//   pred_r = x_r . beta_g(r) (+ b0_g(r)),  resid_r = y_r - pred_r,  row_null_r = (group g(r) is null)
+//
+// The frame is in GROUP ORDER (group g = rows [off[g], off[g+1]) -- the frame itself when its keys are ordered, the gathered
+// copy of keyed.hip otherwise); `perm` (sorted position -> frame row, nullable) sends the results back to the frame's own
+// row order, so a shuffled frame gets its predictions where its rows are.
+//
+// Layout: like pass2.hip -- lane = RPL consecutive rows (16-byte loads, 1 KiB coalesced per instruction), a wave owns a
+// contiguous range of 64 RPL-row chunks and walks it upwards, so the group of a lane's rows only ever moves forward: one
+// binary search when the wave starts, then `while (off[g + 1] <= r) ++g`.  The coefficient rows of the (two or three) groups
+// a chunk touches are read through the vector cache (same-address lanes coalesce).  HBM bound: reads N (p + 1) elements and
+// the n_groups x p' coefficient block, writes 2 N elements + N bytes.
+#include "common.hpp"
+
+#include <type_traits>
+
+namespace pds {
+
+namespace {
+
+template <typename T>
+struct GP16;
+template <>
+struct GP16<double> {
+    typedef double type __attribute__((ext_vector_type(2), aligned(8)));
+    static constexpr int RPL = 2;
+};
+template <>
+struct GP16<float> {
+    typedef float type __attribute__((ext_vector_type(4), aligned(4)));
+    static constexpr int RPL = 4;
+};
+
+constexpr int kGpThreads = 256;
+
+// last group whose first row is <= r (empty groups are skipped over: off is non-decreasing)
+__device__ __forceinline__ int64_t group_of_row(const int64_t* __restrict__ off, int64_t n_groups, int64_t r) {
+    int64_t lo = 0, hi = n_groups;  // invariant: off[lo] <= r < off[hi]
+    while (hi - lo > 1) {
+        const int64_t mid = lo + ((hi - lo) >> 1);
+        if (off[mid] <= r) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// PC: feature count as a compile-time constant (1..16), 0 = run time (any width, column loop)
+template <typename T, int PC, bool PERM>
+__global__ __launch_bounds__(kGpThreads) void grouped_pred_kernel(const T* const* __restrict__ cols, int p_arg, int bias, int64_t n,
+                                                                  const int64_t* __restrict__ off, int64_t n_groups,
+                                                                  const T* __restrict__ coeffs, const uint8_t* __restrict__ flags,
+                                                                  const uint32_t* __restrict__ perm, T* __restrict__ pred,
+                                                                  T* __restrict__ resid, uint8_t* __restrict__ row_null) {
+    using V = typename GP16<T>::type;
+    constexpr int RPL = GP16<T>::RPL;
+    const int p = PC ? PC : p_arg;
+    const int pp = p + bias;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (kGpThreads / 64) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (kGpThreads / 64);
+    const int64_t nchunk = (n + 64 * RPL - 1) / (64 * RPL);
+    const int64_t c0 = nchunk * wave / nwaves, c1 = nchunk * (wave + 1) / nwaves;
+    if (c0 >= c1) return;
+    const T nanv = (T)__builtin_nan("");
+    int64_t g[RPL];
+    {
+        const int64_t r = c0 * 64 * RPL + (int64_t)lane * RPL;
+        const int64_t g0 = group_of_row(off, n_groups, r < n ? r : n - 1);
+#pragma unroll
+        for (int e = 0; e < RPL; ++e) g[e] = g0;
+    }
+    const gptr<T> cy = as_global(cols[p]);
+    for (int64_t ch = c0; ch < c1; ++ch) {
+        const int64_t r0 = ch * 64 * RPL + (int64_t)lane * RPL;
+        if (r0 >= n) continue;
+        const bool full = r0 + RPL <= n;
+        // ---- the groups of the lane's rows (monotone in r: forward steps only)
+#pragma unroll
+        for (int e = 0; e < RPL; ++e) {
+            const int64_t r = (r0 + e < n) ? r0 + e : n - 1;
+            int64_t ge = e ? (g[e - 1] > g[e] ? g[e - 1] : g[e]) : g[0];
+            while (ge + 1 < n_groups && off[ge + 1] <= r) ++ge;
+            g[e] = ge;
+        }
+        double acc[RPL];
+        const T* brow[RPL];
+#pragma unroll
+        for (int e = 0; e < RPL; ++e) {
+            brow[e] = coeffs + g[e] * pp;
+            acc[e] = bias ? (double)brow[e][p] : 0.0;
+        }
+        auto col_step = [&](int c) __attribute__((always_inline)) {
+            const gptr<T> col = as_global(cols[c]);
+            V v;
+            if (full) {
+                v = __builtin_nontemporal_load(reinterpret_cast<gptr<V>>(col + r0));
+            } else {
+#pragma unroll
+                for (int e = 0; e < RPL; ++e) v[e] = (r0 + e < n) ? col[r0 + e] : T(0);
+            }
+#pragma unroll
+            for (int e = 0; e < RPL; ++e) acc[e] = fma((double)v[e], (double)brow[e][c], acc[e]);
+        };
+        if constexpr (PC != 0) {
+#pragma unroll
+            for (int c = 0; c < PC; ++c) col_step(c);
+        } else {
+#pragma unroll 4
+            for (int c = 0; c < p; ++c) col_step(c);
+        }
+        V yv;
+        if (full) {
+            yv = __builtin_nontemporal_load(reinterpret_cast<gptr<V>>(cy + r0));
+        } else {
+#pragma unroll
+            for (int e = 0; e < RPL; ++e) yv[e] = (r0 + e < n) ? cy[r0 + e] : T(0);
+        }
+        V pv, rv;
+        uint8_t nl[RPL];
+#pragma unroll
+        for (int e = 0; e < RPL; ++e) {
+            nl[e] = flags ? flags[g[e]] : (uint8_t)0;
+            const T pr = nl[e] ? nanv : (T)acc[e];
+            pv[e] = pr;
+            rv[e] = nl[e] ? nanv : (T)((double)yv[e] - (double)pr);
+        }
+        if constexpr (PERM) {
+#pragma unroll
+            for (int e = 0; e < RPL; ++e)
+                if (r0 + e < n) {
+                    const int64_t dst = (int64_t)perm[r0 + e];
+                    if (pred) pred[dst] = pv[e];
+                    if (resid) resid[dst] = rv[e];
+                    if (row_null) row_null[dst] = nl[e];
+                }
+        } else if (full) {
+            if (pred) *reinterpret_cast<V*>(pred + r0) = pv;
+            if (resid) *reinterpret_cast<V*>(resid + r0) = rv;
+            if (row_null) {
+#pragma unroll
+                for (int e = 0; e < RPL; ++e) row_null[r0 + e] = nl[e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < RPL; ++e)
+                if (r0 + e < n) {
+                    if (pred) pred[r0 + e] = pv[e];
+                    if (resid) resid[r0 + e] = rv[e];
+                    if (row_null) row_null[r0 + e] = nl[e];
+                }
+        }
+    }
+}
+
+template <typename T, bool PERM>
+void launch_pc(int p, dim3 g, hipStream_t st, const T* const* cols, int bias, int64_t n, const int64_t* off, int64_t ng,
+               const T* co, const uint8_t* fl, const uint32_t* perm, T* pred, T* resid, uint8_t* rn) {
+#define PDS_GP_CASE(PCV)                                                                                                         \
+    case PCV:                                                                                                                    \
+        hipLaunchKernelGGL((grouped_pred_kernel<T, PCV, PERM>), g, dim3(kGpThreads), 0, st, cols, p, bias, n, off, ng, co, fl, perm, \
+                           pred, resid, rn);                                                                                     \
+        break;
+    switch (p) {
+        PDS_GP_CASE(1)
+        PDS_GP_CASE(2)
+        PDS_GP_CASE(3)
+        PDS_GP_CASE(4)
+        PDS_GP_CASE(5)
+        PDS_GP_CASE(6)
+        PDS_GP_CASE(7)
+        PDS_GP_CASE(8)
+        PDS_GP_CASE(9)
+        PDS_GP_CASE(10)
+        PDS_GP_CASE(11)
+        PDS_GP_CASE(12)
+        PDS_GP_CASE(13)
+        PDS_GP_CASE(14)
+        PDS_GP_CASE(15)
+        PDS_GP_CASE(16)
+        default:
+            hipLaunchKernelGGL((grouped_pred_kernel<T, 0, PERM>), g, dim3(kGpThreads), 0, st, cols, p, bias, n, off, ng, co, fl, perm,
+                               pred, resid, rn);
+    }
+#undef PDS_GP_CASE
+}
+
+}  // namespace
+
+// d_cols: device table in kernel order (x_0 .. x_{p-1}, y); d_off: n_groups + 1 device offsets; d_coeffs n_groups x p' row-major;
+// d_flags (nullable) one byte per group; d_perm (nullable) sorted position -> frame row; outputs (each nullable) in frame order
+template <typename T>
+int launch_grouped_pred(pds_ctx* ctx, const T* const* d_cols, int n_feat, int bias, int64_t n_rows, const int64_t* d_off,
+                        int64_t n_groups, const T* d_coeffs, const uint8_t* d_flags, const uint32_t* d_perm, T* d_pred, T* d_resid,
+                        uint8_t* d_row_null) {
+    if (n_rows <= 0 || n_groups <= 0) return PDS_OK;
+    KernelTimer timer(ctx, kKindPass2);
+    constexpr int RPL = GP16<T>::RPL;
+    const int64_t nchunk = (n_rows + 64 * RPL - 1) / (64 * RPL);
+    const int nb = (int)std::min<int64_t>(std::max<int64_t>((nchunk + 3) / 4, 1), (int64_t)ctx->num_cus * 8);
+    if (d_perm)
+        launch_pc<T, true>(n_feat, dim3(nb), ctx->stream, d_cols, bias, n_rows, d_off, n_groups, d_coeffs, d_flags, d_perm, d_pred,
+                           d_resid, d_row_null);
+    else
+        launch_pc<T, false>(n_feat, dim3(nb), ctx->stream, d_cols, bias, n_rows, d_off, n_groups, d_coeffs, d_flags, d_perm, d_pred,
+                            d_resid, d_row_null);
+    PDS_HIP_CHECK(hipGetLastError());
+    return PDS_OK;
+}
+template int launch_grouped_pred<double>(pds_ctx*, const double* const*, int, int, int64_t, const int64_t*, int64_t, const double*,
+                                         const uint8_t*, const uint32_t*, double*, double*, uint8_t*);
+template int launch_grouped_pred<float>(pds_ctx*, const float* const*, int, int, int64_t, const int64_t*, int64_t, const float*,
+                                        const uint8_t*, const uint32_t*, float*, float*, uint8_t*);
+
+}  // namespace pds

@@ -8,16 +8,27 @@
 // Calls that arrive while a batch is on the device are queued and leave together as ONE grouped launch (group commit:
 // no timer, a lone caller is never held back): the thread that finds nobody serving becomes the server, takes everything
 // that is pending with the same parameters, concatenates the frames, runs pds_lr_grouped_* and hands the rows of the
-// result back; it serves until the queue is empty.  Only null-free, unweighted coefficient fits on small frames take this
-// route (solver "svd" does not: the grouped entry point has no SVD, so those calls keep the single-frame path), and a
-// batch of one runs the same grouped entry point as a batch of a thousand.  PDS_PLUGIN_COALESCE=0 switches it off.
+// result back; it serves until the queue is empty.  What takes this route (small frames only): coefficient fits and
+// `return_pred` fits (pds_lr_grouped_pred_*: the batch's pred / resid come back as one block and are cut per request), with or
+// without weights (pds_lr_grouped_weighted_* / the weights argument of the pred entry point), and coefficient fits on frames
+// with nulls under the skip / fill policies (pds_lr_grouped_nullable_*: the requests' validity bitmaps are concatenated bit
+// by bit).  Solver "svd" does not (the grouped entry points have no SVD: those calls keep the single-frame path), nor does a
+// pred fit on a frame with nulls.  A batch of one runs the same grouped entry point as a batch of a thousand.
+// PDS_PLUGIN_COALESCE=0 switches the queue off.
 template <typename T>
 struct LrRequest {
-    const std::vector<Column<T>>* cols;  // [y, x1..xp], all of length n, no nulls
+    const std::vector<Column<T>>* cols;  // [weights?, y, x1..xp], all of length n
+    size_t first = 0;                    // index of y in `cols` (1 with weights)
     int n_feat;
     int64_t n;
     pds_lr_params prm;
+    bool weighted = false;               // cols[0] = weights: per request faer_weighted_lr
+    bool want_pred = false;              // pred / resid (n values each) wanted
+    int null_code = 0;                   // 0: null-free frame; PDS_NULL_SKIP / PDS_NULL_FILL: bitmaps travel with the frame
+    T fill = T(0);
     std::vector<T>* coeffs;              // out: p' values
+    T* pred = nullptr;                   // out (want_pred): n values each
+    T* resid = nullptr;
     int is_null = 0;
     std::string error;
     // completion is signalled per request: one shared condition variable woke every waiting thread after every batch
@@ -115,7 +126,9 @@ class LrCoalescer {
             batch.push_back(pending_.front());
             for (size_t i = 1; i < pending_.size(); ++i) {
                 LrRequest<T>* q = pending_[i];
-                if (q->n_feat == batch[0]->n_feat && same_params(q->prm, batch[0]->prm) && (int64_t)batch.size() < kMaxBatch)
+                if (q->n_feat == batch[0]->n_feat && same_params(q->prm, batch[0]->prm) && q->weighted == batch[0]->weighted &&
+                    q->want_pred == batch[0]->want_pred && q->null_code == batch[0]->null_code && q->fill == batch[0]->fill &&
+                    (int64_t)batch.size() < kMaxBatch)
                     batch.push_back(q);
                 else
                     rest.push_back(q);
@@ -160,8 +173,9 @@ class LrCoalescer {
         while ((long long)batch.size() > prev && !g_coalesce_max_batch.compare_exchange_weak(prev, (long long)batch.size())) {
         }
         try {
-            const int n_feat = batch[0]->n_feat, nc = n_feat + 1;
-            const pds_lr_params prm = batch[0]->prm;
+            const LrRequest<T>& h = *batch[0];
+            const int n_feat = h.n_feat, nc = n_feat + 1 + (h.weighted ? 1 : 0);  // [y, x1..xp, (w)]
+            const pds_lr_params prm = h.prm;
             const int pp = n_feat + prm.add_bias;
             // (a batch of one takes the grouped entry point as well: which solver answers -- and therefore the null decision
             //  next to singular_x_tol and the coefficients of a rank-deficient group -- must not depend on who else happened
@@ -179,14 +193,52 @@ class LrCoalescer {
             std::vector<const T*> ptrs(nc);
             for (int c = 0; c < nc; ++c) {
                 if ((int64_t)cat[c].size() < total) cat[c].resize(total);
-                for (size_t g = 0; g < batch.size(); ++g)
-                    std::memcpy(cat[c].data() + off[g], (*batch[g]->cols)[c].data(), (size_t)batch[g]->n * sizeof(T));
+                for (size_t g = 0; g < batch.size(); ++g) {
+                    const auto& rc = *batch[g]->cols;
+                    const Column<T>& src = c < n_feat + 1 ? rc[batch[g]->first + c] : rc[0];  // (the weights are input 0)
+                    std::memcpy(cat[c].data() + off[g], src.data(), (size_t)batch[g]->n * sizeof(T));
+                }
                 ptrs[c] = cat[c].data();
             }
             std::vector<T> co((size_t)batch.size() * pp);
             std::vector<uint8_t> nu(batch.size());
-            check(Api<T>::grouped(thread_ctx(), ptrs.data(), n_feat, total, off.data(), (int64_t)batch.size(), PDS_HOST, &prm, co.data(),
-                                  nu.data()));
+            const T* wts = h.weighted ? ptrs[n_feat + 1] : nullptr;
+            if (h.want_pred) {
+                static std::vector<T> pr, re;
+                if ((int64_t)pr.size() < total) pr.resize(total), re.resize(total);
+                check(Api<T>::grouped_pred(thread_ctx(), ptrs.data(), wts, n_feat, total, off.data(), (int64_t)batch.size(), PDS_HOST, &prm,
+                                           co.data(), nu.data(), pr.data(), re.data(), nullptr));
+                for (size_t g = 0; g < batch.size(); ++g) {
+                    std::memcpy(batch[g]->pred, pr.data() + off[g], (size_t)batch[g]->n * sizeof(T));
+                    std::memcpy(batch[g]->resid, re.data() + off[g], (size_t)batch[g]->n * sizeof(T));
+                }
+            } else if (h.weighted) {
+                check(Api<T>::grouped_weighted(thread_ctx(), ptrs.data(), wts, n_feat, total, off.data(), (int64_t)batch.size(), PDS_HOST,
+                                               &prm, co.data(), nu.data()));
+            } else if (h.null_code != 0) {
+                // validity of the concatenated frame: bits [off[g], off[g + 1]) of column c = request g's bitmap (all set when the
+                // request's column carries none); a column no request has nulls in goes without a bitmap
+                std::vector<std::vector<uint8_t>> bms(n_feat + 1);
+                std::vector<const uint8_t*> bmp(n_feat + 1, nullptr);
+                std::vector<int64_t> boff(n_feat + 1, 0);
+                for (int c = 0; c < n_feat + 1; ++c) {
+                    bool any = false;
+                    for (auto* q : batch) any |= !(*q->cols)[q->first + c].validity.empty();
+                    if (!any) continue;
+                    bms[c].assign((size_t)(total + 7) / 8, 0);
+                    for (size_t g = 0; g < batch.size(); ++g) {
+                        const Column<T>& src = (*batch[g]->cols)[batch[g]->first + c];
+                        for (int64_t i = 0; i < batch[g]->n; ++i)
+                            if (src.validity.empty() || bit_get(src.validity.data(), i)) bit_set(bms[c], off[g] + i);
+                    }
+                    bmp[c] = bms[c].data();
+                }
+                check(Api<T>::grouped_nullable(thread_ctx(), ptrs.data(), bmp.data(), boff.data(), n_feat, total, off.data(),
+                                               (int64_t)batch.size(), PDS_HOST, h.null_code, h.fill, &prm, co.data(), nu.data()));
+            } else {
+                check(Api<T>::grouped(thread_ctx(), ptrs.data(), n_feat, total, off.data(), (int64_t)batch.size(), PDS_HOST, &prm, co.data(),
+                                      nu.data()));
+            }
             for (size_t g = 0; g < batch.size(); ++g) {
                 batch[g]->coeffs->assign(co.begin() + g * pp, co.begin() + (g + 1) * pp);
                 batch[g]->is_null = nu[g] ? 1 : 0;

@@ -37,6 +37,8 @@ template <> struct Api<double> {
     static constexpr auto rolling = pds_rolling_lr_f64;
     static constexpr auto recursive = pds_recursive_lr_f64;
     static constexpr auto by_key = pds_lr_by_key_f64;
+    static constexpr auto by_key_pred = pds_lr_by_key_pred_f64;
+    static constexpr auto grouped_pred = pds_lr_grouped_pred_f64;
     static constexpr auto grouped = pds_lr_grouped_f64;
     static constexpr auto grouped_weighted = pds_lr_grouped_weighted_f64;
     static constexpr auto grouped_nullable = pds_lr_grouped_nullable_f64;
@@ -53,6 +55,8 @@ template <> struct Api<float> {
     static constexpr auto rolling = pds_rolling_lr_f32;
     static constexpr auto recursive = pds_recursive_lr_f32;
     static constexpr auto by_key = pds_lr_by_key_f32;
+    static constexpr auto by_key_pred = pds_lr_by_key_pred_f32;
+    static constexpr auto grouped_pred = pds_lr_grouped_pred_f32;
     static constexpr auto grouped = pds_lr_grouped_f32;
     static constexpr auto grouped_weighted = pds_lr_grouped_weighted_f32;
     static constexpr auto grouped_nullable = pds_lr_grouped_nullable_f32;

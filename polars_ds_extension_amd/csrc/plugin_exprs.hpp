@@ -35,15 +35,45 @@ void do_pl_lr(SeriesExport* in, size_t n_in, const Kwargs& kw, SeriesExport* out
         export_series(out, make_schema("+s", "", std::move(sk)), struct_array(1, std::move(kids)));
         return;
     }
-    // small null-free coefficient fits (the per-group calls of group_by().agg()): leave together with whatever else is queued
-    if (!weighted && !want_pred && !any_null && n >= pp && n > 0 && (size_t)n * (n_feat + 1) * sizeof(T) <= ((size_t)256 << 10) &&
-        n_feat <= 64 && prm.solver != PDS_SOLVER_SVD && coalescing_enabled()) {
+    // small frames (the per-group calls of group_by().agg() / .over()): leave together with whatever else is queued.  Eligible:
+    // coefficient and pred fits without nulls (weighted or not), coefficient fits with nulls under skip / fill whose kept rows
+    // still cover the coefficients (fewer kept rows than coefficients is an ERROR of the single-frame path, not a null: it keeps it)
+    int queue_null_code = 0;
+    bool queue_ok = n >= pp && n > 0 && (size_t)n * (n_feat + 1 + first) * sizeof(T) <= ((size_t)256 << 10) && n_feat <= 64 &&
+                    prm.solver != PDS_SOLVER_SVD && coalescing_enabled();
+    if (queue_ok && any_null) {
+        queue_ok = !weighted && !want_pred && (pol.kind == Policy::SKIP || pol.kind == Policy::FILL);
+        if (queue_ok) {
+            int64_t kept = 0;
+            for (int64_t i = 0; i < n; ++i) {
+                bool ok = true;
+                const size_t last = pol.kind == Policy::SKIP ? n_in : first + 1;  // (fill: only the target's nulls drop rows)
+                for (size_t c = first; c < last && ok; ++c) ok = cols[c].validity.empty() || bit_get(cols[c].validity.data(), i);
+                kept += ok ? 1 : 0;
+            }
+            queue_ok = kept >= pp;
+            queue_null_code = pol.kind == Policy::SKIP ? PDS_NULL_SKIP : PDS_NULL_FILL;
+        }
+    }
+    if (queue_ok) {
         LrRequest<T> req;
         req.cols = &cols;
+        req.first = first;
         req.n_feat = n_feat;
         req.n = n;
         req.prm = prm;
+        req.weighted = weighted;
+        req.want_pred = want_pred;
+        req.null_code = queue_null_code;
+        req.fill = (T)pol.fill;
         req.coeffs = &coeffs;
+        if (want_pred) {
+            pred_b = raw_buffer<T>((size_t)n);
+            resid_b = raw_buffer<T>((size_t)n);
+            req.pred = as<T>(pred_b);
+            req.resid = as<T>(resid_b);
+            valid.assign(n, 1);
+        }
         static const bool bypass = [] { const char* e = std::getenv("PDS_PLUGIN_COALESCE"); return e && e[0] == '2'; }();
         if (bypass) LrCoalescer<T>::run_one(&req);
         else LrCoalescer<T>::instance().submit(&req);
@@ -262,10 +292,14 @@ void do_windowed(SeriesExport* in, size_t n_in, const Kwargs& kw, SeriesExport* 
     export_series(out, make_schema("+s", "", std::move(sk)), struct_array(n, std::move(kids)));
 }
 
-// ------------------------------------------------------------------------------------------------- pl_lr_by (new)
+// ------------------------------------------------------------------------------------------------- pl_lr_by / pl_lr_by_pred (new)
+// inputs: [key (integer, any row order, nulls = one group), weights?, y, x1..xp]
+//   pl_lr_by       Struct{key, coeffs: List<T>}, one row per group, keys ascending (a null key's group where its stand-in sorts)
+//   pl_lr_by_pred  Struct{pred, resid}, one row per INPUT row, in the frame's row order: what
+//                  `group_by(key).agg(lin_reg(..., return_pred=True))` / `lin_reg(..., return_pred=True).over(key)` compute per
+//                  group (linear_regression.rs:704-820); rows of a null group are null in both fields (:745-750)
 template <typename T>
-void do_lr_by(SeriesExport* in, size_t n_in, const Kwargs& kw, SeriesExport* out) {
-    // inputs: [key (int64, any row order), weights?, y, x1..xp]; output Struct{key, coeffs: List<T>} one row per group
+void do_lr_by(SeriesExport* in, size_t n_in, const Kwargs& kw, SeriesExport* out, bool want_pred) {
     const bool weighted = kw_bool(kw, "weighted");
     if (n_in < (weighted ? 4u : 3u)) raise("pl_lr_by needs a key, a target and at least one feature");
     const pds_lr_params prm = lr_params(kw);
@@ -278,85 +312,86 @@ void do_lr_by(SeriesExport* in, size_t n_in, const Kwargs& kw, SeriesExport* out
     if (any_null && pol.kind == Policy::RAISE) raise("Nulls found in data");
     // pl_lr never compacts its weights (:436-446): a weighted fit on a frame that loses rows fails in the reference too
     if (any_null && weighted) raise("Shape of weights is not the same as the data.");
+    if (any_null && want_pred) raise("pl_lr_by_pred: rows with nulls are not supported (drop or fill them in front of the call)");
     const int64_t n = key.size();
-    if (key.null_count) raise("pl_lr_by: null keys are not supported");
     for (auto& c : cols)
         if (c.size() != n) raise("input columns differ in length");
+    // Polars' group_by makes the null keys ONE group.  They take a key value no valid row uses -- max + 1, so that group comes
+    // last (min - 1 when the maximum is INT64_MAX) -- and the group that carries it is reported with a null key.
+    bool null_group = false;
+    int64_t null_stand_in = 0;
+    if (key.null_count > 0) {
+        const int64_t* k = key.data();
+        int64_t mx = std::numeric_limits<int64_t>::min(), mn = std::numeric_limits<int64_t>::max();
+        bool any_valid = false;
+        for (int64_t i = 0; i < n; ++i)
+            if (bit_get(key.validity.data(), i)) {
+                mx = std::max(mx, k[i]);
+                mn = std::min(mn, k[i]);
+                any_valid = true;
+            }
+        if (!any_valid) null_stand_in = 0;
+        else if (mx < std::numeric_limits<int64_t>::max()) null_stand_in = mx + 1;
+        else if (mn > std::numeric_limits<int64_t>::min()) null_stand_in = mn - 1;
+        else raise("pl_lr_by: the keys span the whole int64 range, no value is left for the null group");
+        auto& kv = key.own();
+        for (int64_t i = 0; i < n; ++i)
+            if (!bit_get(key.validity.data(), i)) kv[i] = null_stand_in;
+        null_group = true;
+    }
     const int n_feat = (int)n_in - 2 - (weighted ? 1 : 0);
     const int pp = n_feat + prm.add_bias;
     const int64_t* ikey = key.data();
-    // non-decreasing keys: groups are contiguous as they stand (only the host-ordered routes ask; the null-free route
-    // leaves the check and the ordering to the device)
-    bool ordered = true;
-    if (weighted || any_null)
-        for (int64_t i = 1; i < n && ordered; ++i) ordered = ikey[i] >= ikey[i - 1];
+    if (n == 0) raise("Empty data");
     // result storage is sized for a guessed capacity but never zeroed: pages the device-to-host copies do not write are
     // never touched (a zeroed 1M-group guess cost 16 ms of page faults per call)
     RawVec<int64_t> keys;
     ByteVec cobuf;
     RawVec<uint8_t> nulls;
+    ByteVec pred_b, resid_b;
+    RawVec<uint8_t> row_null;
     int64_t ng = 0;
-    if (weighted) {
-        // weights ride as one more column through the (host) ordering, then the weighted grouped entry point
-        if (n == 0) raise("Empty data");
-        std::vector<int64_t> perm;
-        if (!ordered) {
-            perm.resize(n);
-            for (int64_t i = 0; i < n; ++i) perm[i] = i;
-            std::stable_sort(perm.begin(), perm.end(), [&](int64_t a, int64_t b) { return ikey[a] < ikey[b]; });
-            std::vector<int64_t> k2(n);
-            for (int64_t i = 0; i < n; ++i) k2[i] = ikey[perm[i]];
-            key.view = nullptr;
-            key.values.swap(k2);
-            ikey = key.values.data();
-            for (auto& c : cols) {
-                std::vector<T> v2(n);
-                const T* src = c.data();
-                for (int64_t i = 0; i < n; ++i) v2[i] = src[perm[i]];
-                c.view = nullptr;
-                c.values.swap(v2);
-            }
-        }
-        std::vector<int64_t> off = {0};
-        for (int64_t i = 0; i < n; ++i)
-            if (i == 0 || ikey[i] != ikey[i - 1]) {
-                if (i) off.push_back(i);
-                keys.push_back(ikey[i]);
-            }
-        off.push_back(n);
-        ng = (int64_t)keys.size();
+    if (!any_null) {
+        // keys in any row order: the device brings the frame into key order (radix sort + gather; the weights ride along as
+        // one more column) -- the grouping Polars' group_by does on the host before it calls pl_lr once per group
+        const size_t first = weighted ? 1 : 0;
         std::vector<const T*> ptrs;
-        for (size_t c = 1; c < cols.size(); ++c) ptrs.push_back(cols[c].data());
-        cobuf = raw_buffer<T>((size_t)ng * pp);
-        nulls.resize(ng);
-        check(Api<T>::grouped_weighted(thread_ctx(), ptrs.data(), cols[0].data(), n_feat, n, off.data(), ng, PDS_HOST, &prm,
-                                       as<T>(cobuf), nulls.data()));
-    } else if (!any_null) {
-        // keys in any row order: the device brings the frame into key order (radix sort + gather) -- the grouping Polars'
-        // group_by does on the host before it calls pl_lr once per group
-        if (n == 0) raise("Empty data");
-        std::vector<const T*> ptrs;
-        for (auto& c : cols) ptrs.push_back(c.data());
-        // output capacity: the number of distinct keys is unknown until the device has counted the runs -- start from a
-        // guess (every row its own group is always enough but costs n x p' of host memory) and repeat with the count once
-        int64_t cap = n <= ((int64_t)1 << 20) ? n : std::max<int64_t>((int64_t)1 << 20, n / 16);
-        for (int attempt = 0;; ++attempt) {
-            keys.resize(cap);
-            cobuf = raw_buffer<T>((size_t)cap * pp);
-            nulls.resize(cap);
-            const int rc = Api<T>::by_key(thread_ctx(), ptrs.data(), ikey, n_feat, n, PDS_HOST, &prm, cap, keys.data(), as<T>(cobuf),
-                                          nulls.data(), &ng);
-            if (rc != 0 && attempt == 0 && ng > cap) {
-                cap = ng;
-                continue;
+        for (size_t c = first; c < cols.size(); ++c) ptrs.push_back(cols[c].data());
+        const T* wts = weighted ? cols[0].data() : nullptr;
+        if (want_pred) {
+            pred_b = raw_buffer<T>((size_t)n);
+            resid_b = raw_buffer<T>((size_t)n);
+            row_null.resize(n);
+            check(Api<T>::by_key_pred(thread_ctx(), ptrs.data(), wts, ikey, n_feat, n, PDS_HOST, &prm, n, nullptr, nullptr, nullptr,
+                                      nullptr, as<T>(pred_b), as<T>(resid_b), row_null.data()));
+        } else {
+            // output capacity: the number of distinct keys is unknown until the device has counted the runs -- start from a
+            // guess (every row its own group is always enough but costs n x p' of host memory) and repeat with the count once
+            int64_t cap = n <= ((int64_t)1 << 20) ? n : std::max<int64_t>((int64_t)1 << 20, n / 16);
+            for (int attempt = 0;; ++attempt) {
+                keys.resize(cap);
+                cobuf = raw_buffer<T>((size_t)cap * pp);
+                nulls.resize(cap);
+                const int rc = weighted ? Api<T>::by_key_pred(thread_ctx(), ptrs.data(), wts, ikey, n_feat, n, PDS_HOST, &prm, cap, keys.data(),
+                                                              as<T>(cobuf), nulls.data(), &ng, nullptr, nullptr, nullptr)
+                                        : Api<T>::by_key(thread_ctx(), ptrs.data(), ikey, n_feat, n, PDS_HOST, &prm, cap, keys.data(),
+                                                         as<T>(cobuf), nulls.data(), &ng);
+                if (rc != 0 && attempt == 0 && ng > cap) {
+                    cap = ng;
+                    continue;
+                }
+                check(rc);
+                break;
             }
-            check(rc);
-            break;
+            keys.resize(ng);
+            nulls.resize(ng);
         }
-        keys.resize(ng);
-        nulls.resize(ng);
     } else {
-        if (!ordered) {  // (nulls + unordered keys: stable host sort of the rows, then the bitmap-aware grouped entry point)
+        // rows with nulls: the rows are put into key order on the host (a stable sort of the row indices; the validity bitmaps
+        // travel with their rows), then the bitmap-aware grouped entry point applies the policy inside every group
+        bool ordered = true;
+        for (int64_t i = 1; i < n && ordered; ++i) ordered = ikey[i] >= ikey[i - 1];
+        if (!ordered) {
             std::vector<int64_t> perm(n);
             for (int64_t i = 0; i < n; ++i) perm[i] = i;
             std::stable_sort(perm.begin(), perm.end(), [&](int64_t a, int64_t b) { return ikey[a] < ikey[b]; });
@@ -401,14 +436,29 @@ void do_lr_by(SeriesExport* in, size_t n_in, const Kwargs& kw, SeriesExport* out
         check(Api<T>::grouped_nullable(thread_ctx(), ptrs.data(), bms.data(), offs.data(), n_feat, n, off.data(), ng, PDS_HOST, code,
                                        (T)pol.fill, &prm, as<T>(cobuf), nulls.data()));
     }
+    if (want_pred) {
+        std::vector<uint8_t> valid(n);
+        for (int64_t i = 0; i < n; ++i) valid[i] = row_null[i] ? 0 : 1;
+        std::vector<std::unique_ptr<ArrowArray>> kids;
+        kids.push_back(prim_array_take<T>(std::move(pred_b), n, valid.data()));
+        kids.push_back(prim_array_take<T>(std::move(resid_b), n, valid.data()));
+        std::vector<std::unique_ptr<ArrowSchema>> sk;
+        sk.push_back(make_schema(fmt_of<T>(), "pred"));
+        sk.push_back(make_schema(fmt_of<T>(), "resid"));
+        export_series(out, make_schema("+s", "", std::move(sk)), struct_array(n, std::move(kids)));
+        return;
+    }
     std::vector<uint8_t> ok(ng);
     for (int64_t g = 0; g < ng; ++g) ok[g] = nulls[g] ? 0 : 1;
     std::vector<std::unique_ptr<ArrowArray>> kids;
     {
-        std::vector<ByteVec> bufs;
-        bufs.emplace_back();
-        bufs.push_back(bytes_of(keys.data(), keys.size()));
-        kids.push_back(make_array(ng, 0, std::move(bufs), {false, true}));
+        std::vector<uint8_t> kvalid;
+        if (null_group) {
+            kvalid.assign(ng, 1);
+            for (int64_t g = 0; g < ng; ++g)
+                if (keys[g] == null_stand_in) kvalid[g] = 0;
+        }
+        kids.push_back(prim_array_take<int64_t>(bytes_of(keys.data(), keys.size()), ng, null_group ? kvalid.data() : nullptr));
     }
     kids.push_back(list_array_take_rows<T>(std::move(cobuf), ng, pp, ok.data()));
     std::vector<std::unique_ptr<ArrowSchema>> sk;

@@ -671,6 +671,81 @@ def lin_reg_by_key(*x, target, key, add_bias: bool = False, l1_reg: float = 0.0,
     return ok[:g], coeffs[:g], nulls[:g]
 
 
+def _offsets_arg(cols: "_Cols", group_offsets):
+    if cols.space == _lib.PDS_DEVICE:
+        import torch
+
+        off = group_offsets if _is_torch(group_offsets) else torch.as_tensor(np.asarray(group_offsets))
+        off = off.to(device=cols.keep[0].device, dtype=torch.int64).contiguous()
+        return off, C.c_void_p(int(off.data_ptr()))
+    off = np.ascontiguousarray(np.asarray(group_offsets), dtype=np.int64)
+    return off, C.c_void_p(off.ctypes.data)
+
+
+def lin_reg_by_pred(*x, target, group_offsets, add_bias: bool = False, l1_reg: float = 0.0, l2_reg: float = 0.0, tol: float = 1e-5,
+                    solver: str = "qr", max_iter: int = 200, positive: bool = False, singular_x_tol: float | None = None,
+                    weights=None, ctx: Context | None = None):
+    """
+    `df.group_by(key).agg(pds.lin_reg(..., return_pred=True))` / `pds.lin_reg(..., return_pred=True).over(key)` for contiguous
+    groups (tests/test_linear_exprs.py:435-474): every group is fitted as `lin_reg_by` fits it, then one more pass writes
+    pred = x . beta_group and resid = y - pred for every row.
+    Returns (pred [n_rows], resid [n_rows], row_is_null [n_rows], coeffs [n_groups, p'], group_is_null [n_groups]); rows of a
+    null group (gated, or fewer rows than coefficients) are NaN / flagged -- the reference returns an all-null struct there.
+    """
+    if max_iter <= 0:
+        raise ValueError("Input `max_iter` must be a positive.")
+    ctx = ctx or default_context()
+    cols = _Cols(target, x, weights)
+    _follow(ctx, cols)
+    prm = (_params(add_bias, 0.0, 0.0, tol, solver, False, max_iter, 0.0) if weights is not None
+           else _params(add_bias, l1_reg, l2_reg, tol, solver, positive, max_iter, singular_x_tol))
+    pp = cols.n_feat + int(bool(add_bias))
+    off, off_p = _offsets_arg(cols, group_offsets)
+    ng = int(off.shape[0]) - 1
+    coeffs, co_p = _out_like(cols, (ng, pp))
+    nulls, nu_p = _out_u8(cols, ng)
+    pred, pr_p = _out_like(cols, cols.n_rows)
+    resid, re_p = _out_like(cols, cols.n_rows)
+    rnull, rn_p = _out_u8(cols, cols.n_rows)
+    _lib.check(ctx.fn("pds_lr_grouped_pred")(ctx._h, cols.cols, cols.weights, cols.n_feat, C.c_int64(cols.n_rows), off_p, C.c_int64(ng),
+                                             cols.space, C.byref(prm), co_p, nu_p, pr_p, re_p, rn_p))
+    return pred, resid, rnull, coeffs, nulls
+
+
+def lin_reg_by_key_pred(*x, target, key, add_bias: bool = False, l1_reg: float = 0.0, l2_reg: float = 0.0, tol: float = 1e-5,
+                        solver: str = "qr", max_iter: int = 200, positive: bool = False, singular_x_tol: float | None = None,
+                        weights=None, ctx: Context | None = None):
+    """
+    The same for an integer key column in ANY row order: pred / resid come back in the FRAME's row order (the device orders the
+    frame by key, fits, and sends every row's prediction back to where the row is).  Returns (pred, resid, row_is_null).
+    """
+    if max_iter <= 0:
+        raise ValueError("Input `max_iter` must be a positive.")
+    ctx = ctx or default_context()
+    cols = _Cols(target, x, weights)
+    _follow(ctx, cols)
+    prm = (_params(add_bias, 0.0, 0.0, tol, solver, False, max_iter, 0.0) if weights is not None
+           else _params(add_bias, l1_reg, l2_reg, tol, solver, positive, max_iter, singular_x_tol))
+    n_rows = cols.n_rows
+    if cols.space == _lib.PDS_DEVICE:
+        import torch
+
+        k = key if _is_torch(key) else torch.as_tensor(np.asarray(key))
+        k = k.to(device=cols.keep[0].device, dtype=torch.int64).contiguous()
+        k_p = C.c_void_p(int(k.data_ptr()))
+    else:
+        k = np.ascontiguousarray(np.asarray(key), dtype=np.int64)
+        k_p = C.c_void_p(k.ctypes.data)
+    if int(k.shape[0]) != n_rows:
+        raise ValueError("`key` must have one entry per row")
+    pred, pr_p = _out_like(cols, n_rows)
+    resid, re_p = _out_like(cols, n_rows)
+    rnull, rn_p = _out_u8(cols, n_rows)
+    _lib.check(ctx.fn("pds_lr_by_key_pred")(ctx._h, cols.cols, cols.weights, k_p, cols.n_feat, C.c_int64(n_rows), cols.space,
+                                            C.byref(prm), C.c_int64(n_rows), None, None, None, None, pr_p, re_p, rn_p))
+    return pred, resid, rnull
+
+
 def _windowed(name, x, target, n, add_bias, l2_reg, min_size, ctx, seed_moments=None):
     ctx = ctx or default_context()
     cols = _Cols(target, x)

@@ -76,28 +76,80 @@ def lin_reg(*x, target, add_bias: bool = False, weights=None, return_pred: bool 
               "max_iter": max_iter, "weighted": weighted, "positive": positive, "singular_x_tol": singular_x_tol}
     dt = _dtype()
     cols = ([_formula(weights).cast(dt).rechunk()] if weighted else []) + [_formula(target).cast(dt)] + [_formula(z) for z in x]
-    if by is not None:  # one call computes every group: Struct{key, coeffs}, one row per (contiguous) group
+    if by is not None:  # one call computes every group (integer key column, any row order, nulls = one group)
         if return_pred:
-            raise ValueError("`by` returns coefficients (one row per group)")
+            # Struct{pred, resid}, one row per input row in the frame's own order: what `.over(by)` / `group_by(by).agg(...)`
+            # of `lin_reg(..., return_pred=True)` give per group (tests/test_linear_exprs.py:435-474)
+            return _plugin("pl_lr_by_pred", [_formula(by), *cols], kwargs).alias("lr_pred")
+        # Struct{key, coeffs}, one row per group, keys ascending
         return _plugin("pl_lr_by", [_formula(by), *cols], kwargs, changes_length=True).alias("coeffs_by")
     if return_pred:
         return _plugin("pl_lr_pred", cols, kwargs).alias("lr_pred")
     return _plugin("pl_lr", cols, kwargs, returns_scalar=True).alias("coeffs")
 
 
-def lin_reg_by_group(df, by: str, *x, target, **kwargs):
+_GID = "__pds_gid"
+
+
+def _is_integer_key(df, by) -> bool:
+    if not isinstance(by, str):
+        return False
+    try:
+        return bool(df.schema[by].is_integer())
+    except Exception:
+        return False
+
+
+def _join(left, right, on, how="left"):
+    """null keys must meet null keys (Polars' group_by makes them one group): `nulls_equal` (polars >= 1.24), `join_nulls` before"""
+    try:
+        return left.join(right, on=on, how=how, nulls_equal=True)
+    except TypeError:
+        return left.join(right, on=on, how=how, join_nulls=True)
+
+
+def _with_group_ids(df, by):
+    """
+    Keys of any dtype (strings, dates, several columns, nulls) -> one dense integer id per row: the distinct key rows in order of
+    first appearance get ids 0, 1, ... (`unique(maintain_order=True).with_row_index`), joined back onto the frame.  Returns
+    (frame with the id column `__pds_gid`, the key table [id, *by]).  A single integer key column does not need this.
+    """
+    cols = [by] if isinstance(by, str) else list(by)
+    keys = df.select(cols).unique(maintain_order=True).with_row_index(_GID)
+    return _join(df, keys, on=cols), keys
+
+
+def lin_reg_by_group(df, by, *x, target, return_pred: bool = False, **kwargs):
     """
     The replacement for `df.group_by(by).agg(pds.lin_reg(*x, target=...))` on this backend: ONE plugin call over the whole
     frame (`pl_lr_by`: keys in any row order, one fused kernel for every group) instead of one `pl_lr` call per group.
     An expression cannot know that it sits inside a `group_by` -- Polars hands the plugin one group's rows at a time, which
     costs a host-to-device round trip per group and runs BELOW the CPU reference (the coalescing queue of csrc/plugin.cpp
-    only softens that) -- so the rewrite is explicit.  Returns a frame with one row per distinct key, keys
-    ascending: columns `by` and `coeffs` (a null list where the reference's per-group call returns a null list).
+    only softens that) -- so the rewrite is explicit.
+    `by`: one key column of any dtype or a list of key columns; null keys form one group, as in Polars.
+    Returns a frame with one row per distinct key: columns *by and `coeffs` (a null list where the reference's per-group call
+    returns a null list); integer keys come back ascending, other keys in order of first appearance.
+    `return_pred=True` (tests/test_linear_exprs.py:435-474): the input frame with `pred` and `resid` columns, row for row.
     """
-    if kwargs.get("return_pred"):
-        raise ValueError("lin_reg_by_group returns coefficients (one row per group)")
-    out = df.select(lin_reg(*x, target=target, by=by, **kwargs)).unnest("coeffs_by")
-    return out
+    if return_pred:
+        if _is_integer_key(df, by):
+            return df.with_columns(lin_reg(*x, target=target, by=by, return_pred=True, **kwargs)).unnest("lr_pred")
+        ids, _ = _with_group_ids(df, by)
+        return ids.with_columns(lin_reg(*x, target=target, by=_GID, return_pred=True, **kwargs)).unnest("lr_pred").drop(_GID)
+    if _is_integer_key(df, by):
+        return df.select(lin_reg(*x, target=target, by=by, **kwargs)).unnest("coeffs_by")
+    ids, keys = _with_group_ids(df, by)
+    res = ids.select(lin_reg(*x, target=target, by=_GID, **kwargs)).unnest("coeffs_by")
+    return _join(keys, res, on=[_GID]).drop(_GID)
+
+
+def lin_reg_over(df, by, *x, target, **kwargs):
+    """
+    `df.with_columns(pds.lin_reg(*x, target=...).over(by))` (examples/basics.ipynb cells 16 / 18): every row carries its group's
+    coefficient list.  One `pl_lr_by` call, then the per-group lists are joined back onto the frame.
+    """
+    cols = [by] if isinstance(by, str) else list(by)
+    return _join(df, lin_reg_by_group(df, by, *x, target=target, **kwargs), on=cols)
 
 
 def lin_reg_w_rcond(*x, target, add_bias: bool = False, rcond: float = 0.0, l2_reg: float = 0.0, null_policy: str = "raise"):

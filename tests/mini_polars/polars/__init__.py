@@ -9,7 +9,8 @@ What it implements is the calling convention Polars documents for expression plu
   * `polars.plugins.register_plugin_function(plugin_path=..., function_name=..., args=..., kwargs=...)` -> an expression
     that, when evaluated, dlopens `plugin_path`, exports every input as a Series over the Arrow C Data Interface, pickles
     the kwargs with protocol 5 and calls `_polars_plugin_<function_name>` (tests/plugin_harness.py);
-  * `DataFrame.select / with_columns / unnest`, and `DataFrame.group_by(key).agg(expr)`, which -- like Polars -- evaluates
+  * `DataFrame.select / with_columns / unnest / drop / unique(maintain_order) / with_row_index / join(on, how="left") / schema`,
+    the frame verbs `polars_exprs.lin_reg_by_group` / `lin_reg_over` use around the key-aware plugin call; and `DataFrame.group_by(key).agg(expr)`, which -- like Polars -- evaluates
     the expression ONCE PER GROUP on the group's rows, from a pool of worker threads (the call pattern behind
     `df.group_by(k).agg(pds.lin_reg(...))`, tests/test_linear_exprs.py:918-953 of the reference).
 It is NOT a claim that the plugin has run inside a real Polars (still unverified).
@@ -38,6 +39,9 @@ class _DType:
 
     def __repr__(self):
         return self.name
+
+    def is_integer(self):
+        return self.pa is not None and pa.types.is_integer(self.pa)
 
 
 Float64 = _DType("Float64", pa.float64())
@@ -283,6 +287,7 @@ class DataFrame:
 
     def select(self, *exprs):
         out = {}
+        exprs = [x for e in exprs for x in (e if isinstance(e, (list, tuple)) else [e])]  # select(["a", "b"]) like Polars
         for e in exprs:
             e = col(e) if isinstance(e, str) else e
             n, a = e._eval(self.cols)
@@ -317,3 +322,46 @@ class DataFrame:
 
     def to_dict(self):
         return {k: v.to_pylist() for k, v in self.cols.items()}
+
+    @property
+    def schema(self):
+        return {k: _DType(str(_combine(v).type), _combine(v).type) for k, v in self.cols.items()}
+
+    def drop(self, *names):
+        names = set(n for a in names for n in ([a] if isinstance(a, str) else a))
+        return DataFrame({k: v for k, v in self.cols.items() if k not in names})
+
+    def _key_rows(self, names):
+        lists = [_combine(self.cols[n]).to_pylist() for n in names]
+        return list(zip(*lists))
+
+    def unique(self, maintain_order=False):
+        rows = self._key_rows(self.columns)
+        seen, keep = set(), []
+        for i, r in enumerate(rows):
+            if r not in seen:
+                seen.add(r)
+                keep.append(i)
+        idx = pa.array(np.array(keep, dtype=np.int64))
+        return DataFrame({k: _combine(v).take(idx) for k, v in self.cols.items()})
+
+    def with_row_index(self, name="index"):
+        out = {name: pa.array(np.arange(len(self), dtype=np.uint32))}
+        out.update(self.cols)
+        return DataFrame(out)
+
+    def join(self, other, on, how="left", nulls_equal=False, join_nulls=False):
+        assert how == "left", "mini_polars: left joins only"
+        on = [on] if isinstance(on, str) else list(on)
+        match_nulls = nulls_equal or join_nulls
+        table = {}
+        for j, r in enumerate(other._key_rows(on)):
+            if match_nulls or all(v is not None for v in r):
+                table.setdefault(r, j)
+        idx = [table.get(r) if (match_nulls or all(v is not None for v in r)) else None for r in self._key_rows(on)]
+        take = pa.array(idx, type=pa.int64())
+        out = dict(self.cols)
+        for k, v in other.cols.items():
+            if k not in on:
+                out[k] = _combine(v).take(take)
+        return DataFrame(out)

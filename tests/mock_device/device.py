@@ -305,6 +305,80 @@ def make_callbacks(sfx):
         _view(out_keys_p, ng, np.int64)[:] = uniq
         return grouped_core(cols, np.concatenate([start, [n]]).astype(np.int64), _prm(prm_p), coeffs_p, null_p)
 
+    def pred_rows(cols, off, bias, co, nu, order, pred_p, resid_p, rn_p):
+        """pred / resid / row_null of the rows of `cols` (group order); `order` (sorted position -> frame row) or None"""
+        n = len(cols[0])
+        X = X_of(cols)
+        Xb = orc.with_bias(X) if bias else X
+        gid = np.repeat(np.arange(len(off) - 1), np.diff(off))
+        with np.errstate(invalid="ignore"):
+            pr = np.einsum("ij,ij->i", np.asarray(Xb, dtype=np.float64), np.asarray(co, dtype=np.float64)[gid]).astype(dt)
+        rn = np.asarray(nu, dtype=bool)[gid]
+        pr[rn] = np.nan
+        re = (np.asarray(cols[0], dtype=np.float64) - pr.astype(np.float64)).astype(dt)
+        dst = np.arange(n) if order is None else order
+        if pred_p:
+            _view(pred_p, n, dt)[dst] = pr
+        if resid_p:
+            _view(resid_p, n, dt)[dst] = re
+        if rn_p:
+            _view(rn_p, n, np.uint8)[dst] = rn
+
+    def _own(ptr, count, dtype):
+        """the caller's buffer, or scratch of the same shape when the caller passed NULL"""
+        arr = np.empty(count, dtype=dtype)
+        return (ptr, None) if ptr else (arr.ctypes.data, arr)
+
+    def grouped_pred(ctx, cols_p, w_p, n_feat, n, off_p, ng, space, prm_p, coeffs_p, null_p, pred_p, resid_p, rn_p):
+        if ng <= 0 or n <= 0:
+            raise MockError(EMPTY, "Empty data")
+        if not (pred_p or resid_p or rn_p):
+            raise MockError(INVALID, "pds_lr_grouped_pred: no per-row output requested")
+        prm = _prm(prm_p)
+        pp = n_feat + prm["add_bias"]
+        cols = _columns(cols_p, n_feat + 1, n, dt)
+        off = _view(off_p, ng + 1, np.int64)
+        cp, keep1 = _own(coeffs_p, ng * pp, dt)
+        npn, keep2 = _own(null_p, ng, np.uint8)
+        if w_p:
+            prm = dict(prm, l1_reg=0.0, l2_reg=0.0, positive=0, singular_x_tol=0.0)
+        grouped_core(cols, off, prm, cp, npn, weights=_view(w_p, n, dt) if w_p else None)
+        pred_rows(cols, off, prm["add_bias"], _view(cp, ng * pp, dt).reshape(ng, pp), _view(npn, ng, np.uint8), None, pred_p, resid_p, rn_p)
+        return OK
+
+    def by_key_pred(ctx, cols_p, w_p, keys_p, n_feat, n, space, prm_p, max_groups, out_keys_p, coeffs_p, null_p, ng_p, pred_p, resid_p,
+                    rn_p):
+        if n <= 0:
+            raise MockError(EMPTY, "Empty data")
+        want_coef = bool(out_keys_p or coeffs_p)
+        if not want_coef:
+            max_groups = n
+        if max_groups < 1:
+            raise MockError(INVALID, "max_groups must be positive")
+        prm = _prm(prm_p)
+        pp = n_feat + prm["add_bias"]
+        keys = _view(keys_p, n, np.int64)
+        order = np.argsort(keys, kind="stable")
+        uniq, start = np.unique(keys[order], return_index=True)
+        ng = len(uniq)
+        if ng_p:
+            C.c_int64.from_address(ng_p).value = ng
+        if ng > max_groups:
+            raise MockError(INVALID, "more distinct keys than max_groups")
+        cols = [c[order] for c in _columns(cols_p, n_feat + 1, n, dt)]
+        off = np.concatenate([start, [n]]).astype(np.int64)
+        if out_keys_p:
+            _view(out_keys_p, ng, np.int64)[:] = uniq
+        cp, keep1 = _own(coeffs_p, ng * pp, dt)
+        npn, keep2 = _own(null_p, ng, np.uint8)
+        if w_p:
+            prm = dict(prm, l1_reg=0.0, l2_reg=0.0, positive=0, singular_x_tol=0.0)
+        grouped_core(cols, off, prm, cp, npn, weights=_view(w_p, n, dt)[order] if w_p else None)
+        if pred_p or resid_p or rn_p:
+            pred_rows(cols, off, prm["add_bias"], _view(cp, ng * pp, dt).reshape(ng, pp), _view(npn, ng, np.uint8), order, pred_p, resid_p,
+                      rn_p)
+        return OK
+
     def windowed(cols, n_feat, n, bias, lam, coeffs_p, pred_p, valid_p, first_valid, rows):
         """rows: (coefficient rows for output rows first_valid.., validity of those rows)"""
         pp = n_feat + int(bool(bias))
@@ -421,7 +495,8 @@ def make_callbacks(sfx):
     return {f"pds_glm_irls_{sfx}": glm_irls, f"pds_lr_with_inv_{sfx}": with_inv, f"pds_moments_{sfx}": moments, f"pds_lr_from_moments_{sfx}": from_moments, f"pds_lr_{sfx}": lr, f"pds_lr_pred_{sfx}": lr_pred, f"pds_lr_nullable_{sfx}": lr_nullable, f"pds_lr_multi_{sfx}": multi,
             f"pds_lr_rcond_{sfx}": rcond, f"pds_elastic_net_{sfx}": elastic_net, f"pds_lin_reg_report_{sfx}": report, f"pds_lin_reg_report_nullable_{sfx}": report_nullable,
             f"pds_lr_grouped_{sfx}": grouped, f"pds_lr_grouped_weighted_{sfx}": grouped_weighted,
-            f"pds_lr_grouped_nullable_{sfx}": grouped_nullable, f"pds_lr_by_key_{sfx}": by_key, f"pds_rolling_lr_{sfx}": rolling,
+            f"pds_lr_grouped_nullable_{sfx}": grouped_nullable, f"pds_lr_by_key_{sfx}": by_key, f"pds_lr_grouped_pred_{sfx}": grouped_pred,
+            f"pds_lr_by_key_pred_{sfx}": by_key_pred, f"pds_rolling_lr_{sfx}": rolling,
             f"pds_recursive_lr_{sfx}": recursive}
 
 

@@ -39,6 +39,50 @@ def _rowrel(a, b):
     return np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64), axis=1) / np.linalg.norm(np.asarray(b, np.float64), axis=1)
 
 
+# ------------------------------------------------------------------------------------------ the headline config of bench.py
+def test_headline_config_against_oracle(pds, orc):
+    """
+    BASELINE.json's metric config, exactly as bench.py times it: group_by(key).agg(lin_reg) on 1e6 groups x 100 rows x 16 f64
+    features (1e8 rows, the frame of tools/synth.headline_frame with bench.py's seed).  The HIP path fits all 1e6 groups; 2e5
+    of them -- the first 1e5, 5e4 from the middle, the last 5e4 -- are brought to the host and fitted by the oracle's
+    per-group gated col-piv QR: null flags equal, every group's coefficients within 1e-10 normwise.
+    """
+    import torch
+
+    import synth
+
+    G, R, P = 1_000_000, 100, 16
+    xs, y = synth.headline_frame(G, R, P, seed=1234)
+    off = torch.arange(0, G * R + 1, R, dtype=torch.int64, device="cuda")
+    co, nu = pds.lin_reg_by(*xs, target=y, group_offsets=off, add_bias=False)
+    assert co.shape == (G, P) and int(nu.sum().item()) == 0
+    worst, checked = 0.0, 0
+    for g0, g1 in ((0, 100_000), (475_000, 525_000), (950_000, 1_000_000)):
+        r0, r1 = g0 * R, g1 * R
+        host = [y[r0:r1].cpu().numpy()] + [x[r0:r1].cpu().numpy() for x in xs]
+        off_h = np.arange(0, (g1 - g0) * R + 1, R, dtype=np.int64)
+        co_o, nu_o = orc.grouped_lr(host, off_h, add_bias=False, tol=1e-12, nthreads=_threads(orc))
+        assert np.array_equal(nu[g0:g1].cpu().numpy().astype(bool), nu_o) and not nu_o.any()
+        err = _rowrel(co[g0:g1].cpu().numpy(), co_o)
+        worst = max(worst, float(err.max()))
+        checked += g1 - g0
+    print(f"headline 1e6 x 100 x 16: {checked} groups vs oracle, max normwise rel {worst:.2e}")
+    assert checked == 200_000 and worst < F64_TOL
+    # the same frame as ONE regression (configs[1]'s Gram build): moment matrix of a 1e7-row prefix against the oracle's
+    # blocked Gram, and of the whole frame against an f64 torch reduction of sampled entries
+    n_s = 10_000_000
+    M = pds.gram_moments(*[x[:n_s] for x in xs], target=y[:n_s])
+    Zs = [x[:n_s].cpu().numpy() for x in xs] + [np.ones(n_s), y[:n_s].cpu().numpy()]
+    ref = orc.gram_cols(Zs, nthreads=_threads(orc))
+    assert np.linalg.norm(M - ref) / np.linalg.norm(ref) < 1e-13
+    Mf = pds.gram_moments(*xs, target=y)
+    for i, j in ((0, 0), (3, 11), (15, 17), (7, 16), (17, 17)):
+        zi = xs[i] if i < P else (torch.ones_like(y) if i == P else y)
+        zj = xs[j] if j < P else (torch.ones_like(y) if j == P else y)
+        want = float(torch.dot(zi, zj).item())
+        assert abs(Mf[i, j] - want) <= 1e-11 * max(abs(want), float(torch.linalg.vector_norm(zi).item() * torch.linalg.vector_norm(zj).item()))
+
+
 # ------------------------------------------------------------------------------------------ configs[2]: grouped, 8(d) C3 spec
 def test_c3_spec_sorted_and_shuffled_keys_against_oracle(pds, orc):
     """
@@ -143,7 +187,10 @@ def test_c2_prefix_against_oracle(pds, orc):
     dp_bound = 2.0 * stats.t.pdf(np.abs(ro["t"]), dof) * dt_bound + 1e-14 * ro["p"]
     assert np.all(np.abs(r["p>|t|"] - ro["p"]) <= dp_bound)
     assert np.sum((ro["p"] > 1e-3) & (ro["p"] < 0.999)) >= 2  # the two zero coefficients give non-trivial p-values
-    assert np.max(np.abs(r["0.025"] - ro["ci_lo"]) / np.maximum(np.abs(ro["ci_lo"]), 1e-3)) < 1e-9
+    # CI ends beta_i -+ t_crit se_i: 1e-10 (|beta| + t_crit se_i), the same propagation
+    t_crit = float(orc.student_t_ppf(0.975, float(dof))) if dof < 1.4e7 else float(stats.t.ppf(0.975, dof))
+    ci_bound = F64_TOL * (np.linalg.norm(ro["beta"]) + t_crit * ro["std_err"])
+    assert np.all(np.abs(r["0.025"] - ro["ci_lo"]) <= ci_bound) and np.all(np.abs(r["0.975"] - ro["ci_hi"]) <= ci_bound)
     assert abs(np.ravel(r["r2"])[0] - ro["r2"]) < 1e-12
 
 
@@ -192,3 +239,69 @@ def test_c5_one_million_rows_against_oracle_f32_and_f64(pds, orc):
         assert d_gpu <= (max(d_orc, 2e-6) if native == "1" else 1e-5)
         assert np.array_equal(np.abs(bb) > 1e-6, np.abs(truth) > 1e-6)  # same support
     assert np.array_equal(np.abs(b) > 1e-6, np.abs(truth) > 1e-6)  # same support
+
+
+def test_c5_configured_size_gram_and_descent(pds, orc):
+    """
+    configs[4] at its configured size, 1e7 rows x 512 f32 features (20.5 GB).  A CPU fit of the whole frame is minutes, so the
+    two stages are held separately, each against an independent reference, for BOTH f32 Gram arithmetics:
+      Gram      the library's f32 moment matrix against an f64 Gram of the same f32 data formed by torch (hipBLAS dgemm over
+                1e6-row chunks): whole matrix, Frobenius; plus the column-sum / X'y / y'y borders;
+      descent   the library's coefficients against the ORACLE's coordinate descent (orc_cd_from_gram, the restatement of
+                lr_solvers.rs:426-538) run on the library's own Gram matrix -- the sweep order, soft threshold and stopping rule
+                at p = 512 -- and against the f64 truth (oracle descent on the f64 Gram, tol 1e-9): 1e-4, same support.
+    """
+    import os
+
+    import torch
+
+    import synth
+
+    n, p = 10_000_000, 512
+    fr = synth.c5_frame(n, p, seed=4)
+    X, y = fr["X"], fr["y"]
+    # ---- f64 reference moments of the f32 data
+    G64 = torch.zeros(p, p, dtype=torch.float64, device="cuda")
+    c64 = torch.zeros(p, dtype=torch.float64, device="cuda")
+    cs64 = torch.zeros(p, dtype=torch.float64, device="cuda")
+    for r0 in range(0, n, 1_000_000):
+        Xc = X[:, r0: r0 + 1_000_000].double()
+        yc = y[r0: r0 + 1_000_000].double()
+        G64.addmm_(Xc, Xc.T)
+        c64.add_(Xc @ yc)
+        cs64.add_(Xc.sum(dim=1))
+        del Xc, yc
+    ysum = float(y.double().sum().item())
+    yy = float((y.double() ** 2).sum().item())
+    G64h, c64h, cs64h = G64.cpu().numpy(), c64.cpu().numpy(), cs64.cpu().numpy()
+    truth, _, conv = orc.cd_from_gram(G64h, c64h, cs64h, ysum, float(n), 0.01, 0.01, False, 1e-9, 5000)
+    assert conv
+    nrm = np.linalg.norm(truth)
+    cols = [X[j] for j in range(p)]
+    pds.config.LIN_REG_EXPR_F64 = False
+    try:
+        for native in ("0", "1"):
+            os.environ["PDS_WIDE_F32_NATIVE"] = native
+            name = "f32 matrix cores" if native == "1" else "bf16 x 3 split"
+            M = np.asarray(pds.gram_moments(*cols, target=y), dtype=np.float64)  # Z'Z, Z = [X | 1 | y]
+            assert M.shape == (p + 2, p + 2)
+            d_g = np.linalg.norm(M[:p, :p] - G64h) / np.linalg.norm(G64h)
+            d_c = np.linalg.norm(M[:p, p + 1] - c64h) / np.linalg.norm(c64h)
+            d_s = np.linalg.norm(M[:p, p] - cs64h) / max(np.linalg.norm(cs64h), np.sqrt(n * p))  # (sums of N(0,1) columns: O(sqrt n))
+            print(f"C5 1e7 x 512 Gram ({name}): X'X {d_g:.2e}  X'y {d_c:.2e}  col sums {d_s:.2e}")
+            assert d_g < (1e-6 if native == "0" else 5e-7) and d_c < 2e-6 and d_s < 1e-4
+            assert abs(M[p, p] - n) < 0.5 and abs(M[p + 1, p + 1] - yy) / yy < 1e-6 and abs(M[p, p + 1] - ysum) <= 1e-6 * np.sqrt(n * yy / n)
+            b = pds.lin_reg(*cols, target=y, l1_reg=0.01, l2_reg=0.01, tol=1e-5)
+            assert b.dtype == np.float32 and b.shape == (p,)
+            # the oracle's descent on the library's own Gram matrix (f64 arithmetic on f32-rounded moments; 2000 sweeps = the f32 cap)
+            bo, _, _ = orc.cd_from_gram(M[:p, :p].copy(), M[:p, p + 1].copy(), M[:p, p].copy(), float(M[p, p + 1]), float(n), 0.01, 0.01,
+                                        False, 1e-5, 2000)
+            d_cd = np.linalg.norm(b - bo) / np.linalg.norm(bo)
+            d_tr = np.linalg.norm(b - truth) / nrm
+            print(f"C5 1e7 x 512 descent ({name}): gpu - oracle CD on the same Gram {d_cd:.2e}; gpu - f64 truth {d_tr:.2e}; "
+                  f"non-zeros {int((np.abs(b) > 1e-6).sum())}")
+            assert d_cd < F32_TOL and d_tr < F32_TOL
+            assert np.array_equal(np.abs(b) > 1e-6, np.abs(truth) > 1e-6)
+    finally:
+        pds.config.LIN_REG_EXPR_F64 = True
+        os.environ.pop("PDS_WIDE_F32_NATIVE", None)

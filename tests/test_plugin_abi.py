@@ -17,7 +17,8 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "tests"))
 import plugin_harness as ph  # noqa: E402
 
-SYMBOLS = ["pl_lr", "pl_lr_pred", "pl_lin_reg_report", "pl_wls_report", "pl_rolling_lr", "pl_recursive_lr", "pl_lr_by", "pl_lr_multi", "pl_lr_multi_pred"]
+SYMBOLS = ["pl_lr", "pl_lr_pred", "pl_lin_reg_report", "pl_wls_report", "pl_rolling_lr", "pl_recursive_lr", "pl_lr_by", "pl_lr_by_pred", "pl_lr_multi",
+           "pl_lr_multi_pred"]
 # every `#[polars_expr] fn` of /root/reference/src/num_ext/linear_regression.rs (:419,517,587,651,704,822,982,1121,1206) and of
 # linear_regression_f32.rs (:289,386,456,515,568,687,846,986,1072) -- the names `polars_ds.exprs.expr_linear` registers
 REFERENCE_EXPRS = ["pl_lr", "pl_lr_multi", "pl_lr_multi_pred", "pl_lr_w_rcond", "pl_lr_pred", "pl_lin_reg_report", "pl_wls_report",
@@ -544,6 +545,112 @@ def test_pl_lr_by_keys_in_any_row_order(so, orc):
 
 
 @pytest.mark.gpu
+def test_pl_lr_by_pred_is_the_reference_group_by_test(so, orc):
+    """/root/reference/tests/test_linear_exprs.py:435-474 (test_lin_reg_in_group_by): group_by("A").agg(lin_reg(..., return_pred=True))
+    equals the per-group `pl_lr_pred` results -- here ONE `pl_lr_by_pred` call over the frame, rows in frame order."""
+    A = np.array([1] * 4 + [2] * 4, dtype=np.int64)
+    Y = np.ones(8)
+    X1 = np.array([1, 2, 3, 4, 5, 6, 7, 8], dtype=np.float64)
+    X2 = np.array([2, 3, 4, 1, 6, 7, 8, 5], dtype=np.float64)
+    kw = dict(LR, bias=False)
+    ins = [("A", pa.array(A)), ("Y", pa.array(Y)), ("X1", pa.array(X1)), ("X2", pa.array(X2))]
+    field, out = ph.call_plugin(so, "pl_lr_by_pred", ins, kw)
+    assert len(out) == 8 and [f.name for f in out.type] == ["pred", "resid"]
+    got = out.to_pylist()
+    for a in (1, 2):
+        m = A == a
+        _, single = ph.call_plugin(so, "pl_lr_pred", [("Y", pa.array(Y[m])), ("X1", pa.array(X1[m])), ("X2", pa.array(X2[m]))], kw)
+        want = single.to_pylist()
+        for r, w in zip([g for g, k in zip(got, m) if k], want):
+            assert abs(r["pred"] - w["pred"]) < 1e-10 and abs(r["resid"] - w["resid"]) < 1e-10
+    # the oracle, per group
+    X = np.c_[X1, X2]
+    for a in (1, 2):
+        m = A == a
+        b = orc.pl_lr(X[m], Y[m])
+        np.testing.assert_allclose([g["pred"] for g, k in zip(got, m) if k], X[m] @ b, rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_pl_lr_by_pred_shuffled_rows_weights_bias_and_null_groups(so, orc):
+    """Rows in any order: every row gets ITS group's prediction where the row is (the `.over(key)` broadcast of
+    examples/basics.ipynb cells 16 / 18); a collinear group is null for all of its rows (linear_regression.rs:745-750); weights."""
+    rng = np.random.default_rng(31)
+    G, per = 120, 35
+    key = np.repeat(rng.permutation(G) * 5 - 100, per).astype(np.int64)
+    X = rng.normal(size=(G * per, 3))
+    bad = key == key[7 * per]
+    X[bad, 1] = 2.0 * X[bad, 0]  # one collinear group -> the rank gate fires
+    y = X @ [0.5, -1.5, 2.0] + 0.2 * rng.normal(size=G * per) + key * 0.01
+    perm = rng.permutation(G * per)
+    kp, Xp, yp = key[perm], X[perm], y[perm]
+    _, out = ph.call_plugin(so, "pl_lr_by_pred", [("key", pa.array(kp))] + _cols(Xp, yp), dict(LR, bias=True))
+    assert len(out) == G * per
+    pred = np.array([np.nan if v is None else v for v in out.field("pred").to_pylist()])
+    resid = np.array([np.nan if v is None else v for v in out.field("resid").to_pylist()])
+    assert out.field("pred").null_count == per and out.field("resid").null_count == per
+    assert np.isnan(pred[kp == key[7 * per]]).all()
+    for k in np.unique(key)[::11]:
+        m = kp == k
+        if k == key[7 * per]:
+            continue
+        b = orc.pl_lr(Xp[m], yp[m], add_bias=True)
+        want = Xp[m] @ b[:3] + b[3]
+        np.testing.assert_allclose(pred[m], want, rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(resid[m], yp[m] - want, rtol=0, atol=1e-9)
+    # weights ([key, w, y, x...], kwargs.weighted): per key the weighted fit, predictions from the unweighted rows
+    w = rng.random(G * per) + 0.2
+    ins_w = [("key", pa.array(kp)), ("w", pa.array(w))] + _cols(Xp, yp)
+    _, out = ph.call_plugin(so, "pl_lr_by_pred", ins_w, dict(LR, bias=True, weighted=True))
+    pred_w = np.array([np.nan if v is None else v for v in out.field("pred").to_pylist()])
+    for k in np.unique(key)[::13]:
+        m = kp == k
+        if k == key[7 * per]:
+            continue
+        b = orc.pl_lr(Xp[m], yp[m], add_bias=True, weights=w[m])
+        np.testing.assert_allclose(pred_w[m], Xp[m] @ b[:3] + b[3], rtol=1e-9, atol=1e-11)
+    # ordered keys take the no-movement route and must agree with the shuffled call row by row
+    order = np.argsort(kp, kind="stable")
+    _, out2 = ph.call_plugin(so, "pl_lr_by_pred", [("key", pa.array(kp[order]))] + _cols(Xp[order], yp[order]), dict(LR, bias=True))
+    pred2 = np.array([np.nan if v is None else v for v in out2.field("pred").to_pylist()])
+    ok = ~np.isnan(pred[order])
+    np.testing.assert_allclose(pred2[ok], pred[order][ok], rtol=1e-10, atol=1e-12)
+    # rows with nulls are refused with a message (not silently mis-grouped)
+    ins_n = [("key", pa.array(kp)), ("y", pa.array(yp)), ("x1", pa.array(Xp[:, 0], mask=rng.random(G * per) < 0.1))] + [
+        (f"x{j + 1}", pa.array(Xp[:, j])) for j in (1, 2)]
+    with pytest.raises(RuntimeError, match="nulls"):
+        ph.call_plugin(so, "pl_lr_by_pred", ins_n, dict(LR, bias=True, null_policy="skip"))
+
+
+@pytest.mark.gpu
+def test_pl_lr_by_null_keys_form_one_group(so, orc):
+    """Polars' group_by makes the null keys one group: pl_lr_by reports it with a null key, pl_lr_by_pred predicts its rows."""
+    rng = np.random.default_rng(77)
+    n = 600
+    key = rng.integers(0, 5, size=n).astype(np.int64)
+    isnull = rng.random(n) < 0.2
+    X = rng.normal(size=(n, 2))
+    y = X @ [1.0, -2.0] + 0.1 * rng.normal(size=n) + np.where(isnull, 3.0, key * 0.5)
+    karr = pa.array(key, mask=isnull)
+    _, out = ph.call_plugin(so, "pl_lr_by", [("key", karr)] + _cols(X, y), dict(LR, bias=True))
+    res = out.to_pylist()
+    assert [r["key"] for r in res] == [0, 1, 2, 3, 4, None]
+    np.testing.assert_allclose(res[-1]["coeffs"], orc.pl_lr(X[isnull], y[isnull], add_bias=True), rtol=1e-9, atol=1e-11)
+    for r in res[:-1]:
+        m = (key == r["key"]) & ~isnull
+        np.testing.assert_allclose(r["coeffs"], orc.pl_lr(X[m], y[m], add_bias=True), rtol=1e-9, atol=1e-11)
+    _, outp = ph.call_plugin(so, "pl_lr_by_pred", [("key", karr)] + _cols(X, y), dict(LR, bias=True))
+    pred = np.array(outp.field("pred").to_pylist(), dtype=np.float64)
+    b = orc.pl_lr(X[isnull], y[isnull], add_bias=True)
+    np.testing.assert_allclose(pred[isnull], X[isnull] @ b[:2] + b[2], rtol=1e-9, atol=1e-11)
+    # all keys null: one group, null key
+    _, out = ph.call_plugin(so, "pl_lr_by", [("key", pa.array(key, mask=np.ones(n, dtype=bool)))] + _cols(X, y), dict(LR, bias=True))
+    res = out.to_pylist()
+    assert len(res) == 1 and res[0]["key"] is None
+    np.testing.assert_allclose(res[0]["coeffs"], orc.pl_lr(X, y, add_bias=True), rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.gpu
 def test_concurrent_pl_lr_calls_are_coalesced(so, orc):
     """group_by().agg(pds.lin_reg(...)) unchanged: Polars' rayon threads call pl_lr once per group.  Calls that arrive while
     a batch is on the device leave together as one grouped launch; every caller must get its own group's coefficients."""
@@ -585,6 +692,79 @@ def test_concurrent_pl_lr_calls_are_coalesced(so, orc):
     # errors stay per call: too few rows raises for that caller only
     with pytest.raises(ph.PluginFailure, match="#Data < #features"):
         ph.call_plugin(so, "pl_lr", _cols(frames[0][0][:2], frames[0][1][:2]), dict(LR, bias=True))
+
+
+@pytest.mark.gpu
+def test_concurrent_pred_weighted_and_null_bearing_calls_are_coalesced(so, orc):
+    """The per-group calls of `group_by().agg(lin_reg(..., return_pred=True))`, of weighted fits and of fits on frames with
+    nulls (skip / fill) batch too: mixed kinds arrive together, every caller gets the answer of ITS frame and ITS kind, and
+    the queue accounts for every request (none falls back to the per-call path)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    rng = np.random.default_rng(21)
+    frames = []
+    for g in range(60):
+        n = int(rng.integers(25, 160))
+        X = rng.normal(size=(n, 3))
+        y = X @ rng.normal(size=3) + 0.3 + 0.1 * rng.normal(size=n)
+        frames.append((X, y, rng.random(n) + 0.2, rng.random(n) < 0.1))
+    X7 = frames[7][0]
+    frames[7] = (np.c_[X7[:, 0], 2.0 * X7[:, 0], X7[:, 2]],) + frames[7][1:]  # collinear -> the gate fires (unweighted kinds)
+
+    def one(job):
+        i, kind = job
+        X, y, w, mask = frames[i]
+        if kind == "pred":
+            _, out = ph.call_plugin(so, "pl_lr_pred", _cols(X, y), dict(LR, bias=True))
+            return out
+        if kind == "wpred":
+            _, out = ph.call_plugin(so, "pl_lr_pred", [("w", pa.array(w))] + _cols(X, y), dict(LR, bias=True, weighted=True))
+            return out
+        if kind == "weighted":
+            _, out = ph.call_plugin(so, "pl_lr", [("w", pa.array(w))] + _cols(X, y), dict(LR, bias=True, weighted=True))
+            return out[0].as_py()
+        ins = [("y", pa.array(y)), ("x1", pa.array(X[:, 0], mask=mask)), ("x2", pa.array(X[:, 1])), ("x3", pa.array(X[:, 2]))]
+        _, out = ph.call_plugin(so, "pl_lr", ins, dict(LR, bias=True, null_policy="skip" if kind == "skip" else "zero"))
+        return out[0].as_py()
+
+    jobs = [(i, k) for k in ("pred", "wpred", "weighted", "skip", "zero") for i in range(len(frames))]
+    order = rng.permutation(len(jobs))
+    so.pds_plugin_debug_coalesce_stats(None, None, None, 1)
+    with ThreadPoolExecutor(max_workers=16) as ex:
+        res = list(ex.map(one, [jobs[j] for j in order]))
+    b, r, m = C.c_longlong(), C.c_longlong(), C.c_longlong()
+    so.pds_plugin_debug_coalesce_stats(C.byref(b), C.byref(r), C.byref(m), 0)
+    assert r.value == len(jobs) and 1 <= b.value <= r.value
+    for j, got in zip(order, res):
+        i, kind = jobs[j]
+        X, y, w, mask = frames[i]
+        Xb = np.c_[X, np.ones(len(y))]
+        if kind in ("pred", "wpred"):
+            bo = orc.pl_lr(X, y, add_bias=True, weights=w if kind == "wpred" else None)
+            if bo is None:
+                assert got.field("pred").null_count == len(y)
+                continue
+            np.testing.assert_allclose(got.field("pred").to_numpy(zero_copy_only=False), Xb @ bo, rtol=1e-9, atol=1e-10)
+            np.testing.assert_allclose(got.field("resid").to_numpy(zero_copy_only=False), y - Xb @ bo, rtol=0, atol=1e-9)
+        elif kind == "weighted":
+            np.testing.assert_allclose(got, orc.pl_lr(X, y, add_bias=True, weights=w), rtol=1e-9, atol=1e-10)
+        else:
+            if kind == "skip":
+                bo = orc.pl_lr(X[~mask], y[~mask], add_bias=True)
+            else:
+                Xz = X.copy()
+                Xz[mask, 0] = 0.0
+                bo = orc.pl_lr(Xz, y, add_bias=True)
+            if bo is None:
+                assert got is None
+            else:
+                np.testing.assert_allclose(got, bo, rtol=1e-9, atol=1e-10)
+    # errors stay per call: a skip frame left with fewer rows than coefficients raises for that caller, as the single-frame path does
+    Xs, ys = frames[0][0][:5], frames[0][1][:5]
+    ins = [("y", pa.array(ys)), ("x1", pa.array(Xs[:, 0], mask=np.array([True, True, True, False, False]))), ("x2", pa.array(Xs[:, 1])),
+           ("x3", pa.array(Xs[:, 2]))]
+    with pytest.raises(ph.PluginFailure, match="#Data < #features"):
+        ph.call_plugin(so, "pl_lr", ins, dict(LR, bias=True, null_policy="skip"))
 
 
 @pytest.mark.gpu

@@ -169,7 +169,64 @@ def t_f32_switch_multi_target_rcond_ar(path, orc):
     np.testing.assert_allclose(ar, orc.pl_lr(L, z[3:], add_bias=True), rtol=1e-8, atol=1e-10)
 
 
-T_FUNCS = [t_select_lin_reg, t_pred_and_weights, t_group_by_agg_equals_by, t_report_rolling_recursive, t_f32_switch_multi_target_rcond_ar]
+def t_group_pred_over_and_any_key(path, orc):
+    """`group_by(k).agg(lin_reg(..., return_pred=True))` (tests/test_linear_exprs.py:435-474) and `.over(k)` (examples/basics.ipynb
+    cells 16 / 18) as ONE key-aware call each; string keys, several key columns and null keys through dense group ids."""
+    px.PLUGIN_PATH = path
+    # ---- the reference's literal frame
+    df = pl.DataFrame({"A": [1] * 4 + [2] * 4, "Y": [1.0] * 8, "X1": [1.0, 2, 3, 4, 5, 6, 7, 8], "X2": [2.0, 3, 4, 1, 6, 7, 8, 5]})
+    got = px.lin_reg_by_group(df, "A", "X1", "X2", target="Y", add_bias=False, return_pred=True)
+    assert got.columns == ["A", "Y", "X1", "X2", "pred", "resid"] and len(got) == 8
+    A = np.array(df["A"].to_list())
+    X = np.c_[df["X1"].to_numpy(), df["X2"].to_numpy()]
+    for a in (1, 2):
+        m = A == a
+        b = orc.pl_lr(X[m], np.ones(m.sum()))
+        np.testing.assert_allclose(got["pred"].to_numpy()[m], X[m] @ b, rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(got["resid"].to_numpy()[m], 1.0 - X[m] @ b, rtol=0, atol=1e-9)
+    # ---- shuffled rows, expression form, .over-style broadcast
+    rng = np.random.default_rng(11)
+    G, per = 60, 30
+    key = np.repeat(rng.permutation(G) * 3 - 40, per)
+    Xs = rng.normal(size=(G * per, 2))
+    ys = Xs @ [1.2, -0.7] + 0.02 * key + 0.1 * rng.normal(size=G * per)
+    perm = rng.permutation(G * per)
+    d2 = pl.DataFrame({"k": key[perm], "y": ys[perm], "x1": Xs[perm, 0], "x2": Xs[perm, 1]})
+    out = d2.with_columns(px.lin_reg("x1", "x2", target="y", add_bias=True, return_pred=True, by="k")).unnest("lr_pred")
+    over = px.lin_reg_over(d2, "k", "x1", "x2", target="y", add_bias=True)
+    assert len(out) == G * per and len(over) == G * per and "coeffs" in over.columns
+    kk = d2["k"].to_numpy()
+    for k in np.unique(key)[::7]:
+        m = kk == k
+        b = orc.pl_lr(Xs[perm][m], ys[perm][m], add_bias=True)
+        np.testing.assert_allclose(out["pred"].to_numpy()[m], Xs[perm][m] @ b[:2] + b[2], rtol=1e-9, atol=1e-11)
+        for row in np.flatnonzero(m)[:3]:
+            np.testing.assert_allclose(over["coeffs"].to_list()[row], b, rtol=1e-9, atol=1e-11)
+    # ---- string keys, two key columns, null keys
+    names = np.array(["ash", "birch", None, "cedar"], dtype=object)
+    s_key = names[rng.integers(0, 4, size=400)]
+    side = rng.integers(0, 2, size=400)
+    Xk = rng.normal(size=(400, 2))
+    yk = Xk @ [0.5, 2.0] + 0.05 * rng.normal(size=400) + side
+    d3 = pl.DataFrame({"tree": list(s_key), "side": side, "y": yk, "x1": Xk[:, 0], "x2": Xk[:, 1]})
+    res = px.lin_reg_by_group(d3, "tree", "x1", "x2", target="y", add_bias=True)
+    assert res.columns == ["tree", "coeffs"] and len(res) == 4 and None in res["tree"].to_list()
+    for t, co in zip(res["tree"].to_list(), res["coeffs"].to_list()):
+        m = np.array([v == t for v in s_key]) if t is not None else np.array([v is None for v in s_key])
+        np.testing.assert_allclose(co, orc.pl_lr(Xk[m], yk[m], add_bias=True), rtol=1e-9, atol=1e-11)
+    res2 = px.lin_reg_by_group(d3, ["tree", "side"], "x1", "x2", target="y")
+    assert res2.columns == ["tree", "side", "coeffs"] and len(res2) == 8
+    for t, sd, co in zip(res2["tree"].to_list(), res2["side"].to_list(), res2["coeffs"].to_list()):
+        m = (np.array([v == t for v in s_key]) if t is not None else np.array([v is None for v in s_key])) & (side == sd)
+        np.testing.assert_allclose(co, orc.pl_lr(Xk[m], yk[m]), rtol=1e-9, atol=1e-11)
+    pr = px.lin_reg_by_group(d3, ["tree", "side"], "x1", "x2", target="y", return_pred=True)
+    assert pr.columns == ["tree", "side", "y", "x1", "x2", "pred", "resid"] and len(pr) == 400
+    m = np.array([v == "birch" for v in s_key]) & (side == 1)
+    np.testing.assert_allclose(pr["pred"].to_numpy()[m], Xk[m] @ orc.pl_lr(Xk[m], yk[m]), rtol=1e-9, atol=1e-11)
+
+
+T_FUNCS = [t_select_lin_reg, t_pred_and_weights, t_group_by_agg_equals_by, t_group_pred_over_and_any_key, t_report_rolling_recursive,
+           t_f32_switch_multi_target_rcond_ar]
 
 
 # ---- CPU: the mock device layer behind the same plugin.cpp ------------------------------------------------------------------

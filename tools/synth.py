@@ -98,3 +98,22 @@ def c5_frame(n: int = 10_000_000, p: int = 512, seed: int = 4, device="cuda", bl
         y[r0:r1] = (bt.float() @ Xb) + 0.5 * torch.randn(r1 - r0, dtype=torch.float32, device=device, generator=g)
         del E
     return dict(X=X, y=y, beta=beta)
+
+
+def headline_frame(n_groups: int = 1_000_000, rows_per_group: int = 100, p: int = 16, seed: int = 1234, device="cuda"):
+    """
+    The frame bench.py's `value` is measured on (BASELINE.json's metric: grouped lstsq, 1e8 rows x 16 f64 features):
+    x ~ N(0,1), per-group beta ~ N(0,1), noise 0.1, a fixed number of rows per group.  Returns (xs, y).
+    """
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    G, R = n_groups, rows_per_group
+    N = G * R
+    xs = [torch.randn(N, dtype=torch.float64, device=device, generator=gen) for _ in range(p)]
+    y = torch.zeros(N, dtype=torch.float64, device=device)
+    for j in range(p):
+        bj = torch.randn(G, dtype=torch.float64, device=device, generator=gen)
+        y.add_(xs[j] * bj.repeat_interleave(R))
+        del bj
+    y.add_(torch.randn(N, dtype=torch.float64, device=device, generator=gen), alpha=0.1)
+    return xs, y
