@@ -21,6 +21,13 @@
         __builtin_amdgcn_wave_barrier();                      \
     } while (0)
 
+// Newton steps x <- x + x (1 - d x) behind v_rcp_f64 for the pivot reciprocals of the in-register L D L' solves
+// (solve_reg_dev.hpp, rolling_seg_dev.hpp); tools/rcp_accuracy.hip measures what the instruction delivers on its own and after
+// each step
+#ifndef PDS_RCP_NEWTON
+#define PDS_RCP_NEWTON 2
+#endif
+
 namespace pds {
 
 // Column base pointers reach the kernels through a device-side table, so the compiler only knows them as generic

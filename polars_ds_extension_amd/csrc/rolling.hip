@@ -450,10 +450,23 @@ static int launch_pp_f(pds_ctx* ctx, const DeviceCols<T>& dc, RollArgs ra, bool 
     [[maybe_unused]] auto launch_seg = [&](auto mode_c, const double* tot) {
         if constexpr (PP <= 8) {
             constexpr int M = decltype(mode_c)::value;
-            using SD = SegDims<T, PP>;
-            const int64_t sb = std::min<int64_t>(std::max<int64_t>(ntiles, 1), (int64_t)ctx->num_cus * 4);
-            hipLaunchKernelGGL((rolling_seg_kernel<T, PP, M, FULLP>), dim3((unsigned)sb), dim3(64), (size_t)SD::LDS_BYTES, ctx->stream,
-                               dc.d_ptrs, ra, tot, d_coeffs, d_pred, d_valid);
+            constexpr int64_t tile = M == 0 ? kSegTileRoll : kSegTile;
+            const int64_t seg_tiles = (ra.n + tile - 1) / tile;
+            const int64_t sb = std::min<int64_t>(std::max<int64_t>(seg_tiles, 1), (int64_t)ctx->num_cus * 4);
+            // window == one stage: the rows leaving the window are the previous stage's rows, kept in registers (no second read
+            // stream); PDS_ROLL_OLD_STREAM=1 keeps the two-stream form for that window too (A/B)
+            static const bool old_stream = [] { const char* e = std::getenv("PDS_ROLL_OLD_STREAM"); return e && e[0] == '1'; }();
+            if (M == 0 && ra.window == kSegStage && !old_stream) {
+                if constexpr (M == 0) {
+                    using SD = SegDims<T, PP, 1>;
+                    hipLaunchKernelGGL((rolling_seg_kernel<T, PP, 0, FULLP, 1>), dim3((unsigned)sb), dim3(64), (size_t)SD::LDS_BYTES,
+                                       ctx->stream, dc.d_ptrs, ra, tot, d_coeffs, d_pred, d_valid);
+                }
+            } else {
+                using SD = SegDims<T, PP, 0>;
+                hipLaunchKernelGGL((rolling_seg_kernel<T, PP, M, FULLP, 0>), dim3((unsigned)sb), dim3(64), (size_t)SD::LDS_BYTES,
+                                   ctx->stream, dc.d_ptrs, ra, tot, d_coeffs, d_pred, d_valid);
+            }
         }
     };
     KernelTimer timer(ctx, kKindRolling);

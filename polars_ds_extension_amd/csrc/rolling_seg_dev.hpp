@@ -37,18 +37,32 @@ constexpr int kSegStage = 64 * kSegK;     // rows per stage
 constexpr int kSegTile = 4096;            // rows per tile (== rolling.hip's kTileRows: the expanding pass shares its tile totals)
 constexpr int kSegStride = 65;            // doubles per moment row of the scan area
 
-template <typename T, int PP>
+template <typename T, int PP, int OLDREG = 0>
 struct SegDims {
     static constexpr int NG = PP * (PP + 1) / 2;
     static constexpr int NV = NG + PP + 1;
     static constexpr int E16 = 16 / (int)sizeof(T);                 // elements per 16-byte lane load
     static constexpr int PIECES = kSegK / E16;                      // 1 KiB pieces per stream and stage
     static constexpr int STREAM_BYTES = kSegStage * (int)sizeof(T);
-    static constexpr int NSTREAM = 2 * (PP + 1);                    // new + old rows of [features.., y]
+    static constexpr int NSTREAM = (OLDREG ? 1 : 2) * (PP + 1);     // new (+ old) rows of [features.., y]
     static constexpr int STAGE_BYTES = NSTREAM * STREAM_BYTES;
     static constexpr int SCAN_BYTES = NV * kSegStride * 8;
     static constexpr int LDS_BYTES = STAGE_BYTES > SCAN_BYTES ? STAGE_BYTES : SCAN_BYTES;
 };
+
+// rows per tile of the ROLLING form (the expanding form shares kSegTile with rolling.hip's totals): the anchor of a tile reads
+// the window in front of it once more and the first stage of a tile waits for its rows, so longer tiles amortise both --
+// as long as there are enough tiles to balance the waves
+// Newton steps x <- x (2 - d x) behind v_rcp_f64 for a pivot reciprocal (tools/rcp_accuracy.hip measures what the instruction
+// delivers on its own and after each step)
+#ifndef PDS_RCP_NEWTON
+#define PDS_RCP_NEWTON 2
+#endif
+#ifndef PDS_ROLL_TILE
+#define PDS_ROLL_TILE 16384
+#endif
+constexpr int kSegTileRoll = PDS_ROLL_TILE;
+static_assert(kSegTileRoll % kSegStage == 0, "tiles are whole stages");
 
 template <int PP>
 struct SegRow {
@@ -93,11 +107,17 @@ __device__ __forceinline__ void seg_zero(SegRow<PP>& r) {
 
 // MODE 0: rolling window.  MODE 2: expanding, main pass (tile_tot holds the exclusive prefix over the tiles' totals, written
 // by rolling.hip's totals pass + tile_prefix_kernel).  FULLP as in rolling.hip (1: p == PP, no bias; 2: p == PP - 1 + bias).
-template <typename T, int PP, int MODE, int FULLP>
+// OLDREG (MODE 0, window == kSegStage): the rows leaving the window during a stage are exactly the rows that ENTERED it one
+// stage earlier -- the same lane's rows of the previous stage, still in its registers.  The second read stream (7.2 GB at C4,
+// re-fetched from HBM because the output stream had evicted it: profiles/r02_traffic.json) and its half of the LDS image and
+// of the LDS -> register hand-over disappear; only the first stage of a tile fetches its leaving rows (straight into registers).
+template <typename T, int PP, int MODE, int FULLP, int OLDREG = 0>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void rolling_seg_kernel(
     const T* const* __restrict__ cols, RollArgs ra_in, const double* __restrict__ tile_tot, T* __restrict__ coeffs,
     T* __restrict__ pred, uint8_t* __restrict__ valid) {
-    using SD = SegDims<T, PP>;
+    static_assert(!OLDREG || MODE == 0, "the register-resident leaving rows belong to the rolling form");
+    using SD = SegDims<T, PP, OLDREG>;
+    constexpr int kTile = MODE == 0 ? kSegTileRoll : kSegTile;
     constexpr int K = kSegK, NG = SD::NG, NV = SD::NV, E16 = SD::E16, PIECES = SD::PIECES;
     static_assert(NV <= 64, "one lane per moment in the scan");
     static_assert(MODE == 0 || MODE == 2, "rolling or the main pass of the expanding fit");
@@ -113,7 +133,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         ra.bias = 1;
     }
     const int p = ra.p;                       // feature columns; column p of the table is y
-    constexpr int NWHICH = MODE == 0 ? 2 : 1; // new rows (+ the rows leaving the window)
+    constexpr int NWHICH = (MODE == 0 && !OLDREG) ? 2 : 1; // new rows (+ the rows leaving the window, unless they are register resident)
     constexpr int NLOAD = NWHICH * (PP + 1) * PIECES;       // 16-byte loads per lane and stage (columns beyond p are skipped)
     constexpr int PER_BATCH = (NLOAD + K - 1) / K;          // ... issued in K batches, one in front of every row of pass 2
     extern __shared__ __attribute__((aligned(16))) double seg_lds[];  // (one name / type per translation unit)
@@ -121,7 +141,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     double* D = seg_lds;
     const int lane = threadIdx.x & 63;
     const int64_t n = ra.n, w = ra.window;
-    const int64_t ntiles = (n + kSegTile - 1) / kSegTile;
+    const int64_t ntiles = (n + kTile - 1) / kTile;
     const double lambda = ra.lambda;
 
     // ---- one 16-byte piece of the next stage: global -> register (issue) -> LDS (commit)
@@ -176,9 +196,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     unsigned long long rprof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
 #endif
+    // the lane's rows of the stage (new) and the rows leaving the window with them (old); OLDREG: `rn` / `okn` of one stage
+    // become `ro` / `oko` of the next, so they live across the stage loop
+    SegRow<PP> rn[K], ro[K];
+    bool okn[K], oko[K];
     for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         RT0();
-        const int64_t t0 = t * kSegTile, t1 = (t0 + kSegTile < n) ? t0 + kSegTile : n;
+        const int64_t t0 = t * kTile, t1 = (t0 + kTile < n) ? t0 + kTile : n;
         // ---- anchor: lane v < NV carries moment v of the window that ends at row t0 - 1
         double carry = 0.0;
         if constexpr (MODE == 2) {
@@ -223,37 +247,76 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
             for (int i = 0; i < NLOAD; ++i) commit(i, tmp[i]);
         }
+        if constexpr (OLDREG) {
+            // the rows in front of the tile ([t0 - w, t0), w == kSegStage: this lane's K rows of the stage before the first)
+            // play the previous stage: straight from global memory, guarded at the front of the frame
+            const int64_t rp = t0 - kSegStage + (int64_t)K * lane;
+            auto load_prev = [&](int cc, double (&v)[K]) __attribute__((always_inline)) {
+                gptr<T> col = as_global(cols[cc]);
+                if (rp >= 0) {
+#pragma unroll
+                    for (int j = 0; j < PIECES; ++j) {
+                        const V16 x = *reinterpret_cast<gptr<V16>>(col + rp + j * E16);
+#pragma unroll
+                        for (int e = 0; e < E16; ++e) v[j * E16 + e] = (double)x[e];
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < K; ++i) v[i] = (rp + i >= 0) ? (double)col[rp + i] : 0.0;
+                }
+            };
+#pragma unroll
+            for (int c = 0; c < PP; ++c) {
+                double v[K];
+                if (c < p) load_prev(c, v);
+#pragma unroll
+                for (int i = 0; i < K; ++i) rn[i].z[c] = (c < p) ? v[i] : ((c == p && ra.bias) ? 1.0 : 0.0);
+            }
+            {
+                double v[K];
+                load_prev(p, v);
+#pragma unroll
+                for (int i = 0; i < K; ++i) rn[i].y = v[i];
+            }
+#pragma unroll
+            for (int i = 0; i < K; ++i) okn[i] = (rp + i >= 0) && seg_finite<PP>(rn[i]);
+        }
         RT1(0);  // anchor + first stage straight through
         for (int64_t base = t0; base < t1; base += kSegStage) {
             RTA();
             PDS_WAVE_LDS_SYNC();  // the stage image is complete
             const int64_t r0 = base + (int64_t)K * lane;
             // ---- the lane's rows: LDS -> registers
-            SegRow<PP> rn[K], ro[K];
-            bool okn[K], oko[K];
+            if constexpr (OLDREG) {
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    ro[i] = rn[i];
+                    oko[i] = okn[i] && (r0 + i < t1);
+                }
+            }
 #pragma unroll
             for (int c = 0; c < PP; ++c) {
                 double a[K], b[K];
                 const bool feat = c < p;
                 if (feat) {
                     pick(0, c, a);
-                    if constexpr (MODE == 0) pick(1, c, b);
+                    if constexpr (MODE == 0 && !OLDREG) pick(1, c, b);
                 }
 #pragma unroll
                 for (int i = 0; i < K; ++i) {
                     const double one = (c == p && ra.bias) ? 1.0 : 0.0;
                     rn[i].z[c] = feat ? a[i] : one;
-                    ro[i].z[c] = (MODE == 0) ? (feat ? b[i] : one) : 0.0;
+                    if constexpr (!OLDREG) ro[i].z[c] = (MODE == 0) ? (feat ? b[i] : one) : 0.0;
                 }
             }
             {
                 double a[K], b[K];
                 pick(0, p, a);
-                if constexpr (MODE == 0) pick(1, p, b);
+                if constexpr (MODE == 0 && !OLDREG) pick(1, p, b);
 #pragma unroll
                 for (int i = 0; i < K; ++i) {
                     rn[i].y = a[i];
-                    ro[i].y = (MODE == 0) ? b[i] : 0.0;
+                    if constexpr (!OLDREG) ro[i].y = (MODE == 0) ? b[i] : 0.0;
                 }
             }
 #pragma unroll
@@ -262,9 +325,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 // (a row that does not count -- outside the tile, in front of the frame, holding a non-finite value -- is
                 //  skipped by an exec-mask branch around its accumulation: 18 selects per row saved over zeroing its values)
                 okn[i] = (r < t1) && seg_finite<PP>(rn[i]);
-                if constexpr (MODE == 0) {
+                if constexpr (MODE == 0 && !OLDREG) {
                     oko[i] = (r < t1) && (r - w >= 0) && seg_finite<PP>(ro[i]);
-                } else {
+                } else if constexpr (MODE != 0) {
                     oko[i] = false;
                 }
             }
@@ -324,7 +387,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #ifdef PDS_ROLL_LDS_DIRECT
             // interior stages (every piece of both streams inside the frame): the asynchronous burst; frame edges keep the
             // guarded register path below
-            const bool direct = (nb < t1) && (nb + kSegStage <= n) && (MODE != 0 || nb - w >= 0);
+            const bool direct = (nb < t1) && (nb + kSegStage <= n) && (MODE != 0 || OLDREG || nb - w >= 0);
             const bool edge = (nb < t1) && !direct;  // (fetched behind the rows, in small batches: rare and allowed to wait)
             const bool more = false;
             if (direct) {
@@ -345,14 +408,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 const double d = GI(S, 0, 0) + diag_add(0);
                 okc = d > 0.0;
                 double x = __builtin_amdgcn_rcp(d);
-                x = x * fma(-d, x, 2.0);
-                x = x * fma(-d, x, 2.0);
+#pragma unroll
+                for (int it = 0; it < PDS_RCP_NEWTON; ++it) x = x * fma(-d, x, 2.0);
                 rd[0] = x;
 #pragma unroll
                 for (int a = 1; a < PP; ++a) {
                     const double tka = GI(S, 0, a) * x;
 #pragma unroll
-                    for (int b = a; b < PP; ++b) GI(g, a, b) = fma(-tka, GI(S, 0, b), GI(S, a, b) + ((a == b) ? diag_add(a) : 0.0));
+                    for (int b = a; b < PP; ++b) {
+                        // (no `+ 0.0` on the off-diagonal entries: the compiler must keep such an add -- it turns -0.0 into
+                        //  +0.0 -- and it cost 28 f64 instructions per row)
+                        if (a == b) GI(g, a, b) = fma(-tka, GI(S, 0, b), GI(S, a, b) + diag_add(a));
+                        else GI(g, a, b) = fma(-tka, GI(S, 0, b), GI(S, a, b));
+                    }
                     GI(g, 0, a) = tka;
                 }
             };
@@ -360,8 +428,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 const double d = GI(g, k, k);
                 okc = okc && (d > 0.0);
                 double x = __builtin_amdgcn_rcp(d);
-                x = x * fma(-d, x, 2.0);
-                x = x * fma(-d, x, 2.0);
+#pragma unroll
+                for (int it = 0; it < PDS_RCP_NEWTON; ++it) x = x * fma(-d, x, 2.0);
                 rd[k] = x;
 #pragma unroll
                 for (int a = k + 1; a < PP; ++a) {

@@ -285,8 +285,8 @@ __device__ __forceinline__ void chol_step(double (&a)[LPS + 1], int j, double& i
     const double d = Grp<LPS>::template bcast<K>(a[K]);
     ok = ok && (d > 0.0);
     double x = __builtin_amdgcn_rcp(d);
-    x = fma(fma(-d, x, 1.0), x, x);
-    x = fma(fma(-d, x, 1.0), x, x);
+#pragma unroll
+    for (int it = 0; it < PDS_RCP_NEWTON; ++it) x = fma(fma(-d, x, 1.0), x, x);
     // lanes <= K keep their finished columns: a zero multiplier instead of a select per element (DPP reads from
     // EXEC-disabled lanes are invalid, so every lane takes part)
     const double nt = (j > K) ? -(a[K] * x) : 0.0;
