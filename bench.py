@@ -430,12 +430,23 @@ def _end_to_end(torch, np, pds, dev, xs, y, G, R, P, cpu):
             ts.append(time.perf_counter() - t1)
         return float(np.median(ts)), res
 
+    # default route: the frame in row slices through two contexts on this device (a slice crosses PCIe while the previous one is
+    # fitted and copied back; with PDS_DEVICES=0,1,.. every device pulls its own slices over its own link), results into pinned
+    # Arrow buffers.  Beside it the single-context route of the earlier rounds (PDS_BY_KEY_MULTI_MIN_ROWS=0).
     t_by, res = timed("pl_lr_by", [key] + host)
     assert len(res) == G
     gb_by = (N * (P + 2) * 8 + G * (P * 8 + 8 + 1)) / 1e9  # keys + y + features up, keys + coefficients + validity down
     out["pl_lr_by"] = {"workload": f"host Arrow frame, {G} groups x {R} rows x {P} f64 feats + int64 keys", "wall_ms": round(t_by * 1e3, 1),
                        "regressions_per_s": round(G / t_by, 1), "pcie_GB": round(gb_by, 2), "GBps": round(gb_by / t_by, 1),
-                       "frac_of_pcie_rate": round(gb_by / t_by / pcie, 3)}
+                       "frac_of_pcie_rate": round(gb_by / t_by / pcie, 3),
+                       "route": f"sliced, {os.environ.get('PDS_BY_KEY_CONTEXTS', '2')} contexts per device, devices {os.environ.get('PDS_DEVICES', '0')}"}
+    os.environ["PDS_BY_KEY_MULTI_MIN_ROWS"] = "0"
+    try:
+        t_by1, _ = timed("pl_lr_by", [key] + host, reps=2)
+    finally:
+        del os.environ["PDS_BY_KEY_MULTI_MIN_ROWS"]
+    out["pl_lr_by"]["single_context_wall_ms"] = round(t_by1 * 1e3, 1)
+    out["pl_lr_by"]["single_context_frac_of_pcie_rate"] = round(gb_by / t_by1 / pcie, 3)
     t_lr, _ = timed("pl_lr", host)
     gb_lr = N * (P + 1) * 8 / 1e9
     out["pl_lr"] = {"workload": f"host Arrow frame, single OLS {N:.0e} rows x {P} f64 feats", "wall_ms": round(t_lr * 1e3, 1),

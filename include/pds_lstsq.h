@@ -344,6 +344,30 @@ int pds_lr_by_key_f32(pds_ctx* ctx, const float* const* cols, const int64_t* key
                       int64_t* n_groups);
 
 /*
+ * pds_lr_by_key_multi_*: pds_lr_by_key_* for a HOST frame with non-decreasing keys, driven through SEVERAL contexts from one
+ * process (the Polars plugin is loaded in-process: python/polars_ds/_utils.py:28-38 -- a torch.distributed launcher cannot
+ * serve `pl_lr_by`; SURVEY.md 8(e) "each GPU pulls its own shard over its own PCIe link").  The frame is cut into n_slices row
+ * ranges at group boundaries (n_slices <= 0: four per context; a slice has at least 2^20 rows), slice s is fitted by context
+ * s mod n_ctx on that context's device and stream from its own host thread, and its keys / coefficients / null flags land
+ * directly in the piece of the outputs that follows the groups of the slices in front of it.  Contexts on DIFFERENT devices:
+ * every device pulls its shard over its own link.  Several contexts on ONE device: a slice's transfer overlaps the previous
+ * slice's fit and result copy.  Results are identical to pds_lr_by_key_* (same kernels per group).  Keys that are not in
+ * order (or n_ctx == 1 with one slice) take pds_lr_by_key_* on ctxs[0].  Arguments as pds_lr_by_key_* (space = PDS_HOST).
+ */
+int pds_lr_by_key_multi_f64(pds_ctx* const* ctxs, int n_ctx, int n_slices, const double* const* cols, const int64_t* keys, int n_feat,
+                            int64_t n_rows, const pds_lr_params* prm, int64_t max_groups, int64_t* out_keys, double* coeffs,
+                            uint8_t* is_null, int64_t* n_groups);
+int pds_lr_by_key_multi_f32(pds_ctx* const* ctxs, int n_ctx, int n_slices, const float* const* cols, const int64_t* keys, int n_feat,
+                            int64_t n_rows, const pds_lr_params* prm, int64_t max_groups, int64_t* out_keys, float* coeffs,
+                            uint8_t* is_null, int64_t* n_groups);
+/* Page-locked host storage (hipHostMalloc, portable across devices) for result buffers the caller owns: device-to-host copies
+ * into it run at the link rate.  The plugin layer keeps the large Arrow result buffers in such storage (plugin_arrow_out.hpp). */
+int pds_host_alloc(size_t bytes, void** out);
+int pds_host_free(void* p);
+/* number of visible devices (the plugin layer's PDS_DEVICES=all) */
+int pds_device_count(int* n);
+
+/*
  * pds_lr_grouped_pred_* / pds_lr_by_key_pred_*: the grouped form of `pl_lr_pred` (linear_regression.rs:704-820) -- what
  * `df.group_by(key).agg(pds.lin_reg(..., return_pred=True))` (tests/test_linear_exprs.py:435-474) and
  * `pds.lin_reg(..., return_pred=True).over(key)` make Polars compute one group at a time: every group is fitted as

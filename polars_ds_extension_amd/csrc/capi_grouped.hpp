@@ -354,18 +354,29 @@ static int grouped_weighted_impl(pds_ctx* ctx, const T* const* cols, const T* we
 // ---------------------------------------------------------------------------------------------
 // grouped by an int64 key column in any row order (keyed.hip brings the frame into key order on the device)
 // ---------------------------------------------------------------------------------------------
+// Where a slice of a frame that is fitted in several pieces (capi_multi.hpp) puts its results: asked once the slice's number of
+// groups is known, before the fit.  `unsorted()` reports that the slice's keys are not in order (the pieces are then meaningless).
+template <typename T>
+struct ByKeyPlace {
+    virtual int at(int64_t n_groups, int64_t** out_keys, T** coeffs, uint8_t** is_null) = 0;
+    virtual void unsorted() = 0;
+    virtual ~ByKeyPlace() = default;
+};
+
 template <typename T>
 static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* keys, int n_feat, int64_t n_rows, pds_space space,
                           const pds_lr_params* prm, int64_t max_groups, int64_t* out_keys, T* coeffs, uint8_t* is_null,
                           int64_t* n_groups,
                           // pds_lr_by_key_pred_*: optional weights (one more column through the ordering), per-row outputs in the
                           // FRAME's row order; out_keys / coeffs / is_null / n_groups are then optional
-                          const T* weights = nullptr, T* pred = nullptr, T* resid = nullptr, uint8_t* row_null = nullptr) {
+                          const T* weights = nullptr, T* pred = nullptr, T* resid = nullptr, uint8_t* row_null = nullptr,
+                          ByKeyPlace<T>* place = nullptr) {
     const bool want_pred = pred || resid || row_null;
-    const bool want_coef = out_keys || coeffs;
+    const bool want_coef = out_keys || coeffs || place;
     if (!ctx || !cols || !keys || !prm) return fail(PDS_ERR_INVALID, "null argument");
-    if (!want_pred && (!out_keys || !coeffs || !n_groups)) return fail(PDS_ERR_INVALID, "null argument");
-    if (want_coef && (!out_keys || !coeffs)) return fail(PDS_ERR_INVALID, "out_keys and coeffs come together");
+    if (!want_pred && !place && (!out_keys || !coeffs || !n_groups)) return fail(PDS_ERR_INVALID, "null argument");
+    if (place && space != PDS_HOST) return fail(PDS_ERR_INVALID, "sliced fits take host frames");
+    if (want_coef && !place && (!out_keys || !coeffs)) return fail(PDS_ERR_INVALID, "out_keys and coeffs come together");
     if (n_feat < 1) return fail(PDS_ERR_INVALID, "need at least one feature column");
     if (n_rows <= 0) return fail(PDS_ERR_EMPTY, "Empty data");
     if (n_rows >= (1ll << 31)) return fail(PDS_ERR_UNSUPPORTED, "keyed grouping: fewer than 2^31 rows per call");
@@ -388,6 +399,10 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
     bool sorted = false;
     if (int rc = keys_nondecreasing(ctx, d_keys, n_rows, static_cast<unsigned*>(ctx->solve_ws.ptr), &sorted)) return rc;
     tr.mark("keys H2D + order check");
+    if (place && !sorted) {
+        place->unsorted();
+        return fail(PDS_ERR_UNSUPPORTED, "sliced fit: the slice's keys are not in order");
+    }
     // ---- workspace: [raw columns (host frames)] [sorted keys, index in/out, gathered columns (unsorted frames)] runs, temp
     const int64_t cap = std::min<int64_t>(max_groups, n_rows);
     const size_t temp_bytes = keyed_temp_bytes(n_rows);
@@ -457,6 +472,8 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
     tr.mark("run lengths + offsets");
     if (n_groups) *n_groups = ng;
     if (ng > max_groups) return fail(PDS_ERR_INVALID, "more distinct keys than max_groups");
+    if (place)
+        if (int rc = place->at(ng, &out_keys, &coeffs, &is_null)) return rc;
     T* d_co = coeffs;
     uint8_t* d_nu = is_null;
     if (space == PDS_HOST || !coeffs) d_co = reinterpret_cast<T*>(take((size_t)cap * pp * sizeof(T)));

@@ -15,6 +15,55 @@ pds_ctx* thread_ctx() {
 void check(int rc) {
     if (rc != PDS_OK) raise(pds_last_error());
 }
+
+// Contexts of the sliced `pl_lr_by` route (pds_lr_by_key_multi_*): PDS_DEVICES = "0,1,..." or "all" names the devices (default:
+// the one PDS_DEVICE / 0 names), PDS_BY_KEY_CONTEXTS the contexts per device (default 2: one slice crosses PCIe while the
+// previous one is fitted and copied back).  One set per process, used by one call at a time (a second concurrent call finds
+// it busy and takes the single-context route on its own thread's context).
+struct MultiContexts {
+    std::mutex busy;
+    std::vector<pds_ctx*> ctxs;
+    bool tried = false;
+    static MultiContexts& get() {
+        static MultiContexts* m = new MultiContexts();
+        return *m;
+    }
+    // call with `busy` held
+    const std::vector<pds_ctx*>& contexts() {
+        if (tried) return ctxs;
+        tried = true;
+        std::vector<int> devs;
+        const char* e = std::getenv("PDS_DEVICES");
+        if (e && std::string(e) == "all") {
+            int n = 0;
+            if (pds_device_count(&n) == PDS_OK)
+                for (int d = 0; d < n; ++d) devs.push_back(d);
+        } else if (e && *e) {
+            std::string tok;
+            for (const char* c = e;; ++c) {
+                if (*c == ',' || *c == 0) {
+                    if (!tok.empty()) devs.push_back(std::atoi(tok.c_str()));
+                    tok.clear();
+                    if (*c == 0) break;
+                } else {
+                    tok.push_back(*c);
+                }
+            }
+        }
+        if (devs.empty()) {
+            const char* d = std::getenv("PDS_DEVICE");
+            devs.push_back(d ? std::atoi(d) : 0);
+        }
+        const char* pc = std::getenv("PDS_BY_KEY_CONTEXTS");
+        const int per = pc ? std::max(1, std::atoi(pc)) : 2;
+        for (int k = 0; k < per; ++k)      // (device-major interleave: slice s goes to device s mod n_dev first)
+            for (int d : devs) {
+                pds_ctx* c = nullptr;
+                if (pds_ctx_create(d, &c) == PDS_OK && c) ctxs.push_back(c);
+            }
+        return ctxs;
+    }
+};
 // PDS_REFERENCE_QUIRKS=1 (read per call): answer the two places where the reference's outputs are accidents of its
 // result assembly exactly as it does instead of the way DESIGN.md section 7 argues for --
 //   pl_lr_pred, null_policy "ignore", nulls present: ONE row {pred: null, resid: null} (the dummy mask of
@@ -38,6 +87,7 @@ template <> struct Api<double> {
     static constexpr auto recursive = pds_recursive_lr_f64;
     static constexpr auto by_key = pds_lr_by_key_f64;
     static constexpr auto by_key_pred = pds_lr_by_key_pred_f64;
+    static constexpr auto by_key_multi = pds_lr_by_key_multi_f64;
     static constexpr auto grouped_pred = pds_lr_grouped_pred_f64;
     static constexpr auto grouped = pds_lr_grouped_f64;
     static constexpr auto grouped_weighted = pds_lr_grouped_weighted_f64;
@@ -56,6 +106,7 @@ template <> struct Api<float> {
     static constexpr auto recursive = pds_recursive_lr_f32;
     static constexpr auto by_key = pds_lr_by_key_f32;
     static constexpr auto by_key_pred = pds_lr_by_key_pred_f32;
+    static constexpr auto by_key_multi = pds_lr_by_key_multi_f32;
     static constexpr auto grouped_pred = pds_lr_grouped_pred_f32;
     static constexpr auto grouped = pds_lr_grouped_f32;
     static constexpr auto grouped_weighted = pds_lr_grouped_weighted_f32;

@@ -372,10 +372,27 @@ void do_lr_by(SeriesExport* in, size_t n_in, const Kwargs& kw, SeriesExport* out
                 keys.resize(cap);
                 cobuf = raw_buffer<T>((size_t)cap * pp);
                 nulls.resize(cap);
-                const int rc = weighted ? Api<T>::by_key_pred(thread_ctx(), ptrs.data(), wts, ikey, n_feat, n, PDS_HOST, &prm, cap, keys.data(),
-                                                              as<T>(cobuf), nulls.data(), &ng, nullptr, nullptr, nullptr)
-                                        : Api<T>::by_key(thread_ctx(), ptrs.data(), ikey, n_feat, n, PDS_HOST, &prm, cap, keys.data(),
-                                                         as<T>(cobuf), nulls.data(), &ng);
+                int rc;
+                // large unweighted frames: the sliced route -- several contexts (devices: PDS_DEVICES; per device:
+                // PDS_BY_KEY_CONTEXTS), every slice over its context's stream / its device's PCIe link (capi_multi.hpp); it
+                // falls back to the single-context entry point by itself when the keys are not in order
+                // (read per call: PDS_BY_KEY_MULTI_MIN_ROWS=0 switches the route off, PDS_BY_KEY_SLICES sets the slice count)
+                const char* e_min = std::getenv("PDS_BY_KEY_MULTI_MIN_ROWS");
+                const int64_t multi_min = e_min ? (int64_t)std::atoll(e_min) : (int64_t)1 << 22;
+                const char* e_sl = std::getenv("PDS_BY_KEY_SLICES");
+                const int slices = e_sl ? std::atoi(e_sl) : 0;
+                std::unique_lock<std::mutex> multi(MultiContexts::get().busy, std::defer_lock);
+                if (weighted) {
+                    rc = Api<T>::by_key_pred(thread_ctx(), ptrs.data(), wts, ikey, n_feat, n, PDS_HOST, &prm, cap, keys.data(), as<T>(cobuf),
+                                             nulls.data(), &ng, nullptr, nullptr, nullptr);
+                } else if (n >= multi_min && multi_min > 0 && multi.try_lock() && MultiContexts::get().contexts().size() > 1) {
+                    const auto& cx = MultiContexts::get().contexts();
+                    rc = Api<T>::by_key_multi(cx.data(), (int)cx.size(), slices, ptrs.data(), ikey, n_feat, n, &prm, cap, keys.data(),
+                                              as<T>(cobuf), nulls.data(), &ng);
+                } else {
+                    rc = Api<T>::by_key(thread_ctx(), ptrs.data(), ikey, n_feat, n, PDS_HOST, &prm, cap, keys.data(), as<T>(cobuf),
+                                        nulls.data(), &ng);
+                }
                 if (rc != 0 && attempt == 0 && ng > cap) {
                     cap = ng;
                     continue;

@@ -671,6 +671,46 @@ def lin_reg_by_key(*x, target, key, add_bias: bool = False, l1_reg: float = 0.0,
     return ok[:g], coeffs[:g], nulls[:g]
 
 
+def lin_reg_by_key_multi(*x, target, key, contexts, n_slices: int = 0, add_bias: bool = False, l1_reg: float = 0.0, l2_reg: float = 0.0,
+                         tol: float = 1e-5, solver: str = "qr", max_iter: int = 200, positive: bool = False,
+                         singular_x_tol: float | None = None, max_groups: int | None = None):
+    """
+    `lin_reg_by_key` for a HOST frame whose keys are in order, driven through several contexts from this one process
+    (pds_lr_by_key_multi_*): the frame is cut into row slices at group boundaries and slice s is fitted by contexts[s mod n] on
+    that context's device -- contexts on different devices pull their shards over their own PCIe links,
+    several contexts on one device overlap a slice's transfer with the previous slice's fit.  Same results as `lin_reg_by_key`.
+    Returns (keys, coeffs, is_null) as numpy arrays.
+    """
+    if max_iter <= 0:
+        raise ValueError("Input `max_iter` must be a positive.")
+    cols = _Cols(target, x)
+    if cols.space != _lib.PDS_HOST:
+        raise ValueError("lin_reg_by_key_multi takes host-resident columns (numpy)")
+    prm = _params(add_bias, l1_reg, l2_reg, tol, solver, positive, max_iter, singular_x_tol)
+    pp = cols.n_feat + int(bool(add_bias))
+    n_rows = cols.n_rows
+    k = np.ascontiguousarray(np.asarray(key), dtype=np.int64)
+    if int(k.shape[0]) != n_rows:
+        raise ValueError("`key` must have one entry per row")
+    cap = int(max_groups) if max_groups is not None else (n_rows if n_rows <= (1 << 20) else max(1 << 20, n_rows // 16))
+    handles = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+    ng = C.c_int64(0)
+    fn = contexts[0].fn("pds_lr_by_key_multi")
+    while True:
+        ok = np.empty(cap, dtype=np.int64)
+        coeffs = np.empty((cap, pp), dtype=_dtype())
+        nulls = np.empty(cap, dtype=np.uint8)
+        rc = fn(handles, len(contexts), int(n_slices), cols.cols, C.c_void_p(k.ctypes.data), cols.n_feat, C.c_int64(n_rows), C.byref(prm),
+                C.c_int64(cap), C.c_void_p(ok.ctypes.data), C.c_void_p(coeffs.ctypes.data), C.c_void_p(nulls.ctypes.data), C.byref(ng))
+        if rc != 0 and max_groups is None and int(ng.value) > cap:
+            cap = int(ng.value)
+            continue
+        _lib.check(rc)
+        break
+    g = int(ng.value)
+    return ok[:g], coeffs[:g], nulls[:g]
+
+
 def _offsets_arg(cols: "_Cols", group_offsets):
     if cols.space == _lib.PDS_DEVICE:
         import torch
