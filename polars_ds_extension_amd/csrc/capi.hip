@@ -10,6 +10,8 @@
 #include <cstdlib>
 #include <mutex>
 
+#include <hipcub/hipcub.hpp>
+
 #include "common.hpp"
 
 namespace pds {

@@ -354,6 +354,38 @@ static int grouped_weighted_impl(pds_ctx* ctx, const T* const* cols, const T* we
 // ---------------------------------------------------------------------------------------------
 // grouped by an int64 key column in any row order (keyed.hip brings the frame into key order on the device)
 // ---------------------------------------------------------------------------------------------
+// keyed_partition.hip's moment table -> coefficients: chunks of groups expanded to (p+2)^2 records (a chunk stays inside the
+// Infinity Cache between the expansion and the solve), then what grouped_impl does with grouped Gram records -- the batched
+// pivoted QR / Cholesky with the rank gate, coordinate descent or NNLS, per pl_lr's dispatch (linear_regression.rs:447-497)
+template <typename T>
+static int solve_partition_table(pds_ctx* ctx, const KeyedPartitionState& st, int n_feat, int64_t n_groups, const int64_t* d_offsets,
+                                 const pds_lr_params* prm, T* d_coeffs, uint8_t* d_null) {
+    const Method method = pick_method(prm);
+    const int bias = prm->add_bias ? 1 : 0, pp = n_feat + bias, q = n_feat + 2;
+    int64_t chunk = std::max<int64_t>(4096, (int64_t)(128ll << 20) / (int64_t)(sizeof(T) * q * q));
+    chunk = std::min(chunk, n_groups);
+    if (int rc = ws_reserve(ctx, 131072 + sizeof(T) * (size_t)chunk * q * q)) return rc;
+    T* d_mom = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * (size_t)chunk * q * q));
+    SolveParams sp{n_feat, bias, prm->solver == PDS_SOLVER_SVD ? PDS_SOLVER_QR : prm->solver, prm->l2_reg, prm->singular_x_tol, 0};
+    const bool f32 = sizeof(T) == 4;
+    for (int64_t g0 = 0; g0 < n_groups; g0 += chunk) {
+        const int64_t gc = std::min(chunk, n_groups - g0);
+        if (int rc = keyed_partition_records<T>(ctx, st, n_feat, g0, gc, d_mom)) return rc;
+        KernelTimer timer(ctx, kKindSolve);
+        if (method.kind == Method::OLS) {
+            if (int rc = launch_solve<T>(ctx, d_mom, gc, sp, d_coeffs + g0 * pp, d_null + g0, nullptr, d_offsets + g0)) return rc;
+        } else if (method.kind == Method::NNLS) {
+            if (int rc = launch_nnls<T>(ctx, d_mom, n_feat, bias, prm->tol, f32 ? 200 : prm->max_iter, d_coeffs + g0 * pp, gc, d_null + g0,
+                                        d_offsets + g0))
+                return rc;
+        } else if (int rc = launch_cd<T>(ctx, d_mom, n_feat, bias, method.l1, method.l2, prm->tol, f32 ? 2000 : prm->max_iter, method.positive,
+                                         d_coeffs + g0 * pp, nullptr, gc, d_null + g0, d_offsets + g0)) {
+            return rc;
+        }
+    }
+    return PDS_OK;
+}
+
 // Where a slice of a frame that is fitted in several pieces (capi_multi.hpp) puts its results: asked once the slice's number of
 // groups is known, before the fit.  `unsorted()` reports that the slice's keys are not in order (the pieces are then meaningless).
 template <typename T>
@@ -403,22 +435,41 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
         place->unsorted();
         return fail(PDS_ERR_UNSUPPORTED, "sliced fit: the slice's keys are not in order");
     }
+    // ---- keys in any order: smallest / largest key decide the route.  Dense integer keys (group ids) of an unweighted
+    // coefficient fit with up to 16 features take the partition route (keyed_partition.hip: no sort, no random-access pass);
+    // PDS_KEYED_SORT=1 keeps the sorting route (A/B)
+    int64_t mm[2] = {0, 0};
+    int64_t* d_minmax = nullptr;
+    int64_t part_buckets = 0;
+    if (!sorted) {
+        size_t tb = 0;
+        (void)hipcub::DeviceReduce::Min(nullptr, tb, (const int64_t*)nullptr, (int64_t*)nullptr, (int)std::min<int64_t>(n_rows, INT32_MAX));
+        if (int rc = ensure_ws(ctx, ctx->solve_ws, 8192 + tb)) return rc;
+        d_minmax = reinterpret_cast<int64_t*>(static_cast<char*>(ctx->solve_ws.ptr) + 256);
+        if (int rc = keyed_minmax(ctx, d_keys, n_rows, static_cast<char*>(ctx->solve_ws.ptr) + 4096, tb, d_minmax, mm)) return rc;
+        static const bool force_sort = [] { const char* e = std::getenv("PDS_KEYED_SORT"); return e && e[0] == '1'; }();
+        if (!force_sort && !weights && !want_pred)
+            part_buckets = keyed_partition_buckets<T>(n_feat, n_rows, (uint64_t)mm[1] - (uint64_t)mm[0] + 1);
+    }
+    const bool partition = part_buckets > 0;
     // ---- workspace: [raw columns (host frames)] [sorted keys, index in/out, gathered columns (unsorted frames)] runs, temp
     const int64_t cap = std::min<int64_t>(max_groups, n_rows);
     const size_t temp_bytes = keyed_temp_bytes(n_rows);
-    size_t need = temp_bytes + 3 * up((size_t)(n_rows + 1) * 8) + 8192;  // unique keys, counts, offsets (at most one per row)
+    const int64_t run_cap = partition ? cap : n_rows;  // unique keys, counts, offsets: at most one per row / per group
+    size_t need = temp_bytes + 3 * up((size_t)(run_cap + 1) * 8) + 8192;
     if (space == PDS_HOST) need += col_bytes * nc;
     if (space == PDS_HOST || !coeffs) need += up((size_t)cap * pp * sizeof(T)) + up((size_t)cap);
-    if (!sorted) need += 2 * key_bytes + 2 * idx_bytes + col_bytes * nc + up((size_t)n_rows * nc * sizeof(T)) + up(2 * (size_t)nc * sizeof(T*)) + 1024;
+    if (partition) need += keyed_partition_workspace<T>(n_feat, n_rows, part_buckets) + up(sizeof(T*) * (size_t)std::max(nc, 18));
+    else if (!sorted) need += 2 * key_bytes + 2 * idx_bytes + col_bytes * nc + up((size_t)n_rows * nc * sizeof(T)) + up(2 * (size_t)nc * sizeof(T*)) + 1024;
     if (want_pred) need += up(sizeof(T*) * (size_t)std::max(nc, 18)) + (space == PDS_HOST ? 2 * col_bytes + up((size_t)n_rows) : 0);
     if (int rc = ensure_ws(ctx, ctx->keyed, need)) return rc;
     tr.mark("workspace");
     char* w = static_cast<char*>(ctx->keyed.ptr);
     auto take = [&](size_t b) { char* r = w; w += up(b); return r; };
     void* d_temp = take(temp_bytes);
-    int64_t* d_unique = reinterpret_cast<int64_t*>(take((size_t)(n_rows + 1) * 8));
-    int64_t* d_counts = reinterpret_cast<int64_t*>(take((size_t)(n_rows + 1) * 8));
-    int64_t* d_offsets = reinterpret_cast<int64_t*>(take((size_t)(n_rows + 1) * 8));
+    int64_t* d_unique = reinterpret_cast<int64_t*>(take((size_t)(run_cap + 1) * 8));
+    int64_t* d_counts = reinterpret_cast<int64_t*>(take((size_t)(run_cap + 1) * 8));
+    int64_t* d_offsets = reinterpret_cast<int64_t*>(take((size_t)(run_cap + 1) * 8));
     int64_t* d_nruns = reinterpret_cast<int64_t*>(take(256));
     std::vector<const T*> src(nc);  // reference order [y, x1..xp, (w)], device resident
     for (int c = 0; c < n_feat + 1; ++c) src[c] = cols[c];
@@ -430,6 +481,39 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
             src[c] = d;
         }
     tr.mark("columns H2D");
+    if (partition) {
+        std::vector<const T*> tbl((size_t)std::max(nc, 18), src[0]);
+        for (int c = 0; c < n_feat; ++c) tbl[c] = src[c + 1];
+        tbl[n_feat] = src[0];
+        const T** d_tbl = reinterpret_cast<const T**>(take(sizeof(T*) * tbl.size()));
+        PDS_HIP_CHECK(hipMemcpyAsync(d_tbl, tbl.data(), sizeof(T*) * tbl.size(), hipMemcpyHostToDevice, ctx->stream));
+        char* pws = take(keyed_partition_workspace<T>(n_feat, n_rows, part_buckets));
+        KeyedPartitionState st;
+        int64_t ng = 0;
+        const int rc0 = keyed_partition_build<T>(ctx, d_tbl, d_keys, d_minmax, (uint64_t)mm[1] - (uint64_t)mm[0] + 1, n_feat, n_rows, part_buckets,
+                                                 pws, cap, d_unique, d_offsets, &ng, st);
+        if (n_groups) *n_groups = ng;
+        if (rc0) return rc0;
+        tr.mark("partition + moments");
+        if (place)
+            if (int rc = place->at(ng, &out_keys, &coeffs, &is_null)) return rc;
+        T* d_co = coeffs;
+        uint8_t* d_nu = is_null;
+        if (space == PDS_HOST || !coeffs) d_co = reinterpret_cast<T*>(take((size_t)cap * pp * sizeof(T)));
+        if (space == PDS_HOST || !is_null) d_nu = reinterpret_cast<uint8_t*>(take((size_t)cap));
+        if (int rc = solve_partition_table<T>(ctx, st, n_feat, ng, d_offsets, prm, d_co, d_nu)) return rc;
+        tr.mark("solve");
+        if (space == PDS_HOST) {
+            if (coeffs) PDS_HIP_CHECK(hipMemcpyAsync(coeffs, d_co, (size_t)ng * pp * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+            if (coeffs && is_null) PDS_HIP_CHECK(hipMemcpyAsync(is_null, d_nu, (size_t)ng, hipMemcpyDeviceToHost, ctx->stream));
+            if (out_keys) PDS_HIP_CHECK(hipMemcpyAsync(out_keys, d_unique, (size_t)ng * 8, hipMemcpyDeviceToHost, ctx->stream));
+        } else if (out_keys) {
+            PDS_HIP_CHECK(hipMemcpyAsync(out_keys, d_unique, (size_t)ng * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        tr.mark("results D2H");
+        return PDS_OK;
+    }
     const int64_t* d_sorted_keys = d_keys;
     const uint32_t* d_perm = nullptr;
     if (!sorted) {
@@ -437,8 +521,7 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
         uint32_t* idx_in = reinterpret_cast<uint32_t*>(take((size_t)n_rows * 4));
         uint32_t* perm = reinterpret_cast<uint32_t*>(take((size_t)n_rows * 4));
         int64_t* sk2 = reinterpret_cast<int64_t*>(take((size_t)n_rows * 8));
-        int64_t* mm = reinterpret_cast<int64_t*>(take(256));
-        if (int rc = keyed_sort(ctx, d_keys, n_rows, idx_in, sk, perm, d_temp, temp_bytes, sk2, mm)) return rc;
+        if (int rc = keyed_sort(ctx, d_keys, n_rows, idx_in, sk, perm, d_temp, temp_bytes, sk2, d_minmax, mm)) return rc;
         d_sorted_keys = sk;
         d_perm = perm;
         static const bool by_column = [] { const char* e = std::getenv("PDS_KEYED_GATHER_BY_COLUMN"); return e && e[0] == '1'; }();

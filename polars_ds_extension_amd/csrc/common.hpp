@@ -288,8 +288,25 @@ size_t rolling_wide_workspace(int n_feat, int64_t n_rows, size_t elem);
 // ---- keyed.hip: int64 keys in any row order -> sorted keys, permutation, distinct keys, group offsets
 int keys_nondecreasing(pds_ctx* ctx, const int64_t* d_keys, int64_t n, unsigned* d_flag, bool* sorted);
 size_t keyed_temp_bytes(int64_t n);
+int keyed_minmax(pds_ctx* ctx, const int64_t* d_keys, int64_t n, void* d_temp, size_t temp_bytes, int64_t* d_minmax, int64_t* mm);
 int keyed_sort(pds_ctx* ctx, const int64_t* d_keys, int64_t n, uint32_t* d_idx_in, int64_t* d_sorted_keys, uint32_t* d_perm,
-               void* d_temp, size_t temp_bytes, int64_t* d_scratch_keys, int64_t* d_minmax);
+               void* d_temp, size_t temp_bytes, int64_t* d_scratch_keys, const int64_t* d_minmax, const int64_t* mm);
+// ---- keyed_partition.hip: grouped moments of a frame in any row order without sorting its rows (dense integer keys)
+struct KeyedPartitionState {
+    double* table = nullptr;   // [ids][nvp]: upper triangle of Z'Z, Z = [x_0..x_{pc-1}, 1, y], per dense id
+    unsigned* ids = nullptr;   // dense id of group r (ascending)
+    int pc = 0, nvp = 0;
+};
+template <typename T>
+int64_t keyed_partition_buckets(int n_feat, int64_t n_rows, uint64_t range);  // 0: not applicable (the sorting route)
+template <typename T>
+size_t keyed_partition_workspace(int n_feat, int64_t n_rows, int64_t n_buckets);
+template <typename T>
+int keyed_partition_build(pds_ctx* ctx, const T* const* d_cols, const int64_t* d_keys, const int64_t* d_kmin, uint64_t range, int n_feat,
+                          int64_t n_rows, int64_t n_buckets, char* ws, int64_t max_groups, int64_t* d_out_keys, int64_t* d_offsets,
+                          int64_t* n_groups, KeyedPartitionState& st);
+template <typename T>
+int keyed_partition_records(pds_ctx* ctx, const KeyedPartitionState& st, int n_feat, int64_t g0, int64_t gc, T* d_records);
 int keyed_runs(pds_ctx* ctx, const int64_t* d_sorted_keys, int64_t n, int64_t* d_unique, int64_t* d_counts, int64_t* d_offsets,
                int64_t* d_nruns, void* d_temp, size_t temp_bytes, int64_t* n_groups);
 template <typename T>

@@ -159,17 +159,22 @@ __global__ __launch_bounds__(256) void widen_keys_kernel(const uint32_t* __restr
         out[i] = (int64_t)((uint64_t)in[i] + base);
 }
 
-// (key, row) radix sort: d_sorted_keys / d_perm out; d_idx_in is scratch of n uint32; d_scratch_keys n int64; d_minmax 2 int64
+// smallest and largest key: d_minmax[0..1] on the device, mm[0..1] on the host (one stream synchronisation)
+int keyed_minmax(pds_ctx* ctx, const int64_t* d_keys, int64_t n, void* d_temp, size_t temp_bytes, int64_t* d_minmax, int64_t* mm) {
+    PDS_HIP_CHECK(hipcub::DeviceReduce::Min(d_temp, temp_bytes, d_keys, d_minmax, (int)n, ctx->stream));
+    PDS_HIP_CHECK(hipcub::DeviceReduce::Max(d_temp, temp_bytes, d_keys, d_minmax + 1, (int)n, ctx->stream));
+    PDS_HIP_CHECK(hipMemcpyAsync(mm, d_minmax, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PDS_OK;
+}
+
+// (key, row) radix sort: d_sorted_keys / d_perm out; d_idx_in is scratch of n uint32; d_scratch_keys n int64; d_minmax / mm: the
+// result of keyed_minmax
 int keyed_sort(pds_ctx* ctx, const int64_t* d_keys, int64_t n, uint32_t* d_idx_in, int64_t* d_sorted_keys, uint32_t* d_perm,
-               void* d_temp, size_t temp_bytes, int64_t* d_scratch_keys, int64_t* d_minmax) {
+               void* d_temp, size_t temp_bytes, int64_t* d_scratch_keys, const int64_t* d_minmax, const int64_t* mm) {
     const int nb = (int)std::min<int64_t>(std::max<int64_t>((n + 255) / 256, 1), (int64_t)ctx->num_cus * 16);
     hipLaunchKernelGGL(iota_u32_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_idx_in, n);
     // key range -> number of significant bits of (key - min): a million groups sort in 3 radix passes instead of 8
-    PDS_HIP_CHECK(hipcub::DeviceReduce::Min(d_temp, temp_bytes, d_keys, d_minmax, (int)n, ctx->stream));
-    PDS_HIP_CHECK(hipcub::DeviceReduce::Max(d_temp, temp_bytes, d_keys, d_minmax + 1, (int)n, ctx->stream));
-    int64_t mm[2] = {0, 0};
-    PDS_HIP_CHECK(hipMemcpyAsync(mm, d_minmax, sizeof(mm), hipMemcpyDeviceToHost, ctx->stream));
-    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     const uint64_t range = (uint64_t)mm[1] - (uint64_t)mm[0];
     int bits = 1;
     while (bits < 64 && (range >> bits) != 0) ++bits;

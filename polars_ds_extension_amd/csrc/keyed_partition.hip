@@ -1,0 +1,419 @@
+// keyed_partition.hip -- grouped fits of a frame whose rows are in ANY order, without sorting the rows.
+//
+// keyed.hip brings such a frame into key order: a radix sort of (key, row) pairs, a transposition of the frame to row-major
+// records and a gather of the records through the permutation -- 1e8 random 72-byte reads, which run at the random-access
+// rate of the HBM stacks (6.75 of the 14.7 ms of the 1e6-group x ~100-row x 8-feature frame, profiles/r02_keyed_*).  A group's
+// fit does not need its rows in order, or even adjacent: it needs their MOMENTS.  So, for integer keys whose range is not
+// much wider than the frame is long (group ids: the usual case; anything else keeps the sorting route):
+//
+//   1. histogram   dense id = key - min; bucket = id >> shift, a bucket = the 2^shift ids whose moment records fit LDS
+//                  together; rows counted per (bucket, stream), stream = the XCD a block runs on (its index mod 8);
+//   2. scatter     ONE pass over the frame: every row becomes a record [x_0 .. x_{p-1}, y | id in bucket, row] appended to its
+//                  (bucket, stream) region.  A region is written front to back by the blocks of one XCD only, so its open
+//                  cache line sits in that XCD's L2 until it is full: the 4096-way scatter leaves the chip as whole lines.
+//                  A wave stages its 64 records in LDS and writes them piece-cooperatively (the lanes that share a record
+//                  write its 16-byte pieces side by side);
+//   3. accumulate  a workgroup streams (a chunk of) one bucket's records and adds every row's outer product z z',
+//                  z = [x, 1, y], to that id's moment record in LDS (ds_add_f64: hardware atomics, conflict-free banks by an
+//                  odd record stride), then adds the non-empty records to the id-indexed table in HBM (global_atomic_add_f64);
+//   4. compact     ids with rows -> groups in ascending key order: distinct keys, sizes, offsets;
+//   5. solve       chunks of groups: the table's upper triangles expanded to the (p+2)^2 records the batched solvers take
+//                  (solve.hip / solve_reg.hip: the reference's pivoted QR with the log-det gate by default) -> coefficients.
+//
+// Traffic: keys once more (histogram), the frame once (scatter in), records out and in: ~3.4x the frame instead of ~5x plus a
+// random-access pass.  Summation order inside a group follows the arrival of the atomics: results agree with the sorting route
+// to rounding (tests hold both to 1e-10 against the oracle), not bit for bit, and not run to run.
+#include <hipcub/hipcub.hpp>
+#include <type_traits>
+
+#include "common.hpp"
+
+namespace pds {
+
+namespace {
+
+constexpr int kPartStreams = 8;        // one per XCD
+constexpr int kPartChunkRows = 4096;   // rows a block takes at a time (histogram and scatter use the same chunk -> stream map)
+constexpr int kPartLdsBytes = 128 * 1024;
+constexpr int kPartAccumChunk = 16384; // records per accumulate workgroup
+
+__host__ __device__ constexpr int tri_count(int q) { return q * (q + 1) / 2; }
+__host__ __device__ constexpr int tri_index(int i, int j, int q) { return i * q - (i * (i - 1)) / 2 + (j - i); }  // i <= j
+
+struct PartLayout {
+    int pc;        // padded feature count (compile-time variant of the accumulate kernel)
+    int qp;        // pc + 2
+    int nv;        // tri_count(qp)
+    int nvp;       // nv | 1: odd stride of a moment record in LDS / in the table
+    int meta_off;  // byte offset of {u32 id in bucket, u32 row} in a record
+    int rs;        // record bytes (multiple of 16)
+    int shift;     // log2(ids per bucket)
+};
+
+inline int padded_features(int p) {
+    static const int steps[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16};
+    for (int s : steps)
+        if (p <= s) return s;
+    return -1;
+}
+
+template <typename T>
+PartLayout make_layout(int p) {
+    PartLayout L;
+    L.pc = padded_features(p);
+    L.qp = L.pc + 2;
+    L.nv = tri_count(L.qp);
+    L.nvp = L.nv | 1;
+    L.meta_off = ((L.pc + 1) * (int)sizeof(T) + 7) & ~7;
+    L.rs = (L.meta_off + 8 + 15) & ~15;
+    int shift = 0;
+    while (((size_t)2 << shift) * L.nvp * 8 <= (size_t)kPartLdsBytes) ++shift;
+    L.shift = shift;
+    return L;
+}
+
+// ---- 1. histogram: counts[bucket * 8 + stream]
+__global__ __launch_bounds__(256) void part_hist_kernel(const int64_t* __restrict__ keys, int64_t n, const int64_t* __restrict__ kmin,
+                                                        int shift, int64_t n_buckets, unsigned* __restrict__ counts) {
+    extern __shared__ unsigned hist_lds[];
+    for (int64_t b = threadIdx.x; b < n_buckets; b += 256) hist_lds[b] = 0u;
+    __syncthreads();
+    const uint64_t base = (uint64_t)*kmin;
+    const int64_t nchunks = (n + kPartChunkRows - 1) / kPartChunkRows;
+    for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const int64_t r0 = c * kPartChunkRows, r1 = (r0 + kPartChunkRows < n) ? r0 + kPartChunkRows : n;
+        for (int64_t r = r0 + threadIdx.x; r < r1; r += 256) {
+            const uint64_t id = (uint64_t)__builtin_nontemporal_load(keys + r) - base;
+            atomicAdd(&hist_lds[id >> shift], 1u);
+        }
+    }
+    __syncthreads();
+    const int stream = blockIdx.x & (kPartStreams - 1);
+    for (int64_t b = threadIdx.x; b < n_buckets; b += 256) {
+        const unsigned v = hist_lds[b];
+        if (v) atomicAdd(&counts[b * kPartStreams + stream], v);
+    }
+}
+
+// ---- 2. scatter.  PPR = 16-byte pieces per record.
+template <typename T, int PPR>
+__global__ __launch_bounds__(256) void part_scatter_kernel(const T* const* __restrict__ cols /*x_0..x_{p-1}, y*/, int p, int pc,
+                                                           const int64_t* __restrict__ keys, int64_t n,
+                                                           const int64_t* __restrict__ kmin, int shift, int meta_off,
+                                                           unsigned* __restrict__ cursor, char* __restrict__ records) {
+    constexpr int RS = PPR * 16;
+    __shared__ __attribute__((aligned(16))) char stage[4][64 * RS];
+    __shared__ unsigned pos_lds[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    char* st = stage[wv];
+    const uint64_t base = (uint64_t)*kmin;
+    const unsigned idmask = (1u << shift) - 1u;
+    const int stream = blockIdx.x & (kPartStreams - 1);
+    const int64_t nchunks = (n + kPartChunkRows - 1) / kPartChunkRows;
+    for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const int64_t r0 = c * kPartChunkRows, r1 = (r0 + kPartChunkRows < n) ? r0 + kPartChunkRows : n;
+        for (int64_t rb = r0 + (int64_t)wv * 64; rb < r1; rb += 256) {
+            const int64_t r = rb + lane;
+            const bool in = r < r1;
+            // ---- the lane's row -> its record in the wave's LDS stage
+            if (in) {
+                const uint64_t id = (uint64_t)__builtin_nontemporal_load(keys + r) - base;
+                const unsigned pos = atomicAdd(&cursor[(id >> shift) * kPartStreams + stream], 1u);
+                pos_lds[wv][lane] = pos;
+                T* rec = reinterpret_cast<T*>(st + lane * RS);
+                for (int cc = 0; cc < p; ++cc) rec[cc] = __builtin_nontemporal_load(as_global(cols[cc]) + r);
+                for (int cc = p; cc < pc; ++cc) rec[cc] = T(0);
+                rec[pc] = __builtin_nontemporal_load(as_global(cols[p]) + r);
+                unsigned* meta = reinterpret_cast<unsigned*>(st + lane * RS + meta_off);
+                meta[0] = (unsigned)id & idmask;
+                meta[1] = (unsigned)r;
+            }
+            PDS_WAVE_LDS_SYNC();
+            // ---- piece-cooperative write: piece j of the wave's stage belongs to record j / PPR
+            const int nrec = (int)((r1 - rb < 64) ? r1 - rb : 64);
+#pragma unroll
+            for (int k = 0; k < PPR; ++k) {
+                const int j = k * 64 + lane;
+                const int rec = j / PPR, piece = j - rec * PPR;
+                if (rec < nrec) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(st + j * 16);
+                    *reinterpret_cast<uint4*>(records + (size_t)pos_lds[wv][rec] * RS + piece * 16) = v;
+                }
+            }
+            PDS_WAVE_LDS_SYNC();
+        }
+    }
+}
+
+// ---- 3. accumulate.  One workgroup per (bucket, chunk of kPartAccumChunk records).
+template <typename T, int PC>
+__global__ __launch_bounds__(256) void part_accum_kernel(const char* __restrict__ records, const unsigned* __restrict__ bucket_start /*n_buckets * 8 + 1*/,
+                                                         const unsigned* __restrict__ chunk_prefix /*n_buckets + 1*/, int64_t n_buckets,
+                                                         int shift, int meta_off, int rs, double* __restrict__ table) {
+    constexpr int QP = PC + 2, NV = tri_count(QP), NVP = NV | 1;
+    extern __shared__ double mom_lds[];
+    const unsigned total_chunks = chunk_prefix[n_buckets];
+    const unsigned w = blockIdx.x;
+    if (w >= total_chunks) return;
+    // bucket of work item w: last b with chunk_prefix[b] <= w
+    int64_t lo = 0, hi = n_buckets;
+    while (hi - lo > 1) {
+        const int64_t mid = lo + ((hi - lo) >> 1);
+        if (chunk_prefix[mid] <= w) lo = mid;
+        else hi = mid;
+    }
+    const int64_t bucket = lo;
+    const unsigned chunk = w - chunk_prefix[bucket];
+    const int64_t b0 = bucket_start[bucket * kPartStreams], b1 = bucket_start[(bucket + 1) * kPartStreams];
+    const int64_t r0 = b0 + (int64_t)chunk * kPartAccumChunk, r1 = (r0 + kPartAccumChunk < b1) ? r0 + kPartAccumChunk : b1;
+    const int gpb = 1 << shift;
+    for (int i = threadIdx.x; i < gpb * NVP; i += 256) mom_lds[i] = 0.0;
+    __syncthreads();
+    typedef __attribute__((address_space(3))) double* lds_d;
+    for (int64_t r = r0 + threadIdx.x; r < r1; r += 256) {
+        const char* rec = records + (size_t)r * rs;
+        double z[QP];
+        const T* vals = reinterpret_cast<const T*>(rec);
+#pragma unroll
+        for (int c = 0; c < PC; ++c) z[c] = (double)vals[c];
+        z[PC] = 1.0;
+        z[PC + 1] = (double)vals[PC];
+        const unsigned lid = *reinterpret_cast<const unsigned*>(rec + meta_off);
+        double* m = mom_lds + (size_t)lid * NVP;
+        int v = 0;
+#pragma unroll
+        for (int a = 0; a < QP; ++a) {
+#pragma unroll
+            for (int b = a; b < QP; ++b) {
+                __builtin_amdgcn_ds_atomic_fadd_f64((lds_d)(m + v), z[a] * z[b]);
+                ++v;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- non-empty ids -> the table (several chunks of one bucket, and nobody else, meet here)
+    constexpr int CNT = tri_index(PC, PC, QP);
+    double* tb = table + (size_t)bucket * gpb * NVP;
+    for (int i = threadIdx.x; i < gpb * NVP; i += 256) {
+        const int lid = i / NVP;
+        if (mom_lds[lid * NVP + CNT] > 0.0) {
+            const double v = mom_lds[i];
+            if (v != 0.0) unsafeAtomicAdd(tb + i, v);
+        }
+    }
+}
+
+// ---- 4. compaction helpers
+template <int DUMMY = 0>
+__global__ __launch_bounds__(256) void part_flags_kernel(const double* __restrict__ table, int64_t n_ids, int nvp, int cnt_index,
+                                                         unsigned* __restrict__ flags) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_ids; i += (int64_t)gridDim.x * 256)
+        flags[i] = table[(size_t)i * nvp + cnt_index] > 0.0 ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void part_compact_kernel(const double* __restrict__ table, int64_t n_ids, int nvp, int cnt_index,
+                                                           const unsigned* __restrict__ rank, const int64_t* __restrict__ kmin,
+                                                           int64_t max_groups, int64_t* __restrict__ out_keys,
+                                                           unsigned* __restrict__ ids, int64_t* __restrict__ sizes) {
+    const uint64_t base = (uint64_t)*kmin;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_ids; i += (int64_t)gridDim.x * 256) {
+        const double c = table[(size_t)i * nvp + cnt_index];
+        if (c > 0.0) {
+            const unsigned r = rank[i];
+            if ((int64_t)r < max_groups) {
+                out_keys[r] = (int64_t)(base + (uint64_t)i);
+                ids[r] = (unsigned)i;
+                sizes[r] = (int64_t)(c + 0.5);
+            }
+        }
+    }
+}
+__global__ void part_close_offsets_kernel(int64_t* __restrict__ off, int64_t ng, int64_t n) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) off[ng] = n;
+}
+__global__ __launch_bounds__(256) void part_chunk_counts_kernel(const unsigned* __restrict__ bucket_start, int64_t n_buckets,
+                                                                unsigned* __restrict__ chunks) {
+    for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < n_buckets; b += (int64_t)gridDim.x * 256) {
+        const unsigned sz = bucket_start[(b + 1) * kPartStreams] - bucket_start[b * kPartStreams];
+        chunks[b] = (sz + kPartAccumChunk - 1) / kPartAccumChunk;
+    }
+}
+
+// ---- 5. table rows (upper triangles over [x_0..x_{PC-1}, 1, y]) -> (p+2)^2 records over [x_0..x_{p-1}, 1, y]
+template <typename T>
+__global__ __launch_bounds__(256) void part_expand_kernel(const double* __restrict__ table, const unsigned* __restrict__ ids, int64_t g0,
+                                                          int64_t gc, int p, int pc, int nvp, T* __restrict__ recs) {
+    const int q = p + 2, qp = pc + 2;
+    const int64_t total = gc * q * q;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t g = e / (q * q);
+        const int ij = (int)(e - g * q * q);
+        int i = ij % q, j = ij / q;
+        if (i > j) {
+            const int t = i;
+            i = j;
+            j = t;
+        }
+        const int pi = i < p ? i : pc + (i - p), pj = j < p ? j : pc + (j - p);
+        recs[e] = (T)table[(size_t)ids[g0 + g] * nvp + tri_index(pi, pj, qp)];
+    }
+}
+
+template <typename T, int PPR>
+void launch_scatter(dim3 g, hipStream_t st, const T* const* cols, int p, const PartLayout& L, const int64_t* keys, int64_t n,
+                    const int64_t* kmin, unsigned* cursor, char* records) {
+    hipLaunchKernelGGL((part_scatter_kernel<T, PPR>), g, dim3(256), 0, st, cols, p, L.pc, keys, n, kmin, L.shift, L.meta_off, cursor, records);
+}
+template <typename T, int PC>
+int launch_accum(pds_ctx* ctx, unsigned grid, const PartLayout& L, const char* records, const unsigned* bucket_start,
+                 const unsigned* chunk_prefix, int64_t n_buckets, double* table) {
+    const size_t lds = ((size_t)1 << L.shift) * L.nvp * 8;
+    auto kern = part_accum_kernel<T, PC>;
+    if (lds > 64 * 1024) PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx->stream, records, bucket_start, chunk_prefix, n_buckets, L.shift, L.meta_off, L.rs,
+                       table);
+    PDS_HIP_CHECK(hipGetLastError());
+    return PDS_OK;
+}
+
+}  // namespace
+
+// Is the partition route applicable?  range = max - min + 1 of the keys (host); returns the bucket count or 0.
+template <typename T>
+int64_t keyed_partition_buckets(int n_feat, int64_t n_rows, uint64_t range) {
+    if (n_feat < 1 || n_feat > 16 || n_rows < (int64_t)1 << 16 || n_rows >= ((int64_t)1 << 31)) return 0;
+    if (range == 0 || range > ((uint64_t)1 << 31) || range > (uint64_t)n_rows * 4) return 0;  // sparse keys: the sorting route
+    const PartLayout L = make_layout<T>(n_feat);
+    const int64_t nb = (int64_t)((range + ((uint64_t)1 << L.shift) - 1) >> L.shift);
+    if (nb > kPartLdsBytes / 4) return 0;  // (the histogram of one block lives in LDS)
+    // the id-indexed moment table (one upper triangle per POSSIBLE key) must stay within twice the frame's own size and 16 GiB
+    const uint64_t table_bytes = ((uint64_t)nb << L.shift) * (uint64_t)L.nvp * 8;
+    if (table_bytes > 2 * (uint64_t)n_rows * (uint64_t)(n_feat + 1) * sizeof(T) || table_bytes > ((uint64_t)16 << 30)) return 0;
+    return nb;
+}
+template int64_t keyed_partition_buckets<double>(int, int64_t, uint64_t);
+template int64_t keyed_partition_buckets<float>(int, int64_t, uint64_t);
+
+template <typename T>
+size_t keyed_partition_workspace(int n_feat, int64_t n_rows, int64_t n_buckets) {
+    const PartLayout L = make_layout<T>(n_feat);
+    const size_t ids = (size_t)n_buckets << L.shift;
+    size_t temp = 0, t2 = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, temp, (const unsigned*)nullptr, (unsigned*)nullptr, (int)std::min<size_t>(ids + 1, INT32_MAX));
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t2, (const int64_t*)nullptr, (int64_t*)nullptr, (int)std::min<size_t>(ids + 1, INT32_MAX));
+    temp = std::max(temp, t2);
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    return up((size_t)n_rows * L.rs) + up(ids * L.nvp * 8) + 3 * up(((size_t)n_buckets * kPartStreams + 1) * 4) + 2 * up(((size_t)n_buckets + 1) * 4) +
+           2 * up((ids + 1) * 4) + up(ids * 4) + up(temp) + 8192;
+}
+template size_t keyed_partition_workspace<double>(int, int64_t, int64_t);
+template size_t keyed_partition_workspace<float>(int, int64_t, int64_t);
+
+// The whole route up to the moment table and the group list.  d_cols: DEVICE table in kernel order (x_0..x_{p-1}, y).
+//   out: *n_groups (host; a stream synchronisation), d_out_keys / d_sizes_as_offsets (n_groups + 1, exclusive scan + n) for up to
+//   max_groups groups, and the handles the solve stage needs (table, ids, layout) in `st`.
+template <typename T>
+int keyed_partition_build(pds_ctx* ctx, const T* const* d_cols, const int64_t* d_keys, const int64_t* d_kmin, uint64_t range, int n_feat,
+                          int64_t n_rows, int64_t n_buckets, char* ws, int64_t max_groups, int64_t* d_out_keys, int64_t* d_offsets,
+                          int64_t* n_groups, KeyedPartitionState& st) {
+    const PartLayout L = make_layout<T>(n_feat);
+    const size_t ids = (size_t)n_buckets << L.shift;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    auto take = [&](size_t b) { char* r = ws; ws += up(b); return r; };
+    char* records = take((size_t)n_rows * L.rs);
+    double* table = reinterpret_cast<double*>(take(ids * L.nvp * 8));
+    const size_t ncnt = (size_t)n_buckets * kPartStreams + 1;
+    unsigned* counts = reinterpret_cast<unsigned*>(take(ncnt * 4));
+    unsigned* starts = reinterpret_cast<unsigned*>(take(ncnt * 4));
+    unsigned* cursor = reinterpret_cast<unsigned*>(take(ncnt * 4));
+    unsigned* chunks = reinterpret_cast<unsigned*>(take(((size_t)n_buckets + 1) * 4));
+    unsigned* chunk_prefix = reinterpret_cast<unsigned*>(take(((size_t)n_buckets + 1) * 4));
+    unsigned* flags = reinterpret_cast<unsigned*>(take((ids + 1) * 4));
+    unsigned* rank = reinterpret_cast<unsigned*>(take((ids + 1) * 4));
+    unsigned* id_of = reinterpret_cast<unsigned*>(take(ids * 4));
+    size_t temp_bytes = 0, t2 = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, temp_bytes, (const unsigned*)nullptr, (unsigned*)nullptr, (int)std::min<size_t>(ids + 1, INT32_MAX));
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t2, (const int64_t*)nullptr, (int64_t*)nullptr, (int)std::min<size_t>(ids + 1, INT32_MAX));
+    temp_bytes = std::max(temp_bytes, t2);
+    void* d_temp = take(temp_bytes);
+    hipStream_t s = ctx->stream;
+    PDS_HIP_CHECK(hipMemsetAsync(counts, 0, ncnt * 4, s));
+    PDS_HIP_CHECK(hipMemsetAsync(table, 0, ids * L.nvp * 8, s));
+    PDS_HIP_CHECK(hipMemsetAsync(chunks + n_buckets, 0, 4, s));
+    PDS_HIP_CHECK(hipMemsetAsync(flags + ids, 0, 4, s));
+    // ---- 1. histogram (a grid that is resident at once and a multiple of the stream count: block b runs on XCD b mod 8)
+    const int64_t nchunks = (n_rows + kPartChunkRows - 1) / kPartChunkRows;
+    const size_t hist_lds = (size_t)n_buckets * 4;
+    if (hist_lds > 64 * 1024)
+        PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(part_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds));
+    int hb = (int)std::min<int64_t>(nchunks, (int64_t)ctx->num_cus * (hist_lds > 32 * 1024 ? 1 : 4));
+    hb = std::max(kPartStreams, hb / kPartStreams * kPartStreams);
+    hipLaunchKernelGGL(part_hist_kernel, dim3(hb), dim3(256), hist_lds, s, d_keys, n_rows, d_kmin, L.shift, n_buckets, counts);
+    PDS_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(d_temp, temp_bytes, (const unsigned*)counts, starts, (int)ncnt, s));
+    PDS_HIP_CHECK(hipMemcpyAsync(cursor, starts, ncnt * 4, hipMemcpyDeviceToDevice, s));
+    // ---- 2. scatter
+    int sb = (int)std::min<int64_t>(nchunks, (int64_t)ctx->num_cus * 4);
+    sb = std::max(kPartStreams, sb / kPartStreams * kPartStreams);
+    const int ppr = L.rs / 16;
+    switch (ppr) {
+#define PDS_PART_PPR(N) case N: launch_scatter<T, N>(dim3(sb), s, d_cols, n_feat, L, d_keys, n_rows, d_kmin, cursor, records); break;
+        PDS_PART_PPR(1) PDS_PART_PPR(2) PDS_PART_PPR(3) PDS_PART_PPR(4) PDS_PART_PPR(5) PDS_PART_PPR(6) PDS_PART_PPR(7) PDS_PART_PPR(8)
+        PDS_PART_PPR(9) PDS_PART_PPR(10)
+#undef PDS_PART_PPR
+        default: return fail(PDS_ERR_UNSUPPORTED, "keyed partition: record too wide");
+    }
+    PDS_HIP_CHECK(hipGetLastError());
+    // ---- 3. accumulate: work items = (bucket, chunk); their count is bounded on the host, surplus workgroups leave at once
+    const int cb = (int)std::min<int64_t>(std::max<int64_t>((n_buckets + 255) / 256, 1), 1024);
+    hipLaunchKernelGGL(part_chunk_counts_kernel, dim3(cb), dim3(256), 0, s, (const unsigned*)starts, n_buckets, chunks);
+    PDS_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(d_temp, temp_bytes, (const unsigned*)chunks, chunk_prefix, (int)n_buckets + 1, s));
+    const unsigned max_items = (unsigned)(n_buckets + (n_rows + kPartAccumChunk - 1) / kPartAccumChunk);
+    int rc = PDS_OK;
+    switch (L.pc) {
+#define PDS_PART_PC(N) case N: rc = launch_accum<T, N>(ctx, max_items, L, records, starts, chunk_prefix, n_buckets, table); break;
+        PDS_PART_PC(1) PDS_PART_PC(2) PDS_PART_PC(3) PDS_PART_PC(4) PDS_PART_PC(5) PDS_PART_PC(6) PDS_PART_PC(7) PDS_PART_PC(8)
+        PDS_PART_PC(10) PDS_PART_PC(12) PDS_PART_PC(14) PDS_PART_PC(16)
+#undef PDS_PART_PC
+        default: return fail(PDS_ERR_UNSUPPORTED, "keyed partition: feature count");
+    }
+    if (rc) return rc;
+    // ---- 4. groups = ids with rows, ascending
+    const int cnt_index = tri_index(L.pc, L.pc, L.qp);
+    const int fb = (int)std::min<int64_t>(std::max<int64_t>(((int64_t)ids + 255) / 256, 1), (int64_t)ctx->num_cus * 16);
+    hipLaunchKernelGGL(part_flags_kernel<0>, dim3(fb), dim3(256), 0, s, (const double*)table, (int64_t)ids, L.nvp, cnt_index, flags);
+    PDS_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(d_temp, temp_bytes, (const unsigned*)flags, rank, (int)ids + 1, s));
+    unsigned h_ng = 0;
+    PDS_HIP_CHECK(hipMemcpyAsync(&h_ng, rank + ids, 4, hipMemcpyDeviceToHost, s));
+    PDS_HIP_CHECK(hipStreamSynchronize(s));
+    *n_groups = (int64_t)h_ng;
+    st.table = table;
+    st.ids = id_of;
+    st.pc = L.pc;
+    st.nvp = L.nvp;
+    if ((int64_t)h_ng > max_groups) return fail(PDS_ERR_INVALID, "more distinct keys than max_groups");
+    int64_t* sizes = d_offsets;  // sizes are scanned in place into offsets
+    hipLaunchKernelGGL(part_compact_kernel, dim3(fb), dim3(256), 0, s, (const double*)table, (int64_t)ids, L.nvp, cnt_index, (const unsigned*)rank,
+                       d_kmin, max_groups, d_out_keys, id_of, sizes);
+    PDS_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(d_temp, temp_bytes, (const int64_t*)sizes, d_offsets, (int)h_ng, s));
+    hipLaunchKernelGGL(part_close_offsets_kernel, dim3(1), dim3(64), 0, s, d_offsets, (int64_t)h_ng, n_rows);
+    PDS_HIP_CHECK(hipGetLastError());
+    return PDS_OK;
+}
+template int keyed_partition_build<double>(pds_ctx*, const double* const*, const int64_t*, const int64_t*, uint64_t, int, int64_t, int64_t,
+                                           char*, int64_t, int64_t*, int64_t*, int64_t*, KeyedPartitionState&);
+template int keyed_partition_build<float>(pds_ctx*, const float* const*, const int64_t*, const int64_t*, uint64_t, int, int64_t, int64_t, char*,
+                                          int64_t, int64_t*, int64_t*, int64_t*, KeyedPartitionState&);
+
+// (p+2)^2 moment records of groups [g0, g0 + gc) for the batched solvers
+template <typename T>
+int keyed_partition_records(pds_ctx* ctx, const KeyedPartitionState& st, int n_feat, int64_t g0, int64_t gc, T* d_records) {
+    const int q = n_feat + 2;
+    const int nb = (int)std::min<int64_t>(std::max<int64_t>((gc * q * q + 255) / 256, 1), (int64_t)ctx->num_cus * 16);
+    hipLaunchKernelGGL((part_expand_kernel<T>), dim3(nb), dim3(256), 0, ctx->stream, (const double*)st.table, (const unsigned*)st.ids, g0, gc, n_feat,
+                       st.pc, st.nvp, d_records);
+    PDS_HIP_CHECK(hipGetLastError());
+    return PDS_OK;
+}
+template int keyed_partition_records<double>(pds_ctx*, const KeyedPartitionState&, int, int64_t, int64_t, double*);
+template int keyed_partition_records<float>(pds_ctx*, const KeyedPartitionState&, int, int64_t, int64_t, float*);
+
+}  // namespace pds

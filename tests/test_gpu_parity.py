@@ -587,6 +587,87 @@ def test_by_key_multi_context_equals_single_context(pds, orc, n_ctx, n_slices):
         c.close()
 
 
+@pytest.mark.parametrize("p,bias,kw", [(1, False, {}), (3, True, {}), (5, False, {"l2_reg": 0.3}), (8, True, {}), (8, False, {"l1_reg": 0.02}),
+                                        (11, False, {}), (16, True, {}), (6, True, {"positive": True})])
+def test_by_key_partition_route_against_oracle(pds, orc, p, bias, kw):
+    """Shuffled rows, dense integer keys, >= 2^16 rows: the partition route (keyed_partition.hip -- no sort of the rows: bucketed
+    records, moments by LDS atomics, batched solve) against the oracle per group; sparse key values (every third id unused),
+    too-small and collinear groups; and against the sorting route (PDS_KEYED_SORT is read once per process, so the sorted
+    call is made on the frame in key order, which moves nothing)."""
+    rng = np.random.default_rng(700 + p)
+    G = 2500
+    sizes = rng.integers(p + 2, 160, size=G)
+    sizes[::83] = rng.integers(1, p + 1, size=len(sizes[::83]))  # fewer rows than coefficients -> null
+    keys_g = (rng.permutation(G) * 3 - 1000).astype(np.int64)
+    key = np.repeat(keys_g, sizes)
+    N = len(key)
+    assert N >= 1 << 16
+    X = rng.normal(size=(N, p))
+    y = X @ rng.normal(size=p) + 1e-3 * key + 0.1 * rng.normal(size=N) + (0.5 if bias else 0.0)
+    off0 = np.concatenate([[0], np.cumsum(sizes)])
+    if p >= 2 and not kw:
+        for g in range(7, G, 301):
+            X[off0[g]: off0[g + 1], 1] = 2.0 * X[off0[g]: off0[g + 1], 0]
+    perm = rng.permutation(N)
+    kp, Xp, yp = key[perm], X[perm], y[perm]
+    k1, c1, n1 = pds.lin_reg_by_key(*cols_of(Xp), target=dev(yp), key=dev(kp), add_bias=bias, tol=1e-9, max_iter=2000, **kw)
+    k1, c1, n1 = k1.cpu().numpy(), c1.cpu().numpy(), n1.cpu().numpy().astype(bool)
+    order = np.argsort(key, kind="stable")
+    ks, Xs, ys = key[order], X[order], y[order]
+    uk, cnt = np.unique(ks, return_counts=True)
+    assert np.array_equal(k1, uk)
+    off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+    pp = p + int(bias)
+    worst = 0.0
+    nulls_o = np.zeros(len(uk), dtype=bool)
+    for g in range(len(uk)):
+        sl = slice(off[g], off[g + 1])
+        if cnt[g] < pp:
+            nulls_o[g] = True
+            continue
+        b = orc.pl_lr(Xs[sl], ys[sl], add_bias=bias, tol=1e-9, max_iter=2000, **kw)
+        if b is None:
+            nulls_o[g] = True
+            continue
+        if cnt[g] >= 2 * pp + 8 and not n1[g]:
+            worst = max(worst, np.linalg.norm(c1[g] - b) / max(np.linalg.norm(b), 1e-300))
+    assert np.array_equal(n1, nulls_o), (n1.sum(), nulls_o.sum())
+    assert worst < (1e-8 if kw.get("l1_reg") or kw.get("positive") else F64_TOL), worst
+    # the frame in key order (nothing moves, fused streaming kernel): same groups, same nulls, same fits
+    k2, c2, n2 = pds.lin_reg_by_key(*cols_of(Xs), target=dev(ys), key=dev(ks), add_bias=bias, tol=1e-9, max_iter=2000, **kw)
+    assert np.array_equal(k2.cpu().numpy(), k1) and np.array_equal(n2.cpu().numpy().astype(bool), n1)
+    ok = ~n1 & (cnt >= 2 * pp + 8)
+    d = np.linalg.norm(c2.cpu().numpy()[ok] - c1[ok], axis=1) / np.linalg.norm(c1[ok], axis=1)
+    assert d.max() < (1e-8 if kw.get("l1_reg") or kw.get("positive") else 1e-9)
+    # host frame through the same route
+    k3, c3, n3 = pds.lin_reg_by_key(*[np.ascontiguousarray(Xp[:, j]) for j in range(p)], target=yp, key=kp, add_bias=bias, tol=1e-9,
+                                    max_iter=2000, **kw)
+    assert np.array_equal(k3, k1) and np.array_equal(n3.astype(bool), n1)
+    assert np.max(np.linalg.norm(c3[ok] - c1[ok], axis=1) / np.linalg.norm(c1[ok], axis=1)) < 1e-9
+
+
+def test_by_key_partition_route_f32_and_giant_group(pds, orc, f32):
+    """f32 frames (moments in f64 LDS accumulators) and a skewed frame: one key holds half of the rows, so its bucket is fitted by
+    many accumulate workgroups that meet in the table through global atomics."""
+    rng = np.random.default_rng(808)
+    G, p = 900, 6
+    sizes = rng.integers(20, 120, size=G)
+    sizes[17] = 120_000
+    key = np.repeat(np.arange(G, dtype=np.int64) + 5, sizes)
+    N = len(key)
+    X = rng.normal(size=(N, p)).astype(np.float32)
+    y = (X @ rng.normal(size=p) + 0.1 * rng.normal(size=N) + 0.25).astype(np.float32)
+    perm = rng.permutation(N)
+    k1, c1, n1 = pds.lin_reg_by_key(*cols_of(X[perm]), target=dev(y[perm]), key=dev(key[perm]), add_bias=True)
+    assert c1.dtype.is_floating_point and c1.element_size() == 4 and not n1.any().item()
+    c1 = c1.cpu().numpy().astype(np.float64)
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    for g in (0, 17, 400, G - 1):
+        sl = slice(off[g], off[g + 1])
+        truth = orc.pl_lr(X[sl].astype(np.float64), y[sl].astype(np.float64), add_bias=True)
+        assert np.linalg.norm(c1[g] - truth) / np.linalg.norm(truth) < F32_TOL
+
+
 def test_grouped_ridge_host_space(pds, orc):
     rng = np.random.default_rng(77)
     G, p = 500, 5
