@@ -137,8 +137,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     constexpr int NLOAD = NWHICH * (PP + 1) * PIECES;       // 16-byte loads per lane and stage (columns beyond p are skipped)
     constexpr int PER_BATCH = (NLOAD + K - 1) / K;          // ... issued in K batches, one in front of every row of pass 2
     extern __shared__ __attribute__((aligned(16))) double seg_lds[];  // (one name / type per translation unit)
-    char* sm = reinterpret_cast<char*>(seg_lds);
-    double* D = seg_lds;
+    // explicit LDS address space: with the profiling statements in the way the compiler no longer inferred it for every access and
+    // emitted generic stores (whose aperture check it then failed to select: "Illegal instruction ... src_shared_base")
+    typedef __attribute__((address_space(3))) char* lds_c;
+    typedef __attribute__((address_space(3))) double* lds_dp;
+    lds_c sm = (lds_c)reinterpret_cast<char*>(seg_lds);
+    lds_dp D = (lds_dp)seg_lds;
     const int lane = threadIdx.x & 63;
     const int64_t n = ra.n, w = ra.window;
     const int64_t ntiles = (n + kTile - 1) / kTile;
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     auto commit = [&](int idx, const V16& v) __attribute__((always_inline)) {
         const int c = (idx / PIECES) % (PP + 1), piece = idx % PIECES, which = idx / (PIECES * (PP + 1));
         if (c > p) return;
-        *reinterpret_cast<V16*>(sm + (which * (PP + 1) + c) * SD::STREAM_BYTES + piece * 1024 + lane * 16) = v;
+        *(__attribute__((address_space(3))) V16*)(sm + (which * (PP + 1) + c) * SD::STREAM_BYTES + piece * 1024 + lane * 16) = v;
     };
 #ifdef PDS_ROLL_LDS_DIRECT
     // gfx950: global_load_lds_dwordx4 -- the 16 bytes of lane L land at (wave-uniform LDS base) + 16 L without passing
@@ -183,10 +187,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #endif
     // the lane's K rows of stream (which, c) out of the LDS image
     auto pick = [&](int which, int c, double (&out)[K]) __attribute__((always_inline)) {
-        const char* src = sm + (which * (PP + 1) + c) * SD::STREAM_BYTES + lane * (K * (int)sizeof(T));
+        const lds_c src = sm + (which * (PP + 1) + c) * SD::STREAM_BYTES + lane * (K * (int)sizeof(T));
 #pragma unroll
         for (int j = 0; j < PIECES; ++j) {
-            const V16 v = *reinterpret_cast<const V16*>(src + 16 * j);
+            const V16 v = *(const __attribute__((address_space(3))) V16*)(src + 16 * j);
 #pragma unroll
             for (int e = 0; e < E16; ++e) out[j * E16 + e] = (double)v[e];
         }
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             for (int v = 0; v < NV; ++v) D[v * kSegStride + lane] = A[v];
             PDS_WAVE_LDS_SYNC();
             if (lane < NV) {
-                const double* rowp = D + lane * kSegStride;
+                const lds_dp rowp = D + lane * kSegStride;
                 double s = 0.0;
 #pragma unroll 16
                 for (int i = 0; i < 64; ++i) s += rowp[i];
@@ -358,7 +362,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             for (int v = 0; v < NV; ++v) D[v * kSegStride + lane] = S[v];
             PDS_WAVE_LDS_SYNC();
             if (lane < NV) {
-                double* rowp = D + lane * kSegStride;
+                lds_dp rowp = D + lane * kSegStride;
                 double run = carry;
 #pragma unroll
                 for (int i0 = 0; i0 < 64; i0 += 16) {
