@@ -496,7 +496,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             static_assert(K % 2 == 0, "rows are walked in pairs");
 #pragma unroll
             for (int i = 0; i < K; i += 2) {
-#ifdef PDS_ROLL_LDS_DIRECT
+#if defined(PDS_ROLL_LDS_DIRECT) && defined(PDS_ROLL_WAIT_LAST_ROW)
                 if (i == K - 2 && direct) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (see the single-row form below)
 #endif
                 double g0[NG], g1[NG], c0[PP], c1[PP], rd0[PP], rd1[PP];
@@ -527,6 +527,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     bwd_step(a, g0, c0);
                     bwd_step(a, g1, c1);
                 }
+#if defined(PDS_ROLL_LDS_DIRECT) && !defined(PDS_ROLL_WAIT_LAST_ROW)
+                if (i == 0 && direct) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (see the single-row form below)
+#endif
                 emit(i, c0, ok0, cnt0);
                 emit(i + 1, c1, ok1, cnt1);
             }
@@ -540,10 +543,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     for (int j = 0; j < PER_BATCH; ++j)
                         if (i * PER_BATCH + j < NLOAD) issue(i * PER_BATCH + j, nb, tmp[j]);
                 }
-#ifdef PDS_ROLL_LDS_DIRECT
-                // The compiler does not order LDS reads behind global_load_lds (its ISA for this kernel has no vmcnt wait in
-                // front of the next stage's ds_reads), so the wave waits itself: in front of the LAST row -- the burst was
-                // issued three rows (~10 000 clk) ago, and the stores of this row then stay in flight across the loop edge.
+#if defined(PDS_ROLL_LDS_DIRECT) && defined(PDS_ROLL_WAIT_LAST_ROW)
+                // (round 2's placement, kept for the A/B: in front of the LAST row -- but vmcnt counts stores as well, so this
+                //  also waited for the three rows of coefficient stores issued since the burst to reach memory)
                 if (i == K - 1 && direct) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
                 advance(i);
@@ -558,6 +560,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 for (int a = 0; a < PP; ++a) c[a] *= rd[a];
 #pragma unroll
                 for (int a = PP - 2; a >= 0; --a) bwd_step(a, g, c);
+#if defined(PDS_ROLL_LDS_DIRECT) && !defined(PDS_ROLL_WAIT_LAST_ROW)
+                // The compiler does not order LDS reads behind global_load_lds (its ISA for this kernel has no vmcnt wait in
+                // front of the next stage's ds_reads), so the wave waits itself.  vmcnt counts loads AND stores (in issue order),
+                // so the wait sits where no store of this stage has been issued yet: behind the first row's arithmetic (the burst
+                // has had a row's time, ~3 500 clk), in front of its stores -- the stores of all four rows then drain behind the
+                // following rows' arithmetic instead of being waited for.
+                if (i == 0 && direct) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
                 emit(i, c, okc, S[NV - 1]);
                 if (more) {
 #ifdef PDS_PROFILE_ROLLING

@@ -551,8 +551,8 @@ def test_grouped_pred_by_key_shuffled_weighted_f32(pds, orc):
 @pytest.mark.parametrize("n_ctx,n_slices", [(1, 3), (2, 0), (3, 7), (4, 4)])
 def test_by_key_multi_context_equals_single_context(pds, orc, n_ctx, n_slices):
     """One host frame through several contexts of ONE process (pds_lr_by_key_multi_*: the route by which a Polars plugin can
-    drive several devices; here N contexts on device 0): slices cut at group boundaries, results bitwise those of the
-    single-context call -- keys, coefficients, null flags -- incl. collinear groups and the rank gate's second pass per slice."""
+    drive several devices; here N contexts on device 0): slices cut at group boundaries, keys and null flags those of the
+    single-context call, coefficients equal to rounding -- incl. collinear groups and the rank gate's second pass per slice."""
     rng = np.random.default_rng(500 + 10 * n_ctx + n_slices)
     G, p = 60_000, 5
     sizes = rng.integers(20, 120, size=G)
@@ -570,7 +570,10 @@ def test_by_key_multi_context_equals_single_context(pds, orc, n_ctx, n_slices):
     ctxs = [pds.Context(0) for _ in range(n_ctx)]
     k2, c2, n2 = pds.lin_reg_by_key_multi(*cols, target=y, key=key, contexts=ctxs, n_slices=n_slices, add_bias=True)
     assert np.array_equal(k1, k2) and np.array_equal(n1, n2) and n1.sum() >= 50
-    assert np.array_equal(c1[~n1.astype(bool)], c2[~n2.astype(bool)])
+    # (same kernels, but a slice starts its 128-row tiles at its own first row: a group's rows meet the matrix core in other
+    #  tile positions than in the whole-frame call, so the sums round differently -- agreement to rounding, not bit for bit)
+    okm = ~n1.astype(bool)
+    assert np.max(np.linalg.norm(c1[okm] - c2[okm], axis=1) / np.linalg.norm(c1[okm], axis=1)) < 1e-11
     co_o, nu_o = orc.grouped_lr([y] + cols, off, add_bias=True, nthreads=4)
     assert np.array_equal(n2.astype(bool), nu_o)
     # a capacity that is too small is reported with the total count (the plugin's retry protocol), nothing is written past it
