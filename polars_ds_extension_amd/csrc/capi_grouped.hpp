@@ -427,9 +427,12 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
         d_keys = static_cast<const int64_t*>(ctx->stage.ptr);
     }
     if (int rc = ensure_pinned(ctx, 4096)) return rc;
-    if (int rc = ensure_ws(ctx, ctx->solve_ws, 4096)) return rc;  // a flag word that outlives the workspace sizing below
+    if (int rc = ensure_ws(ctx, ctx->solve_ws, 8192)) return rc;  // order flag + key range: outlive the workspace sizing below
     bool sorted = false;
-    if (int rc = keys_nondecreasing(ctx, d_keys, n_rows, static_cast<unsigned*>(ctx->solve_ws.ptr), &sorted)) return rc;
+    int64_t mm[2] = {0, 0};
+    int64_t* d_state = reinterpret_cast<int64_t*>(static_cast<char*>(ctx->solve_ws.ptr) + 256);
+    int64_t* d_minmax = d_state + 2;
+    if (int rc = keys_order_minmax(ctx, d_keys, n_rows, d_state, &sorted, mm)) return rc;
     tr.mark("keys H2D + order check");
     if (place && !sorted) {
         place->unsorted();
@@ -438,15 +441,8 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
     // ---- keys in any order: smallest / largest key decide the route.  Dense integer keys (group ids) of an unweighted
     // coefficient fit with up to 16 features take the partition route (keyed_partition.hip: no sort, no random-access pass);
     // PDS_KEYED_SORT=1 keeps the sorting route (A/B)
-    int64_t mm[2] = {0, 0};
-    int64_t* d_minmax = nullptr;
     int64_t part_buckets = 0;
     if (!sorted) {
-        size_t tb = 0;
-        (void)hipcub::DeviceReduce::Min(nullptr, tb, (const int64_t*)nullptr, (int64_t*)nullptr, (int)std::min<int64_t>(n_rows, INT32_MAX));
-        if (int rc = ensure_ws(ctx, ctx->solve_ws, 8192 + tb)) return rc;
-        d_minmax = reinterpret_cast<int64_t*>(static_cast<char*>(ctx->solve_ws.ptr) + 256);
-        if (int rc = keyed_minmax(ctx, d_keys, n_rows, static_cast<char*>(ctx->solve_ws.ptr) + 4096, tb, d_minmax, mm)) return rc;
         static const bool force_sort = [] { const char* e = std::getenv("PDS_KEYED_SORT"); return e && e[0] == '1'; }();
         if (!force_sort && !weights && !want_pred)
             part_buckets = keyed_partition_buckets<T>(n_feat, n_rows, (uint64_t)mm[1] - (uint64_t)mm[0] + 1);

@@ -600,7 +600,10 @@ static int launch_stream_lps(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, 
 static int ensure_mark_state(pds_ctx* ctx) {
     if (ctx->mark_count) return PDS_OK;
     PDS_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ctx->mark_count), 256));
-    PDS_HIP_CHECK(hipMemset(ctx->mark_count, 0, 256));
+    // zeroed ON THE CONTEXT'S STREAM by the first launch (mark_dirty): a hipMemset here runs on the null stream, which a context's
+    // own stream is not ordered behind -- the counter could be reset while the first kernel was already counting, and the
+    // marked groups beyond the surviving count kept their provisional flag (seen as a flaky null-flag mismatch on fresh contexts)
+    ctx->mark_dirty = true;
     PDS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ctx->mark_host), 64, hipHostMallocMapped | hipHostMallocCoherent));
     *ctx->mark_host = 0u;
     PDS_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->mark_host_dev), ctx->mark_host, 0));

@@ -23,6 +23,29 @@ __global__ __launch_bounds__(256) void key_descent_kernel(const int64_t* __restr
     if (__any(found) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
 }
 
+// one pass over the keys: is any key smaller than its predecessor, and the smallest / largest key (state: [flag, -, min, max] as
+// four int64 slots; min / max start at INT64_MAX / INT64_MIN)
+__global__ __launch_bounds__(256) void key_order_minmax_kernel(const int64_t* __restrict__ keys, int64_t n, long long* __restrict__ state) {
+    bool found = false;
+    long long mn = 0x7fffffffffffffffll, mx = -0x7fffffffffffffffll - 1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const long long k = __builtin_nontemporal_load(keys + i);
+        if (i + 1 < n) found = found || keys[i + 1] < k;
+        mn = k < mn ? k : mn;
+        mx = k > mx ? k : mx;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long a = __shfl_down(mn, o), b = __shfl_down(mx, o);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+    }
+    if (__any(found) && (threadIdx.x & 63) == 0) atomicOr(reinterpret_cast<unsigned long long*>(state), 1ull);
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(state + 2, mn);
+        atomicMax(state + 3, mx);
+    }
+}
+
 __global__ __launch_bounds__(256) void iota_u32_kernel(uint32_t* __restrict__ idx, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) idx[i] = (uint32_t)i;
 }
@@ -117,6 +140,22 @@ int keys_nondecreasing(pds_ctx* ctx, const int64_t* d_keys, int64_t n, unsigned*
     PDS_HIP_CHECK(hipMemcpyAsync(&h, d_flag, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
     PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     *sorted = h == 0;
+    return PDS_OK;
+}
+
+// order check + key range in ONE pass (d_state: 4 int64 slots on the device; d_state + 2 is the {min, max} pair keyed_sort and
+// the partition route read on the device)
+int keys_order_minmax(pds_ctx* ctx, const int64_t* d_keys, int64_t n, int64_t* d_state, bool* sorted, int64_t* mm) {
+    const long long init[4] = {0, 0, 0x7fffffffffffffffll, -0x7fffffffffffffffll - 1};
+    PDS_HIP_CHECK(hipMemcpyAsync(d_state, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+    const int nb = (int)std::min<int64_t>(std::max<int64_t>((n + 255) / 256, 1), (int64_t)ctx->num_cus * 8);
+    hipLaunchKernelGGL(key_order_minmax_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_keys, n, reinterpret_cast<long long*>(d_state));
+    long long h[4] = {0, 0, 0, 0};
+    PDS_HIP_CHECK(hipMemcpyAsync(h, d_state, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // (also makes `init` safe to leave scope)
+    *sorted = h[0] == 0;
+    mm[0] = h[2];
+    mm[1] = h[3];
     return PDS_OK;
 }
 

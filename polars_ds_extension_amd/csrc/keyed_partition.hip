@@ -34,8 +34,9 @@ namespace {
 
 constexpr int kPartStreams = 8;        // one per XCD
 constexpr int kPartChunkRows = 4096;   // rows a block takes at a time (histogram and scatter use the same chunk -> stream map)
-constexpr int kPartLdsBytes = 128 * 1024;
+constexpr int kPartLdsBytes = 152 * 1024;  // of the 160 KB of a CU
 constexpr int kPartAccumChunk = 16384; // records per accumulate workgroup
+constexpr int kAccumThreads = 1024;    // sixteen waves: the LDS atomics are latency bound (tools/valu_lds_rate.hip: 3.2 / 5.1 / 10 lanes per clk with 4 / 8 / 16 waves)
 
 __host__ __device__ constexpr int tri_count(int q) { return q * (q + 1) / 2; }
 __host__ __device__ constexpr int tri_index(int i, int j, int q) { return i * q - (i * (i - 1)) / 2 + (j - i); }  // i <= j
@@ -66,8 +67,10 @@ PartLayout make_layout(int p) {
     L.nvp = L.nv | 1;
     L.meta_off = ((L.pc + 1) * (int)sizeof(T) + 7) & ~7;
     L.rs = (L.meta_off + 8 + 15) & ~15;
+    // ids per bucket: their moment records share the CU's LDS with the accumulate kernel's per-wave record stages (sixteen waves)
+    const size_t stage = (size_t)(kAccumThreads / 64) * 64 * L.rs + 16;
     int shift = 0;
-    while (((size_t)2 << shift) * L.nvp * 8 <= (size_t)kPartLdsBytes) ++shift;
+    while (((size_t)2 << shift) * L.nvp * 8 + stage <= (size_t)kPartLdsBytes) ++shift;
     L.shift = shift;
     return L;
 }
@@ -146,12 +149,25 @@ __global__ __launch_bounds__(256) void part_scatter_kernel(const T* const* __res
 }
 
 // ---- 3. accumulate.  One workgroup per (bucket, chunk of kPartAccumChunk records).
-template <typename T, int PC>
-__global__ __launch_bounds__(256) void part_accum_kernel(const char* __restrict__ records, const unsigned* __restrict__ bucket_start /*n_buckets * 8 + 1*/,
-                                                         const unsigned* __restrict__ chunk_prefix /*n_buckets + 1*/, int64_t n_buckets,
-                                                         int shift, int meta_off, int rs, double* __restrict__ table) {
-    constexpr int QP = PC + 2, NV = tri_count(QP), NVP = NV | 1;
-    extern __shared__ double mom_lds[];
+// Sixteen waves.  The records of a tile reach the wave through its own LDS stage: 16-byte pieces loaded by consecutive lanes from
+// consecutive addresses (1 KiB coalesced per instruction; the next tile's pieces wait in registers while this one is worked on).
+// What the kernel costs is its LDS atomics: 55 ds_add_f64 per record at 8 features, latency bound (tools/valu_lds_rate.hip: 3.2
+// lanes / clk with four waves on a CU, 5.1 with eight, 10 with sixteen); without them the pass takes 3.0 of its 6.1 ms (eight
+// waves, no prefetch), 1.5 of 4.6 ms as it stands (PDS_PART_DEBUG=1).  Lanes of a wave that share an id serialise on the same
+// addresses: ~3 lanes / clk here against 10 in the conflict-free microbenchmark.  Tried and slower (tools/experiments/): the
+// matrix cores on id-sorted half-tiles (keyed_partition_accum_mfma: 8.8 ms -- a run of ~4 records is one instruction behind a
+// chain of LDS round trips); wave-owned ids with register-resident records (keyed_partition_accum_wave_owned_ids: 8.3 ms --
+// one record per instruction sequence instead of 64).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <typename T, int PC, int PPR>
+__global__ __launch_bounds__(kAccumThreads) void part_accum_kernel(const char* __restrict__ records, const unsigned* __restrict__ bucket_start /*n_buckets * 8 + 1*/,
+                                                                   const unsigned* __restrict__ chunk_prefix /*n_buckets + 1*/, int64_t n_buckets,
+                                                                   int shift, int meta_off, double* __restrict__ table, int debug) {
+    constexpr int QP = PC + 2, NV = tri_count(QP), NVP = NV | 1, RS = PPR * 16;
+    extern __shared__ __attribute__((aligned(16))) double mom_lds[];
+    const int gpb = 1 << shift;
+    char* stage_all = reinterpret_cast<char*>(mom_lds + (size_t)gpb * NVP);
+    stage_all += (16 - (reinterpret_cast<uintptr_t>(stage_all) & 15)) & 15;
     const unsigned total_chunks = chunk_prefix[n_buckets];
     const unsigned w = blockIdx.x;
     if (w >= total_chunks) return;
@@ -166,35 +182,71 @@ __global__ __launch_bounds__(256) void part_accum_kernel(const char* __restrict_
     const unsigned chunk = w - chunk_prefix[bucket];
     const int64_t b0 = bucket_start[bucket * kPartStreams], b1 = bucket_start[(bucket + 1) * kPartStreams];
     const int64_t r0 = b0 + (int64_t)chunk * kPartAccumChunk, r1 = (r0 + kPartAccumChunk < b1) ? r0 + kPartAccumChunk : b1;
-    const int gpb = 1 << shift;
-    for (int i = threadIdx.x; i < gpb * NVP; i += 256) mom_lds[i] = 0.0;
+    for (int i = threadIdx.x; i < gpb * NVP; i += kAccumThreads) mom_lds[i] = 0.0;
     __syncthreads();
     typedef __attribute__((address_space(3))) double* lds_d;
-    for (int64_t r = r0 + threadIdx.x; r < r1; r += 256) {
-        const char* rec = records + (size_t)r * rs;
-        double z[QP];
-        const T* vals = reinterpret_cast<const T*>(rec);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    char* st = stage_all + (size_t)wv * 64 * RS;
+    // the wave's tiles of 64 records; the next tile's pieces are loaded into registers while this one is worked on
+    constexpr int64_t STEP = (kAccumThreads / 64) * 64;
+    u32x4 nxt[PPR];
+    auto fetch = [&](int64_t base) __attribute__((always_inline)) {
+        const int nrec = (int)((r1 - base < 64) ? r1 - base : 64);
+        const u32x4* src = reinterpret_cast<const u32x4*>(records + (size_t)base * RS);
 #pragma unroll
-        for (int c = 0; c < PC; ++c) z[c] = (double)vals[c];
-        z[PC] = 1.0;
-        z[PC + 1] = (double)vals[PC];
-        const unsigned lid = *reinterpret_cast<const unsigned*>(rec + meta_off);
-        double* m = mom_lds + (size_t)lid * NVP;
-        int v = 0;
+        for (int k = 0; k < PPR; ++k) {
+            const int j = k * 64 + lane;
+            if (j < nrec * PPR) nxt[k] = __builtin_nontemporal_load(src + j);
+        }
+    };
+    int64_t base = r0 + (int64_t)wv * 64;
+    if (base < r1) fetch(base);
+    for (; base < r1; base += STEP) {
+        const int nrec = (int)((r1 - base < 64) ? r1 - base : 64);
 #pragma unroll
-        for (int a = 0; a < QP; ++a) {
+        for (int k = 0; k < PPR; ++k) {
+            const int j = k * 64 + lane;
+            if (j < nrec * PPR) *reinterpret_cast<u32x4*>(st + j * 16) = nxt[k];
+        }
+        PDS_WAVE_LDS_SYNC();
+        if (base + STEP < r1) fetch(base + STEP);
+        if (lane < nrec) {
+            const char* rec = st + lane * RS;
+            double z[QP];
+            const T* vals = reinterpret_cast<const T*>(rec);
 #pragma unroll
-            for (int b = a; b < QP; ++b) {
-                __builtin_amdgcn_ds_atomic_fadd_f64((lds_d)(m + v), z[a] * z[b]);
-                ++v;
+            for (int c = 0; c < PC; ++c) z[c] = (double)vals[c];
+            z[PC] = 1.0;
+            z[PC + 1] = (double)vals[PC];
+            const unsigned lid = *reinterpret_cast<const unsigned*>(rec + meta_off);
+            double* m = mom_lds + (size_t)lid * NVP;
+            int v = 0;
+            if (debug & 1) {  // (experiment: everything but the LDS atomics)
+                double sacc = 0.0;
+#pragma unroll
+                for (int a = 0; a < QP; ++a)
+#pragma unroll
+                    for (int b = a; b < QP; ++b) sacc += z[a] * z[b];
+                if (sacc == 1.2345e300) m[0] = sacc;
+            } else {
+#pragma unroll
+                for (int a = 0; a < QP; ++a) {
+#pragma unroll
+                    for (int b = a; b < QP; ++b) {
+                        __builtin_amdgcn_ds_atomic_fadd_f64((lds_d)(m + v), z[a] * z[b]);
+                        ++v;
+                    }
+                }
             }
         }
+        PDS_WAVE_LDS_SYNC();
     }
     __syncthreads();
+    if (debug & 2) return;  // (experiment: no flush to the table)
     // ---- non-empty ids -> the table (several chunks of one bucket, and nobody else, meet here)
     constexpr int CNT = tri_index(PC, PC, QP);
     double* tb = table + (size_t)bucket * gpb * NVP;
-    for (int i = threadIdx.x; i < gpb * NVP; i += 256) {
+    for (int i = threadIdx.x; i < gpb * NVP; i += kAccumThreads) {
         const int lid = i / NVP;
         if (mom_lds[lid * NVP + CNT] > 0.0) {
             const double v = mom_lds[i];
@@ -266,11 +318,14 @@ void launch_scatter(dim3 g, hipStream_t st, const T* const* cols, int p, const P
 template <typename T, int PC>
 int launch_accum(pds_ctx* ctx, unsigned grid, const PartLayout& L, const char* records, const unsigned* bucket_start,
                  const unsigned* chunk_prefix, int64_t n_buckets, double* table) {
-    const size_t lds = ((size_t)1 << L.shift) * L.nvp * 8;
-    auto kern = part_accum_kernel<T, PC>;
+    constexpr int PPR = ((((PC + 1) * (int)sizeof(T) + 7) & ~7) + 8 + 15) / 16;  // = make_layout<T>(PC).rs / 16
+    if (L.rs != PPR * 16) return fail(PDS_ERR_INVALID, "internal: record size");
+    const size_t lds = ((size_t)1 << L.shift) * L.nvp * 8 + (size_t)(kAccumThreads / 64) * 64 * L.rs + 16;
+    auto kern = part_accum_kernel<T, PC, PPR>;
     if (lds > 64 * 1024) PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx->stream, records, bucket_start, chunk_prefix, n_buckets, L.shift, L.meta_off, L.rs,
-                       table);
+    const char* dbg = std::getenv("PDS_PART_DEBUG");
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kAccumThreads), lds, ctx->stream, records, bucket_start, chunk_prefix, n_buckets, L.shift, L.meta_off,
+                       table, dbg ? std::atoi(dbg) : 0);
     PDS_HIP_CHECK(hipGetLastError());
     return PDS_OK;
 }
@@ -284,7 +339,7 @@ int64_t keyed_partition_buckets(int n_feat, int64_t n_rows, uint64_t range) {
     if (range == 0 || range > ((uint64_t)1 << 31) || range > (uint64_t)n_rows * 4) return 0;  // sparse keys: the sorting route
     const PartLayout L = make_layout<T>(n_feat);
     const int64_t nb = (int64_t)((range + ((uint64_t)1 << L.shift) - 1) >> L.shift);
-    if (nb > kPartLdsBytes / 4) return 0;  // (the histogram of one block lives in LDS)
+    if (nb > 32768) return 0;  // (the histogram of one block lives in LDS: 128 KB of counters)
     // the id-indexed moment table (one upper triangle per POSSIBLE key) must stay within twice the frame's own size and 16 GiB
     const uint64_t table_bytes = ((uint64_t)nb << L.shift) * (uint64_t)L.nvp * 8;
     if (table_bytes > 2 * (uint64_t)n_rows * (uint64_t)(n_feat + 1) * sizeof(T) || table_bytes > ((uint64_t)16 << 30)) return 0;
