@@ -556,6 +556,14 @@ def _c5(torch, pds, ctx, dev):
             useful = n * (p + 2) * (p + 3)  # flops of the upper triangle incl. the diagonal, 2 per multiply-add
             out[name] = {"wall_ms": round(wall, 2), "gram_ms": round(gram, 3), "gram_useful_TFLOPs": round(useful / gram / 1e9, 1),
                          "frac_of_f32_mfma_peak_157TF": round(useful / gram / 1e9 / 157.3, 3), "nonzero": int((abs(b) > 1e-6).sum())}
+            if native == "0":
+                # the split path does NOT execute on the f32 pipe: every product is six v_mfma_f32_32x32x16_bf16 (hh, hm, mh, hl,
+                # lh, mm), so the pipe it runs on sees 6x the useful flops; against the dense bf16 peak (2.5 PFLOP/s) and against
+                # the decomposition's own matrix-core floor (12.3 ms at the clock the kernel runs at)
+                out[name]["executed_bf16_TFLOPs"] = round(6 * useful / gram / 1e9, 1)
+                out[name]["frac_of_bf16_mfma_peak_2500TF"] = round(6 * useful / gram / 1e9 / 2500.0, 3)
+                out[name]["frac_of_bf16_pipe_floor_12.3ms"] = round(12.3 / gram, 3)
+                out[name]["pipe"] = "bf16 matrix cores (three exact bf16 planes per f32 value); the f32-peak fraction above is a useful-flop rate, not a utilisation of that pipe"
     finally:
         os.environ.pop("PDS_WIDE_F32_NATIVE", None)
         pds.config.LIN_REG_EXPR_F64 = True

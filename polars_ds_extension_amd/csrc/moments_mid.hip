@@ -1,0 +1,269 @@
+// moments_mid.hip -- the Gram / moment build of ONE regression with 17 .. 64 f64 features: a STREAMING kernel in the style of the
+// p <= 16 kernel (moments.hip), several 16-feature tile columns wide.
+//
+// get_xtx_with_lambda + build_xty (lr_solvers.rs:183-211, 262-278) for the usual width of a hand-built regression.  The tiled
+// SYRK of moments_wide.hip serves these widths through a compact form (MODE 3 / 4 / 5: one 128-column block, tiles dealt to four
+// waves, a shared LDS panel, two barriers per 32-row stage, ONE stage of loads in flight): 1.5 - 2.0 TB/s -- a 17th feature cost
+// four times the 16-feature kernel per row.  Here nothing is shared and nothing waits for a neighbour:
+//   * one wave per SIMD owns a contiguous row range and a private LDS image of two half-tiles of HR rows x (16 NBLK + 1) columns;
+//     the next half-tile is fetched global -> LDS asynchronously (global_load_lds, 16 bytes per lane straight down a column) while
+//     the matrix core consumes the current one;
+//   * per 4-row step the wave reads NBLK operand registers (lane = (feature i of the block, row slot k): column stride HR * 8 + 16
+//     bytes keeps the half-wave's reads on distinct banks) and issues NBLK (NBLK + 1) / 2 v_mfma_f64_16x16x4_f64 -- the upper
+//     block triangle of X'X, A and B operands being the same registers -- with independent accumulators;
+//   * X'y, the column sums, y'y and sum y ride on the VALU from the same operand registers (the target is one more LDS column);
+//   * per-wave partial records, summed in wave order by a finalize kernel: no atomics, bit-reproducible.
+// Bound: HBM up to 32 features (2 x 3 matrix instructions per 4 rows = 0.55 ms per 2e7 rows against 1.05 ms of HBM time for
+// 2e7 x 33 doubles), the f64 matrix pipe beyond (10 instructions per 4 rows at 64 features: 2.9 ms of pipe per 2e7 rows at the
+// measured 86 clk per instruction, tools/mfma_peak.hip).
+#include "common.hpp"
+#include "moments_dev.hpp"
+
+namespace pds {
+
+namespace {
+
+constexpr int kMidWavesPerCu = 4;
+
+// NBLK = 2 (17 .. 32 features) or 4 (33 .. 64).  One asynchronous load instruction moves 1 KiB: NBLK columns x HR rows -- the 64 / NBLK
+// lanes of lane group g fetch 16 bytes each of column 16 g + i -- so a half-tile is 16 such instructions + one for the target.
+// (One column per instruction with half or a quarter of the lanes active: the instruction count, not the bytes, was the limit --
+// ~90 clk of the wave's time per global_load_lds whatever it moves.)  The LDS image keeps an instruction's 1 KiB together: column
+// (b, i) of the half-tile sits at i * GS + b * HR * 8, GS = 1024 + 16.  The operand fetch of block b reads 16 consecutive i at one b:
+// bank = (4 i + 2 row) mod 64 -- distinct within a half-wave.
+template <int NBLK>
+struct MidDims {
+    static constexpr int HR = 128 / NBLK;                      // rows per half-tile
+    static constexpr int GL = 64 / NBLK;                       // lanes per lane group = 16-byte pieces per column
+    static constexpr int GS = 1024 + 16;                       // bytes between the images of instructions i and i + 1
+    static constexpr int Y_OFF = 16 * GS;                      // the target column's image (HR * 8 bytes)
+    static constexpr int HALF_BYTES = 16 * GS + 1024;
+    static constexpr int NBUF = 2;
+    static constexpr int LDS_BYTES = NBUF * HALF_BYTES;
+    static constexpr int NS = HR / 4;                          // 4-row steps per half-tile
+    static constexpr int NPAIR = NBLK * (NBLK + 1) / 2;
+    // per-wave partial record (doubles): NPAIR tiles of 4 registers x 64 lanes | xy, cs: NBLK x 64 each | yy, ys: 64 each
+    static constexpr int REC = NPAIR * 256 + 2 * NBLK * 64 + 128;
+};
+
+template <int NBLK>
+__global__ __launch_bounds__(64) void moments_mid_kernel(const double* const* __restrict__ cols, int p, int64_t n,
+                                                         double* __restrict__ partials) {
+    using MD = MidDims<NBLK>;
+    constexpr int HR = MD::HR, GS = MD::GS, NPAIR = MD::NPAIR, NS = MD::NS;
+    extern __shared__ __attribute__((aligned(16))) char mid_lds[];
+    typedef __attribute__((address_space(3))) char* lds_c;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    typedef double mid_d2 __attribute__((ext_vector_type(2)));
+    lds_c sm = (lds_c)mid_lds;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = blockIdx.x, nwaves = gridDim.x;
+    // whole half-tiles, dealt as contiguous ranges; the ragged tail (n mod HR rows) belongs to the last wave
+    const int64_t nh = n / HR;
+    const int64_t h0 = nh * wave / nwaves, h1 = nh * (wave + 1) / nwaves;
+    const int tail = (wave == nwaves - 1) ? (int)(n - nh * HR) : 0;
+    // ---- the lane's 16 column pointers (column 16 g + i, g = its lane group), already advanced to its two rows of a half-tile;
+    // `valid` bit i: that column exists (the others keep the zeros both images start with)
+    const int g = lane / MD::GL, piece = lane % MD::GL;
+    const double* cbase[16];
+    unsigned valid = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = 16 * g + i;
+        cbase[i] = cols[c < p ? c : p] + 2 * piece;
+        if (c < p) valid |= 1u << i;
+    }
+    const double* ybase = cols[p] + 2 * lane;  // (lanes 0 .. HR / 2 - 1)
+    for (int i = lane * 16; i < MD::LDS_BYTES; i += 64 * 16) *(__attribute__((address_space(3))) mid_d2*)(sm + i) = mid_d2{0.0, 0.0};
+    static_assert(MD::LDS_BYTES % 16 == 0, "zeroed in 16-byte pieces");
+    PDS_WAVE_LDS_SYNC();
+    // instruction i of a half-tile (i == 16: the target)
+    auto issue_one = [&](int i, int buf, int64_t row0) __attribute__((always_inline)) {
+        if (i < 16) {
+            if ((valid >> i) & 1u)
+                __builtin_amdgcn_global_load_lds((glb_ptr)(as_global(cbase[i]) + row0), (lds_ptr)(sm + buf * MD::HALF_BYTES + i * GS), 16, 0, 0);
+        } else if (lane < HR / 2) {
+            __builtin_amdgcn_global_load_lds((glb_ptr)(as_global(ybase) + row0), (lds_ptr)(sm + buf * MD::HALF_BYTES + MD::Y_OFF), 16, 0, 0);
+        }
+    };
+    auto issue = [&](int buf, int64_t row0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i <= 16; ++i) issue_one(i, buf, row0);
+    };
+    // guarded form for the ragged tail: zero rows beyond `rows`
+    auto load_tail = [&](int buf, int64_t row0, int rows) __attribute__((always_inline)) {
+        for (int c = 0; c <= p; ++c) {
+            const int off = c < p ? (c % 16) * GS + (c / 16) * HR * 8 : MD::Y_OFF;
+            const gptr<double> col = as_global(cols[c]);
+            for (int r = lane; r < HR; r += 64)
+                *(__attribute__((address_space(3))) double*)(sm + buf * MD::HALF_BYTES + off + r * 8) = r < rows ? col[row0 + r] : 0.0;
+        }
+    };
+    d4 acc[NPAIR];
+#pragma unroll
+    for (int q = 0; q < NPAIR; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
+    double xy[NBLK], cs[NBLK], yy = 0.0, ys = 0.0;
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) xy[b] = cs[b] = 0.0;
+    const int fi = lane & 15, fk = lane >> 4;
+    // `next`: the following half-tile's 17 loads are issued between the matrix instructions of the first steps
+    constexpr int IPS = (17 + NS - 1) / NS < 2 ? 2 : (17 + NS - 1) / NS;  // load instructions per step
+    auto consume = [&](int buf, bool next, int64_t next_row0) __attribute__((always_inline)) {
+        const lds_c base = sm + buf * MD::HALF_BYTES;
+        auto fetch = [&](int s, double (&a)[NBLK], double& yk) __attribute__((always_inline)) {
+            const int roff = (4 * s + fk) * 8;
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) a[b] = *(const __attribute__((address_space(3))) double*)(base + fi * GS + b * HR * 8 + roff);
+            yk = *(const __attribute__((address_space(3))) double*)(base + MD::Y_OFF + roff);
+        };
+        // operands of step s + 1 are fetched from LDS before step s multiplies (one wave per SIMD: nobody else hides the round trip)
+        double a[NBLK], yk;
+        fetch(0, a, yk);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            double an[NBLK], ykn = 0.0;
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) an[b] = 0.0;
+            if (s + 1 < NS) fetch(s + 1, an, ykn);
+            if (next) {
+#pragma unroll
+                for (int cc = 0; cc < IPS; ++cc)
+                    if (s * IPS + cc <= 16) issue_one(s * IPS + cc, buf ^ 1, next_row0);
+            }
+            int q = 0;
+#pragma unroll
+            for (int I = 0; I < NBLK; ++I)
+#pragma unroll
+                for (int J = I; J < NBLK; ++J) {
+                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], a[J], acc[q], 0, 0, 0);
+                    ++q;
+                }
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) {
+                xy[b] = fma(a[b], yk, xy[b]);
+                cs[b] += a[b];
+            }
+            yy = fma(yk, yk, yy);
+            ys += yk;
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) a[b] = an[b];
+            yk = ykn;
+        }
+    };
+    if (h0 < h1) {
+        issue(0, h0 * HR);
+        for (int64_t h = h0; h < h1; ++h) {
+            const int buf = (int)((h - h0) & 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // half-tile h has landed (the compiler does not order LDS reads behind it)
+            __builtin_amdgcn_wave_barrier();
+            consume(buf, h + 1 < h1, (h + 1) * HR);  // (the other image was consumed one iteration ago: free for the next half-tile)
+            PDS_WAVE_LDS_SYNC();
+        }
+    }
+    if (tail > 0) {
+        load_tail(0, nh * HR, tail);
+        PDS_WAVE_LDS_SYNC();
+        consume(0, false, 0);
+    }
+    // ---- the wave's partial record
+    double* rec = partials + (size_t)wave * MD::REC;
+#pragma unroll
+    for (int q = 0; q < NPAIR; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rec[(q * 4 + r) * 64 + lane] = acc[q][r];
+    double* v = rec + NPAIR * 256;
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) {
+        v[b * 64 + lane] = xy[b];
+        v[(NBLK + b) * 64 + lane] = cs[b];
+    }
+    v[2 * NBLK * 64 + lane] = yy;
+    v[2 * NBLK * 64 + 64 + lane] = ys;
+}
+
+// per-wave records -> one record: entry idx summed over the waves in a fixed order (four interleaved partial sums, then their sum)
+__global__ __launch_bounds__(256) void moments_mid_reduce_kernel(const double* __restrict__ partials, int nwaves, int rec, double* __restrict__ out) {
+    __shared__ double part[4][64];
+    const int i = threadIdx.x & 63, g = threadIdx.x >> 6, idx = blockIdx.x * 64 + i;
+    double s = 0.0;
+    if (idx < rec)
+        for (int w = g; w < nwaves; w += 4) s += partials[(size_t)w * rec + idx];
+    part[g][i] = s;
+    __syncthreads();
+    if (g == 0 && idx < rec) out[idx] = (part[0][i] + part[1][i]) + (part[2][i] + part[3][i]);
+}
+
+// one thread per entry (i <= j) of the (p+2)^2 moment matrix over [x_0 .. x_{p-1}, 1, y]: fixed-order sum over the waves
+template <int NBLK>
+__global__ __launch_bounds__(256) void moments_mid_finalize_kernel(const double* __restrict__ partials, int nwaves, int p, int64_t n,
+                                                                   double* __restrict__ out) {
+    using MD = MidDims<NBLK>;
+    const int q = p + 2;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= q * q) return;
+    int i = e % q, j = e / q;
+    if (i > j) {
+        const int t = i;
+        i = j;
+        j = t;
+    }
+    double s = 0.0;
+    if (j < p) {  // X'X: tile (I, J), D[row = ii][col = jj] sits in register ii / 4 of lane jj + 16 (ii % 4)
+        const int I = i / 16, J = j / 16, ii = i % 16, jj = j % 16;
+        int pair = 0;
+        for (int a = 0; a < I; ++a) pair += NBLK - a;
+        pair += J - I;
+        const int idx = (pair * 4 + ii / 4) * 64 + jj + 16 * (ii % 4);
+        for (int w = 0; w < nwaves; ++w) s += partials[(size_t)w * MD::REC + idx];
+    } else if (i < p) {  // column sums (j == p) or X'y (j == p + 1): the four row slots of feature i
+        const int b = i / 16, ii = i % 16;
+        const int base = MD::NPAIR * 256 + ((j == p ? NBLK : 0) + b) * 64;
+        for (int w = 0; w < nwaves; ++w) {
+            const double* v = partials + (size_t)w * MD::REC + base;
+            s += (v[ii] + v[ii + 16]) + (v[ii + 32] + v[ii + 48]);
+        }
+    } else if (i == p && j == p) {
+        s = (double)n;
+    } else {  // sum y (i == p) or y'y (i == p + 1): lanes 0, 16, 32, 48 hold the four row slots
+        const int base = MD::NPAIR * 256 + 2 * NBLK * 64 + (i == p ? 64 : 0);
+        for (int w = 0; w < nwaves; ++w) {
+            const double* v = partials + (size_t)w * MD::REC + base;
+            s += (v[0] + v[16]) + (v[32] + v[48]);
+        }
+    }
+    out[e] = s;
+}
+
+template <int NBLK>
+int launch_mid(pds_ctx* ctx, const DeviceCols<double>& dc, int p, int64_t n, double* d_moments) {
+    using MD = MidDims<NBLK>;
+    const int nwaves = ctx->num_cus * kMidWavesPerCu;
+    double* partials = reinterpret_cast<double*>(ws_take(ctx, (size_t)(nwaves + 1) * MD::REC * sizeof(double)));
+    if (!partials) return fail(PDS_ERR_HIP, "workspace allocation failed");
+    auto kern = moments_mid_kernel<NBLK>;
+    if (MD::LDS_BYTES > 64 * 1024)
+        PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, MD::LDS_BYTES));
+    KernelTimer timer(ctx, kKindMoments);
+    hipLaunchKernelGGL(kern, dim3(nwaves), dim3(64), MD::LDS_BYTES, ctx->stream, dc.d_ptrs, p, n, partials);
+    const int q = p + 2;
+    double* reduced = partials + (size_t)nwaves * MD::REC;
+    hipLaunchKernelGGL(moments_mid_reduce_kernel, dim3((MD::REC + 63) / 64), dim3(256), 0, ctx->stream, (const double*)partials, nwaves, MD::REC, reduced);
+    hipLaunchKernelGGL((moments_mid_finalize_kernel<NBLK>), dim3((q * q + 255) / 256), dim3(256), 0, ctx->stream, (const double*)reduced, 1, p, n,
+                       d_moments);
+    PDS_HIP_CHECK(hipGetLastError());
+    return PDS_OK;
+}
+
+}  // namespace
+
+size_t moments_mid_workspace(int num_cus) { return (size_t)(num_cus * kMidWavesPerCu + 1) * MidDims<4>::REC * sizeof(double) + 4096; }
+
+// 17 .. 64 f64 features, unweighted: d_moments = (p+2)^2 column-major over [x_0 .. x_{p-1}, 1, y]
+int launch_moments_mid(pds_ctx* ctx, const DeviceCols<double>& dc, int n_feat, int64_t n_rows, double* d_moments) {
+    if (n_feat <= 32) return launch_mid<2>(ctx, dc, n_feat, n_rows, d_moments);
+    if (n_feat <= 64) return launch_mid<4>(ctx, dc, n_feat, n_rows, d_moments);
+    return fail(PDS_ERR_UNSUPPORTED, "moments_mid: up to 64 features");
+}
+
+}  // namespace pds

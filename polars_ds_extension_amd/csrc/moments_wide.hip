@@ -940,6 +940,11 @@ static int launch_moments_wide_w(pds_ctx* ctx, const DeviceCols<T>& dc, int n_fe
 
 template <typename T>
 int launch_moments_wide(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, bool weighted, T* d_moments) {
+    if constexpr (sizeof(T) == 8) {
+        // 17 .. 64 f64 features, unweighted: the streaming kernel of moments_mid.hip (PDS_MID_GRAM=0 keeps the compact tile forms: A/B)
+        const char* e = std::getenv("PDS_MID_GRAM");
+        if (!weighted && n_feat <= 64 && !(e && e[0] == '0')) return launch_moments_mid(ctx, dc, n_feat, n_rows, d_moments);
+    }
     if constexpr (sizeof(T) == 4) {
         // f32: products on the bf16 matrix cores as three-plane splits (2.7x the f32 matrix-core rate at f32 accuracy);
         // PDS_WIDE_F32_NATIVE=1 keeps v_mfma_f32_32x32x2_f32 (A/B, and the exact-fmaf-chain arithmetic)
@@ -959,7 +964,8 @@ size_t moments_wide_workspace(int num_cus, int n_feat, int64_t n_rows, bool weig
     int ns;
     int64_t rps;
     wide_split<float>(num_cus, npairs, n_rows, ns, rps);  // the f32 plan has the most splits; 8 B covers both types
-    return (size_t)(ns + 1) * npairs * kWB * kWB * sizeof(double) + 4096 + (weighted ? (size_t)n_rows * sizeof(double) + 512 : 0);
+    const size_t wide = (size_t)(ns + 1) * npairs * kWB * kWB * sizeof(double) + 4096 + (weighted ? (size_t)n_rows * sizeof(double) + 512 : 0);
+    return std::max(wide, n_feat <= 64 ? moments_mid_workspace(num_cus) : (size_t)0);
 }
 
 template int launch_moments_wide<double>(pds_ctx*, const DeviceCols<double>&, int, int64_t, bool, double*);

@@ -88,6 +88,25 @@ def test_moments_f64(pds, orc, n, p):
     assert nrel(Mw, Z.T @ (Z * w[:, None])) < 1e-13
 
 
+@pytest.mark.parametrize("n,p", [(5, 17), (63, 20), (64, 31), (1000, 32), (4097, 33), (100_003, 40), (65_536, 47), (70_001, 48),
+                                 (300_017, 49), (200_000, 64)])
+def test_moments_mid_width_f64(pds, orc, n, p):
+    """17 .. 64 f64 features: the streaming multi-tile-column Gram kernel (moments_mid.hip) -- every tile-column count, ragged row
+    counts incl. fewer rows than one half-tile, run-to-run reproducible; unaligned column starts (an Arrow slice)."""
+    rng = np.random.default_rng(n + 7 * p)
+    X, y, _ = make_xy(rng, n, p)
+    Z = np.c_[X, np.ones(n), y]
+    ref = Z.T @ Z
+    M = pds.gram_moments(*cols_of(X), target=dev(y))
+    assert nrel(M, ref) < 1e-13 and nrel(M, M.T) < 1e-15
+    assert np.array_equal(M, pds.gram_moments(*cols_of(X), target=dev(y)))
+    if n > 2:  # columns that start 8 bytes into a 16-byte unit
+        full = dev(np.ascontiguousarray(np.c_[X, y].T))  # (p + 1) x n
+        M2 = pds.gram_moments(*[full[j, 1:] for j in range(p)], target=full[p, 1:])
+        Z2 = Z[1:]
+        assert nrel(M2, Z2.T @ Z2) < 1e-13
+
+
 def test_moments_host_and_device_inputs_agree_bitwise(pds):
     rng = np.random.default_rng(3)
     X, y, _ = make_xy(rng, 300_017, 9)
