@@ -186,10 +186,10 @@ int launch_sum_moment_slots(pds_ctx* ctx, const double* d_slots, int nslots, int
 template <typename T>
 int launch_moments_wide(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, bool weighted, T* d_moments);
 size_t moments_wide_workspace(int num_cus, int n_feat, int64_t n_rows, bool weighted = false);
-// moments_mid.hip: 17 .. 64 f64 features, unweighted -- the streaming kernel (several 16-feature tile columns); its per-wave
+// moments_mid.hip: 17 .. 64 f64 features -- the streaming kernel (several 16-feature tile columns); its per-wave
 // partial records come out of ctx->ws like the wide kernel's (moments_wide_workspace() covers them)
 size_t moments_mid_workspace(int num_cus);
-int launch_moments_mid(pds_ctx* ctx, const DeviceCols<double>& dc, int n_feat, int64_t n_rows, double* d_moments);
+int launch_moments_mid(pds_ctx* ctx, const DeviceCols<double>& dc, int n_feat, int64_t n_rows, bool weighted, double* d_moments);
 
 // segmented (per-group) moments: d_moments [n_groups][(p+2)^2].  d_group_index (p <= 16 only): record g belongs to group
 // d_group_index[g] of the offsets array instead of group g.
@@ -244,6 +244,10 @@ template <typename T>
 int launch_grouped_pred(pds_ctx* ctx, const T* const* d_cols, int n_feat, int bias, int64_t n_rows, const int64_t* d_off,
                         int64_t n_groups, const T* d_coeffs, const uint8_t* d_flags, const uint32_t* d_perm, T* d_pred, T* d_resid,
                         uint8_t* d_row_null);
+
+// ---- leverage_mid.hip: HC2 / HC3 leverages of 17 .. 64 f64 features on the matrix cores (PDS_ERR_UNSUPPORTED: not applicable, nothing done)
+int launch_leverage_mid(pds_ctx* ctx, const DeviceCols<double>& dc, int n_feat, int bias, int64_t n_rows, const double* d_inv, int hc_mode,
+                        double* d_s_rows);
 
 // ---- pass2.hip ----
 // sum y and sum y^2 of one device column in f64 (fixed-order two-stage reduction): d_out[0..1]

@@ -37,16 +37,18 @@ struct MidDims {
     static constexpr int GL = 64 / NBLK;                       // lanes per lane group = 16-byte pieces per column
     static constexpr int GS = 1024 + 16;                       // bytes between the images of instructions i and i + 1
     static constexpr int Y_OFF = 16 * GS;                      // the target column's image (HR * 8 bytes)
-    static constexpr int HALF_BYTES = 16 * GS + 1024;
+    static constexpr int W_OFF = 16 * GS + HR * 8 + 16;        // the weight column's image (weighted form)
+    static constexpr int HALF_BYTES = 16 * GS + 2 * (HR * 8 + 16) + 16;
     static constexpr int NBUF = 2;
     static constexpr int LDS_BYTES = NBUF * HALF_BYTES;
     static constexpr int NS = HR / 4;                          // 4-row steps per half-tile
     static constexpr int NPAIR = NBLK * (NBLK + 1) / 2;
-    // per-wave partial record (doubles): NPAIR tiles of 4 registers x 64 lanes | xy, cs: NBLK x 64 each | yy, ys: 64 each
-    static constexpr int REC = NPAIR * 256 + 2 * NBLK * 64 + 128;
+    // per-wave partial record (doubles): NPAIR tiles of 4 registers x 64 lanes | xy, cs: NBLK x 64 each | yy, ys, sw: 64 each
+    static constexpr int REC = NPAIR * 256 + 2 * NBLK * 64 + 192;  // (+ sum w, weighted form)
 };
 
-template <int NBLK>
+// WEIGHTED: cols[p + 1] = w; the record is then Z' diag(w) Z (faer_weighted_lr's X'WX | X'Wy, lr_solvers.rs:386-409; entry (1, 1) = sum w)
+template <int NBLK, bool WEIGHTED>
 __global__ __launch_bounds__(64) void moments_mid_kernel(const double* const* __restrict__ cols, int p, int64_t n,
                                                          double* __restrict__ partials) {
     using MD = MidDims<NBLK>;
@@ -75,6 +77,7 @@ __global__ __launch_bounds__(64) void moments_mid_kernel(const double* const* __
         if (c < p) valid |= 1u << i;
     }
     const double* ybase = cols[p] + 2 * lane;  // (lanes 0 .. HR / 2 - 1)
+    const double* wbase = WEIGHTED ? cols[p + 1] + 2 * lane : ybase;
     for (int i = lane * 16; i < MD::LDS_BYTES; i += 64 * 16) *(__attribute__((address_space(3))) mid_d2*)(sm + i) = mid_d2{0.0, 0.0};
     static_assert(MD::LDS_BYTES % 16 == 0, "zeroed in 16-byte pieces");
     PDS_WAVE_LDS_SYNC();
@@ -85,6 +88,8 @@ __global__ __launch_bounds__(64) void moments_mid_kernel(const double* const* __
                 __builtin_amdgcn_global_load_lds((glb_ptr)(as_global(cbase[i]) + row0), (lds_ptr)(sm + buf * MD::HALF_BYTES + i * GS), 16, 0, 0);
         } else if (lane < HR / 2) {
             __builtin_amdgcn_global_load_lds((glb_ptr)(as_global(ybase) + row0), (lds_ptr)(sm + buf * MD::HALF_BYTES + MD::Y_OFF), 16, 0, 0);
+            if constexpr (WEIGHTED)
+                __builtin_amdgcn_global_load_lds((glb_ptr)(as_global(wbase) + row0), (lds_ptr)(sm + buf * MD::HALF_BYTES + MD::W_OFF), 16, 0, 0);
         }
     };
     auto issue = [&](int buf, int64_t row0) __attribute__((always_inline)) {
@@ -93,8 +98,8 @@ __global__ __launch_bounds__(64) void moments_mid_kernel(const double* const* __
     };
     // guarded form for the ragged tail: zero rows beyond `rows`
     auto load_tail = [&](int buf, int64_t row0, int rows) __attribute__((always_inline)) {
-        for (int c = 0; c <= p; ++c) {
-            const int off = c < p ? (c % 16) * GS + (c / 16) * HR * 8 : MD::Y_OFF;
+        for (int c = 0; c <= p + (WEIGHTED ? 1 : 0); ++c) {
+            const int off = c < p ? (c % 16) * GS + (c / 16) * HR * 8 : (c == p ? MD::Y_OFF : MD::W_OFF);
             const gptr<double> col = as_global(cols[c]);
             for (int r = lane; r < HR; r += 64)
                 *(__attribute__((address_space(3))) double*)(sm + buf * MD::HALF_BYTES + off + r * 8) = r < rows ? col[row0 + r] : 0.0;
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(64) void moments_mid_kernel(const double* const* __
     d4 acc[NPAIR];
 #pragma unroll
     for (int q = 0; q < NPAIR; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
-    double xy[NBLK], cs[NBLK], yy = 0.0, ys = 0.0;
+    double xy[NBLK], cs[NBLK], yy = 0.0, ys = 0.0, sw = 0.0;
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) xy[b] = cs[b] = 0.0;
     const int fi = lane & 15, fk = lane >> 4;
@@ -111,44 +116,52 @@ __global__ __launch_bounds__(64) void moments_mid_kernel(const double* const* __
     constexpr int IPS = (17 + NS - 1) / NS < 2 ? 2 : (17 + NS - 1) / NS;  // load instructions per step
     auto consume = [&](int buf, bool next, int64_t next_row0) __attribute__((always_inline)) {
         const lds_c base = sm + buf * MD::HALF_BYTES;
-        auto fetch = [&](int s, double (&a)[NBLK], double& yk) __attribute__((always_inline)) {
+        auto fetch = [&](int s, double (&a)[NBLK], double& yk, double& wk) __attribute__((always_inline)) {
             const int roff = (4 * s + fk) * 8;
 #pragma unroll
             for (int b = 0; b < NBLK; ++b) a[b] = *(const __attribute__((address_space(3))) double*)(base + fi * GS + b * HR * 8 + roff);
             yk = *(const __attribute__((address_space(3))) double*)(base + MD::Y_OFF + roff);
+            if constexpr (WEIGHTED) wk = *(const __attribute__((address_space(3))) double*)(base + MD::W_OFF + roff);
         };
         // operands of step s + 1 are fetched from LDS before step s multiplies (one wave per SIMD: nobody else hides the round trip)
-        double a[NBLK], yk;
-        fetch(0, a, yk);
+        double a[NBLK], yk, wk = 1.0;
+        fetch(0, a, yk, wk);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            double an[NBLK], ykn = 0.0;
+            double an[NBLK], ykn = 0.0, wkn = 1.0;
 #pragma unroll
             for (int b = 0; b < NBLK; ++b) an[b] = 0.0;
-            if (s + 1 < NS) fetch(s + 1, an, ykn);
+            if (s + 1 < NS) fetch(s + 1, an, ykn, wkn);
             if (next) {
 #pragma unroll
                 for (int cc = 0; cc < IPS; ++cc)
                     if (s * IPS + cc <= 16) issue_one(s * IPS + cc, buf ^ 1, next_row0);
             }
+            // weighted: the A operand carries w x, the B operand x -- sum_k (w_k x_ki) x_kj
+            double aw[NBLK];
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) aw[b] = WEIGHTED ? a[b] * wk : a[b];
+            const double ywk = WEIGHTED ? yk * wk : yk;
             int q = 0;
 #pragma unroll
             for (int I = 0; I < NBLK; ++I)
 #pragma unroll
                 for (int J = I; J < NBLK; ++J) {
-                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], a[J], acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw[I], a[J], acc[q], 0, 0, 0);
                     ++q;
                 }
 #pragma unroll
             for (int b = 0; b < NBLK; ++b) {
-                xy[b] = fma(a[b], yk, xy[b]);
-                cs[b] += a[b];
+                xy[b] = fma(aw[b], yk, xy[b]);
+                cs[b] += aw[b];
             }
-            yy = fma(yk, yk, yy);
-            ys += yk;
+            yy = fma(ywk, yk, yy);
+            ys += ywk;
+            if constexpr (WEIGHTED) sw += wk;
 #pragma unroll
             for (int b = 0; b < NBLK; ++b) a[b] = an[b];
             yk = ykn;
+            wk = wkn;
         }
     };
     if (h0 < h1) {
@@ -180,6 +193,7 @@ __global__ __launch_bounds__(64) void moments_mid_kernel(const double* const* __
     }
     v[2 * NBLK * 64 + lane] = yy;
     v[2 * NBLK * 64 + 64 + lane] = ys;
+    v[2 * NBLK * 64 + 128 + lane] = sw;
 }
 
 // per-wave records -> one record: entry idx summed over the waves in a fixed order (four interleaved partial sums, then their sum)
@@ -196,7 +210,7 @@ __global__ __launch_bounds__(256) void moments_mid_reduce_kernel(const double* _
 
 // one thread per entry (i <= j) of the (p+2)^2 moment matrix over [x_0 .. x_{p-1}, 1, y]: fixed-order sum over the waves
 template <int NBLK>
-__global__ __launch_bounds__(256) void moments_mid_finalize_kernel(const double* __restrict__ partials, int nwaves, int p, int64_t n,
+__global__ __launch_bounds__(256) void moments_mid_finalize_kernel(const double* __restrict__ partials, int nwaves, int p, int64_t n, int weighted,
                                                                    double* __restrict__ out) {
     using MD = MidDims<NBLK>;
     const int q = p + 2;
@@ -224,7 +238,15 @@ __global__ __launch_bounds__(256) void moments_mid_finalize_kernel(const double*
             s += (v[ii] + v[ii + 16]) + (v[ii + 32] + v[ii + 48]);
         }
     } else if (i == p && j == p) {
-        s = (double)n;
+        if (weighted) {
+            const int base = MD::NPAIR * 256 + 2 * NBLK * 64 + 128;
+            for (int w = 0; w < nwaves; ++w) {
+                const double* v = partials + (size_t)w * MD::REC + base;
+                s += (v[0] + v[16]) + (v[32] + v[48]);
+            }
+        } else {
+            s = (double)n;
+        }
     } else {  // sum y (i == p) or y'y (i == p + 1): lanes 0, 16, 32, 48 hold the four row slots
         const int base = MD::NPAIR * 256 + 2 * NBLK * 64 + (i == p ? 64 : 0);
         for (int w = 0; w < nwaves; ++w) {
@@ -235,13 +257,13 @@ __global__ __launch_bounds__(256) void moments_mid_finalize_kernel(const double*
     out[e] = s;
 }
 
-template <int NBLK>
+template <int NBLK, bool WEIGHTED>
 int launch_mid(pds_ctx* ctx, const DeviceCols<double>& dc, int p, int64_t n, double* d_moments) {
     using MD = MidDims<NBLK>;
     const int nwaves = ctx->num_cus * kMidWavesPerCu;
     double* partials = reinterpret_cast<double*>(ws_take(ctx, (size_t)(nwaves + 1) * MD::REC * sizeof(double)));
     if (!partials) return fail(PDS_ERR_HIP, "workspace allocation failed");
-    auto kern = moments_mid_kernel<NBLK>;
+    auto kern = moments_mid_kernel<NBLK, WEIGHTED>;
     if (MD::LDS_BYTES > 64 * 1024)
         PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, MD::LDS_BYTES));
     KernelTimer timer(ctx, kKindMoments);
@@ -250,7 +272,7 @@ int launch_mid(pds_ctx* ctx, const DeviceCols<double>& dc, int p, int64_t n, dou
     double* reduced = partials + (size_t)nwaves * MD::REC;
     hipLaunchKernelGGL(moments_mid_reduce_kernel, dim3((MD::REC + 63) / 64), dim3(256), 0, ctx->stream, (const double*)partials, nwaves, MD::REC, reduced);
     hipLaunchKernelGGL((moments_mid_finalize_kernel<NBLK>), dim3((q * q + 255) / 256), dim3(256), 0, ctx->stream, (const double*)reduced, 1, p, n,
-                       d_moments);
+                       WEIGHTED ? 1 : 0, d_moments);
     PDS_HIP_CHECK(hipGetLastError());
     return PDS_OK;
 }
@@ -259,10 +281,10 @@ int launch_mid(pds_ctx* ctx, const DeviceCols<double>& dc, int p, int64_t n, dou
 
 size_t moments_mid_workspace(int num_cus) { return (size_t)(num_cus * kMidWavesPerCu + 1) * MidDims<4>::REC * sizeof(double) + 4096; }
 
-// 17 .. 64 f64 features, unweighted: d_moments = (p+2)^2 column-major over [x_0 .. x_{p-1}, 1, y]
-int launch_moments_mid(pds_ctx* ctx, const DeviceCols<double>& dc, int n_feat, int64_t n_rows, double* d_moments) {
-    if (n_feat <= 32) return launch_mid<2>(ctx, dc, n_feat, n_rows, d_moments);
-    if (n_feat <= 64) return launch_mid<4>(ctx, dc, n_feat, n_rows, d_moments);
+// 17 .. 64 f64 features (weights: table entry p + 1): d_moments = (p+2)^2 column-major over [x_0 .. x_{p-1}, 1, y]
+int launch_moments_mid(pds_ctx* ctx, const DeviceCols<double>& dc, int n_feat, int64_t n_rows, bool weighted, double* d_moments) {
+    if (n_feat <= 32) return weighted ? launch_mid<2, true>(ctx, dc, n_feat, n_rows, d_moments) : launch_mid<2, false>(ctx, dc, n_feat, n_rows, d_moments);
+    if (n_feat <= 64) return weighted ? launch_mid<4, true>(ctx, dc, n_feat, n_rows, d_moments) : launch_mid<4, false>(ctx, dc, n_feat, n_rows, d_moments);
     return fail(PDS_ERR_UNSUPPORTED, "moments_mid: up to 64 features");
 }
 

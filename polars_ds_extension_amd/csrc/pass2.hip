@@ -382,7 +382,19 @@ int launch_pass2(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_ro
             hipLaunchKernelGGL((pass2_wide_kernel<T, false>), dim3(nb), dim3(kP2Threads), 0, ctx->stream, dc.d_ptrs, n_feat,
                                add_bias ? 1 : 0, n_rows, d_beta, d_pred, d_resid, s_rows, ctx->partials);
         hipLaunchKernelGGL(pass2_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->partials, nb, d_sums);
-        if (hc_mode >= 2) {
+        bool lev_done = false;
+        if constexpr (std::is_same<T, double>::value) {
+            // 17 .. 64 f64 features: the leverages as an n x p' x p' product on the matrix cores (leverage_mid.hip);
+            // PDS_LEVERAGE_VALU=1 keeps the per-row vector-ALU form below (A/B)
+            const char* e = std::getenv("PDS_LEVERAGE_VALU");
+            if (hc_mode >= 2 && n_feat <= 64 && !(e && e[0] == '1')) {
+                PDS_HIP_CHECK(hipGetLastError());
+                const int rc = launch_leverage_mid(ctx, dc, n_feat, add_bias ? 1 : 0, n_rows, d_inv, hc_mode, s_rows);
+                if (rc == PDS_OK) lev_done = true;
+                else if (rc != PDS_ERR_UNSUPPORTED) return rc;
+            }
+        }
+        if (hc_mode >= 2 && !lev_done) {
             const int pp = n_feat + (add_bias ? 1 : 0);
             const size_t lds = (size_t)pp * ((pp + 15) & ~15) * sizeof(double);
             auto regs_form = [&](auto nc_c) {

@@ -100,6 +100,9 @@ def test_moments_mid_width_f64(pds, orc, n, p):
     M = pds.gram_moments(*cols_of(X), target=dev(y))
     assert nrel(M, ref) < 1e-13 and nrel(M, M.T) < 1e-15
     assert np.array_equal(M, pds.gram_moments(*cols_of(X), target=dev(y)))
+    w = rng.random(n) + 0.5
+    Mw = pds.gram_moments(*cols_of(X), target=dev(y), weights=dev(w))
+    assert nrel(Mw, Z.T @ (Z * w[:, None])) < 1e-13
     if n > 2:  # columns that start 8 bytes into a 16-byte unit
         full = dev(np.ascontiguousarray(np.c_[X, y].T))  # (p + 1) x n
         M2 = pds.gram_moments(*[full[j, 1:] for j in range(p)], target=full[p, 1:])
