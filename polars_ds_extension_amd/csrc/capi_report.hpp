@@ -25,6 +25,13 @@ static int report_second_pass(pds_ctx* ctx, const DeviceCols<T>& dc, int p, int6
         ha.hc_pow = hc - 1;
         return launch_moments<T>(ctx, dc, p, n_rows, false, d_mom2, d_beta, bias, d_sums, nullptr, &ha);
     }
+    if constexpr (std::is_same<T, double>::value) {
+        // 17 .. 64 f64 features: the same fusion on the streaming multi-tile-column kernel (moments_mid.hip, FUSE)
+        if (hc && !weighted && p > kMaxFeatSmall && p <= 64 && !no_fuse && (hc == 1 || d_inv)) {
+            const int rc = launch_report_mid(ctx, dc, p, bias, n_rows, d_beta, d_inv, hc, d_sums, d_mom2);
+            if (rc != PDS_ERR_UNSUPPORTED) return rc;
+        }
+    }
     T* d_s = hc ? reinterpret_cast<T*>(ws_take(ctx, (size_t)n_rows * sizeof(T))) : nullptr;
     if (int rc = launch_pass2<T>(ctx, dc, p, n_rows, bias, weighted, d_beta, d_inv, hc, nullptr, nullptr, d_sums,
                                  reinterpret_cast<double*>(d_s)))

@@ -246,6 +246,9 @@ int launch_grouped_pred(pds_ctx* ctx, const T* const* d_cols, int n_feat, int bi
                         uint8_t* d_row_null);
 
 // ---- leverage_mid.hip: HC2 / HC3 leverages of 17 .. 64 f64 features on the matrix cores (PDS_ERR_UNSUPPORTED: not applicable, nothing done)
+int leverage_operand(pds_ctx* ctx, const double* d_inv, int n_feat, int bias, const double** d_lop);
+int launch_report_mid(pds_ctx* ctx, const DeviceCols<double>& dc, int n_feat, int bias, int64_t n_rows, const double* d_beta, const double* d_inv,
+                      int hc_mode, double* d_sums, double* d_meat);  // moments_mid.hip: residuals + leverages + meat in one stream
 int launch_leverage_mid(pds_ctx* ctx, const DeviceCols<double>& dc, int n_feat, int bias, int64_t n_rows, const double* d_inv, int hc_mode,
                         double* d_s_rows);
 

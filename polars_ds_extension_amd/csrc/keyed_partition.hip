@@ -35,11 +35,14 @@ namespace {
 constexpr int kPartStreams = 8;        // one per XCD
 constexpr int kPartChunkRows = 4096;   // rows a block takes at a time (histogram and scatter use the same chunk -> stream map)
 constexpr int kPartLdsBytes = 152 * 1024;  // of the 160 KB of a CU
-constexpr int kPartAccumChunk = 16384; // records per accumulate workgroup
-constexpr int kAccumThreads = 1024;    // sixteen waves: the LDS atomics are latency bound (tools/valu_lds_rate.hip: 3.2 / 5.1 / 10 lanes per clk with 4 / 8 / 16 waves)
+constexpr int kPartAccumChunk = 32768; // records per accumulate workgroup
+constexpr int kAccumThreads = 256;     // four waves = (id groups of 64) x (parts of an id's moment record); two workgroups per CU, up to 256 registers per lane
 
 __host__ __device__ constexpr int tri_count(int q) { return q * (q + 1) / 2; }
 __host__ __device__ constexpr int tri_index(int i, int j, int q) { return i * q - (i * (i - 1)) / 2 + (j - i); }  // i <= j
+
+// threads that share one id's moment record in the accumulate kernel (NV entries of the upper triangle)
+__host__ __device__ constexpr int accum_tpi(int nv) { return nv <= 55 ? 1 : (nv <= 110 ? 2 : 4); }
 
 struct PartLayout {
     int pc;        // padded feature count (compile-time variant of the accumulate kernel)
@@ -67,10 +70,10 @@ PartLayout make_layout(int p) {
     L.nvp = L.nv | 1;
     L.meta_off = ((L.pc + 1) * (int)sizeof(T) + 7) & ~7;
     L.rs = (L.meta_off + 8 + 15) & ~15;
-    // ids per bucket: their moment records share the CU's LDS with the accumulate kernel's per-wave record stages (sixteen waves)
-    const size_t stage = (size_t)(kAccumThreads / 64) * 64 * L.rs + 16;
+    // ids per bucket: the accumulate kernel keeps their moment records in the registers of its 1024 threads, TPI threads per id
     int shift = 0;
-    while (((size_t)2 << shift) * L.nvp * 8 + stage <= (size_t)kPartLdsBytes) ++shift;
+    while ((2 << shift) <= kAccumThreads / accum_tpi(L.nv)) ++shift;
+    if (const char* e = std::getenv("PDS_PART_SHIFT")) shift = std::atoi(e);  // (scatter timing experiments: the accumulate launch then refuses)
     L.shift = shift;
     return L;
 }
@@ -149,25 +152,68 @@ __global__ __launch_bounds__(256) void part_scatter_kernel(const T* const* __res
 }
 
 // ---- 3. accumulate.  One workgroup per (bucket, chunk of kPartAccumChunk records).
-// Sixteen waves.  The records of a tile reach the wave through its own LDS stage: 16-byte pieces loaded by consecutive lanes from
-// consecutive addresses (1 KiB coalesced per instruction; the next tile's pieces wait in registers while this one is worked on).
-// What the kernel costs is its LDS atomics: 55 ds_add_f64 per record at 8 features, latency bound (tools/valu_lds_rate.hip: 3.2
-// lanes / clk with four waves on a CU, 5.1 with eight, 10 with sixteen); without them the pass takes 3.0 of its 6.1 ms (eight
-// waves, no prefetch), 1.5 of 4.6 ms as it stands (PDS_PART_DEBUG=1).  Lanes of a wave that share an id serialise on the same
-// addresses: ~3 lanes / clk here against 10 in the conflict-free microbenchmark.  Tried and slower (tools/experiments/): the
-// matrix cores on id-sorted half-tiles (keyed_partition_accum_mfma: 8.8 ms -- a run of ~4 records is one instruction behind a
-// chain of LDS round trips); wave-owned ids with register-resident records (keyed_partition_accum_wave_owned_ids: 8.3 ms --
-// one record per instruction sequence instead of 64).
+// The moment records of a bucket's ids live in REGISTERS: TPI threads own one id (EPT = ceil(NV / TPI) entries of its upper triangle
+// each -- up to 8 features ONE thread holds all 55); the waves of a workgroup are (id group of 64) x (part), so every lane of a
+// wave runs the same entries and the code of a part is straight-line.  (Sixteen waves with four threads per id read every record
+// four times: the random 16-byte LDS reads cost ~20 clk per wave instruction in bank conflicts and bounded the pass at 3.1 ms.)  A tile of TILE records is staged in LDS (the next one waits in registers), counting-sorted by id there
+// (one returning LDS atomic per record, a scan over the ids, one 16-bit slot per record), and every owner walks its id's records:
+// ~QP LDS reads and EPT FMAs per record and part -- against NV LDS atomics per record in the first version (55 ds_add_f64 at 8
+// features: ~3 lanes / clk with same-id lanes serialising, 4.6 ms of the 11.3 ms of the shuffled C3 frame; tools/valu_lds_rate.hip).
+// An id with more than kHeavy records in a tile (a giant group) leaves the owners' loop: the whole workgroup forms its records'
+// products, reduces them per wave and hands the sum to the owners through an LDS scratch.
+// Tried and slower (tools/experiments/): the matrix cores on id-sorted half-tiles (keyed_partition_accum_mfma: 8.8 ms); wave-owned
+// ids with register-resident records (keyed_partition_accum_wave_owned_ids: 8.3 ms); LDS atomics (keyed_partition_accum_lds_atomics).
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__host__ __device__ constexpr int accum_tile(int rs) { return rs <= 96 ? 512 : 256; }
+constexpr int kHeavy = 64;
+// ids whose records go through LDS to the table at a time (64, or 32 where 64 would need more LDS than the tile does)
+__host__ __device__ constexpr int accum_flush_ids(int nv, int rs) {
+    return (size_t)64 * (nv | 1) * 8 <= (size_t)accum_tile(rs) * rs + 4096 ? 64 : 32;
+}
+__host__ __device__ constexpr size_t accum_lds_bytes(int nv, int rs) {
+    const int tpi = accum_tpi(nv), ids = kAccumThreads / tpi, tile = accum_tile(rs), max_heavy = tile / kHeavy;
+    const size_t lists = (size_t)(ids + ids + 1 + 16 + max_heavy + 1) * 4 + (size_t)tile * 2 + 16 + (size_t)nv * 8;
+    const size_t work = (size_t)tile * rs + lists, flush = (size_t)accum_flush_ids(nv, rs) * (nv | 1) * 8;
+    return (work > flush ? work : flush) + 16;
+}
+
+template <typename T, int PC, int PART, int EPT>
+__device__ __forceinline__ void accum_record(const char* rec, double (&acc)[EPT]) {
+    constexpr int QP = PC + 2;
+    const T* vals = reinterpret_cast<const T*>(rec);
+    double z[QP];
+#pragma unroll
+    for (int c = 0; c < PC; ++c) z[c] = (double)vals[c];
+    z[PC] = 1.0;
+    z[PC + 1] = (double)vals[PC];
+    int v = 0;
+#pragma unroll
+    for (int a = 0; a < QP; ++a) {
+#pragma unroll
+        for (int b = a; b < QP; ++b) {
+            if (v >= PART * EPT && v < (PART + 1) * EPT) acc[v - PART * EPT] = fma(z[a], z[b], acc[v - PART * EPT]);
+            ++v;
+        }
+    }
+}
+
 template <typename T, int PC, int PPR>
 __global__ __launch_bounds__(kAccumThreads) void part_accum_kernel(const char* __restrict__ records, const unsigned* __restrict__ bucket_start /*n_buckets * 8 + 1*/,
                                                                    const unsigned* __restrict__ chunk_prefix /*n_buckets + 1*/, int64_t n_buckets,
-                                                                   int shift, int meta_off, double* __restrict__ table, int debug) {
+                                                                   int meta_off, double* __restrict__ table, int debug) {
     constexpr int QP = PC + 2, NV = tri_count(QP), NVP = NV | 1, RS = PPR * 16;
-    extern __shared__ __attribute__((aligned(16))) double mom_lds[];
-    const int gpb = 1 << shift;
-    char* stage_all = reinterpret_cast<char*>(mom_lds + (size_t)gpb * NVP);
-    stage_all += (16 - (reinterpret_cast<uintptr_t>(stage_all) & 15)) & 15;
+    constexpr int TPI = accum_tpi(NV), EPT = (NV + TPI - 1) / TPI, IDS = kAccumThreads / TPI, TILE = accum_tile(RS);
+    constexpr int KPT = (PPR * TILE + kAccumThreads - 1) / kAccumThreads;  // 16-byte pieces of the next tile a thread holds
+    constexpr int kMaxHeavy = TILE / kHeavy;
+    extern __shared__ __attribute__((aligned(16))) char acc_lds[];
+    char* tile = acc_lds;
+    unsigned* cnt = reinterpret_cast<unsigned*>(acc_lds + (size_t)TILE * RS);
+    unsigned* off = cnt + IDS;          // IDS + 1
+    unsigned* wtot = off + IDS + 1;     // 16
+    unsigned* heavy = wtot + 16;        // kMaxHeavy ids, then their count
+    unsigned short* sorted = reinterpret_cast<unsigned short*>(heavy + kMaxHeavy + 1);
+    double* scratch = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(sorted + TILE) + 7) & ~(uintptr_t)7);
+    double* mom = reinterpret_cast<double*>(acc_lds);  // (the flush at the end reuses the tile)
     const unsigned total_chunks = chunk_prefix[n_buckets];
     const unsigned w = blockIdx.x;
     if (w >= total_chunks) return;
@@ -182,76 +228,161 @@ __global__ __launch_bounds__(kAccumThreads) void part_accum_kernel(const char* _
     const unsigned chunk = w - chunk_prefix[bucket];
     const int64_t b0 = bucket_start[bucket * kPartStreams], b1 = bucket_start[(bucket + 1) * kPartStreams];
     const int64_t r0 = b0 + (int64_t)chunk * kPartAccumChunk, r1 = (r0 + kPartAccumChunk < b1) ? r0 + kPartAccumChunk : b1;
-    for (int i = threadIdx.x; i < gpb * NVP; i += kAccumThreads) mom_lds[i] = 0.0;
-    __syncthreads();
-    typedef __attribute__((address_space(3))) double* lds_d;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    char* st = stage_all + (size_t)wv * 64 * RS;
-    // the wave's tiles of 64 records; the next tile's pieces are loaded into registers while this one is worked on
-    constexpr int64_t STEP = (kAccumThreads / 64) * 64;
-    u32x4 nxt[PPR];
-    auto fetch = [&](int64_t base) __attribute__((always_inline)) {
-        const int nrec = (int)((r1 - base < 64) ? r1 - base : 64);
-        const u32x4* src = reinterpret_cast<const u32x4*>(records + (size_t)base * RS);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int part = __builtin_amdgcn_readfirstlane(wv % TPI);
+    const int my = (wv / TPI) * 64 + lane;  // the id (within the bucket) this thread owns a part of
+    for (int i = tid; i < IDS; i += kAccumThreads) cnt[i] = 0u;
+    if (tid < NV) scratch[tid] = 0.0;
+    static_assert(NV <= kAccumThreads && TILE % kAccumThreads == 0 && TPI <= 4, "scratch is cleared by one thread per entry");
+    double acc[EPT];
 #pragma unroll
-        for (int k = 0; k < PPR; ++k) {
-            const int j = k * 64 + lane;
-            if (j < nrec * PPR) nxt[k] = __builtin_nontemporal_load(src + j);
+    for (int e = 0; e < EPT; ++e) acc[e] = 0.0;
+    u32x4 nxt[KPT];
+    auto fetch = [&](int64_t base) __attribute__((always_inline)) {
+        const int np = (int)((r1 - base < TILE) ? r1 - base : TILE) * PPR;
+        const u32x4* src = reinterpret_cast<const u32x4*>(records + (size_t)base * RS);
+        // unconditional loads from a clamped index: a load under its own exec mask made the compiler wait for the previous one
+        // (vmcnt(0) in front of every address computation) -- five HBM round trips in a row per tile, 1.7 of the kernel's 3.6 ms
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const int j = k * kAccumThreads + tid;
+            nxt[k] = __builtin_nontemporal_load(src + (j < np ? j : np - 1));
         }
     };
-    int64_t base = r0 + (int64_t)wv * 64;
-    if (base < r1) fetch(base);
-    for (; base < r1; base += STEP) {
-        const int nrec = (int)((r1 - base < 64) ? r1 - base : 64);
+    if (r0 < r1) fetch(r0);
+    for (int64_t base = r0; base < r1; base += TILE) {
+        const int nrec = (int)((r1 - base < TILE) ? r1 - base : TILE);
 #pragma unroll
-        for (int k = 0; k < PPR; ++k) {
-            const int j = k * 64 + lane;
-            if (j < nrec * PPR) *reinterpret_cast<u32x4*>(st + j * 16) = nxt[k];
+        for (int k = 0; k < KPT; ++k) {
+            const int j = k * kAccumThreads + tid;
+            if (j < nrec * PPR) reinterpret_cast<u32x4*>(tile)[j] = nxt[k];
         }
-        PDS_WAVE_LDS_SYNC();
-        if (base + STEP < r1) fetch(base + STEP);
-        if (lane < nrec) {
-            const char* rec = st + lane * RS;
-            double z[QP];
-            const T* vals = reinterpret_cast<const T*>(rec);
+        if (tid == 0) heavy[kMaxHeavy] = 0u;
+        __syncthreads();  // (A) the tile is in LDS; the counters are zero
+        if (base + TILE < r1) fetch(base + TILE);
+        // ---- counting sort of the tile's records by id
+        constexpr int RPT = TILE / kAccumThreads;  // records a thread files
+        unsigned lid[RPT], rank[RPT];
+        if (debug & 2) continue;  // (experiment: stream the records only)
 #pragma unroll
-            for (int c = 0; c < PC; ++c) z[c] = (double)vals[c];
-            z[PC] = 1.0;
-            z[PC + 1] = (double)vals[PC];
-            const unsigned lid = *reinterpret_cast<const unsigned*>(rec + meta_off);
-            double* m = mom_lds + (size_t)lid * NVP;
-            int v = 0;
-            if (debug & 1) {  // (experiment: everything but the LDS atomics)
-                double sacc = 0.0;
+        for (int q = 0; q < RPT; ++q) {
+            const int t = q * kAccumThreads + tid;
+            lid[q] = rank[q] = 0u;
+            if (t < nrec) {
+                lid[q] = *reinterpret_cast<const unsigned*>(tile + (size_t)t * RS + meta_off);
+                rank[q] = atomicAdd(&cnt[lid[q]], 1u);
+            }
+        }
+        __syncthreads();  // (B)
+        unsigned c = 0u, incl = 0u;
+        if (tid < IDS) {
+            c = cnt[tid];
+            incl = c;
 #pragma unroll
-                for (int a = 0; a < QP; ++a)
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned t = __shfl_up(incl, d);
+                if (lane >= d) incl += t;
+            }
+            if (lane == 63) wtot[wv] = incl;
+        }
+        __syncthreads();  // (C)
+        if (tid < IDS) {
+            unsigned o = 0u;
+            for (int ww = 0; ww < wv; ++ww) o += wtot[ww];
+            off[tid] = o + incl - c;
+            if (tid == IDS - 1) off[IDS] = o + incl;
+            cnt[tid] = 0u;  // (read above; next written behind the next (A))
+        }
+        __syncthreads();  // (D)
 #pragma unroll
-                    for (int b = a; b < QP; ++b) sacc += z[a] * z[b];
-                if (sacc == 1.2345e300) m[0] = sacc;
-            } else {
-#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int t = q * kAccumThreads + tid;
+            if (t < nrec) sorted[off[lid[q]] + rank[q]] = (unsigned short)t;
+        }
+        __syncthreads();  // (E)
+        // ---- every owner walks its id's records
+        {
+            const unsigned k0 = off[my], k1 = off[my + 1];
+            if (k1 - k0 > (unsigned)kHeavy) {
+                if (part == 0) heavy[atomicAdd(&heavy[kMaxHeavy], 1u)] = (unsigned)my;
+            } else if (k0 < k1 && !(debug & 1)) {  // (debug 1 -- experiment: everything but the owners' loop)
+                auto run = [&](auto part_c) __attribute__((always_inline)) {
+                    constexpr int PART = decltype(part_c)::value;
+                    unsigned r = sorted[k0];
+                    for (unsigned k = k0; k < k1; ++k) {
+                        const unsigned rn = sorted[k + 1 < k1 ? k + 1 : k];
+                        accum_record<T, PC, PART, EPT>(tile + (size_t)r * RS, acc);
+                        r = rn;
+                    }
+                };
+                switch (part) {
+#define PDS_PART_CASE(N) case N: if constexpr (TPI > N) run(std::integral_constant<int, N>{}); break;
+                    PDS_PART_CASE(0) PDS_PART_CASE(1) PDS_PART_CASE(2) PDS_PART_CASE(3)
+#undef PDS_PART_CASE
+                    default: break;
+                }
+            }
+        }
+        __syncthreads();  // (F) everybody is done with the tile -- but for the heavy ids
+        const unsigned nh = heavy[kMaxHeavy];
+        for (unsigned i = 0; i < nh; ++i) {
+            const unsigned h = heavy[i], hk0 = off[h], hk1 = off[h + 1];
+            for (unsigned kb = hk0; kb < hk1; kb += kAccumThreads) {
+                if (kb + (unsigned)wv * 64 >= hk1) continue;  // (wave-uniform)
+                const unsigned k = kb + tid;
+                const bool in = k < hk1;
+                // (rare path: run-time loops, values straight from LDS -- no register arrays next to the owners' accumulators)
+                const T* vals = reinterpret_cast<const T*>(tile + (size_t)sorted[in ? k : hk0] * RS);
+                auto zval = [&](int idx) __attribute__((always_inline)) {
+                    return !in ? 0.0 : (idx == PC ? 1.0 : (double)vals[idx < PC ? idx : PC]);
+                };
+                int v = 0;
+#pragma unroll 1
                 for (int a = 0; a < QP; ++a) {
-#pragma unroll
+                    const double za = zval(a);
+#pragma unroll 1
                     for (int b = a; b < QP; ++b) {
-                        __builtin_amdgcn_ds_atomic_fadd_f64((lds_d)(m + v), z[a] * z[b]);
+                        double pv = za * zval(b);
+#pragma unroll
+                        for (int o = 32; o >= 1; o >>= 1) pv += __shfl_xor(pv, o);
+                        if (lane == 0) __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)(scratch + v), pv);
                         ++v;
                     }
                 }
             }
+            __syncthreads();
+            if ((unsigned)my == h) {
+#pragma unroll
+                for (int e = 0; e < EPT; ++e)
+                    if (part * EPT + e < NV) acc[e] += scratch[part * EPT + e];
+            }
+            __syncthreads();
+            if (tid < NV) scratch[tid] = 0.0;
+            __syncthreads();
         }
-        PDS_WAVE_LDS_SYNC();
     }
     __syncthreads();
-    if (debug & 2) return;  // (experiment: no flush to the table)
-    // ---- non-empty ids -> the table (several chunks of one bucket, and nobody else, meet here)
+    // ---- the owners' registers -> LDS, 64 ids at a time -> the table (several chunks of one bucket, and nobody else, meet here)
     constexpr int CNT = tri_index(PC, PC, QP);
-    double* tb = table + (size_t)bucket * gpb * NVP;
-    for (int i = threadIdx.x; i < gpb * NVP; i += kAccumThreads) {
-        const int lid = i / NVP;
-        if (mom_lds[lid * NVP + CNT] > 0.0) {
-            const double v = mom_lds[i];
-            if (v != 0.0) unsafeAtomicAdd(tb + i, v);
+    constexpr int FID = accum_flush_ids(NV, RS);
+    for (int id0 = 0; id0 < IDS; id0 += FID) {
+        if (my >= id0 && my < id0 + FID) {
+            const int l = my - id0;
+#pragma unroll
+            for (int e = 0; e < EPT; ++e)
+                if (part * EPT + e < NV) mom[l * NVP + part * EPT + e] = acc[e];
+            if (part == 0 && NVP > NV) mom[l * NVP + NV] = 0.0;
         }
+        __syncthreads();
+        double* tb = table + ((size_t)bucket * IDS + (size_t)id0) * NVP;
+        for (int i = tid; i < FID * NVP; i += kAccumThreads) {
+            const int l = i / NVP;
+            if (mom[l * NVP + CNT] > 0.0) {
+                const double v = mom[i];
+                if (v != 0.0) unsafeAtomicAdd(tb + i, v);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -320,12 +451,14 @@ int launch_accum(pds_ctx* ctx, unsigned grid, const PartLayout& L, const char* r
                  const unsigned* chunk_prefix, int64_t n_buckets, double* table) {
     constexpr int PPR = ((((PC + 1) * (int)sizeof(T) + 7) & ~7) + 8 + 15) / 16;  // = make_layout<T>(PC).rs / 16
     if (L.rs != PPR * 16) return fail(PDS_ERR_INVALID, "internal: record size");
-    const size_t lds = ((size_t)1 << L.shift) * L.nvp * 8 + (size_t)(kAccumThreads / 64) * 64 * L.rs + 16;
+    constexpr size_t lds = accum_lds_bytes(tri_count(PC + 2), PPR * 16);
+    static_assert(lds <= (size_t)kPartLdsBytes / 2, "two workgroups share the CU's LDS");
+    if ((1 << L.shift) != kAccumThreads / accum_tpi(tri_count(PC + 2))) return fail(PDS_ERR_INVALID, "internal: ids per bucket");
     auto kern = part_accum_kernel<T, PC, PPR>;
     if (lds > 64 * 1024) PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const char* dbg = std::getenv("PDS_PART_DEBUG");
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kAccumThreads), lds, ctx->stream, records, bucket_start, chunk_prefix, n_buckets, L.shift, L.meta_off,
-                       table, dbg ? std::atoi(dbg) : 0);
+    const char* dbg = std::getenv("PDS_PART_DEBUG");  // timing experiments only: the results are wrong with it
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kAccumThreads), lds, ctx->stream, records, bucket_start, chunk_prefix, n_buckets, L.meta_off, table,
+                       dbg ? std::atoi(dbg) : 0);
     PDS_HIP_CHECK(hipGetLastError());
     return PDS_OK;
 }

@@ -155,11 +155,10 @@ __global__ __launch_bounds__(256) void leverage_mid_kernel(const double* const* 
 }
 
 template <int NBLK>
-int launch_lev(pds_ctx* ctx, const DeviceCols<double>& dc, int p, int bias, int64_t n, const std::vector<double>& L, int pp, int hc,
-               double* s_rows) {
+void fill_lev_operand(const std::vector<double>& L, int p, int pp, int bias, std::vector<double>& lop) {
     using LD = LevDims<NBLK>;
-    // ---- operand-ordered copy of L: block (ablk, kstep): lane (k = lane >> 4, j = lane & 15) holds L[4 kstep + k][16 ablk + j]
-    std::vector<double> lop(LD::L_BYTES / 8, 0.0);
+    // operand-ordered copy of L: block (ablk, kstep): lane (k = lane >> 4, j = lane & 15) holds L[4 kstep + k][16 ablk + j]
+    lop.assign(LD::L_BYTES / 8, 0.0);
     for (int ablk = 0; ablk < NBLK; ++ablk)
         for (int ks = 4 * ablk; ks < 4 * NBLK; ++ks)
             for (int lane = 0; lane < 64; ++lane) {
@@ -170,24 +169,24 @@ int launch_lev(pds_ctx* ctx, const DeviceCols<double>& dc, int p, int bias, int6
         for (int a = 0; a < p; ++a) lop[(size_t)LD::NLB * 64 + a] = L[p + (size_t)a * pp];  // row p of L: the intercept's contribution
         lop[(size_t)LD::NLB * 64 + 16 * NBLK] = L[p + (size_t)p * pp] * L[p + (size_t)p * pp];
     }
-    double* d_lop = reinterpret_cast<double*>(ws_take(ctx, lop.size() * sizeof(double)));
-    if (!d_lop) return fail(PDS_ERR_HIP, "workspace allocation failed");
-    PDS_HIP_CHECK(hipMemcpyAsync(d_lop, lop.data(), lop.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+}
+
+template <int NBLK>
+int launch_lev(pds_ctx* ctx, const DeviceCols<double>& dc, int p, int bias, int64_t n, const double* d_lop, int hc, double* s_rows) {
+    using LD = LevDims<NBLK>;
     auto kern = leverage_mid_kernel<NBLK>;
     PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LD::LDS_BYTES));
-    hipLaunchKernelGGL(kern, dim3(ctx->num_cus), dim3(256), LD::LDS_BYTES, ctx->stream, dc.d_ptrs, p, bias, n, (const double*)d_lop, hc, s_rows);
+    hipLaunchKernelGGL(kern, dim3(ctx->num_cus), dim3(256), LD::LDS_BYTES, ctx->stream, dc.d_ptrs, p, bias, n, d_lop, hc, s_rows);
     PDS_HIP_CHECK(hipGetLastError());
-    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // (lop: source of the copy)
     return PDS_OK;
 }
 
 }  // namespace
 
-// s_rows[r] *= 1 / (1 - h_r)^(hc - 1), h_r = z_r' inv z_r, z = [x_0 .. x_{p-1}, (1)]; d_inv: p' x p' column-major on the device.
-// Returns PDS_OK, or PDS_ERR_UNSUPPORTED (nothing done) when the inverse has no Cholesky factor in f64 -- the caller then keeps
-// the vector-ALU form.
-int launch_leverage_mid(pds_ctx* ctx, const DeviceCols<double>& dc, int n_feat, int bias, int64_t n_rows, const double* d_inv, int hc_mode,
-                        double* d_s_rows) {
+// The operand-ordered Cholesky factor of d_inv (p' x p' column-major on the device; inv = L L') in the workspace of ctx:
+//   [ blocks (ablk, kstep >= 4 ablk) of 64 doubles | row p of L (16 NBLK doubles) | L[p][p]^2, 0 ],  NBLK = 2 (p <= 32) or 4.
+// Returns PDS_ERR_UNSUPPORTED (nothing done) when the inverse has no Cholesky factor in f64.  Synchronises the stream.
+int leverage_operand(pds_ctx* ctx, const double* d_inv, int n_feat, int bias, const double** d_lop) {
     if (n_feat < 17 || n_feat > 64) return PDS_ERR_UNSUPPORTED;
     const int pp = n_feat + (bias ? 1 : 0);
     std::vector<double> A((size_t)pp * pp), L((size_t)pp * pp, 0.0);
@@ -205,9 +204,27 @@ int launch_leverage_mid(pds_ctx* ctx, const DeviceCols<double>& dc, int n_feat, 
             L[i + (size_t)j * pp] = s / ljj;
         }
     }
+    std::vector<double> lop;
+    if (n_feat <= 32) fill_lev_operand<2>(L, n_feat, pp, bias, lop);
+    else fill_lev_operand<4>(L, n_feat, pp, bias, lop);
+    double* d = reinterpret_cast<double*>(ws_take(ctx, lop.size() * sizeof(double)));
+    if (!d) return fail(PDS_ERR_HIP, "workspace allocation failed");
+    PDS_HIP_CHECK(hipMemcpyAsync(d, lop.data(), lop.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // (lop: source of the copy)
+    *d_lop = d;
+    return PDS_OK;
+}
+
+// s_rows[r] *= 1 / (1 - h_r)^(hc - 1), h_r = z_r' inv z_r, z = [x_0 .. x_{p-1}, (1)]; d_inv: p' x p' column-major on the device.
+// Returns PDS_OK, or PDS_ERR_UNSUPPORTED (nothing done) when the inverse has no Cholesky factor in f64 -- the caller then keeps
+// the vector-ALU form.
+int launch_leverage_mid(pds_ctx* ctx, const DeviceCols<double>& dc, int n_feat, int bias, int64_t n_rows, const double* d_inv, int hc_mode,
+                        double* d_s_rows) {
+    const double* d_lop = nullptr;
+    if (int rc = leverage_operand(ctx, d_inv, n_feat, bias, &d_lop)) return rc;
     KernelTimer timer(ctx, kKindPass2);
-    if (n_feat <= 32) return launch_lev<2>(ctx, dc, n_feat, bias, n_rows, L, pp, hc_mode, d_s_rows);
-    return launch_lev<4>(ctx, dc, n_feat, bias, n_rows, L, pp, hc_mode, d_s_rows);
+    if (n_feat <= 32) return launch_lev<2>(ctx, dc, n_feat, bias, n_rows, d_lop, hc_mode, d_s_rows);
+    return launch_lev<4>(ctx, dc, n_feat, bias, n_rows, d_lop, hc_mode, d_s_rows);
 }
 
 }  // namespace pds

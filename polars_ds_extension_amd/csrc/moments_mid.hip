@@ -44,23 +44,60 @@ struct MidDims {
     static constexpr int NS = HR / 4;                          // 4-row steps per half-tile
     static constexpr int NPAIR = NBLK * (NBLK + 1) / 2;
     // per-wave partial record (doubles): NPAIR tiles of 4 registers x 64 lanes | xy, cs: NBLK x 64 each | yy, ys, sw: 64 each
-    static constexpr int REC = NPAIR * 256 + 2 * NBLK * 64 + 192;  // (+ sum w, weighted form)
+    static constexpr int REC = NPAIR * 256 + 2 * NBLK * 64 + 256;  // (+ sum w, weighted form; + sum e^2, fused report form)
 };
 
+// Fused report form (FUSE = 1: HC0 / HC1, 2: HC2 / HC3): four waves per workgroup share a front of the LDS --
+//   [ FUSE == 2: operand blocks of L | row p of L | L[p][p]^2, 0 ]  (leverage_operand, leverage_mid.hip)   | beta (16 NBLK) | b0, 0
+template <int NBLK, int FUSE>
+struct MidShared {
+    static constexpr int NLB = 4 * (NBLK * (NBLK + 1) / 2);
+    static constexpr int LB_OFF = FUSE == 2 ? NLB * 512 : 0;
+    static constexpr int C0_OFF = LB_OFF + (FUSE == 2 ? 16 * NBLK * 8 : 0);
+    static constexpr int BETA_OFF = C0_OFF + (FUSE == 2 ? 16 : 0);
+    static constexpr int BYTES = FUSE ? BETA_OFF + (16 * NBLK + 2) * 8 : 0;
+    static constexpr int WPB = FUSE ? 4 : 1;  // waves per workgroup
+};
+
+// operand block (ablk, kstep), kstep >= 4 ablk (the layout of leverage_operand)
+template <int NBLK>
+__device__ constexpr int mid_lev_block(int ablk, int kstep) {
+    int base = 0;
+    for (int a = 0; a < ablk; ++a) base += 4 * NBLK - 4 * a;
+    return base + (kstep - 4 * ablk);
+}
+
 // WEIGHTED: cols[p + 1] = w; the record is then Z' diag(w) Z (faer_weighted_lr's X'WX | X'Wy, lr_solvers.rs:386-409; entry (1, 1) = sum w)
-template <int NBLK, bool WEIGHTED>
-__global__ __launch_bounds__(64) void moments_mid_kernel(const double* const* __restrict__ cols, int p, int64_t n,
-                                                         double* __restrict__ partials) {
+// FUSE (the second pass of pl_lin_reg_report's robust errors, linear_regression.rs:880-909, in ONE stream over the frame): the weights
+// are made in the kernel from the half-tile it has just loaded -- s_r = e_r^2 (FUSE = 1: HC0 / HC1) or e_r^2 / (1 - h_r)^(hc - 1)
+// (FUSE = 2: HC2 / HC3, h_r = ||L' z_r||^2 on the matrix cores as in leverage_mid.hip) -- written to the weight column's LDS image and
+// consumed by the weighted Gram steps: the record is the meat X' diag(s) X, sum e^2 rides along, and neither the residuals nor the
+// n-row weight vector ever exist in memory.
+template <int NBLK, bool WEIGHTED, int FUSE>
+__global__ __launch_bounds__(FUSE ? 256 : 64) void moments_mid_kernel(const double* const* __restrict__ cols, int p, int64_t n,
+                                                                      double* __restrict__ partials, int bias, const double* __restrict__ beta,
+                                                                      const double* __restrict__ lop, int hc) {
     using MD = MidDims<NBLK>;
+    using MS = MidShared<NBLK, FUSE>;
     constexpr int HR = MD::HR, GS = MD::GS, NPAIR = MD::NPAIR, NS = MD::NS;
+    constexpr bool WT = WEIGHTED || FUSE != 0;      // the Gram steps read a weight image
+    constexpr bool WLOAD = WEIGHTED && FUSE == 0;   // ... which comes from memory
     extern __shared__ __attribute__((aligned(16))) char mid_lds[];
     typedef __attribute__((address_space(3))) char* lds_c;
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* glb_ptr;
     typedef double mid_d2 __attribute__((ext_vector_type(2)));
-    lds_c sm = (lds_c)mid_lds;
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = blockIdx.x, nwaves = gridDim.x;
+#define PDS_MID_LDSD(addr) (*(__attribute__((address_space(3))) double*)(addr))
+    const lds_c shared = (lds_c)mid_lds;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    lds_c sm = shared + MS::BYTES + wv * MD::LDS_BYTES;
+    const int64_t wave = (int64_t)blockIdx.x * MS::WPB + wv, nwaves = (int64_t)gridDim.x * MS::WPB;
+    if constexpr (FUSE != 0) {
+        if constexpr (FUSE == 2)
+            for (int i = threadIdx.x; i < MS::BETA_OFF / 8; i += 256) PDS_MID_LDSD(shared + i * 8) = lop[i];
+        for (int i = threadIdx.x; i < 16 * NBLK + 2; i += 256)
+            PDS_MID_LDSD(shared + MS::BETA_OFF + i * 8) = i < p ? beta[i] : ((i == 16 * NBLK && bias) ? beta[p] : 0.0);
+    }
     // whole half-tiles, dealt as contiguous ranges; the ragged tail (n mod HR rows) belongs to the last wave
     const int64_t nh = n / HR;
     const int64_t h0 = nh * wave / nwaves, h1 = nh * (wave + 1) / nwaves;
@@ -77,10 +114,11 @@ __global__ __launch_bounds__(64) void moments_mid_kernel(const double* const* __
         if (c < p) valid |= 1u << i;
     }
     const double* ybase = cols[p] + 2 * lane;  // (lanes 0 .. HR / 2 - 1)
-    const double* wbase = WEIGHTED ? cols[p + 1] + 2 * lane : ybase;
+    const double* wbase = WLOAD ? cols[p + 1] + 2 * lane : ybase;
     for (int i = lane * 16; i < MD::LDS_BYTES; i += 64 * 16) *(__attribute__((address_space(3))) mid_d2*)(sm + i) = mid_d2{0.0, 0.0};
-    static_assert(MD::LDS_BYTES % 16 == 0, "zeroed in 16-byte pieces");
-    PDS_WAVE_LDS_SYNC();
+    static_assert(MD::LDS_BYTES % 16 == 0 && MS::BYTES % 16 == 0, "zeroed in 16-byte pieces");
+    if constexpr (FUSE != 0) __syncthreads();  // (the only workgroup barrier: every wave reaches it)
+    else PDS_WAVE_LDS_SYNC();
     // instruction i of a half-tile (i == 16: the target)
     auto issue_one = [&](int i, int buf, int64_t row0) __attribute__((always_inline)) {
         if (i < 16) {
@@ -88,7 +126,7 @@ __global__ __launch_bounds__(64) void moments_mid_kernel(const double* const* __
                 __builtin_amdgcn_global_load_lds((glb_ptr)(as_global(cbase[i]) + row0), (lds_ptr)(sm + buf * MD::HALF_BYTES + i * GS), 16, 0, 0);
         } else if (lane < HR / 2) {
             __builtin_amdgcn_global_load_lds((glb_ptr)(as_global(ybase) + row0), (lds_ptr)(sm + buf * MD::HALF_BYTES + MD::Y_OFF), 16, 0, 0);
-            if constexpr (WEIGHTED)
+            if constexpr (WLOAD)
                 __builtin_amdgcn_global_load_lds((glb_ptr)(as_global(wbase) + row0), (lds_ptr)(sm + buf * MD::HALF_BYTES + MD::W_OFF), 16, 0, 0);
         }
     };
@@ -98,7 +136,7 @@ __global__ __launch_bounds__(64) void moments_mid_kernel(const double* const* __
     };
     // guarded form for the ragged tail: zero rows beyond `rows`
     auto load_tail = [&](int buf, int64_t row0, int rows) __attribute__((always_inline)) {
-        for (int c = 0; c <= p + (WEIGHTED ? 1 : 0); ++c) {
+        for (int c = 0; c <= p + (WLOAD ? 1 : 0); ++c) {
             const int off = c < p ? (c % 16) * GS + (c / 16) * HR * 8 : (c == p ? MD::Y_OFF : MD::W_OFF);
             const gptr<double> col = as_global(cols[c]);
             for (int r = lane; r < HR; r += 64)
@@ -112,6 +150,75 @@ __global__ __launch_bounds__(64) void moments_mid_kernel(const double* const* __
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) xy[b] = cs[b] = 0.0;
     const int fi = lane & 15, fk = lane >> 4;
+    // ---- fused report form: the weight image of half-tile `buf` (rows beyond `rows` get weight 0).  Per 16 rows: lane = (row fi,
+    // feature slot fk); the residual's dot product rides on the operand registers of the first output block; the next half-tile's
+    // loads go out between the row groups (they have the whole Gram phase to land)
+    double sse = 0.0;
+    auto produce = [&](int buf, int rows, bool next, int64_t next_row0) __attribute__((always_inline)) {
+        const lds_c base = sm + buf * MD::HALF_BYTES;
+        constexpr int RG = HR / 16, KS = 4 * NBLK, LPG = (17 + RG - 1) / RG;
+        const double b0 = PDS_MID_LDSD(shared + MS::BETA_OFF + 16 * NBLK * 8);
+        const double c0 = FUSE == 2 ? PDS_MID_LDSD(shared + MS::C0_OFF) : 0.0;
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg) {
+            if (next) {
+#pragma unroll
+                for (int cc = 0; cc < LPG; ++cc)
+                    if (rg * LPG + cc <= 16) issue_one(rg * LPG + cc, buf ^ 1, next_row0);
+            }
+            double predp = 0.0, hrow = 0.0;
+            auto operand = [&](int ks) __attribute__((always_inline)) {
+                return PDS_MID_LDSD(base + (4 * (ks & 3) + fk) * GS + (ks >> 2) * HR * 8 + (16 * rg + fi) * 8);
+            };
+            if constexpr (FUSE == 2) {
+                double hs[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ablk = 0; ablk < NBLK; ++ablk) {
+                    const double init = PDS_MID_LDSD(shared + MS::LB_OFF + (16 * ablk + fi) * 8);  // the intercept's row of L (zeros without)
+                    d4 t = d4{init, init, init, init};
+#pragma unroll
+                    for (int ks = 4 * ablk; ks < KS; ++ks) {
+                        const double a = operand(ks);
+                        const double b = PDS_MID_LDSD(shared + mid_lev_block<NBLK>(ablk, ks) * 512 + lane * 8);
+                        if (ablk == 0) predp = fma(a, PDS_MID_LDSD(shared + MS::BETA_OFF + (4 * ks + fk) * 8), predp);
+                        t = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, t, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hs[r] = fma(t[r], t[r], hs[r]);
+                }
+                // D has col = lane & 15 = output a, row = (lane >> 4) + 4 r: sum over a, then hand row fi its value
+                double hv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double v = hs[r];
+                    v += __shfl_xor(v, 1);
+                    v += __shfl_xor(v, 2);
+                    v += __shfl_xor(v, 4);
+                    v += __shfl_xor(v, 8);
+                    hv[r] = __shfl(v, 16 * (fi & 3));
+                }
+                const int rsel = fi >> 2;
+                hrow = (rsel == 0 ? hv[0] : rsel == 1 ? hv[1] : rsel == 2 ? hv[2] : hv[3]) + c0;
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) predp = fma(operand(ks), PDS_MID_LDSD(shared + MS::BETA_OFF + (4 * ks + fk) * 8), predp);
+            }
+            predp += __shfl_xor(predp, 16);
+            predp += __shfl_xor(predp, 32);
+            const int lr = 16 * rg + fi;
+            const double e = PDS_MID_LDSD(base + MD::Y_OFF + lr * 8) - (predp + b0);
+            const double e2 = lr < rows ? e * e : 0.0;
+            double sc = 1.0;
+            if constexpr (FUSE == 2) {
+                const double om = 1.0 - hrow;
+                sc = hc == 2 ? 1.0 / om : 1.0 / (om * om);
+            }
+            if (fk == 0) {
+                PDS_MID_LDSD(base + MD::W_OFF + lr * 8) = lr < rows ? e2 * sc : 0.0;
+                sse += e2;
+            }
+        }
+    };
     // `next`: the following half-tile's 17 loads are issued between the matrix instructions of the first steps
     constexpr int IPS = (17 + NS - 1) / NS < 2 ? 2 : (17 + NS - 1) / NS;  // load instructions per step
     auto consume = [&](int buf, bool next, int64_t next_row0) __attribute__((always_inline)) {
@@ -121,7 +228,7 @@ __global__ __launch_bounds__(64) void moments_mid_kernel(const double* const* __
 #pragma unroll
             for (int b = 0; b < NBLK; ++b) a[b] = *(const __attribute__((address_space(3))) double*)(base + fi * GS + b * HR * 8 + roff);
             yk = *(const __attribute__((address_space(3))) double*)(base + MD::Y_OFF + roff);
-            if constexpr (WEIGHTED) wk = *(const __attribute__((address_space(3))) double*)(base + MD::W_OFF + roff);
+            if constexpr (WT) wk = *(const __attribute__((address_space(3))) double*)(base + MD::W_OFF + roff);
         };
         // operands of step s + 1 are fetched from LDS before step s multiplies (one wave per SIMD: nobody else hides the round trip)
         double a[NBLK], yk, wk = 1.0;
@@ -132,7 +239,7 @@ __global__ __launch_bounds__(64) void moments_mid_kernel(const double* const* __
 #pragma unroll
             for (int b = 0; b < NBLK; ++b) an[b] = 0.0;
             if (s + 1 < NS) fetch(s + 1, an, ykn, wkn);
-            if (next) {
+            if (FUSE == 0 && next) {
 #pragma unroll
                 for (int cc = 0; cc < IPS; ++cc)
                     if (s * IPS + cc <= 16) issue_one(s * IPS + cc, buf ^ 1, next_row0);
@@ -140,8 +247,8 @@ __global__ __launch_bounds__(64) void moments_mid_kernel(const double* const* __
             // weighted: the A operand carries w x, the B operand x -- sum_k (w_k x_ki) x_kj
             double aw[NBLK];
 #pragma unroll
-            for (int b = 0; b < NBLK; ++b) aw[b] = WEIGHTED ? a[b] * wk : a[b];
-            const double ywk = WEIGHTED ? yk * wk : yk;
+            for (int b = 0; b < NBLK; ++b) aw[b] = WT ? a[b] * wk : a[b];
+            const double ywk = WT ? yk * wk : yk;
             int q = 0;
 #pragma unroll
             for (int I = 0; I < NBLK; ++I)
@@ -157,7 +264,7 @@ __global__ __launch_bounds__(64) void moments_mid_kernel(const double* const* __
             }
             yy = fma(ywk, yk, yy);
             ys += ywk;
-            if constexpr (WEIGHTED) sw += wk;
+            if constexpr (WT) sw += wk;
 #pragma unroll
             for (int b = 0; b < NBLK; ++b) a[b] = an[b];
             yk = ykn;
@@ -170,6 +277,10 @@ __global__ __launch_bounds__(64) void moments_mid_kernel(const double* const* __
             const int buf = (int)((h - h0) & 1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // half-tile h has landed (the compiler does not order LDS reads behind it)
             __builtin_amdgcn_wave_barrier();
+            if constexpr (FUSE != 0) {
+                produce(buf, HR, h + 1 < h1, (h + 1) * HR);
+                PDS_WAVE_LDS_SYNC();
+            }
             consume(buf, h + 1 < h1, (h + 1) * HR);  // (the other image was consumed one iteration ago: free for the next half-tile)
             PDS_WAVE_LDS_SYNC();
         }
@@ -177,6 +288,10 @@ __global__ __launch_bounds__(64) void moments_mid_kernel(const double* const* __
     if (tail > 0) {
         load_tail(0, nh * HR, tail);
         PDS_WAVE_LDS_SYNC();
+        if constexpr (FUSE != 0) {
+            produce(0, tail, false, 0);
+            PDS_WAVE_LDS_SYNC();
+        }
         consume(0, false, 0);
     }
     // ---- the wave's partial record
@@ -194,6 +309,8 @@ __global__ __launch_bounds__(64) void moments_mid_kernel(const double* const* __
     v[2 * NBLK * 64 + lane] = yy;
     v[2 * NBLK * 64 + 64 + lane] = ys;
     v[2 * NBLK * 64 + 128 + lane] = sw;
+    v[2 * NBLK * 64 + 192 + lane] = sse;
+#undef PDS_MID_LDSD
 }
 
 // per-wave records -> one record: entry idx summed over the waves in a fixed order (four interleaved partial sums, then their sum)
@@ -211,10 +328,19 @@ __global__ __launch_bounds__(256) void moments_mid_reduce_kernel(const double* _
 // one thread per entry (i <= j) of the (p+2)^2 moment matrix over [x_0 .. x_{p-1}, 1, y]: fixed-order sum over the waves
 template <int NBLK>
 __global__ __launch_bounds__(256) void moments_mid_finalize_kernel(const double* __restrict__ partials, int nwaves, int p, int64_t n, int weighted,
-                                                                   double* __restrict__ out) {
+                                                                   double* __restrict__ out, double* __restrict__ sums /* nullable: [sum e^2, 0] */) {
     using MD = MidDims<NBLK>;
     const int q = p + 2;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e == 0 && sums) {
+        double t = 0.0;
+        for (int w = 0; w < nwaves; ++w) {
+            const double* v = partials + (size_t)w * MD::REC + MD::NPAIR * 256 + 2 * NBLK * 64 + 192;
+            for (int l = 0; l < 64; l += 4) t += (v[l] + v[l + 1]) + (v[l + 2] + v[l + 3]);
+        }
+        sums[0] = t;
+        sums[1] = 0.0;
+    }
     if (e >= q * q) return;
     int i = e % q, j = e / q;
     if (i > j) {
@@ -257,22 +383,25 @@ __global__ __launch_bounds__(256) void moments_mid_finalize_kernel(const double*
     out[e] = s;
 }
 
-template <int NBLK, bool WEIGHTED>
-int launch_mid(pds_ctx* ctx, const DeviceCols<double>& dc, int p, int64_t n, double* d_moments) {
+template <int NBLK, bool WEIGHTED, int FUSE>
+int launch_mid(pds_ctx* ctx, const DeviceCols<double>& dc, int p, int64_t n, double* d_moments, int bias = 0, const double* d_beta = nullptr,
+               const double* d_lop = nullptr, int hc = 0, double* d_sums = nullptr) {
     using MD = MidDims<NBLK>;
+    using MS = MidShared<NBLK, FUSE>;
     const int nwaves = ctx->num_cus * kMidWavesPerCu;
     double* partials = reinterpret_cast<double*>(ws_take(ctx, (size_t)(nwaves + 1) * MD::REC * sizeof(double)));
     if (!partials) return fail(PDS_ERR_HIP, "workspace allocation failed");
-    auto kern = moments_mid_kernel<NBLK, WEIGHTED>;
-    if (MD::LDS_BYTES > 64 * 1024)
-        PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, MD::LDS_BYTES));
-    KernelTimer timer(ctx, kKindMoments);
-    hipLaunchKernelGGL(kern, dim3(nwaves), dim3(64), MD::LDS_BYTES, ctx->stream, dc.d_ptrs, p, n, partials);
+    auto kern = moments_mid_kernel<NBLK, WEIGHTED, FUSE>;
+    constexpr int lds = MS::BYTES + MS::WPB * MD::LDS_BYTES;
+    static_assert(lds <= 160 * 1024, "one workgroup per CU at most");
+    if (lds > 64 * 1024) PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    KernelTimer timer(ctx, FUSE ? kKindPass2 : kKindMoments);
+    hipLaunchKernelGGL(kern, dim3(nwaves / MS::WPB), dim3(64 * MS::WPB), lds, ctx->stream, dc.d_ptrs, p, n, partials, bias, d_beta, d_lop, hc);
     const int q = p + 2;
     double* reduced = partials + (size_t)nwaves * MD::REC;
     hipLaunchKernelGGL(moments_mid_reduce_kernel, dim3((MD::REC + 63) / 64), dim3(256), 0, ctx->stream, (const double*)partials, nwaves, MD::REC, reduced);
     hipLaunchKernelGGL((moments_mid_finalize_kernel<NBLK>), dim3((q * q + 255) / 256), dim3(256), 0, ctx->stream, (const double*)reduced, 1, p, n,
-                       WEIGHTED ? 1 : 0, d_moments);
+                       (WEIGHTED || FUSE) ? 1 : 0, d_moments, d_sums);
     PDS_HIP_CHECK(hipGetLastError());
     return PDS_OK;
 }
@@ -283,9 +412,25 @@ size_t moments_mid_workspace(int num_cus) { return (size_t)(num_cus * kMidWavesP
 
 // 17 .. 64 f64 features (weights: table entry p + 1): d_moments = (p+2)^2 column-major over [x_0 .. x_{p-1}, 1, y]
 int launch_moments_mid(pds_ctx* ctx, const DeviceCols<double>& dc, int n_feat, int64_t n_rows, bool weighted, double* d_moments) {
-    if (n_feat <= 32) return weighted ? launch_mid<2, true>(ctx, dc, n_feat, n_rows, d_moments) : launch_mid<2, false>(ctx, dc, n_feat, n_rows, d_moments);
-    if (n_feat <= 64) return weighted ? launch_mid<4, true>(ctx, dc, n_feat, n_rows, d_moments) : launch_mid<4, false>(ctx, dc, n_feat, n_rows, d_moments);
+    if (n_feat <= 32) return weighted ? launch_mid<2, true, 0>(ctx, dc, n_feat, n_rows, d_moments) : launch_mid<2, false, 0>(ctx, dc, n_feat, n_rows, d_moments);
+    if (n_feat <= 64) return weighted ? launch_mid<4, true, 0>(ctx, dc, n_feat, n_rows, d_moments) : launch_mid<4, false, 0>(ctx, dc, n_feat, n_rows, d_moments);
     return fail(PDS_ERR_UNSUPPORTED, "moments_mid: up to 64 features");
+}
+
+// The second pass of an UNWEIGHTED report with robust errors, 17 .. 64 f64 features, as one stream: d_sums = [sum e^2, 0] and
+// d_meat = the (p+2)^2 moment layout of X' diag(s) X, s = e^2 (hc_mode 1) or e^2 / (1 - h)^(hc_mode - 1) (2, 3; d_inv = (X'X)^-1).
+// PDS_ERR_UNSUPPORTED (nothing done): the inverse has no Cholesky factor -- the caller keeps the three-kernel form.
+int launch_report_mid(pds_ctx* ctx, const DeviceCols<double>& dc, int n_feat, int bias, int64_t n_rows, const double* d_beta, const double* d_inv,
+                      int hc_mode, double* d_sums, double* d_meat) {
+    if (n_feat < 17 || n_feat > 64 || hc_mode < 1) return PDS_ERR_UNSUPPORTED;
+    if (hc_mode == 1) {
+        if (n_feat <= 32) return launch_mid<2, false, 1>(ctx, dc, n_feat, n_rows, d_meat, bias, d_beta, nullptr, 1, d_sums);
+        return launch_mid<4, false, 1>(ctx, dc, n_feat, n_rows, d_meat, bias, d_beta, nullptr, 1, d_sums);
+    }
+    const double* d_lop = nullptr;
+    if (int rc = leverage_operand(ctx, d_inv, n_feat, bias, &d_lop)) return rc;
+    if (n_feat <= 32) return launch_mid<2, false, 2>(ctx, dc, n_feat, n_rows, d_meat, bias, d_beta, d_lop, hc_mode, d_sums);
+    return launch_mid<4, false, 2>(ctx, dc, n_feat, n_rows, d_meat, bias, d_beta, d_lop, hc_mode, d_sums);
 }
 
 }  // namespace pds

@@ -1588,7 +1588,7 @@ def test_multi_target(pds, orc, p):
     assert out["target_0"] is None and out["target_1"] is None  # the gate depends on X only: all targets null
 
 
-@pytest.mark.parametrize("p,bias", [(17, True), (40, False), (130, True)])
+@pytest.mark.parametrize("p,bias", [(17, True), (32, True), (33, False), (40, False), (64, True), (130, True)])
 def test_wide_weighted_and_hc(pds, orc, p, bias):
     # p > 16 with a weight column: X' diag(w) X as the Gram of sqrt(w) Z; WLS report; HC0 / HC1 sandwich
     rng = np.random.default_rng(900 + p)
@@ -1610,6 +1610,8 @@ def test_wide_weighted_and_hc(pds, orc, p, bias):
         ro = orc.lin_reg_report(Xb, y, std_err=se)
         assert nrel(r["beta"], ro["beta"]) < F64_TOL and frel(r[f"{se}_se"], ro["std_err"], 1e-12) < 1e-9
         assert frel(r["t"], ro["t"], 1e-6) < 1e-8 and frel(r["p>|t|"], ro["p"], 1e-12) < 1e-6
+        # 17 .. 64 features: residuals, leverages and the meat come out of ONE kernel (moments_mid.hip FUSE) -- sum e^2 too
+        assert abs(r["r2"][0] - ro["r2"]) < 1e-11
 
 
 def test_wide_pred_and_report(pds, orc):
