@@ -25,22 +25,57 @@ __global__ __launch_bounds__(256) void key_descent_kernel(const int64_t* __restr
 
 // one pass over the keys: is any key smaller than its predecessor, and the smallest / largest key (state: [flag, -, min, max] as
 // four int64 slots; min / max start at INT64_MAX / INT64_MIN)
+// Every wave takes 128-key pieces (1 KiB per load instruction, 16 bytes per lane, four pieces in flight); a key's successor is the
+// lane's own second key, the next lane's first (DPP shift) or -- lane 63 -- the first key of the next piece (one extra 8-byte load).
+// (The first version read every key twice with 8-byte loads: 0.40 ms for 1e8 keys = 2 TB/s, a quarter of every ordered by-key call.)
 __global__ __launch_bounds__(256) void key_order_minmax_kernel(const int64_t* __restrict__ keys, int64_t n, long long* __restrict__ state) {
+    typedef long long ll2 __attribute__((ext_vector_type(2), aligned(16)));
     bool found = false;
     long long mn = 0x7fffffffffffffffll, mx = -0x7fffffffffffffffll - 1;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const long long k = __builtin_nontemporal_load(keys + i);
-        if (i + 1 < n) found = found || keys[i + 1] < k;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    // 16-byte alignment of the buffer decides where the vector part starts
+    const int64_t head = (((uintptr_t)keys & 15) != 0 && n > 0) ? 1 : 0;
+    const int64_t npieces = (n - head) / 128;
+    auto take = [&](long long k, long long next) __attribute__((always_inline)) {
+        found = found || next < k;
         mn = k < mn ? k : mn;
         mx = k > mx ? k : mx;
+    };
+    constexpr int U = 4;
+    for (int64_t p0 = wave * U; p0 < npieces; p0 += nwaves * U) {
+        ll2 v[U];
+        long long edge[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t pc = p0 + u < npieces ? p0 + u : npieces - 1;  // (clamped: unconditional loads)
+            const int64_t base = head + pc * 128;
+            v[u] = __builtin_nontemporal_load(reinterpret_cast<const ll2*>(keys + base) + lane);
+            const int64_t e = base + 128 < n ? base + 128 : n - 1;
+            edge[u] = keys[e];  // (wave-uniform address: one scalar-like broadcast load)
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (p0 + u < npieces) {
+                long long nxt = __shfl_down(v[u].x, 1);
+                if (lane == 63) nxt = edge[u];  // (the frame's last key is its own successor: the clamped index)
+                take(v[u].x, v[u].y);
+                take(v[u].y, nxt);
+            }
+        }
+    }
+    // the unaligned first key and the keys behind the last whole piece
+    if (wave == 0) {
+        if (head && lane == 0) take(keys[0], n > 1 ? keys[1] : keys[0]);
+        for (int64_t i = head + npieces * 128 + lane; i < n; i += 64) take(keys[i], i + 1 < n ? keys[i + 1] : keys[i]);
     }
     for (int o = 32; o > 0; o >>= 1) {
         const long long a = __shfl_down(mn, o), b = __shfl_down(mx, o);
         mn = a < mn ? a : mn;
         mx = b > mx ? b : mx;
     }
-    if (__any(found) && (threadIdx.x & 63) == 0) atomicOr(reinterpret_cast<unsigned long long*>(state), 1ull);
-    if ((threadIdx.x & 63) == 0) {
+    if (__any(found) && lane == 0) atomicOr(reinterpret_cast<unsigned long long*>(state), 1ull);
+    if (lane == 0) {
         atomicMin(state + 2, mn);
         atomicMax(state + 3, mx);
     }

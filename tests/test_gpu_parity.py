@@ -795,6 +795,27 @@ def test_grouped_by_key_any_row_order(pds, orc, p, bias):
     assert np.max(np.linalg.norm(co2.cpu().numpy() - co_o, axis=1) / np.linalg.norm(co_o, axis=1)) < 1e-9
 
 
+def test_by_key_order_check_sees_every_inversion(pds):
+    """keyed.hip's one-pass order check (16-byte loads, the successor of a key from the lane itself, the next lane or the next
+    128-key piece): ONE adjacent inversion anywhere -- inside a lane's pair, between lanes, between pieces, in the unaligned head,
+    in the tail behind the last whole piece -- must send the frame down the sorting route.  A missed inversion would show: the
+    run-length groups of an unsorted key column repeat a key."""
+    import torch
+
+    for n, shift in ((128 * 9 + 37, 0), (128 * 9 + 37, 1), (131, 0), (129, 1), (128, 0), (5, 0), (2, 0)):
+        base = torch.arange(n + shift, dtype=torch.int64, device="cuda")
+        x = torch.linspace(0.0, 1.0, n + shift, dtype=torch.float64, device="cuda")
+        spots = sorted({0, 1, 2, 62, 63, 64, 125, 126, 127, 128, 129, 254, 255, 256, 511, 512, n - 3, n - 2} & set(range(n - 1)))
+        for i in spots:
+            k = base.clone()
+            k[shift + i], k[shift + i + 1] = base[shift + i + 1].clone(), base[shift + i].clone()
+            kk, xx = k[shift:], x[shift:]  # (shift = 1: a key buffer that is 8- but not 16-byte aligned)
+            k_out, _, _ = pds.lin_reg_by_key(xx, target=xx, key=kk)
+            assert torch.equal(k_out, base[shift:]), (n, shift, i)
+        k_out, _, _ = pds.lin_reg_by_key(x[shift:], target=x[shift:], key=base[shift:])  # ordered: the keys as they are
+        assert torch.equal(k_out, base[shift:])
+
+
 @pytest.mark.parametrize("p,bias", [(4, True), (15, True), (16, False), (20, True)])
 def test_grouped_weighted(pds, orc, p, bias):
     """group_by(key).agg(pds.lin_reg(..., weights=w)): per group faer_weighted_lr (lr_solvers.rs:386-409)."""
