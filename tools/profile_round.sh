@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (via gpurun): collects everything profiles/rNN_* is built from into gpurun_out/prof/.
-#   bash tools/profile_round.sh        then, back in the repo:  python tools/summarize_profiles.py r02
+#   bash tools/profile_round.sh        then, back in the repo:  python tools/summarize_profiles.py r03
 # PMC passes are separate runs with --kernel-trace only (never combined with sys/hip/hsa traces).
 # Every profiler run is under `timeout` and writes to a file (tools/README.md, GPU-box hygiene).
 set -u
@@ -23,4 +23,13 @@ done
 timeout -k 5 500 python -u $ROOT/tools/bench_extra.py > $OUT/bench_extra.json 2> $OUT/bench_extra.err
 rm -rf /tmp/p3 && timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p3 -o x -- python -u $ROOT/tools/bench_extra.py rolling en single report > $OUT/extra_stats_run.log 2>&1
 cp $(find /tmp/p3 -name "*kernel_stats.csv" | head -1) $OUT/extra_kernel_stats.csv
+# round 3: the routes added this round -- shuffled keys (partition route), grouped pred, mid-width reports -- kernel stats and HBM counters
+rm -rf /tmp/p5 && timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p5 -o k -- python -u $ROOT/tools/ab_quick.py keyed pred > $OUT/keyed_run.log 2>&1
+cp $(find /tmp/p5 -name "*kernel_stats.csv" | head -1) $OUT/keyed_kernel_stats.csv
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/p6 && timeout -k 5 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/p6 -o k -- python -u $ROOT/tools/ab_quick.py keyed > $OUT/pmc_keyed_$c.log 2>&1
+  cp $(find /tmp/p6 -name "*counter_collection.csv" | head -1) $OUT/pmc_keyed_$c.csv
+done
+rm -rf /tmp/p7 && timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p7 -o w -- python -u $ROOT/tools/wide_report_prof.py > $OUT/wide_run.log 2>&1
+cp $(find /tmp/p7 -name "*kernel_stats.csv" | head -1) $OUT/wide_kernel_stats.csv
 ls -la $OUT

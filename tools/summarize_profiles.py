@@ -108,5 +108,32 @@ md += ["", f"Algorithmic bytes per launch of the fused grouped kernel: {rf['algo
 for n, c, us, pct in stats(SRC / "extra_kernel_stats.csv"):
     md.append(f"| `{n}` | {c} | {us:.1f} |")
 md += ["", "```json", json.dumps({k: v for k, v in extra.items()}, indent=1), "```", ""]
+# ---- round 3: shuffled keys (partition route) + grouped pred, mid-width reports
+for tag, title, cmd in (("keyed", "Keys in any row order (C3 frame, shuffled) + grouped pred", "python tools/ab_quick.py keyed pred"),
+                        ("wide", "Mid-width single regressions and reports (2e7 x 20 / 32 / 64 f64)", "python tools/wide_report_prof.py")):
+    f = SRC / f"{tag}_kernel_stats.csv"
+    if not f.exists():
+        continue
+    (OUT / f"{rnd}_{tag}_kernel_stats.csv").write_text(f.read_text())
+    md += [f"## {title}: `rocprofv3 --kernel-trace --stats -- {cmd}`", "", "| kernel | calls | avg us |", "|---|---|---|"]
+    for n, c, us, pct in stats(f):
+        if us * c > 200.0:
+            md.append(f"| `{n}` | {c} | {us:.1f} |")
+    log = SRC / f"{tag}_run.log"
+    if log.exists():
+        keep = [l for l in log.read_text().splitlines() if l.startswith(("keyed", "n=")) or " ms" in l and "rocprof" not in l and "amdgpu" not in l]
+        md += ["", "```", *keep[:40], "```", ""]
+kf, kw = SRC / "pmc_keyed_FETCH_SIZE.csv", SRC / "pmc_keyed_WRITE_SIZE.csv"
+if kf.exists() and kw.exists():
+    f2, w2 = pmc(kf), pmc(kw)
+    md += ["HBM traffic of the shuffled-keys route (PMC, per launch):", "", "| kernel | read MB | write MB |", "|---|---|---|"]
+    kt = {}
+    for k in f2:
+        rd, wr = 2.0 * f2[k][0] * 1024, w2.get(k, (0.0, 0))[0] * 1024
+        if rd + wr > 5e7:
+            md.append(f"| `{k}` | {rd / 1e6:.1f} | {wr / 1e6:.1f} |")
+            kt[k] = {"read_bytes_corrected": rd, "write_bytes": wr, "launches_sampled": f2[k][1]}
+    (OUT / f"{rnd}_keyed_traffic.json").write_text(json.dumps(kt, indent=1) + "\n")
+    md.append("")
 (OUT / f"{rnd}_summary.md").write_text("\n".join(md))
 print("wrote", sorted(p.name for p in OUT.glob(f"{rnd}_*")))
