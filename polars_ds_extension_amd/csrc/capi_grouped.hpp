@@ -439,12 +439,13 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
         return fail(PDS_ERR_UNSUPPORTED, "sliced fit: the slice's keys are not in order");
     }
     // ---- keys in any order: smallest / largest key decide the route.  Dense integer keys (group ids) of an unweighted
-    // coefficient fit with up to 16 features take the partition route (keyed_partition.hip: no sort, no random-access pass);
+    // fit with up to 16 features take the partition route (keyed_partition.hip: no sort, no random-access pass; per-row
+    // predictions then look the row's group up from its key -- grouped_pred.hip MODE 2 -- and nothing is ever permuted);
     // PDS_KEYED_SORT=1 keeps the sorting route (A/B)
     int64_t part_buckets = 0;
     if (!sorted) {
         static const bool force_sort = [] { const char* e = std::getenv("PDS_KEYED_SORT"); return e && e[0] == '1'; }();
-        if (!force_sort && !weights && !want_pred)
+        if (!force_sort && !weights)
             part_buckets = keyed_partition_buckets<T>(n_feat, n_rows, (uint64_t)mm[1] - (uint64_t)mm[0] + 1);
     }
     const bool partition = part_buckets > 0;
@@ -499,6 +500,25 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
         if (space == PDS_HOST || !is_null) d_nu = reinterpret_cast<uint8_t*>(take((size_t)cap));
         if (int rc = solve_partition_table<T>(ctx, st, n_feat, ng, d_offsets, prm, d_co, d_nu)) return rc;
         tr.mark("solve");
+        if (want_pred) {
+            T* d_pred = pred;
+            T* d_resid = resid;
+            uint8_t* d_rn = row_null;
+            if (space == PDS_HOST) {
+                if (pred) d_pred = reinterpret_cast<T*>(take((size_t)n_rows * sizeof(T)));
+                if (resid) d_resid = reinterpret_cast<T*>(take((size_t)n_rows * sizeof(T)));
+                if (row_null) d_rn = reinterpret_cast<uint8_t*>(take((size_t)n_rows));
+            }
+            if (int rc = launch_grouped_pred_by_id<T>(ctx, d_tbl, n_feat, prm->add_bias ? 1 : 0, n_rows, d_keys, d_minmax, st.rank, ng, d_co, d_nu,
+                                                      d_pred, d_resid, d_rn))
+                return rc;
+            if (space == PDS_HOST) {
+                if (pred) PDS_HIP_CHECK(hipMemcpyAsync(pred, d_pred, (size_t)n_rows * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+                if (resid) PDS_HIP_CHECK(hipMemcpyAsync(resid, d_resid, (size_t)n_rows * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+                if (row_null) PDS_HIP_CHECK(hipMemcpyAsync(row_null, d_rn, (size_t)n_rows, hipMemcpyDeviceToHost, ctx->stream));
+            }
+            tr.mark("pred");
+        }
         if (space == PDS_HOST) {
             if (coeffs) PDS_HIP_CHECK(hipMemcpyAsync(coeffs, d_co, (size_t)ng * pp * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
             if (coeffs && is_null) PDS_HIP_CHECK(hipMemcpyAsync(is_null, d_nu, (size_t)ng, hipMemcpyDeviceToHost, ctx->stream));

@@ -245,6 +245,10 @@ int launch_grouped_pred(pds_ctx* ctx, const T* const* d_cols, int n_feat, int bi
                         int64_t n_groups, const T* d_coeffs, const uint8_t* d_flags, const uint32_t* d_perm, T* d_pred, T* d_resid,
                         uint8_t* d_row_null);
 
+template <typename T>
+int launch_grouped_pred_by_id(pds_ctx* ctx, const T* const* d_cols, int n_feat, int bias, int64_t n_rows, const int64_t* d_keys,
+                              const int64_t* d_kmin, const uint32_t* d_rank, int64_t n_groups, const T* d_coeffs, const uint8_t* d_flags,
+                              T* d_pred, T* d_resid, uint8_t* d_row_null);  // grouped_pred.hip
 // ---- leverage_mid.hip: HC2 / HC3 leverages of 17 .. 64 f64 features on the matrix cores (PDS_ERR_UNSUPPORTED: not applicable, nothing done)
 int leverage_operand(pds_ctx* ctx, const double* d_inv, int n_feat, int bias, const double** d_lop);
 int launch_report_mid(pds_ctx* ctx, const DeviceCols<double>& dc, int n_feat, int bias, int64_t n_rows, const double* d_beta, const double* d_inv,
@@ -307,6 +311,7 @@ int keyed_sort(pds_ctx* ctx, const int64_t* d_keys, int64_t n, uint32_t* d_idx_i
 struct KeyedPartitionState {
     double* table = nullptr;   // [ids][nvp]: upper triangle of Z'Z, Z = [x_0..x_{pc-1}, 1, y], per dense id
     unsigned* ids = nullptr;   // dense id of group r (ascending)
+    unsigned* rank = nullptr;  // group of dense id i (valid where the id has rows)
     int pc = 0, nvp = 0;
 };
 template <typename T>

@@ -49,12 +49,18 @@ __device__ __forceinline__ int64_t group_of_row(const int64_t* __restrict__ off,
 }
 
 // PC: feature count as a compile-time constant (1..16), 0 = run time (any width, column loop)
-template <typename T, int PC, bool PERM>
+// MODE 0: rows in group order (offsets); 1: ... and results sent back through `perm`; 2: rows in ANY order, the group of a row looked
+// up from its key (dense ids: group = rank[key - *kmin], keyed_partition.hip) -- the frame is read where it lies, nothing is
+// permuted, and the n_groups x p' coefficient block is the only randomly read object (72 MB at 1e6 groups x 8 features: it lives
+// in the L2s / the memory-side cache)
+template <typename T, int PC, int MODE>
 __global__ __launch_bounds__(kGpThreads) void grouped_pred_kernel(const T* const* __restrict__ cols, int p_arg, int bias, int64_t n,
                                                                   const int64_t* __restrict__ off, int64_t n_groups,
                                                                   const T* __restrict__ coeffs, const uint8_t* __restrict__ flags,
-                                                                  const uint32_t* __restrict__ perm, T* __restrict__ pred,
-                                                                  T* __restrict__ resid, uint8_t* __restrict__ row_null) {
+                                                                  const uint32_t* __restrict__ perm /* MODE 2: rank */, T* __restrict__ pred,
+                                                                  T* __restrict__ resid, uint8_t* __restrict__ row_null,
+                                                                  const int64_t* __restrict__ keys, const int64_t* __restrict__ kmin) {
+    constexpr bool PERM = MODE == 1;
     using V = typename GP16<T>::type;
     constexpr int RPL = GP16<T>::RPL;
     const int p = PC ? PC : p_arg;
@@ -67,7 +73,10 @@ __global__ __launch_bounds__(kGpThreads) void grouped_pred_kernel(const T* const
     if (c0 >= c1) return;
     const T nanv = (T)__builtin_nan("");
     int64_t g[RPL];
-    {
+    uint64_t kbase = 0;
+    if constexpr (MODE == 2) {
+        kbase = (uint64_t)*kmin;
+    } else {
         const int64_t r = c0 * 64 * RPL + (int64_t)lane * RPL;
         const int64_t g0 = group_of_row(off, n_groups, r < n ? r : n - 1);
 #pragma unroll
@@ -78,13 +87,22 @@ __global__ __launch_bounds__(kGpThreads) void grouped_pred_kernel(const T* const
         const int64_t r0 = ch * 64 * RPL + (int64_t)lane * RPL;
         if (r0 >= n) continue;
         const bool full = r0 + RPL <= n;
-        // ---- the groups of the lane's rows (monotone in r: forward steps only)
+        if constexpr (MODE == 2) {
+            // ---- the groups of the lane's rows: key -> dense id -> rank
 #pragma unroll
-        for (int e = 0; e < RPL; ++e) {
-            const int64_t r = (r0 + e < n) ? r0 + e : n - 1;
-            int64_t ge = e ? (g[e - 1] > g[e] ? g[e - 1] : g[e]) : g[0];
-            while (ge + 1 < n_groups && off[ge + 1] <= r) ++ge;
-            g[e] = ge;
+            for (int e = 0; e < RPL; ++e) {
+                const int64_t r = (r0 + e < n) ? r0 + e : n - 1;
+                g[e] = (int64_t)perm[(uint64_t)__builtin_nontemporal_load(keys + r) - kbase];
+            }
+        } else {
+            // ---- the groups of the lane's rows (monotone in r: forward steps only)
+#pragma unroll
+            for (int e = 0; e < RPL; ++e) {
+                const int64_t r = (r0 + e < n) ? r0 + e : n - 1;
+                int64_t ge = e ? (g[e - 1] > g[e] ? g[e - 1] : g[e]) : g[0];
+                while (ge + 1 < n_groups && off[ge + 1] <= r) ++ge;
+                g[e] = ge;
+            }
         }
         double acc[RPL];
         const T* brow[RPL];
@@ -156,13 +174,14 @@ __global__ __launch_bounds__(kGpThreads) void grouped_pred_kernel(const T* const
     }
 }
 
-template <typename T, bool PERM>
+template <typename T, int MODE>
 void launch_pc(int p, dim3 g, hipStream_t st, const T* const* cols, int bias, int64_t n, const int64_t* off, int64_t ng,
-               const T* co, const uint8_t* fl, const uint32_t* perm, T* pred, T* resid, uint8_t* rn) {
+               const T* co, const uint8_t* fl, const uint32_t* perm, T* pred, T* resid, uint8_t* rn, const int64_t* keys = nullptr,
+               const int64_t* kmin = nullptr) {
 #define PDS_GP_CASE(PCV)                                                                                                         \
     case PCV:                                                                                                                    \
-        hipLaunchKernelGGL((grouped_pred_kernel<T, PCV, PERM>), g, dim3(kGpThreads), 0, st, cols, p, bias, n, off, ng, co, fl, perm, \
-                           pred, resid, rn);                                                                                     \
+        hipLaunchKernelGGL((grouped_pred_kernel<T, PCV, MODE>), g, dim3(kGpThreads), 0, st, cols, p, bias, n, off, ng, co, fl, perm, \
+                           pred, resid, rn, keys, kmin);                                                                         \
         break;
     switch (p) {
         PDS_GP_CASE(1)
@@ -182,8 +201,8 @@ void launch_pc(int p, dim3 g, hipStream_t st, const T* const* cols, int bias, in
         PDS_GP_CASE(15)
         PDS_GP_CASE(16)
         default:
-            hipLaunchKernelGGL((grouped_pred_kernel<T, 0, PERM>), g, dim3(kGpThreads), 0, st, cols, p, bias, n, off, ng, co, fl, perm,
-                               pred, resid, rn);
+            hipLaunchKernelGGL((grouped_pred_kernel<T, 0, MODE>), g, dim3(kGpThreads), 0, st, cols, p, bias, n, off, ng, co, fl, perm,
+                               pred, resid, rn, keys, kmin);
     }
 #undef PDS_GP_CASE
 }
@@ -202,14 +221,33 @@ int launch_grouped_pred(pds_ctx* ctx, const T* const* d_cols, int n_feat, int bi
     const int64_t nchunk = (n_rows + 64 * RPL - 1) / (64 * RPL);
     const int nb = (int)std::min<int64_t>(std::max<int64_t>((nchunk + 3) / 4, 1), (int64_t)ctx->num_cus * 8);
     if (d_perm)
-        launch_pc<T, true>(n_feat, dim3(nb), ctx->stream, d_cols, bias, n_rows, d_off, n_groups, d_coeffs, d_flags, d_perm, d_pred,
+        launch_pc<T, 1>(n_feat, dim3(nb), ctx->stream, d_cols, bias, n_rows, d_off, n_groups, d_coeffs, d_flags, d_perm, d_pred,
                            d_resid, d_row_null);
     else
-        launch_pc<T, false>(n_feat, dim3(nb), ctx->stream, d_cols, bias, n_rows, d_off, n_groups, d_coeffs, d_flags, d_perm, d_pred,
+        launch_pc<T, 0>(n_feat, dim3(nb), ctx->stream, d_cols, bias, n_rows, d_off, n_groups, d_coeffs, d_flags, d_perm, d_pred,
                             d_resid, d_row_null);
     PDS_HIP_CHECK(hipGetLastError());
     return PDS_OK;
 }
+// rows in any order, dense integer keys: group of row r = d_rank[keys[r] - *d_kmin] (the partition route's id -> group table)
+template <typename T>
+int launch_grouped_pred_by_id(pds_ctx* ctx, const T* const* d_cols, int n_feat, int bias, int64_t n_rows, const int64_t* d_keys,
+                              const int64_t* d_kmin, const uint32_t* d_rank, int64_t n_groups, const T* d_coeffs, const uint8_t* d_flags,
+                              T* d_pred, T* d_resid, uint8_t* d_row_null) {
+    if (n_rows <= 0 || n_groups <= 0) return PDS_OK;
+    KernelTimer timer(ctx, kKindPass2);
+    constexpr int RPL = GP16<T>::RPL;
+    const int64_t nchunk = (n_rows + 64 * RPL - 1) / (64 * RPL);
+    const int nb = (int)std::min<int64_t>(std::max<int64_t>((nchunk + 3) / 4, 1), (int64_t)ctx->num_cus * 8);
+    launch_pc<T, 2>(n_feat, dim3(nb), ctx->stream, d_cols, bias, n_rows, nullptr, n_groups, d_coeffs, d_flags, d_rank, d_pred, d_resid,
+                    d_row_null, d_keys, d_kmin);
+    PDS_HIP_CHECK(hipGetLastError());
+    return PDS_OK;
+}
+template int launch_grouped_pred_by_id<double>(pds_ctx*, const double* const*, int, int, int64_t, const int64_t*, const int64_t*,
+                                               const uint32_t*, int64_t, const double*, const uint8_t*, double*, double*, uint8_t*);
+template int launch_grouped_pred_by_id<float>(pds_ctx*, const float* const*, int, int, int64_t, const int64_t*, const int64_t*,
+                                              const uint32_t*, int64_t, const float*, const uint8_t*, float*, float*, uint8_t*);
 template int launch_grouped_pred<double>(pds_ctx*, const double* const*, int, int, int64_t, const int64_t*, int64_t, const double*,
                                          const uint8_t*, const uint32_t*, double*, double*, uint8_t*);
 template int launch_grouped_pred<float>(pds_ctx*, const float* const*, int, int, int64_t, const int64_t*, int64_t, const float*,

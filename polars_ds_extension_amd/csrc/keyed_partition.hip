@@ -575,6 +575,7 @@ int keyed_partition_build(pds_ctx* ctx, const T* const* d_cols, const int64_t* d
     *n_groups = (int64_t)h_ng;
     st.table = table;
     st.ids = id_of;
+    st.rank = rank;
     st.pc = L.pc;
     st.nvp = L.nvp;
     if ((int64_t)h_ng > max_groups) return fail(PDS_ERR_INVALID, "more distinct keys than max_groups");

@@ -669,6 +669,24 @@ def test_by_key_partition_route_against_oracle(pds, orc, p, bias, kw):
                                     max_iter=2000, **kw)
     assert np.array_equal(k3, k1) and np.array_equal(n3.astype(bool), n1)
     assert np.max(np.linalg.norm(c3[ok] - c1[ok], axis=1) / np.linalg.norm(c1[ok], axis=1)) < 1e-9
+    if not kw:
+        # per-row predictions of the shuffled frame (grouped_pred.hip MODE 2: the row's group looked up from its key, nothing
+        # permuted): the route's own coefficients applied to every row where it lies; rows of null groups are null
+        pr, rs, rn = pds.lin_reg_by_key_pred(*cols_of(Xp), target=dev(yp), key=dev(kp), add_bias=bias)
+        pr, rs, rn = pr.cpu().numpy(), rs.cpu().numpy(), rn.cpu().numpy().astype(bool)
+        gi = np.searchsorted(uk, kp)
+        assert np.array_equal(rn, n1[gi])
+        Xb = np.c_[Xp, np.ones(N)] if bias else Xp
+        live = ~rn
+        own = np.einsum("ij,ij->i", Xb[live], c1[gi[live]])
+        scale = np.linalg.norm(Xb[live], axis=1) * np.linalg.norm(c1[gi[live]], axis=1)
+        assert np.max(np.abs(pr[live] - own) / scale) < 1e-12
+        assert np.max(np.abs(rs[live] - (yp[live] - own)) / np.maximum(scale, np.abs(yp[live]))) < 1e-12
+        assert np.all(np.isnan(pr[rn])) and np.all(np.isnan(rs[rn]))
+        ph, rh, nh = pds.lin_reg_by_key_pred(*[np.ascontiguousarray(Xp[:, j]) for j in range(p)], target=yp, key=kp, add_bias=bias)
+        # (not bit for bit: the records of a bucket arrive in the order of the scatter's atomics, so the sums round differently per call)
+        assert np.array_equal(nh.astype(bool), rn)
+        assert np.max(np.abs(ph[live] - pr[live]) / scale) < 1e-9 and np.max(np.abs(rh[live] - rs[live]) / np.maximum(scale, np.abs(yp[live]))) < 1e-9
 
 
 def test_by_key_partition_route_f32_and_giant_group(pds, orc, f32):

@@ -13,7 +13,7 @@ OUT.mkdir(exist_ok=True)
 
 
 def short(name):
-    name = name.replace("void ", "")
+    name = name.replace("void ", "").replace("(anonymous namespace)::", "")
     return name.split("(")[0]
 
 
