@@ -13,9 +13,9 @@
 //     block triangle of X'X, A and B operands being the same registers -- with independent accumulators;
 //   * X'y, the column sums, y'y and sum y ride on the VALU from the same operand registers (the target is one more LDS column);
 //   * per-wave partial records, summed in wave order by a finalize kernel: no atomics, bit-reproducible.
-// Bound: HBM up to 32 features (2 x 3 matrix instructions per 4 rows = 0.55 ms per 2e7 rows against 1.05 ms of HBM time for
-// 2e7 x 33 doubles), the f64 matrix pipe beyond (10 instructions per 4 rows at 64 features: 2.9 ms of pipe per 2e7 rows at the
-// measured 86 clk per instruction, tools/mfma_peak.hip).
+// Bound: HBM up to 32 features (3 matrix instructions per 4 rows = 0.52 ms per 2e7 rows against 1.05 ms of HBM time for
+// 2e7 x 33 doubles), the f64 matrix pipe beyond (10 instructions per 4 rows at 64 features: 1.75 ms of pipe per 2e7 rows at the
+// measured 86 clk per instruction and SIMD, tools/mfma_peak.hip, against 1.30 ms of HBM time).
 #include "common.hpp"
 #include "moments_dev.hpp"
 
