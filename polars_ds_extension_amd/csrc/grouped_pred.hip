@@ -36,6 +36,7 @@ struct GP16<float> {
 };
 
 constexpr int kGpThreads = 256;
+constexpr int kGpStage = 192;  // doubles of wave-private LDS for the coefficient rows of the groups a 64-lane chunk touches
 
 // last group whose first row is <= r (empty groups are skipped over: off is non-decreasing)
 __device__ __forceinline__ int64_t group_of_row(const int64_t* __restrict__ off, int64_t n_groups, int64_t r) {
@@ -72,6 +73,12 @@ __global__ __launch_bounds__(kGpThreads) void grouped_pred_kernel(const T* const
     const int64_t c0 = nchunk * wave / nwaves, c1 = nchunk * (wave + 1) / nwaves;
     if (c0 >= c1) return;
     const T nanv = (T)__builtin_nan("");
+    // coefficient rows of a chunk's groups, staged once per chunk (rows in group order only): per column step a lane then reads its
+    // coefficient from LDS -- without the stage every column cost RPL more vector-memory instructions (51 instead of 17 per chunk
+    // at 16 features; the kernel ran at 0.60 of the HBM peak against 0.82 for the single-regression residual pass)
+    __shared__ T coef_stage[kGpThreads / 64][kGpStage];
+    T* stage = coef_stage[threadIdx.x >> 6];
+    const bool rn_vec = (reinterpret_cast<uintptr_t>(row_null) & (RPL - 1)) == 0;
     int64_t g[RPL];
     uint64_t kbase = 0;
     if constexpr (MODE == 2) {
@@ -85,8 +92,8 @@ __global__ __launch_bounds__(kGpThreads) void grouped_pred_kernel(const T* const
     const gptr<T> cy = as_global(cols[p]);
     for (int64_t ch = c0; ch < c1; ++ch) {
         const int64_t r0 = ch * 64 * RPL + (int64_t)lane * RPL;
-        if (r0 >= n) continue;
-        const bool full = r0 + RPL <= n;
+        const bool full = r0 + RPL <= n;  // (lanes behind the last row stay in the loop -- clamped rows, masked stores: the chunk's
+                                          // cross-lane steps below need the whole wave)
         if constexpr (MODE == 2) {
             // ---- the groups of the lane's rows: key -> dense id -> rank
 #pragma unroll
@@ -106,11 +113,26 @@ __global__ __launch_bounds__(kGpThreads) void grouped_pred_kernel(const T* const
         }
         double acc[RPL];
         const T* brow[RPL];
+        bool staged = false;
+        if constexpr (MODE != 2) {
+            const int64_t g_lo = __shfl(g[0], 0), g_hi = __shfl(g[RPL - 1], 63);
+            const int64_t cnt = (g_hi - g_lo + 1) * pp;
+            staged = cnt <= kGpStage;  // (wave-uniform)
+            if (staged) {
+                PDS_WAVE_LDS_SYNC();  // (the previous chunk's reads are done)
+                const T* src = coeffs + g_lo * pp;
+                for (int i = lane; i < (int)cnt; i += 64) stage[i] = src[i];
+                PDS_WAVE_LDS_SYNC();
 #pragma unroll
-        for (int e = 0; e < RPL; ++e) {
-            brow[e] = coeffs + g[e] * pp;
-            acc[e] = bias ? (double)brow[e][p] : 0.0;
+                for (int e = 0; e < RPL; ++e) brow[e] = stage + (g[e] - g_lo) * pp;
+            }
         }
+        if (!staged) {
+#pragma unroll
+            for (int e = 0; e < RPL; ++e) brow[e] = coeffs + g[e] * pp;
+        }
+#pragma unroll
+        for (int e = 0; e < RPL; ++e) acc[e] = bias ? (double)brow[e][p] : 0.0;
         auto col_step = [&](int c) __attribute__((always_inline)) {
             const gptr<T> col = as_global(cols[c]);
             V v;
@@ -159,8 +181,13 @@ __global__ __launch_bounds__(kGpThreads) void grouped_pred_kernel(const T* const
             if (pred) *reinterpret_cast<V*>(pred + r0) = pv;
             if (resid) *reinterpret_cast<V*>(resid + r0) = rv;
             if (row_null) {
+                if (rn_vec) {  // one RPL-byte store per lane instead of RPL byte stores
+                    if constexpr (RPL == 2) *reinterpret_cast<uint16_t*>(row_null + r0) = (uint16_t)(nl[0] | (nl[1] << 8));
+                    else *reinterpret_cast<uint32_t*>(row_null + r0) = (uint32_t)nl[0] | ((uint32_t)nl[1] << 8) | ((uint32_t)nl[2] << 16) | ((uint32_t)nl[3] << 24);
+                } else {
 #pragma unroll
-                for (int e = 0; e < RPL; ++e) row_null[r0 + e] = nl[e];
+                    for (int e = 0; e < RPL; ++e) row_null[r0 + e] = nl[e];
+                }
             }
         } else {
 #pragma unroll

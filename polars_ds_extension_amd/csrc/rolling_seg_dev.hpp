@@ -219,14 +219,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             for (int64_t r = a0 + lane; r < t0; r += 64) {
                 SegRow<PP> row;
                 const bool in = r >= 0;
+                // unconditional loads from clamped (column, row): a load under its own exec mask is serialised behind the previous
+                // one by the compiler's vmcnt(0) (keyed_partition.hip found the same pattern)
+                const int64_t rc = in ? r : 0;
 #pragma unroll
                 for (int c = 0; c < PP; ++c) {
-                    double x = 0.0;
-                    if (c < p) x = in ? (double)as_global(cols[c])[r] : 0.0;
-                    else if (c == p && ra.bias) x = 1.0;
-                    row.z[c] = x;
+                    const double x = (double)as_global(cols[c < p ? c : p])[rc];
+                    row.z[c] = (c < p) ? (in ? x : 0.0) : ((c == p && ra.bias) ? 1.0 : 0.0);
                 }
-                row.y = in ? (double)as_global(cols[p])[r] : 0.0;
+                row.y = in ? (double)as_global(cols[p])[rc] : 0.0;
                 const bool ok = in && seg_finite<PP>(row);
                 if (!ok) seg_zero<PP>(row);
                 seg_accumulate<PP, NV, 1>(A, row, ok);
@@ -256,23 +257,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             // play the previous stage: straight from global memory, guarded at the front of the frame
             const int64_t rp = t0 - kSegStage + (int64_t)K * lane;
             auto load_prev = [&](int cc, double (&v)[K]) __attribute__((always_inline)) {
+                // branch-free (tiles start at multiples of the tile length, so the K rows are all inside the frame or all in front of
+                // it): the loads of the PP + 1 columns go out back to back instead of one round trip per column
                 gptr<T> col = as_global(cols[cc]);
-                if (rp >= 0) {
+                const int64_t rq = rp >= 0 ? rp : 0;
 #pragma unroll
-                    for (int j = 0; j < PIECES; ++j) {
-                        const V16 x = *reinterpret_cast<gptr<V16>>(col + rp + j * E16);
+                for (int j = 0; j < PIECES; ++j) {
+                    const V16 x = *reinterpret_cast<gptr<V16>>(col + rq + j * E16);
 #pragma unroll
-                        for (int e = 0; e < E16; ++e) v[j * E16 + e] = (double)x[e];
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < K; ++i) v[i] = (rp + i >= 0) ? (double)col[rp + i] : 0.0;
+                    for (int e = 0; e < E16; ++e) v[j * E16 + e] = rp >= 0 ? (double)x[e] : 0.0;
                 }
             };
 #pragma unroll
             for (int c = 0; c < PP; ++c) {
                 double v[K];
-                if (c < p) load_prev(c, v);
+                load_prev(c < p ? c : p, v);  // (unconditional: see the anchor loop)
 #pragma unroll
                 for (int i = 0; i < K; ++i) rn[i].z[c] = (c < p) ? v[i] : ((c == p && ra.bias) ? 1.0 : 0.0);
             }
