@@ -368,6 +368,18 @@ static int solve_partition_table(pds_ctx* ctx, const KeyedPartitionState& st, in
     T* d_mom = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * (size_t)chunk * q * q));
     SolveParams sp{n_feat, bias, prm->solver == PDS_SOLVER_SVD ? PDS_SOLVER_QR : prm->solver, prm->l2_reg, prm->singular_x_tol, 0};
     const bool f32 = sizeof(T) == 4;
+    // OLS / ridge with up to 16 coefficients: the register-resident solver reads the table's triangles itself (no expansion pass)
+    if (method.kind == Method::OLS && pp <= 16 && (sp.solver != PDS_SOLVER_CHOLESKEY || sp.gate_tol > 0.0)) {
+        static const bool expand = [] { const char* e = std::getenv("PDS_PART_EXPAND"); return e && e[0] == '1'; }();  // (A/B)
+        if (!expand) {
+            TriSource tri;
+            tri.table = st.table;
+            tri.ids = st.ids;
+            tri.nvp = st.nvp;
+            tri.pc = st.pc;
+            return launch_solve_reg<T>(ctx, nullptr, n_groups, sp, d_coeffs, d_null, d_offsets, &tri);
+        }
+    }
     for (int64_t g0 = 0; g0 < n_groups; g0 += chunk) {
         const int64_t gc = std::min(chunk, n_groups - g0);
         if (int rc = keyed_partition_records<T>(ctx, st, n_feat, g0, gc, d_mom)) return rc;

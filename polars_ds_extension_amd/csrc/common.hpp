@@ -226,10 +226,16 @@ template <typename T>
 int launch_solve_big(pds_ctx* ctx, const T* d_moments, int64_t n_sys, const SolveParams& sp, T* d_coeffs, uint8_t* d_flags,
                      T* d_inv_out);
 
-// solve_reg.hip: register-resident variant (p' <= 16, QR, no inverse); used by launch_solve
+// solve_reg.hip: register-resident variant (p' <= 16, QR, no inverse); used by launch_solve.  `tri` (nullable): the systems are rows
+// ids[s] of an id-indexed table of packed upper triangles over [x_0 .. x_{pc-1}, 1, y] (keyed_partition.hip) instead of d_moments
+struct TriSource {
+    const double* table = nullptr;
+    const unsigned* ids = nullptr;
+    int nvp = 0, pc = 0;
+};
 template <typename T>
 int launch_solve_reg(pds_ctx* ctx, const T* d_moments, int64_t n_sys, const SolveParams& sp, T* d_coeffs,
-                     uint8_t* d_flags, const int64_t* d_rows_per_sys);
+                     uint8_t* d_flags, const int64_t* d_rows_per_sys, const TriSource* tri = nullptr);
 
 template <typename T>
 int launch_cd(pds_ctx* ctx, const T* d_moments, int p, int add_bias, double l1, double l2, double tol,

@@ -539,7 +539,8 @@ int keyed_partition_build(pds_ctx* ctx, const T* const* d_cols, const int64_t* d
     PDS_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(d_temp, temp_bytes, (const unsigned*)counts, starts, (int)ncnt, s));
     PDS_HIP_CHECK(hipMemcpyAsync(cursor, starts, ncnt * 4, hipMemcpyDeviceToDevice, s));
     // ---- 2. scatter
-    int sb = (int)std::min<int64_t>(nchunks, (int64_t)ctx->num_cus * 4);
+    static const int scatter_bpc = [] { const char* e = std::getenv("PDS_PART_SCATTER_BPC"); return e ? std::max(1, std::atoi(e)) : 6; }();  // (2: 7.1 ms, 4: 4.76, 6: 4.59, 8: 5.52 on the C3 frame -- tools/gpu_scatter_bpc.sh)
+    int sb = (int)std::min<int64_t>(nchunks, (int64_t)ctx->num_cus * scatter_bpc);
     sb = std::max(kPartStreams, sb / kPartStreams * kPartStreams);
     const int ppr = L.rs / 16;
     switch (ppr) {
