@@ -59,7 +59,7 @@ while time.time() < t_end:
         note("lr/" + method, e)
         assert e < (1e-7 if method in ("lasso", "enet", "nnls") else 1e-9), (method, p, n, bias, e)
     elif kind == "report":
-        p = int(rng.choice([1, 3, 8, 16, 20, 33]))
+        p = int(rng.choice([1, 3, 8, 16, 17, 20, 32, 33, 48, 64]))  # 17 .. 64: the fused one-stream robust errors (moments_mid.hip)
         n = int(rng.integers(20 * p + 50, 80_000))
         bias = bool(rng.integers(0, 2))
         se = str(rng.choice(["se", "hc0", "hc1", "hc2", "hc3"]))
@@ -93,7 +93,7 @@ while time.time() < t_end:
         note(kind, e)
         assert e < 1e-7, (kind, p, bias, n, w, lam, e)   # the reference's chain itself drifts ~1e-10 from the direct solves
     else:
-        p = int(rng.choice([1, 4, 8, 16]))
+        p = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 10, 12, 16]))
         G = int(rng.integers(2, 3000))
         sizes = rng.integers(0, int(rng.choice([5, 60, 400])), size=G) + (p + 2)
         keys = np.repeat(rng.permutation(G).astype(np.int64) * 7 - 1000, sizes)
@@ -111,6 +111,18 @@ while time.time() < t_end:
             if m.sum() >= 3 * (p + bias) + 5 and not nu[g]:
                 note("keyed", nrel(co[g], orc.pl_lr(X[m], y[m], add_bias=bias)))
         assert worst.get("keyed", 0.0) < 1e-8, (p, G, bias)
+        # per-row predictions in the frame's (shuffled) order: the call's own coefficients applied to every row
+        pr, rs, rn = pds.lin_reg_by_key_pred(*[dev(X[perm, j]) for j in range(p)], target=dev(y[perm]), key=dev(keys[perm]), add_bias=bias)
+        pr, rn = pr.cpu().numpy(), rn.cpu().numpy().astype(bool)
+        gi = np.searchsorted(uk, keys[perm])
+        assert np.array_equal(rn, nu[gi]), (p, G, bias, N)
+        Xb = np.c_[X[perm], np.ones(N)] if bias else X[perm]
+        live = ~rn
+        if live.any():
+            own = np.einsum("ij,ij->i", Xb[live], co[gi[live]])
+            sc = np.linalg.norm(Xb[live], axis=1) * np.linalg.norm(co[gi[live]], axis=1) + 1e-300
+            note("keyed-pred" + ("/partition" if N >= 65536 else "/sort"), float(np.max(np.abs(pr[live] - own) / sc)))
+            assert worst["keyed-pred" + ("/partition" if N >= 65536 else "/sort")] < 1e-9, (p, G, bias, N)
 print("configurations per entry point and the worst normwise distance to the oracle:")
 for k in sorted(count):
     print(f"  {k:14s} {count[k]:5d}   {worst[k]:.2e}")
