@@ -447,6 +447,19 @@ def _end_to_end(torch, np, pds, dev, xs, y, G, R, P, cpu):
         del os.environ["PDS_BY_KEY_MULTI_MIN_ROWS"]
     out["pl_lr_by"]["single_context_wall_ms"] = round(t_by1 * 1e3, 1)
     out["pl_lr_by"]["single_context_frac_of_pcie_rate"] = round(gb_by / t_by1 / pcie, 3)
+    # `.over(key)` / group_by().agg(lin_reg(return_pred=True)) on the same host frame: pred + resid of every row come back
+    # (PCIe is full duplex: with slices the predictions of slice s travel down while slice s + 1 travels up)
+    t_bp, resp = timed("pl_lr_by_pred", [key] + host, reps=2)
+    assert len(resp) == N
+    os.environ["PDS_BY_KEY_MULTI_MIN_ROWS"] = "0"
+    try:
+        t_bp1, _ = timed("pl_lr_by_pred", [key] + host, reps=2)
+    finally:
+        del os.environ["PDS_BY_KEY_MULTI_MIN_ROWS"]
+    del resp
+    out["pl_lr_by_pred"] = {"workload": "same host frame, per-row pred + resid of every group's fit (Struct{pred,resid}, frame order)",
+                            "wall_ms": round(t_bp * 1e3, 1), "up_GB": round(N * (P + 2) * 8 / 1e9, 2), "down_GB": round(N * 17 / 1e9, 2),
+                            "frac_of_pcie_rate_up": round(N * (P + 2) * 8 / 1e9 / t_bp / pcie, 3), "single_context_wall_ms": round(t_bp1 * 1e3, 1)}
     t_lr, _ = timed("pl_lr", host)
     gb_lr = N * (P + 1) * 8 / 1e9
     out["pl_lr"] = {"workload": f"host Arrow frame, single OLS {N:.0e} rows x {P} f64 feats", "wall_ms": round(t_lr * 1e3, 1),

@@ -360,6 +360,20 @@ int pds_lr_by_key_multi_f64(pds_ctx* const* ctxs, int n_ctx, int n_slices, const
 int pds_lr_by_key_multi_f32(pds_ctx* const* ctxs, int n_ctx, int n_slices, const float* const* cols, const int64_t* keys, int n_feat,
                             int64_t n_rows, const pds_lr_params* prm, int64_t max_groups, int64_t* out_keys, float* coeffs,
                             uint8_t* is_null, int64_t* n_groups);
+/*
+ * pds_lr_by_key_pred_multi_*: the per-row predictions of pds_lr_by_key_pred_* (pred / resid / row_null of the frame's length, in the
+ * frame's row order; each nullable, not all) for a HOST frame with non-decreasing keys over several contexts -- what
+ * `pds.lin_reg(..., return_pred=True).over(key)` (tests/test_linear_exprs.py:435-474) needs for a host frame: slice s + 1 crosses
+ * the link while slice s is fitted and its predictions travel back (PCIe is full duplex), and contexts on different devices use
+ * their own links.  Slices are independent (no group list comes back).  Keys not in order: pds_lr_by_key_pred_* on ctxs[0].
+ *   weights  nullable, n_rows values (per-group faer_weighted_lr).
+ */
+int pds_lr_by_key_pred_multi_f64(pds_ctx* const* ctxs, int n_ctx, int n_slices, const double* const* cols, const double* weights,
+                                 const int64_t* keys, int n_feat, int64_t n_rows, const pds_lr_params* prm, double* pred, double* resid,
+                                 uint8_t* row_null);
+int pds_lr_by_key_pred_multi_f32(pds_ctx* const* ctxs, int n_ctx, int n_slices, const float* const* cols, const float* weights,
+                                 const int64_t* keys, int n_feat, int64_t n_rows, const pds_lr_params* prm, float* pred, float* resid,
+                                 uint8_t* row_null);
 /* Page-locked host storage (hipHostMalloc, portable across devices) for result buffers the caller owns: device-to-host copies
  * into it run at the link rate.  The plugin layer keeps the large Arrow result buffers in such storage (plugin_arrow_out.hpp). */
 int pds_host_alloc(size_t bytes, void** out);

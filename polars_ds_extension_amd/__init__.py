@@ -15,6 +15,7 @@ from .lstsq import (  # noqa: F401
     lin_reg_by,
     lin_reg_by_key,
     lin_reg_by_key_multi,
+    lin_reg_by_key_pred_multi,
     lin_reg_by_key_pred,
     lin_reg_by_pred,
     lin_reg_from_moments,

@@ -360,6 +360,16 @@ int pds_lr_by_key_multi_f32(pds_ctx* const* ctxs, int n_ctx, int n_slices, const
     return pds::lr_by_key_multi_impl<float>(ctxs, n_ctx, n_slices, cols, keys, n_feat, n_rows, prm, max_groups, out_keys, coeffs, is_null,
                                             n_groups);
 }
+int pds_lr_by_key_pred_multi_f64(pds_ctx* const* ctxs, int n_ctx, int n_slices, const double* const* cols, const double* weights,
+                                 const int64_t* keys, int n_feat, int64_t n_rows, const pds_lr_params* prm, double* pred, double* resid,
+                                 uint8_t* row_null) {
+    return pds::lr_by_key_pred_multi_impl<double>(ctxs, n_ctx, n_slices, cols, weights, keys, n_feat, n_rows, prm, pred, resid, row_null);
+}
+int pds_lr_by_key_pred_multi_f32(pds_ctx* const* ctxs, int n_ctx, int n_slices, const float* const* cols, const float* weights,
+                                 const int64_t* keys, int n_feat, int64_t n_rows, const pds_lr_params* prm, float* pred, float* resid,
+                                 uint8_t* row_null) {
+    return pds::lr_by_key_pred_multi_impl<float>(ctxs, n_ctx, n_slices, cols, weights, keys, n_feat, n_rows, prm, pred, resid, row_null);
+}
 // pinned (page-locked, portable) host storage for results: a device-to-host copy into it runs at the link rate instead of the
 // pageable rate (7.8 -> ~2.5 ms for the 136 MB of the headline frame's coefficients)
 int pds_host_alloc(size_t bytes, void** out) {

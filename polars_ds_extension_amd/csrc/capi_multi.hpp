@@ -167,3 +167,76 @@ static int lr_by_key_multi_impl(pds_ctx* const* ctxs, int n_ctx, int n_slices, c
     }
     return PDS_OK;
 }
+
+// ---- per-row predictions of a host frame with non-decreasing keys over several contexts: the slices are fully independent (no
+// group list comes back, so there is nothing to place), slice s's pred / resid / row flags land at its own rows.  A slice whose keys
+// turn out not to be in order sends the whole frame to the single-context call.
+template <typename T>
+struct PredSlicePlace final : ByKeyPlace<T> {
+    std::atomic<bool>* unsorted_flag;
+    explicit PredSlicePlace(std::atomic<bool>* f) : unsorted_flag(f) {}
+    int at(int64_t, int64_t**, T**, uint8_t**) override { return PDS_OK; }  // (no coefficient outputs: nothing to place)
+    void unsorted() override { unsorted_flag->store(true); }
+};
+
+template <typename T>
+static int lr_by_key_pred_multi_impl(pds_ctx* const* ctxs, int n_ctx, int n_slices, const T* const* cols, const T* weights, const int64_t* keys,
+                                     int n_feat, int64_t n_rows, const pds_lr_params* prm, T* pred, T* resid, uint8_t* row_null) {
+    if (!ctxs || n_ctx < 1 || !cols || !keys || !prm || !(pred || resid || row_null)) return fail(PDS_ERR_INVALID, "null argument");
+    for (int c = 0; c < n_ctx; ++c)
+        if (!ctxs[c]) return fail(PDS_ERR_INVALID, "null context");
+    if (n_feat < 1) return fail(PDS_ERR_INVALID, "need at least one feature column");
+    if (n_rows <= 0) return fail(PDS_ERR_EMPTY, "Empty data");
+    auto single = [&]() {
+        return lr_by_key_impl<T>(ctxs[0], cols, keys, n_feat, n_rows, PDS_HOST, prm, n_rows, nullptr, nullptr, nullptr, nullptr, weights, pred,
+                                 resid, row_null);
+    };
+    constexpr int64_t kMinSliceRows = (int64_t)1 << 20;
+    int S = n_slices > 0 ? n_slices : 4 * n_ctx;
+    S = (int)std::min<int64_t>(S, std::max<int64_t>(1, n_rows / kMinSliceRows));
+    if (S <= 1) return single();
+    std::vector<int64_t> bounds = {0};
+    for (int s = 1; s < S; ++s) {
+        int64_t c = n_rows / S * s + std::min<int64_t>(s, n_rows % S);
+        if (c <= bounds.back()) continue;
+        while (c < n_rows && keys[c] == keys[c - 1]) ++c;
+        if (c < n_rows && c > bounds.back()) bounds.push_back(c);
+    }
+    bounds.push_back(n_rows);
+    S = (int)bounds.size() - 1;
+    if (S <= 1 || !keys_look_ordered(keys, n_rows, bounds)) return single();
+    const int nc = n_feat + 1;
+    std::atomic<bool> unsorted(false), failed(false);
+    std::mutex em;
+    int first_rc = PDS_OK;
+    std::string first_err;
+    const int workers = std::min(n_ctx, S);
+    auto work = [&](int c) {
+        for (int s = c; s < S; s += workers) {
+            if (unsorted.load() || failed.load()) return;
+            const int64_t r0 = bounds[s], rows = bounds[s + 1] - r0;
+            std::vector<const T*> ptrs(nc);
+            for (int k = 0; k < nc; ++k) ptrs[k] = cols[k] + r0;
+            PredSlicePlace<T> place(&unsorted);
+            const int rc = lr_by_key_impl<T>(ctxs[c], ptrs.data(), keys + r0, n_feat, rows, PDS_HOST, prm, rows, nullptr, nullptr, nullptr, nullptr,
+                                             weights ? weights + r0 : nullptr, pred ? pred + r0 : nullptr, resid ? resid + r0 : nullptr,
+                                             row_null ? row_null + r0 : nullptr, &place);
+            if (rc != PDS_OK && !unsorted.load()) {
+                std::lock_guard<std::mutex> g(em);
+                if (!failed.exchange(true)) {
+                    first_rc = rc;
+                    first_err = g_err;  // (this worker's thread-local message)
+                }
+                return;
+            }
+        }
+    };
+    std::vector<std::thread> threads;
+    for (int c = 1; c < workers; ++c) threads.emplace_back(work, c);
+    work(0);
+    for (auto& t : threads) t.join();
+    if (unsorted.load()) return single();
+    if (failed.load()) return fail(first_rc, first_err.empty() ? std::string("sliced fit failed") : first_err);
+    return PDS_OK;
+}
+

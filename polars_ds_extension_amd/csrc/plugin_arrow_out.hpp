@@ -209,6 +209,19 @@ int64_t pack_validity(const uint8_t* flags, int64_t n, ByteVec& bm) {
         }
     return n - set;
 }
+// any non-zero byte among n flags?  (a result without null rows needs no validity bitmap at all: eight flags per compare)
+inline bool any_flag(const uint8_t* flags, int64_t n) {
+    int64_t i = 0;
+    uint64_t acc = 0;
+    for (; i + 64 <= n; i += 64) {
+        uint64_t w[8];
+        std::memcpy(w, flags + i, 64);
+        acc |= (w[0] | w[1]) | (w[2] | w[3]) | (w[4] | w[5]) | (w[6] | w[7]);
+        if (acc) return true;
+    }
+    for (; i < n; ++i) acc |= flags[i];
+    return acc != 0;
+}
 template <typename T>
 const char* fmt_of() { return sizeof(T) == 8 ? "g" : "f"; }
 
@@ -222,6 +235,14 @@ std::unique_ptr<ArrowArray> prim_array_take(ByteVec&& values, int64_t n, const u
     bufs.push_back(std::move(bm));
     bufs.push_back(std::move(values));
     return make_array(n, nulls, std::move(bufs), {nulls > 0, true}, {}, {0, (size_t)skip_rows * sizeof(T)});
+}
+// ... with a validity bitmap that is already packed (`bm`: (n + 7) / 8 + 8 bytes; `nulls` zero bits among the first n)
+template <typename T>
+std::unique_ptr<ArrowArray> prim_array_take_bitmap(ByteVec&& values, int64_t n, ByteVec&& bm, int64_t nulls) {
+    std::vector<ByteVec> bufs;
+    bufs.push_back(std::move(bm));
+    bufs.push_back(std::move(values));
+    return make_array(n, nulls, std::move(bufs), {nulls > 0, true}, {}, {0, 0});
 }
 template <typename T>
 std::unique_ptr<ArrowArray> prim_array(const T* v, int64_t n, const uint8_t* valid_flags /*nullable*/) {

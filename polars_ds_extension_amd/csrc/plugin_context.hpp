@@ -88,6 +88,7 @@ template <> struct Api<double> {
     static constexpr auto by_key = pds_lr_by_key_f64;
     static constexpr auto by_key_pred = pds_lr_by_key_pred_f64;
     static constexpr auto by_key_multi = pds_lr_by_key_multi_f64;
+    static constexpr auto by_key_pred_multi = pds_lr_by_key_pred_multi_f64;
     static constexpr auto grouped_pred = pds_lr_grouped_pred_f64;
     static constexpr auto grouped = pds_lr_grouped_f64;
     static constexpr auto grouped_weighted = pds_lr_grouped_weighted_f64;
@@ -107,6 +108,7 @@ template <> struct Api<float> {
     static constexpr auto by_key = pds_lr_by_key_f32;
     static constexpr auto by_key_pred = pds_lr_by_key_pred_f32;
     static constexpr auto by_key_multi = pds_lr_by_key_multi_f32;
+    static constexpr auto by_key_pred_multi = pds_lr_by_key_pred_multi_f32;
     static constexpr auto grouped_pred = pds_lr_grouped_pred_f32;
     static constexpr auto grouped = pds_lr_grouped_f32;
     static constexpr auto grouped_weighted = pds_lr_grouped_weighted_f32;

@@ -786,6 +786,35 @@ def lin_reg_by_key_pred(*x, target, key, add_bias: bool = False, l1_reg: float =
     return pred, resid, rnull
 
 
+def lin_reg_by_key_pred_multi(*x, target, key, contexts, n_slices: int = 0, add_bias: bool = False, l1_reg: float = 0.0, l2_reg: float = 0.0,
+                              tol: float = 1e-5, solver: str = "qr", max_iter: int = 200, positive: bool = False,
+                              singular_x_tol: float | None = None, weights=None):
+    """
+    `lin_reg_by_key_pred` for a HOST frame whose keys are in order, over several contexts of this one process
+    (pds_lr_by_key_pred_multi_*): independent row slices cut at group boundaries, slice s on contexts[s mod n]; a slice's
+    predictions travel back while the next slice's rows arrive.  Returns (pred, resid, row_is_null) as numpy arrays, frame order.
+    """
+    if max_iter <= 0:
+        raise ValueError("Input `max_iter` must be a positive.")
+    cols = _Cols(target, x, weights)
+    if cols.space != _lib.PDS_HOST:
+        raise ValueError("lin_reg_by_key_pred_multi takes host-resident columns (numpy)")
+    prm = (_params(add_bias, 0.0, 0.0, tol, solver, False, max_iter, 0.0) if weights is not None
+           else _params(add_bias, l1_reg, l2_reg, tol, solver, positive, max_iter, singular_x_tol))
+    n_rows = cols.n_rows
+    k = np.ascontiguousarray(np.asarray(key), dtype=np.int64)
+    if int(k.shape[0]) != n_rows:
+        raise ValueError("`key` must have one entry per row")
+    pred, resid = np.empty(n_rows, dtype=_dtype()), np.empty(n_rows, dtype=_dtype())
+    rnull = np.empty(n_rows, dtype=np.uint8)
+    handles = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+    _lib.check(contexts[0].fn("pds_lr_by_key_pred_multi")(handles, len(contexts), int(n_slices), cols.cols, cols.weights,
+                                                          C.c_void_p(k.ctypes.data), cols.n_feat, C.c_int64(n_rows), C.byref(prm),
+                                                          C.c_void_p(pred.ctypes.data), C.c_void_p(resid.ctypes.data),
+                                                          C.c_void_p(rnull.ctypes.data)))
+    return pred, resid, rnull
+
+
 def _windowed(name, x, target, n, add_bias, l2_reg, min_size, ctx, seed_moments=None):
     ctx = ctx or default_context()
     cols = _Cols(target, x)

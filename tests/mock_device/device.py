@@ -382,6 +382,9 @@ def make_callbacks(sfx):
     def by_key_multi(ctxs_p, n_ctx, n_slices, cols_p, keys_p, n_feat, n, prm_p, max_groups, out_keys_p, coeffs_p, null_p, ng_p):
         return by_key(None, cols_p, keys_p, n_feat, n, 0, prm_p, max_groups, out_keys_p, coeffs_p, null_p, ng_p)
 
+    def by_key_pred_multi(ctxs_p, n_ctx, n_slices, cols_p, w_p, keys_p, n_feat, n, prm_p, pred_p, resid_p, rn_p):
+        return by_key_pred(None, cols_p, w_p, keys_p, n_feat, n, 0, prm_p, n, None, None, None, None, pred_p, resid_p, rn_p)
+
     def windowed(cols, n_feat, n, bias, lam, coeffs_p, pred_p, valid_p, first_valid, rows):
         """rows: (coefficient rows for output rows first_valid.., validity of those rows)"""
         pp = n_feat + int(bool(bias))
@@ -499,7 +502,7 @@ def make_callbacks(sfx):
             f"pds_lr_rcond_{sfx}": rcond, f"pds_elastic_net_{sfx}": elastic_net, f"pds_lin_reg_report_{sfx}": report, f"pds_lin_reg_report_nullable_{sfx}": report_nullable,
             f"pds_lr_grouped_{sfx}": grouped, f"pds_lr_grouped_weighted_{sfx}": grouped_weighted,
             f"pds_lr_grouped_nullable_{sfx}": grouped_nullable, f"pds_lr_by_key_{sfx}": by_key, f"pds_lr_grouped_pred_{sfx}": grouped_pred,
-            f"pds_lr_by_key_pred_{sfx}": by_key_pred, f"pds_lr_by_key_multi_{sfx}": by_key_multi, f"pds_rolling_lr_{sfx}": rolling,
+            f"pds_lr_by_key_pred_{sfx}": by_key_pred, f"pds_lr_by_key_multi_{sfx}": by_key_multi, f"pds_lr_by_key_pred_multi_{sfx}": by_key_pred_multi, f"pds_rolling_lr_{sfx}": rolling,
             f"pds_recursive_lr_{sfx}": recursive}
 
 

@@ -608,6 +608,24 @@ def test_by_key_multi_context_equals_single_context(pds, orc, n_ctx, n_slices):
     assert np.array_equal(k3, k1) and np.array_equal(n3, n1)
     ok = ~n1.astype(bool)
     assert np.max(np.linalg.norm(c3[ok] - c1[ok], axis=1) / np.linalg.norm(c1[ok], axis=1)) < 1e-9
+    # per-row predictions over the same contexts (pds_lr_by_key_pred_multi_*: independent slices): the single-context call's rows,
+    # with and without weights; a shuffled frame falls back to the single-context route and still lands in frame order
+    w = rng.random(N) + 0.25
+    for wts in (None, w):
+        p1, r1, f1 = pds.lin_reg_by_key_pred(*cols, target=y, key=key, add_bias=True, weights=wts)
+        p2, r2, f2 = pds.lin_reg_by_key_pred_multi(*cols, target=y, key=key, contexts=ctxs, n_slices=n_slices, add_bias=True, weights=wts)
+        assert np.array_equal(f1, f2) and np.array_equal(np.isnan(p1), np.isnan(p2))
+        # (the weighted per-group fit is ungated, as faer_weighted_lr: the collinear groups' rows are NaN without a flag, in both)
+        live = ~f1.astype(bool) & np.isfinite(p1)
+        scale = np.abs(y[live]) + np.abs(p1[live]) + 1.0
+        assert np.max(np.abs(p1[live] - p2[live]) / scale) < 1e-10 and np.max(np.abs(r1[live] - r2[live]) / scale) < 1e-10
+        assert np.all(np.isnan(p2[f1.astype(bool)]))
+    p3, r3, f3 = pds.lin_reg_by_key_pred_multi(*[c[perm] for c in cols], target=y[perm], key=key[perm], contexts=ctxs, n_slices=n_slices,
+                                               add_bias=True)
+    p1, r1, f1 = pds.lin_reg_by_key_pred(*cols, target=y, key=key, add_bias=True)
+    live = ~f1.astype(bool)
+    assert np.array_equal(f3, f1[perm])
+    assert np.max(np.abs(p3[live[perm]] - p1[perm][live[perm]]) / (np.abs(y[perm][live[perm]]) + np.abs(p1[perm][live[perm]]) + 1.0)) < 1e-9
     for c in ctxs:
         c.close()
 

@@ -572,6 +572,39 @@ def test_pl_lr_by_pred_is_the_reference_group_by_test(so, orc):
 
 
 @pytest.mark.gpu
+def test_pl_lr_by_pred_large_host_frame_takes_the_sliced_route(so, orc):
+    """A host frame of >= 2^22 rows with ordered keys: `pl_lr_by_pred` cuts it into slices over the process's contexts
+    (pds_lr_by_key_pred_multi_*: PDS_BY_KEY_CONTEXTS per device); predictions equal the single-context call's
+    (PDS_BY_KEY_MULTI_MIN_ROWS=0) row by row and the oracle's on sampled groups."""
+    rng = np.random.default_rng(77)
+    G = 45_000
+    sizes = rng.integers(60, 130, size=G)
+    key = np.repeat(np.arange(G, dtype=np.int64) * 3 + 5, sizes)
+    n = len(key)
+    assert n >= 1 << 22
+    X = rng.normal(size=(n, 2))
+    y = X @ [0.7, -1.1] + 1e-4 * key + 0.3 * rng.normal(size=n)
+    ins = [("key", pa.array(key))] + _cols(X, y)
+    _, out = ph.call_plugin(so, "pl_lr_by_pred", ins, dict(LR, bias=True))
+    pred = out.field("pred").to_numpy(zero_copy_only=False)
+    import os
+
+    os.environ["PDS_BY_KEY_MULTI_MIN_ROWS"] = "0"
+    try:
+        _, out1 = ph.call_plugin(so, "pl_lr_by_pred", ins, dict(LR, bias=True))
+    finally:
+        del os.environ["PDS_BY_KEY_MULTI_MIN_ROWS"]
+    pred1 = out1.field("pred").to_numpy(zero_copy_only=False)
+    assert out.field("pred").null_count == 0 and len(pred) == n
+    assert np.max(np.abs(pred - pred1) / (np.abs(pred1) + 1.0)) < 1e-10
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    for g in rng.choice(G, size=25, replace=False):
+        sl = slice(off[g], off[g + 1])
+        b = orc.pl_lr(X[sl], y[sl], add_bias=True)
+        np.testing.assert_allclose(pred[sl], X[sl] @ b[:2] + b[2], rtol=1e-9, atol=1e-10)
+
+
+@pytest.mark.gpu
 def test_pl_lr_by_pred_shuffled_rows_weights_bias_and_null_groups(so, orc):
     """Rows in any order: every row gets ITS group's prediction where the row is (the `.over(key)` broadcast of
     examples/basics.ipynb cells 16 / 18); a collinear group is null for all of its rows (linear_regression.rs:745-750); weights."""
