@@ -195,9 +195,12 @@ static int lr_by_key_pred_multi_impl(pds_ctx* const* ctxs, int n_ctx, int n_slic
     int S = n_slices > 0 ? n_slices : 4 * n_ctx;
     S = (int)std::min<int64_t>(S, std::max<int64_t>(1, n_rows / kMinSliceRows));
     if (S <= 1) return single();
+    // the first slice is HALF a slice: with equal slices the workers run in lockstep -- all of them uploading, then all of them
+    // fitting and downloading -- and the predictions' way back (1.7 of 16 GB) never meets an upload; half a slice out of phase, one
+    // worker's download runs under the other's upload (the link is full duplex: tools/pcie_duplex.py, 97 GB/s both ways at once)
     std::vector<int64_t> bounds = {0};
     for (int s = 1; s < S; ++s) {
-        int64_t c = n_rows / S * s + std::min<int64_t>(s, n_rows % S);
+        int64_t c = (int64_t)((double)n_rows * ((double)s - 0.5) / ((double)S - 0.5));
         if (c <= bounds.back()) continue;
         while (c < n_rows && keys[c] == keys[c - 1]) ++c;
         if (c < n_rows && c > bounds.back()) bounds.push_back(c);

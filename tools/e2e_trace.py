@@ -26,5 +26,5 @@ kw = {"bias": False, "null_policy": "raise", "l1_reg": 0.0, "l2_reg": 0.0, "solv
       "weighted": False, "positive": False, "singular_x_tol": 1e-12}
 for i in range(3):
     t0 = time.perf_counter()
-    _, res = ph.call_plugin(lib, "pl_lr_by", [key] + host, kw)
-    print(f"call {i}: {1e3 * (time.perf_counter() - t0):.1f} ms wall, {len(res)} groups", file=sys.stderr, flush=True)
+    _, res = ph.call_plugin(lib, sys.argv[1] if len(sys.argv) > 1 else "pl_lr_by", [key] + host, kw)
+    print(f"call {i}: {1e3 * (time.perf_counter() - t0):.1f} ms wall, {len(res)} rows out", file=sys.stderr, flush=True)
