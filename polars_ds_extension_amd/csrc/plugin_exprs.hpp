@@ -312,10 +312,69 @@ void do_lr_by(SeriesExport* in, size_t n_in, const Kwargs& kw, SeriesExport* out
     if (any_null && pol.kind == Policy::RAISE) raise("Nulls found in data");
     // pl_lr never compacts its weights (:436-446): a weighted fit on a frame that loses rows fails in the reference too
     if (any_null && weighted) raise("Shape of weights is not the same as the data.");
-    if (any_null && want_pred) raise("pl_lr_by_pred: rows with nulls are not supported (drop or fill them in front of the call)");
-    const int64_t n = key.size();
+    int64_t n = key.size();
     for (auto& c : cols)
         if (c.size() != n) raise("input columns differ in length");
+    // per-row predictions of a frame with nulls: what every group's pl_lr_pred does with them (linear_regression.rs:151-267,
+    // 790-812) -- "skip" fits on the rows without a null, a fill policy fills the features and drops the rows whose target is
+    // null; the dropped rows come back as null rows.  The frame is compacted on the host, fitted, and re-expanded below.
+    std::vector<uint8_t> keep;   // non-empty: the call runs on the kept rows only
+    const int64_t n_full = n;
+    if (any_null && want_pred) {
+        if (pol.kind != Policy::SKIP && pol.kind != Policy::FILL)
+            raise("pl_lr_by_pred: rows with nulls take null_policy 'skip' or a fill value");
+        if (pol.kind == Policy::FILL)
+            for (size_t k = 1; k < cols.size(); ++k) {
+                auto& c = cols[k];
+                if (!c.null_count) continue;
+                auto& v = c.own();
+                for (int64_t i = 0; i < n; ++i)
+                    if (!bit_get(c.validity.data(), i)) v[i] = (T)pol.fill;
+            }
+        const size_t judged = pol.kind == Policy::FILL ? 1 : cols.size();
+        keep.assign((size_t)n, 1);
+        for (size_t k = 0; k < judged; ++k)
+            if (cols[k].null_count)
+                for (int64_t i = 0; i < n; ++i)
+                    if (!bit_get(cols[k].validity.data(), i)) keep[i] = 0;
+        int64_t m = 0;
+        for (int64_t i = 0; i < n; ++i) m += keep[i];
+        if (m == n) {
+            keep.clear();  // (only filled features: nothing was dropped)
+        } else {
+            for (auto& c : cols) {
+                auto& v = c.own();
+                int64_t d = 0;
+                for (int64_t i = 0; i < n; ++i)
+                    if (keep[i]) v[d++] = v[i];
+                c.shrink(m);
+            }
+            auto& kv = key.own();
+            int64_t d = 0;
+            std::vector<uint8_t> kvalid;
+            if (key.null_count > 0) kvalid.assign((size_t)(m + 7) / 8, 0);
+            for (int64_t i = 0; i < n; ++i)
+                if (keep[i]) {
+                    if (key.null_count > 0 && bit_get(key.validity.data(), i)) bit_set(kvalid, d);
+                    kv[d++] = kv[i];
+                }
+            key.shrink(m);
+            if (key.null_count > 0) {
+                key.validity.swap(kvalid);
+                int64_t nn = 0;
+                for (int64_t i = 0; i < m; ++i) nn += bit_get(key.validity.data(), i) ? 0 : 1;
+                key.null_count = nn;
+                if (nn == 0) key.validity.clear();
+            }
+            n = m;
+        }
+        for (auto& c : cols) {
+            c.validity.clear();
+            c.null_count = 0;
+        }
+        any_null = false;
+        if (n == 0) raise("Empty data");
+    }
     // Polars' group_by makes the null keys ONE group.  They take a key value no valid row uses -- max + 1, so that group comes
     // last (min - 1 when the maximum is INT64_MAX) -- and the group that carries it is reported with a null key.
     bool null_group = false;
@@ -463,6 +522,36 @@ void do_lr_by(SeriesExport* in, size_t n_in, const Kwargs& kw, SeriesExport* out
         const int code = pol.kind == Policy::FILL ? PDS_NULL_FILL : pol.kind == Policy::SKIP ? PDS_NULL_SKIP : PDS_NULL_IGNORE;
         check(Api<T>::grouped_nullable(thread_ctx(), ptrs.data(), bms.data(), offs.data(), n_feat, n, off.data(), ng, PDS_HOST, code,
                                        (T)pol.fill, &prm, as<T>(cobuf), nulls.data()));
+    }
+    if (want_pred && !keep.empty()) {
+        // re-expansion through the row mask (linear_regression.rs:790-812): dropped rows are null rows of the result
+        ByteVec pf = raw_buffer<T>((size_t)n_full), rf = raw_buffer<T>((size_t)n_full);
+        std::vector<uint8_t> valid((size_t)n_full, 0);
+        T* pd = as<T>(pf);
+        T* rd = as<T>(rf);
+        const T* ps = as<T>(pred_b);
+        const T* rs = as<T>(resid_b);
+        const T nanv = std::numeric_limits<T>::quiet_NaN();
+        int64_t k = 0;
+        for (int64_t i = 0; i < n_full; ++i) {
+            if (keep[i]) {
+                pd[i] = ps[k];
+                rd[i] = rs[k];
+                valid[i] = row_null[k] ? 0 : 1;
+                ++k;
+            } else {
+                pd[i] = nanv;
+                rd[i] = nanv;
+            }
+        }
+        std::vector<std::unique_ptr<ArrowArray>> kids;
+        kids.push_back(prim_array_take<T>(std::move(pf), n_full, valid.data()));
+        kids.push_back(prim_array_take<T>(std::move(rf), n_full, valid.data()));
+        std::vector<std::unique_ptr<ArrowSchema>> sk;
+        sk.push_back(make_schema(fmt_of<T>(), "pred"));
+        sk.push_back(make_schema(fmt_of<T>(), "resid"));
+        export_series(out, make_schema("+s", "", std::move(sk)), struct_array(n_full, std::move(kids)));
+        return;
     }
     if (want_pred) {
         // validity of the two children: none at all when no row is null (the usual case: a scan of the n flag bytes instead of

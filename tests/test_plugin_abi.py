@@ -648,11 +648,28 @@ def test_pl_lr_by_pred_shuffled_rows_weights_bias_and_null_groups(so, orc):
     pred2 = np.array([np.nan if v is None else v for v in out2.field("pred").to_pylist()])
     ok = ~np.isnan(pred[order])
     np.testing.assert_allclose(pred2[ok], pred[order][ok], rtol=1e-10, atol=1e-12)
-    # rows with nulls are refused with a message (not silently mis-grouped)
-    ins_n = [("key", pa.array(kp)), ("y", pa.array(yp)), ("x1", pa.array(Xp[:, 0], mask=rng.random(G * per) < 0.1))] + [
+    # rows with nulls: what every group's pl_lr_pred does (linear_regression.rs:151-267, 790-812) -- "skip" fits on the rows
+    # without a null and the dropped rows come back null; a fill value fills the features and drops the rows whose target is null
+    mx = rng.random(G * per) < 0.1
+    my = rng.random(G * per) < 0.05
+    mx[kp == key[7 * per]] = False  # (a filled feature would break the collinear group's collinearity)
+    ins_n = [("key", pa.array(kp)), ("y", pa.array(yp, mask=my)), ("x1", pa.array(Xp[:, 0], mask=mx))] + [
         (f"x{j + 1}", pa.array(Xp[:, j])) for j in (1, 2)]
-    with pytest.raises(RuntimeError, match="nulls"):
-        ph.call_plugin(so, "pl_lr_by_pred", ins_n, dict(LR, bias=True, null_policy="skip"))
+    for policy, dropped, Xf in (("skip", mx | my, Xp), ("0.5", my, np.c_[np.where(mx, 0.5, Xp[:, 0]), Xp[:, 1:]])):
+        _, outn = ph.call_plugin(so, "pl_lr_by_pred", ins_n, dict(LR, bias=True, null_policy=policy))
+        assert len(outn) == G * per
+        pn = np.array([np.nan if v is None else v for v in outn.field("pred").to_pylist()])
+        nulls_n = np.array([v is None for v in outn.field("pred").to_pylist()])
+        bad_group = kp == key[7 * per]
+        assert np.array_equal(nulls_n, dropped | bad_group), policy
+        for k in np.unique(key)[::17]:
+            m = (kp == k) & ~dropped
+            if k == key[7 * per]:
+                continue
+            b = orc.pl_lr(Xf[m], yp[m], add_bias=True)
+            np.testing.assert_allclose(pn[m], Xf[m] @ b[:3] + b[3], rtol=1e-9, atol=1e-10)
+    with pytest.raises(RuntimeError, match="null_policy"):
+        ph.call_plugin(so, "pl_lr_by_pred", ins_n, dict(LR, bias=True, null_policy="ignore"))
 
 
 @pytest.mark.gpu
