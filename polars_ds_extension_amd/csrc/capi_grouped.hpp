@@ -439,12 +439,16 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
         d_keys = static_cast<const int64_t*>(ctx->stage.ptr);
     }
     if (int rc = ensure_pinned(ctx, 4096)) return rc;
-    if (int rc = ensure_ws(ctx, ctx->solve_ws, 8192)) return rc;  // order flag + key range: outlive the workspace sizing below
+    // order flag + key range + the run counts of the order check (keyed.hip): they outlive the workspace sizing below
+    const size_t run_slots = key_run_slots(n_rows);
+    if (int rc = ensure_ws(ctx, ctx->solve_ws, 8192 + 2 * up((run_slots + 1) * sizeof(uint32_t)))) return rc;
     bool sorted = false;
     int64_t mm[2] = {0, 0};
     int64_t* d_state = reinterpret_cast<int64_t*>(static_cast<char*>(ctx->solve_ws.ptr) + 256);
     int64_t* d_minmax = d_state + 2;
-    if (int rc = keys_order_minmax(ctx, d_keys, n_rows, d_state, &sorted, mm)) return rc;
+    uint32_t* d_run_counts = reinterpret_cast<uint32_t*>(static_cast<char*>(ctx->solve_ws.ptr) + 4096);
+    uint32_t* d_run_prefix = reinterpret_cast<uint32_t*>(static_cast<char*>(ctx->solve_ws.ptr) + 4096 + up((run_slots + 1) * sizeof(uint32_t)));
+    if (int rc = keys_order_minmax(ctx, d_keys, n_rows, d_state, &sorted, mm, d_run_counts)) return rc;
     tr.mark("keys H2D + order check");
     if (place && !sorted) {
         place->unsorted();
@@ -579,7 +583,12 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
     }
     tr.mark("sort + gather");
     int64_t ng = 0;
-    if (int rc = keyed_runs(ctx, d_sorted_keys, n_rows, d_unique, d_counts, d_offsets, d_nruns, d_temp, temp_bytes, &ng)) return rc;
+    if (sorted) {  // keys in order: the order check has counted the run starts already -- a scan and one writing pass
+        if (int rc = keyed_runs_ordered(ctx, d_keys, n_rows, d_run_counts, d_run_prefix, run_cap, d_unique, d_offsets, d_temp, temp_bytes, &ng))
+            return rc;
+    } else if (int rc = keyed_runs(ctx, d_sorted_keys, n_rows, d_unique, d_counts, d_offsets, d_nruns, d_temp, temp_bytes, &ng)) {
+        return rc;
+    }
     tr.mark("run lengths + offsets");
     if (n_groups) *n_groups = ng;
     if (ng > max_groups) return fail(PDS_ERR_INVALID, "more distinct keys than max_groups");

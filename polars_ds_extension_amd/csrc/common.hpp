@@ -309,7 +309,11 @@ size_t rolling_wide_workspace(int n_feat, int64_t n_rows, size_t elem);
 // ---- keyed.hip: int64 keys in any row order -> sorted keys, permutation, distinct keys, group offsets
 int keys_nondecreasing(pds_ctx* ctx, const int64_t* d_keys, int64_t n, unsigned* d_flag, bool* sorted);
 size_t keyed_temp_bytes(int64_t n);
-int keys_order_minmax(pds_ctx* ctx, const int64_t* d_keys, int64_t n, int64_t* d_state, bool* sorted, int64_t* mm);
+int keys_order_minmax(pds_ctx* ctx, const int64_t* d_keys, int64_t n, int64_t* d_state, bool* sorted, int64_t* mm,
+                      uint32_t* d_run_counts = nullptr /* key_run_slots(n) entries: see keyed_runs_ordered */);
+size_t key_run_slots(int64_t n);
+int keyed_runs_ordered(pds_ctx* ctx, const int64_t* d_keys, int64_t n, uint32_t* d_counts, uint32_t* d_prefix, int64_t cap, int64_t* d_unique,
+                       int64_t* d_offsets, void* d_temp, size_t temp_bytes, int64_t* n_groups);
 int keyed_minmax(pds_ctx* ctx, const int64_t* d_keys, int64_t n, void* d_temp, size_t temp_bytes, int64_t* d_minmax, int64_t* mm);
 int keyed_sort(pds_ctx* ctx, const int64_t* d_keys, int64_t n, uint32_t* d_idx_in, int64_t* d_sorted_keys, uint32_t* d_perm,
                void* d_temp, size_t temp_bytes, int64_t* d_scratch_keys, const int64_t* d_minmax, const int64_t* mm);

@@ -831,6 +831,31 @@ def test_grouped_by_key_any_row_order(pds, orc, p, bias):
     assert np.max(np.linalg.norm(co2.cpu().numpy() - co_o, axis=1) / np.linalg.norm(co_o, axis=1)) < 1e-9
 
 
+@pytest.mark.parametrize("shift", [0, 1])
+def test_by_key_ordered_keys_run_lengths(pds, shift):
+    """Ordered keys: the distinct keys and group offsets come from the order check's run counts + one writing pass (keyed.hip:
+    key_run_starts_kernel) -- runs of every length around the 128-key pieces, single-row groups, one long run, tiny frames, and a
+    key buffer that is 8- but not 16-byte aligned.  The fits must be those of the offsets entry point on the same groups, bit for bit."""
+    import torch
+
+    rng = np.random.default_rng(60 + shift)
+    cases = [rng.integers(1, 6, size=700), rng.integers(100, 300, size=40), np.array([1] * 300), np.array([5000]), np.array([3]),
+             np.array([1, 1]), np.array([127, 1, 128, 129, 2, 255, 1, 1, 64, 64]), rng.integers(1, 400, size=900)]
+    for sizes in cases:
+        keys_g = np.cumsum(rng.integers(1, 9, size=len(sizes))) - 40
+        key = np.repeat(keys_g, sizes).astype(np.int64)
+        n = len(key)
+        x = rng.normal(size=n + shift)
+        y = 0.5 * x + 0.1 * rng.normal(size=n + shift)
+        kd = torch.from_numpy(np.concatenate([np.zeros(shift, dtype=np.int64), key])).cuda()[shift:]
+        xd, yd = torch.from_numpy(x).cuda()[shift:], torch.from_numpy(y).cuda()[shift:]
+        k_out, co, nu = pds.lin_reg_by_key(xd, target=yd, key=kd, add_bias=True)
+        assert np.array_equal(k_out.cpu().numpy(), keys_g), (len(sizes), n)
+        off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        co2, nu2 = pds.lin_reg_by(xd, target=yd, group_offsets=off, add_bias=True)
+        assert torch.equal(nu, nu2) and torch.equal(torch.nan_to_num(co), torch.nan_to_num(co2))
+
+
 def test_by_key_order_check_sees_every_inversion(pds):
     """keyed.hip's one-pass order check (16-byte loads, the successor of a key from the lane itself, the next lane or the next
     128-key piece): ONE adjacent inversion anywhere -- inside a lane's pair, between lanes, between pieces, in the unaligned head,
