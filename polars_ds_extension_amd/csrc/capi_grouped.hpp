@@ -97,6 +97,7 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
     chunk = std::min(chunk, n_groups);
     size_t need = 131072 + sizeof(T) * (size_t)chunk * q * q;
     need += (size_t)n_groups * 4 + (size_t)chunk * (pp * sizeof(T) + 1) + 4096;  // the fused path's pivoted-QR pass: list, results
+    if (n_feat > 16 && n_feat <= 64) need += solve_wave_workspace(n_feat, bias, chunk, sizeof(T)) + 512;
     if (big) need += (size_t)n_groups * (n_feat + 1) * sizeof(T*) + moments_wide_workspace(ctx->num_cus, n_feat, n_rows) + 8192;
     if (space == PDS_HOST || !coeffs) need += (size_t)(n_groups + 1) * 8 + (size_t)n_groups * (pp * sizeof(T) + 1) + 4096;
     if (want_pred && space == PDS_HOST) need += 2 * ((size_t)n_rows * sizeof(T) + 256) + (size_t)n_rows + 256;
@@ -211,10 +212,15 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
     } else if (n_feat <= 16 && !want_piv && !(unfused_env && unfused_env[0] == '1') && n_groups < (1ll << 31)) {
         if (int rc = launch_grouped_fused<T>(ctx, dc, n_feat, n_rows, d_off, n_groups, sp, d_coeffs, d_null, d_mom, chunk)) return rc;
     } else {
+        void* d_wave_ws = (n_feat > 16 && n_feat <= 64 && !want_piv) ? ws_take(ctx, solve_wave_workspace(n_feat, bias, chunk, sizeof(T))) : nullptr;
         for (int64_t g0 = 0; g0 < n_groups; g0 += chunk) {
             const int64_t gc = std::min(chunk, n_groups - g0);
             if (int rc = launch_grouped_moments<T>(ctx, dc, n_feat, d_off + g0, gc, d_mom)) return rc;
-            if (int rc = launch_solve<T>(ctx, d_mom, gc, sp, d_coeffs + g0 * pp, d_null + g0, nullptr, d_off + g0)) return rc;
+            // 17 .. 64 features, gate on: one wave per system in registers (solve_wave.hip), the pivoted QR only for what it marks
+            int rcw = want_piv ? PDS_ERR_UNSUPPORTED
+                               : launch_solve_wave<T>(ctx, d_mom, gc, sp, d_coeffs + g0 * pp, d_null + g0, d_off + g0, d_wave_ws);
+            if (rcw == PDS_ERR_UNSUPPORTED) rcw = launch_solve<T>(ctx, d_mom, gc, sp, d_coeffs + g0 * pp, d_null + g0, nullptr, d_off + g0);
+            if (rcw) return rcw;
         }
     }
     if (want_pred) {

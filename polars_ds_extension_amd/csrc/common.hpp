@@ -237,6 +237,13 @@ template <typename T>
 int launch_solve_reg(pds_ctx* ctx, const T* d_moments, int64_t n_sys, const SolveParams& sp, T* d_coeffs,
                      uint8_t* d_flags, const int64_t* d_rows_per_sys, const TriSource* tri = nullptr);
 
+// solve_wave.hip: 17 .. 64 features, one wave per system, L D L' in registers + a pivoted-QR pass over the systems it marks
+// (PDS_ERR_UNSUPPORTED without an error message: not applicable, the caller keeps launch_solve)
+template <typename T>
+int launch_solve_wave(pds_ctx* ctx, const T* d_moments, int64_t n_sys, const SolveParams& sp, T* d_coeffs, uint8_t* d_flags,
+                      const int64_t* d_rows_per_sys, void* d_ws);
+size_t solve_wave_workspace(int n_feat, int add_bias, int64_t n_sys, size_t elem);
+
 template <typename T>
 int launch_cd(pds_ctx* ctx, const T* d_moments, int p, int add_bias, double l1, double l2, double tol,
               int max_iter, int positive, T* d_coeffs, int* d_info /*per system: [0]=sweeps,[1]=converged; nullable*/,

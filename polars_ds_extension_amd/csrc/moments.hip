@@ -587,13 +587,21 @@ __global__ __launch_bounds__(64) void grouped_moments_mid_kernel(const T* const*
             const int row = lane & 31;
             const int64_t r = base + row;
             const bool in = r < r1;
-            for (int c0 = 0; c0 < q; c0 += 2) {
-                const int c = c0 + (lane >> 5);
-                if (c < q) {
-                    double v = 0.0;
-                    if (in) v = (c < p) ? (double)as_global(cols[c])[r] : (c == p ? 1.0 : (double)as_global(cols[p])[r]);
-                    tile[c * kMidStride + row] = v;
-                }
+            // all loads of the stage first (unconditional, clamped column and row: a load under its own exec mask is serialised
+            // behind the previous one by the compiler's vmcnt(0) -- 33 HBM round trips per 32 rows made this kernel run at
+            // 0.1 - 0.3 TB/s), then the LDS stores
+            const int64_t rc = in ? r : r1 - 1;
+            T vreg[NB * 8];
+#pragma unroll
+            for (int k = 0; k < NB * 8; ++k) {
+                const int c = 2 * k + (lane >> 5);
+                const int cc = c < p ? c : p;  // (column p of the table is y: it serves c == p + 1, the ones column and the padding)
+                vreg[k] = as_global(cols[cc])[rc];
+            }
+#pragma unroll
+            for (int k = 0; k < NB * 8; ++k) {
+                const int c = 2 * k + (lane >> 5);
+                if (c < q) tile[c * kMidStride + row] = !in ? 0.0 : (c == p ? 1.0 : (double)vreg[k]);
             }
             PDS_WAVE_LDS_SYNC();
 #pragma unroll

@@ -877,6 +877,50 @@ def test_by_key_order_check_sees_every_inversion(pds):
         assert torch.equal(k_out, base[shift:])
 
 
+@pytest.mark.parametrize("p,bias,l2", [(17, True, 0.0), (24, False, 0.0), (32, True, 0.0), (33, False, 0.3), (40, True, 0.0), (49, True, 0.0),
+                                        (57, False, 0.0), (64, True, 0.0), (64, False, 0.2)])
+def test_grouped_mid_width_wave_solver(pds, orc, p, bias, l2):
+    """17 .. 64 features per group: the Gram records are solved one wave per system in registers (solve_wave.hip: centred L D L',
+    rank gate as a pivot-ratio product); collinear groups and groups next to the gate go through the pivoted-QR pass over the marked
+    records, groups with fewer rows than coefficients are null.  Against the oracle's gated col-piv QR, group by group."""
+    rng = np.random.default_rng(4000 + p)
+    G = 260
+    pp = p + int(bias)
+    # (rows well above the column count: with n ~ p the relative determinant of a random Gram matrix is itself below the 1e-12 gate)
+    sizes = rng.integers(5 * pp, 9 * pp, size=G)
+    sizes[::37] = rng.integers(1, pp, size=len(sizes[::37]))          # too few rows -> null
+    sizes[3::29] = pp + 2                                              # barely enough rows: next to the gate or beyond it
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    N = int(off[-1])
+    X = rng.normal(size=(N, p)) + rng.normal(size=p) * 0.3
+    y = X @ rng.normal(size=p) + (0.7 if bias else 0.0) + 0.2 * rng.normal(size=N)
+    for g in range(5, G, 41):                                           # collinear groups -> gated
+        X[off[g]: off[g + 1], 3] = 2.0 * X[off[g]: off[g + 1], 1] - X[off[g]: off[g + 1], 0]
+    for g in range(9, G, 53):                                           # nearly collinear: next to the gate
+        X[off[g]: off[g + 1], 2] = X[off[g]: off[g + 1], 1] + 3e-6 * rng.normal(size=int(sizes[g]))
+    co, nu = pds.lin_reg_by(*cols_of(X), target=dev(y), group_offsets=off, add_bias=bias, l2_reg=l2)
+    co, nu = co.cpu().numpy(), nu.cpu().numpy().astype(bool)
+    co_o, nu_o = orc.grouped_lr([y] + [X[:, j] for j in range(p)], off, add_bias=bias, l2_reg=l2, nthreads=4)
+    assert np.array_equal(nu, nu_o), (nu.sum(), nu_o.sum(), np.flatnonzero(nu != nu_o)[:10])
+    assert nu.sum() >= 7 and (~nu).sum() >= G // 2
+    ok = ~nu
+    err = np.linalg.norm(co[ok] - co_o[ok], axis=1) / np.linalg.norm(co_o[ok], axis=1)
+    # groups whose own conditioning makes two correct solvers differ by more than 1e-10 (sizes go down to p' + 3 rows): 64 eps cond(X'X)
+    worst = 0.0
+    for g in np.flatnonzero(ok)[np.argsort(err)[-6:]]:
+        Xg = X[off[g]: off[g + 1]]
+        Xb = np.c_[Xg, np.ones(len(Xg))] if bias else Xg
+        bound = max(F64_TOL, 64 * 2.2e-16 * np.linalg.cond(Xb.T @ Xb + l2 * np.eye(Xb.shape[1])))
+        worst = max(worst, float(err[np.flatnonzero(ok) == g][0] / bound))
+    assert worst < 1.0, (worst, err.max())
+    # solver = "choleskey" IS the register factorisation (no second pass): same accept / reject rule on the clear groups
+    co_c, nu_c = pds.lin_reg_by(*cols_of(X), target=dev(y), group_offsets=off, add_bias=bias, l2_reg=l2, solver="choleskey")
+    co_c, nu_c = co_c.cpu().numpy(), nu_c.cpu().numpy().astype(bool)
+    both = ~nu_c & ok
+    assert both.sum() >= 0.8 * ok.sum()
+    assert np.median(np.linalg.norm(co_c[both] - co_o[both], axis=1) / np.linalg.norm(co_o[both], axis=1)) < 1e-10
+
+
 @pytest.mark.parametrize("p,bias", [(4, True), (15, True), (16, False), (20, True)])
 def test_grouped_weighted(pds, orc, p, bias):
     """group_by(key).agg(pds.lin_reg(..., weights=w)): per group faer_weighted_lr (lr_solvers.rs:386-409)."""
