@@ -32,4 +32,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 rm -rf /tmp/p7 && timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p7 -o w -- python -u $ROOT/tools/wide_report_prof.py > $OUT/wide_run.log 2>&1
 cp $(find /tmp/p7 -name "*kernel_stats.csv" | head -1) $OUT/wide_kernel_stats.csv
+# grouped fits with 17 .. 64 features: the wave-per-system register solver against the LDS solver (PDS_SOLVE_WAVE=0)
+timeout -k 5 200 python -u $ROOT/tools/grouped_mid_width.py > $OUT/grouped_mid.log 2>&1
+PDS_SOLVE_WAVE=0 timeout -k 5 300 python -u $ROOT/tools/grouped_mid_width.py 2>&1 | sed 's/^/[PDS_SOLVE_WAVE=0: LDS pivoted QR for every system] /' >> $OUT/grouped_mid.log
+timeout -k 5 100 python -u $ROOT/tools/sorted_keys_prof.py >> $OUT/keyed_run.log 2>&1
 ls -la $OUT

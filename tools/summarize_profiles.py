@@ -121,8 +121,13 @@ for tag, title, cmd in (("keyed", "Keys in any row order (C3 frame, shuffled) + 
             md.append(f"| `{n}` | {c} | {us:.1f} |")
     log = SRC / f"{tag}_run.log"
     if log.exists():
-        keep = [l for l in log.read_text().splitlines() if l.startswith(("keyed", "n=")) or " ms" in l and "rocprof" not in l and "amdgpu" not in l]
+        keep = [l for l in log.read_text().splitlines() if l.startswith(("keyed", "n=", "ordered")) or " ms" in l and "rocprof" not in l and "amdgpu" not in l]
         md += ["", "```", *keep[:40], "```", ""]
+gm = SRC / "grouped_mid.log"
+if gm.exists():
+    lines = [l for l in gm.read_text().splitlines() if "groups x" in l]
+    (OUT / f"{rnd}_grouped_mid_width.txt").write_text("# python tools/grouped_mid_width.py: grouped OLS with 17 .. 64 features, wall ms per call (Gram records + solves)\n" + "\n".join(lines) + "\n")
+    md += ["## Grouped fits with 17 .. 64 features (`tools/grouped_mid_width.py`)", "", "```", *lines, "```", ""]
 kf, kw = SRC / "pmc_keyed_FETCH_SIZE.csv", SRC / "pmc_keyed_WRITE_SIZE.csv"
 if kf.exists() and kw.exists():
     f2, w2 = pmc(kf), pmc(kw)
