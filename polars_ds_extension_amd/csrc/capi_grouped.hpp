@@ -447,14 +447,23 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
     if (int rc = ensure_pinned(ctx, 4096)) return rc;
     // order flag + key range + the run counts of the order check (keyed.hip): they outlive the workspace sizing below
     const size_t run_slots = key_run_slots(n_rows);
-    if (int rc = ensure_ws(ctx, ctx->solve_ws, 8192 + 2 * up((run_slots + 1) * sizeof(uint32_t)))) return rc;
+    const size_t slot_bytes = (size_t)kKeySlots * 8 * sizeof(unsigned);
+    if (int rc = ensure_ws(ctx, ctx->solve_ws, 8192 + 2 * up((run_slots + 1) * sizeof(uint32_t)) + up(slot_bytes))) return rc;
     bool sorted = false;
     int64_t mm[2] = {0, 0};
     int64_t* d_state = reinterpret_cast<int64_t*>(static_cast<char*>(ctx->solve_ws.ptr) + 256);
     int64_t* d_minmax = d_state + 2;
     uint32_t* d_run_counts = reinterpret_cast<uint32_t*>(static_cast<char*>(ctx->solve_ws.ptr) + 4096);
     uint32_t* d_run_prefix = reinterpret_cast<uint32_t*>(static_cast<char*>(ctx->solve_ws.ptr) + 4096 + up((run_slots + 1) * sizeof(uint32_t)));
-    if (int rc = keys_order_minmax(ctx, d_keys, n_rows, d_state, &sorted, mm, d_run_counts)) return rc;
+    // dense-key candidates (unweighted, <= 16 features): the order check takes the partition route's bucket histogram along
+    static const bool force_sort = [] { const char* e = std::getenv("PDS_KEYED_SORT"); return e && e[0] == '1'; }();
+    const bool part_candidate = !force_sort && !weights && n_feat <= 16 && !place;
+    const int part_shift = part_candidate ? keyed_partition_shift<T>(n_feat) : -1;
+    unsigned* d_slots = reinterpret_cast<unsigned*>(static_cast<char*>(ctx->solve_ws.ptr) + 4096 + 2 * up((run_slots + 1) * sizeof(uint32_t)));
+    bool hist_taken = false;
+    if (int rc = keys_order_minmax(ctx, d_keys, n_rows, d_state, &sorted, mm, d_run_counts, part_shift, part_candidate ? d_slots : nullptr,
+                                   &hist_taken))
+        return rc;
     tr.mark("keys H2D + order check");
     if (place && !sorted) {
         place->unsorted();
@@ -465,12 +474,17 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
     // predictions then look the row's group up from its key -- grouped_pred.hip MODE 2 -- and nothing is ever permuted);
     // PDS_KEYED_SORT=1 keeps the sorting route (A/B)
     int64_t part_buckets = 0;
-    if (!sorted) {
-        static const bool force_sort = [] { const char* e = std::getenv("PDS_KEYED_SORT"); return e && e[0] == '1'; }();
-        if (!force_sort && !weights)
-            part_buckets = keyed_partition_buckets<T>(n_feat, n_rows, (uint64_t)mm[1] - (uint64_t)mm[0] + 1);
+    int64_t part_base = 0;       // smallest key rounded down to a multiple of the bucket width: the origin of the dense ids
+    uint64_t part_range = 0;
+    if (!sorted && part_candidate) {
+        const int64_t wdt = (int64_t)1 << part_shift;
+        part_base = mm[0] - (((mm[0] % wdt) + wdt) % wdt);
+        part_range = (uint64_t)mm[1] - (uint64_t)part_base + 1;
+        part_buckets = keyed_partition_buckets<T>(n_feat, n_rows, part_range);
     }
     const bool partition = part_buckets > 0;
+    int64_t* d_part_base = d_state + 1;  // (the unused slot of the order check's state)
+    if (partition) PDS_HIP_CHECK(hipMemcpyAsync(d_part_base, &part_base, sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
     // ---- workspace: [raw columns (host frames)] [sorted keys, index in/out, gathered columns (unsorted frames)] runs, temp
     const int64_t cap = std::min<int64_t>(max_groups, n_rows);
     const size_t temp_bytes = keyed_temp_bytes(n_rows);
@@ -509,8 +523,10 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
         char* pws = take(keyed_partition_workspace<T>(n_feat, n_rows, part_buckets));
         KeyedPartitionState st;
         int64_t ng = 0;
-        const int rc0 = keyed_partition_build<T>(ctx, d_tbl, d_keys, d_minmax, (uint64_t)mm[1] - (uint64_t)mm[0] + 1, n_feat, n_rows, part_buckets,
-                                                 pws, cap, d_unique, d_offsets, &ng, st);
+        const bool use_slots = hist_taken && part_buckets <= kKeySlots;
+        const unsigned first_slot = (unsigned)((part_base >> part_shift) & (int64_t)(kKeySlots - 1));
+        const int rc0 = keyed_partition_build<T>(ctx, d_tbl, d_keys, d_part_base, part_range, n_feat, n_rows, part_buckets, pws, cap, d_unique,
+                                                 d_offsets, &ng, st, use_slots ? d_slots : nullptr, first_slot);
         if (n_groups) *n_groups = ng;
         if (rc0) return rc0;
         tr.mark("partition + moments");
@@ -531,7 +547,7 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
                 if (resid) d_resid = reinterpret_cast<T*>(take((size_t)n_rows * sizeof(T)));
                 if (row_null) d_rn = reinterpret_cast<uint8_t*>(take((size_t)n_rows));
             }
-            if (int rc = launch_grouped_pred_by_id<T>(ctx, d_tbl, n_feat, prm->add_bias ? 1 : 0, n_rows, d_keys, d_minmax, st.rank, ng, d_co, d_nu,
+            if (int rc = launch_grouped_pred_by_id<T>(ctx, d_tbl, n_feat, prm->add_bias ? 1 : 0, n_rows, d_keys, d_part_base, st.rank, ng, d_co, d_nu,
                                                       d_pred, d_resid, d_rn))
                 return rc;
             if (space == PDS_HOST) {

@@ -316,8 +316,10 @@ size_t rolling_wide_workspace(int n_feat, int64_t n_rows, size_t elem);
 // ---- keyed.hip: int64 keys in any row order -> sorted keys, permutation, distinct keys, group offsets
 int keys_nondecreasing(pds_ctx* ctx, const int64_t* d_keys, int64_t n, unsigned* d_flag, bool* sorted);
 size_t keyed_temp_bytes(int64_t n);
+constexpr int kKeySlots = 8192;  // slots of the histogram the order check can take along (keyed.hip / keyed_partition.hip)
 int keys_order_minmax(pds_ctx* ctx, const int64_t* d_keys, int64_t n, int64_t* d_state, bool* sorted, int64_t* mm,
-                      uint32_t* d_run_counts = nullptr /* key_run_slots(n) entries: see keyed_runs_ordered */);
+                      uint32_t* d_run_counts = nullptr /* key_run_slots(n) entries: see keyed_runs_ordered */, int hist_shift = -1,
+                      unsigned* d_slot_counts = nullptr /* kKeySlots x 8 */, bool* hist_taken = nullptr);
 size_t key_run_slots(int64_t n);
 int keyed_runs_ordered(pds_ctx* ctx, const int64_t* d_keys, int64_t n, uint32_t* d_counts, uint32_t* d_prefix, int64_t cap, int64_t* d_unique,
                        int64_t* d_offsets, void* d_temp, size_t temp_bytes, int64_t* n_groups);
@@ -336,9 +338,12 @@ int64_t keyed_partition_buckets(int n_feat, int64_t n_rows, uint64_t range);  //
 template <typename T>
 size_t keyed_partition_workspace(int n_feat, int64_t n_rows, int64_t n_buckets);
 template <typename T>
-int keyed_partition_build(pds_ctx* ctx, const T* const* d_cols, const int64_t* d_keys, const int64_t* d_kmin, uint64_t range, int n_feat,
-                          int64_t n_rows, int64_t n_buckets, char* ws, int64_t max_groups, int64_t* d_out_keys, int64_t* d_offsets,
-                          int64_t* n_groups, KeyedPartitionState& st);
+int keyed_partition_shift(int n_feat);  // log2 of the bucket width (ids per bucket)
+template <typename T>
+int keyed_partition_build(pds_ctx* ctx, const T* const* d_cols, const int64_t* d_keys, const int64_t* d_kmin /* base: see keyed_partition.hip */,
+                          uint64_t range, int n_feat, int64_t n_rows, int64_t n_buckets, char* ws, int64_t max_groups, int64_t* d_out_keys,
+                          int64_t* d_offsets, int64_t* n_groups, KeyedPartitionState& st, const unsigned* d_slot_counts = nullptr,
+                          unsigned first_slot = 0);
 template <typename T>
 int keyed_partition_records(pds_ctx* ctx, const KeyedPartitionState& st, int n_feat, int64_t g0, int64_t gc, T* d_records);
 int keyed_runs(pds_ctx* ctx, const int64_t* d_sorted_keys, int64_t n, int64_t* d_unique, int64_t* d_counts, int64_t* d_offsets,

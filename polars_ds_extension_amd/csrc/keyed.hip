@@ -32,9 +32,21 @@ __global__ __launch_bounds__(256) void key_descent_kernel(const int64_t* __restr
 // piece): how many keys j of the slot differ from their successor j + 1 < n -- for keys that ARE in order, the number of groups that
 // start at j + 1.  An exclusive scan of the slots and a second pass (key_run_starts_kernel) then write the distinct keys and the
 // group offsets: the run-length encoding of an ordered key column without a library pass of its own (hipCUB's: 0.35 ms per 1e8 keys).
+// slot_counts (nullable; kKeySlots x 8 counters, zeroed by the caller; needs a 16-byte aligned key buffer and a grid that is a multiple
+// of 16): the histogram the partition route (keyed_partition.hip) starts from, taken in the same pass -- slot = (key >> hist_shift) mod
+// kKeySlots, stream = (row / 4096) mod 8 (a block's pieces all belong to one stream: (blockIdx / 2) mod 8).  Valid when the key range
+// turns out to span at most kKeySlots buckets; bucket b is then slot (b + (min >> hist_shift)) mod kKeySlots.  A wave whose 128 keys
+// share one slot -- ordered keys -- adds once.
 __global__ __launch_bounds__(256) void key_order_minmax_kernel(const int64_t* __restrict__ keys, int64_t n, long long* __restrict__ state,
-                                                               uint32_t* __restrict__ run_counts) {
+                                                               uint32_t* __restrict__ run_counts, int hist_shift,
+                                                               unsigned* __restrict__ slot_counts) {
     typedef long long ll2 __attribute__((ext_vector_type(2), aligned(16)));
+    __shared__ unsigned hist[kKeySlots];
+    const bool do_hist = slot_counts != nullptr;
+    if (do_hist) {
+        for (int i = threadIdx.x; i < kKeySlots; i += 256) hist[i] = 0u;
+        __syncthreads();
+    }
     bool found = false;
     long long mn = 0x7fffffffffffffffll, mx = -0x7fffffffffffffffll - 1;
     const int lane = threadIdx.x & 63;
@@ -70,6 +82,17 @@ __global__ __launch_bounds__(256) void key_order_minmax_kernel(const int64_t* __
                     const unsigned c = (unsigned)__popcll(__ballot(v[u].x != v[u].y)) + (unsigned)__popcll(__ballot(v[u].y != nxt));
                     if (lane == 0) run_counts[1 + p0 + u] = c;
                 }
+                if (do_hist) {
+                    const unsigned sx = (unsigned)((v[u].x >> hist_shift) & (long long)(kKeySlots - 1));
+                    const unsigned sy = (unsigned)((v[u].y >> hist_shift) & (long long)(kKeySlots - 1));
+                    const unsigned f = (unsigned)__builtin_amdgcn_readfirstlane((int)sx);
+                    if (__all(sx == f && sy == f)) {
+                        if (lane == 0) atomicAdd(&hist[f], 128u);
+                    } else {
+                        atomicAdd(&hist[sx], 1u);
+                        atomicAdd(&hist[sy], 1u);
+                    }
+                }
             }
         }
     }
@@ -83,6 +106,8 @@ __global__ __launch_bounds__(256) void key_order_minmax_kernel(const int64_t* __
             const long long k = in ? keys[i] : 0, nx = (in && i + 1 < n) ? keys[i + 1] : k;
             if (in) take(k, nx);
             ct += (unsigned)__popcll(__ballot(in && k != nx));
+            if (do_hist && in)  // (fewer than 128 keys: straight to the counters of their own chunk's stream)
+                atomicAdd(&slot_counts[(unsigned)((k >> hist_shift) & (long long)(kKeySlots - 1)) * 8u + (unsigned)((i >> 12) & 7)], 1u);
         }
         if (run_counts && lane == 0) {
             run_counts[0] = (head && n > 1 && keys[0] != keys[1]) ? 1u : 0u;
@@ -113,6 +138,13 @@ __global__ __launch_bounds__(256) void key_order_minmax_kernel(const int64_t* __
         if (any_found[0] | any_found[1] | any_found[2] | any_found[3]) atomicOr(reinterpret_cast<unsigned long long*>(state), 1ull);
         atomicMin(state + 2, mn);
         atomicMax(state + 3, mx);
+    }
+    if (do_hist) {  // (the __syncthreads above also closed the histogram)
+        const unsigned stream = (blockIdx.x >> 1) & 7u;
+        for (int i = threadIdx.x; i < kKeySlots; i += 256) {
+            const unsigned c = hist[i];
+            if (c) atomicAdd(&slot_counts[(unsigned)i * 8u + stream], c);
+        }
     }
 }
 
@@ -215,11 +247,20 @@ int keys_nondecreasing(pds_ctx* ctx, const int64_t* d_keys, int64_t n, unsigned*
 
 // order check + key range in ONE pass (d_state: 4 int64 slots on the device; d_state + 2 is the {min, max} pair keyed_sort and
 // the partition route read on the device)
-int keys_order_minmax(pds_ctx* ctx, const int64_t* d_keys, int64_t n, int64_t* d_state, bool* sorted, int64_t* mm, uint32_t* d_run_counts) {
+int keys_order_minmax(pds_ctx* ctx, const int64_t* d_keys, int64_t n, int64_t* d_state, bool* sorted, int64_t* mm, uint32_t* d_run_counts,
+                      int hist_shift, unsigned* d_slot_counts, bool* hist_taken) {
     const long long init[4] = {0, 0, 0x7fffffffffffffffll, -0x7fffffffffffffffll - 1};
     PDS_HIP_CHECK(hipMemcpyAsync(d_state, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
-    const int nb = (int)std::min<int64_t>(std::max<int64_t>((n + 2047) / 2048, 1), (int64_t)ctx->num_cus * 4);
-    hipLaunchKernelGGL(key_order_minmax_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_keys, n, reinterpret_cast<long long*>(d_state), d_run_counts);
+    int nb = (int)std::min<int64_t>(std::max<int64_t>((n + 2047) / 2048, 1), (int64_t)ctx->num_cus * 4);
+    // the fused histogram: aligned keys, a grid in which a block's pieces all belong to one stream, enough keys to be worth it
+    const bool hist = d_slot_counts && hist_shift >= 0 && ((uintptr_t)d_keys & 15) == 0 && nb >= 16;
+    if (hist) {
+        nb = nb / 16 * 16;
+        PDS_HIP_CHECK(hipMemsetAsync(d_slot_counts, 0, (size_t)kKeySlots * 8 * sizeof(unsigned), ctx->stream));
+    }
+    if (hist_taken) *hist_taken = hist;
+    hipLaunchKernelGGL(key_order_minmax_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_keys, n, reinterpret_cast<long long*>(d_state), d_run_counts,
+                       hist ? hist_shift : 0, hist ? d_slot_counts : (unsigned*)nullptr);
     long long h[4] = {0, 0, 0, 0};
     PDS_HIP_CHECK(hipMemcpyAsync(h, d_state, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // (also makes `init` safe to leave scope)

@@ -101,6 +101,15 @@ __global__ __launch_bounds__(256) void part_hist_kernel(const int64_t* __restric
     }
 }
 
+// ---- 1'. the histogram the order check took along (keyed.hip: slot = (key >> shift) mod kKeySlots) -> counts[bucket * 8 + stream]
+__global__ __launch_bounds__(256) void part_counts_from_slots_kernel(const unsigned* __restrict__ slots, unsigned first_slot, int64_t n_buckets,
+                                                                     unsigned* __restrict__ counts) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_buckets * kPartStreams; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / kPartStreams;
+        counts[i] = slots[(((unsigned)b + first_slot) & (unsigned)(kKeySlots - 1)) * kPartStreams + (unsigned)(i - b * kPartStreams)];
+    }
+}
+
 // ---- 2. scatter.  PPR = 16-byte pieces per record.
 template <typename T, int PPR>
 __global__ __launch_bounds__(256) void part_scatter_kernel(const T* const* __restrict__ cols /*x_0..x_{p-1}, y*/, int p, int pc,
@@ -226,6 +235,7 @@ __global__ __launch_bounds__(kAccumThreads) void part_accum_kernel(const char* _
     }
     const int64_t bucket = lo;
     const unsigned chunk = w - chunk_prefix[bucket];
+    const bool single = chunk_prefix[bucket + 1] - chunk_prefix[bucket] == 1u;
     const int64_t b0 = bucket_start[bucket * kPartStreams], b1 = bucket_start[(bucket + 1) * kPartStreams];
     const int64_t r0 = b0 + (int64_t)chunk * kPartAccumChunk, r1 = (r0 + kPartAccumChunk < b1) ? r0 + kPartAccumChunk : b1;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -375,14 +385,30 @@ __global__ __launch_bounds__(kAccumThreads) void part_accum_kernel(const char* _
         }
         __syncthreads();
         double* tb = table + ((size_t)bucket * IDS + (size_t)id0) * NVP;
-        for (int i = tid; i < FID * NVP; i += kAccumThreads) {
-            const int l = i / NVP;
-            if (mom[l * NVP + CNT] > 0.0) {
-                const double v = mom[i];
-                if (v != 0.0) unsafeAtomicAdd(tb + i, v);
+        if (single) {  // the bucket's only workgroup: plain stores of every entry (ids without rows: zeros) -- its rows need no memset
+            for (int i = tid; i < FID * NVP; i += kAccumThreads) tb[i] = mom[i];
+        } else {
+            for (int i = tid; i < FID * NVP; i += kAccumThreads) {
+                const int l = i / NVP;
+                if (mom[l * NVP + CNT] > 0.0) {
+                    const double v = mom[i];
+                    if (v != 0.0) unsafeAtomicAdd(tb + i, v);
+                }
             }
         }
         __syncthreads();
+    }
+}
+
+// table rows of the buckets that are NOT written by exactly one accumulate workgroup (no records at all, or several chunks that meet
+// through atomics) start from zero; the usual bucket -- one chunk -- is overwritten whole by its workgroup instead (a memset of the
+// whole id-indexed table was 0.1 ms of the C3 frame's 7.7)
+__global__ __launch_bounds__(256) void part_zero_rows_kernel(double* __restrict__ table, const unsigned* __restrict__ chunks, int64_t n_buckets,
+                                                             int64_t row_doubles) {
+    for (int64_t b = blockIdx.x; b < n_buckets; b += gridDim.x) {
+        if (chunks[b] == 1u) continue;
+        double* t = table + (size_t)b * row_doubles;
+        for (int64_t i = threadIdx.x; i < row_doubles; i += 256) t[i] = 0.0;
     }
 }
 
@@ -500,9 +526,17 @@ template size_t keyed_partition_workspace<float>(int, int64_t, int64_t);
 //   out: *n_groups (host; a stream synchronisation), d_out_keys / d_sizes_as_offsets (n_groups + 1, exclusive scan + n) for up to
 //   max_groups groups, and the handles the solve stage needs (table, ids, layout) in `st`.
 template <typename T>
+int keyed_partition_shift(int n_feat) { return make_layout<T>(n_feat).shift; }
+template int keyed_partition_shift<double>(int);
+template int keyed_partition_shift<float>(int);
+
+// d_kmin: the BASE of the dense ids on the device -- the smallest key rounded down to a multiple of the bucket width, so that
+// (key - base) >> shift = (key >> shift) - (base >> shift): the order check's histogram (d_slot_counts, nullable; first_slot =
+// (base >> shift) mod kKeySlots) uses the same buckets
+template <typename T>
 int keyed_partition_build(pds_ctx* ctx, const T* const* d_cols, const int64_t* d_keys, const int64_t* d_kmin, uint64_t range, int n_feat,
                           int64_t n_rows, int64_t n_buckets, char* ws, int64_t max_groups, int64_t* d_out_keys, int64_t* d_offsets,
-                          int64_t* n_groups, KeyedPartitionState& st) {
+                          int64_t* n_groups, KeyedPartitionState& st, const unsigned* d_slot_counts, unsigned first_slot) {
     const PartLayout L = make_layout<T>(n_feat);
     const size_t ids = (size_t)n_buckets << L.shift;
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
@@ -524,8 +558,9 @@ int keyed_partition_build(pds_ctx* ctx, const T* const* d_cols, const int64_t* d
     temp_bytes = std::max(temp_bytes, t2);
     void* d_temp = take(temp_bytes);
     hipStream_t s = ctx->stream;
-    PDS_HIP_CHECK(hipMemsetAsync(counts, 0, ncnt * 4, s));
-    PDS_HIP_CHECK(hipMemsetAsync(table, 0, ids * L.nvp * 8, s));
+    if (!d_slot_counts) PDS_HIP_CHECK(hipMemsetAsync(counts, 0, ncnt * 4, s));
+    else PDS_HIP_CHECK(hipMemsetAsync(counts + (ncnt - 1), 0, 4, s));
+    // (the table is zeroed bucket by bucket where that is needed: part_zero_rows_kernel below)
     PDS_HIP_CHECK(hipMemsetAsync(chunks + n_buckets, 0, 4, s));
     PDS_HIP_CHECK(hipMemsetAsync(flags + ids, 0, 4, s));
     // ---- 1. histogram (a grid that is resident at once and a multiple of the stream count: block b runs on XCD b mod 8)
@@ -535,7 +570,12 @@ int keyed_partition_build(pds_ctx* ctx, const T* const* d_cols, const int64_t* d
         PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(part_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds));
     int hb = (int)std::min<int64_t>(nchunks, (int64_t)ctx->num_cus * (hist_lds > 32 * 1024 ? 1 : 4));
     hb = std::max(kPartStreams, hb / kPartStreams * kPartStreams);
-    hipLaunchKernelGGL(part_hist_kernel, dim3(hb), dim3(256), hist_lds, s, d_keys, n_rows, d_kmin, L.shift, n_buckets, counts);
+    if (d_slot_counts) {
+        const int pb = (int)std::min<int64_t>((n_buckets * kPartStreams + 255) / 256, 1024);
+        hipLaunchKernelGGL(part_counts_from_slots_kernel, dim3(pb), dim3(256), 0, s, d_slot_counts, first_slot, n_buckets, counts);
+    } else {
+        hipLaunchKernelGGL(part_hist_kernel, dim3(hb), dim3(256), hist_lds, s, d_keys, n_rows, d_kmin, L.shift, n_buckets, counts);
+    }
     PDS_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(d_temp, temp_bytes, (const unsigned*)counts, starts, (int)ncnt, s));
     PDS_HIP_CHECK(hipMemcpyAsync(cursor, starts, ncnt * 4, hipMemcpyDeviceToDevice, s));
     // ---- 2. scatter
@@ -555,6 +595,8 @@ int keyed_partition_build(pds_ctx* ctx, const T* const* d_cols, const int64_t* d
     const int cb = (int)std::min<int64_t>(std::max<int64_t>((n_buckets + 255) / 256, 1), 1024);
     hipLaunchKernelGGL(part_chunk_counts_kernel, dim3(cb), dim3(256), 0, s, (const unsigned*)starts, n_buckets, chunks);
     PDS_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(d_temp, temp_bytes, (const unsigned*)chunks, chunk_prefix, (int)n_buckets + 1, s));
+    hipLaunchKernelGGL(part_zero_rows_kernel, dim3((unsigned)std::min<int64_t>(n_buckets, (int64_t)ctx->num_cus * 8)), dim3(256), 0, s, table,
+                       (const unsigned*)chunks, n_buckets, (int64_t)(((size_t)1 << L.shift) * L.nvp));
     const unsigned max_items = (unsigned)(n_buckets + (n_rows + kPartAccumChunk - 1) / kPartAccumChunk);
     int rc = PDS_OK;
     switch (L.pc) {
@@ -589,9 +631,9 @@ int keyed_partition_build(pds_ctx* ctx, const T* const* d_cols, const int64_t* d
     return PDS_OK;
 }
 template int keyed_partition_build<double>(pds_ctx*, const double* const*, const int64_t*, const int64_t*, uint64_t, int, int64_t, int64_t,
-                                           char*, int64_t, int64_t*, int64_t*, int64_t*, KeyedPartitionState&);
+                                           char*, int64_t, int64_t*, int64_t*, int64_t*, KeyedPartitionState&, const unsigned*, unsigned);
 template int keyed_partition_build<float>(pds_ctx*, const float* const*, const int64_t*, const int64_t*, uint64_t, int, int64_t, int64_t, char*,
-                                          int64_t, int64_t*, int64_t*, int64_t*, KeyedPartitionState&);
+                                          int64_t, int64_t*, int64_t*, int64_t*, KeyedPartitionState&, const unsigned*, unsigned);
 
 // (p+2)^2 moment records of groups [g0, g0 + gc) for the batched solvers
 template <typename T>
