@@ -18,7 +18,7 @@ def note(k, e):
     worst[k] = max(worst.get(k, 0.0), e)
 
 while time.time() < t_end:
-    kind = rng.choice(["lr", "lr", "report", "rolling", "recursive", "keyed", "weighted", "multi"])
+    kind = rng.choice(["lr", "lr", "report", "rolling", "recursive", "keyed", "weighted", "multi", "grouped"])
     if kind in ("lr", "weighted", "multi"):
         p = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 17, 24, 40, 70]))
         n = int(rng.integers(max(3 * p, 40), 60_000))
@@ -58,6 +58,30 @@ while time.time() < t_end:
         e = nrel(b, bo)
         note("lr/" + method, e)
         assert e < (1e-7 if method in ("lasso", "enet", "nnls") else 1e-9), (method, p, n, bias, e)
+    elif kind == "grouped":
+        # contiguous groups, 1 .. 64 features (17 .. 64: one wave per system in registers + the pivoted-QR pass over what it marks)
+        p = int(rng.choice([2, 9, 16, 17, 20, 31, 32, 33, 47, 48, 63, 64]))
+        bias = bool(rng.integers(0, 2))
+        pp = p + bias
+        G = int(rng.integers(1, 400))
+        sizes = rng.integers(max(1, pp - 3), int(rng.choice([2, 6, 12])) * pp + 5, size=G)
+        off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        N = int(off[-1])
+        X = rng.normal(size=(N, p)) + rng.normal(size=p) * float(rng.choice([0.0, 0.5]))
+        y = X @ rng.normal(size=p) + 0.3 + 0.1 * rng.normal(size=N)
+        l2 = float(rng.choice([0.0, 0.0, 0.2]))
+        co, nu = pds.lin_reg_by(*[dev(X[:, j]) for j in range(p)], target=dev(y), group_offsets=off, add_bias=bias, l2_reg=l2)
+        co, nu = co.cpu().numpy(), nu.cpu().numpy().astype(bool)
+        co_o, nu_o = orc.grouped_lr([y] + [X[:, j] for j in range(p)], off, add_bias=bias, l2_reg=l2, nthreads=4)
+        # (a group next to the 1e-12 gate may fall on either side of it in two correct factorisations: count those, bound them)
+        mism = int((nu != nu_o).sum())
+        note("grouped/gate-side-differs", mism / max(G, 1))
+        assert mism <= max(1, G // 50), (p, bias, G, l2, mism)
+        ok = ~nu & ~nu_o & (sizes >= 2 * pp + 8)
+        if ok.any():
+            e = float(np.max(np.linalg.norm(co[ok] - co_o[ok], axis=1) / np.linalg.norm(co_o[ok], axis=1)))
+            note("grouped/p<=16" if p <= 16 else "grouped/17..64", e)
+            assert e < 1e-7, (p, bias, G, l2, e)
     elif kind == "report":
         p = int(rng.choice([1, 3, 8, 16, 17, 20, 32, 33, 48, 64]))  # 17 .. 64: the fused one-stream robust errors (moments_mid.hip)
         n = int(rng.integers(20 * p + 50, 80_000))
