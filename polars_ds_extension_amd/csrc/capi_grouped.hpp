@@ -93,7 +93,11 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
     // chunk the groups so one chunk's moment records (q*q values per group) stay inside the 256 MiB
     // Infinity Cache between the Gram kernel that writes them and the solve kernel that reads them
     const bool big = n_feat > kMaxFeatWide;  // > 64 features: one tiled-SYRK Gram build per group + solve_big
-    int64_t chunk = std::max<int64_t>(big ? 64 : 4096, (int64_t)(128ll << 20) / (int64_t)(sizeof(T) * q * q));
+    // (17 .. 64 features: 512 MiB of records per chunk -- every chunk ends in a host synchronisation for the solver's marked count, and
+    //  fourteen of those cost the 200 000 x 100 x 32 frame 0.6 of its 4.4 ms; PDS_GROUPED_CHUNK_MB overrides)
+    static const int64_t chunk_env = [] { const char* e = std::getenv("PDS_GROUPED_CHUNK_MB"); return e ? std::max<int64_t>(1, std::atoll(e)) : 0; }();
+    const int64_t chunk_mb = chunk_env ? chunk_env : ((n_feat > 16 && n_feat <= kMaxFeatWide) ? 512 : 128);
+    int64_t chunk = std::max<int64_t>(big ? 64 : 4096, (int64_t)(chunk_mb << 20) / (int64_t)(sizeof(T) * q * q));
     chunk = std::min(chunk, n_groups);
     size_t need = 131072 + sizeof(T) * (size_t)chunk * q * q;
     need += (size_t)n_groups * 4 + (size_t)chunk * (pp * sizeof(T) + 1) + 4096;  // the fused path's pivoted-QR pass: list, results
@@ -215,7 +219,18 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
         void* d_wave_ws = (n_feat > 16 && n_feat <= 64 && !want_piv) ? ws_take(ctx, solve_wave_workspace(n_feat, bias, chunk, sizeof(T))) : nullptr;
         for (int64_t g0 = 0; g0 < n_groups; g0 += chunk) {
             const int64_t gc = std::min(chunk, n_groups - g0);
-            if (int rc = launch_grouped_moments<T>(ctx, dc, n_feat, d_off + g0, gc, d_mom)) return rc;
+            bool streamed = false;
+            if constexpr (std::is_same<T, double>::value) {
+                // 17 .. 64 f64 features: the chunk's records from ONE stream over its rows (moments_mid.hip); PDS_GROUPED_STREAM=0: A/B
+                static const bool stream_off = [] { const char* e = std::getenv("PDS_GROUPED_STREAM"); return e && e[0] == '0'; }();
+                // (below ~28 features the padded 32-wide stream costs more than the one-wave-per-group kernel saves: 2.7 against 2.5 ms at 20)
+                if (n_feat >= 28 && n_feat <= 64 && !stream_off) {
+                    if (int rc = launch_grouped_moments_stream(ctx, dc, n_feat, n_rows, d_off + g0, gc, d_mom)) return rc;
+                    streamed = true;
+                }
+            }
+            if (!streamed)
+                if (int rc = launch_grouped_moments<T>(ctx, dc, n_feat, d_off + g0, gc, d_mom)) return rc;
             // 17 .. 64 features, gate on: one wave per system in registers (solve_wave.hip), the pivoted QR only for what it marks
             int rcw = want_piv ? PDS_ERR_UNSUPPORTED
                                : launch_solve_wave<T>(ctx, d_mom, gc, sp, d_coeffs + g0 * pp, d_null + g0, d_off + g0, d_wave_ws);

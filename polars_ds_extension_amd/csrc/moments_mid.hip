@@ -406,6 +406,274 @@ int launch_mid(pds_ctx* ctx, const DeviceCols<double>& dc, int p, int64_t n, dou
     return PDS_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Grouped form: the (p+2)^2 moment records of CONTIGUOUS GROUPS (group g = rows [off[g], off[g+1])) from ONE stream over the frame --
+// `group_by(key).agg(pds.lin_reg(...))` with 17 .. 64 f64 features.  The one-wave-per-group kernel of moments.hip loads 32 rows at a
+// time with 8-byte loads and nothing in flight behind them (1.2 - 2.5 TB/s); here the rows are read exactly as above (waves own
+// contiguous, half-tile aligned row ranges; 1 KiB asynchronous loads into wave-private LDS images) and the accumulators are CUT at
+// group boundaries: a half-tile is walked as segments [lo, hi) of one group each, the first and last 4-row step of a segment with the
+// rows outside it zeroed in the operands, and a finished group's tiles go straight from the accumulator registers into its record.
+// Groups that lie inside one wave's rows are written with plain stores; a group cut by a wave boundary (two per wave, or a giant group
+// over many waves) is added to the zero-initialised record with atomics.
+template <int NBLK>
+__global__ __launch_bounds__(64) void grouped_mid_stream_kernel(const double* const* __restrict__ cols, int p, int64_t n_frame,
+                                                                const int64_t* __restrict__ off, int64_t n_groups,
+                                                                double* __restrict__ records, int debug) {
+    using MD = MidDims<NBLK>;
+    constexpr int HR = MD::HR, GS = MD::GS, NPAIR = MD::NPAIR;
+    extern __shared__ __attribute__((aligned(16))) char gmid_lds[];
+    typedef __attribute__((address_space(3))) char* lds_c;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    typedef double mid_d2 __attribute__((ext_vector_type(2)));
+#define PDS_GM_LDSD(addr) (*(__attribute__((address_space(3))) double*)(addr))
+    lds_c sm = (lds_c)gmid_lds;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = blockIdx.x, nwaves = gridDim.x;
+    const int64_t row_begin = off[0], row_end = off[n_groups];
+    if (row_end <= row_begin) return;
+    // half-tiles [H0, H1) cover the chunk's rows; a wave takes a contiguous range of them
+    const int64_t H0 = row_begin / HR, H1 = (row_end + HR - 1) / HR;
+    const int64_t h0 = H0 + (H1 - H0) * wave / nwaves, h1 = H0 + (H1 - H0) * (wave + 1) / nwaves;
+    if (h0 >= h1) return;
+    const int64_t W0 = h0 * HR > row_begin ? h0 * HR : row_begin, W1 = h1 * HR < row_end ? h1 * HR : row_end;  // the wave's rows
+    const int q = p + 2;
+    const int g_ = lane / MD::GL, piece = lane % MD::GL;
+    const double* cbase[16];
+    unsigned valid = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = 16 * g_ + i;
+        cbase[i] = cols[c < p ? c : p] + 2 * piece;
+        if (c < p) valid |= 1u << i;
+    }
+    const double* ybase = cols[p] + 2 * lane;
+    for (int i = lane * 16; i < MD::LDS_BYTES; i += 64 * 16) *(__attribute__((address_space(3))) mid_d2*)(sm + i) = mid_d2{0.0, 0.0};
+    PDS_WAVE_LDS_SYNC();
+    auto issue = [&](int buf, int64_t row0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if ((valid >> i) & 1u)
+                __builtin_amdgcn_global_load_lds((glb_ptr)(as_global(cbase[i]) + row0), (lds_ptr)(sm + buf * MD::HALF_BYTES + i * GS), 16, 0, 0);
+        if (lane < HR / 2)
+            __builtin_amdgcn_global_load_lds((glb_ptr)(as_global(ybase) + row0), (lds_ptr)(sm + buf * MD::HALF_BYTES + MD::Y_OFF), 16, 0, 0);
+    };
+    auto load_guarded = [&](int buf, int64_t row0) __attribute__((always_inline)) {  // the frame's last, partial half-tile
+        for (int c = 0; c <= p; ++c) {
+            const int offb = c < p ? (c % 16) * GS + (c / 16) * HR * 8 : MD::Y_OFF;
+            const gptr<double> col = as_global(cols[c]);
+            for (int r = lane; r < HR; r += 64) PDS_GM_LDSD(sm + buf * MD::HALF_BYTES + offb + r * 8) = row0 + r < n_frame ? col[row0 + r] : 0.0;
+        }
+    };
+    auto fetch_tile = [&](int buf, int64_t h) __attribute__((always_inline)) {
+        if ((h + 1) * HR <= n_frame) issue(buf, h * HR);
+        else load_guarded(buf, h * HR);
+    };
+    d4 acc[NPAIR];
+    double xy[NBLK], cs[NBLK], yy = 0.0, ys = 0.0;
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < NPAIR; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) xy[b] = cs[b] = 0.0;
+        yy = ys = 0.0;
+    };
+    zero_acc();
+    const int fi = lane & 15, fk = lane >> 4;
+    // ---- the group that holds the wave's first row
+    int64_t g = 0;
+    {
+        int64_t lo = 0, hi = n_groups;  // last g with off[g] <= W0
+        while (hi - lo > 1) {
+            const int64_t mid = lo + ((hi - lo) >> 1);
+            if (off[mid] <= W0) lo = mid;
+            else hi = mid;
+        }
+        g = lo;
+    }
+    // the group walk is wave-uniform: with g known to be uniform the offsets come through the SCALAR cache (their own counter) --
+    // as vector loads every group end waited, through the in-order vmcnt, for the next half-tile's 17 loads as well (12 us per
+    // half-tile instead of 2); the end of the NEXT group is fetched one group ahead
+    auto uni64 = [](int64_t v) __attribute__((always_inline)) {
+        const int lo32 = __builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)v), hi32 = __builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
+        return (int64_t)(((uint64_t)(uint32_t)hi32 << 32) | (uint64_t)(uint32_t)lo32);
+    };
+    g = uni64(g);
+    int64_t gs = off[g], ge = off[g + 1];
+    int64_t ge_next = off[g + 2 <= n_groups ? g + 2 : n_groups];
+    int64_t rows_in_acc = 0;
+    // accumulate rows [lo, hi) (relative to the half-tile in `buf`) into acc: a masked step at either end where the segment does not
+    // start / end on a 4-row step, the steps in between unmasked with the next step's operands fetched from LDS before this step
+    // multiplies (fetch -> wait -> multiply per step ran at half the stream rate: one wave per SIMD, nobody else hides the round trip)
+    auto consume = [&](int buf, int lo, int hi) __attribute__((always_inline)) {
+        const lds_c base = sm + buf * MD::HALF_BYTES;
+        auto fetch = [&](int s, double (&a)[NBLK], double& yk) __attribute__((always_inline)) {
+            const int roff = (4 * s + fk) * 8;
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) a[b] = PDS_GM_LDSD(base + fi * GS + b * HR * 8 + roff);
+            yk = PDS_GM_LDSD(base + MD::Y_OFF + roff);
+        };
+        auto mult = [&](const double (&a)[NBLK], double yk) __attribute__((always_inline)) {
+            int t = 0;
+#pragma unroll
+            for (int I = 0; I < NBLK; ++I)
+#pragma unroll
+                for (int J = I; J < NBLK; ++J) {
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], a[J], acc[t], 0, 0, 0);
+                    ++t;
+                }
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) {
+                xy[b] = fma(a[b], yk, xy[b]);
+                cs[b] += a[b];
+            }
+            yy = fma(yk, yk, yy);
+            ys += yk;
+        };
+        auto masked = [&](int s) __attribute__((always_inline)) {
+            const int rr = 4 * s + fk;
+            const bool in = rr >= lo && rr < hi;
+            double a[NBLK], yk;
+            fetch(s, a, yk);
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) a[b] = in ? a[b] : 0.0;
+            yk = in ? yk : 0.0;
+            mult(a, yk);
+        };
+        int s0 = lo >> 2, s1 = (hi + 3) >> 2;  // steps [s0, s1)
+        if ((lo & 3) != 0 || s1 - s0 == 1) {    // (a segment inside one step: that step masked on both sides)
+            masked(s0);
+            ++s0;
+        }
+        if (s0 < s1 && (hi & 3) != 0) {
+            --s1;
+            masked(s1);
+        }
+        if (s0 < s1) {
+            double a[NBLK], yk;
+            fetch(s0, a, yk);
+            for (int s = s0; s < s1; ++s) {
+                double an[NBLK], ykn;
+                fetch(s + 1 < s1 ? s + 1 : s, an, ykn);
+                mult(a, yk);
+#pragma unroll
+                for (int b = 0; b < NBLK; ++b) a[b] = an[b];
+                yk = ykn;
+            }
+        }
+        rows_in_acc += hi - lo;
+    };
+    // the accumulated rows of group g -> its record (plain stores when the whole group lies in this wave's rows)
+    auto flush = [&]() __attribute__((always_inline)) {
+        const bool whole = gs >= W0 && ge <= W1;
+        if (debug & 2) {  // (timing experiment: no record stores)
+            zero_acc();
+            rows_in_acc = 0;
+            return;
+        }
+        double* M = records + g * (int64_t)q * q;
+        auto put = [&](int64_t idx, double v) __attribute__((always_inline)) {
+            if (whole) M[idx] = v;
+            else if (v != 0.0) unsafeAtomicAdd(M + idx, v);
+        };
+        int t = 0;
+#pragma unroll
+        for (int I = 0; I < NBLK; ++I)
+#pragma unroll
+            for (int J = I; J < NBLK; ++J) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * I + fk + 4 * r, j = 16 * J + fi;
+                    if (i < p && j < p) {
+                        put(i + (int64_t)j * q, acc[t][r]);
+                        if (I != J) put(j + (int64_t)i * q, acc[t][r]);
+                    }
+                }
+                ++t;
+            }
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) {
+            double vx = xy[b], vc = cs[b];
+            vx += __shfl_xor(vx, 16);
+            vx += __shfl_xor(vx, 32);
+            vc += __shfl_xor(vc, 16);
+            vc += __shfl_xor(vc, 32);
+            const int f = 16 * b + fi;
+            if (fk == 0 && f < p) {
+                put(f + (int64_t)(p + 1) * q, vx);
+                put((p + 1) + (int64_t)f * q, vx);
+                put(f + (int64_t)p * q, vc);
+                put(p + (int64_t)f * q, vc);
+            }
+        }
+        double vyy = yy, vys = ys;
+        vyy += __shfl_xor(vyy, 16);
+        vyy += __shfl_xor(vyy, 32);
+        vys += __shfl_xor(vys, 16);
+        vys += __shfl_xor(vys, 32);
+        if (lane == 0) {
+            put(p + (int64_t)p * q, (double)rows_in_acc);
+            put(p + (int64_t)(p + 1) * q, vys);
+            put((p + 1) + (int64_t)p * q, vys);
+            put((p + 1) + (int64_t)(p + 1) * q, vyy);
+        }
+        zero_acc();
+        rows_in_acc = 0;
+    };
+    // ---- stream the half-tiles
+    int64_t pos = W0;
+    fetch_tile(0, h0);
+    for (int64_t h = h0; h < h1; ++h) {
+        const int buf = (int)((h - h0) & 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // half-tile h has landed (and this wave's record stores are out)
+        PDS_WAVE_LDS_SYNC();
+        if (h + 1 < h1) fetch_tile(buf ^ 1, h + 1);  // (the other image was consumed one iteration ago)
+        const int64_t R0 = h * HR;
+        const int64_t tile_end = R0 + HR < W1 ? R0 + HR : W1;
+        while (pos < tile_end) {
+            const int64_t seg_end = ge < tile_end ? ge : tile_end;
+            if (seg_end > pos && !(debug & 1)) consume(buf, (int)(pos - R0), (int)(seg_end - R0));
+            if (debug & 1) rows_in_acc += seg_end - pos;
+            pos = seg_end;
+            if (pos == ge) {  // group complete (as far as this wave's rows go: `whole` decides how it is written)
+                if (rows_in_acc > 0) flush();
+                do {  // (empty groups: their records stay zero)
+                    ++g;
+                    gs = ge;
+                    ge = ge_next;
+                    ge_next = off[g + 2 <= n_groups ? g + 2 : n_groups];
+                } while (g < n_groups && ge == pos);
+                if (g >= n_groups) break;
+            }
+        }
+        if (g >= n_groups) break;
+        PDS_WAVE_LDS_SYNC();
+    }
+    if (rows_in_acc > 0 && g < n_groups) flush();  // the group that continues in the next wave's rows
+#undef PDS_GM_LDSD
+}
+
+template <int NBLK>
+int launch_grouped_stream(pds_ctx* ctx, const DeviceCols<double>& dc, int p, int64_t n_frame, const int64_t* d_off, int64_t n_groups,
+                          double* d_records) {
+    using MD = MidDims<NBLK>;
+    const int q = p + 2;
+    PDS_HIP_CHECK(hipMemsetAsync(d_records, 0, (size_t)n_groups * q * q * sizeof(double), ctx->stream));
+    auto kern = grouped_mid_stream_kernel<NBLK>;
+    if (MD::LDS_BYTES > 64 * 1024)
+        PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, MD::LDS_BYTES));
+    // a wave takes at least eight half-tiles: a group then meets at most two waves unless it is longer than a wave's whole range, and
+    // the sum of two partial records does not depend on their order -- results are reproducible run to run but for such giant groups
+    // (the row count of the chunk is not known on the host: the frame's is an upper bound)
+    const int64_t waves = std::min<int64_t>((int64_t)ctx->num_cus * kMidWavesPerCu, std::max<int64_t>(1, n_frame / (8 * MD::HR)));
+    const char* dbg = std::getenv("PDS_GMID_DEBUG");  // (timing experiments only: wrong results)
+    hipLaunchKernelGGL(kern, dim3((unsigned)waves), dim3(64), MD::LDS_BYTES, ctx->stream, dc.d_ptrs, p, n_frame, d_off, n_groups, d_records,
+                       dbg ? std::atoi(dbg) : 0);
+    PDS_HIP_CHECK(hipGetLastError());
+    return PDS_OK;
+}
+
 }  // namespace
 
 size_t moments_mid_workspace(int num_cus) { return (size_t)(num_cus * kMidWavesPerCu + 1) * MidDims<4>::REC * sizeof(double) + 4096; }
@@ -431,6 +699,17 @@ int launch_report_mid(pds_ctx* ctx, const DeviceCols<double>& dc, int n_feat, in
     if (int rc = leverage_operand(ctx, d_inv, n_feat, bias, &d_lop)) return rc;
     if (n_feat <= 32) return launch_mid<2, false, 2>(ctx, dc, n_feat, n_rows, d_meat, bias, d_beta, d_lop, hc_mode, d_sums);
     return launch_mid<4, false, 2>(ctx, dc, n_feat, n_rows, d_meat, bias, d_beta, d_lop, hc_mode, d_sums);
+}
+
+// Moment records ((p+2)^2 doubles each, column-major over [x_0 .. x_{p-1}, 1, y]) of n_groups contiguous groups (d_off: n_groups + 1
+// device offsets into the frame of n_frame rows) with 17 .. 64 f64 features, from one stream over the groups' rows.
+int launch_grouped_moments_stream(pds_ctx* ctx, const DeviceCols<double>& dc, int n_feat, int64_t n_frame, const int64_t* d_off, int64_t n_groups,
+                                  double* d_records) {
+    if (n_groups <= 0) return PDS_OK;
+    KernelTimer timer(ctx, kKindGroupedMoments);
+    if (n_feat <= 32) return launch_grouped_stream<2>(ctx, dc, n_feat, n_frame, d_off, n_groups, d_records);
+    if (n_feat <= 64) return launch_grouped_stream<4>(ctx, dc, n_feat, n_frame, d_off, n_groups, d_records);
+    return fail(PDS_ERR_UNSUPPORTED, "grouped_mid_stream: up to 64 features");
 }
 
 }  // namespace pds

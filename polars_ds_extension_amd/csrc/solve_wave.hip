@@ -203,7 +203,7 @@ int launch_solve_wave(pds_ctx* ctx, const T* d_moments, int64_t n_sys, const Sol
         d_list = reinterpret_cast<int32_t*>(take((size_t)n_sys * sizeof(int32_t)));
         PDS_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(unsigned), ctx->stream));
     }
-    const int nb = (int)std::min<int64_t>(n_sys, (int64_t)ctx->num_cus * 8);
+    const int nb = (int)std::min<int64_t>(n_sys, (int64_t)ctx->num_cus * (sp.p <= 32 ? 16 : 8));  // (up to 32 features: ~100 registers, four waves per SIMD)
     {
         KernelTimer timer(ctx, kKindSolve);
         const dim3 g((unsigned)nb);

@@ -514,6 +514,8 @@ def test_grouped_pred(pds, orc, p, bias):
     # pred_i = x_i . beta: the contract's 1e-10 on beta (normwise), propagated -- |x_i| |beta| 1e-10; groups whose own conditioning
     # loosens beta (rows barely above features) are judged per group like test_grouped does
     co2, nu2 = pds.lin_reg_by(*cols_of(X), target=dev(y), group_offsets=off, add_bias=bias)
+    # (same kernels in both calls: the same bits.  17 .. 64 features: a group cut by a wave boundary is summed from partial records --
+    #  two of them in either order are the same number, so this holds there too unless a group outgrows a whole wave's rows)
     assert np.array_equal(co.cpu().numpy()[~nu.cpu().numpy().astype(bool)], co2.cpu().numpy()[~nu2.cpu().numpy().astype(bool)])
     gid = np.repeat(np.arange(G), sizes)
     well = (sizes >= 2 * (p + bias) + 8)[gid] & ok
