@@ -541,6 +541,23 @@ __global__ __launch_bounds__(64) void grouped_mid_stream_kernel(const double* co
             yk = in ? yk : 0.0;
             mult(a, yk);
         };
+        if (lo == 0 && hi == HR) {  // a whole half-tile of one group: the unrolled form of the single-regression kernel
+            double a[NBLK], yk;
+            fetch(0, a, yk);
+#pragma unroll
+            for (int s = 0; s < MD::NS; ++s) {
+                double an[NBLK], ykn = 0.0;
+#pragma unroll
+                for (int b = 0; b < NBLK; ++b) an[b] = 0.0;
+                if (s + 1 < MD::NS) fetch(s + 1, an, ykn);
+                mult(a, yk);
+#pragma unroll
+                for (int b = 0; b < NBLK; ++b) a[b] = an[b];
+                yk = ykn;
+            }
+            rows_in_acc += HR;
+            return;
+        }
         int s0 = lo >> 2, s1 = (hi + 3) >> 2;  // steps [s0, s1)
         if ((lo & 3) != 0 || s1 - s0 == 1) {    // (a segment inside one step: that step masked on both sides)
             masked(s0);
