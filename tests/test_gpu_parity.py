@@ -879,6 +879,32 @@ def test_by_key_order_check_sees_every_inversion(pds):
         assert torch.equal(k_out, base[shift:])
 
 
+@pytest.mark.parametrize("p", [28, 40, 64])
+def test_grouped_stream_record_edges(pds, orc, p):
+    """The streamed Gram records of 28 .. 64 features (moments_mid.hip grouped_mid_stream_kernel): a group that spans many waves (its
+    record is summed from partial records by atomics), groups that start / end inside a 4-row step, empty groups, one- and two-row
+    groups, a last group that ends in a partial half-tile, and frames shorter than one half-tile -- coefficients and null flags
+    against the oracle, group by group."""
+    rng = np.random.default_rng(9000 + p)
+    for sizes in (np.r_[7000, rng.integers(p + 2, p + 9, size=60), 0, 0, 1, 2, 3 * p + 1, 0, rng.integers(2 * p, 5 * p, size=40), 3, 4 * p + 3],
+                  np.r_[2 * p + 1], np.r_[1, 0, 2 * p + 3], np.r_[rng.integers(p + 1, 3 * p, size=7)]):
+        sizes = np.asarray(sizes, dtype=np.int64)
+        off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        N, G = int(off[-1]), len(sizes)
+        X = rng.normal(size=(N, p))
+        y = X @ rng.normal(size=p) + 0.2 + 0.1 * rng.normal(size=N)
+        co, nu = pds.lin_reg_by(*cols_of(X), target=dev(y), group_offsets=off, add_bias=True)
+        co, nu = co.cpu().numpy(), nu.cpu().numpy().astype(bool)
+        co_o, nu_o = orc.grouped_lr([y] + [X[:, j] for j in range(p)], off, add_bias=True, nthreads=2)
+        # (groups with barely more rows than columns sit next to the 1e-12 gate: two correct factorisations may disagree there)
+        clear = sizes >= 2 * (p + 1)
+        assert np.array_equal(nu[clear | (sizes <= p)], nu_o[clear | (sizes <= p)]), (sizes[nu != nu_o], N)
+        ok = clear & ~nu
+        if ok.any():
+            err = np.linalg.norm(co[ok] - co_o[ok], axis=1) / np.linalg.norm(co_o[ok], axis=1)
+            assert err.max() < 1e-8, (err.max(), sizes[ok][np.argmax(err)])
+
+
 @pytest.mark.parametrize("p,bias,l2", [(17, True, 0.0), (24, False, 0.0), (32, True, 0.0), (33, False, 0.3), (40, True, 0.0), (49, True, 0.0),
                                         (57, False, 0.0), (64, True, 0.0), (64, False, 0.2)])
 def test_grouped_mid_width_wave_solver(pds, orc, p, bias, l2):
