@@ -70,6 +70,9 @@ PartLayout make_layout(int p) {
     L.nvp = L.nv | 1;
     L.meta_off = ((L.pc + 1) * (int)sizeof(T) + 7) & ~7;
     L.rs = (L.meta_off + 8 + 15) & ~15;
+#ifdef PDS_PART_RS_ALIGN32
+    L.rs = (L.rs + 31) & ~31;  // (experiment: whole 32-byte sectors per record)
+#endif
     // ids per bucket: the accumulate kernel keeps their moment records in the registers of its 1024 threads, TPI threads per id
     int shift = 0;
     while ((2 << shift) <= kAccumThreads / accum_tpi(L.nv)) ++shift;
@@ -475,7 +478,11 @@ void launch_scatter(dim3 g, hipStream_t st, const T* const* cols, int p, const P
 template <typename T, int PC>
 int launch_accum(pds_ctx* ctx, unsigned grid, const PartLayout& L, const char* records, const unsigned* bucket_start,
                  const unsigned* chunk_prefix, int64_t n_buckets, double* table) {
+#ifdef PDS_PART_RS_ALIGN32
+    constexpr int PPR = (((((((PC + 1) * (int)sizeof(T) + 7) & ~7) + 8 + 15) & ~15) + 31) & ~31) / 16;
+#else
     constexpr int PPR = ((((PC + 1) * (int)sizeof(T) + 7) & ~7) + 8 + 15) / 16;  // = make_layout<T>(PC).rs / 16
+#endif
     if (L.rs != PPR * 16) return fail(PDS_ERR_INVALID, "internal: record size");
     constexpr size_t lds = accum_lds_bytes(tri_count(PC + 2), PPR * 16);
     static_assert(lds <= (size_t)kPartLdsBytes / 2, "two workgroups share the CU's LDS");
