@@ -89,6 +89,21 @@ static bool keys_look_ordered(const int64_t* keys, int64_t n, const std::vector<
     return true;
 }
 
+// slice boundaries: about n / S rows each (at least kMinSliceRows: a slice costs a few launches and copies), moved forward to the next
+// key change so that no group is split; `stagger`: the first slice is half a slice
+constexpr int64_t kMinSliceRows = (int64_t)1 << 20;
+static std::vector<int64_t> slice_bounds(const int64_t* keys, int64_t n_rows, int S, bool stagger) {
+    std::vector<int64_t> bounds = {0};
+    for (int s = 1; s < S; ++s) {
+        int64_t c = stagger ? (int64_t)((double)n_rows * ((double)s - 0.5) / ((double)S - 0.5)) : n_rows / S * s + std::min<int64_t>(s, n_rows % S);
+        if (c <= bounds.back()) continue;
+        while (c < n_rows && keys[c] == keys[c - 1]) ++c;
+        if (c < n_rows && c > bounds.back()) bounds.push_back(c);
+    }
+    bounds.push_back(n_rows);
+    return bounds;
+}
+
 template <typename T>
 static int lr_by_key_multi_impl(pds_ctx* const* ctxs, int n_ctx, int n_slices, const T* const* cols, const int64_t* keys, int n_feat,
                                 int64_t n_rows, const pds_lr_params* prm, int64_t max_groups, int64_t* out_keys, T* coeffs,
@@ -103,18 +118,10 @@ static int lr_by_key_multi_impl(pds_ctx* const* ctxs, int n_ctx, int n_slices, c
         return lr_by_key_impl<T>(ctxs[0], cols, keys, n_feat, n_rows, PDS_HOST, prm, max_groups, out_keys, coeffs, is_null, n_groups);
     };
     // ---- slices: at least kMinSliceRows rows each (a slice costs a few launches and copies), cut at key changes
-    constexpr int64_t kMinSliceRows = (int64_t)1 << 20;
     int S = n_slices > 0 ? n_slices : 4 * n_ctx;
     S = (int)std::min<int64_t>(S, std::max<int64_t>(1, n_rows / kMinSliceRows));
     if (S <= 1 && n_ctx == 1) return single();
-    std::vector<int64_t> bounds = {0};
-    for (int s = 1; s < S; ++s) {
-        int64_t c = n_rows / S * s + std::min<int64_t>(s, n_rows % S);
-        if (c <= bounds.back()) continue;
-        while (c < n_rows && keys[c] == keys[c - 1]) ++c;
-        if (c < n_rows && c > bounds.back()) bounds.push_back(c);
-    }
-    bounds.push_back(n_rows);
+    const std::vector<int64_t> bounds = slice_bounds(keys, n_rows, S, false);
     S = (int)bounds.size() - 1;
     if (S <= 1 || !keys_look_ordered(keys, n_rows, bounds)) return single();
     const int nc = n_feat + 1, pp = n_feat + (prm->add_bias ? 1 : 0);
@@ -191,21 +198,13 @@ static int lr_by_key_pred_multi_impl(pds_ctx* const* ctxs, int n_ctx, int n_slic
         return lr_by_key_impl<T>(ctxs[0], cols, keys, n_feat, n_rows, PDS_HOST, prm, n_rows, nullptr, nullptr, nullptr, nullptr, weights, pred,
                                  resid, row_null);
     };
-    constexpr int64_t kMinSliceRows = (int64_t)1 << 20;
     int S = n_slices > 0 ? n_slices : 4 * n_ctx;
     S = (int)std::min<int64_t>(S, std::max<int64_t>(1, n_rows / kMinSliceRows));
     if (S <= 1) return single();
     // the first slice is HALF a slice: with equal slices the workers run in lockstep -- all of them uploading, then all of them
     // fitting and downloading -- and the predictions' way back (1.7 of 16 GB) never meets an upload; half a slice out of phase, one
     // worker's download runs under the other's upload (the link is full duplex: tools/pcie_duplex.py, 97 GB/s both ways at once)
-    std::vector<int64_t> bounds = {0};
-    for (int s = 1; s < S; ++s) {
-        int64_t c = (int64_t)((double)n_rows * ((double)s - 0.5) / ((double)S - 0.5));
-        if (c <= bounds.back()) continue;
-        while (c < n_rows && keys[c] == keys[c - 1]) ++c;
-        if (c < n_rows && c > bounds.back()) bounds.push_back(c);
-    }
-    bounds.push_back(n_rows);
+    const std::vector<int64_t> bounds = slice_bounds(keys, n_rows, S, true);
     S = (int)bounds.size() - 1;
     if (S <= 1 || !keys_look_ordered(keys, n_rows, bounds)) return single();
     const int nc = n_feat + 1;

@@ -76,7 +76,9 @@ PartLayout make_layout(int p) {
     // ids per bucket: the accumulate kernel keeps their moment records in the registers of its 1024 threads, TPI threads per id
     int shift = 0;
     while ((2 << shift) <= kAccumThreads / accum_tpi(L.nv)) ++shift;
-    if (const char* e = std::getenv("PDS_PART_SHIFT")) shift = std::atoi(e);  // (scatter timing experiments: the accumulate launch then refuses)
+#ifdef PDS_DEV_SWITCHES  // (development builds only: EXTRA=-DPDS_DEV_SWITCHES; the accumulate launch refuses a foreign bucket width)
+    if (const char* e = std::getenv("PDS_PART_SHIFT")) shift = std::atoi(e);
+#endif
     L.shift = shift;
     return L;
 }
@@ -489,7 +491,11 @@ int launch_accum(pds_ctx* ctx, unsigned grid, const PartLayout& L, const char* r
     if ((1 << L.shift) != kAccumThreads / accum_tpi(tri_count(PC + 2))) return fail(PDS_ERR_INVALID, "internal: ids per bucket");
     auto kern = part_accum_kernel<T, PC, PPR>;
     if (lds > 64 * 1024) PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const char* dbg = std::getenv("PDS_PART_DEBUG");  // timing experiments only: the results are wrong with it
+#ifdef PDS_DEV_SWITCHES  // timing experiments of development builds (EXTRA=-DPDS_DEV_SWITCHES): the results are wrong with it
+    const char* dbg = std::getenv("PDS_PART_DEBUG");
+#else
+    const char* dbg = nullptr;
+#endif
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kAccumThreads), lds, ctx->stream, records, bucket_start, chunk_prefix, n_buckets, L.meta_off, table,
                        dbg ? std::atoi(dbg) : 0);
     PDS_HIP_CHECK(hipGetLastError());

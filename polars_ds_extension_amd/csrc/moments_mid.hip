@@ -684,7 +684,11 @@ int launch_grouped_stream(pds_ctx* ctx, const DeviceCols<double>& dc, int p, int
     // the sum of two partial records does not depend on their order -- results are reproducible run to run but for such giant groups
     // (the row count of the chunk is not known on the host: the frame's is an upper bound)
     const int64_t waves = std::min<int64_t>((int64_t)ctx->num_cus * kMidWavesPerCu, std::max<int64_t>(1, n_frame / (8 * MD::HR)));
-    const char* dbg = std::getenv("PDS_GMID_DEBUG");  // (timing experiments only: wrong results)
+#ifdef PDS_DEV_SWITCHES  // timing experiments of development builds (EXTRA=-DPDS_DEV_SWITCHES): wrong results with it
+    const char* dbg = std::getenv("PDS_GMID_DEBUG");
+#else
+    const char* dbg = nullptr;
+#endif
     hipLaunchKernelGGL(kern, dim3((unsigned)waves), dim3(64), MD::LDS_BYTES, ctx->stream, dc.d_ptrs, p, n_frame, d_off, n_groups, d_records,
                        dbg ? std::atoi(dbg) : 0);
     PDS_HIP_CHECK(hipGetLastError());
