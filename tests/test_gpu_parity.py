@@ -709,6 +709,37 @@ def test_by_key_partition_route_against_oracle(pds, orc, p, bias, kw):
         assert np.max(np.abs(ph[live] - pr[live]) / scale) < 1e-9 and np.max(np.abs(rh[live] - rs[live]) / np.maximum(scale, np.abs(yp[live]))) < 1e-9
 
 
+def test_by_key_partition_route_unaligned_keys_and_negative_base(pds, orc):
+    """The partition route's bucket histogram rides on the order check only for a 16-byte aligned key buffer; an 8-byte aligned one
+    takes the separate histogram pass.  Both must give the same groups -- also with negative keys, where the dense ids start at the
+    smallest key rounded DOWN to a bucket boundary."""
+    import torch
+
+    rng = np.random.default_rng(515)
+    G, p = 1800, 3
+    sizes = rng.integers(20, 70, size=G)
+    keys_g = (rng.permutation(G) * 2 - 2501).astype(np.int64)   # negative and positive, every second id unused
+    key = np.repeat(keys_g, sizes)
+    N = len(key)
+    assert N >= 1 << 16
+    X = rng.normal(size=(N, p))
+    y = X @ rng.normal(size=p) + 1e-3 * key + 0.1 * rng.normal(size=N)
+    perm = rng.permutation(N)
+    kp, Xp, yp = key[perm], X[perm], y[perm]
+    kbuf = torch.from_numpy(np.concatenate([[0], kp])).cuda()
+    k_al = torch.from_numpy(kp).cuda()
+    assert kbuf[1:].data_ptr() % 16 == 8 and k_al.data_ptr() % 16 == 0
+    k1, c1, n1 = pds.lin_reg_by_key(*cols_of(Xp), target=dev(yp), key=k_al, add_bias=True)
+    k2, c2, n2 = pds.lin_reg_by_key(*cols_of(Xp), target=dev(yp), key=kbuf[1:], add_bias=True)
+    assert torch.equal(k1, k2) and torch.equal(n1, n2) and np.array_equal(k1.cpu().numpy(), np.sort(keys_g))
+    assert float(torch.max(torch.linalg.norm(c1 - c2, dim=1) / torch.linalg.norm(c1, dim=1))) < 1e-10
+    order = np.argsort(key, kind="stable")
+    off = np.concatenate([[0], np.cumsum(np.unique(key, return_counts=True)[1])]).astype(np.int64)
+    co_o, nu_o = orc.grouped_lr([y[order]] + [X[order][:, j] for j in range(p)], off, add_bias=True, nthreads=2)
+    assert not nu_o.any() and not n1.any().item()
+    assert np.max(np.linalg.norm(c1.cpu().numpy() - co_o, axis=1) / np.linalg.norm(co_o, axis=1)) < 1e-9
+
+
 def test_by_key_partition_route_f32_and_giant_group(pds, orc, f32):
     """f32 frames (moments in f64 LDS accumulators) and a skewed frame: one key holds half of the rows, so its bucket is fitted by
     many accumulate workgroups that meet in the table through global atomics."""
