@@ -189,7 +189,8 @@ size_t moments_wide_workspace(int num_cus, int n_feat, int64_t n_rows, bool weig
 // moments_mid.hip: 17 .. 64 f64 features -- the streaming kernel (several 16-feature tile columns); its per-wave
 // partial records come out of ctx->ws like the wide kernel's (moments_wide_workspace() covers them)
 size_t moments_mid_workspace(int num_cus);
-int launch_moments_mid(pds_ctx* ctx, const DeviceCols<double>& dc, int n_feat, int64_t n_rows, bool weighted, double* d_moments);
+template <typename T>
+int launch_moments_mid(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, bool weighted, T* d_moments);
 
 // segmented (per-group) moments: d_moments [n_groups][(p+2)^2].  d_group_index (p <= 16 only): record g belongs to group
 // d_group_index[g] of the offsets array instead of group g.

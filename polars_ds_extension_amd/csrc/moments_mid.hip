@@ -31,14 +31,14 @@ constexpr int kMidWavesPerCu = 4;
 // ~90 clk of the wave's time per global_load_lds whatever it moves.)  The LDS image keeps an instruction's 1 KiB together: column
 // (b, i) of the half-tile sits at i * GS + b * HR * 8, GS = 1024 + 16.  The operand fetch of block b reads 16 consecutive i at one b:
 // bank = (4 i + 2 row) mod 64 -- distinct within a half-wave.
-template <int NBLK>
+template <int NBLK, int ES = 8 /* element bytes: f64 frames; 4 = f32 frames, widened to f64 on their way out of LDS */>
 struct MidDims {
-    static constexpr int HR = 128 / NBLK;                      // rows per half-tile
+    static constexpr int HR = 1024 / (NBLK * ES);              // rows per half-tile (128 / NBLK at f64, 256 / NBLK at f32)
     static constexpr int GL = 64 / NBLK;                       // lanes per lane group = 16-byte pieces per column
     static constexpr int GS = 1024 + 16;                       // bytes between the images of instructions i and i + 1
-    static constexpr int Y_OFF = 16 * GS;                      // the target column's image (HR * 8 bytes)
-    static constexpr int W_OFF = 16 * GS + HR * 8 + 16;        // the weight column's image (weighted form)
-    static constexpr int HALF_BYTES = 16 * GS + 2 * (HR * 8 + 16) + 16;
+    static constexpr int Y_OFF = 16 * GS;                      // the target column's image (HR * ES bytes)
+    static constexpr int W_OFF = 16 * GS + HR * ES + 16;       // the weight column's image (weighted form)
+    static constexpr int HALF_BYTES = 16 * GS + 2 * (HR * ES + 16) + 16;
     static constexpr int NBUF = 2;
     static constexpr int LDS_BYTES = NBUF * HALF_BYTES;
     static constexpr int NS = HR / 4;                          // 4-row steps per half-tile
@@ -73,11 +73,13 @@ __device__ constexpr int mid_lev_block(int ablk, int kstep) {
 // (FUSE = 2: HC2 / HC3, h_r = ||L' z_r||^2 on the matrix cores as in leverage_mid.hip) -- written to the weight column's LDS image and
 // consumed by the weighted Gram steps: the record is the meat X' diag(s) X, sum e^2 rides along, and neither the residuals nor the
 // n-row weight vector ever exist in memory.
-template <int NBLK, bool WEIGHTED, int FUSE>
-__global__ __launch_bounds__(FUSE ? 256 : 64) void moments_mid_kernel(const double* const* __restrict__ cols, int p, int64_t n,
+template <int NBLK, bool WEIGHTED, int FUSE, typename T = double>
+__global__ __launch_bounds__(FUSE ? 256 : 64) void moments_mid_kernel(const T* const* __restrict__ cols, int p, int64_t n,
                                                                       double* __restrict__ partials, int bias, const double* __restrict__ beta,
                                                                       const double* __restrict__ lop, int hc) {
-    using MD = MidDims<NBLK>;
+    constexpr int ES = (int)sizeof(T), EPL = 16 / ES;  // element bytes; elements per 16-byte lane piece
+    static_assert(FUSE == 0 || ES == 8, "the fused report form is the f64 kernel's");
+    using MD = MidDims<NBLK, ES>;
     using MS = MidShared<NBLK, FUSE>;
     constexpr int HR = MD::HR, GS = MD::GS, NPAIR = MD::NPAIR, NS = MD::NS;
     constexpr bool WT = WEIGHTED || FUSE != 0;      // the Gram steps read a weight image
@@ -105,16 +107,16 @@ __global__ __launch_bounds__(FUSE ? 256 : 64) void moments_mid_kernel(const doub
     // ---- the lane's 16 column pointers (column 16 g + i, g = its lane group), already advanced to its two rows of a half-tile;
     // `valid` bit i: that column exists (the others keep the zeros both images start with)
     const int g = lane / MD::GL, piece = lane % MD::GL;
-    const double* cbase[16];
+    const T* cbase[16];
     unsigned valid = 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int c = 16 * g + i;
-        cbase[i] = cols[c < p ? c : p] + 2 * piece;
+        cbase[i] = cols[c < p ? c : p] + EPL * piece;
         if (c < p) valid |= 1u << i;
     }
-    const double* ybase = cols[p] + 2 * lane;  // (lanes 0 .. HR / 2 - 1)
-    const double* wbase = WLOAD ? cols[p + 1] + 2 * lane : ybase;
+    const T* ybase = cols[p] + EPL * lane;  // (lanes 0 .. GL - 1)
+    const T* wbase = WLOAD ? cols[p + 1] + EPL * lane : ybase;
     for (int i = lane * 16; i < MD::LDS_BYTES; i += 64 * 16) *(__attribute__((address_space(3))) mid_d2*)(sm + i) = mid_d2{0.0, 0.0};
     static_assert(MD::LDS_BYTES % 16 == 0 && MS::BYTES % 16 == 0, "zeroed in 16-byte pieces");
     if constexpr (FUSE != 0) __syncthreads();  // (the only workgroup barrier: every wave reaches it)
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(FUSE ? 256 : 64) void moments_mid_kernel(const doub
         if (i < 16) {
             if ((valid >> i) & 1u)
                 __builtin_amdgcn_global_load_lds((glb_ptr)(as_global(cbase[i]) + row0), (lds_ptr)(sm + buf * MD::HALF_BYTES + i * GS), 16, 0, 0);
-        } else if (lane < HR / 2) {
+        } else if (lane < MD::GL) {
             __builtin_amdgcn_global_load_lds((glb_ptr)(as_global(ybase) + row0), (lds_ptr)(sm + buf * MD::HALF_BYTES + MD::Y_OFF), 16, 0, 0);
             if constexpr (WLOAD)
                 __builtin_amdgcn_global_load_lds((glb_ptr)(as_global(wbase) + row0), (lds_ptr)(sm + buf * MD::HALF_BYTES + MD::W_OFF), 16, 0, 0);
@@ -137,10 +139,10 @@ __global__ __launch_bounds__(FUSE ? 256 : 64) void moments_mid_kernel(const doub
     // guarded form for the ragged tail: zero rows beyond `rows`
     auto load_tail = [&](int buf, int64_t row0, int rows) __attribute__((always_inline)) {
         for (int c = 0; c <= p + (WLOAD ? 1 : 0); ++c) {
-            const int off = c < p ? (c % 16) * GS + (c / 16) * HR * 8 : (c == p ? MD::Y_OFF : MD::W_OFF);
-            const gptr<double> col = as_global(cols[c]);
+            const int off = c < p ? (c % 16) * GS + (c / 16) * HR * ES : (c == p ? MD::Y_OFF : MD::W_OFF);
+            const gptr<T> col = as_global(cols[c]);
             for (int r = lane; r < HR; r += 64)
-                *(__attribute__((address_space(3))) double*)(sm + buf * MD::HALF_BYTES + off + r * 8) = r < rows ? col[row0 + r] : 0.0;
+                *(__attribute__((address_space(3))) T*)(sm + buf * MD::HALF_BYTES + off + r * ES) = r < rows ? col[row0 + r] : T(0);
         }
     };
     d4 acc[NPAIR];
@@ -224,11 +226,13 @@ __global__ __launch_bounds__(FUSE ? 256 : 64) void moments_mid_kernel(const doub
     auto consume = [&](int buf, bool next, int64_t next_row0) __attribute__((always_inline)) {
         const lds_c base = sm + buf * MD::HALF_BYTES;
         auto fetch = [&](int s, double (&a)[NBLK], double& yk, double& wk) __attribute__((always_inline)) {
-            const int roff = (4 * s + fk) * 8;
+            const int roff = (4 * s + fk) * ES;
 #pragma unroll
-            for (int b = 0; b < NBLK; ++b) a[b] = *(const __attribute__((address_space(3))) double*)(base + fi * GS + b * HR * 8 + roff);
-            yk = *(const __attribute__((address_space(3))) double*)(base + MD::Y_OFF + roff);
-            if constexpr (WT) wk = *(const __attribute__((address_space(3))) double*)(base + MD::W_OFF + roff);
+            for (int b = 0; b < NBLK; ++b) a[b] = (double)*(const __attribute__((address_space(3))) T*)(base + fi * GS + b * HR * ES + roff);
+            yk = (double)*(const __attribute__((address_space(3))) T*)(base + MD::Y_OFF + roff);
+            // (FUSE: the weight image is made in the kernel, in f64 -- and FUSE is the f64 kernel's)
+            if constexpr (WT) wk = FUSE ? *(const __attribute__((address_space(3))) double*)(base + MD::W_OFF + roff)
+                                        : (double)*(const __attribute__((address_space(3))) T*)(base + MD::W_OFF + roff);
         };
         // operands of step s + 1 are fetched from LDS before step s multiplies (one wave per SIMD: nobody else hides the round trip)
         double a[NBLK], yk, wk = 1.0;
@@ -326,9 +330,9 @@ __global__ __launch_bounds__(256) void moments_mid_reduce_kernel(const double* _
 }
 
 // one thread per entry (i <= j) of the (p+2)^2 moment matrix over [x_0 .. x_{p-1}, 1, y]: fixed-order sum over the waves
-template <int NBLK>
+template <int NBLK, typename T = double>
 __global__ __launch_bounds__(256) void moments_mid_finalize_kernel(const double* __restrict__ partials, int nwaves, int p, int64_t n, int weighted,
-                                                                   double* __restrict__ out, double* __restrict__ sums /* nullable: [sum e^2, 0] */) {
+                                                                   T* __restrict__ out, double* __restrict__ sums /* nullable: [sum e^2, 0] */) {
     using MD = MidDims<NBLK>;
     const int q = p + 2;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -380,18 +384,18 @@ __global__ __launch_bounds__(256) void moments_mid_finalize_kernel(const double*
             s += (v[0] + v[16]) + (v[32] + v[48]);
         }
     }
-    out[e] = s;
+    out[e] = (T)s;
 }
 
-template <int NBLK, bool WEIGHTED, int FUSE>
-int launch_mid(pds_ctx* ctx, const DeviceCols<double>& dc, int p, int64_t n, double* d_moments, int bias = 0, const double* d_beta = nullptr,
+template <int NBLK, bool WEIGHTED, int FUSE, typename T = double>
+int launch_mid(pds_ctx* ctx, const DeviceCols<T>& dc, int p, int64_t n, T* d_moments, int bias = 0, const double* d_beta = nullptr,
                const double* d_lop = nullptr, int hc = 0, double* d_sums = nullptr) {
-    using MD = MidDims<NBLK>;
+    using MD = MidDims<NBLK, (int)sizeof(T)>;
     using MS = MidShared<NBLK, FUSE>;
     const int nwaves = ctx->num_cus * kMidWavesPerCu;
     double* partials = reinterpret_cast<double*>(ws_take(ctx, (size_t)(nwaves + 1) * MD::REC * sizeof(double)));
     if (!partials) return fail(PDS_ERR_HIP, "workspace allocation failed");
-    auto kern = moments_mid_kernel<NBLK, WEIGHTED, FUSE>;
+    auto kern = moments_mid_kernel<NBLK, WEIGHTED, FUSE, T>;
     constexpr int lds = MS::BYTES + MS::WPB * MD::LDS_BYTES;
     static_assert(lds <= 160 * 1024, "one workgroup per CU at most");
     if (lds > 64 * 1024) PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -400,7 +404,7 @@ int launch_mid(pds_ctx* ctx, const DeviceCols<double>& dc, int p, int64_t n, dou
     const int q = p + 2;
     double* reduced = partials + (size_t)nwaves * MD::REC;
     hipLaunchKernelGGL(moments_mid_reduce_kernel, dim3((MD::REC + 63) / 64), dim3(256), 0, ctx->stream, (const double*)partials, nwaves, MD::REC, reduced);
-    hipLaunchKernelGGL((moments_mid_finalize_kernel<NBLK>), dim3((q * q + 255) / 256), dim3(256), 0, ctx->stream, (const double*)reduced, 1, p, n,
+    hipLaunchKernelGGL((moments_mid_finalize_kernel<NBLK, T>), dim3((q * q + 255) / 256), dim3(256), 0, ctx->stream, (const double*)reduced, 1, p, n,
                        (WEIGHTED || FUSE) ? 1 : 0, d_moments, d_sums);
     PDS_HIP_CHECK(hipGetLastError());
     return PDS_OK;
@@ -699,12 +703,19 @@ int launch_grouped_stream(pds_ctx* ctx, const DeviceCols<double>& dc, int p, int
 
 size_t moments_mid_workspace(int num_cus) { return (size_t)(num_cus * kMidWavesPerCu + 1) * MidDims<4>::REC * sizeof(double) + 4096; }
 
-// 17 .. 64 f64 features (weights: table entry p + 1): d_moments = (p+2)^2 column-major over [x_0 .. x_{p-1}, 1, y]
-int launch_moments_mid(pds_ctx* ctx, const DeviceCols<double>& dc, int n_feat, int64_t n_rows, bool weighted, double* d_moments) {
-    if (n_feat <= 32) return weighted ? launch_mid<2, true, 0>(ctx, dc, n_feat, n_rows, d_moments) : launch_mid<2, false, 0>(ctx, dc, n_feat, n_rows, d_moments);
-    if (n_feat <= 64) return weighted ? launch_mid<4, true, 0>(ctx, dc, n_feat, n_rows, d_moments) : launch_mid<4, false, 0>(ctx, dc, n_feat, n_rows, d_moments);
+// 17 .. 64 features (weights: table entry p + 1): d_moments = (p+2)^2 column-major over [x_0 .. x_{p-1}, 1, y].  f32 frames: the
+// values are widened on their way out of LDS -- exact f32 products, f64 sums on the f64 matrix instruction -- and the record is
+// rounded to f32 once at the end.
+template <typename T>
+int launch_moments_mid(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, bool weighted, T* d_moments) {
+    if (n_feat <= 32)
+        return weighted ? launch_mid<2, true, 0, T>(ctx, dc, n_feat, n_rows, d_moments) : launch_mid<2, false, 0, T>(ctx, dc, n_feat, n_rows, d_moments);
+    if (n_feat <= 64)
+        return weighted ? launch_mid<4, true, 0, T>(ctx, dc, n_feat, n_rows, d_moments) : launch_mid<4, false, 0, T>(ctx, dc, n_feat, n_rows, d_moments);
     return fail(PDS_ERR_UNSUPPORTED, "moments_mid: up to 64 features");
 }
+template int launch_moments_mid<double>(pds_ctx*, const DeviceCols<double>&, int, int64_t, bool, double*);
+template int launch_moments_mid<float>(pds_ctx*, const DeviceCols<float>&, int, int64_t, bool, float*);
 
 // The second pass of an UNWEIGHTED report with robust errors, 17 .. 64 f64 features, as one stream: d_sums = [sum e^2, 0] and
 // d_meat = the (p+2)^2 moment layout of X' diag(s) X, s = e^2 (hc_mode 1) or e^2 / (1 - h)^(hc_mode - 1) (2, 3; d_inv = (X'X)^-1).

@@ -940,10 +940,10 @@ static int launch_moments_wide_w(pds_ctx* ctx, const DeviceCols<T>& dc, int n_fe
 
 template <typename T>
 int launch_moments_wide(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, bool weighted, T* d_moments) {
-    if constexpr (sizeof(T) == 8) {
-        // 17 .. 64 f64 features: the streaming kernel of moments_mid.hip (PDS_MID_GRAM=0 keeps the compact tile forms: A/B)
+    {
+        // 17 .. 64 features: the streaming kernel of moments_mid.hip, both precisions (PDS_MID_GRAM=0 keeps the compact tile forms: A/B)
         const char* e = std::getenv("PDS_MID_GRAM");
-        if (n_feat <= 64 && !(e && e[0] == '0')) return launch_moments_mid(ctx, dc, n_feat, n_rows, weighted, d_moments);
+        if (n_feat <= 64 && !(e && e[0] == '0')) return launch_moments_mid<T>(ctx, dc, n_feat, n_rows, weighted, d_moments);
     }
     if constexpr (sizeof(T) == 4) {
         // f32: products on the bf16 matrix cores as three-plane splits (2.7x the f32 matrix-core rate at f32 accuracy);

@@ -129,6 +129,33 @@ def test_moments_f32(pds, orc, f32):
     assert nrel(M, Z.T @ Z) < 2e-7  # f32 matrix-core tiles folded into f64 every 256 rows
 
 
+@pytest.mark.parametrize("n,p", [(100_003, 17), (50_001, 32), (31, 40), (257, 48), (300_007, 64)])
+def test_moments_mid_width_f32(pds, orc, f32, n, p):
+    """17 .. 64 f32 features on the streaming kernel: the f32 values are widened on their way out of LDS (exact products, f64 sums on
+    the f64 matrix instruction) and the record is rounded to f32 once -- one f32 rounding away from the f64 truth of the f32 frame;
+    weights; ragged row counts; columns that start 4 bytes into a 16-byte unit."""
+    rng = np.random.default_rng(n + 11 * p)
+    X, y, _ = make_xy(rng, n, p)
+    X32, y32 = X.astype(np.float32), y.astype(np.float32)
+    Z = np.c_[X32.astype(np.float64), np.ones(n), y32.astype(np.float64)]
+    M = pds.gram_moments(*cols_of(X32), target=dev(y32))
+    assert M.dtype == np.float32 and nrel(M, Z.T @ Z) < 1.2e-7
+    assert np.array_equal(M, pds.gram_moments(*cols_of(X32), target=dev(y32)))
+    w32 = (rng.random(n) + 0.5).astype(np.float32)
+    Mw = pds.gram_moments(*cols_of(X32), target=dev(y32), weights=dev(w32))
+    assert nrel(Mw, Z.T @ (Z * w32.astype(np.float64)[:, None])) < 1.2e-7
+    if n > 4:
+        full = dev(np.ascontiguousarray(np.c_[X32, y32].T))
+        M2 = pds.gram_moments(*[full[j, 1:] for j in range(p)], target=full[p, 1:])
+        assert nrel(M2, Z[1:].T @ Z[1:]) < 1.2e-7
+    # the fit on top of it (rank gate off: make_xy's columns are correlated enough for the f32 default gate): the f32 contract
+    # against the f64 truth of the same f32 frame
+    if n > 4 * p:
+        b = pds.lin_reg(*cols_of(X32), target=dev(y32), add_bias=True, singular_x_tol=0.0)
+        bt = orc.pl_lr(X32.astype(np.float64), y32.astype(np.float64), add_bias=True, singular_x_tol=0.0)
+        assert nrel(b, bt) < F32_TOL
+
+
 # ------------------------------------------------------------------------------------------ pl_lr dispatch
 @pytest.mark.parametrize("bias", [False, True])
 @pytest.mark.parametrize(
