@@ -937,6 +937,29 @@ def test_by_key_order_check_sees_every_inversion(pds):
         assert torch.equal(k_out, base[shift:])
 
 
+@pytest.mark.parametrize("p,bias", [(24, True), (40, False), (64, True)])
+def test_grouped_mid_width_f32(pds, orc, f32, p, bias):
+    """f32 frames, 17 .. 64 features per group: f32 Gram records (f64 sums behind f32 products), the wave-per-system solver in f64 on
+    them -- the f32 contract (1e-4 normwise) against the f64 truth of the same f32 frame; too-small groups null."""
+    rng = np.random.default_rng(777 + p)
+    G = 150
+    pp = p + int(bias)
+    sizes = rng.integers(6 * pp, 10 * pp, size=G)
+    sizes[::31] = rng.integers(1, pp, size=len(sizes[::31]))
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    N = int(off[-1])
+    X = rng.normal(size=(N, p)).astype(np.float32)
+    y = (X.astype(np.float64) @ rng.normal(size=p) + (0.5 if bias else 0.0) + 0.2 * rng.normal(size=N)).astype(np.float32)
+    co, nu = pds.lin_reg_by(*cols_of(X), target=dev(y), group_offsets=off, add_bias=bias, singular_x_tol=1e-10)
+    assert co.dtype.is_floating_point and co.element_size() == 4
+    co, nu = co.cpu().numpy().astype(np.float64), nu.cpu().numpy().astype(bool)
+    X64, y64 = X.astype(np.float64), y.astype(np.float64)
+    co_t, nu_t = orc.grouped_lr([y64] + [X64[:, j] for j in range(p)], off, add_bias=bias, tol=1e-10, nthreads=2)
+    assert np.array_equal(nu, nu_t) and nu.sum() >= 4
+    ok = ~nu
+    assert np.max(np.linalg.norm(co[ok] - co_t[ok], axis=1) / np.linalg.norm(co_t[ok], axis=1)) < F32_TOL
+
+
 @pytest.mark.parametrize("p", [28, 40, 64])
 def test_grouped_stream_record_edges(pds, orc, p):
     """The streamed Gram records of 28 .. 64 features (moments_mid.hip grouped_mid_stream_kernel): a group that spans many waves (its
