@@ -18,7 +18,7 @@ def note(k, e):
     worst[k] = max(worst.get(k, 0.0), e)
 
 while time.time() < t_end:
-    kind = rng.choice(["lr", "lr", "report", "rolling", "recursive", "keyed", "weighted", "multi", "grouped"])
+    kind = rng.choice(["lr", "lr", "report", "rolling", "recursive", "keyed", "weighted", "multi", "grouped", "f32"])
     if kind in ("lr", "weighted", "multi"):
         p = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 17, 24, 40, 70]))
         n = int(rng.integers(max(3 * p, 40), 60_000))
@@ -58,6 +58,23 @@ while time.time() < t_end:
         e = nrel(b, bo)
         note("lr/" + method, e)
         assert e < (1e-7 if method in ("lasso", "enet", "nnls") else 1e-9), (method, p, n, bias, e)
+    elif kind == "f32":
+        # f32 frames (LIN_REG_EXPR_F64 = False): single fits and Gram records at every width class, against the f64 truth of the f32 frame
+        p = int(rng.choice([3, 8, 16, 17, 24, 32, 33, 48, 64, 80]))
+        n = int(rng.integers(max(6 * p, 100), 120_000))
+        bias = bool(rng.integers(0, 2))
+        X = rng.normal(size=(n, p)).astype(np.float32)
+        y = (X.astype(np.float64) @ rng.normal(size=p) + 0.3 + 0.1 * rng.normal(size=n)).astype(np.float32)
+        pds.config.LIN_REG_EXPR_F64 = False
+        try:
+            M = pds.gram_moments(*[dev(X[:, j]) for j in range(p)], target=dev(y))
+            b = pds.lin_reg(*[dev(X[:, j]) for j in range(p)], target=dev(y), add_bias=bias, singular_x_tol=0.0)
+        finally:
+            pds.config.LIN_REG_EXPR_F64 = True
+        Z = np.c_[X.astype(np.float64), np.ones(n), y.astype(np.float64)]
+        note("f32/gram", nrel(M, Z.T @ Z))
+        note("f32/lin_reg", nrel(b, orc.pl_lr(X.astype(np.float64), y.astype(np.float64), add_bias=bias, singular_x_tol=0.0)))
+        assert worst["f32/gram"] < 1e-6 and worst["f32/lin_reg"] < 1e-4, (p, n, bias, worst["f32/gram"], worst["f32/lin_reg"])
     elif kind == "grouped":
         # contiguous groups, 1 .. 64 features (17 .. 64: one wave per system in registers + the pivoted-QR pass over what it marks)
         p = int(rng.choice([2, 9, 16, 17, 20, 31, 32, 33, 47, 48, 63, 64]))
