@@ -6,23 +6,27 @@
 // fit does not need its rows in order, or even adjacent: it needs their MOMENTS.  So, for integer keys whose range is not
 // much wider than the frame is long (group ids: the usual case; anything else keeps the sorting route):
 //
-//   1. histogram   dense id = key - min; bucket = id >> shift, a bucket = the 2^shift ids whose moment records fit LDS
-//                  together; rows counted per (bucket, stream), stream = the XCD a block runs on (its index mod 8);
+//   1. histogram   dense id = key - base (base: the smallest key rounded down to a bucket boundary); bucket = id >> shift, a bucket =
+//                  the 2^shift ids whose moment records the accumulate kernel holds in its registers; rows counted per (bucket,
+//                  stream), stream = the XCD a block runs on (its index mod 8).  Normally taken along by the order check of keyed.hip
+//                  (same buckets: key >> shift); part_hist_kernel is the separate pass for key buffers that are not 16-byte aligned
+//                  or ranges beyond kKeySlots buckets;
 //   2. scatter     ONE pass over the frame: every row becomes a record [x_0 .. x_{p-1}, y | id in bucket, row] appended to its
 //                  (bucket, stream) region.  A region is written front to back by the blocks of one XCD only, so its open
-//                  cache line sits in that XCD's L2 until it is full: the 4096-way scatter leaves the chip as whole lines.
-//                  A wave stages its 64 records in LDS and writes them piece-cooperatively (the lanes that share a record
-//                  write its 16-byte pieces side by side);
-//   3. accumulate  a workgroup streams (a chunk of) one bucket's records and adds every row's outer product z z',
-//                  z = [x, 1, y], to that id's moment record in LDS (ds_add_f64: hardware atomics, conflict-free banks by an
-//                  odd record stride), then adds the non-empty records to the id-indexed table in HBM (global_atomic_add_f64);
+//                  cache line sits in that XCD's L2 until it is full.  A wave stages its 64 records in LDS and writes them
+//                  piece-cooperatively (the lanes that share a record write its 16-byte pieces side by side);
+//   3. accumulate  a workgroup streams (a chunk of) one bucket's records in tiles, counting-sorts each tile by id in LDS and lets
+//                  the thread(s) that own an id walk that id's records: the moment records (upper triangles of z z', z = [x, 1, y])
+//                  live in registers; they go to the id-indexed table in HBM through LDS -- plain stores when the bucket has one
+//                  chunk (the usual case: its rows of the table need no memset), atomics where several chunks meet;
 //   4. compact     ids with rows -> groups in ascending key order: distinct keys, sizes, offsets;
-//   5. solve       chunks of groups: the table's upper triangles expanded to the (p+2)^2 records the batched solvers take
-//                  (solve.hip / solve_reg.hip: the reference's pivoted QR with the log-det gate by default) -> coefficients.
+//   5. solve       the register solver of solve_reg.hip reads the table's packed triangles through the id list (OLS / ridge); the
+//                  other methods take chunks of triangles expanded to (p+2)^2 records (part_expand_kernel).
+//   Per-row predictions (grouped_pred.hip MODE 2) look a row's group up as rank[key - base]: nothing is ever permuted.
 //
-// Traffic: keys once more (histogram), the frame once (scatter in), records out and in: ~3.4x the frame instead of ~5x plus a
-// random-access pass.  Summation order inside a group follows the arrival of the atomics: results agree with the sorting route
-// to rounding (tests hold both to 1e-10 against the oracle), not bit for bit, and not run to run.
+// Traffic: the frame once (scatter in), records out and in: 3.9x the frame by the PMC counters (profiles/r03_keyed_traffic.json)
+// instead of ~5x plus a random-access pass.  Records arrive in their regions in the order of the scatter's cursor atomics: results
+// agree with the sorting route to rounding (tests hold both to 1e-10 against the oracle), not bit for bit, and not run to run.
 #include <hipcub/hipcub.hpp>
 #include <type_traits>
 

@@ -663,7 +663,7 @@ def test_by_key_multi_context_equals_single_context(pds, orc, n_ctx, n_slices):
                                         (11, False, {}), (16, True, {}), (6, True, {"positive": True})])
 def test_by_key_partition_route_against_oracle(pds, orc, p, bias, kw):
     """Shuffled rows, dense integer keys, >= 2^16 rows: the partition route (keyed_partition.hip -- no sort of the rows: bucketed
-    records, moments by LDS atomics, batched solve) against the oracle per group; sparse key values (every third id unused),
+    records, moments in the accumulate kernel's registers, batched solve) against the oracle per group; sparse key values (every third id unused),
     too-small and collinear groups; and against the sorting route (PDS_KEYED_SORT is read once per process, so the sorted
     call is made on the frame in key order, which moves nothing)."""
     rng = np.random.default_rng(700 + p)
@@ -768,7 +768,7 @@ def test_by_key_partition_route_unaligned_keys_and_negative_base(pds, orc):
 
 
 def test_by_key_partition_route_f32_and_giant_group(pds, orc, f32):
-    """f32 frames (moments in f64 LDS accumulators) and a skewed frame: one key holds half of the rows, so its bucket is fitted by
+    """f32 frames (moments in f64 register accumulators) and a skewed frame: one key holds half of the rows, so its bucket is fitted by
     many accumulate workgroups that meet in the table through global atomics."""
     rng = np.random.default_rng(808)
     G, p = 900, 6
