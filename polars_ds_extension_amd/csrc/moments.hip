@@ -560,8 +560,9 @@ int launch_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_
 // NB = ceil(q / 16) blocks of 16 columns.  32 rows at a time are staged column-major in LDS (f32 frames are widened to
 // f64 on the way in), every 4-row step feeds the NB operand registers to the upper-triangular block pairs of
 // v_mfma_f64_16x16x4_f64 (<= 15 accumulator tiles = 120 VGPRs), and the finished group writes its full symmetric
-// (p+2)^2 moment record.  Two-kernel pipeline (record -> solve_kernel): at these widths a group's record is as large
-// as its rows, so nothing is gained by fusing; this path exists for coverage, the headline path is p <= 16.
+// (p+2)^2 moment record.  Two-kernel pipeline (record -> solve_wave.hip's register solver): at these widths a group's record is as
+// large as its rows, so nothing is gained by fusing.  f64 frames with 28 .. 64 features take the streamed form instead
+// (moments_mid.hip, grouped_mid_stream_kernel); this kernel serves 17 .. 27 features and f32 frames.
 // ---------------------------------------------------------------------------------------------
 constexpr int kMidRows = 32;
 constexpr int kMidStride = 34;  // doubles per LDS column: 68 dwords = 4 mod 64 -> conflict-free b64 operand reads
