@@ -472,6 +472,31 @@ def _end_to_end(torch, np, pds, dev, xs, y, G, R, P, cpu):
     return out
 
 
+def _mid_width(torch, np, pds, ctx, dev, wall):
+    """17 .. 64 features (between the two BASELINE widths): single-regression Gram / robust report on 2e7 x 32 f64, and the grouped fit
+    of 200 000 groups x 100 rows x 32 -- the streaming multi-tile-column kernels and the wave-per-system solver."""
+    n, p = 20_000_000, 32
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(5)
+    xs = [torch.randn(n, dtype=torch.float64, device=dev, generator=gen) for _ in range(p)]
+    y = sum(xs[j] * (0.05 * (j + 1)) for j in range(0, p, 5)) + torch.randn(n, dtype=torch.float64, device=dev, generator=gen)
+    gb = n * (p + 1) * 8 / 1e9
+    out = {"workload": f"{n:.0e} rows x {p} f64 features"}
+    ms = wall(lambda: pds.gram_moments(*xs, target=y, ctx=ctx))
+    out["gram_ms"] = round(ms, 3)
+    out["gram_frac_of_hbm_peak"] = round(gb / ms * 1e3 / HBM_PEAK_GBPS, 4)
+    for se in ("se", "hc3"):
+        out[f"report_{se}_ms"] = round(wall(lambda: pds.lin_reg_report(*xs, target=y, add_bias=True, std_err=se, ctx=ctx)), 3)
+    G, R = 200_000, 100
+    off = np.arange(0, G * R + 1, R, dtype=np.int64)
+    ms = wall(lambda: pds.lin_reg_by(*xs, target=y, group_offsets=off, ctx=ctx))
+    out["grouped_200000x100_ms"] = round(ms, 3)
+    out["grouped_regressions_per_s"] = round(G / ms * 1e3, 1)
+    del xs, y
+    torch.cuda.empty_cache()
+    return out
+
+
 def _other_configs(torch, pds, ctx, dev, xs, y, N, P, with_cpu=True):
     out = {}
 
@@ -517,6 +542,12 @@ def _other_configs(torch, pds, ctx, dev, xs, y, N, P, with_cpu=True):
         out["elastic_net_c5"] = _c5(torch, pds, ctx, dev)
     except Exception as e:
         out["elastic_net_c5"] = {"error": f"{type(e).__name__}: {e}"}
+    try:
+        import numpy as _np
+
+        out["mid_width"] = _mid_width(torch, _np, pds, ctx, dev, wall)
+    except Exception as e:
+        out["mid_width"] = {"error": f"{type(e).__name__}: {e}"}
     if with_cpu:  # the reference's rolling driver is one sequential Woodbury chain: single thread, bounded sample of the same frame
         import numpy as np
 
