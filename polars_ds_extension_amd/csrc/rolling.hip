@@ -69,6 +69,7 @@ struct RollArgs {
 
 }  // namespace pds
 #include "rolling_seg_dev.hpp"  // (needs RollArgs)
+#include "rolling_pair_dev.hpp"
 namespace pds {
 
 // fetch_row: raw z (PP entries, padding = 0, bias entry = 1) and y of row r (zeros when r is out of range) -- only
@@ -450,6 +451,21 @@ static int launch_pp_f(pds_ctx* ctx, const DeviceCols<T>& dc, RollArgs ra, bool 
     [[maybe_unused]] auto launch_seg = [&](auto mode_c, const double* tot) {
         if constexpr (PP <= 8) {
             constexpr int M = decltype(mode_c)::value;
+            // f64 frames whose p' is the even template width: two lanes per chain of rows, two waves per SIMD
+            // (rolling_pair_dev.hpp); PDS_ROLL_PAIR=0 keeps the lane = 4 rows kernel below (A/B)
+            if constexpr (std::is_same<T, double>::value && PP % 2 == 0 && FULLP != 0) {
+                static const bool pair_off = [] { const char* e = std::getenv("PDS_ROLL_PAIR"); return e && e[0] == '0'; }();
+                if (!pair_off) {
+                    using PD = PairDims<PP>;
+                    const int64_t ptiles = (ra.n + kPairTile - 1) / kPairTile;
+                    int per_cu_p = 8;
+                    if (const char* e = std::getenv("PDS_ROLL_PAIR_PER_CU")) per_cu_p = std::max(1, atoi(e));
+                    const int64_t pb = std::min<int64_t>(std::max<int64_t>((ptiles + 3) / 4, 1), (int64_t)ctx->num_cus * per_cu_p);
+                    hipLaunchKernelGGL((rolling_pair_kernel<PP, M, FULLP>), dim3((unsigned)pb), dim3(64), (size_t)PD::LDS_BYTES,
+                                       ctx->stream, dc.d_ptrs, ra, tot, d_coeffs, d_pred, d_valid);
+                    return;
+                }
+            }
             constexpr int64_t tile = M == 0 ? kSegTileRoll : kSegTile;
             const int64_t seg_tiles = (ra.n + tile - 1) / tile;
             const int64_t sb = std::min<int64_t>(std::max<int64_t>(seg_tiles, 1), (int64_t)ctx->num_cus * 4);
