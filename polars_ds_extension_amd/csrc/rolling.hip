@@ -452,9 +452,11 @@ static int launch_pp_f(pds_ctx* ctx, const DeviceCols<T>& dc, RollArgs ra, bool 
         if constexpr (PP <= 8) {
             constexpr int M = decltype(mode_c)::value;
             // f64 frames whose p' is the even template width: two lanes per chain of rows, two waves per SIMD
-            // (rolling_pair_dev.hpp); PDS_ROLL_PAIR=0 keeps the lane = 4 rows kernel below (A/B)
+            // (rolling_pair_dev.hpp).  OPT-IN (PDS_ROLL_PAIR=1, read per call): parity-green, but measured SLOWER than the lane = 4
+            // rows kernel below at C4 -- rolling 6.0 vs 3.9 ms, expanding main pass 3.7 vs 3.7 ms (profiles/r04_rolling_pair_ab.txt)
             if constexpr (std::is_same<T, double>::value && PP % 2 == 0 && FULLP != 0) {
-                static const bool pair_off = [] { const char* e = std::getenv("PDS_ROLL_PAIR"); return e && e[0] == '0'; }();
+                const char* pe = std::getenv("PDS_ROLL_PAIR");
+                const bool pair_off = !(pe && pe[0] == '1');
                 if (!pair_off) {
                     using PD = PairDims<PP>;
                     const int64_t ptiles = (ra.n + kPairTile - 1) / kPairTile;

@@ -131,6 +131,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             // every piece of the wave inside the frame: asynchronous 1 KiB bursts (global_load_lds_dwordx4)
 #pragma unroll
             for (int wh = 0; wh < NWHICH; ++wh) {
+#ifdef PDS_PAIR_EXP_NO_OLD_DMA
+                if (wh == 1) continue;  // (timing experiment: what the kernel would cost if the leaving rows were already in LDS)
+#endif
 #pragma unroll
                 for (int c = 0; c <= P_FEAT; ++c) {
                     const int slotc = c < P_FEAT ? c : PP;
@@ -206,6 +209,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         dst[NS - 1] = src[NS - 1] + dcnt;
     };
 
+#ifdef PDS_PROFILE_ROLLING
+    unsigned long long rprof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
     double P[NS], Q[NS];  // state after the odd / even rows of the chain (pass 2); pass 1: Q = the chain's own increments
     const int64_t round_tiles = (int64_t)gridDim.x * 4;
     for (int64_t tb = (int64_t)blockIdx.x * 4; tb < ntiles; tb += round_tiles) {
@@ -216,6 +223,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const bool tvalid = t0 < nrel;
         const int t1 = tvalid ? ((t0 + kPairTile < nrel) ? t0 + kPairTile : nrel) : 0;  // (no row of an absent tile counts)
         const int nst = ((nrel < kPairTile ? nrel : kPairTile) + kPairSub - 1) / kPairSub;  // stages of the round's longest tile
+        RT0();
         load_stage(0);
         // ---- anchor: every lane's half of the state in front of the tile
         if constexpr (MODE == 2) {
@@ -279,10 +287,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 P[k] = v;
             }
         }
+        RT1(0);  // anchor
         for (int st = 0; st < nst; ++st) {
             const int r0 = t0 + st * kPairSub + 4 * ch;  // first row of my chain (offset from rb)
+            RTA();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stage image has landed (the compiler does not order LDS reads behind global_load_lds)
             PDS_WAVE_LDS_SYNC();
+            RT1(1);  // waiting for the stage image
+            RTA();
             // ---- pass 1: the chain's own increments; which rows count.  A row that does not count (outside the tile, in front of
             // the frame, holding a non-finite value: OnlineLR::update lr_online_solvers.rs:85-89) is skipped by an exec-mask branch
             // around its accumulation and ZEROED IN THE IMAGE, so that pass 2 is branch free.
@@ -314,6 +326,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 }
             }
             PDS_WAVE_LDS_SYNC();  // (the zeroed rows are read back by pass 2, by both lanes of the pair)
+#ifdef PDS_PROFILE_ROLLING
+            asm volatile("" ::"v"(Q[0]), "v"(Q[NS - 1]));
+#endif
+            RT1(2);  // pass 1
+            RTA();
             // ---- rotate and scan over the 8 chains: P <- state in front of the chain's first row
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
@@ -324,6 +341,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 v += dpp_mov<0x118 /*row_shr:8*/>(0.0, v);
                 P[k] = v;
             }
+#ifdef PDS_PROFILE_ROLLING
+            asm volatile("" ::"v"(P[0]), "v"(P[NS - 1]));
+#endif
+            RT1(3);  // rotate and scan
+            RTA();
             // ---- pass 2: two rows at a time
 #pragma unroll
             for (int m = 0; m < kPairK / 2; ++m) {
@@ -442,11 +464,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                         (good && okrow) ? pr : nanv;  // (a non-finite row: x_r . beta is NaN in the reference too)
                     (valid + rb)[(unsigned)r] = v_ok ? 1 : 0;
                 }
+#ifdef PDS_PROFILE_ROLLING
+                if (m == 0) {
+                    RT1(4);  // pass 2, rows 0 - 1
+                    RTA();
+                }
+#endif
             }
+            RT1(5);  // pass 2, rows 2 - 3 (+ the next stage's loads issued)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PDS_WAVE_LDS_SYNC();  // the next round's first stage overwrites the images
     }
+#ifdef PDS_PROFILE_ROLLING
+    rprof[7] = __builtin_amdgcn_s_memtime() - t_begin;
+    if (lane == 0)
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_roll_cycles[k], rprof[k]);
+#endif
 }
 
 }  // namespace pds

@@ -1355,9 +1355,12 @@ def test_rolling_skip_non_finite(pds, orc):
 
 @pytest.mark.parametrize("pp,bias", [(2, False), (2, True), (4, True), (6, False), (8, False), (8, True)])
 @pytest.mark.parametrize("n,w", [(33, 5), (4099, 31), (4096 * 4 + 5, 32), (40_013, 256), (70_001, 1000)])
-def test_rolling_pair_kernel_shapes(pds, pp, bias, n, w):
-    """rolling_pair_dev.hpp (f64, even p'): two lanes per chain of rows, four tiles per wave.  Frame lengths off every
+def test_rolling_pair_kernel_shapes(pds, monkeypatch, pp, bias, n, w):
+    """rolling_pair_dev.hpp (f64, even p'; opt-in PDS_ROLL_PAIR=1): two lanes per chain of rows, four tiles per wave.  Frame lengths off every
     granule (2-row pieces, 4-row chains, 32-row stages, 4096-row tiles, 4-tile rounds), windows shorter / longer than a stage and a tile."""
+    if w < pp:
+        pytest.skip("window shorter than the coefficient count")
+    monkeypatch.setenv("PDS_ROLL_PAIR", "1")
     rng = np.random.default_rng(1000 * pp + w)
     p = pp - (1 if bias else 0)
     X = rng.random((n, p))
@@ -1369,7 +1372,7 @@ def test_rolling_pair_kernel_shapes(pds, pp, bias, n, w):
     assert va[w - 1 :].all() and not va[: w - 1].any()
     assert np.isnan(co[: w - 1]).all() and np.isnan(pr[: w - 1]).all() and np.isfinite(co[w - 1 :]).all()
     rows = np.unique(np.r_[w - 1, w, n - 1, n - 2, rng.integers(w - 1, n, size=150),
-                           [r for r in (31, 32, 33, 127, 128, 4095, 4096, 4097, 8191, 8192, 16383, 16384, 16385) if w - 1 <= r < n]])
+                           [r for r in (31, 32, 33, 127, 128, 4095, 4096, 4097, 8191, 8192, 16383, 16384, 16385) if w - 1 <= r < n]]).astype(int)
     for i in rows:
         A = Xb[i - w + 1 : i + 1]
         direct = np.linalg.solve(A.T @ A + lam * np.eye(pp), A.T @ y[i - w + 1 : i + 1])
@@ -1380,15 +1383,16 @@ def test_rolling_pair_kernel_shapes(pds, pp, bias, n, w):
     co2, pr2, va2 = pds.recursive_lin_reg(*cols_of(X), target=dev(y), start_with=n0, add_bias=bias, l2_reg=lam)
     co2, pr2, va2 = co2.cpu().numpy(), pr2.cpu().numpy(), va2.cpu().numpy().astype(bool)
     assert va2[n0 - 1 :].all() and not va2[: n0 - 1].any()
-    for i in np.unique(np.r_[n0 - 1, n - 1, rng.integers(n0 - 1, n, size=40), [r for r in (4095, 4096, 16384) if n0 - 1 <= r < n]]):
+    for i in np.unique(np.r_[n0 - 1, n - 1, rng.integers(n0 - 1, n, size=40), [r for r in (4095, 4096, 16384) if n0 - 1 <= r < n]]).astype(int):
         direct = np.linalg.solve(Xb[: i + 1].T @ Xb[: i + 1] + lam * np.eye(pp), Xb[: i + 1].T @ y[: i + 1])
         assert nrel(co2[i], direct) < 1e-9, i
         assert abs(pr2[i] - Xb[i] @ direct) < 1e-8
 
 
 @pytest.mark.parametrize("pp,bias,w,m", [(2, False, 10, 6), (4, True, 40, 20), (8, False, 256, 200)])
-def test_rolling_pair_kernel_non_finite_rows(pds, orc, pp, bias, w, m):
+def test_rolling_pair_kernel_non_finite_rows(pds, orc, monkeypatch, pp, bias, w, m):
     """Non-finite rows in the pair kernel: left out of the sums, counted out of the window, NaN pred (lr_online_solvers.rs:85-89, 218-301)."""
+    monkeypatch.setenv("PDS_ROLL_PAIR", "1")
     rng = np.random.default_rng(17 + pp)
     n = 9000
     p = pp - (1 if bias else 0)
