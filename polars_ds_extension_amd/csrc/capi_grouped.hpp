@@ -102,6 +102,7 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
     size_t need = 131072 + sizeof(T) * (size_t)chunk * q * q;
     need += (size_t)n_groups * 4 + (size_t)chunk * (pp * sizeof(T) + 1) + 4096;  // the fused path's pivoted-QR pass: list, results
     if (n_feat > 16 && n_feat <= 64) need += solve_wave_workspace(n_feat, bias, chunk, sizeof(T)) + 512;
+    if (n_feat > 16 && n_feat <= 32 && sizeof(T) == 8) need += grouped_mid_fused_workspace(ctx->num_cus, n_feat, bias) + 512;
     if (big) need += (size_t)n_groups * (n_feat + 1) * sizeof(T*) + moments_wide_workspace(ctx->num_cus, n_feat, n_rows) + 8192;
     if (space == PDS_HOST || !coeffs) need += (size_t)(n_groups + 1) * 8 + (size_t)n_groups * (pp * sizeof(T) + 1) + 4096;
     if (want_pred && space == PDS_HOST) need += 2 * ((size_t)n_rows * sizeof(T) + 256) + (size_t)n_rows + 256;
@@ -216,8 +217,21 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
     } else if (n_feat <= 16 && !want_piv && !(unfused_env && unfused_env[0] == '1') && n_groups < (1ll << 31)) {
         if (int rc = launch_grouped_fused<T>(ctx, dc, n_feat, n_rows, d_off, n_groups, sp, d_coeffs, d_null, d_mom, chunk)) return rc;
     } else {
-        void* d_wave_ws = (n_feat > 16 && n_feat <= 64 && !want_piv) ? ws_take(ctx, solve_wave_workspace(n_feat, bias, chunk, sizeof(T))) : nullptr;
-        for (int64_t g0 = 0; g0 < n_groups; g0 += chunk) {
+        // 17 .. 32 f64 features, rank gate on (round 4): one stream, the solves in the streaming waves, no moment records
+        // (moments_mid.hip, SPPC); PDS_GROUPED_MID_FUSED=0: the record pipeline below (A/B); it also takes over when more systems sit
+        // next to the gate than the fused form's marked list holds
+        bool mid_done = false;
+        if constexpr (std::is_same<T, double>::value) {
+            const char* mf = std::getenv("PDS_GROUPED_MID_FUSED");
+            if (n_feat > 16 && n_feat <= 32 && !want_piv && !(mf && mf[0] == '0')) {
+                void* d_fws = ws_take(ctx, grouped_mid_fused_workspace(ctx->num_cus, n_feat, bias));
+                const int rcf = launch_grouped_mid_fused(ctx, dc, n_feat, n_rows, d_off, n_groups, sp, d_coeffs, d_null, d_fws);
+                if (rcf == PDS_OK) mid_done = true;
+                else if (rcf != PDS_ERR_UNSUPPORTED) return rcf;
+            }
+        }
+        void* d_wave_ws = (!mid_done && n_feat > 16 && n_feat <= 64 && !want_piv) ? ws_take(ctx, solve_wave_workspace(n_feat, bias, chunk, sizeof(T))) : nullptr;
+        for (int64_t g0 = 0; g0 < n_groups && !mid_done; g0 += chunk) {
             const int64_t gc = std::min(chunk, n_groups - g0);
             bool streamed = false;
             if constexpr (std::is_same<T, double>::value) {

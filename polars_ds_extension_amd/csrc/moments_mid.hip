@@ -18,6 +18,8 @@
 // measured 86 clk per instruction and SIMD, tools/mfma_peak.hip, against 1.30 ms of HBM time).
 #include "common.hpp"
 #include "moments_dev.hpp"
+#include "solve_wave_dev.hpp"
+#include "solve_row16_dev.hpp"
 
 namespace pds {
 
@@ -420,10 +422,31 @@ int launch_mid(pds_ctx* ctx, const DeviceCols<T>& dc, int p, int64_t n, T* d_mom
 // rows outside it zeroed in the operands, and a finished group's tiles go straight from the accumulator registers into its record.
 // Groups that lie inside one wave's rows are written with plain stores; a group cut by a wave boundary (two per wave, or a giant group
 // over many waves) is added to the zero-initialised record with atomics.
-template <int NBLK>
+// SPPC > 0 (NBLK = 2, up to 32 features, round 4): NO RECORDS -- a finished group is solved in the wave that streamed it.  Its
+// accumulator tiles go through a 4 KB LDS scratch (16 columns per trip) into one of four pending systems -- one per 16-lane DPP row,
+// lane t = columns t and 16 + t, centred -- and four pending systems are factored side by side (solve_row16_dev.hpp: L D L' with the
+// pivot-ratio gate) and their coefficients written; only what cannot be answered in place leaves as a record: a group cut by a wave
+// boundary (atomics into the side table's slot of the wave it starts in: at most one per wave) and a system next to the gate
+// (appended to the marked list for the pivoted QR; its record is rebuilt from its rows).  The per-group dispatch
+// of pl_lr under group_by (linear_regression.rs:447-497) at 17 .. 32 features then moves input + coefficients only, as at <= 16.
+struct MidSolveArgs {
+    SolveRegDev sp;
+    double* coeffs = nullptr;      // [n_groups][p + bias]
+    uint8_t* flags = nullptr;      // [n_groups]: 1 = null
+    double* side_rec = nullptr;    // [waves][q * q], zeroed: records of groups that straddle wave boundaries
+    int32_t* side_list = nullptr;  // [waves], -1: slot w = the group that starts in wave w's rows and ends beyond them
+    double* mark_rec = nullptr;    // [mark_cap][q * q]: records of systems the in-wave solve marked
+    int32_t* mark_list = nullptr;  // [mark_cap]
+    unsigned* mark_count = nullptr;  // appended count (beyond mark_cap: overflow, the caller falls back to the record pipeline)
+    unsigned mark_cap = 0;
+};
+constexpr int kMidSolveScratch = 16 * 34 * 8;  // bytes: 16 columns x 32 rows, stride 34 doubles
+
+template <int NBLK, int SPPC = 0>
 __global__ __launch_bounds__(64) void grouped_mid_stream_kernel(const double* const* __restrict__ cols, int p, int64_t n_frame,
                                                                 const int64_t* __restrict__ off, int64_t n_groups,
-                                                                double* __restrict__ records, int debug) {
+                                                                double* __restrict__ records, int debug, MidSolveArgs sa) {
+    static_assert(SPPC == 0 || NBLK == 2, "the in-wave solve serves two tile columns");
     using MD = MidDims<NBLK>;
     constexpr int HR = MD::HR, GS = MD::GS, NPAIR = MD::NPAIR;
     extern __shared__ __attribute__((aligned(16))) char gmid_lds[];
@@ -585,17 +608,10 @@ __global__ __launch_bounds__(64) void grouped_mid_stream_kernel(const double* co
         }
         rows_in_acc += hi - lo;
     };
-    // the accumulated rows of group g -> its record (plain stores when the whole group lies in this wave's rows)
-    auto flush = [&]() __attribute__((always_inline)) {
-        const bool whole = gs >= W0 && ge <= W1;
-        if (debug & 2) {  // (timing experiment: no record stores)
-            zero_acc();
-            rows_in_acc = 0;
-            return;
-        }
-        double* M = records + g * (int64_t)q * q;
+    // the accumulated rows of group g -> a record at M (plain stores, or atomics into a zeroed record that other waves add to)
+    auto put_record = [&](double* M, bool plain) __attribute__((always_inline)) {
         auto put = [&](int64_t idx, double v) __attribute__((always_inline)) {
-            if (whole) M[idx] = v;
+            if (plain) M[idx] = v;
             else if (v != 0.0) unsafeAtomicAdd(M + idx, v);
         };
         int t = 0;
@@ -639,6 +655,178 @@ __global__ __launch_bounds__(64) void grouped_mid_stream_kernel(const double* co
             put((p + 1) + (int64_t)p * q, vys);
             put((p + 1) + (int64_t)(p + 1) * q, vyy);
         }
+    };
+    // SPPC: finished groups wait, up to four of them (one per 16-lane DPP row, two columns per lane: solve_row16_dev.hpp), and are
+    // solved side by side.  A system next to the gate is marked; its record is rebuilt from the group's rows (a rare, slow path: the
+    // accumulators it came from are gone by then).
+    double pa0[SPPC + 1], pa1[SPPC + 1], pdj0 = 1.0, pdj1 = 1.0, psj0 = 0.0, psj1 = 0.0, pnn = 1.0, psy = 0.0;
+    int64_t pgid = -1;
+    bool pfew = false;
+    int npend = 0;
+    if constexpr (SPPC > 0) {
+#pragma unroll
+        for (int i = 0; i <= SPPC; ++i) pa0[i] = pa1[i] = 0.0;
+    }
+    auto record_from_rows = [&](int64_t gg, double* M) __attribute__((always_inline)) {
+        const int64_t r0 = off[gg], r1 = off[gg + 1];
+        for (int e = lane; e < q * q; e += 64) {
+            const int i = e % q, j = e / q;
+            if (i > j) continue;
+            const gptr<double> ci = as_global(cols[i < p ? i : p]), cj = as_global(cols[j < p ? j : p]);  // (index p: the target column)
+            double sacc = 0.0;
+            for (int64_t r = r0; r < r1; ++r) {
+                const double zi = i < p ? ci[r] : (i == p ? 1.0 : ci[r]);
+                const double zj = j < p ? cj[r] : (j == p ? 1.0 : cj[r]);
+                sacc = fma(zi, zj, sacc);
+            }
+            M[i + (int64_t)j * q] = sacc;
+            M[j + (int64_t)i * q] = sacc;
+        }
+    };
+    auto solve_pending = [&]() __attribute__((always_inline)) {
+        if constexpr (SPPC > 0) {
+            if (npend == 0) return;
+            const int t = lane & 15, R = lane >> 4, pout = p + sa.sp.bias;
+            const bool live = R < npend;
+            double w0, w1;
+            bool is_null, suspect;
+            row16_ldl_solve<SPPC>(pa0, pa1, pdj0, pdj1, t, p, pfew, sa.sp, w0, w1, is_null, suspect);
+            const double nanv = __builtin_nan("");
+            const int64_t gq = live ? pgid : 0;
+            double* co = sa.coeffs + gq * (int64_t)pout;
+            if (live && t < p) co[t] = is_null ? nanv : w0;
+            if (live && 16 + t < p) co[16 + t] = is_null ? nanv : w1;
+            if (sa.sp.bias) {
+                const double sb = Grp<16>::sum((t < p ? psj0 * w0 : 0.0) + (16 + t < p ? psj1 * w1 : 0.0));
+                if (live && t == 0) co[p] = is_null ? nanv : (psy - sb) / pnn;
+            }
+            if (live && t == 0) sa.flags[gq] = is_null ? 1 : 0;
+            // marked systems: one DPP row after the other (wave-uniform control flow)
+            const unsigned long long sus = __builtin_amdgcn_ballot_w64(live && suspect);
+            for (int r = 0; r < 4; ++r) {
+                if (!((sus >> (16 * r)) & 1ull)) continue;
+                const int glo = __builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)pgid, 16 * r);
+                const int ghi = __builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)pgid >> 32), 16 * r);
+                const int64_t gg = (int64_t)(((uint64_t)(uint32_t)ghi << 32) | (uint64_t)(uint32_t)glo);
+                unsigned slot = 0;
+                if (lane == 0) slot = atomicAdd(sa.mark_count, 1u);
+                slot = (unsigned)__builtin_amdgcn_readfirstlane((int)slot);
+                if (slot < sa.mark_cap) {
+                    if (lane == 0) sa.mark_list[slot] = (int32_t)gg;
+                    record_from_rows(gg, sa.mark_rec + (int64_t)slot * q * q);
+                }
+            }
+            npend = 0;
+        }
+    };
+    // the finished group's accumulators -> DPP row `npend` of the pending registers (through a 4 KB LDS scratch, 16 columns per trip)
+    auto route_pending = [&]() __attribute__((always_inline)) {
+        if constexpr (SPPC > 0) {
+            typedef __attribute__((address_space(3))) double* lds_dp;
+            constexpr int SS = 34;
+            lds_dp S = (lds_dp)(sm + MD::LDS_BYTES);
+            const int t = lane & 15, R = lane >> 4, pout = p + sa.sp.bias;
+            const bool mine = R == npend;
+            double c0[SPPC + 1], c1[SPPC + 1];
+            // ---- columns 0 .. 15: rows 0 .. 15 from block (0, 0), rows 16 .. 31 from block (0, 1) transposed (G is symmetric)
+            PDS_WAVE_LDS_SYNC();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                S[fi * SS + fk + 4 * r] = acc[0][r];
+                S[(fk + 4 * r) * SS + 16 + fi] = acc[1][r];
+            }
+            PDS_WAVE_LDS_SYNC();
+#pragma unroll
+            for (int i = 0; i < SPPC; ++i) c0[i] = S[t * SS + i];
+            PDS_WAVE_LDS_SYNC();
+            // ---- columns 16 .. 31: rows 0 .. 15 from block (0, 1), rows 16 .. 31 from block (1, 1)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                S[fi * SS + fk + 4 * r] = acc[1][r];
+                S[fi * SS + 16 + fk + 4 * r] = acc[2][r];
+            }
+            PDS_WAVE_LDS_SYNC();
+#pragma unroll
+            for (int i = 0; i < SPPC; ++i) c1[i] = S[t * SS + i];
+            // X'y and the column sums (lane 16 b' + t of ANY row holds feature 16 b + t's sums after the reduction over the row slots)
+            double vx0 = xy[0], vx1 = xy[1], vc0 = cs[0], vc1 = cs[1], vys = ys;
+            vx0 += __shfl_xor(vx0, 16); vx0 += __shfl_xor(vx0, 32);
+            vx1 += __shfl_xor(vx1, 16); vx1 += __shfl_xor(vx1, 32);
+            vc0 += __shfl_xor(vc0, 16); vc0 += __shfl_xor(vc0, 32);
+            vc1 += __shfl_xor(vc1, 16); vc1 += __shfl_xor(vc1, 32);
+            vys += __shfl_xor(vys, 16); vys += __shfl_xor(vys, 32);
+            const bool c0v = t < p, c1v = 16 + t < p;
+            c0[SPPC] = c0v ? vx0 : 0.0;
+            c1[SPPC] = c1v ? vx1 : 0.0;
+            const double nn = (double)rows_in_acc;
+            double dj0 = 1.0, dj1 = 1.0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (i == t) {
+                    if (c0v) dj0 = c0[i] + sa.sp.lambda;
+                    c0[i] += sa.sp.lambda;  // (columns beyond p: lambda on a row nobody eliminates)
+                    if (16 + i < SPPC) {
+                        if (c1v) dj1 = c1[16 + i] + sa.sp.lambda;
+                        c1[16 + i] += sa.sp.lambda;
+                    }
+                }
+            }
+            const double sj0 = (c0v && sa.sp.bias) ? vc0 : 0.0, sj1 = (c1v && sa.sp.bias) ? vc1 : 0.0;
+            if (sa.sp.bias) {  // centre: G_ij - s_i s_j / n (the intercept never takes a lane)
+                const double m0 = sj0 / nn, m1 = sj1 / nn;
+                Row16Centre<SPPC, SPPC - 1>::run(c0, c1, sj0, sj1, m0, m1);
+                c0[SPPC] = fma(-vys, m0, c0[SPPC]);
+                c1[SPPC] = fma(-vys, m1, c1[SPPC]);
+            }
+            // (selects, not an exec-masked copy: the masked form measured slower -- 19.3 against 9.7 ms at 32 features)
+#pragma unroll
+            for (int i = 0; i <= SPPC; ++i) {
+                pa0[i] = mine ? c0[i] : pa0[i];
+                pa1[i] = mine ? c1[i] : pa1[i];
+            }
+            pdj0 = mine ? dj0 : pdj0;
+            pdj1 = mine ? dj1 : pdj1;
+            psj0 = mine ? sj0 : psj0;
+            psj1 = mine ? sj1 : psj1;
+            pnn = mine ? nn : pnn;
+            psy = mine ? vys : psy;
+            pgid = mine ? g : pgid;
+            pfew = mine ? (rows_in_acc < pout) : pfew;
+            ++npend;
+            if (npend == 4) solve_pending();
+        }
+    };
+    auto flush = [&]() __attribute__((always_inline)) {
+        const bool whole = gs >= W0 && ge <= W1;
+        if (debug & 2) {  // (timing experiment: no record stores)
+            zero_acc();
+            rows_in_acc = 0;
+            return;
+        }
+        if constexpr (SPPC > 0) {
+            if (whole) {
+                route_pending();
+            } else {
+                // the wave the group starts in owns the side-table slot (largest w whose first row is <= gs)
+                int64_t slot = wave;
+                if (gs < W0) {
+                    int64_t lo = 0, hi = wave;
+                    while (hi - lo > 1) {
+                        const int64_t mid = lo + ((hi - lo) >> 1);
+                        const int64_t hm = H0 + (H1 - H0) * mid / nwaves;
+                        const int64_t wm = hm * HR > row_begin ? hm * HR : row_begin;
+                        if (wm <= gs) lo = mid;
+                        else hi = mid;
+                    }
+                    slot = lo;
+                } else if (lane == 0) {
+                    sa.side_list[wave] = (int32_t)g;
+                }
+                put_record(sa.side_rec + slot * (int64_t)q * q, false);
+            }
+        } else {
+            put_record(records + g * (int64_t)q * q, whole);
+        }
         zero_acc();
         rows_in_acc = 0;
     };
@@ -672,6 +860,7 @@ __global__ __launch_bounds__(64) void grouped_mid_stream_kernel(const double* co
         PDS_WAVE_LDS_SYNC();
     }
     if (rows_in_acc > 0 && g < n_groups) flush();  // the group that continues in the next wave's rows
+    solve_pending();
 #undef PDS_GM_LDSD
 }
 
@@ -694,9 +883,67 @@ int launch_grouped_stream(pds_ctx* ctx, const DeviceCols<double>& dc, int p, int
     const char* dbg = nullptr;
 #endif
     hipLaunchKernelGGL(kern, dim3((unsigned)waves), dim3(64), MD::LDS_BYTES, ctx->stream, dc.d_ptrs, p, n_frame, d_off, n_groups, d_records,
-                       dbg ? std::atoi(dbg) : 0);
+                       dbg ? std::atoi(dbg) : 0, MidSolveArgs{});
     PDS_HIP_CHECK(hipGetLastError());
     return PDS_OK;
+}
+
+// ---- the in-wave-solve form (SPPC): host side
+constexpr unsigned kMidMarkCap = 8192;  // records of marked systems kept for the pivoted QR; more than that: the record pipeline
+inline int64_t mid_fused_waves(const pds_ctx* ctx, int64_t n_frame) {
+    return std::min<int64_t>((int64_t)ctx->num_cus * kMidWavesPerCu, std::max<int64_t>(1, n_frame / (8 * MidDims<2>::HR)));
+}
+// side table -> compact: the groups that straddle wave boundaries (slot w used iff side_list[w] >= 0), their records, row counts as
+// offsets, and the count (one block: there are at most `waves` <= 1024 of them)
+__global__ __launch_bounds__(1024) void mid_side_compact_kernel(const double* __restrict__ side_rec, const int32_t* __restrict__ side_list,
+                                                                int waves, int qq, const int64_t* __restrict__ off, double* __restrict__ rec_c,
+                                                                int32_t* __restrict__ list_c, int64_t* __restrict__ rows_c,
+                                                                unsigned* __restrict__ count_out) {
+    // thread w = slot w (waves <= 1024): inclusive scans of "used" and of the row counts through shared memory
+    __shared__ int s_cnt[1024];
+    __shared__ long long s_rows[1024];
+    __shared__ int s_slot[1024];
+    const int w = threadIdx.x;
+    const int32_t g = w < waves ? side_list[w] : -1;
+    const long long rows = g >= 0 ? (long long)(off[g + 1] - off[g]) : 0;
+    s_cnt[w] = g >= 0 ? 1 : 0;
+    s_rows[w] = rows;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int c = w >= d ? s_cnt[w - d] : 0;
+        const long long r = w >= d ? s_rows[w - d] : 0;
+        __syncthreads();
+        s_cnt[w] += c;
+        s_rows[w] += r;
+        __syncthreads();
+    }
+    const int n = s_cnt[1023];
+    if (g >= 0) {
+        const int k = s_cnt[w] - 1;
+        s_slot[k] = w;
+        list_c[k] = g;
+        rows_c[k + 1] = s_rows[w];
+    }
+    if (w == 0) {
+        rows_c[0] = 0;
+        *count_out = (unsigned)n;
+    }
+    __syncthreads();
+    for (int64_t e = w; e < (int64_t)n * qq; e += 1024) {
+        const int k = (int)(e / qq);
+        rec_c[e] = side_rec[(int64_t)s_slot[k] * qq + (e - (int64_t)k * qq)];
+    }
+}
+__global__ __launch_bounds__(256) void mid_scatter_kernel(const double* __restrict__ co_c, const uint8_t* __restrict__ fl_c,
+                                                          const int32_t* __restrict__ list, int64_t n, int pp, double* __restrict__ coeffs,
+                                                          uint8_t* __restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * pp) return;
+    const int64_t k = i / pp;
+    const int c = (int)(i - k * pp);
+    const int64_t g = list[k];
+    coeffs[g * pp + c] = co_c[i];
+    if (c == 0) flags[g] = fl_c[k] ? 1 : 0;
 }
 
 }  // namespace
@@ -742,6 +989,104 @@ int launch_grouped_moments_stream(pds_ctx* ctx, const DeviceCols<double>& dc, in
     if (n_feat <= 32) return launch_grouped_stream<2>(ctx, dc, n_feat, n_frame, d_off, n_groups, d_records);
     if (n_feat <= 64) return launch_grouped_stream<4>(ctx, dc, n_feat, n_frame, d_off, n_groups, d_records);
     return fail(PDS_ERR_UNSUPPORTED, "grouped_mid_stream: up to 64 features");
+}
+
+// OLS / ridge fits of n_groups contiguous groups with 17 .. 32 f64 features, rank gate on, as ONE stream with the solves in the
+// streaming waves (grouped_mid_stream_kernel, SPPC): coefficients [n_groups][p + bias] and null flags; no per-group records.
+// PDS_ERR_UNSUPPORTED (nothing usable written): not applicable, or more systems next to the gate than the marked list holds -- the
+// caller keeps the record pipeline.  d_ws: grouped_mid_fused_workspace() bytes.
+size_t grouped_mid_fused_workspace(int num_cus, int n_feat, int add_bias) {
+    const size_t q = (size_t)n_feat + 2, pp = (size_t)n_feat + (add_bias ? 1 : 0), waves = (size_t)num_cus * kMidWavesPerCu;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t sysmax = std::max<size_t>(waves, kMidMarkCap);
+    return 4096 + 2 * up(waves * q * q * 8) + 2 * up(waves * 4) + up((waves + 1) * 8) + up((size_t)kMidMarkCap * q * q * 8) + up((size_t)kMidMarkCap * 4) +
+           up(sysmax * pp * 8) + up(sysmax) + solve_wave_workspace(n_feat, add_bias, (int64_t)waves, 8) + 512;
+}
+int launch_grouped_mid_fused(pds_ctx* ctx, const DeviceCols<double>& dc, int n_feat, int64_t n_frame, const int64_t* d_off, int64_t n_groups,
+                             const SolveParams& sp, double* d_coeffs, uint8_t* d_flags, void* d_ws) {
+    if (n_feat <= 16 || n_feat > 32 || !(sp.gate_tol > 0.0) || sp.lambda_on_bias || !d_flags || !d_ws || n_groups <= 0 ||
+        n_groups >= (1ll << 31))
+        return PDS_ERR_UNSUPPORTED;
+    using MD = MidDims<2>;
+    const int p = n_feat, q = p + 2, bias = sp.add_bias ? 1 : 0, pp = p + bias;
+    const int64_t waves = mid_fused_waves(ctx, n_frame);
+    if (waves > 1024) return PDS_ERR_UNSUPPORTED;  // (mid_side_compact_kernel: one thread per wave)
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    char* wsp = static_cast<char*>(d_ws);
+    wsp += (256 - (reinterpret_cast<uintptr_t>(wsp) & 255)) & 255;
+    auto take = [&](size_t b) { char* r = wsp; wsp += up(b); return r; };
+    MidSolveArgs sa;
+    sa.sp.p = p;
+    sa.sp.pp = p;
+    sa.sp.bias = bias;
+    sa.sp.lambda_on_bias = 0;
+    sa.sp.lambda = sp.lambda;
+    sa.sp.gate_on = 1;
+    sa.sp.ln_tol = std::log(sp.gate_tol);
+    sa.sp.inv_tol = 1.0 / sp.gate_tol;
+    const bool second_pass = sp.solver != PDS_SOLVER_CHOLESKEY;  // (as launch_solve_wave: "choleskey" IS the in-wave factorisation)
+    sa.sp.sus_tol = second_pass ? std::sqrt(sa.sp.inv_tol) : 0.0;
+    sa.coeffs = d_coeffs;
+    sa.flags = d_flags;
+    unsigned* d_counts = reinterpret_cast<unsigned*>(take(256));  // [0] marked, [1] side groups
+    sa.mark_count = d_counts;
+    sa.side_rec = reinterpret_cast<double*>(take((size_t)waves * q * q * 8));
+    sa.side_list = reinterpret_cast<int32_t*>(take((size_t)waves * 4));
+    sa.mark_rec = reinterpret_cast<double*>(take((size_t)kMidMarkCap * q * q * 8));
+    sa.mark_list = reinterpret_cast<int32_t*>(take((size_t)kMidMarkCap * 4));
+    sa.mark_cap = kMidMarkCap;
+    double* rec_c = reinterpret_cast<double*>(take((size_t)waves * q * q * 8));
+    int32_t* list_c = reinterpret_cast<int32_t*>(take((size_t)waves * 4));
+    int64_t* rows_c = reinterpret_cast<int64_t*>(take((size_t)(waves + 1) * 8));
+    const size_t sysmax = std::max<size_t>((size_t)waves, kMidMarkCap);
+    double* co_c = reinterpret_cast<double*>(take(sysmax * pp * 8));
+    uint8_t* fl_c = reinterpret_cast<uint8_t*>(take(sysmax));
+    void* wave_ws = take(solve_wave_workspace(n_feat, bias, waves, 8));
+    PDS_HIP_CHECK(hipMemsetAsync(d_counts, 0, 256, ctx->stream));
+    PDS_HIP_CHECK(hipMemsetAsync(sa.side_rec, 0, (size_t)waves * q * q * 8, ctx->stream));
+    PDS_HIP_CHECK(hipMemsetAsync(sa.side_list, 0xFF, (size_t)waves * 4, ctx->stream));
+    constexpr int lds = MD::LDS_BYTES + kMidSolveScratch;
+    {
+        KernelTimer timer(ctx, kKindGroupedMoments);
+#ifdef PDS_DEV_SWITCHES  // timing experiments of development builds (EXTRA=-DPDS_DEV_SWITCHES): wrong results with it
+        const char* dbg = std::getenv("PDS_GMID_DEBUG");
+#else
+        const char* dbg = nullptr;
+#endif
+        const int debug = dbg ? std::atoi(dbg) : 0;
+        auto launch = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3((unsigned)waves), dim3(64), lds, ctx->stream, dc.d_ptrs, p, n_frame, d_off, n_groups, (double*)nullptr, debug, sa);
+        };
+        if (p <= 24) launch(grouped_mid_stream_kernel<2, 24>);
+        else launch(grouped_mid_stream_kernel<2, 32>);
+        PDS_HIP_CHECK(hipGetLastError());
+    }
+    // the groups cut by wave boundaries: compacted, then the record solver
+    hipLaunchKernelGGL(mid_side_compact_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const double*)sa.side_rec, (const int32_t*)sa.side_list,
+                       (int)waves, q * q, d_off, rec_c, list_c, rows_c, d_counts + 1);
+    unsigned h_counts[2] = {0, 0};
+    PDS_HIP_CHECK(hipMemcpyAsync(h_counts, d_counts, sizeof(h_counts), hipMemcpyDeviceToHost, ctx->stream));
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+#ifdef PDS_DEV_SWITCHES
+    if (std::getenv("PDS_GMID_VERBOSE")) std::fprintf(stderr, "grouped_mid_fused: waves %lld marked %u side %u\n", (long long)waves, h_counts[0], h_counts[1]);
+#endif
+    if (h_counts[0] > kMidMarkCap) return PDS_ERR_UNSUPPORTED;  // (every group will be answered by the record pipeline instead)
+    if (h_counts[1] > 0) {
+        const int64_t ns = h_counts[1];
+        if (int rc = launch_solve_wave<double>(ctx, rec_c, ns, sp, co_c, fl_c, rows_c, wave_ws)) return rc;
+        hipLaunchKernelGGL(mid_scatter_kernel, dim3((unsigned)((ns * pp + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)co_c,
+                           (const uint8_t*)fl_c, (const int32_t*)list_c, ns, pp, d_coeffs, d_flags);
+    }
+    if (h_counts[0] > 0) {  // systems next to the gate: the reference's default factorisation (pivoted QR, log-det gate)
+        const int64_t nm = h_counts[0];
+        SolveParams sq = sp;
+        sq.solver = PDS_SOLVER_QR;
+        if (int rc = launch_solve<double>(ctx, sa.mark_rec, nm, sq, co_c, fl_c, nullptr, nullptr)) return rc;
+        hipLaunchKernelGGL(mid_scatter_kernel, dim3((unsigned)((nm * pp + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)co_c,
+                           (const uint8_t*)fl_c, (const int32_t*)sa.mark_list, nm, pp, d_coeffs, d_flags);
+    }
+    PDS_HIP_CHECK(hipGetLastError());
+    return PDS_OK;
 }
 
 }  // namespace pds

@@ -15,25 +15,11 @@
 //     log-det gate of solve.hip -- in a second pass over the marked records only.  solver = "choleskey" IS this factorisation.
 #include "common.hpp"
 #include "solve_reg_dev.hpp"
+#include "solve_wave_dev.hpp"
 
 namespace pds {
 
 namespace {
-
-__device__ __forceinline__ double lane_bcast(double v, int k) {  // k wave-uniform
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), k), hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-__device__ __forceinline__ double wave_prod(double v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v *= __shfl_xor(v, o);
-    return v;
-}
 
 // PPC: compile-time bound of the feature count (a multiple of 8); p <= PPC features, rows / columns beyond p are exact zeros
 template <typename T, int PPC>
@@ -71,48 +57,14 @@ __global__ __launch_bounds__(64) void solve_wave_kernel(const T* __restrict__ mo
             }
             a[PPC] = fma(-sy, m, a[PPC]);
         }
-        bool is_null = false;
-        if (rows_per_sys && rows_per_sys[sys + 1] - rows_per_sys[sys] < pout) is_null = true;  // "#Data < #features"
-        const bool few = is_null;
-        if (__any(colv && dj <= 0.0)) is_null = true;  // a non-positive diagonal entry gates (lr_solvers.rs:341-347)
-        // ---- L D L' (the elimination of solve_reg_dev.hpp's chol_step over 64 lanes)
-        double invd = 1.0;
-        bool ok = true;
-#pragma unroll
-        for (int K = 0; K < PPC; ++K) {
-            if (K < p) {
-                const double d = lane_bcast(a[K], K);
-                ok = ok && (d > 0.0);
-                double x = __builtin_amdgcn_rcp(d);
-#pragma unroll
-                for (int it = 0; it < PDS_RCP_NEWTON; ++it) x = fma(fma(-d, x, 1.0), x, x);
-                const double nt = (j > K) ? -(a[K] * x) : 0.0;
-#pragma unroll
-                for (int i = K + 1; i <= PPC; ++i) {
-                    a[i] = fma(lane_bcast(a[i], K), nt, a[i]);
-                    // (keep the broadcasts next to their FMAs: hoisted in bulk they needed ~800 scalar registers and spilled)
-                    if (((i - K) & 7) == 0) __builtin_amdgcn_sched_barrier(0);
-                }
-                if (j == K) invd = x;
-            }
-        }
-        if (!ok) is_null = true;  // "Not positive-definite -> rank-deficient" (lr_solvers.rs:370-371)
-        const double grow = wave_prod(colv ? dj * invd : 1.0);  // prod G_kk / L_kk^2
-        if (grow >= sp.inv_tol) is_null = true;
-        const bool suspect = sp.sus_tol > 0.0 && (!ok || !(grow < sp.sus_tol)) && !few;
-        is_null = is_null || suspect;
-        // ---- back substitution: w <- w + bcast_M(w) (-a[M] / d_j), lane j final after step j + 1
-        double w = a[PPC] * invd;
-#pragma unroll
-        for (int Mi = PPC - 1; Mi >= 1; --Mi) {
-            if (Mi < p) {
-                const double c = (j < Mi) ? -(a[Mi] * invd) : 0.0;
-                w = fma(lane_bcast(w, Mi), c, w);
-            }
-        }
+        const bool few = rows_per_sys && rows_per_sys[sys + 1] - rows_per_sys[sys] < pout;  // "#Data < #features"
+        // ---- L D L', rank gate, back substitution (solve_wave_dev.hpp)
+        double w;
+        bool is_null, suspect;
+        wave_ldl_solve<PPC>(a, dj, j, p, few, sp, w, is_null, suspect);
         if (colv) coeffs[sys * (int64_t)pout + j] = is_null ? (T)nanv : (T)w;
         if (bias) {
-            const double sb = wave_sum(colv ? sj * w : 0.0);
+            const double sb = wave_sum64(colv ? sj * w : 0.0);
             if (j == 0) coeffs[sys * (int64_t)pout + p] = is_null ? (T)nanv : (T)((sy - sb) / nn);
         }
         if (j == 0) {

@@ -1030,6 +1030,61 @@ def test_grouped_mid_width_wave_solver(pds, orc, p, bias, l2):
     assert np.median(np.linalg.norm(co_c[both] - co_o[both], axis=1) / np.linalg.norm(co_o[both], axis=1)) < 1e-10
 
 
+@pytest.mark.parametrize("p,bias,l2", [(17, True, 0.0), (22, False, 0.05), (28, True, 0.0), (32, False, 0.0)])
+def test_grouped_mid_fused_wave_boundaries(pds, orc, p, bias, l2):
+    """17 .. 32 f64 features, round 4: ONE stream, a finished group solved in the streaming wave (moments_mid.hip SPPC), no moment
+    records.  ~600 waves over this frame: groups cut by wave boundaries (side table + record solver), a group longer than many
+    waves' ranges, empty and too-small groups, collinear / nearly collinear groups (marked -> pivoted QR).  Against the oracle."""
+    rng = np.random.default_rng(5000 + p)
+    pp = p + int(bias)
+    sizes = rng.integers(2 * pp, 5 * pp, size=3000)
+    sizes[100] = 40_000                      # spans dozens of waves
+    sizes[1500] = 3 * 512 + 7                # a few waves
+    sizes[::97] = 0                          # empty groups
+    sizes[5::113] = rng.integers(1, pp, size=len(sizes[5::113]))  # fewer rows than coefficients -> null
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    N, G = int(off[-1]), len(sizes)
+    X = rng.normal(size=(N, p)) + rng.normal(size=p) * 0.3
+    y = X @ rng.normal(size=p) + (0.7 if bias else 0.0) + 0.2 * rng.normal(size=N)
+    for g in range(7, G, 211):               # collinear -> gated
+        X[off[g]: off[g + 1], 3] = 2.0 * X[off[g]: off[g + 1], 1] - X[off[g]: off[g + 1], 0]
+    for g in range(11, G, 173):              # nearly collinear: next to the gate
+        X[off[g]: off[g + 1], 2] = X[off[g]: off[g + 1], 1] + 3e-6 * rng.normal(size=int(sizes[g]))
+    co, nu = pds.lin_reg_by(*cols_of(X), target=dev(y), group_offsets=off, add_bias=bias, l2_reg=l2)
+    co, nu = co.cpu().numpy(), nu.cpu().numpy().astype(bool)
+    co_o, nu_o = orc.grouped_lr([y] + [X[:, j] for j in range(p)], off, add_bias=bias, l2_reg=l2, nthreads=4)
+    assert np.array_equal(nu, nu_o), (nu.sum(), nu_o.sum(), np.flatnonzero(nu != nu_o)[:10])
+    ok = ~nu
+    assert ok.sum() > 0.9 * G and nu.sum() >= 40
+    err = np.linalg.norm(co[ok] - co_o[ok], axis=1) / np.linalg.norm(co_o[ok], axis=1)
+    worst = 0.0
+    for g in np.flatnonzero(ok)[np.argsort(err)[-6:]]:
+        Xg = X[off[g]: off[g + 1]]
+        Xb = np.c_[Xg, np.ones(len(Xg))] if bias else Xg
+        bound = max(F64_TOL, 64 * 2.2e-16 * np.linalg.cond(Xb.T @ Xb + l2 * np.eye(Xb.shape[1])))
+        worst = max(worst, float(err[np.flatnonzero(ok) == g][0] / bound))
+    assert worst < 1.0, (worst, err.max())
+    assert err[np.flatnonzero(ok) == 100][0] < F64_TOL and err[np.flatnonzero(ok) == 1500][0] < F64_TOL
+
+
+def test_grouped_mid_fused_falls_back_when_the_marked_list_overflows(pds, orc):
+    """More systems next to the gate than the fused form keeps records for (8192): the record pipeline answers the call."""
+    rng = np.random.default_rng(77)
+    p, G = 17, 9000
+    sizes = np.full(G, p + 3)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    N = int(off[-1])
+    X = rng.normal(size=(N, p))
+    y = X @ rng.normal(size=p) + 0.1 * rng.normal(size=N)
+    co, nu = pds.lin_reg_by(*cols_of(X), target=dev(y), group_offsets=off, add_bias=False)
+    co, nu = co.cpu().numpy(), nu.cpu().numpy().astype(bool)
+    co_o, nu_o = orc.grouped_lr([y] + [X[:, j] for j in range(p)], off, add_bias=False, nthreads=4)
+    assert np.array_equal(nu, nu_o)
+    ok = ~nu
+    err = np.linalg.norm(co[ok] - co_o[ok], axis=1) / np.linalg.norm(co_o[ok], axis=1)
+    assert np.median(err) < 1e-9
+
+
 @pytest.mark.parametrize("p,bias", [(4, True), (15, True), (16, False), (20, True)])
 def test_grouped_weighted(pds, orc, p, bias):
     """group_by(key).agg(pds.lin_reg(..., weights=w)): per group faer_weighted_lr (lr_solvers.rs:386-409)."""
