@@ -183,8 +183,9 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
         if (n_rows == 0) return fail(PDS_ERR_EMPTY, "Empty data");
     }
     T* d_mom = reinterpret_cast<T*>(ws_take(ctx, sizeof(T) * (size_t)chunk * q * q));
-    SolveParams sp{n_feat, bias, prm->solver == PDS_SOLVER_SVD ? PDS_SOLVER_QR : prm->solver, prm->l2_reg,
-                   prm->singular_x_tol, 0};
+    // solver = "svd" travels on: the streaming kernels answer the clear systems (any factorisation agrees on them to rounding) and
+    // mark the ones next to the rank gate, which launch_solve_marked puts through the reference's SVD gate (lr_solvers.rs:358-366)
+    SolveParams sp{n_feat, bias, prm->solver, prm->l2_reg, prm->singular_x_tol, 0};
     {
         const char* piv0 = std::getenv("PDS_GROUPED_PIVOTED");
         if (piv0 && piv0[0] == '1' && sp.solver == PDS_SOLVER_CHOLESKEY) sp.solver = PDS_SOLVER_QR;
@@ -485,7 +486,11 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
     uint32_t* d_run_counts = reinterpret_cast<uint32_t*>(static_cast<char*>(ctx->solve_ws.ptr) + 4096);
     uint32_t* d_run_prefix = reinterpret_cast<uint32_t*>(static_cast<char*>(ctx->solve_ws.ptr) + 4096 + up((run_slots + 1) * sizeof(uint32_t)));
     // dense-key candidates (unweighted, <= 16 features): the order check takes the partition route's bucket histogram along
-    static const bool force_sort = [] { const char* e = std::getenv("PDS_KEYED_SORT"); return e && e[0] == '1'; }();
+    // PDS_KEYED_SORT=1 (read per call): the sorting route for every unordered frame -- the DETERMINISM switch: the partition route's
+    // record order follows cursor atomics, so its sums are reproducible to rounding only.  solver = "svd" with the
+    // rank gate on also sorts: the partition route solves every group with the pivoted QR and marks nothing for the SVD gate.
+    const char* ks_env = std::getenv("PDS_KEYED_SORT");
+    const bool force_sort = (ks_env && ks_env[0] == '1') || (prm->solver == PDS_SOLVER_SVD && prm->singular_x_tol > 0.0);
     const bool part_candidate = !force_sort && !weights && n_feat <= 16 && !place;
     const int part_shift = part_candidate ? keyed_partition_shift<T>(n_feat) : -1;
     unsigned* d_slots = reinterpret_cast<unsigned*>(static_cast<char*>(ctx->solve_ws.ptr) + 4096 + 2 * up((run_slots + 1) * sizeof(uint32_t)));

@@ -82,6 +82,90 @@ static void host_normal_eq(const std::vector<T>& M, int p, int bias, double lamb
         for (int i = 0; i < p; ++i) G[i + (size_t)i * pp] += lambda;
 }
 
+// The reference's SVD route on one moment record (faer_solve_lr_gated with thin_svd, lr_solvers.rs:358-366; solve :284): gate on
+// sum ln sigma_i - sum ln G_ii, beta = V (U'c / sigma).  Returns false when the Jacobi iteration failed on an ungated system
+// (the caller falls back to QR, :284-287); `null` = gated / rank-deficient.
+template <typename T>
+static bool host_svd_gated(const std::vector<T>& M, int p, int bias, double l2, double gate_tol, std::vector<double>& beta, bool& null) {
+    const int pp = p + bias;
+    std::vector<double> G, c, u, s, v;
+    host_normal_eq(M, p, bias, l2, G, c);
+    const bool gate = gate_tol > 0.0;
+    double ln_den = 0.0;
+    null = false;
+    if (gate)
+        for (int i = 0; i < pp; ++i) {
+            if (G[i + (size_t)i * pp] <= 0.0) null = true;
+            else ln_den += std::log(G[i + (size_t)i * pp]);
+        }
+    const bool ok = !null && jacobi_svd(G, pp, u, s, v);
+    if (gate && !null) {
+        if (!ok) null = true;  // "SVD failure -> treat as rank-deficient" lr_solvers.rs:361-362
+        else {
+            double ln_det = 0.0;
+            for (int i = 0; i < pp; ++i) ln_det += std::log(s[i]);
+            if (ln_det - ln_den <= std::log(gate_tol)) null = true;
+        }
+    }
+    beta.assign(pp, NAN);
+    if (null) return true;
+    if (!ok) return false;
+    std::vector<double> z(pp);
+    for (int i = 0; i < pp; ++i) {
+        double acc = 0;
+        for (int r = 0; r < pp; ++r) acc += u[r + (size_t)i * pp] * c[r];
+        z[i] = acc / s[i];
+    }
+    for (int r = 0; r < pp; ++r) {
+        double acc = 0;
+        for (int i = 0; i < pp; ++i) acc += v[r + (size_t)i * pp] * z[i];
+        beta[r] = acc;
+    }
+    return true;
+}
+
+// Grouped fits: the records of the systems the streaming kernels marked (next to the rank gate, gated, broken down) through the
+// reference's factorisation for `sp.solver` -- the pivoted QR with the log-det gate (solve.hip) for "qr", the SVD gate above for
+// "svd" (on the host: the marked systems are few; per-solver gate, tests/test_linear_exprs.py:1326-1340).  d_co [n][p'], d_fl [n].
+template <typename T>
+int launch_solve_marked(pds_ctx* ctx, const T* d_rec, int64_t n, const SolveParams& sp, T* d_co, uint8_t* d_fl, const int64_t* d_rows_per_sys) {
+    if (n <= 0) return PDS_OK;
+    SolveParams sq = sp;
+    if (sp.solver != PDS_SOLVER_SVD || !(sp.gate_tol > 0.0)) {
+        sq.solver = PDS_SOLVER_QR;
+        return launch_solve<T>(ctx, d_rec, n, sq, d_co, d_fl, nullptr, d_rows_per_sys);
+    }
+    const int p = sp.p, bias = sp.add_bias ? 1 : 0, pp = p + bias, q = p + 2;
+    std::vector<T> rec((size_t)n * q * q), co((size_t)n * pp);
+    std::vector<uint8_t> fl((size_t)n, 0);
+    std::vector<int64_t> rows;
+    PDS_HIP_CHECK(hipMemcpyAsync(rec.data(), d_rec, rec.size() * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+    if (d_rows_per_sys) {
+        rows.resize((size_t)n + 1);
+        PDS_HIP_CHECK(hipMemcpyAsync(rows.data(), d_rows_per_sys, rows.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    std::vector<T> M((size_t)q * q);
+    std::vector<int64_t> retry;
+    for (int64_t k = 0; k < n; ++k) {
+        std::copy(rec.begin() + k * q * q, rec.begin() + (k + 1) * q * q, M.begin());
+        std::vector<double> beta;
+        bool null = false;
+        bool ok = true;
+        if (!rows.empty() && rows[k + 1] - rows[k] < pp) null = true, beta.assign(pp, NAN);  // "#Data < #features"
+        else ok = host_svd_gated(M, p, bias, sp.lambda, sp.gate_tol, beta, null);
+        (void)ok;  // (gated: a failed iteration is "rank-deficient", never a retry)
+        fl[k] = null ? 1 : 0;
+        for (int r = 0; r < pp; ++r) co[(size_t)k * pp + r] = (T)beta[r];
+    }
+    PDS_HIP_CHECK(hipMemcpyAsync(d_co, co.data(), co.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    PDS_HIP_CHECK(hipMemcpyAsync(d_fl, fl.data(), fl.size(), hipMemcpyHostToDevice, ctx->stream));
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // (the staging vectors live on this frame)
+    return PDS_OK;
+}
+template int launch_solve_marked<double>(pds_ctx*, const double*, int64_t, const SolveParams&, double*, uint8_t*, const int64_t*);
+template int launch_solve_marked<float>(pds_ctx*, const float*, int64_t, const SolveParams&, float*, uint8_t*, const int64_t*);
+
 struct Method {
     enum Kind { OLS, NNLS, CD } kind;
     double l1, l2;
@@ -124,40 +208,14 @@ static int lr_from_device_moments(pds_ctx* ctx, const T* d_mom, int p, const pds
         std::vector<T> M((size_t)q * q);
         PDS_HIP_CHECK(hipMemcpyAsync(M.data(), d_mom, sizeof(T) * M.size(), hipMemcpyDeviceToHost, ctx->stream));
         PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        std::vector<double> G, c, u, s, v;
-        host_normal_eq(M, p, bias, weighted ? 0.0 : m.l2, G, c);
-        const bool gate = !weighted && prm->singular_x_tol > 0.0;
-        double ln_den = 0.0;
+        std::vector<double> beta;
         bool null = false;
-        if (gate)
-            for (int i = 0; i < pp; ++i) {
-                if (G[i + (size_t)i * pp] <= 0.0) null = true;
-                else ln_den += std::log(G[i + (size_t)i * pp]);
-            }
-        bool ok = !null && jacobi_svd(G, pp, u, s, v);
-        if (gate && !null) {
-            if (!ok) null = true;  // "SVD failure -> treat as rank-deficient" lr_solvers.rs:361-362
-            else {
-                double ln_det = 0.0;
-                for (int i = 0; i < pp; ++i) ln_det += std::log(s[i]);
-                if (ln_det - ln_den <= std::log(prm->singular_x_tol)) null = true;
-            }
-        }
+        const bool ok = host_svd_gated(M, p, bias, weighted ? 0.0 : m.l2, weighted ? 0.0 : prm->singular_x_tol, beta, null);
         if (null) {
             for (int i = 0; i < pp; ++i) coeffs[i] = (T)NAN;
             if (is_null) *is_null = 1;
         } else if (ok) {
-            std::vector<double> z(pp);
-            for (int i = 0; i < pp; ++i) {
-                double acc = 0;
-                for (int r = 0; r < pp; ++r) acc += u[r + (size_t)i * pp] * c[r];
-                z[i] = acc / s[i];
-            }
-            for (int r = 0; r < pp; ++r) {
-                double acc = 0;
-                for (int i = 0; i < pp; ++i) acc += v[r + (size_t)i * pp] * z[i];
-                coeffs[r] = (T)acc;
-            }
+            for (int r = 0; r < pp; ++r) coeffs[r] = (T)beta[r];
         } else {
             // ungated SVD failure falls back to QR (lr_solvers.rs:284-287)
             SolveParams sp{p, bias, PDS_SOLVER_QR, m.l2, 0.0, 0};

@@ -222,6 +222,11 @@ template <typename T>
 int launch_solve(pds_ctx* ctx, const T* d_moments, int64_t n_sys, const SolveParams& sp, T* d_coeffs,
                  uint8_t* d_flags, T* d_inv_out, const int64_t* d_rows_per_sys /*nullable*/);
 
+// capi_lr.hpp: the marked systems of a grouped fit through the reference's factorisation for sp.solver (pivoted QR; "svd": host SVD gate)
+template <typename T>
+int launch_solve_marked(pds_ctx* ctx, const T* d_rec, int64_t n_sys, const SolveParams& sp, T* d_coeffs, uint8_t* d_flags,
+                        const int64_t* d_rows_per_sys);
+
 // solve_big.hip: p' > 64 (Cholesky on an HBM/L2 workspace, one workgroup per system); used by launch_solve
 template <typename T>
 int launch_solve_big(pds_ctx* ctx, const T* d_moments, int64_t n_sys, const SolveParams& sp, T* d_coeffs, uint8_t* d_flags,

@@ -686,12 +686,10 @@ int launch_grouped_fused(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int6
     T* co_c = reinterpret_cast<T*>(ws_take(ctx, (size_t)chunk * pp * sizeof(T)));
     uint8_t* fl_c = reinterpret_cast<uint8_t*>(ws_take(ctx, (size_t)chunk));
     if (!co_c || !fl_c) return fail(PDS_ERR_HIP, "workspace allocation failed");
-    SolveParams sq = sp;
-    sq.solver = PDS_SOLVER_QR;
     for (int64_t k0 = 0; k0 < marked; k0 += chunk) {
         const int64_t kc = std::min(chunk, marked - k0);
         if (int rc2 = launch_grouped_moments<T>(ctx, dc, n_feat, d_offsets, kc, d_mom_scratch, d_list + k0)) return rc2;
-        if (int rc2 = launch_solve<T>(ctx, d_mom_scratch, kc, sq, co_c, fl_c, nullptr, nullptr)) return rc2;
+        if (int rc2 = launch_solve_marked<T>(ctx, d_mom_scratch, kc, sp, co_c, fl_c, nullptr)) return rc2;  // (pivoted QR; "svd": SVD gate)
         hipLaunchKernelGGL((scatter_marked_kernel<T>), dim3((unsigned)((kc * pp + 255) / 256)), dim3(256), 0, ctx->stream, co_c, fl_c,
                            d_list + k0, kc, pp, d_coeffs, d_flags);
         PDS_HIP_CHECK(hipGetLastError());

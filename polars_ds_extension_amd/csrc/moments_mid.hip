@@ -1079,9 +1079,7 @@ int launch_grouped_mid_fused(pds_ctx* ctx, const DeviceCols<double>& dc, int n_f
     }
     if (h_counts[0] > 0) {  // systems next to the gate: the reference's default factorisation (pivoted QR, log-det gate)
         const int64_t nm = h_counts[0];
-        SolveParams sq = sp;
-        sq.solver = PDS_SOLVER_QR;
-        if (int rc = launch_solve<double>(ctx, sa.mark_rec, nm, sq, co_c, fl_c, nullptr, nullptr)) return rc;
+        if (int rc = launch_solve_marked<double>(ctx, sa.mark_rec, nm, sp, co_c, fl_c, nullptr)) return rc;
         hipLaunchKernelGGL(mid_scatter_kernel, dim3((unsigned)((nm * pp + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)co_c,
                            (const uint8_t*)fl_c, (const int32_t*)sa.mark_list, nm, pp, d_coeffs, d_flags);
     }

@@ -320,9 +320,28 @@ void do_lr_by(SeriesExport* in, size_t n_in, const Kwargs& kw, SeriesExport* out
     // null; the dropped rows come back as null rows.  The frame is compacted on the host, fitted, and re-expanded below.
     std::vector<uint8_t> keep;   // non-empty: the call runs on the kept rows only
     const int64_t n_full = n;
+    // "ignore": a group that holds a null fits on NaN (series_to_mat_for_lr keeps the rows, null -> NaN, linear_regression.rs:196,
+    // utils/mod.rs:146-154) and every one of ITS rows comes back NaN (valid, not null -- this library's answer for pl_lr_pred + ignore,
+    // DESIGN 7); the other groups are fitted as usual.  The nulls are zeroed for the fit and the rows of the affected keys overwritten.
+    std::vector<uint8_t> row_has_null;
+    if (any_null && want_pred && pol.kind == Policy::IGNORE) {
+        row_has_null.assign((size_t)n, 0);
+        for (auto& c : cols) {
+            if (!c.null_count) continue;
+            auto& v = c.own();
+            for (int64_t i = 0; i < n; ++i)
+                if (!bit_get(c.validity.data(), i)) {
+                    v[i] = T(0);
+                    row_has_null[i] = 1;
+                }
+            c.validity.clear();
+            c.null_count = 0;
+        }
+        any_null = false;
+    }
     if (any_null && want_pred) {
         if (pol.kind != Policy::SKIP && pol.kind != Policy::FILL)
-            raise("pl_lr_by_pred: rows with nulls take null_policy 'skip' or a fill value");
+            raise("pl_lr_by_pred: rows with nulls take null_policy 'skip', 'ignore' or a fill value");
         if (pol.kind == Policy::FILL)
             for (size_t k = 1; k < cols.size(); ++k) {
                 auto& c = cols[k];
@@ -552,6 +571,20 @@ void do_lr_by(SeriesExport* in, size_t n_in, const Kwargs& kw, SeriesExport* out
         sk.push_back(make_schema(fmt_of<T>(), "resid"));
         export_series(out, make_schema("+s", "", std::move(sk)), struct_array(n_full, std::move(kids)));
         return;
+    }
+    if (want_pred && !row_has_null.empty()) {
+        std::unordered_set<int64_t> bad;  // (the null key's rows carry its stand-in by now)
+        for (int64_t i = 0; i < n; ++i)
+            if (row_has_null[i]) bad.insert(ikey[i]);
+        T* pd = as<T>(pred_b);
+        T* rd = as<T>(resid_b);
+        const T nanv = std::numeric_limits<T>::quiet_NaN();
+        for (int64_t i = 0; i < n; ++i)
+            if (bad.count(ikey[i])) {
+                pd[i] = nanv;
+                rd[i] = nanv;
+                row_null[i] = 0;
+            }
     }
     if (want_pred) {
         // validity of the two children: none at all when no row is null (the usual case: a scan of the n flag bytes instead of

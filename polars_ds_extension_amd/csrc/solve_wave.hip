@@ -178,9 +178,7 @@ int launch_solve_wave(pds_ctx* ctx, const T* d_moments, int64_t n_sys, const Sol
     if (marked * 4 > n_sys && pp_all <= 64) {
         // most of the chunk sits next to the gate (e.g. groups with barely more rows than columns): the pivoted QR over the whole
         // chunk in place costs what it always did; compacting it 512 records at a time would cost twice that
-        SolveParams sq = sp;
-        sq.solver = PDS_SOLVER_QR;
-        return launch_solve<T>(ctx, d_moments, n_sys, sq, d_coeffs, d_flags, nullptr, d_rows_per_sys);
+        return launch_solve_marked<T>(ctx, d_moments, n_sys, sp, d_coeffs, d_flags, d_rows_per_sys);
     }
     // ---- marked systems: their records, compacted, through the pivoted QR with the log-det gate (solve.hip), results scattered back
     const int q = sp.p + 2, pp = sp.p + (sp.add_bias ? 1 : 0);
@@ -198,7 +196,7 @@ int launch_solve_wave(pds_ctx* ctx, const T* d_moments, int64_t n_sys, const Sol
                            rec_c, d_rows_per_sys, rows_c);
         // (64 features + intercept = 65 coefficients is beyond the LDS solver: the big-system solver takes those -- it has no
         //  row-count rule, and needs none: systems with too few rows were answered above and are never marked)
-        if (int rc = launch_solve<T>(ctx, rec_c, kc, sq, co_c, fl_c, nullptr, (d_rows_per_sys && pp <= 64) ? rows_c : nullptr)) return rc;
+        if (int rc = launch_solve_marked<T>(ctx, rec_c, kc, sp, co_c, fl_c, (d_rows_per_sys && pp <= 64) ? rows_c : nullptr)) return rc;
         hipLaunchKernelGGL((scatter_results_idx_kernel<T>), dim3((unsigned)((kc * pp + 255) / 256)), dim3(256), 0, ctx->stream, (const T*)co_c,
                            (const uint8_t*)fl_c, (const int32_t*)(d_list + k0), kc, pp, d_coeffs, d_flags);
         PDS_HIP_CHECK(hipGetLastError());

@@ -1085,6 +1085,43 @@ def test_grouped_mid_fused_falls_back_when_the_marked_list_overflows(pds, orc):
     assert np.median(err) < 1e-9
 
 
+@pytest.mark.parametrize("p", [5, 20, 40])
+def test_grouped_solver_svd_gate(pds, orc, p):
+    """group_by().agg(lin_reg(solver="svd")): the streaming kernels answer the clear groups, the groups next to the rank gate go
+    through the reference's SVD gate (sum ln sigma_i of X'X against sum ln G_ii, lr_solvers.rs:358-366) -- not through the pivoted
+    QR's log-det as before round 4.  Against the oracle's svd route, group by group (tests/test_linear_exprs.py:1326-1340)."""
+    rng = np.random.default_rng(600 + p)
+    G = 400
+    sizes = rng.integers(4 * p, 7 * p, size=G)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    N = int(off[-1])
+    X = rng.normal(size=(N, p))
+    y = X @ rng.normal(size=p) + 0.3 + 0.2 * rng.normal(size=N)
+    for g in range(3, G, 17):    # collinear -> gated
+        X[off[g]: off[g + 1], 2] = X[off[g]: off[g + 1], 0] - 2.0 * X[off[g]: off[g + 1], 1]
+    for k, g in enumerate(range(5, G, 13)):    # nearly collinear, on both sides of the 1e-12 gate
+        X[off[g]: off[g + 1], 3] = X[off[g]: off[g + 1], 1] + 10.0 ** (-4 - (k % 5)) * rng.normal(size=int(sizes[g]))
+    co, nu = pds.lin_reg_by(*cols_of(X), target=dev(y), group_offsets=off, add_bias=True, solver="svd")
+    co, nu = co.cpu().numpy(), nu.cpu().numpy().astype(bool)
+    co_o, nu_o = orc.grouped_lr([y] + [X[:, j] for j in range(p)], off, add_bias=True, solver="svd", nthreads=4)
+    assert np.array_equal(nu, nu_o), np.flatnonzero(nu != nu_o)[:10]
+    assert nu.sum() >= G // 17 and (~nu).sum() > G // 2
+    ok = ~nu
+    err = np.linalg.norm(co[ok] - co_o[ok], axis=1) / np.linalg.norm(co_o[ok], axis=1)
+    for g, e in zip(np.flatnonzero(ok), err):
+        if e > F64_TOL:
+            Xb = np.c_[X[off[g]: off[g + 1]], np.ones(int(sizes[g]))]
+            assert e < 64 * 2.2e-16 * np.linalg.cond(Xb.T @ Xb), (g, e)
+    # unordered dense keys with "svd": the sorting route (the partition route has no marked pass), same answers
+    if p == 5:
+        key = np.repeat(np.arange(G, dtype=np.int64), sizes)
+        perm = rng.permutation(N)
+        k2, co2, nu2 = pds.lin_reg_by_key(*cols_of(X[perm]), target=dev(y[perm]), key=dev(key[perm]), add_bias=True, solver="svd")
+        assert np.array_equal(nu2.cpu().numpy().astype(bool), nu_o)
+        co2 = co2.cpu().numpy()
+        assert np.median(np.linalg.norm(co2[ok] - co_o[ok], axis=1) / np.linalg.norm(co_o[ok], axis=1)) < 1e-10
+
+
 @pytest.mark.parametrize("p,bias", [(4, True), (15, True), (16, False), (20, True)])
 def test_grouped_weighted(pds, orc, p, bias):
     """group_by(key).agg(pds.lin_reg(..., weights=w)): per group faer_weighted_lr (lr_solvers.rs:386-409)."""

@@ -10,8 +10,10 @@ from scipy import stats
 
 
 # ------------------------------------------------------------------ (1) notebook golden vectors
-def test_golden_pred_resid_head(orc, golden):
-    # examples/basics.ipynb cell "return_pred=True": pred = X beta with the full-frame beta.
+def test_golden_pred_head_is_x_times_the_printed_beta(golden):
+    # examples/basics.ipynb cell "return_pred=True": pred = X beta with the full-frame beta, resid = y - pred.  A consistency check
+    # of the two printed cells (the 10 000-row frame is unseeded, so beta cannot be refitted): it pins the pl_lr_pred CONVENTION the
+    # oracle and the kernels restate (linear_regression.rs:704-820), not an oracle solver -- the oracle is not called here.
     g = golden["pred_head"]
     beta = np.array(golden["lin_reg_full_frame_coeffs"])
     X = np.c_[g["x1"], g["x2"]]
@@ -34,8 +36,9 @@ def test_golden_rolling_window5(orc, golden):
 
 
 # ------------------------------------------------------------------ (2) literal frames of the reference tests
-def test_golden_report_table(orc, golden):
-    """The report table the reference's notebook prints (10 000 rows, 3 features + bias: dof 9 996), f64 and f32 cells: the
+def test_golden_report_table_epilogue_with_the_oracle_t_quantile(orc, golden):
+    """Oracle pin: student_t_ppf(0.975, 9996) only -- the rest is the printed table's own consistency under the epilogue formulas.
+    The report table the reference's notebook prints (10 000 rows, 3 features + bias: dof 9 996), f64 and f32 cells: the
     columns are tied together by the epilogue arithmetic this repo restates (linear_regression.rs:861-939) -- t = beta / se,
     CI = beta -/+ t_ppf(0.975, dof) se with the reference's own Student-t quantile, adj_r2 = 1 - (1 - r2)(n - 1)/(dof - 1)."""
     n, dof = golden["report_rows"], golden["report_dof"]

@@ -668,8 +668,24 @@ def test_pl_lr_by_pred_shuffled_rows_weights_bias_and_null_groups(so, orc):
                 continue
             b = orc.pl_lr(Xf[m], yp[m], add_bias=True)
             np.testing.assert_allclose(pn[m], Xf[m] @ b[:3] + b[3], rtol=1e-9, atol=1e-10)
-    with pytest.raises(RuntimeError, match="null_policy"):
-        ph.call_plugin(so, "pl_lr_by_pred", ins_n, dict(LR, bias=True, null_policy="ignore"))
+    # "ignore": a group that holds a null fits on NaN -- all of ITS rows come back NaN (valid), the other groups as usual
+    mi = np.zeros(G * per, bool)
+    hit = np.unique(key)[[3, 40, 77]]
+    for k in hit:
+        mi[np.flatnonzero(kp == k)[:2]] = True
+    ins_i = [("key", pa.array(kp)), ("y", pa.array(yp)), ("x1", pa.array(Xp[:, 0], mask=mi))] + [
+        (f"x{j + 1}", pa.array(Xp[:, j])) for j in (1, 2)]
+    _, outi = ph.call_plugin(so, "pl_lr_by_pred", ins_i, dict(LR, bias=True, null_policy="ignore"))
+    pl_ = outi.field("pred").to_pylist()
+    rl_ = outi.field("resid").to_pylist()
+    in_hit = np.isin(kp, hit)
+    bad_group = kp == key[7 * per]
+    assert all((v is None) == bool(b) for v, b in zip(pl_, bad_group))          # only the collinear group is null
+    assert all(v is not None and np.isnan(v) for v, h in zip(pl_, in_hit) if h)  # NaN rows, not null rows
+    assert all(v is not None and np.isnan(v) for v, h in zip(rl_, in_hit) if h)
+    pi = np.array([np.nan if v is None else v for v in pl_])
+    rest = ~in_hit & ~bad_group
+    np.testing.assert_allclose(pi[rest], pred[rest], rtol=1e-10, atol=1e-12)     # untouched groups: the null-free call's answers
 
 
 @pytest.mark.gpu
