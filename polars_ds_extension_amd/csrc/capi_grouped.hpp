@@ -525,7 +525,9 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
     const int64_t run_cap = partition ? cap : n_rows;  // unique keys, counts, offsets: at most one per row / per group
     size_t need = temp_bytes + 3 * up((size_t)(run_cap + 1) * 8) + 8192;
     if (space == PDS_HOST) need += col_bytes * nc;
-    if (space == PDS_HOST || !coeffs) need += up((size_t)cap * pp * sizeof(T)) + up((size_t)cap);
+    // (the same predicates as the take() sites below: a device frame with coeffs but no is_null still takes its flags here)
+    if (space == PDS_HOST || !coeffs) need += up((size_t)cap * pp * sizeof(T));
+    if (space == PDS_HOST || !is_null) need += up((size_t)cap);
     if (partition) need += keyed_partition_workspace<T>(n_feat, n_rows, part_buckets) + up(sizeof(T*) * (size_t)std::max(nc, 18));
     else if (!sorted) need += 2 * key_bytes + 2 * idx_bytes + col_bytes * nc + up((size_t)n_rows * nc * sizeof(T)) + up(2 * (size_t)nc * sizeof(T*)) + 1024;
     if (want_pred) need += up(sizeof(T*) * (size_t)std::max(nc, 18)) + (space == PDS_HOST ? 2 * col_bytes + up((size_t)n_rows) : 0);

@@ -133,13 +133,24 @@ static int lr_by_key_multi_impl(pds_ctx* const* ctxs, int n_ctx, int n_slices, c
     board.coeffs = coeffs;
     board.is_null = is_null;
     const int workers = std::min(n_ctx, S);
-    auto work = [&](int c) {
+    auto work_slices = [&](int c) {
         for (int s = c; s < S; s += workers) {
-            {
-                std::lock_guard<std::mutex> g(board.m);
-                if (board.failed && board.unsorted) return;  // (after an overflow the remaining slices still count their groups)
-            }
             const int64_t r0 = bounds[s], rows = bounds[s + 1] - r0;
+            {
+                std::unique_lock<std::mutex> g(board.m);
+                if (board.failed && board.unsorted) return;
+                if (board.failed) {
+                    // after an overflow (or another slice's failure) the remaining slices only COUNT their groups, on the host: the
+                    // caller learns the total it has to size for without this slice's columns crossing the link for nothing
+                    g.unlock();
+                    int64_t cnt = rows > 0 ? 1 : 0;
+                    for (int64_t i = r0 + 1; i < r0 + rows; ++i) cnt += keys[i] != keys[i - 1];
+                    g.lock();
+                    if (board.ng[s] < 0) board.ng[s] = cnt;
+                    board.cv.notify_all();
+                    continue;
+                }
+            }
             std::vector<const T*> ptrs(nc);
             for (int k = 0; k < nc; ++k) ptrs[k] = cols[k] + r0;
             SlicePlace<T> place(&board, s);
@@ -154,6 +165,19 @@ static int lr_by_key_multi_impl(pds_ctx* const* ctxs, int n_ctx, int n_slices, c
                 }
                 board.fail_with(rc, g_err);  // (g_err is this worker's thread-local message)
             }
+        }
+    };
+    // (an exception in a worker -- bad_alloc from a vector -- must not reach std::terminate inside the host process)
+    auto work = [&](int c) {
+        try {
+            work_slices(c);
+        } catch (const std::exception& e) {
+            {
+                std::lock_guard<std::mutex> g(board.m);
+                for (int s = c; s < S; s += workers)
+                    if (board.ng[s] < 0) board.ng[s] = 0;
+            }
+            board.fail_with(PDS_ERR_HIP, std::string("sliced fit: ") + e.what());
         }
     };
     std::vector<std::thread> threads;

@@ -183,14 +183,11 @@ static int report_impl(pds_ctx* ctx, const T* const* cols, const T* weights, int
     // those entries are rounded to f32 and syy - sy^2 / n would cancel for |mean| >> std, so y is summed once more in f64.
     double mom_y[2] = {0.0, 0.0};
     if (derive_var) {
-        if constexpr (std::is_same<T, double>::value) {
-            PDS_HIP_CHECK(hipMemcpyAsync(&mom_y[0], d_mom + p + (size_t)(p + 1) * q, sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
-            PDS_HIP_CHECK(hipMemcpyAsync(&mom_y[1], d_mom + (p + 1) + (size_t)(p + 1) * q, sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
-        } else {
-            double* d_ys = reinterpret_cast<double*>(ws_take(ctx, 64));
-            if (int rc = launch_y_sums<T>(ctx, dc.h_ptrs[p], n_rows, d_ys)) return rc;
-            PDS_HIP_CHECK(hipMemcpyAsync(mom_y, d_ys, sizeof(mom_y), hipMemcpyDeviceToHost, ctx->stream));
-        }
+        // var(y) as Polars' `target.var()` delivers it to the reference (numerically stable): from the sums of y - y[0], one more
+        // pass over the target column -- the raw moments of the Gram record (sum y, sum y^2) cancel when |mean| >> std
+        double* d_ys = reinterpret_cast<double*>(ws_take(ctx, 64));
+        if (int rc = launch_y_sums<T>(ctx, dc.h_ptrs[p], n_rows, d_ys, true)) return rc;
+        PDS_HIP_CHECK(hipMemcpyAsync(mom_y, d_ys, sizeof(mom_y), hipMemcpyDeviceToHost, ctx->stream));
     }
     PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (derive_var) {

@@ -284,7 +284,7 @@ int launch_leverage_mid(pds_ctx* ctx, const DeviceCols<double>& dc, int n_feat, 
 // ---- pass2.hip ----
 // sum y and sum y^2 of one device column in f64 (fixed-order two-stage reduction): d_out[0..1]
 template <typename T>
-int launch_y_sums(pds_ctx* ctx, const T* d_y, int64_t n_rows, double* d_out);
+int launch_y_sums(pds_ctx* ctx, const T* d_y, int64_t n_rows, double* d_out, bool shifted = false /* sums of y - y[0] */);
 // streaming residual pass: pred/resid (nullable outputs), sums: [0]=sum e^2, [1]=sum w e^2,
 // meat (p' x p') = sum s_i x_i x_i' with s_i = e_i^2 * hc_scale(h_ii) when meat != null.
 template <typename T>

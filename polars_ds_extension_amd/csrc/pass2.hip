@@ -445,13 +445,16 @@ int launch_pass2(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_ro
 
 // ---- sum y, sum y^2 in f64 (the f32 report's own var(y): capi_report.hpp) -- per-block partials, fixed-order finish
 template <typename T>
-__global__ __launch_bounds__(256) void y_sums_kernel(const T* __restrict__ y, int64_t n, double* __restrict__ part) {
+__global__ __launch_bounds__(256) void y_sums_kernel(const T* __restrict__ y, int64_t n, double* __restrict__ part, int shifted) {
     __shared__ double sh[2][4];
     double s = 0.0, ss = 0.0;
+    // shifted: sums of (y - y[0]) -- the variance from them is the textbook shifted-data form: with y[0] a sample of the data the
+    // subtraction ss - s^2 / n no longer cancels when |mean| >> std (timestamps, prices with an offset)
+    const double c = (shifted && n > 0) ? (double)y[0] : 0.0;
     const int64_t per = (n + gridDim.x - 1) / gridDim.x;
     const int64_t a = (int64_t)blockIdx.x * per, b = a + per < n ? a + per : n;
     for (int64_t i = a + threadIdx.x; i < b; i += 256) {
-        const double v = (double)y[i];
+        const double v = (double)y[i] - c;
         s += v;
         ss = fma(v, v, ss);
     }
@@ -480,16 +483,16 @@ __global__ void y_sums_finish_kernel(const double* __restrict__ part, int nblock
     out[1] = ss;
 }
 template <typename T>
-int launch_y_sums(pds_ctx* ctx, const T* d_y, int64_t n_rows, double* d_out) {
+int launch_y_sums(pds_ctx* ctx, const T* d_y, int64_t n_rows, double* d_out, bool shifted) {
     const int nb = (int)std::min<int64_t>(std::max<int64_t>((n_rows + 4095) / 4096, 1), (int64_t)ctx->num_cus * 4);
     double* part = reinterpret_cast<double*>(ws_take(ctx, sizeof(double) * 2 * (size_t)nb));
-    hipLaunchKernelGGL((y_sums_kernel<T>), dim3(nb), dim3(256), 0, ctx->stream, d_y, n_rows, part);
+    hipLaunchKernelGGL((y_sums_kernel<T>), dim3(nb), dim3(256), 0, ctx->stream, d_y, n_rows, part, shifted ? 1 : 0);
     hipLaunchKernelGGL(y_sums_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, (const double*)part, nb, d_out);
     PDS_HIP_CHECK(hipGetLastError());
     return PDS_OK;
 }
-template int launch_y_sums<double>(pds_ctx*, const double*, int64_t, double*);
-template int launch_y_sums<float>(pds_ctx*, const float*, int64_t, double*);
+template int launch_y_sums<double>(pds_ctx*, const double*, int64_t, double*, bool);
+template int launch_y_sums<float>(pds_ctx*, const float*, int64_t, double*, bool);
 
 template int launch_pass2<double>(pds_ctx*, const DeviceCols<double>&, int, int64_t, int, bool, const double*,
                                   const double*, int, double*, double*, double*, double*);

@@ -45,7 +45,17 @@ std::unique_ptr<ArrowSchema> make_schema(const std::string& format, const std::s
 // keyed by the block size, at most kPinnedCacheBytes cached; Polars frees a result through the array's release callback,
 // which brings its blocks back here.  No device / no pinned memory left: pageable storage as before.
 struct PinnedPool {
-    static constexpr size_t kMinBytes = (size_t)4 << 20, kMaxBytes = (size_t)4 << 30, kPinnedCacheBytes = (size_t)6 << 30;
+    static constexpr size_t kMinBytes = (size_t)4 << 20, kMaxBytes = (size_t)4 << 30;
+    // page-locked memory kept cached between results: 1 GiB unless PDS_PLUGIN_PINNED_CACHE_MB says otherwise (0: nothing is cached).
+    // Pinned pages are taken from every other process on the host, so the cache is bounded, evicts its largest blocks first when a
+    // returning block would exceed the bound, and serves a request from any cached block up to twice its size.
+    static size_t cache_cap() {
+        static const size_t cap = [] {
+            const char* e = std::getenv("PDS_PLUGIN_PINNED_CACHE_MB");
+            return e ? (size_t)std::max<long long>(0, std::atoll(e)) << 20 : (size_t)1 << 30;
+        }();
+        return cap;
+    }
     std::mutex m;
     std::multimap<size_t, void*> free_blocks;   // size -> block
     std::map<void*, size_t> live;               // blocks handed out (size)
@@ -66,12 +76,13 @@ struct PinnedPool {
         {
             std::lock_guard<std::mutex> g(m);
             if (disabled) return nullptr;
-            auto it = free_blocks.find(sz);
-            if (it != free_blocks.end()) {
+            auto it = free_blocks.lower_bound(sz);  // best fit: the smallest cached block that holds the request, up to 2x its size
+            if (it != free_blocks.end() && it->first <= 2 * sz) {
                 void* p = it->second;
+                const size_t have = it->first;
                 free_blocks.erase(it);
-                cached -= sz;
-                live[p] = sz;
+                cached -= have;
+                live[p] = have;
                 return p;
             }
         }
@@ -87,19 +98,28 @@ struct PinnedPool {
     }
     bool give_back(void* p) {  // false: not one of ours
         size_t sz = 0;
+        std::vector<void*> evicted;
         {
             std::lock_guard<std::mutex> g(m);
             auto it = live.find(p);
             if (it == live.end()) return false;
             sz = it->second;
             live.erase(it);
-            if (cached + sz <= kPinnedCacheBytes) {
+            if (sz <= cache_cap()) {
+                // make room by unpinning the largest cached blocks (freed below, outside the lock)
+                while (cached + sz > cache_cap() && !free_blocks.empty()) {
+                    auto last = std::prev(free_blocks.end());
+                    evicted.push_back(last->second);
+                    cached -= last->first;
+                    free_blocks.erase(last);
+                }
                 free_blocks.emplace(sz, p);
                 cached += sz;
-                return true;
+                p = nullptr;
             }
         }
-        (void)pds_host_free(p);
+        for (void* e : evicted) (void)pds_host_free(e);
+        if (p) (void)pds_host_free(p);
         return true;
     }
 };

@@ -115,7 +115,8 @@ def _with_group_ids(df, by):
     (frame with the id column `__pds_gid`, the key table [id, *by]).  A single integer key column does not need this.
     """
     cols = [by] if isinstance(by, str) else list(by)
-    keys = df.select(cols).unique(maintain_order=True).with_row_index(_GID)
+    # (the plugin returns its key field as Int64 and `with_row_index` makes UInt32: Polars refuses to join the two)
+    keys = df.select(cols).unique(maintain_order=True).with_row_index(_GID).with_columns(_pl().col(_GID).cast(_pl().Int64))
     return _join(df, keys, on=cols), keys
 
 
@@ -137,7 +138,10 @@ def lin_reg_by_group(df, by, *x, target, return_pred: bool = False, **kwargs):
         ids, _ = _with_group_ids(df, by)
         return ids.with_columns(lin_reg(*x, target=target, by=_GID, return_pred=True, **kwargs)).unnest("lr_pred").drop(_GID)
     if _is_integer_key(df, by):
-        return df.select(lin_reg(*x, target=target, by=by, **kwargs)).unnest("coeffs_by")
+        # (the key field comes back Int64 under the key column's name: back to the frame's own integer dtype, so that callers
+        #  -- lin_reg_over below -- can join it onto the frame)
+        res = df.select(lin_reg(*x, target=target, by=by, **kwargs)).unnest("coeffs_by")
+        return res.with_columns(_pl().col(by).cast(df.schema[by]))
     ids, keys = _with_group_ids(df, by)
     res = ids.select(lin_reg(*x, target=target, by=_GID, **kwargs)).unnest("coeffs_by")
     return _join(keys, res, on=[_GID]).drop(_GID)

@@ -353,6 +353,10 @@ class DataFrame:
     def join(self, other, on, how="left", nulls_equal=False, join_nulls=False):
         assert how == "left", "mini_polars: left joins only"
         on = [on] if isinstance(on, str) else list(on)
+        for k in on:  # real Polars: SchemaError "datatypes of join keys don't match"
+            lt, rt = _combine(self.cols[k]).type, _combine(other.cols[k]).type
+            if lt != rt:
+                raise TypeError(f"datatypes of join keys don't match - `{k}`: {lt} on left does not match `{k}`: {rt} on right")
         match_nulls = nulls_equal or join_nulls
         table = {}
         for j, r in enumerate(other._key_rows(on)):

@@ -98,10 +98,20 @@ def call_plugin(lib: C.CDLL, symbol: str, inputs, kwargs: dict | None):
     return field, out
 
 
-def output_field(lib: C.CDLL, symbol: str) -> pa.Field:
+def output_field(lib: C.CDLL, symbol: str, input_fields=None) -> pa.Field:
+    """`input_fields`: the pa.Field list Polars passes as the expression's input schema (None: no inputs, as before)."""
     ret = ArrowSchema()
     fn = getattr(lib, "_polars_plugin_field_" + symbol)
     fn.restype = None
     fn.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(ArrowSchema)]
-    fn(None, 0, C.byref(ret))
+    if not input_fields:
+        fn(None, 0, C.byref(ret))
+    else:
+        arr = (ArrowSchema * len(input_fields))()
+        for i, f in enumerate(input_fields):
+            f._export_to_c(C.addressof(arr[i]))
+        fn(C.cast(arr, C.c_void_p), len(input_fields), C.byref(ret))
+        for i in range(len(input_fields)):  # (the callee borrows them)
+            if arr[i].release:
+                C.CFUNCTYPE(None, C.POINTER(ArrowSchema))(arr[i].release)(C.byref(arr[i]))
     return pa.Field._import_from_c(C.addressof(ret))

@@ -435,6 +435,20 @@ def test_report_f32_derived_variance_does_not_cancel(pds, f32):
     assert abs(float(a["r2"][0]) - float(b["r2"][0])) < 1e-5, (a["r2"], b["r2"])
 
 
+def test_report_derived_variance_with_a_large_offset(pds):
+    """f64, |mean(y)| / std(y) = 1e9 (timestamps, prices with an offset): the raw-moment formula (sum y^2 - (sum y)^2 / n) loses
+    every digit there (1e-16 * 1e18); the derived var(y) comes from sums of y - y[0] instead and r2 matches the one computed with
+    the centred variance -- what Polars' `target.var()` hands the reference."""
+    rng = np.random.default_rng(43)
+    n = 300_000
+    X = rng.normal(size=(n, 3))
+    y = 1.0e9 + X @ np.array([0.5, -0.25, 0.125]) + 0.1 * rng.normal(size=n)
+    yv = float(np.var(y, ddof=1))
+    a = pds.lin_reg_report(*cols_of(X), target=dev(y), add_bias=True)
+    b = pds.lin_reg_report(*cols_of(X), target=dev(y), add_bias=True, y_var=yv)
+    assert 0.5 < float(b["r2"][0]) < 1.0 and abs(float(a["r2"][0]) - float(b["r2"][0])) < 1e-6, (a["r2"][0], b["r2"][0])
+
+
 def test_default_context_is_per_thread(pds):
     """Python threads calling the functional API concurrently get their own context (stream, workspace, staging)."""
     from concurrent.futures import ThreadPoolExecutor

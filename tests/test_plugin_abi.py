@@ -243,6 +243,12 @@ def test_output_fields(so):
     assert f.name == "lin_reg_report" and [c.name for c in f.type] == ["features", "beta", "std_err", "t", "p>|t|", "0.025", "0.975", "r2", "adj_r2"]
     f = ph.output_field(so, "pl_rolling_lr")
     assert [c.name for c in f.type] == ["coeffs", "pred"]
+    # pl_lr_by: the key field carries the key COLUMN's name (what the exported array is called), as Int64
+    ins = [pa.field("gid", pa.int32()), pa.field("y", pa.float64()), pa.field("x1", pa.float64())]
+    f = ph.output_field(so, "pl_lr_by", ins)
+    assert [c.name for c in f.type] == ["gid", "coeffs"] and f.type[0].type == pa.int64()
+    assert [c.name for c in ph.output_field(so, "pl_lr_by_f32", ins).type] == ["gid", "coeffs"]
+    assert [c.name for c in ph.output_field(so, "pl_lr_by").type] == ["key", "coeffs"]
 
 
 # ---------------------------------------------------------------------------------------------------- GPU

@@ -202,6 +202,14 @@ def t_group_pred_over_and_any_key(path, orc):
         np.testing.assert_allclose(out["pred"].to_numpy()[m], Xs[perm][m] @ b[:2] + b[2], rtol=1e-9, atol=1e-11)
         for row in np.flatnonzero(m)[:3]:
             np.testing.assert_allclose(over["coeffs"].to_list()[row], b, rtol=1e-9, atol=1e-11)
+    # ---- an integer key that is not Int64: the plugin's key field is Int64, Polars joins only equal dtypes
+    d2i = pl.DataFrame({"k": key[perm].astype(np.int32), "y": ys[perm], "x1": Xs[perm, 0], "x2": Xs[perm, 1]})
+    by32 = px.lin_reg_by_group(d2i, "k", "x1", "x2", target="y", add_bias=True)
+    assert str(by32.schema["k"]) == str(d2i.schema["k"]) and len(by32) == G
+    over32 = px.lin_reg_over(d2i, "k", "x1", "x2", target="y", add_bias=True)
+    assert len(over32) == G * per
+    for row in (0, 17, G * per - 1):
+        np.testing.assert_allclose(over32["coeffs"].to_list()[row], over["coeffs"].to_list()[row], rtol=1e-12)
     # ---- string keys, two key columns, null keys
     names = np.array(["ash", "birch", None, "cedar"], dtype=object)
     s_key = names[rng.integers(0, 4, size=400)]
