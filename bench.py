@@ -45,7 +45,7 @@ sys.path.insert(0, str(ROOT))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-PROFILE_TAG = "r03"     # profiles/<tag>_traffic.json: HBM bytes per launch from the rocprofv3 PMC passes
+PROFILE_TAG = "r04"     # profiles/<tag>_traffic.json: HBM bytes per launch from the rocprofv3 PMC passes
 
 
 def _gen_frame(torch, dev, seed, G, R, P):
@@ -175,19 +175,21 @@ def main() -> int:
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     # HBM bytes per launch measured offline with rocprofv3 PMC passes (profiles/<tag>_traffic.json, committed)
     traffic = None
-    for tag in (PROFILE_TAG, "r02", "r01"):
+    traffic_source = None
+    for tag in (PROFILE_TAG, "r03", "r02", "r01"):
         try:
             tj = json.loads((ROOT / "profiles" / f"{tag}_traffic.json").read_text())["kernels"]
             want = "pds::grouped_stream_kernel<double, 16," if fused else "pds::grouped_moments_kernel<double>"
             hit = [v for k, v in tj.items() if k.startswith(want)]
             if hit and G == 1_000_000 and R == 100 and P == 16 and launches_per_step == 1:
                 traffic = int(hit[0]["hbm_bytes_per_launch"])
+                traffic_source = f"profiles/{tag}_traffic.json (offline rocprofv3 PMC passes of this kernel on this workload, not a counter of this run)"
                 break
         except Exception:
             continue
     roofline = {
         "bound": "hbm", "kernel": "grouped_stream_kernel<double,16,cholesky> (Gram + solve fused)" if fused else "grouped_moments_kernel<double>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
         "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches_per_step,
         "launch_ms_min_median_max": [round(launch_ms[0], 4), round(launch_ms[len(launch_ms) // 2], 4), round(launch_ms[-1], 4)] if launch_ms else None,
         "algorithmic_bytes_per_launch": int(alg_bytes),
@@ -205,8 +207,9 @@ def main() -> int:
             b.copy_(a)
         torch.cuda.synchronize(dev)
         copy_gbps = 5 * 2 * (1 << 30) / (time.perf_counter() - t0) / 1e9
-        roofline["measured_copy_GBps"] = round(copy_gbps, 1)  # read + write bytes of a 1 GiB device-to-device copy
-        roofline["frac_of_measured_copy"] = round(achieved / copy_gbps, 4)
+        # (read + write bytes of a 1 GiB device-to-device copy: a reference figure of the box, NOT a ceiling for a read-only stream --
+        #  the achievable read stream of this box is `read_stream_GBps` below, the single-OLS Gram kernel on the same frame)
+        roofline["measured_copy_GBps"] = round(copy_gbps, 1)
         del a, b
 
     # ---- config 2 on the same frame: single OLS Gram build (pds_moments), HBM GB/s
@@ -226,6 +229,8 @@ def main() -> int:
         gram = {"workload": f"single OLS Gram build, {N:.0e} rows x {P} f64 feats", "algorithmic_GB": round(gb, 3),
                 "avg_launch_ms": round(g_ms, 4), "achieved_GBps": round(gb / (g_ms * 1e-3), 1),
                 "frac_of_hbm_peak": round(gb / (g_ms * 1e-3) / HBM_PEAK_GBPS, 4)}
+        roofline["read_stream_GBps"] = gram["achieved_GBps"]  # what a pure read stream of these columns reaches on this box (Gram kernel)
+        roofline["frac_of_read_stream"] = round(achieved / gram["achieved_GBps"], 4) if gram["achieved_GBps"] else None
 
     # ---- BASELINE.json configs[2] as written (8 features; the headline metric is quoted on 16 -- SURVEY.md 8d asks for
     # both): the same groups on the first 8 feature columns

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (via gpurun): collects everything profiles/rNN_* is built from into gpurun_out/prof/.
-#   bash tools/profile_round.sh        then, back in the repo:  python tools/summarize_profiles.py r03
+#   bash tools/profile_round.sh        then, back in the repo:  python tools/summarize_profiles.py r04
 # PMC passes are separate runs with --kernel-trace only (never combined with sys/hip/hsa traces).
 # Every profiler run is under `timeout` and writes to a file (tools/README.md, GPU-box hygiene).
 set -u
@@ -36,4 +36,22 @@ cp $(find /tmp/p7 -name "*kernel_stats.csv" | head -1) $OUT/wide_kernel_stats.cs
 timeout -k 5 200 python -u $ROOT/tools/grouped_mid_width.py > $OUT/grouped_mid.log 2>&1
 PDS_SOLVE_WAVE=0 timeout -k 5 300 python -u $ROOT/tools/grouped_mid_width.py 2>&1 | sed 's/^/[PDS_SOLVE_WAVE=0: LDS pivoted QR for every system] /' >> $OUT/grouped_mid.log
 timeout -k 5 100 python -u $ROOT/tools/sorted_keys_prof.py >> $OUT/keyed_run.log 2>&1
+# round 4: HBM counters of the mid-width kernels (moments_mid, leverage_mid, fused report), the grouped 17 .. 32-feature stream and the
+# grouped pred pass; the 16 -> 17 feature cliff; matrix-pipe / wait-state counters of the headline kernel with the Gram kernel as control
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/p8 && timeout -k 5 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/p8 -o w -- python -u $ROOT/tools/wide_report_prof.py > $OUT/pmc_wide_$c.log 2>&1
+  cp $(find /tmp/p8 -name "*counter_collection.csv" | head -1) $OUT/pmc_wide_$c.csv
+  rm -rf /tmp/p9 && timeout -k 5 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/p9 -o g -- python -u $ROOT/tools/grouped_mid_width.py > $OUT/pmc_gmid_$c.log 2>&1
+  cp $(find /tmp/p9 -name "*counter_collection.csv" | head -1) $OUT/pmc_gmid_$c.csv
+  rm -rf /tmp/p10 && timeout -k 5 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/p10 -o q -- python -u $ROOT/tools/ab_quick.py pred > $OUT/pmc_pred_$c.log 2>&1
+  cp $(find /tmp/p10 -name "*counter_collection.csv" | head -1) $OUT/pmc_pred_$c.csv
+done
+timeout -k 5 300 python -u $ROOT/tools/grouped_width_cliff.py > $OUT/width_cliff.log 2>&1
+PDS_GROUPED_MID_FUSED=0 timeout -k 5 300 python -u $ROOT/tools/grouped_width_cliff.py >> $OUT/width_cliff.log 2>&1
+k=0
+for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAVES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_FLAT SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "GRBM_GUI_ACTIVE"; do
+  k=$((k+1))
+  rm -rf /tmp/p11 && timeout -k 5 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/p11 -o s -- python -u $ROOT/bench.py --steps 3 --warmup 1 --no-cpu --no-extras > $OUT/pmc_sq_$k.log 2>&1
+  f=$(find /tmp/p11 -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp $f $OUT/pmc_sq_$k.csv
+done
 ls -la $OUT

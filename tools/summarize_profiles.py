@@ -140,5 +140,44 @@ if kf.exists() and kw.exists():
             kt[k] = {"read_bytes_corrected": rd, "write_bytes": wr, "launches_sampled": f2[k][1]}
     (OUT / f"{rnd}_keyed_traffic.json").write_text(json.dumps(kt, indent=1) + "\n")
     md.append("")
+# ---- round 4: traffic of the mid-width kernels / grouped stream / grouped pred against their algorithmic bytes, the width cliff, SQ counters
+mid = {}
+for tag in ("wide", "gmid", "pred"):
+    fp, wp = SRC / f"pmc_{tag}_FETCH_SIZE.csv", SRC / f"pmc_{tag}_WRITE_SIZE.csv"
+    if fp.exists() and wp.exists():
+        f2, w2 = pmc(fp), pmc(wp)
+        for k in f2:
+            rd, wr = 2.0 * f2[k][0] * 1024, w2.get(k, (0.0, 0))[0] * 1024
+            if rd + wr > 2e8:
+                mid[f"{tag}: {k}"] = {"read_bytes_corrected": rd, "write_bytes": wr, "launches_averaged": f2[k][1]}
+if mid:
+    (OUT / f"{rnd}_mid_traffic.json").write_text(json.dumps({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, averaged over ALL launches of a kernel in "
+                                                              "tools/wide_report_prof.py (2e7 rows x 64 / 32 / 20 f64: 10.4 / 5.28 / 3.36 GB per stream), tools/grouped_mid_width.py, "
+                                                              "tools/ab_quick.py pred (C3 frame: 1e8 x 9 f64 in, pred + resid out); read = 2 x FETCH_SIZE KiB x 1024", "kernels": mid}, indent=1) + "\n")
+    md += ["## Round-4 counters: mid-width kernels, grouped stream, grouped pred (PMC averages over the launches of each tool run)", "",
+           "| run: kernel | read MB | write MB | launches |", "|---|---|---|---|"]
+    for k, v in mid.items():
+        md.append(f"| `{k}` | {v['read_bytes_corrected'] / 1e6:.1f} | {v['write_bytes'] / 1e6:.1f} | {v['launches_averaged']} |")
+    md.append("")
+wc = SRC / "width_cliff.log"
+if wc.exists():
+    lines = [l for l in wc.read_text().splitlines() if l.startswith(("#", "1e6"))]
+    md += ["## The 16 -> 17 feature cliff (`tools/grouped_width_cliff.py`; second block: `PDS_GROUPED_MID_FUSED=0`)", "", "```", *lines, "```", ""]
+sq = {}
+for f in sorted(SRC.glob("pmc_sq_*.csv")):
+    for r in csv.DictReader(open(f)):
+        n = short(r["Kernel_Name"])
+        for tagk, key in (("grouped_stream_kernel<double, 16", "grouped_stream_kernel<double,16> (headline)"), ("moments_small_kernel<double, 0", "moments_small_kernel<double,0> (Gram, control)")):
+            if tagk in r["Kernel_Name"]:
+                sq.setdefault(key, defaultdict(list))[r["Counter_Name"]].append(float(r["Counter_Value"]))
+if sq:
+    table = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in sq.items()}
+    (OUT / f"{rnd}_pmc_grouped.json").write_text(json.dumps(table, indent=1) + "\n")
+    names = sorted({c for d in table.values() for c in d})
+    md += ["## SQ counters per launch: the fused grouped kernel against the Gram kernel (`bench.py --steps 3 --warmup 1 --no-cpu --no-extras`, one counter set per pass)", "",
+           "| counter | " + " | ".join(table) + " |", "|---|" + "---|" * len(table)]
+    for c in names:
+        md.append(f"| {c} | " + " | ".join(f"{table[k].get(c, float('nan')):.4g}" for k in table) + " |")
+    md.append("")
 (OUT / f"{rnd}_summary.md").write_text("\n".join(md))
 print("wrote", sorted(p.name for p in OUT.glob(f"{rnd}_*")))
