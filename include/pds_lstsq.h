@@ -351,8 +351,13 @@ int pds_lr_by_key_f32(pds_ctx* ctx, const float* const* cols, const int64_t* key
  * s mod n_ctx on that context's device and stream from its own host thread, and its keys / coefficients / null flags land
  * directly in the piece of the outputs that follows the groups of the slices in front of it.  Contexts on DIFFERENT devices:
  * every device pulls its shard over its own link.  Several contexts on ONE device: a slice's transfer overlaps the previous
- * slice's fit and result copy.  Results are identical to pds_lr_by_key_* (same kernels per group).  Keys that are not in
- * order (or n_ctx == 1 with one slice) take pds_lr_by_key_* on ctxs[0].  Arguments as pds_lr_by_key_* (space = PDS_HOST).
+ * slice's fit and result copy.  Results are identical to pds_lr_by_key_* (same kernels per group).
+ * Keys that are NOT in order (round 4; SURVEY.md 8(e) row C3 "hash(key) % R", here without moving rows): one row slice per context
+ * whatever the order; every context builds the id-indexed moment table of its rows (dense integer keys, <= 16 features: the
+ * partition route of pds_lr_by_key_*), the tables are summed on ctxs[0] (same device: in place; another device: hipMemcpyPeer),
+ * which lists the groups and solves them -- one exchange of (key range) x (p+2)(p+3)/2 doubles per extra context.  Frames the
+ * partition route does not take (sparse keys, wider frames, PDS_KEYED_SORT=1) and n_ctx == 1 take pds_lr_by_key_* on ctxs[0].
+ * Arguments as pds_lr_by_key_* (space = PDS_HOST).
  */
 int pds_lr_by_key_multi_f64(pds_ctx* const* ctxs, int n_ctx, int n_slices, const double* const* cols, const int64_t* keys, int n_feat,
                             int64_t n_rows, const pds_lr_params* prm, int64_t max_groups, int64_t* out_keys, double* coeffs,
@@ -374,6 +379,33 @@ int pds_lr_by_key_pred_multi_f64(pds_ctx* const* ctxs, int n_ctx, int n_slices, 
 int pds_lr_by_key_pred_multi_f32(pds_ctx* const* ctxs, int n_ctx, int n_slices, const float* const* cols, const float* weights,
                                  const int64_t* keys, int n_feat, int64_t n_rows, const pds_lr_params* prm, float* pred, float* resid,
                                  uint8_t* row_null);
+/*
+ * The three exchange steps of SURVEY.md 8(e) for a host that drives SEVERAL devices from ONE process (a Rust plugin inside the
+ * Polars process: no launcher, no RCCL communicator) -- peer copies between the contexts' devices plus one kernel, each ordered on
+ * the contexts' own streams; every call returns after all of its contexts' streams have been synchronised.  A host with one
+ * process per device uses its collective library for the same three steps (python: polars_ds_extension_amd/parallel.py over
+ * torch.distributed / RCCL); the compute entry points on either side are the same (pds_moments_*, pds_lr_from_moments_*,
+ * pds_report_partials_*, pds_recursive_lr_seeded_*, pds_lr_grouped_*).
+ *   pds_allreduce_sum_f64   bufs[c]: `count` doubles resident on ctxs[c]'s device (moment blocks, report partials, the seeds of the
+ *                           expanding fit); afterwards every buffer holds the element-wise sum in rank order 0, 1, ..: rows C2 /
+ *                           C5 ("all-reduce of the Gram block") and C4 ("prefix Gram": with `prefix != 0` buffer c receives the
+ *                           sum of buffers 0 .. c-1 instead -- the exclusive scan the row-sharded expanding fit seeds with).
+ *   pds_scatter_rows_f64    a frame resident on ctxs[0]'s device: column k's rows [bounds[c], bounds[c+1]) -> dst[c][k] on ctxs[c]'s
+ *                           device (row C3, device-resident frame: "root -> peers, all links at once"); dst[0] may be null (rank
+ *                           0 keeps reading the frame in place).
+ *   pds_gather_f64          src[c]: counts[c] doubles on ctxs[c]'s device -> dst on ctxs[0]'s device, back to back in rank order
+ *                           (row C3: the coefficient blocks of the ranks' groups).
+ * f32 twins move floats (the all-reduce sums them in f64 on the way).
+ */
+int pds_allreduce_sum_f64(pds_ctx* const* ctxs, int n_ctx, double* const* bufs, int64_t count, int prefix);
+int pds_allreduce_sum_f32(pds_ctx* const* ctxs, int n_ctx, float* const* bufs, int64_t count, int prefix);
+int pds_scatter_rows_f64(pds_ctx* const* ctxs, int n_ctx, const double* const* cols, int n_cols, const int64_t* bounds,
+                         double* const* const* dst);
+int pds_scatter_rows_f32(pds_ctx* const* ctxs, int n_ctx, const float* const* cols, int n_cols, const int64_t* bounds,
+                         float* const* const* dst);
+int pds_gather_f64(pds_ctx* const* ctxs, int n_ctx, const double* const* src, const int64_t* counts, double* dst);
+int pds_gather_f32(pds_ctx* const* ctxs, int n_ctx, const float* const* src, const int64_t* counts, float* dst);
+
 /* Page-locked host storage (hipHostMalloc, portable across devices) for result buffers the caller owns: device-to-host copies
  * into it run at the link rate.  The plugin layer keeps the large Arrow result buffers in such storage (plugin_arrow_out.hpp). */
 int pds_host_alloc(size_t bytes, void** out);

@@ -9,7 +9,9 @@ from . import config  # noqa: F401
 from . import linear_models  # noqa: F401  (LR / ElasticNet / OnlineLR over NumPy or CUDA tensors)
 from .lstsq import (  # noqa: F401
     Context,
+    allreduce_sum,
     default_context,
+    gather,
     gram_moments,
     lin_reg,
     lin_reg_by,
@@ -24,6 +26,7 @@ from .lstsq import (  # noqa: F401
     query_ar_coeffs,
     recursive_lin_reg,
     rolling_lin_reg,
+    scatter_rows,
 )
 
 __version__ = "0.1.0"

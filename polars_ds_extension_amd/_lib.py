@@ -34,6 +34,7 @@ EXPORTS = [
     "pds_lr_with_inv_f64", "pds_lr_with_inv_f32",
     "pds_moments_f64", "pds_moments_f32", "pds_lr_from_moments_f64", "pds_lr_from_moments_f32",
     "pds_student_t_sf", "pds_student_t_ppf",
+    "pds_allreduce_sum_f64", "pds_allreduce_sum_f32", "pds_scatter_rows_f64", "pds_scatter_rows_f32", "pds_gather_f64", "pds_gather_f32",
 ]
 
 

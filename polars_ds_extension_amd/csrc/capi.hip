@@ -483,4 +483,24 @@ int pds_lr_from_moments_f32(pds_ctx* ctx, const float* moments, pds_space mom_sp
     return from_moments_impl<float>(ctx, moments, mom_space, n_feat, prm, coeffs, is_null);
 }
 
+// ---- exchange steps between the contexts of one process (capi_multi.hpp)
+int pds_allreduce_sum_f64(pds_ctx* const* ctxs, int n_ctx, double* const* bufs, int64_t count, int prefix) {
+    return pds::allreduce_sum_impl<double>(ctxs, n_ctx, bufs, count, prefix);
+}
+int pds_allreduce_sum_f32(pds_ctx* const* ctxs, int n_ctx, float* const* bufs, int64_t count, int prefix) {
+    return pds::allreduce_sum_impl<float>(ctxs, n_ctx, bufs, count, prefix);
+}
+int pds_scatter_rows_f64(pds_ctx* const* ctxs, int n_ctx, const double* const* cols, int n_cols, const int64_t* bounds, double* const* const* dst) {
+    return pds::scatter_rows_impl<double>(ctxs, n_ctx, cols, n_cols, bounds, dst);
+}
+int pds_scatter_rows_f32(pds_ctx* const* ctxs, int n_ctx, const float* const* cols, int n_cols, const int64_t* bounds, float* const* const* dst) {
+    return pds::scatter_rows_impl<float>(ctxs, n_ctx, cols, n_cols, bounds, dst);
+}
+int pds_gather_f64(pds_ctx* const* ctxs, int n_ctx, const double* const* src, const int64_t* counts, double* dst) {
+    return pds::gather_impl<double>(ctxs, n_ctx, src, counts, dst);
+}
+int pds_gather_f32(pds_ctx* const* ctxs, int n_ctx, const float* const* src, const int64_t* counts, float* dst) {
+    return pds::gather_impl<float>(ctxs, n_ctx, src, counts, dst);
+}
+int pds_debug_last_multi_route(void) { return pds::g_multi_route; }
 }  // extern "C"

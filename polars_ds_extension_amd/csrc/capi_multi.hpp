@@ -9,14 +9,16 @@
 // device two contexts do something useful as well: slice k + 1 crosses PCIe on one stream while slice k is fitted and its
 // results travel back on the other, so only the last slice's fit + D2H + export sit behind the last column.
 //
-// Contract: keys non-decreasing over the whole frame (a frame sorted by its key: groups are contiguous).  Slice boundaries are
+// Contract of the ORDERED route: keys non-decreasing over the whole frame (a frame sorted by its key: groups are contiguous).  Slice boundaries are
 // the row counts n s / S moved forward to the next key change, so no group is split and no cross-slice exchange exists; the
 // slices' results land in disjoint pieces of the caller's arrays (slice s starts where the groups of slices < s end: a slice
 // learns its number of groups before it fits, publishes it, and waits for the counts in front of it).  Frames whose keys are
-// not in order take the single-context route (device sort + gather): distributing THEIR rows by key is a host-side shuffle of
-// the whole frame, which costs more than the link saves.
+// NOT in order (round 4): lr_by_key_multi_unordered below -- row slices in any order, per-context moment tables, one sum.
 #pragma once
 // (<condition_variable>, <mutex>, <thread> are included by capi.hip: this header sits inside namespace pds)
+
+// which route the last pds_lr_by_key_multi_* call of this thread took (tests: 0 single context, 1 ordered slices, 2 unordered slices)
+static thread_local int g_multi_route = 0;
 
 template <typename T>
 struct SliceBoard {
@@ -104,6 +106,152 @@ static std::vector<int64_t> slice_bounds(const int64_t* keys, int64_t n_rows, in
     return bounds;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Keys in ANY row order over several contexts / devices ("hash(key) % R" -- here without moving a row to
+// "its" device): a group's fit needs its rows' MOMENTS, and moment tables of row slices are additive.  The frame is cut into one
+// row slice per context wherever the cut falls; every context pulls its slice over its own link and runs the partition route's
+// histogram / scatter / accumulate on it (keyed_partition.hip, phase 1) against the SAME dense ids (base and range of the whole
+// frame's keys: one parallel host pass over the keys); the tables meet on the first context (same device: read in place; another
+// device: hipMemcpyPeer + add), which lists the groups and solves them (phase 2 + solve_partition_table).  One exchange step of
+// ids x nv doubles per extra context -- 440 MB at 1e6 ids x 8 features against the 1.8 GB of frame a context of eight pulls.
+// PDS_ERR_UNSUPPORTED (nothing done): the partition route does not apply (sparse keys, > 16 features, ...): the caller keeps the
+// single-context sorting route.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <typename T>
+static int lr_by_key_multi_unordered(pds_ctx* const* ctxs, int n_ctx, const T* const* cols, const int64_t* keys, int n_feat, int64_t n_rows,
+                                     const pds_lr_params* prm, int64_t max_groups, int64_t* out_keys, T* coeffs, uint8_t* is_null,
+                                     int64_t* n_groups) {
+    const char* ks_env = std::getenv("PDS_KEYED_SORT");
+    if ((ks_env && ks_env[0] == '1') || (prm->solver == PDS_SOLVER_SVD && prm->singular_x_tol > 0.0)) return PDS_ERR_UNSUPPORTED;
+    if (n_ctx < 2 || n_feat > 16 || n_rows < ((int64_t)1 << 17) || n_rows >= ((int64_t)1 << 31)) return PDS_ERR_UNSUPPORTED;
+    const int S = n_ctx, nc = n_feat + 1, pp = n_feat + (prm->add_bias ? 1 : 0);
+    std::vector<int64_t> bounds(S + 1);
+    for (int s = 0; s <= S; ++s) bounds[s] = n_rows / S * s + std::min<int64_t>(s, n_rows % S);
+    // ---- the key range (host, one thread per slice)
+    std::vector<int64_t> kmin(S, std::numeric_limits<int64_t>::max()), kmax(S, std::numeric_limits<int64_t>::min());
+    {
+        std::vector<std::thread> th;
+        auto scan = [&](int s) {
+            int64_t lo = std::numeric_limits<int64_t>::max(), hi = std::numeric_limits<int64_t>::min();
+            for (int64_t i = bounds[s]; i < bounds[s + 1]; ++i) {
+                lo = std::min(lo, keys[i]);
+                hi = std::max(hi, keys[i]);
+            }
+            kmin[s] = lo;
+            kmax[s] = hi;
+        };
+        for (int s = 1; s < S; ++s) th.emplace_back(scan, s);
+        scan(0);
+        for (auto& t : th) t.join();
+    }
+    const int64_t lo = *std::min_element(kmin.begin(), kmin.end()), hi = *std::max_element(kmax.begin(), kmax.end());
+    const int shift = keyed_partition_shift<T>(n_feat);
+    const int64_t wdt = (int64_t)1 << shift;
+    const int64_t base = lo - (((lo % wdt) + wdt) % wdt);
+    if ((uint64_t)hi - (uint64_t)base >= ((uint64_t)1 << 31)) return PDS_ERR_UNSUPPORTED;
+    const uint64_t range = (uint64_t)hi - (uint64_t)base + 1;
+    const int64_t buckets = keyed_partition_buckets<T>(n_feat, n_rows, range);
+    if (buckets <= 0) return PDS_ERR_UNSUPPORTED;
+    for (int s = 0; s < S; ++s)
+        if (bounds[s + 1] - bounds[s] < ((int64_t)1 << 16)) return PDS_ERR_UNSUPPORTED;
+    const int64_t n_ids = keyed_partition_table_ids<T>(n_feat, buckets);
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const int64_t cap = std::min<int64_t>(max_groups, n_rows);
+    struct Slot {
+        KeyedPartitionState st;
+        char* pws = nullptr;
+        int64_t* d_base = nullptr;
+        int rc = PDS_OK;
+        std::string err;
+    };
+    std::vector<Slot> slot(S);
+    auto build = [&](int c) {
+        Slot& me = slot[c];
+        try {
+            pds_ctx* ctx = ctxs[c];
+            auto run = [&]() -> int {
+                PDS_HIP_CHECK(hipSetDevice(ctx->device));
+                const int64_t r0 = bounds[c], rows = bounds[c + 1] - r0;
+                size_t need = 4096 + up((size_t)rows * 8) + (size_t)nc * up((size_t)rows * sizeof(T)) + up(sizeof(T*) * 18) + 256 +
+                              keyed_partition_workspace<T>(n_feat, rows, buckets);
+                // (first context: group list, results, and room for a peer's table -- bounded by the partition workspace of zero rows)
+                if (c == 0) need += 2 * up((size_t)(cap + 1) * 8) + up((size_t)cap * pp * sizeof(T)) + up((size_t)cap) +
+                                    keyed_partition_workspace<T>(n_feat, 0, buckets);
+                if (int rc = ensure_ws(ctx, ctx->keyed, need)) return rc;
+                char* w = static_cast<char*>(ctx->keyed.ptr);
+                auto take = [&](size_t b) { char* r = w; w += up(b); return r; };
+                int64_t* d_keys = reinterpret_cast<int64_t*>(take((size_t)rows * 8));
+                PDS_HIP_CHECK(hipMemcpyAsync(d_keys, keys + r0, (size_t)rows * 8, hipMemcpyHostToDevice, ctx->stream));
+                std::vector<const T*> tbl(18, nullptr);
+                for (int k = 0; k < nc; ++k) {  // reference order [y, x1..xp] -> kernel order x_0..x_{p-1}, y
+                    T* d = reinterpret_cast<T*>(take((size_t)rows * sizeof(T)));
+                    PDS_HIP_CHECK(hipMemcpyAsync(d, cols[k] + r0, (size_t)rows * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+                    if (k == 0) tbl[n_feat] = d;
+                    else tbl[k - 1] = d;
+                }
+                for (int k = nc; k < 18; ++k) tbl[k] = tbl[0];
+                const T** d_tbl = reinterpret_cast<const T**>(take(sizeof(T*) * 18));
+                PDS_HIP_CHECK(hipMemcpyAsync(d_tbl, tbl.data(), sizeof(T*) * 18, hipMemcpyHostToDevice, ctx->stream));
+                me.d_base = reinterpret_cast<int64_t*>(take(256));
+                PDS_HIP_CHECK(hipMemcpyAsync(me.d_base, &base, 8, hipMemcpyHostToDevice, ctx->stream));
+                me.pws = take(keyed_partition_workspace<T>(n_feat, rows, buckets));
+                int64_t ng_unused = 0;
+                if (int rc = keyed_partition_build<T>(ctx, d_tbl, d_keys, me.d_base, range, n_feat, rows, buckets, me.pws, cap, nullptr, nullptr,
+                                                      &ng_unused, me.st, nullptr, 0u, /*phases*/ 1))
+                    return rc;
+                PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // (tbl and base live on this frame; the table is complete)
+                return PDS_OK;
+            };
+            me.rc = run();
+            if (me.rc) me.err = g_err;
+        } catch (const std::exception& e) {
+            me.rc = PDS_ERR_HIP;
+            me.err = std::string("sliced fit: ") + e.what();
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int c = 1; c < S; ++c) th.emplace_back(build, c);
+        build(0);
+        for (auto& t : th) t.join();
+    }
+    for (int c = 0; c < S; ++c)
+        if (slot[c].rc) return fail(slot[c].rc, slot[c].err.empty() ? std::string("sliced fit failed") : slot[c].err);
+    // ---- the exchange step: every other context's table into the first one's
+    pds_ctx* c0 = ctxs[0];
+    PDS_HIP_CHECK(hipSetDevice(c0->device));
+    const size_t table_bytes = (size_t)n_ids * (size_t)slot[0].st.nvp * 8;
+    char* w0 = slot[0].pws + up(keyed_partition_workspace<T>(n_feat, bounds[1] - bounds[0], buckets));
+    auto take0 = [&](size_t b) { char* r = w0; w0 += up(b); return r; };
+    int64_t* d_unique = reinterpret_cast<int64_t*>(take0((size_t)(cap + 1) * 8));
+    int64_t* d_offsets = reinterpret_cast<int64_t*>(take0((size_t)(cap + 1) * 8));
+    T* d_co = reinterpret_cast<T*>(take0((size_t)cap * pp * sizeof(T)));
+    uint8_t* d_nu = reinterpret_cast<uint8_t*>(take0((size_t)cap));
+    double* d_peer = nullptr;
+    for (int c = 1; c < S; ++c) {
+        const double* other = slot[c].st.table;
+        if (ctxs[c]->device != c0->device) {
+            if (!d_peer) d_peer = reinterpret_cast<double*>(take0(table_bytes));
+            PDS_HIP_CHECK(hipMemcpyPeerAsync(d_peer, c0->device, other, ctxs[c]->device, table_bytes, c0->stream));
+            other = d_peer;
+        }
+        if (int rc = keyed_partition_add_table(c0, slot[0].st, n_ids, other)) return rc;
+    }
+    // ---- the group list and the fits, on the first context
+    int64_t ng = 0;
+    KeyedPartitionState st = slot[0].st;
+    const int rc2 = keyed_partition_build<T>(c0, nullptr, nullptr, slot[0].d_base, range, n_feat, bounds[1] - bounds[0], buckets, slot[0].pws, cap,
+                                             d_unique, d_offsets, &ng, st, nullptr, 0u, /*phases*/ 2, n_rows);
+    *n_groups = ng;
+    if (rc2) return rc2;
+    if (int rc = solve_partition_table<T>(c0, st, n_feat, ng, d_offsets, prm, d_co, d_nu)) return rc;
+    PDS_HIP_CHECK(hipMemcpyAsync(coeffs, d_co, (size_t)ng * pp * sizeof(T), hipMemcpyDeviceToHost, c0->stream));
+    if (is_null) PDS_HIP_CHECK(hipMemcpyAsync(is_null, d_nu, (size_t)ng, hipMemcpyDeviceToHost, c0->stream));
+    PDS_HIP_CHECK(hipMemcpyAsync(out_keys, d_unique, (size_t)ng * 8, hipMemcpyDeviceToHost, c0->stream));
+    PDS_HIP_CHECK(hipStreamSynchronize(c0->stream));
+    return PDS_OK;
+}
+
 template <typename T>
 static int lr_by_key_multi_impl(pds_ctx* const* ctxs, int n_ctx, int n_slices, const T* const* cols, const int64_t* keys, int n_feat,
                                 int64_t n_rows, const pds_lr_params* prm, int64_t max_groups, int64_t* out_keys, T* coeffs,
@@ -115,15 +263,29 @@ static int lr_by_key_multi_impl(pds_ctx* const* ctxs, int n_ctx, int n_slices, c
     if (n_rows <= 0) return fail(PDS_ERR_EMPTY, "Empty data");
     if (max_groups < 1) return fail(PDS_ERR_INVALID, "max_groups must be positive");
     auto single = [&]() {
+        g_multi_route = 0;
         return lr_by_key_impl<T>(ctxs[0], cols, keys, n_feat, n_rows, PDS_HOST, prm, max_groups, out_keys, coeffs, is_null, n_groups);
     };
+    g_multi_route = 1;
+    auto unordered = [&]() {
+        g_multi_route = 2;
+        // keys not in order: row slices whatever the order, moment tables summed (above); the sorting route on one context otherwise
+        const int rcu = lr_by_key_multi_unordered<T>(ctxs, n_ctx, cols, keys, n_feat, n_rows, prm, max_groups, out_keys, coeffs, is_null, n_groups);
+        return rcu == PDS_ERR_UNSUPPORTED ? single() : rcu;
+    };
+    {
+        const int64_t probes = 4096, step = std::max<int64_t>(1, n_rows / probes);
+        for (int64_t i = 0; i + 1 < n_rows; i += step)
+            if (keys[i] > keys[i + 1]) return unordered();
+    }
     // ---- slices: at least kMinSliceRows rows each (a slice costs a few launches and copies), cut at key changes
     int S = n_slices > 0 ? n_slices : 4 * n_ctx;
     S = (int)std::min<int64_t>(S, std::max<int64_t>(1, n_rows / kMinSliceRows));
     if (S <= 1 && n_ctx == 1) return single();
     const std::vector<int64_t> bounds = slice_bounds(keys, n_rows, S, false);
     S = (int)bounds.size() - 1;
-    if (S <= 1 || !keys_look_ordered(keys, n_rows, bounds)) return single();
+    if (S <= 1) return single();
+    if (!keys_look_ordered(keys, n_rows, bounds)) return unordered();
     const int nc = n_feat + 1, pp = n_feat + (prm->add_bias ? 1 : 0);
     SliceBoard<T> board;
     board.ng.assign(S, -1);
@@ -184,7 +346,7 @@ static int lr_by_key_multi_impl(pds_ctx* const* ctxs, int n_ctx, int n_slices, c
     for (int c = 1; c < workers; ++c) threads.emplace_back(work, c);
     work(0);
     for (auto& t : threads) t.join();
-    if (board.unsorted) return single();  // (sampled as ordered, found unordered by a device: the whole frame takes the sorting route)
+    if (board.unsorted) return unordered();  // (sampled as ordered, found unordered by a device)
     int64_t total = 0;
     bool all_counted = true;
     for (int s = 0; s < S; ++s) {
@@ -266,3 +428,114 @@ static int lr_by_key_pred_multi_impl(pds_ctx* const* ctxs, int n_ctx, int n_slic
     return PDS_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The exchange steps of SURVEY.md 8(e) between the contexts of ONE process (include/pds_lstsq.h): peer copies + one kernel.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void exchange_add_kernel(T* __restrict__ dst, const T* __restrict__ src, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = (T)((double)dst[i] + (double)src[i]);
+}
+template <typename T>
+static int exchange_copy(pds_ctx* dst_ctx, T* dst, pds_ctx* src_ctx, const T* src, int64_t count) {
+    if (count <= 0) return PDS_OK;
+    if (dst_ctx->device == src_ctx->device)
+        PDS_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)count * sizeof(T), hipMemcpyDeviceToDevice, dst_ctx->stream));
+    else
+        PDS_HIP_CHECK(hipMemcpyPeerAsync(dst, dst_ctx->device, src, src_ctx->device, (size_t)count * sizeof(T), dst_ctx->stream));
+    return PDS_OK;
+}
+static int exchange_sync_all(pds_ctx* const* ctxs, int n_ctx) {
+    for (int c = 0; c < n_ctx; ++c) {
+        PDS_HIP_CHECK(hipSetDevice(ctxs[c]->device));
+        PDS_HIP_CHECK(hipStreamSynchronize(ctxs[c]->stream));
+    }
+    return PDS_OK;
+}
+static int exchange_check(pds_ctx* const* ctxs, int n_ctx) {
+    if (!ctxs || n_ctx < 1) return fail(PDS_ERR_INVALID, "null argument");
+    for (int c = 0; c < n_ctx; ++c)
+        if (!ctxs[c]) return fail(PDS_ERR_INVALID, "null context");
+    return PDS_OK;
+}
+
+template <typename T>
+static int allreduce_sum_impl(pds_ctx* const* ctxs, int n_ctx, T* const* bufs, int64_t count, int prefix) {
+    if (int rc = exchange_check(ctxs, n_ctx)) return rc;
+    if (!bufs || count < 0) return fail(PDS_ERR_INVALID, "null argument");
+    for (int c = 0; c < n_ctx; ++c)
+        if (!bufs[c]) return fail(PDS_ERR_INVALID, "null buffer");
+    if (count == 0 || (n_ctx == 1 && !prefix)) return PDS_OK;
+    if (int rc = exchange_sync_all(ctxs, n_ctx)) return rc;  // (the buffers' producers have finished)
+    pds_ctx* c0 = ctxs[0];
+    PDS_HIP_CHECK(hipSetDevice(c0->device));
+    // everything meets on the first context: acc = running sum in rank order, tmp = the next rank's buffer
+    if (int rc = ws_reserve(c0, 2 * ((size_t)count * sizeof(T) + 256) + 4096)) return rc;
+    T* acc = reinterpret_cast<T*>(ws_take(c0, (size_t)count * sizeof(T)));
+    T* tmp = reinterpret_cast<T*>(ws_take(c0, (size_t)count * sizeof(T)));
+    if (!acc || !tmp) return fail(PDS_ERR_HIP, "workspace allocation failed");
+    const int nb = (int)std::min<int64_t>((count + 255) / 256, (int64_t)c0->num_cus * 8);
+    if (prefix) {
+        // exclusive scan: buffer c <- sum of the ORIGINAL buffers 0 .. c-1
+        PDS_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)count * sizeof(T), c0->stream));
+        for (int c = 0; c < n_ctx; ++c) {  // (all on the first context's stream: in order)
+            if (int rc = exchange_copy<T>(c0, tmp, ctxs[c], bufs[c], count)) return rc;  // the rank's own block
+            if (ctxs[c]->device == c0->device)
+                PDS_HIP_CHECK(hipMemcpyAsync(bufs[c], acc, (size_t)count * sizeof(T), hipMemcpyDeviceToDevice, c0->stream));
+            else
+                PDS_HIP_CHECK(hipMemcpyPeerAsync(bufs[c], ctxs[c]->device, acc, c0->device, (size_t)count * sizeof(T), c0->stream));
+            hipLaunchKernelGGL((exchange_add_kernel<T>), dim3(nb), dim3(256), 0, c0->stream, acc, (const T*)tmp, count);
+        }
+        PDS_HIP_CHECK(hipGetLastError());
+        return exchange_sync_all(ctxs, n_ctx);
+    }
+    if (int rc = exchange_copy<T>(c0, acc, c0, bufs[0], count)) return rc;
+    for (int c = 1; c < n_ctx; ++c) {
+        if (int rc = exchange_copy<T>(c0, tmp, ctxs[c], bufs[c], count)) return rc;
+        hipLaunchKernelGGL((exchange_add_kernel<T>), dim3(nb), dim3(256), 0, c0->stream, acc, (const T*)tmp, count);
+    }
+    PDS_HIP_CHECK(hipGetLastError());
+    for (int c = 0; c < n_ctx; ++c) {
+        if (ctxs[c]->device == c0->device) PDS_HIP_CHECK(hipMemcpyAsync(bufs[c], acc, (size_t)count * sizeof(T), hipMemcpyDeviceToDevice, c0->stream));
+        else PDS_HIP_CHECK(hipMemcpyPeerAsync(bufs[c], ctxs[c]->device, acc, c0->device, (size_t)count * sizeof(T), c0->stream));
+    }
+    return exchange_sync_all(ctxs, n_ctx);
+}
+
+template <typename T>
+static int scatter_rows_impl(pds_ctx* const* ctxs, int n_ctx, const T* const* cols, int n_cols, const int64_t* bounds, T* const* const* dst) {
+    if (int rc = exchange_check(ctxs, n_ctx)) return rc;
+    if (!cols || !bounds || !dst || n_cols < 1) return fail(PDS_ERR_INVALID, "null argument");
+    for (int c = 0; c < n_ctx; ++c)
+        if (bounds[c + 1] < bounds[c]) return fail(PDS_ERR_INVALID, "bounds must be non-decreasing");
+    if (int rc = exchange_sync_all(ctxs, 1)) return rc;
+    for (int c = 0; c < n_ctx; ++c) {
+        if (!dst[c]) {
+            if (c == 0) continue;
+            return fail(PDS_ERR_INVALID, "null destination table");
+        }
+        PDS_HIP_CHECK(hipSetDevice(ctxs[c]->device));  // the receiving rank's stream pulls its shard: all links at once
+        for (int k = 0; k < n_cols; ++k) {
+            if (!cols[k] || !dst[c][k]) return fail(PDS_ERR_INVALID, "null column");
+            if (int rc = exchange_copy<T>(ctxs[c], dst[c][k], ctxs[0], cols[k] + bounds[c], bounds[c + 1] - bounds[c])) return rc;
+        }
+    }
+    return exchange_sync_all(ctxs, n_ctx);
+}
+
+template <typename T>
+static int gather_impl(pds_ctx* const* ctxs, int n_ctx, const T* const* src, const int64_t* counts, T* dst) {
+    if (int rc = exchange_check(ctxs, n_ctx)) return rc;
+    if (!src || !counts || !dst) return fail(PDS_ERR_INVALID, "null argument");
+    if (int rc = exchange_sync_all(ctxs, n_ctx)) return rc;
+    pds_ctx* c0 = ctxs[0];
+    PDS_HIP_CHECK(hipSetDevice(c0->device));
+    int64_t at = 0;
+    for (int c = 0; c < n_ctx; ++c) {
+        if (counts[c] < 0 || (counts[c] > 0 && !src[c])) return fail(PDS_ERR_INVALID, "null block");
+        if (int rc = exchange_copy<T>(c0, dst + at, ctxs[c], src[c], counts[c])) return rc;
+        at += counts[c];
+    }
+    PDS_HIP_CHECK(hipStreamSynchronize(c0->stream));
+    return PDS_OK;
+}

@@ -355,7 +355,11 @@ template <typename T>
 int keyed_partition_build(pds_ctx* ctx, const T* const* d_cols, const int64_t* d_keys, const int64_t* d_kmin /* base: see keyed_partition.hip */,
                           uint64_t range, int n_feat, int64_t n_rows, int64_t n_buckets, char* ws, int64_t max_groups, int64_t* d_out_keys,
                           int64_t* d_offsets, int64_t* n_groups, KeyedPartitionState& st, const unsigned* d_slot_counts = nullptr,
-                          unsigned first_slot = 0);
+                          unsigned first_slot = 0, int phases = 3 /* 1: the moment table of these rows; 2: the group list from the table */,
+                          int64_t n_rows_total = 0 /* rows behind the table when it sums several slices */);
+int keyed_partition_add_table(pds_ctx* ctx, const KeyedPartitionState& st, int64_t n_ids, const double* d_other);  // st.table += other
+template <typename T>
+int64_t keyed_partition_table_ids(int n_feat, int64_t n_buckets);  // rows of the id-indexed table (st.nvp doubles each)
 template <typename T>
 int keyed_partition_records(pds_ctx* ctx, const KeyedPartitionState& st, int n_feat, int64_t g0, int64_t gc, T* d_records);
 int keyed_runs(pds_ctx* ctx, const int64_t* d_sorted_keys, int64_t n, int64_t* d_unique, int64_t* d_counts, int64_t* d_offsets,

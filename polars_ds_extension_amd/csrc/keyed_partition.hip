@@ -553,7 +553,11 @@ template int keyed_partition_shift<float>(int);
 template <typename T>
 int keyed_partition_build(pds_ctx* ctx, const T* const* d_cols, const int64_t* d_keys, const int64_t* d_kmin, uint64_t range, int n_feat,
                           int64_t n_rows, int64_t n_buckets, char* ws, int64_t max_groups, int64_t* d_out_keys, int64_t* d_offsets,
-                          int64_t* n_groups, KeyedPartitionState& st, const unsigned* d_slot_counts, unsigned first_slot) {
+                          int64_t* n_groups, KeyedPartitionState& st, const unsigned* d_slot_counts, unsigned first_slot, int phases,
+                          int64_t n_rows_total) {
+    // phases (capi_multi.hpp: one frame over several contexts): 1 = histogram .. accumulate only -- the id-indexed moment table of
+    // THESE rows, complete (st.table; tables of row slices are additive: keyed_partition_add_table) -- 2 = the group list from the
+    // table that is there (same workspace: the carving below is the same); 3 = both, the single-context route.
     const PartLayout L = make_layout<T>(n_feat);
     const size_t ids = (size_t)n_buckets << L.shift;
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
@@ -575,6 +579,14 @@ int keyed_partition_build(pds_ctx* ctx, const T* const* d_cols, const int64_t* d
     temp_bytes = std::max(temp_bytes, t2);
     void* d_temp = take(temp_bytes);
     hipStream_t s = ctx->stream;
+    st.table = table;
+    st.ids = id_of;
+    st.rank = rank;
+    st.pc = L.pc;
+    st.nvp = L.nvp;
+    const int cnt_index = tri_index(L.pc, L.pc, L.qp);
+    const int fb = (int)std::min<int64_t>(std::max<int64_t>(((int64_t)ids + 255) / 256, 1), (int64_t)ctx->num_cus * 16);
+    if (phases & 1) {
     if (!d_slot_counts) PDS_HIP_CHECK(hipMemsetAsync(counts, 0, ncnt * 4, s));
     else PDS_HIP_CHECK(hipMemsetAsync(counts + (ncnt - 1), 0, 4, s));
     // (the table is zeroed bucket by bucket where that is needed: part_zero_rows_kernel below)
@@ -624,33 +636,46 @@ int keyed_partition_build(pds_ctx* ctx, const T* const* d_cols, const int64_t* d
         default: return fail(PDS_ERR_UNSUPPORTED, "keyed partition: feature count");
     }
     if (rc) return rc;
+    }  // phases & 1
+    if (!(phases & 2)) return PDS_OK;
     // ---- 4. groups = ids with rows, ascending
-    const int cnt_index = tri_index(L.pc, L.pc, L.qp);
-    const int fb = (int)std::min<int64_t>(std::max<int64_t>(((int64_t)ids + 255) / 256, 1), (int64_t)ctx->num_cus * 16);
+    PDS_HIP_CHECK(hipMemsetAsync(flags + ids, 0, 4, s));
     hipLaunchKernelGGL(part_flags_kernel<0>, dim3(fb), dim3(256), 0, s, (const double*)table, (int64_t)ids, L.nvp, cnt_index, flags);
     PDS_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(d_temp, temp_bytes, (const unsigned*)flags, rank, (int)ids + 1, s));
     unsigned h_ng = 0;
     PDS_HIP_CHECK(hipMemcpyAsync(&h_ng, rank + ids, 4, hipMemcpyDeviceToHost, s));
     PDS_HIP_CHECK(hipStreamSynchronize(s));
     *n_groups = (int64_t)h_ng;
-    st.table = table;
-    st.ids = id_of;
-    st.rank = rank;
-    st.pc = L.pc;
-    st.nvp = L.nvp;
     if ((int64_t)h_ng > max_groups) return fail(PDS_ERR_INVALID, "more distinct keys than max_groups");
     int64_t* sizes = d_offsets;  // sizes are scanned in place into offsets
     hipLaunchKernelGGL(part_compact_kernel, dim3(fb), dim3(256), 0, s, (const double*)table, (int64_t)ids, L.nvp, cnt_index, (const unsigned*)rank,
                        d_kmin, max_groups, d_out_keys, id_of, sizes);
     PDS_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(d_temp, temp_bytes, (const int64_t*)sizes, d_offsets, (int)h_ng, s));
-    hipLaunchKernelGGL(part_close_offsets_kernel, dim3(1), dim3(64), 0, s, d_offsets, (int64_t)h_ng, n_rows);
+    hipLaunchKernelGGL(part_close_offsets_kernel, dim3(1), dim3(64), 0, s, d_offsets, (int64_t)h_ng, n_rows_total > 0 ? n_rows_total : n_rows);
     PDS_HIP_CHECK(hipGetLastError());
     return PDS_OK;
 }
 template int keyed_partition_build<double>(pds_ctx*, const double* const*, const int64_t*, const int64_t*, uint64_t, int, int64_t, int64_t,
-                                           char*, int64_t, int64_t*, int64_t*, int64_t*, KeyedPartitionState&, const unsigned*, unsigned);
+                                           char*, int64_t, int64_t*, int64_t*, int64_t*, KeyedPartitionState&, const unsigned*, unsigned, int, int64_t);
 template int keyed_partition_build<float>(pds_ctx*, const float* const*, const int64_t*, const int64_t*, uint64_t, int, int64_t, int64_t, char*,
-                                          int64_t, int64_t*, int64_t*, int64_t*, KeyedPartitionState&, const unsigned*, unsigned);
+                                          int64_t, int64_t*, int64_t*, int64_t*, KeyedPartitionState&, const unsigned*, unsigned, int, int64_t);
+
+// table += other (both id-indexed moment tables of the same layout, both readable from ctx's device): the exchange step of the
+// row-sliced route -- moment tables of row slices are additive whatever the row order
+__global__ __launch_bounds__(256) void part_add_table_kernel(double* __restrict__ dst, const double* __restrict__ src, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] += src[i];
+}
+int keyed_partition_add_table(pds_ctx* ctx, const KeyedPartitionState& st, int64_t n_ids, const double* d_other) {
+    const size_t n = (size_t)n_ids * (size_t)st.nvp;
+    const int nb = (int)std::min<size_t>((n + 255) / 256, (size_t)ctx->num_cus * 16);
+    hipLaunchKernelGGL(part_add_table_kernel, dim3(nb), dim3(256), 0, ctx->stream, st.table, d_other, n);
+    PDS_HIP_CHECK(hipGetLastError());
+    return PDS_OK;
+}
+template <typename T>
+int64_t keyed_partition_table_ids(int n_feat, int64_t n_buckets) { return n_buckets << make_layout<T>(n_feat).shift; }
+template int64_t keyed_partition_table_ids<double>(int, int64_t);
+template int64_t keyed_partition_table_ids<float>(int, int64_t);
 
 // (p+2)^2 moment records of groups [g0, g0 + gc) for the batched solvers
 template <typename T>

@@ -711,6 +711,69 @@ def lin_reg_by_key_multi(*x, target, key, contexts, n_slices: int = 0, add_bias:
     return ok[:g], coeffs[:g], nulls[:g]
 
 
+# ---- the exchange steps of SURVEY.md 8(e) between the contexts of ONE process (include/pds_lstsq.h: pds_allreduce_sum_*,
+# pds_scatter_rows_*, pds_gather_*): what a host without a collective library composes the multi-device paths from
+def _exchange_suffix(t) -> str:
+    import torch
+
+    if t.dtype == torch.float64:
+        return "_f64"
+    if t.dtype == torch.float32:
+        return "_f32"
+    raise ValueError("exchange steps move float64 / float32 device tensors")
+
+
+def allreduce_sum(contexts, tensors, prefix: bool = False) -> None:
+    """tensors[c]: a contiguous CUDA tensor on contexts[c]'s device, all of one shape and dtype.  In place: every tensor becomes the
+    element-wise sum (prefix=True: tensor c becomes the sum of tensors 0 .. c-1 -- the exclusive scan of the row-sharded expanding fit)."""
+    n = len(contexts)
+    if len(tensors) != n or n < 1:
+        raise ValueError("one tensor per context")
+    suf = _exchange_suffix(tensors[0])
+    for x in tensors:
+        if not (x.is_cuda and x.is_contiguous() and x.shape == tensors[0].shape and x.dtype == tensors[0].dtype):
+            raise ValueError("contiguous CUDA tensors of one shape and dtype")
+    h = (C.c_void_p * n)(*[c._h for c in contexts])
+    b = (C.c_void_p * n)(*[x.data_ptr() for x in tensors])
+    _lib.check(getattr(_lib.load(), "pds_allreduce_sum" + suf)(h, n, b, C.c_int64(tensors[0].numel()), 1 if prefix else 0))
+
+
+def scatter_rows(contexts, cols, bounds):
+    """cols: CUDA column tensors on contexts[0]'s device; rows [bounds[c], bounds[c+1]) of every column -> new tensors on contexts[c]'s
+    device.  Returns a list (per context) of lists of column tensors; rank 0 gets views of the frame itself."""
+    import torch
+
+    n = len(contexts)
+    suf = _exchange_suffix(cols[0])
+    bounds = [int(v) for v in bounds]
+    out = [[c[bounds[0]:bounds[1]] for c in cols]]
+    for r in range(1, n):
+        out.append([torch.empty(bounds[r + 1] - bounds[r], dtype=cols[0].dtype, device=torch.device("cuda", contexts[r].device)) for _ in cols])
+    h = (C.c_void_p * n)(*[c._h for c in contexts])
+    src = (C.c_void_p * len(cols))(*[c.data_ptr() for c in cols])
+    tabs = [(C.c_void_p * len(cols))(*[x.data_ptr() for x in o]) for o in out]
+    dst = (C.c_void_p * n)(*([None] + [C.cast(tb, C.c_void_p) for tb in tabs[1:]]))
+    bd = (C.c_int64 * (n + 1))(*bounds)
+    _lib.check(getattr(_lib.load(), "pds_scatter_rows" + suf)(h, n, src, len(cols), bd, dst))
+    return out
+
+
+def gather(contexts, blocks):
+    """blocks[c]: a contiguous CUDA tensor on contexts[c]'s device -> one tensor on contexts[0]'s device, the blocks' elements back
+    to back in rank order."""
+    import torch
+
+    n = len(contexts)
+    suf = _exchange_suffix(blocks[0])
+    counts = [int(b.numel()) for b in blocks]
+    out = torch.empty(sum(counts), dtype=blocks[0].dtype, device=torch.device("cuda", contexts[0].device))
+    h = (C.c_void_p * n)(*[c._h for c in contexts])
+    src = (C.c_void_p * n)(*[b.data_ptr() for b in blocks])
+    cn = (C.c_int64 * n)(*counts)
+    _lib.check(getattr(_lib.load(), "pds_gather" + suf)(h, n, src, cn, C.c_void_p(out.data_ptr())))
+    return out
+
+
 def _offsets_arg(cols: "_Cols", group_offsets):
     if cols.space == _lib.PDS_DEVICE:
         import torch

@@ -613,6 +613,57 @@ def test_grouped_pred_by_key_shuffled_weighted_f32(pds, orc):
     assert np.max(np.abs(p32.cpu().numpy().astype(np.float64) - po[back]) / scale) < F32_TOL
 
 
+@pytest.mark.parametrize("n_ctx", [2, 3])
+def test_exchange_steps_compose_the_multi_device_paths_through_the_c_abi(pds, orc, n_ctx):
+    """pds_allreduce_sum_* / pds_scatter_rows_* / pds_gather_* (include/pds_lstsq.h, round 4): the three exchange steps of SURVEY.md
+    8(e) for a host that drives several devices from one process and has no collective library -- here N contexts on device 0.
+    (1) C2: a frame on rank 0 scattered by row ranges, every rank's moment block, all-reduce, the replicated solve = the whole-frame
+    fit (oracle, 1e-10); (2) C4: prefix mode = the exclusive scan that seeds the row-sharded expanding fit; (3) C3: the ranks'
+    coefficient blocks gathered in rank order."""
+    import torch
+
+    rng = np.random.default_rng(900 + n_ctx)
+    n, p = 600_000, 6
+    X = rng.normal(size=(n, p))
+    y = X @ rng.normal(size=p) + 0.7 + 0.1 * rng.normal(size=n)
+    ctxs = [pds.Context(0) for _ in range(n_ctx)]
+    cols_dev = [dev(y)] + cols_of(X)
+    bounds = [0] + [int(n * (c + 1) / n_ctx) + (7 if c + 1 < n_ctx else 0) for c in range(n_ctx)]
+    shards = pds.scatter_rows(ctxs, cols_dev, bounds)
+    for c in range(n_ctx):
+        assert all(torch.equal(s, full[bounds[c]:bounds[c + 1]]) for s, full in zip(shards[c], cols_dev))
+    moms = [pds.gram_moments(*sh[1:], target=sh[0], ctx=ctxs[c], out_device=True).contiguous() for c, sh in enumerate(shards)]
+    parts = [m.clone() for m in moms]
+    pds.allreduce_sum(ctxs, moms)
+    want = sum(parts)
+    for m in moms:
+        assert torch.allclose(m, want, rtol=1e-14, atol=0.0)
+    b = pds.lin_reg_from_moments(moms[n_ctx - 1], add_bias=True, ctx=ctxs[n_ctx - 1])
+    b = b.cpu().numpy() if hasattr(b, "cpu") else np.asarray(b)
+    assert nrel(b.ravel(), orc.pl_lr(X, y, add_bias=True)) < F64_TOL
+    # prefix mode: rank c receives the sum of the ranks in front of it (rank 0: zeros)
+    pre = [m.clone() for m in parts]
+    pds.allreduce_sum(ctxs, pre, prefix=True)
+    run = torch.zeros_like(parts[0])
+    for c in range(n_ctx):
+        assert torch.allclose(pre[c], run, rtol=1e-14, atol=0.0)
+        run = run + parts[c]
+    # the seeded expanding fit of the last shard = the tail of the whole-frame expanding fit
+    co_full, pr_full, va_full = pds.recursive_lin_reg(*cols_of(X), target=dev(y), start_with=20, add_bias=True)
+    c = n_ctx - 1
+    co_s, pr_s, va_s = pds.recursive_lin_reg(*shards[c][1:], target=shards[c][0], start_with=20, add_bias=True, seed_moments=pre[c], ctx=ctxs[c])
+    assert np.max(np.abs(co_s.cpu().numpy() - co_full.cpu().numpy()[bounds[c]:])) < 1e-9
+    # gather: blocks of different lengths, rank order
+    blocks = [torch.arange(100 * (c + 1), dtype=torch.float64, device="cuda") + 1000.0 * c for c in range(n_ctx)]
+    got = pds.gather(ctxs, blocks)
+    assert torch.equal(got, torch.cat(blocks))
+    f32b = [torch.full((5,), float(c + 1), dtype=torch.float32, device="cuda") for c in range(n_ctx)]
+    pds.allreduce_sum(ctxs, f32b)
+    assert all(torch.equal(t, torch.full((5,), float(n_ctx * (n_ctx + 1) // 2), dtype=torch.float32, device="cuda")) for t in f32b)
+    for cx in ctxs:
+        cx.close()
+
+
 @pytest.mark.parametrize("n_ctx,n_slices", [(1, 3), (2, 0), (3, 7), (4, 4)])
 def test_by_key_multi_context_equals_single_context(pds, orc, n_ctx, n_slices):
     """One host frame through several contexts of ONE process (pds_lr_by_key_multi_*: the route by which a Polars plugin can
@@ -644,13 +695,23 @@ def test_by_key_multi_context_equals_single_context(pds, orc, n_ctx, n_slices):
     # a capacity that is too small is reported with the total count (the plugin's retry protocol), nothing is written past it
     with pytest.raises(Exception, match="max_groups"):
         pds.lin_reg_by_key_multi(*cols, target=y, key=key, contexts=ctxs, n_slices=n_slices, add_bias=True, max_groups=G - 5)
-    # keys out of order: the sliced route hands the frame to the sorting single-context route
+    # keys out of order (round 4): one row slice per context whatever the order, every context builds the id-indexed moment table
+    # of ITS rows (keyed_partition.hip), the tables are summed on the first context, which lists the groups and solves them
+    # (SURVEY 8(e) row C3 without moving a row to "its" device).  Against the single-context call AND the oracle at 1e-10.
     perm = rng.permutation(N)
     k3, c3, n3 = pds.lin_reg_by_key_multi(*[c[perm] for c in cols], target=y[perm], key=key[perm], contexts=ctxs, n_slices=n_slices,
                                           add_bias=True)
-    assert np.array_equal(k3, k1) and np.array_equal(n3, n1)
+    from polars_ds_extension_amd import _lib
+
+    assert _lib.load().pds_debug_last_multi_route() == (2 if n_ctx > 1 else 0)  # (the summed-tables route was taken)
+    assert np.array_equal(k3, k1) and np.array_equal(n3, n1) and np.array_equal(n3.astype(bool), nu_o)
     ok = ~n1.astype(bool)
     assert np.max(np.linalg.norm(c3[ok] - c1[ok], axis=1) / np.linalg.norm(c1[ok], axis=1)) < 1e-9
+    rel_o = np.linalg.norm(c3[ok] - co_o[ok], axis=1) / np.linalg.norm(co_o[ok], axis=1)
+    assert np.median(rel_o) < 1e-12 and np.quantile(rel_o, 0.999) < F64_TOL, (np.median(rel_o), rel_o.max())
+    with pytest.raises(Exception, match="max_groups"):
+        pds.lin_reg_by_key_multi(*[c[perm] for c in cols], target=y[perm], key=key[perm], contexts=ctxs, n_slices=n_slices, add_bias=True,
+                                 max_groups=G - 5)
     # per-row predictions over the same contexts (pds_lr_by_key_pred_multi_*: independent slices): the single-context call's rows,
     # with and without weights; a shuffled frame falls back to the single-context route and still lands in frame order
     w = rng.random(N) + 0.25
