@@ -440,7 +440,7 @@ struct MidSolveArgs {
     unsigned* mark_count = nullptr;  // appended count (beyond mark_cap: overflow, the caller falls back to the record pipeline)
     unsigned mark_cap = 0;
 };
-constexpr int kMidSolveScratch = 16 * 34 * 8;  // bytes: 16 columns x 32 rows, stride 34 doubles
+constexpr int kMidSolveScratch = 5120;  // bytes behind the tile images (4 x 40 KB per CU): 24 columns x 26 doubles in one trip, or 16 x 34 per trip
 
 template <int NBLK, int SPPC = 0>
 __global__ __launch_bounds__(64) void grouped_mid_stream_kernel(const double* const* __restrict__ cols, int p, int64_t n_frame,
@@ -547,7 +547,8 @@ __global__ __launch_bounds__(64) void grouped_mid_stream_kernel(const double* co
             for (int I = 0; I < NBLK; ++I)
 #pragma unroll
                 for (int J = I; J < NBLK; ++J) {
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], a[J], acc[t], 0, 0, 0);
+                    if (t == 0 || !(debug & 8))  // (timing experiment: the first block only)
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], a[J], acc[t], 0, 0, 0);
                     ++t;
                 }
 #pragma unroll
@@ -659,9 +660,10 @@ __global__ __launch_bounds__(64) void grouped_mid_stream_kernel(const double* co
     // SPPC: finished groups wait, up to four of them (one per 16-lane DPP row, two columns per lane: solve_row16_dev.hpp), and are
     // solved side by side.  A system next to the gate is marked; its record is rebuilt from the group's rows (a rare, slow path: the
     // accumulators it came from are gone by then).
-    double pa0[SPPC + 1], pa1[SPPC + 1], pdj0 = 1.0, pdj1 = 1.0, psj0 = 0.0, psj1 = 0.0, pnn = 1.0, psy = 0.0;
+    // pending systems: RAW moments (the centring, lambda and the diagonal wait for the solve, where they cost once per four groups)
+    //   pa0 / pa1[i] = G[i][t] / G[i][16 + t], [SPPC] = X'y; psj0 / psj1 = column sums; pnn = rows; psy = sum y; pgid = group
+    double pa0[SPPC + 1], pa1[SPPC + 1], psj0 = 0.0, psj1 = 0.0, pnn = 1.0, psy = 0.0;
     int64_t pgid = -1;
-    bool pfew = false;
     int npend = 0;
     if constexpr (SPPC > 0) {
 #pragma unroll
@@ -688,6 +690,32 @@ __global__ __launch_bounds__(64) void grouped_mid_stream_kernel(const double* co
             if (npend == 0) return;
             const int t = lane & 15, R = lane >> 4, pout = p + sa.sp.bias;
             const bool live = R < npend;
+            // ---- raw moments -> the centred system with lambda on the diagonal (all pending rows at once)
+            const bool c0v = t < p, c1v = 16 + t < p;
+            pa0[SPPC] = c0v ? pa0[SPPC] : 0.0;
+            pa1[SPPC] = c1v ? pa1[SPPC] : 0.0;
+            double pdj0 = 1.0, pdj1 = 1.0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (i == t) {
+                    if (c0v) pdj0 = pa0[i] + sa.sp.lambda;
+                    pa0[i] += sa.sp.lambda;  // (columns beyond p: lambda on a row nobody eliminates)
+                    if (16 + i < SPPC) {
+                        if (c1v) pdj1 = pa1[16 + i] + sa.sp.lambda;
+                        pa1[16 + i] += sa.sp.lambda;
+                    }
+                }
+            }
+            if (!sa.sp.bias) psj0 = psj1 = 0.0;
+            psj0 = c0v ? psj0 : 0.0;
+            psj1 = c1v ? psj1 : 0.0;
+            if (sa.sp.bias) {  // centre: G_ij - s_i s_j / n (the intercept never takes a lane)
+                const double m0 = psj0 / pnn, m1 = psj1 / pnn;
+                Row16Centre<SPPC, SPPC - 1>::run(pa0, pa1, psj0, psj1, m0, m1);
+                pa0[SPPC] = fma(-psy, m0, pa0[SPPC]);
+                pa1[SPPC] = fma(-psy, m1, pa1[SPPC]);
+            }
+            const bool pfew = pnn < (double)pout;  // "#Data < #features"
             double w0, w1;
             bool is_null, suspect;
             row16_ldl_solve<SPPC>(pa0, pa1, pdj0, pdj1, t, p, pfew, sa.sp, w0, w1, is_null, suspect);
@@ -719,81 +747,91 @@ __global__ __launch_bounds__(64) void grouped_mid_stream_kernel(const double* co
             npend = 0;
         }
     };
-    // the finished group's accumulators -> DPP row `npend` of the pending registers (through a 4 KB LDS scratch, 16 columns per trip)
+    // the finished group's accumulators -> DPP row `npend` of the pending registers, through the LDS scratch behind the tile images
+    // (every lane of every row reads column t / 16 + t; a ROW-MASKED DPP move -- identity permutation, row_mask = the pending row --
+    // drops the values into that row's lanes only: two instructions per value, no select against the old contents, no temporaries)
     auto route_pending = [&]() __attribute__((always_inline)) {
         if constexpr (SPPC > 0) {
             typedef __attribute__((address_space(3))) double* lds_dp;
-            constexpr int SS = 34;
+            constexpr int SS = SPPC + 2;                                   // doubles per column of the scratch
+            constexpr bool ONE_TRIP = SPPC * SS * 8 <= kMidSolveScratch;   // all SPPC columns at once (up to 24 features)
             lds_dp S = (lds_dp)(sm + MD::LDS_BYTES);
-            const int t = lane & 15, R = lane >> 4, pout = p + sa.sp.bias;
-            const bool mine = R == npend;
-            double c0[SPPC + 1], c1[SPPC + 1];
-            // ---- columns 0 .. 15: rows 0 .. 15 from block (0, 0), rows 16 .. 31 from block (0, 1) transposed (G is symmetric)
-            PDS_WAVE_LDS_SYNC();
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                S[fi * SS + fk + 4 * r] = acc[0][r];
-                S[(fk + 4 * r) * SS + 16 + fi] = acc[1][r];
-            }
-            PDS_WAVE_LDS_SYNC();
-#pragma unroll
-            for (int i = 0; i < SPPC; ++i) c0[i] = S[t * SS + i];
-            PDS_WAVE_LDS_SYNC();
-            // ---- columns 16 .. 31: rows 0 .. 15 from block (0, 1), rows 16 .. 31 from block (1, 1)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                S[fi * SS + fk + 4 * r] = acc[1][r];
-                S[fi * SS + 16 + fk + 4 * r] = acc[2][r];
-            }
-            PDS_WAVE_LDS_SYNC();
-#pragma unroll
-            for (int i = 0; i < SPPC; ++i) c1[i] = S[t * SS + i];
-            // X'y and the column sums (lane 16 b' + t of ANY row holds feature 16 b + t's sums after the reduction over the row slots)
+            const int t = lane & 15;
             double vx0 = xy[0], vx1 = xy[1], vc0 = cs[0], vc1 = cs[1], vys = ys;
             vx0 += __shfl_xor(vx0, 16); vx0 += __shfl_xor(vx0, 32);
             vx1 += __shfl_xor(vx1, 16); vx1 += __shfl_xor(vx1, 32);
             vc0 += __shfl_xor(vc0, 16); vc0 += __shfl_xor(vc0, 32);
             vc1 += __shfl_xor(vc1, 16); vc1 += __shfl_xor(vc1, 32);
             vys += __shfl_xor(vys, 16); vys += __shfl_xor(vys, 32);
-            const bool c0v = t < p, c1v = 16 + t < p;
-            c0[SPPC] = c0v ? vx0 : 0.0;
-            c1[SPPC] = c1v ? vx1 : 0.0;
             const double nn = (double)rows_in_acc;
-            double dj0 = 1.0, dj1 = 1.0;
+            auto into_row = [&](auto rm) __attribute__((always_inline)) {
+                constexpr int RM = 1 << decltype(rm)::value;
+                auto put = [&](double& dst, double v) __attribute__((always_inline)) {
+                    dst = __builtin_amdgcn_update_dpp(dst, v, 0xE4 /*quad_perm:[0,1,2,3]*/, RM, 0xf, false);
+                };
+                auto put64 = [&](int64_t& dst, int64_t v) __attribute__((always_inline)) {
+                    int lo = (int)(uint32_t)(uint64_t)dst, hi = (int)(uint32_t)((uint64_t)dst >> 32);
+                    lo = __builtin_amdgcn_update_dpp(lo, (int)(uint32_t)(uint64_t)v, 0xE4, RM, 0xf, false);
+                    hi = __builtin_amdgcn_update_dpp(hi, (int)(uint32_t)((uint64_t)v >> 32), 0xE4, RM, 0xf, false);
+                    dst = (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo);
+                };
+                PDS_WAVE_LDS_SYNC();
+                // columns 0 .. 15: rows 0 .. 15 from block (0, 0), rows 16 .. from block (0, 1) transposed (G is symmetric)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if (i == t) {
-                    if (c0v) dj0 = c0[i] + sa.sp.lambda;
-                    c0[i] += sa.sp.lambda;  // (columns beyond p: lambda on a row nobody eliminates)
-                    if (16 + i < SPPC) {
-                        if (c1v) dj1 = c1[16 + i] + sa.sp.lambda;
-                        c1[16 + i] += sa.sp.lambda;
+                for (int r = 0; r < 4; ++r) {
+                    S[fi * SS + fk + 4 * r] = acc[0][r];
+                    if (16 + fi < SPPC) S[(fk + 4 * r) * SS + 16 + fi] = acc[1][r];
+                }
+                if constexpr (ONE_TRIP) {
+                    // columns 16 .. SPPC - 1 behind them: rows 0 .. 15 from block (0, 1), rows 16 .. from block (1, 1)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (16 + fi < SPPC) {
+                            S[(16 + fi) * SS + fk + 4 * r] = acc[1][r];
+                            if (16 + fk + 4 * r < SPPC) S[(16 + fi) * SS + 16 + fk + 4 * r] = acc[2][r];
+                        }
                     }
                 }
-            }
-            const double sj0 = (c0v && sa.sp.bias) ? vc0 : 0.0, sj1 = (c1v && sa.sp.bias) ? vc1 : 0.0;
-            if (sa.sp.bias) {  // centre: G_ij - s_i s_j / n (the intercept never takes a lane)
-                const double m0 = sj0 / nn, m1 = sj1 / nn;
-                Row16Centre<SPPC, SPPC - 1>::run(c0, c1, sj0, sj1, m0, m1);
-                c0[SPPC] = fma(-vys, m0, c0[SPPC]);
-                c1[SPPC] = fma(-vys, m1, c1[SPPC]);
-            }
-            // (selects, not an exec-masked copy: the masked form measured slower -- 19.3 against 9.7 ms at 32 features)
+                PDS_WAVE_LDS_SYNC();
 #pragma unroll
-            for (int i = 0; i <= SPPC; ++i) {
-                pa0[i] = mine ? c0[i] : pa0[i];
-                pa1[i] = mine ? c1[i] : pa1[i];
+                for (int i = 0; i < SPPC; ++i) put(pa0[i], S[t * SS + i]);
+                if constexpr (ONE_TRIP) {
+                    const int t1 = (16 + t < SPPC) ? 16 + t : 0;  // (lanes without a second column read a valid address, their values are zeroed)
+#pragma unroll
+                    for (int i = 0; i < SPPC; ++i) {
+                        const double v = S[t1 * SS + i];
+                        put(pa1[i], (16 + t < SPPC) ? v : 0.0);
+                    }
+                } else {
+                    PDS_WAVE_LDS_SYNC();
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        S[fi * SS + fk + 4 * r] = acc[1][r];
+                        S[fi * SS + 16 + fk + 4 * r] = acc[2][r];
+                    }
+                    PDS_WAVE_LDS_SYNC();
+#pragma unroll
+                    for (int i = 0; i < SPPC; ++i) put(pa1[i], S[t * SS + i]);
+                }
+                put(pa0[SPPC], vx0);
+                put(pa1[SPPC], vx1);
+                put(psj0, vc0);
+                put(psj1, vc1);
+                put(pnn, nn);
+                put(psy, vys);
+                put64(pgid, g);
+            };
+            switch (npend) {
+                case 0: into_row(std::integral_constant<int, 0>{}); break;
+                case 1: into_row(std::integral_constant<int, 1>{}); break;
+                case 2: into_row(std::integral_constant<int, 2>{}); break;
+                default: into_row(std::integral_constant<int, 3>{}); break;
             }
-            pdj0 = mine ? dj0 : pdj0;
-            pdj1 = mine ? dj1 : pdj1;
-            psj0 = mine ? sj0 : psj0;
-            psj1 = mine ? sj1 : psj1;
-            pnn = mine ? nn : pnn;
-            psy = mine ? vys : psy;
-            pgid = mine ? g : pgid;
-            pfew = mine ? (rows_in_acc < pout) : pfew;
             ++npend;
-            if (npend == 4) solve_pending();
+            if (npend == 4) {
+                if (debug & 4) npend = 0;  // (timing experiment: routed, never solved)
+                else solve_pending();
+            }
         }
     };
     auto flush = [&]() __attribute__((always_inline)) {

@@ -1,5 +1,5 @@
 """Timing experiments on the fused 17 .. 32-feature grouped kernel (development build, EXTRA=-DPDS_DEV_SWITCHES): PDS_GMID_DEBUG=1 skips
-the matrix steps, =2 skips the in-wave solves / record stores (wrong results either way).  Kernel-class times through the library's hooks."""
+the matrix steps, =2 skips the hand-over and the solves, =4 hands finished groups over but never solves them (wrong results either way).  Kernel-class times through the library's hooks."""
 import os, sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -16,7 +16,7 @@ ctx = pds.Context(0)
 ctx.set_stream(torch.cuda.current_stream())
 os.environ["PDS_GMID_VERBOSE"] = "1"
 for p in (17, 32):
-    for dbg in ("0", "1", "2", "3"):
+    for dbg in ("0", "4", "2", "10", "3"):
         os.environ["PDS_GMID_DEBUG"] = dbg
         pds.lin_reg_by(*xs[:p], target=y, group_offsets=off, ctx=ctx)
         os.environ.pop("PDS_GMID_VERBOSE", None)
