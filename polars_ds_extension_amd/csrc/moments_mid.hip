@@ -441,12 +441,21 @@ struct MidSolveArgs {
     unsigned mark_cap = 0;
 };
 constexpr int kMidSolveScratch = 5120;  // bytes behind the tile images (4 x 40 KB per CU): 24 columns x 26 doubles in one trip, or 16 x 34 per trip
+template <int NBLK>
+constexpr int kMidPairLds = MidDims<NBLK>::LDS_BYTES + kMidSolveScratch + 64;  // tile images + scratch + flag words of one pair of waves (PAIRED)
 
-template <int NBLK, int SPPC = 0>
-__global__ __launch_bounds__(64) void grouped_mid_stream_kernel(const double* const* __restrict__ cols, int p, int64_t n_frame,
+// PAIRED (with SPPC): a workgroup is FOUR PAIRS of waves -- waves 0 .. 3 stream (loads, matrix steps, group walk: what a wave of the
+// unpaired form does up to the finished group), waves 4 .. 7 are their solvers: a finished group's moments cross the pair's LDS scratch
+// (a sequence-numbered slot: full / taken / done words behind it, polled with s_sleep -- no workgroup barrier after the first), the
+// solver wave keeps the four pending systems, factors them and writes coefficients, flags and marks.  Waves w and w + 4 of a workgroup
+// share a SIMD (tools/wave_placement.hip), so every SIMD runs one streaming and one solving wave: the hand-over and the solves of one
+// overlap the load waits and matrix instructions of the other (they ran one after the other in a single wave: 2.5 of 7.65 ms).
+template <int NBLK, int SPPC = 0, bool PAIRED = false>
+__global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(const double* const* __restrict__ cols, int p, int64_t n_frame,
                                                                 const int64_t* __restrict__ off, int64_t n_groups,
                                                                 double* __restrict__ records, int debug, MidSolveArgs sa) {
     static_assert(SPPC == 0 || NBLK == 2, "the in-wave solve serves two tile columns");
+    static_assert(!PAIRED || SPPC > 0, "pairs exist for the in-kernel solve");
     using MD = MidDims<NBLK>;
     constexpr int HR = MD::HR, GS = MD::GS, NPAIR = MD::NPAIR;
     extern __shared__ __attribute__((aligned(16))) char gmid_lds[];
@@ -454,18 +463,213 @@ __global__ __launch_bounds__(64) void grouped_mid_stream_kernel(const double* co
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* glb_ptr;
     typedef double mid_d2 __attribute__((ext_vector_type(2)));
+    typedef volatile __attribute__((address_space(3))) unsigned* lds_flag;
 #define PDS_GM_LDSD(addr) (*(__attribute__((address_space(3))) double*)(addr))
-    lds_c sm = (lds_c)gmid_lds;
     const int lane = threadIdx.x & 63;
-    const int64_t wave = blockIdx.x, nwaves = gridDim.x;
+    const int wv = PAIRED ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0, pairi = wv & 3;
+    const bool consumer = PAIRED && wv >= 4;
+    lds_c sm = (lds_c)gmid_lds + (PAIRED ? pairi * kMidPairLds<NBLK> : 0);
+    const lds_flag FL = (lds_flag)(sm + MD::LDS_BYTES + kMidSolveScratch);  // [0] trips published, [1] trips taken, [2] stream finished
+    const int64_t wave = PAIRED ? (int64_t)blockIdx.x * 4 + pairi : (int64_t)blockIdx.x, nwaves = PAIRED ? (int64_t)gridDim.x * 4 : (int64_t)gridDim.x;
     const int64_t row_begin = off[0], row_end = off[n_groups];
     if (row_end <= row_begin) return;
     // half-tiles [H0, H1) cover the chunk's rows; a wave takes a contiguous range of them
     const int64_t H0 = row_begin / HR, H1 = (row_end + HR - 1) / HR;
     const int64_t h0 = H0 + (H1 - H0) * wave / nwaves, h1 = H0 + (H1 - H0) * (wave + 1) / nwaves;
+    if (!consumer) {
+        for (int i = lane * 16; i < MD::LDS_BYTES; i += 64 * 16) *(__attribute__((address_space(3))) mid_d2*)(sm + i) = mid_d2{0.0, 0.0};
+        if constexpr (PAIRED)
+            if (lane < 4) FL[lane] = 0u;
+        PDS_WAVE_LDS_SYNC();
+    }
+    if constexpr (PAIRED) __syncthreads();  // (the only workgroup barrier: the flag words are zero before a solver wave polls them)
     if (h0 >= h1) return;
     const int64_t W0 = h0 * HR > row_begin ? h0 * HR : row_begin, W1 = h1 * HR < row_end ? h1 * HR : row_end;  // the wave's rows
     const int q = p + 2;
+    // SPPC: finished groups wait, up to four of them (one per 16-lane DPP row, two columns per lane: solve_row16_dev.hpp), and are
+    // solved side by side.  A system next to the gate is marked; its record is rebuilt from the group's rows (a rare, slow path: the
+    // accumulators it came from are gone by then).
+    // pending systems: RAW moments (the centring, lambda and the diagonal wait for the solve, where they cost once per four groups)
+    //   pa0 / pa1[i] = G[i][t] / G[i][16 + t], [SPPC] = X'y; psj0 / psj1 = column sums; pnn = rows; psy = sum y; pgid = group
+    double pa0[SPPC + 1], pa1[SPPC + 1], psj0 = 0.0, psj1 = 0.0, pnn = 1.0, psy = 0.0;
+    int64_t pgid = -1;
+    int npend = 0;
+    if constexpr (SPPC > 0) {
+#pragma unroll
+        for (int i = 0; i <= SPPC; ++i) pa0[i] = pa1[i] = 0.0;
+    }
+    auto record_from_rows = [&](int64_t gg, double* M) __attribute__((always_inline)) {
+        const int64_t r0 = off[gg], r1 = off[gg + 1];
+        for (int e = lane; e < q * q; e += 64) {
+            const int i = e % q, j = e / q;
+            if (i > j) continue;
+            const gptr<double> ci = as_global(cols[i < p ? i : p]), cj = as_global(cols[j < p ? j : p]);  // (index p: the target column)
+            double sacc = 0.0;
+            for (int64_t r = r0; r < r1; ++r) {
+                const double zi = i < p ? ci[r] : (i == p ? 1.0 : ci[r]);
+                const double zj = j < p ? cj[r] : (j == p ? 1.0 : cj[r]);
+                sacc = fma(zi, zj, sacc);
+            }
+            M[i + (int64_t)j * q] = sacc;
+            M[j + (int64_t)i * q] = sacc;
+        }
+    };
+    auto solve_pending = [&]() __attribute__((always_inline)) {
+        if constexpr (SPPC > 0) {
+            if (npend == 0) return;
+            const int t = lane & 15, R = lane >> 4, pout = p + sa.sp.bias;
+            const bool live = R < npend;
+            // ---- raw moments -> the centred system with lambda on the diagonal (all pending rows at once)
+            const bool c0v = t < p, c1v = 16 + t < p;
+            pa0[SPPC] = c0v ? pa0[SPPC] : 0.0;
+            pa1[SPPC] = c1v ? pa1[SPPC] : 0.0;
+            double pdj0 = 1.0, pdj1 = 1.0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (i == t) {
+                    if (c0v) pdj0 = pa0[i] + sa.sp.lambda;
+                    pa0[i] += sa.sp.lambda;  // (columns beyond p: lambda on a row nobody eliminates)
+                    if (16 + i < SPPC) {
+                        if (c1v) pdj1 = pa1[16 + i] + sa.sp.lambda;
+                        pa1[16 + i] += sa.sp.lambda;
+                    }
+                }
+            }
+            if (!sa.sp.bias) psj0 = psj1 = 0.0;
+            psj0 = c0v ? psj0 : 0.0;
+            psj1 = c1v ? psj1 : 0.0;
+            if (sa.sp.bias) {  // centre: G_ij - s_i s_j / n (the intercept never takes a lane)
+                const double m0 = psj0 / pnn, m1 = psj1 / pnn;
+                Row16Centre<SPPC, SPPC - 1>::run(pa0, pa1, psj0, psj1, m0, m1);
+                pa0[SPPC] = fma(-psy, m0, pa0[SPPC]);
+                pa1[SPPC] = fma(-psy, m1, pa1[SPPC]);
+            }
+            const bool pfew = pnn < (double)pout;  // "#Data < #features"
+            double w0, w1;
+            bool is_null, suspect;
+            row16_ldl_solve<SPPC>(pa0, pa1, pdj0, pdj1, t, p, pfew, sa.sp, w0, w1, is_null, suspect);
+            const double nanv = __builtin_nan("");
+            const int64_t gq = live ? pgid : 0;
+            double* co = sa.coeffs + gq * (int64_t)pout;
+            if (live && t < p) co[t] = is_null ? nanv : w0;
+            if (live && 16 + t < p) co[16 + t] = is_null ? nanv : w1;
+            if (sa.sp.bias) {
+                const double sb = Grp<16>::sum((t < p ? psj0 * w0 : 0.0) + (16 + t < p ? psj1 * w1 : 0.0));
+                if (live && t == 0) co[p] = is_null ? nanv : (psy - sb) / pnn;
+            }
+            if (live && t == 0) sa.flags[gq] = is_null ? 1 : 0;
+            // marked systems: one DPP row after the other (wave-uniform control flow)
+            const unsigned long long sus = __builtin_amdgcn_ballot_w64(live && suspect);
+            for (int r = 0; r < 4; ++r) {
+                if (!((sus >> (16 * r)) & 1ull)) continue;
+                const int glo = __builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)pgid, 16 * r);
+                const int ghi = __builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)pgid >> 32), 16 * r);
+                const int64_t gg = (int64_t)(((uint64_t)(uint32_t)ghi << 32) | (uint64_t)(uint32_t)glo);
+                unsigned slot = 0;
+                if (lane == 0) slot = atomicAdd(sa.mark_count, 1u);
+                slot = (unsigned)__builtin_amdgcn_readfirstlane((int)slot);
+                if (slot < sa.mark_cap) {
+                    if (lane == 0) sa.mark_list[slot] = (int32_t)gg;
+                    record_from_rows(gg, sa.mark_rec + (int64_t)slot * q * q);
+                }
+            }
+            npend = 0;
+        }
+    };
+    // PAIRED, solving wave: trips -> DPP row `npend` of the pending registers (row-masked moves, as route_pending), four pending -> solve
+    auto solver_wave = [&]() __attribute__((always_inline)) {
+        if constexpr (PAIRED) {
+            typedef __attribute__((address_space(3))) double* lds_dp;
+            constexpr int SS = SPPC + 2;
+            constexpr bool ONE_TRIP = SPPC * SS * 8 + 32 <= kMidSolveScratch;
+            constexpr int TAIL = (ONE_TRIP ? SPPC : 16) * SS;
+            lds_dp S = (lds_dp)(sm + MD::LDS_BYTES);
+            const int t = lane & 15;
+            unsigned cseq = 0;
+            auto taken = [&]() __attribute__((always_inline)) {
+                PDS_WAVE_LDS_SYNC();  // (the values are in registers)
+                ++cseq;
+                FL[1] = cseq;
+            };
+            auto take_row = [&](auto rm) __attribute__((always_inline)) {
+                constexpr int RM = 1 << decltype(rm)::value;
+                auto put = [&](double& dst, double v) __attribute__((always_inline)) {
+                    dst = __builtin_amdgcn_update_dpp(dst, v, 0xE4 /*quad_perm:[0,1,2,3]*/, RM, 0xf, false);
+                };
+#pragma unroll
+                for (int i = 0; i < SPPC; ++i) {
+                    put(pa0[i], S[t * SS + i]);
+                    if (i % 8 == 7) __builtin_amdgcn_sched_barrier(0);  // (eight reads in flight, not SPPC: their temporaries count)
+                }
+                put(pa0[SPPC], S[t * SS + SPPC]);
+                put(psj0, S[t * SS + SPPC + 1]);
+                put(pnn, S[TAIL]);
+                put(psy, S[TAIL + 1]);
+                {
+                    const long long gv = __double_as_longlong(S[TAIL + 2]);
+                    int lo = (int)(uint32_t)(uint64_t)pgid, hi = (int)(uint32_t)((uint64_t)pgid >> 32);
+                    lo = __builtin_amdgcn_update_dpp(lo, (int)(uint32_t)(uint64_t)gv, 0xE4, RM, 0xf, false);
+                    hi = __builtin_amdgcn_update_dpp(hi, (int)(uint32_t)((uint64_t)gv >> 32), 0xE4, RM, 0xf, false);
+                    pgid = (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo);
+                }
+                if constexpr (ONE_TRIP) {
+                    const bool c1 = 16 + t < SPPC;
+                    const int t1 = c1 ? 16 + t : 0;  // (lanes without a second column read a valid address, their values are zeroed)
+#pragma unroll
+                    for (int i = 0; i < SPPC; ++i) {
+                        const double v = S[t1 * SS + i];
+                        put(pa1[i], c1 ? v : 0.0);
+                        if (i % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+                    }
+                    const double vx = S[t1 * SS + SPPC], vc = S[t1 * SS + SPPC + 1];
+                    put(pa1[SPPC], c1 ? vx : 0.0);
+                    put(psj1, c1 ? vc : 0.0);
+                    taken();
+                } else {
+                    taken();
+                    while (FL[0] == cseq) __builtin_amdgcn_s_sleep(1);  // (the second trip of a group always follows)
+#pragma unroll
+                    for (int i = 0; i < SPPC; ++i) {
+                        put(pa1[i], S[t * SS + i]);
+                        if (i % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+                    }
+                    put(pa1[SPPC], S[t * SS + SPPC]);
+                    put(psj1, S[t * SS + SPPC + 1]);
+                    taken();
+                }
+            };
+            for (;;) {
+                bool fin = false;
+                for (;;) {
+                    const unsigned d = FL[2], f = FL[0];  // (in this order: after `done` nothing is published)
+                    if (f != cseq) break;
+                    if (d) {
+                        fin = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (fin) break;
+                switch (npend) {
+                    case 0: take_row(std::integral_constant<int, 0>{}); break;
+                    case 1: take_row(std::integral_constant<int, 1>{}); break;
+                    case 2: take_row(std::integral_constant<int, 2>{}); break;
+                    default: take_row(std::integral_constant<int, 3>{}); break;
+                }
+                ++npend;
+                if (npend == 4) {
+                    if (debug & 4) npend = 0;  // (timing experiment: routed, never solved)
+                    else solve_pending();
+                }
+            }
+            solve_pending();
+        }
+    };
+    if constexpr (PAIRED)
+        if (consumer) {  // (before the streaming wave's state exists: none of it is live in the solver's registers)
+            solver_wave();
+            return;
+        }
     const int g_ = lane / MD::GL, piece = lane % MD::GL;
     const double* cbase[16];
     unsigned valid = 0;
@@ -476,8 +680,6 @@ __global__ __launch_bounds__(64) void grouped_mid_stream_kernel(const double* co
         if (c < p) valid |= 1u << i;
     }
     const double* ybase = cols[p] + 2 * lane;
-    for (int i = lane * 16; i < MD::LDS_BYTES; i += 64 * 16) *(__attribute__((address_space(3))) mid_d2*)(sm + i) = mid_d2{0.0, 0.0};
-    PDS_WAVE_LDS_SYNC();
     auto issue = [&](int buf, int64_t row0) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 16; ++i)
@@ -657,96 +859,6 @@ __global__ __launch_bounds__(64) void grouped_mid_stream_kernel(const double* co
             put((p + 1) + (int64_t)(p + 1) * q, vyy);
         }
     };
-    // SPPC: finished groups wait, up to four of them (one per 16-lane DPP row, two columns per lane: solve_row16_dev.hpp), and are
-    // solved side by side.  A system next to the gate is marked; its record is rebuilt from the group's rows (a rare, slow path: the
-    // accumulators it came from are gone by then).
-    // pending systems: RAW moments (the centring, lambda and the diagonal wait for the solve, where they cost once per four groups)
-    //   pa0 / pa1[i] = G[i][t] / G[i][16 + t], [SPPC] = X'y; psj0 / psj1 = column sums; pnn = rows; psy = sum y; pgid = group
-    double pa0[SPPC + 1], pa1[SPPC + 1], psj0 = 0.0, psj1 = 0.0, pnn = 1.0, psy = 0.0;
-    int64_t pgid = -1;
-    int npend = 0;
-    if constexpr (SPPC > 0) {
-#pragma unroll
-        for (int i = 0; i <= SPPC; ++i) pa0[i] = pa1[i] = 0.0;
-    }
-    auto record_from_rows = [&](int64_t gg, double* M) __attribute__((always_inline)) {
-        const int64_t r0 = off[gg], r1 = off[gg + 1];
-        for (int e = lane; e < q * q; e += 64) {
-            const int i = e % q, j = e / q;
-            if (i > j) continue;
-            const gptr<double> ci = as_global(cols[i < p ? i : p]), cj = as_global(cols[j < p ? j : p]);  // (index p: the target column)
-            double sacc = 0.0;
-            for (int64_t r = r0; r < r1; ++r) {
-                const double zi = i < p ? ci[r] : (i == p ? 1.0 : ci[r]);
-                const double zj = j < p ? cj[r] : (j == p ? 1.0 : cj[r]);
-                sacc = fma(zi, zj, sacc);
-            }
-            M[i + (int64_t)j * q] = sacc;
-            M[j + (int64_t)i * q] = sacc;
-        }
-    };
-    auto solve_pending = [&]() __attribute__((always_inline)) {
-        if constexpr (SPPC > 0) {
-            if (npend == 0) return;
-            const int t = lane & 15, R = lane >> 4, pout = p + sa.sp.bias;
-            const bool live = R < npend;
-            // ---- raw moments -> the centred system with lambda on the diagonal (all pending rows at once)
-            const bool c0v = t < p, c1v = 16 + t < p;
-            pa0[SPPC] = c0v ? pa0[SPPC] : 0.0;
-            pa1[SPPC] = c1v ? pa1[SPPC] : 0.0;
-            double pdj0 = 1.0, pdj1 = 1.0;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if (i == t) {
-                    if (c0v) pdj0 = pa0[i] + sa.sp.lambda;
-                    pa0[i] += sa.sp.lambda;  // (columns beyond p: lambda on a row nobody eliminates)
-                    if (16 + i < SPPC) {
-                        if (c1v) pdj1 = pa1[16 + i] + sa.sp.lambda;
-                        pa1[16 + i] += sa.sp.lambda;
-                    }
-                }
-            }
-            if (!sa.sp.bias) psj0 = psj1 = 0.0;
-            psj0 = c0v ? psj0 : 0.0;
-            psj1 = c1v ? psj1 : 0.0;
-            if (sa.sp.bias) {  // centre: G_ij - s_i s_j / n (the intercept never takes a lane)
-                const double m0 = psj0 / pnn, m1 = psj1 / pnn;
-                Row16Centre<SPPC, SPPC - 1>::run(pa0, pa1, psj0, psj1, m0, m1);
-                pa0[SPPC] = fma(-psy, m0, pa0[SPPC]);
-                pa1[SPPC] = fma(-psy, m1, pa1[SPPC]);
-            }
-            const bool pfew = pnn < (double)pout;  // "#Data < #features"
-            double w0, w1;
-            bool is_null, suspect;
-            row16_ldl_solve<SPPC>(pa0, pa1, pdj0, pdj1, t, p, pfew, sa.sp, w0, w1, is_null, suspect);
-            const double nanv = __builtin_nan("");
-            const int64_t gq = live ? pgid : 0;
-            double* co = sa.coeffs + gq * (int64_t)pout;
-            if (live && t < p) co[t] = is_null ? nanv : w0;
-            if (live && 16 + t < p) co[16 + t] = is_null ? nanv : w1;
-            if (sa.sp.bias) {
-                const double sb = Grp<16>::sum((t < p ? psj0 * w0 : 0.0) + (16 + t < p ? psj1 * w1 : 0.0));
-                if (live && t == 0) co[p] = is_null ? nanv : (psy - sb) / pnn;
-            }
-            if (live && t == 0) sa.flags[gq] = is_null ? 1 : 0;
-            // marked systems: one DPP row after the other (wave-uniform control flow)
-            const unsigned long long sus = __builtin_amdgcn_ballot_w64(live && suspect);
-            for (int r = 0; r < 4; ++r) {
-                if (!((sus >> (16 * r)) & 1ull)) continue;
-                const int glo = __builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)pgid, 16 * r);
-                const int ghi = __builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)pgid >> 32), 16 * r);
-                const int64_t gg = (int64_t)(((uint64_t)(uint32_t)ghi << 32) | (uint64_t)(uint32_t)glo);
-                unsigned slot = 0;
-                if (lane == 0) slot = atomicAdd(sa.mark_count, 1u);
-                slot = (unsigned)__builtin_amdgcn_readfirstlane((int)slot);
-                if (slot < sa.mark_cap) {
-                    if (lane == 0) sa.mark_list[slot] = (int32_t)gg;
-                    record_from_rows(gg, sa.mark_rec + (int64_t)slot * q * q);
-                }
-            }
-            npend = 0;
-        }
-    };
     // the finished group's accumulators -> DPP row `npend` of the pending registers, through the LDS scratch behind the tile images
     // (every lane of every row reads column t / 16 + t; a ROW-MASKED DPP move -- identity permutation, row_mask = the pending row --
     // drops the values into that row's lanes only: two instructions per value, no select against the old contents, no temporaries)
@@ -834,6 +946,75 @@ __global__ __launch_bounds__(64) void grouped_mid_stream_kernel(const double* co
             }
         }
     };
+    // PAIRED, streaming wave: the finished group's accumulators -> the pair's scratch, one sequence-numbered trip (two from 25 features);
+    // the layout of a trip is route_pending's, with X'y and the column sum in the two spare rows of a column and [rows, sum y, group]
+    // behind the columns
+    unsigned pseq = 0;
+    auto hand_over = [&]() __attribute__((always_inline)) {
+        if constexpr (PAIRED) {
+            typedef __attribute__((address_space(3))) double* lds_dp;
+            constexpr int SS = SPPC + 2;
+            constexpr bool ONE_TRIP = SPPC * SS * 8 + 32 <= kMidSolveScratch;
+            constexpr int TAIL = (ONE_TRIP ? SPPC : 16) * SS;
+            lds_dp S = (lds_dp)(sm + MD::LDS_BYTES);
+            double vx0 = xy[0], vx1 = xy[1], vc0 = cs[0], vc1 = cs[1], vys = ys;
+            vx0 += __shfl_xor(vx0, 16); vx0 += __shfl_xor(vx0, 32);
+            vx1 += __shfl_xor(vx1, 16); vx1 += __shfl_xor(vx1, 32);
+            vc0 += __shfl_xor(vc0, 16); vc0 += __shfl_xor(vc0, 32);
+            vc1 += __shfl_xor(vc1, 16); vc1 += __shfl_xor(vc1, 32);
+            vys += __shfl_xor(vys, 16); vys += __shfl_xor(vys, 32);
+            auto wait_taken = [&]() __attribute__((always_inline)) {
+                while (FL[1] != pseq) __builtin_amdgcn_s_sleep(1);
+            };
+            auto publish = [&]() __attribute__((always_inline)) {
+                PDS_WAVE_LDS_SYNC();
+                ++pseq;
+                FL[0] = pseq;
+            };
+            wait_taken();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                S[fi * SS + fk + 4 * r] = acc[0][r];
+                if (16 + fi < SPPC) S[(fk + 4 * r) * SS + 16 + fi] = acc[1][r];
+            }
+            if (fk == 0) {
+                S[fi * SS + SPPC] = vx0;
+                S[fi * SS + SPPC + 1] = vc0;
+            }
+            if (lane == 0) {
+                S[TAIL] = (double)rows_in_acc;
+                S[TAIL + 1] = vys;
+                S[TAIL + 2] = __longlong_as_double((long long)g);
+            }
+            if constexpr (ONE_TRIP) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (16 + fi < SPPC) {
+                        S[(16 + fi) * SS + fk + 4 * r] = acc[1][r];
+                        if (16 + fk + 4 * r < SPPC) S[(16 + fi) * SS + 16 + fk + 4 * r] = acc[2][r];
+                    }
+                }
+                if (fk == 0 && 16 + fi < SPPC) {
+                    S[(16 + fi) * SS + SPPC] = vx1;
+                    S[(16 + fi) * SS + SPPC + 1] = vc1;
+                }
+                publish();
+            } else {
+                publish();
+                wait_taken();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    S[fi * SS + fk + 4 * r] = acc[1][r];
+                    S[fi * SS + 16 + fk + 4 * r] = acc[2][r];
+                }
+                if (fk == 0) {
+                    S[fi * SS + SPPC] = vx1;
+                    S[fi * SS + SPPC + 1] = vc1;
+                }
+                publish();
+            }
+        }
+    };
     auto flush = [&]() __attribute__((always_inline)) {
         const bool whole = gs >= W0 && ge <= W1;
         if (debug & 2) {  // (timing experiment: no record stores)
@@ -843,7 +1024,8 @@ __global__ __launch_bounds__(64) void grouped_mid_stream_kernel(const double* co
         }
         if constexpr (SPPC > 0) {
             if (whole) {
-                route_pending();
+                if constexpr (PAIRED) hand_over();
+                else route_pending();
             } else {
                 // the wave the group starts in owns the side-table slot (largest w whose first row is <= gs)
                 int64_t slot = wave;
@@ -898,7 +1080,12 @@ __global__ __launch_bounds__(64) void grouped_mid_stream_kernel(const double* co
         PDS_WAVE_LDS_SYNC();
     }
     if (rows_in_acc > 0 && g < n_groups) flush();  // the group that continues in the next wave's rows
-    solve_pending();
+    if constexpr (PAIRED) {
+        PDS_WAVE_LDS_SYNC();
+        FL[2] = 1u;
+    } else {
+        solve_pending();
+    }
 #undef PDS_GM_LDSD
 }
 
@@ -929,7 +1116,8 @@ int launch_grouped_stream(pds_ctx* ctx, const DeviceCols<double>& dc, int p, int
 // ---- the in-wave-solve form (SPPC): host side
 constexpr unsigned kMidMarkCap = 8192;  // records of marked systems kept for the pivoted QR; more than that: the record pipeline
 inline int64_t mid_fused_waves(const pds_ctx* ctx, int64_t n_frame) {
-    return std::min<int64_t>((int64_t)ctx->num_cus * kMidWavesPerCu, std::max<int64_t>(1, n_frame / (8 * MidDims<2>::HR)));
+    const int64_t w = std::min<int64_t>((int64_t)ctx->num_cus * kMidWavesPerCu, std::max<int64_t>(1, n_frame / (8 * MidDims<2>::HR)));
+    return w >= 4 ? w / 4 * 4 : w;  // (whole workgroups of four pairs: the PAIRED form)
 }
 // side table -> compact: the groups that straddle wave boundaries (slot w used iff side_list[w] >= 0), their records, row counts as
 // offsets, and the count (one block: there are at most `waves` <= 1024 of them)
@@ -1084,6 +1272,9 @@ int launch_grouped_mid_fused(pds_ctx* ctx, const DeviceCols<double>& dc, int n_f
     PDS_HIP_CHECK(hipMemsetAsync(sa.side_rec, 0, (size_t)waves * q * q * 8, ctx->stream));
     PDS_HIP_CHECK(hipMemsetAsync(sa.side_list, 0xFF, (size_t)waves * 4, ctx->stream));
     constexpr int lds = MD::LDS_BYTES + kMidSolveScratch;
+    const char* pair_env = std::getenv("PDS_GROUPED_MID_PAIRED");
+    // (beyond 24 features the solving wave does not fit the 256 registers of a shared SIMD yet: 840 spilled registers; '2' forces it)
+    const bool paired = !(pair_env && pair_env[0] == '0') && waves % 4 == 0 && (p <= 24 || (pair_env && pair_env[0] == '2'));
     {
         KernelTimer timer(ctx, kKindGroupedMoments);
 #ifdef PDS_DEV_SWITCHES  // timing experiments of development builds (EXTRA=-DPDS_DEV_SWITCHES): wrong results with it
@@ -1095,8 +1286,20 @@ int launch_grouped_mid_fused(pds_ctx* ctx, const DeviceCols<double>& dc, int n_f
         auto launch = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3((unsigned)waves), dim3(64), lds, ctx->stream, dc.d_ptrs, p, n_frame, d_off, n_groups, (double*)nullptr, debug, sa);
         };
-        if (p <= 24) launch(grouped_mid_stream_kernel<2, 24>);
-        else launch(grouped_mid_stream_kernel<2, 32>);
+        auto launch_paired = [&](auto kern) {
+            constexpr int plds = 4 * kMidPairLds<2>;
+            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, plds);
+            (void)attr;
+            hipLaunchKernelGGL(kern, dim3((unsigned)(waves / 4)), dim3(512), plds, ctx->stream, dc.d_ptrs, p, n_frame, d_off, n_groups, (double*)nullptr,
+                               debug, sa);
+        };
+        if (paired) {
+            if (p <= 24) launch_paired(grouped_mid_stream_kernel<2, 24, true>);
+            else launch_paired(grouped_mid_stream_kernel<2, 32, true>);
+        } else {
+            if (p <= 24) launch(grouped_mid_stream_kernel<2, 24>);
+            else launch(grouped_mid_stream_kernel<2, 32>);
+        }
         PDS_HIP_CHECK(hipGetLastError());
     }
     // the groups cut by wave boundaries: compacted, then the record solver

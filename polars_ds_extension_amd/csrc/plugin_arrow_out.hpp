@@ -46,13 +46,14 @@ std::unique_ptr<ArrowSchema> make_schema(const std::string& format, const std::s
 // which brings its blocks back here.  No device / no pinned memory left: pageable storage as before.
 struct PinnedPool {
     static constexpr size_t kMinBytes = (size_t)4 << 20, kMaxBytes = (size_t)4 << 30;
-    // page-locked memory kept cached between results: 1 GiB unless PDS_PLUGIN_PINNED_CACHE_MB says otherwise (0: nothing is cached).
+    // page-locked memory kept cached between results: 4 GiB unless PDS_PLUGIN_PINNED_CACHE_MB says otherwise (0: nothing is cached;
+    // the per-row results of the headline frame are two 0.8 GB blocks: with 1 GiB one of them was pinned afresh on every call, +40 ms).
     // Pinned pages are taken from every other process on the host, so the cache is bounded, evicts its largest blocks first when a
     // returning block would exceed the bound, and serves a request from any cached block up to twice its size.
     static size_t cache_cap() {
         static const size_t cap = [] {
             const char* e = std::getenv("PDS_PLUGIN_PINNED_CACHE_MB");
-            return e ? (size_t)std::max<long long>(0, std::atoll(e)) << 20 : (size_t)1 << 30;
+            return e ? (size_t)std::max<long long>(0, std::atoll(e)) << 20 : (size_t)4 << 30;
         }();
         return cap;
     }

@@ -25,12 +25,16 @@ __device__ __forceinline__ void row16_step(double (&a0)[PPC + 1], double (&a1)[P
     // finished columns keep their entries through a zero multiplier (DPP reads from EXEC-disabled lanes are invalid: every lane takes part)
     const double nt0 = (S == 0 && t > KL) ? -(a0[K] * x) : 0.0;
     const double nt1 = (S == 0 || t > KL) ? -(a1[K] * x) : 0.0;
+    // (eight rows at a time: left alone the scheduler lifts all of a step's broadcasts to the front -- 64 temporaries beside the 132
+    // registers of the system, which does not fit the 256 of a wave that shares its SIMD)
 #pragma unroll
     for (int i = K + 1; i <= PPC; ++i) {
         const double b = Grp<16>::template bcast<KL>(S == 0 ? a0[i] : a1[i]);
         if (S == 0) a0[i] = fma(b, nt0, a0[i]);
         a1[i] = fma(b, nt1, a1[i]);
+        if ((i - K) % 8 == 0) __builtin_amdgcn_sched_barrier(0);
     }
+    __builtin_amdgcn_sched_barrier(0);
     if (t == KL) {
         if (S == 0) invd0 = x;
         else invd1 = x;
