@@ -441,6 +441,14 @@ struct MidSolveArgs {
     unsigned mark_cap = 0;
 };
 constexpr int kMidSolveScratch = 5120;  // bytes behind the tile images (4 x 40 KB per CU): 24 columns x 26 doubles in one trip, or 16 x 34 per trip
+// the slot between a streaming and a solving wave (PAIRED): the upper triangle of the SPPC x SPPC moment block row by row, U(r, c) at
+// tri(r) + c - r, then X'y, the column sums, and [rows, sum y, group] -- 4 760 bytes at 32 features
+template <int SPPC>
+struct MidPacked {
+    static constexpr int tri(int r) { return r * SPPC - r * (r - 1) / 2; }
+    static __device__ __forceinline__ int tri_rt(int r) { return r * SPPC - ((r * (r - 1)) >> 1); }
+    static constexpr int XY = SPPC * (SPPC + 1) / 2, CS = XY + SPPC, TAIL = CS + SPPC, COUNT = TAIL + 3;
+};
 template <int NBLK>
 constexpr int kMidPairLds = MidDims<NBLK>::LDS_BYTES + kMidSolveScratch + 64;  // tile images + scratch + flag words of one pair of waves (PAIRED)
 
@@ -456,6 +464,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
                                                                 double* __restrict__ records, int debug, MidSolveArgs sa) {
     static_assert(SPPC == 0 || NBLK == 2, "the in-wave solve serves two tile columns");
     static_assert(!PAIRED || SPPC > 0, "pairs exist for the in-kernel solve");
+    static_assert(!PAIRED || MidPacked<SPPC ? SPPC : 1>::COUNT * 8 <= kMidSolveScratch, "the slot holds one group");
     using MD = MidDims<NBLK>;
     constexpr int HR = MD::HR, GS = MD::GS, NPAIR = MD::NPAIR;
     extern __shared__ __attribute__((aligned(16))) char gmid_lds[];
@@ -518,21 +527,22 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
         if constexpr (SPPC > 0) {
             if (npend == 0) return;
             const int t = lane & 15, R = lane >> 4, pout = p + sa.sp.bias;
-            const bool live = R < npend;
+            const bool live = R < npend && pgid >= 0;  // (pgid < 0: padding of the paired form's last batch)
             // ---- raw moments -> the centred system with lambda on the diagonal (all pending rows at once)
             const bool c0v = t < p, c1v = 16 + t < p;
             pa0[SPPC] = c0v ? pa0[SPPC] : 0.0;
             pa1[SPPC] = c1v ? pa1[SPPC] : 0.0;
             double pdj0 = 1.0, pdj1 = 1.0;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if (i == t) {
-                    if (c0v) pdj0 = pa0[i] + sa.sp.lambda;
-                    pa0[i] += sa.sp.lambda;  // (columns beyond p: lambda on a row nobody eliminates)
-                    if (16 + i < SPPC) {
-                        if (c1v) pdj1 = pa1[16 + i] + sa.sp.lambda;
-                        pa1[16 + i] += sa.sp.lambda;
-                    }
+            for (int i = 0; i < 16; ++i) {  // (selects, not a branch per i; a column beyond p gets a unit diagonal: its step changes nothing)
+                const bool at = i == t;
+                const double d0 = pa0[i] + sa.sp.lambda;
+                pdj0 = (at && c0v) ? d0 : pdj0;
+                pa0[i] = at ? (c0v ? d0 : 1.0) : pa0[i];
+                if (16 + i < SPPC) {
+                    const double d1 = pa1[16 + i] + sa.sp.lambda;
+                    pdj1 = (at && c1v) ? d1 : pdj1;
+                    pa1[16 + i] = at ? (c1v ? d1 : 1.0) : pa1[16 + i];
                 }
             }
             if (!sa.sp.bias) psj0 = psj1 = 0.0;
@@ -547,7 +557,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
             const bool pfew = pnn < (double)pout;  // "#Data < #features"
             double w0, w1;
             bool is_null, suspect;
-            row16_ldl_solve<SPPC>(pa0, pa1, pdj0, pdj1, t, p, pfew, sa.sp, w0, w1, is_null, suspect);
+            row16_ldl_solve<SPPC, (PAIRED && SPPC > 24)>(pa0, pa1, pdj0, pdj1, t, p, pfew, sa.sp, w0, w1, is_null, suspect);
             const double nanv = __builtin_nan("");
             const int64_t gq = live ? pgid : 0;
             double* co = sa.coeffs + gq * (int64_t)pout;
@@ -576,93 +586,96 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
             npend = 0;
         }
     };
-    // PAIRED, solving wave: trips -> DPP row `npend` of the pending registers (row-masked moves, as route_pending), four pending -> solve
+    // PAIRED, solving wave: a published slot -> DPP row `npend` of the pending registers (row-masked moves, as route_pending), four
+    // pending -> solve.  The slot holds the UPPER TRIANGLE of G row by row (MidPacked: one trip at any width; the full columns of
+    // route_pending's layout took two from 25 features, and the streaming wave stood still between them while a solve ran): lane t
+    // reads row i of its column at U(i, t) for i <= t and at U(t, i) below the diagonal -- an immediate offset on one of two lane
+    // addresses, chosen per element only inside the two diagonal blocks.
     auto solver_wave = [&]() __attribute__((always_inline)) {
         if constexpr (PAIRED) {
             typedef __attribute__((address_space(3))) double* lds_dp;
-            constexpr int SS = SPPC + 2;
-            constexpr bool ONE_TRIP = SPPC * SS * 8 + 32 <= kMidSolveScratch;
-            constexpr int TAIL = (ONE_TRIP ? SPPC : 16) * SS;
+            using PK = MidPacked<SPPC>;
             lds_dp S = (lds_dp)(sm + MD::LDS_BYTES);
             const int t = lane & 15;
+            const bool c1 = 16 + t < SPPC;
+            const int u = c1 ? 16 + t : 16;  // (lanes without a second column read a valid address, their values are zeroed)
+            const int rowt = PK::tri_rt(t) - t, rowu = PK::tri_rt(u) - u;  // U(t, i) = S[rowt + i], U(u, i) = S[rowu + i]
             unsigned cseq = 0;
-            auto taken = [&]() __attribute__((always_inline)) {
+            // A batch is straight-line code: group 0 goes to EVERY row (plain reads: the registers are defined afresh, nothing of the last
+            // batch stays live), groups 1 .. 3 into their rows by row-masked DPP moves, then the solve.  With the row as a run-time
+            // value (a switch over four variants, or a branch on the lane's row) every pending register existed twice around the merge
+            // points -- copies, and a register file that spilled into the stream's memory queue: 15 000 clk per group.
+            auto wait_group = [&]() __attribute__((always_inline)) {  // false: the stream has finished and nothing is published
+                for (;;) {
+                    const unsigned d = FL[2], f = FL[0];  // (in this order: after `done` nothing is published)
+                    if (f != cseq) return true;
+                    if (d) return false;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            };
+            auto took = [&]() __attribute__((always_inline)) {
                 PDS_WAVE_LDS_SYNC();  // (the values are in registers)
                 ++cseq;
                 FL[1] = cseq;
             };
-            auto take_row = [&](auto rm) __attribute__((always_inline)) {
-                constexpr int RM = 1 << decltype(rm)::value;
+            auto take = [&](auto rm) __attribute__((always_inline)) {
+                constexpr int ROW = decltype(rm)::value;
                 auto put = [&](double& dst, double v) __attribute__((always_inline)) {
-                    dst = __builtin_amdgcn_update_dpp(dst, v, 0xE4 /*quad_perm:[0,1,2,3]*/, RM, 0xf, false);
+                    if constexpr (ROW == 0) dst = v;
+                    else dst = __builtin_amdgcn_update_dpp(dst, v, 0xE4 /*quad_perm:[0,1,2,3]*/, 1 << ROW, 0xf, false);
                 };
+                // (the lane terms pass through an empty asm: per-lane addresses inside the diagonal blocks are loop invariants otherwise,
+                // one register each)
+                int tl = t, ul = u, rt = rowt, ru = rowu;
+                asm volatile("" : "+v"(tl), "+v"(ul), "+v"(rt), "+v"(ru));
 #pragma unroll
                 for (int i = 0; i < SPPC; ++i) {
-                    put(pa0[i], S[t * SS + i]);
-                    if (i % 8 == 7) __builtin_amdgcn_sched_barrier(0);  // (eight reads in flight, not SPPC: their temporaries count)
+                    // column t: rows beyond 15 are always below the diagonal
+                    const int e0 = (i < 16 && i <= t) ? PK::tri(i) - i + tl : rt + i;
+                    put(pa0[i], S[e0]);
+                    // column 16 + t: rows up to 15 are always above it
+                    const int e1 = (i < 16 || i <= u) ? PK::tri(i) - i + ul : ru + i;
+                    const double v1 = S[e1];
+                    put(pa1[i], c1 ? v1 : 0.0);
+                    if (i % 4 == 3) __builtin_amdgcn_sched_barrier(0);  // (eight reads in flight, not 2 SPPC: their temporaries count)
                 }
-                put(pa0[SPPC], S[t * SS + SPPC]);
-                put(psj0, S[t * SS + SPPC + 1]);
-                put(pnn, S[TAIL]);
-                put(psy, S[TAIL + 1]);
+                const double x0 = S[PK::XY + tl], x1 = S[PK::XY + ul], s0 = S[PK::CS + tl], s1 = S[PK::CS + ul];
+                put(pa0[SPPC], x0);
+                put(pa1[SPPC], c1 ? x1 : 0.0);
+                put(psj0, s0);
+                put(psj1, c1 ? s1 : 0.0);
+                put(pnn, S[PK::TAIL]);
+                put(psy, S[PK::TAIL + 1]);
                 {
-                    const long long gv = __double_as_longlong(S[TAIL + 2]);
-                    int lo = (int)(uint32_t)(uint64_t)pgid, hi = (int)(uint32_t)((uint64_t)pgid >> 32);
-                    lo = __builtin_amdgcn_update_dpp(lo, (int)(uint32_t)(uint64_t)gv, 0xE4, RM, 0xf, false);
-                    hi = __builtin_amdgcn_update_dpp(hi, (int)(uint32_t)((uint64_t)gv >> 32), 0xE4, RM, 0xf, false);
-                    pgid = (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo);
-                }
-                if constexpr (ONE_TRIP) {
-                    const bool c1 = 16 + t < SPPC;
-                    const int t1 = c1 ? 16 + t : 0;  // (lanes without a second column read a valid address, their values are zeroed)
-#pragma unroll
-                    for (int i = 0; i < SPPC; ++i) {
-                        const double v = S[t1 * SS + i];
-                        put(pa1[i], c1 ? v : 0.0);
-                        if (i % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+                    const long long gv = __double_as_longlong(S[PK::TAIL + 2]);
+                    if constexpr (ROW == 0) {
+                        pgid = (int64_t)gv;
+                    } else {
+                        int lo = (int)(uint32_t)(uint64_t)pgid, hi = (int)(uint32_t)((uint64_t)pgid >> 32);
+                        lo = __builtin_amdgcn_update_dpp(lo, (int)(uint32_t)(uint64_t)gv, 0xE4, 1 << ROW, 0xf, false);
+                        hi = __builtin_amdgcn_update_dpp(hi, (int)(uint32_t)((uint64_t)gv >> 32), 0xE4, 1 << ROW, 0xf, false);
+                        pgid = (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo);
                     }
-                    const double vx = S[t1 * SS + SPPC], vc = S[t1 * SS + SPPC + 1];
-                    put(pa1[SPPC], c1 ? vx : 0.0);
-                    put(psj1, c1 ? vc : 0.0);
-                    taken();
-                } else {
-                    taken();
-                    while (FL[0] == cseq) __builtin_amdgcn_s_sleep(1);  // (the second trip of a group always follows)
-#pragma unroll
-                    for (int i = 0; i < SPPC; ++i) {
-                        put(pa1[i], S[t * SS + i]);
-                        if (i % 8 == 7) __builtin_amdgcn_sched_barrier(0);
-                    }
-                    put(pa1[SPPC], S[t * SS + SPPC]);
-                    put(psj1, S[t * SS + SPPC + 1]);
-                    taken();
                 }
+                took();
+            };
+            // (the streaming wave pads its last batch with discarded groups -- gid < 0 -- so a batch is always four: the only way out of the
+            // loop is in front of a batch, with no pending register live)
+            auto next_group = [&]() __attribute__((always_inline)) {
+                while (FL[0] == cseq) __builtin_amdgcn_s_sleep(1);
             };
             for (;;) {
-                bool fin = false;
-                for (;;) {
-                    const unsigned d = FL[2], f = FL[0];  // (in this order: after `done` nothing is published)
-                    if (f != cseq) break;
-                    if (d) {
-                        fin = true;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                if (fin) break;
-                switch (npend) {
-                    case 0: take_row(std::integral_constant<int, 0>{}); break;
-                    case 1: take_row(std::integral_constant<int, 1>{}); break;
-                    case 2: take_row(std::integral_constant<int, 2>{}); break;
-                    default: take_row(std::integral_constant<int, 3>{}); break;
-                }
-                ++npend;
-                if (npend == 4) {
-                    if (debug & 4) npend = 0;  // (timing experiment: routed, never solved)
-                    else solve_pending();
-                }
+                if (!wait_group()) break;
+                take(std::integral_constant<int, 0>{});
+                next_group();
+                take(std::integral_constant<int, 1>{});
+                next_group();
+                take(std::integral_constant<int, 2>{});
+                next_group();
+                take(std::integral_constant<int, 3>{});
+                npend = 4;
+                if (!(debug & 4)) solve_pending();  // (bit 4, a timing experiment: routed, never solved)
             }
-            solve_pending();
         }
     };
     if constexpr (PAIRED)
@@ -946,72 +959,78 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
             }
         }
     };
-    // PAIRED, streaming wave: the finished group's accumulators -> the pair's scratch, one sequence-numbered trip (two from 25 features);
-    // the layout of a trip is route_pending's, with X'y and the column sum in the two spare rows of a column and [rows, sum y, group]
-    // behind the columns
+    // PAIRED, streaming wave: the finished group's moments -> the pair's slot (MidPacked), published under a sequence number.  A slot
+    // the solving wave has not taken yet (it is in the middle of a solve) does not stop the stream: the group waits in a spare set of
+    // registers and goes out in front of the next one -- the stream stands still only when the solver is two groups behind.
     unsigned pseq = 0;
-    auto hand_over = [&]() __attribute__((always_inline)) {
+    d4 st_acc[NPAIR];
+    double st_x0 = 0.0, st_x1 = 0.0, st_c0 = 0.0, st_c1 = 0.0, st_nn = 0.0, st_ys = 0.0;
+    int64_t st_g = 0;
+    bool stashed = false;
+    auto slot_free = [&]() __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane((int)FL[1]) == (int)pseq; };
+    auto publish_group = [&](const d4 (&A)[NPAIR], double vx0, double vx1, double vc0, double vc1, double nn, double vys, int64_t gid)
+                             __attribute__((always_inline)) {
         if constexpr (PAIRED) {
             typedef __attribute__((address_space(3))) double* lds_dp;
-            constexpr int SS = SPPC + 2;
-            constexpr bool ONE_TRIP = SPPC * SS * 8 + 32 <= kMidSolveScratch;
-            constexpr int TAIL = (ONE_TRIP ? SPPC : 16) * SS;
+            using PK = MidPacked<SPPC>;
             lds_dp S = (lds_dp)(sm + MD::LDS_BYTES);
+            while (!slot_free()) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = fk + 4 * r;  // block (0, 0): G[i][fi], block (0, 1): G[i][16 + fi], block (1, 1): G[16 + i][16 + fi]
+                if (i <= fi) S[PK::tri_rt(i) - i + fi] = A[0][r];
+                if (16 + fi < SPPC) {
+                    S[PK::tri_rt(i) - i + 16 + fi] = A[1][r];
+                    if (i <= fi) S[PK::tri_rt(16 + i) - i + fi] = A[2][r];
+                }
+            }
+            if (fk == 0) {
+                S[PK::XY + fi] = vx0;
+                S[PK::CS + fi] = vc0;
+                if (16 + fi < SPPC) {
+                    S[PK::XY + 16 + fi] = vx1;
+                    S[PK::CS + 16 + fi] = vc1;
+                }
+            }
+            if (lane == 0) {
+                S[PK::TAIL] = nn;
+                S[PK::TAIL + 1] = vys;
+                S[PK::TAIL + 2] = __longlong_as_double((long long)gid);
+            }
+            PDS_WAVE_LDS_SYNC();
+            ++pseq;
+            FL[0] = pseq;
+        }
+    };
+    auto flush_stash = [&]() __attribute__((always_inline)) {
+        if constexpr (PAIRED) {
+            if (stashed) {
+                publish_group(st_acc, st_x0, st_x1, st_c0, st_c1, st_nn, st_ys, st_g);
+                stashed = false;
+            }
+        }
+    };
+    auto hand_over = [&]() __attribute__((always_inline)) {
+        if constexpr (PAIRED) {
             double vx0 = xy[0], vx1 = xy[1], vc0 = cs[0], vc1 = cs[1], vys = ys;
             vx0 += __shfl_xor(vx0, 16); vx0 += __shfl_xor(vx0, 32);
             vx1 += __shfl_xor(vx1, 16); vx1 += __shfl_xor(vx1, 32);
             vc0 += __shfl_xor(vc0, 16); vc0 += __shfl_xor(vc0, 32);
             vc1 += __shfl_xor(vc1, 16); vc1 += __shfl_xor(vc1, 32);
             vys += __shfl_xor(vys, 16); vys += __shfl_xor(vys, 32);
-            auto wait_taken = [&]() __attribute__((always_inline)) {
-                while (FL[1] != pseq) __builtin_amdgcn_s_sleep(1);
-            };
-            auto publish = [&]() __attribute__((always_inline)) {
-                PDS_WAVE_LDS_SYNC();
-                ++pseq;
-                FL[0] = pseq;
-            };
-            wait_taken();
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                S[fi * SS + fk + 4 * r] = acc[0][r];
-                if (16 + fi < SPPC) S[(fk + 4 * r) * SS + 16 + fi] = acc[1][r];
-            }
-            if (fk == 0) {
-                S[fi * SS + SPPC] = vx0;
-                S[fi * SS + SPPC + 1] = vc0;
-            }
-            if (lane == 0) {
-                S[TAIL] = (double)rows_in_acc;
-                S[TAIL + 1] = vys;
-                S[TAIL + 2] = __longlong_as_double((long long)g);
-            }
-            if constexpr (ONE_TRIP) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (16 + fi < SPPC) {
-                        S[(16 + fi) * SS + fk + 4 * r] = acc[1][r];
-                        if (16 + fk + 4 * r < SPPC) S[(16 + fi) * SS + 16 + fk + 4 * r] = acc[2][r];
-                    }
-                }
-                if (fk == 0 && 16 + fi < SPPC) {
-                    S[(16 + fi) * SS + SPPC] = vx1;
-                    S[(16 + fi) * SS + SPPC + 1] = vc1;
-                }
-                publish();
+            flush_stash();
+#ifdef PDS_GMID_NO_STASH
+            if (true) {
+#else
+            if (slot_free()) {
+#endif
+                publish_group(acc, vx0, vx1, vc0, vc1, (double)rows_in_acc, vys, g);
             } else {
-                publish();
-                wait_taken();
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    S[fi * SS + fk + 4 * r] = acc[1][r];
-                    S[fi * SS + 16 + fk + 4 * r] = acc[2][r];
-                }
-                if (fk == 0) {
-                    S[fi * SS + SPPC] = vx1;
-                    S[fi * SS + SPPC + 1] = vc1;
-                }
-                publish();
+                for (int b = 0; b < NPAIR; ++b) st_acc[b] = acc[b];
+                st_x0 = vx0; st_x1 = vx1; st_c0 = vc0; st_c1 = vc1;
+                st_nn = (double)rows_in_acc; st_ys = vys; st_g = g;
+                stashed = true;
             }
         }
     };
@@ -1081,6 +1100,15 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     }
     if (rows_in_acc > 0 && g < n_groups) flush();  // the group that continues in the next wave's rows
     if constexpr (PAIRED) {
+        flush_stash();
+        while ((pseq & 3u) != 0u) {  // pad the last batch: the slot's contents once more (a valid system), marked as discarded
+            typedef __attribute__((address_space(3))) double* lds_dp;
+            while (!slot_free()) __builtin_amdgcn_s_sleep(1);
+            if (lane == 0) ((lds_dp)(sm + MD::LDS_BYTES))[MidPacked<SPPC>::TAIL + 2] = __longlong_as_double(-1ll);
+            PDS_WAVE_LDS_SYNC();
+            ++pseq;
+            FL[0] = pseq;
+        }
         PDS_WAVE_LDS_SYNC();
         FL[2] = 1u;
     } else {
@@ -1273,8 +1301,7 @@ int launch_grouped_mid_fused(pds_ctx* ctx, const DeviceCols<double>& dc, int n_f
     PDS_HIP_CHECK(hipMemsetAsync(sa.side_list, 0xFF, (size_t)waves * 4, ctx->stream));
     constexpr int lds = MD::LDS_BYTES + kMidSolveScratch;
     const char* pair_env = std::getenv("PDS_GROUPED_MID_PAIRED");
-    // (beyond 24 features the solving wave does not fit the 256 registers of a shared SIMD yet: 840 spilled registers; '2' forces it)
-    const bool paired = !(pair_env && pair_env[0] == '0') && waves % 4 == 0 && (p <= 24 || (pair_env && pair_env[0] == '2'));
+    const bool paired = !(pair_env && pair_env[0] == '0') && waves % 4 == 0;
     {
         KernelTimer timer(ctx, kKindGroupedMoments);
 #ifdef PDS_DEV_SWITCHES  // timing experiments of development builds (EXTRA=-DPDS_DEV_SWITCHES): wrong results with it

@@ -40,23 +40,26 @@ __device__ __forceinline__ void row16_step(double (&a0)[PPC + 1], double (&a1)[P
         else invd1 = x;
     }
 }
-template <int PPC, int K>
+// ALL: every one of the PPC steps runs -- columns beyond p are unit columns (diagonal 1, zeros elsewhere: the caller's part), so their
+// steps change nothing.  The `K < p` branches of the other form cost a solving wave that shares its SIMD 840 spilled registers at
+// PPC = 32 (the values merged behind each branch are copies); without them 86, all of them outside the steps.
+template <int PPC, int K, bool ALL = false>
 struct Row16Steps {
     static __device__ __forceinline__ void run(double (&a0)[PPC + 1], double (&a1)[PPC + 1], int t, int p, double& i0, double& i1, bool& ok) {
-        Row16Steps<PPC, K - 1>::run(a0, a1, t, p, i0, i1, ok);
-        if (K < p) row16_step<PPC, K>(a0, a1, t, i0, i1, ok);
+        Row16Steps<PPC, K - 1, ALL>::run(a0, a1, t, p, i0, i1, ok);
+        if (ALL || K < p) row16_step<PPC, K>(a0, a1, t, i0, i1, ok);
     }
 };
-template <int PPC>
-struct Row16Steps<PPC, -1> {
+template <int PPC, bool ALL>
+struct Row16Steps<PPC, -1, ALL> {
     static __device__ __forceinline__ void run(double (&)[PPC + 1], double (&)[PPC + 1], int, int, double&, double&, bool&) {}
 };
 // back substitution: w <- w + bcast_M(w) (-a[M] / d_j), a column final after step (its index) + 1
-template <int PPC, int M>
+template <int PPC, int M, bool ALL = false>
 struct Row16Back {
     static __device__ __forceinline__ void run(const double (&a0)[PPC + 1], const double (&a1)[PPC + 1], int t, int p, double i0, double i1,
                                                double& w0, double& w1) {
-        if (M < p) {
+        if (ALL || M < p) {
             constexpr int S = M / 16, ML = M % 16;
             const double bm = Grp<16>::template bcast<ML>(S == 0 ? w0 : w1);
             const double c0 = (S == 1 || t < ML) ? -(a0[M] * i0) : 0.0;   // column t < M
@@ -64,11 +67,11 @@ struct Row16Back {
             w0 = fma(bm, c0, w0);
             w1 = fma(bm, c1, w1);
         }
-        Row16Back<PPC, M - 1>::run(a0, a1, t, p, i0, i1, w0, w1);
+        Row16Back<PPC, M - 1, ALL>::run(a0, a1, t, p, i0, i1, w0, w1);
     }
 };
-template <int PPC>
-struct Row16Back<PPC, 0> {
+template <int PPC, bool ALL>
+struct Row16Back<PPC, 0, ALL> {
     static __device__ __forceinline__ void run(const double (&)[PPC + 1], const double (&)[PPC + 1], int, int, double, double, double&, double&) {}
 };
 
@@ -89,7 +92,7 @@ struct Row16Centre<PPC, -1> {
 
 // in : a0 / a1 as above, dj0 / dj1 = uncentred diagonal (+ lambda) of the lane's columns (1 where there is none), few = "#Data < #features"
 // out: w0 / w1 = the coefficients of columns t / 16 + t; is_null, suspect: uniform inside a 16-lane row (one system)
-template <int PPC>
+template <int PPC, bool ALL = false>
 __device__ __forceinline__ void row16_ldl_solve(double (&a0)[PPC + 1], double (&a1)[PPC + 1], double dj0, double dj1, int t, int p, bool few,
                                                 const SolveRegDev& sp, double& w0, double& w1, bool& is_null, bool& suspect) {
     const bool c0v = t < p, c1v = 16 + t < p;
@@ -98,7 +101,7 @@ __device__ __forceinline__ void row16_ldl_solve(double (&a0)[PPC + 1], double (&
     if (Grp<16>::sum(((c0v && dj0 <= 0.0) || (c1v && dj1 <= 0.0)) ? 1.0 : 0.0) > 0.0) is_null = true;
     double i0 = 1.0, i1 = 1.0;
     bool ok = true;
-    Row16Steps<PPC, PPC - 1>::run(a0, a1, t, p, i0, i1, ok);
+    Row16Steps<PPC, PPC - 1, ALL>::run(a0, a1, t, p, i0, i1, ok);
     if (!ok) is_null = true;  // "Not positive-definite -> rank-deficient" (lr_solvers.rs:370-371)
     const double grow = grp_prod<16>((c0v ? dj0 * i0 : 1.0) * (c1v ? dj1 * i1 : 1.0));  // prod G_kk / d_k
     if (grow >= sp.inv_tol) is_null = true;
@@ -106,7 +109,7 @@ __device__ __forceinline__ void row16_ldl_solve(double (&a0)[PPC + 1], double (&
     is_null = is_null || suspect;
     w0 = a0[PPC] * i0;
     w1 = a1[PPC] * i1;
-    Row16Back<PPC, PPC - 1>::run(a0, a1, t, p, i0, i1, w0, w1);
+    Row16Back<PPC, PPC - 1, ALL>::run(a0, a1, t, p, i0, i1, w0, w1);
 }
 
 }  // namespace pds
