@@ -23,6 +23,16 @@
 
 namespace pds {
 
+// -DPDS_PROFILE_MID: per-phase shader-clock sums of the paired grouped stream's waves (development; tools/grouped_mid_profile.py)
+#ifdef PDS_PROFILE_MID
+__device__ unsigned long long g_mid_phase[16];
+#define PDS_MT(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define PDS_MADD(k, t0) mprof[k] += __builtin_amdgcn_s_memtime() - (t0)
+#else
+#define PDS_MT(var) do {} while (0)
+#define PDS_MADD(k, t0) do {} while (0)
+#endif
+
 namespace {
 
 constexpr int kMidWavesPerCu = 4;
@@ -443,11 +453,13 @@ struct MidSolveArgs {
 constexpr int kMidSolveScratch = 5120;  // bytes behind the tile images (4 x 40 KB per CU): 24 columns x 26 doubles in one trip, or 16 x 34 per trip
 // the slot between a streaming and a solving wave (PAIRED): the upper triangle of the SPPC x SPPC moment block row by row, U(r, c) at
 // tri(r) + c - r, then X'y, the column sums, and [rows, sum y, group] -- 4 760 bytes at 32 features
-template <int SPPC>
+// YC: the triangle is that of [X 1 y]' [X 1 y] (QC = columns incl. the two), only the group id follows it.
+template <int SPPC, bool YC = false>
 struct MidPacked {
-    static constexpr int tri(int r) { return r * SPPC - r * (r - 1) / 2; }
-    static __device__ __forceinline__ int tri_rt(int r) { return r * SPPC - ((r * (r - 1)) >> 1); }
-    static constexpr int XY = SPPC * (SPPC + 1) / 2, CS = XY + SPPC, TAIL = CS + SPPC, COUNT = TAIL + 3;
+    static constexpr int QC = YC ? (SPPC + 2 < 32 ? SPPC + 2 : 32) : SPPC;
+    static constexpr int tri(int r) { return r * QC - r * (r - 1) / 2; }
+    static __device__ __forceinline__ int tri_rt(int r) { return r * QC - ((r * (r - 1)) >> 1); }
+    static constexpr int XY = QC * (QC + 1) / 2, CS = XY + (YC ? 0 : SPPC), TAIL = CS + (YC ? 0 : SPPC), GID = TAIL + (YC ? 0 : 2), COUNT = GID + 1;
 };
 template <int NBLK>
 constexpr int kMidPairLds = MidDims<NBLK>::LDS_BYTES + kMidSolveScratch + 64;  // tile images + scratch + flag words of one pair of waves (PAIRED)
@@ -458,13 +470,17 @@ constexpr int kMidPairLds = MidDims<NBLK>::LDS_BYTES + kMidSolveScratch + 64;  /
 // solver wave keeps the four pending systems, factors them and writes coefficients, flags and marks.  Waves w and w + 4 of a workgroup
 // share a SIMD (tools/wave_placement.hip), so every SIMD runs one streaming and one solving wave: the hand-over and the solves of one
 // overlap the load waits and matrix instructions of the other (they ran one after the other in a single wave: 2.5 of 7.65 ms).
-template <int NBLK, int SPPC = 0, bool PAIRED = false>
+// YC (PAIRED, up to 30 features): the ones and the target are columns p and p + 1 of the second operand block -- the column sums, X'y, the
+// row count and sum y come out of the matrix instructions that run anyway (no side sums per step, no cross-row reductions per group),
+// and the accumulator blocks ARE the record [X 1 y]' [X 1 y].
+template <int NBLK, int SPPC = 0, bool PAIRED = false, bool YC = false>
 __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(const double* const* __restrict__ cols, int p, int64_t n_frame,
                                                                 const int64_t* __restrict__ off, int64_t n_groups,
                                                                 double* __restrict__ records, int debug, MidSolveArgs sa) {
     static_assert(SPPC == 0 || NBLK == 2, "the in-wave solve serves two tile columns");
     static_assert(!PAIRED || SPPC > 0, "pairs exist for the in-kernel solve");
-    static_assert(!PAIRED || MidPacked<SPPC ? SPPC : 1>::COUNT * 8 <= kMidSolveScratch, "the slot holds one group");
+    static_assert(!PAIRED || MidPacked<SPPC ? SPPC : 1, YC>::COUNT * 8 <= kMidSolveScratch, "the slot holds one group");
+    static_assert(!YC || PAIRED, "the ones / target columns are the paired form's");
     using MD = MidDims<NBLK>;
     constexpr int HR = MD::HR, GS = MD::GS, NPAIR = MD::NPAIR;
     extern __shared__ __attribute__((aligned(16))) char gmid_lds[];
@@ -474,6 +490,15 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     typedef double mid_d2 __attribute__((ext_vector_type(2)));
     typedef volatile __attribute__((address_space(3))) unsigned* lds_flag;
 #define PDS_GM_LDSD(addr) (*(__attribute__((address_space(3))) double*)(addr))
+#ifdef PDS_PROFILE_MID
+    unsigned long long mprof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto mprof_out = [&]() __attribute__((always_inline)) {
+        if ((threadIdx.x & 63) == 0)
+            for (int k = 0; k < 16; ++k)
+                if (mprof[k]) atomicAdd(&g_mid_phase[k], mprof[k]);
+    };
+#endif
+    PDS_MT(t_kernel);
     const int lane = threadIdx.x & 63;
     const int wv = PAIRED ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0, pairi = wv & 3;
     const bool consumer = PAIRED && wv >= 4;
@@ -489,6 +514,11 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
         for (int i = lane * 16; i < MD::LDS_BYTES; i += 64 * 16) *(__attribute__((address_space(3))) mid_d2*)(sm + i) = mid_d2{0.0, 0.0};
         if constexpr (PAIRED)
             if (lane < 4) FL[lane] = 0u;
+        if constexpr (YC) {  // the ones column: the (otherwise unused) weight image of both half-tiles, written once
+            PDS_WAVE_LDS_SYNC();
+            for (int b = 0; b < MD::NBUF; ++b) PDS_GM_LDSD(sm + b * MD::HALF_BYTES + MD::W_OFF + lane * 8) = 1.0;
+            static_assert(!YC || MD::HR == 64, "one lane per row of the ones image");
+        }
         PDS_WAVE_LDS_SYNC();
     }
     if constexpr (PAIRED) __syncthreads();  // (the only workgroup barrier: the flag words are zero before a solver wave polls them)
@@ -594,10 +624,10 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     auto solver_wave = [&]() __attribute__((always_inline)) {
         if constexpr (PAIRED) {
             typedef __attribute__((address_space(3))) double* lds_dp;
-            using PK = MidPacked<SPPC>;
+            using PK = MidPacked<SPPC, YC>;
             lds_dp S = (lds_dp)(sm + MD::LDS_BYTES);
             const int t = lane & 15;
-            const bool c1 = 16 + t < SPPC;
+            const bool c1 = YC ? 16 + t < p : 16 + t < SPPC;  // (YC: columns p, p + 1 of the slot are the ones and the target, not the system's)
             const int u = c1 ? 16 + t : 16;  // (lanes without a second column read a valid address, their values are zeroed)
             const int rowt = PK::tri_rt(t) - t, rowu = PK::tri_rt(u) - u;  // U(t, i) = S[rowt + i], U(u, i) = S[rowu + i]
             unsigned cseq = 0;
@@ -632,22 +662,26 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
                 for (int i = 0; i < SPPC; ++i) {
                     // column t: rows beyond 15 are always below the diagonal
                     const int e0 = (i < 16 && i <= t) ? PK::tri(i) - i + tl : rt + i;
-                    put(pa0[i], S[e0]);
+                    const double v0 = S[e0];
+                    const bool rowv = !YC || i < 16 || i < p;  // (YC: rows p, p + 1 of the slot are not the system's either)
+                    put(pa0[i], rowv ? v0 : 0.0);
                     // column 16 + t: rows up to 15 are always above it
                     const int e1 = (i < 16 || i <= u) ? PK::tri(i) - i + ul : ru + i;
                     const double v1 = S[e1];
-                    put(pa1[i], c1 ? v1 : 0.0);
-                    if (i % 4 == 3) __builtin_amdgcn_sched_barrier(0);  // (eight reads in flight, not 2 SPPC: their temporaries count)
+                    put(pa1[i], (c1 && rowv) ? v1 : 0.0);
+                    if (i % 8 == 7) __builtin_amdgcn_sched_barrier(0);  // (sixteen reads in flight, not 2 SPPC: their temporaries count)
                 }
-                const double x0 = S[PK::XY + tl], x1 = S[PK::XY + ul], s0 = S[PK::CS + tl], s1 = S[PK::CS + ul];
+                // X'y, column sums, rows, sum y -- YC: entries (., p + 1), (., p), (p, p), (p, p + 1) of the triangle
+                const double x0 = YC ? S[rt + p + 1] : S[PK::XY + tl], x1 = YC ? S[ru + p + 1] : S[PK::XY + ul];
+                const double s0 = YC ? S[rt + p] : S[PK::CS + tl], s1 = YC ? S[ru + p] : S[PK::CS + ul];
                 put(pa0[SPPC], x0);
                 put(pa1[SPPC], c1 ? x1 : 0.0);
                 put(psj0, s0);
                 put(psj1, c1 ? s1 : 0.0);
-                put(pnn, S[PK::TAIL]);
-                put(psy, S[PK::TAIL + 1]);
+                put(pnn, YC ? S[PK::tri_rt(p)] : S[PK::TAIL]);
+                put(psy, YC ? S[PK::tri_rt(p) + 1] : S[PK::TAIL + 1]);
                 {
-                    const long long gv = __double_as_longlong(S[PK::TAIL + 2]);
+                    const long long gv = __double_as_longlong(S[PK::GID]);
                     if constexpr (ROW == 0) {
                         pgid = (int64_t)gv;
                     } else {
@@ -665,22 +699,44 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
                 while (FL[0] == cseq) __builtin_amdgcn_s_sleep(1);
             };
             for (;;) {
+                PDS_MT(c0);
                 if (!wait_group()) break;
+                PDS_MADD(8, c0);
+                PDS_MT(c1);
                 take(std::integral_constant<int, 0>{});
+                PDS_MADD(9, c1);
+                PDS_MT(c2);
                 next_group();
+                PDS_MADD(8, c2);
+                PDS_MT(c3);
                 take(std::integral_constant<int, 1>{});
+                PDS_MADD(9, c3);
+                PDS_MT(c4);
                 next_group();
+                PDS_MADD(8, c4);
+                PDS_MT(c5);
                 take(std::integral_constant<int, 2>{});
+                PDS_MADD(9, c5);
+                PDS_MT(c6);
                 next_group();
+                PDS_MADD(8, c6);
+                PDS_MT(c7);
                 take(std::integral_constant<int, 3>{});
+                PDS_MADD(9, c7);
                 npend = 4;
+                PDS_MT(c8);
                 if (!(debug & 4)) solve_pending();  // (bit 4, a timing experiment: routed, never solved)
+                PDS_MADD(10, c8);
             }
         }
     };
     if constexpr (PAIRED)
         if (consumer) {  // (before the streaming wave's state exists: none of it is live in the solver's registers)
             solver_wave();
+#ifdef PDS_PROFILE_MID
+            PDS_MADD(15, t_kernel);
+            mprof_out();
+#endif
             return;
         }
     const int g_ = lane / MD::GL, piece = lane % MD::GL;
@@ -723,6 +779,13 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     };
     zero_acc();
     const int fi = lane & 15, fk = lane >> 4;
+    int opo[NBLK];  // the lane's operand column of block b inside an image
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) opo[b] = fi * GS + b * HR * 8;
+    if constexpr (YC) {  // columns p and p + 1 of the second block: the ones image and the target's image
+        if (16 + fi == p) opo[1] = MD::W_OFF;
+        if (16 + fi == p + 1) opo[1] = MD::Y_OFF;
+    }
     // ---- the group that holds the wave's first row
     int64_t g = 0;
     {
@@ -753,8 +816,9 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
         auto fetch = [&](int s, double (&a)[NBLK], double& yk) __attribute__((always_inline)) {
             const int roff = (4 * s + fk) * 8;
 #pragma unroll
-            for (int b = 0; b < NBLK; ++b) a[b] = PDS_GM_LDSD(base + fi * GS + b * HR * 8 + roff);
-            yk = PDS_GM_LDSD(base + MD::Y_OFF + roff);
+            for (int b = 0; b < NBLK; ++b) a[b] = PDS_GM_LDSD(base + opo[b] + roff);
+            if constexpr (!YC) yk = PDS_GM_LDSD(base + MD::Y_OFF + roff);
+            else yk = 0.0;
         };
         auto mult = [&](const double (&a)[NBLK], double yk) __attribute__((always_inline)) {
             int t = 0;
@@ -766,13 +830,15 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
                         acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], a[J], acc[t], 0, 0, 0);
                     ++t;
                 }
+            if constexpr (!YC) {
 #pragma unroll
-            for (int b = 0; b < NBLK; ++b) {
-                xy[b] = fma(a[b], yk, xy[b]);
-                cs[b] += a[b];
+                for (int b = 0; b < NBLK; ++b) {
+                    xy[b] = fma(a[b], yk, xy[b]);
+                    cs[b] += a[b];
+                }
+                yy = fma(yk, yk, yy);
+                ys += yk;
             }
-            yy = fma(yk, yk, yy);
-            ys += yk;
         };
         auto masked = [&](int s) __attribute__((always_inline)) {
             const int rr = 4 * s + fk;
@@ -831,6 +897,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
             else if (v != 0.0) unsafeAtomicAdd(M + idx, v);
         };
         int t = 0;
+        const int pe = YC ? q : p;  // (YC: the blocks hold [X 1 y]' [X 1 y], which is the record)
 #pragma unroll
         for (int I = 0; I < NBLK; ++I)
 #pragma unroll
@@ -838,13 +905,14 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int i = 16 * I + fk + 4 * r, j = 16 * J + fi;
-                    if (i < p && j < p) {
+                    if (i < pe && j < pe) {
                         put(i + (int64_t)j * q, acc[t][r]);
                         if (I != J) put(j + (int64_t)i * q, acc[t][r]);
                     }
                 }
                 ++t;
             }
+        if constexpr (YC) return;
 #pragma unroll
         for (int b = 0; b < NBLK; ++b) {
             double vx = xy[b], vc = cs[b];
@@ -972,31 +1040,35 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
                              __attribute__((always_inline)) {
         if constexpr (PAIRED) {
             typedef __attribute__((address_space(3))) double* lds_dp;
-            using PK = MidPacked<SPPC>;
+            using PK = MidPacked<SPPC, YC>;
             lds_dp S = (lds_dp)(sm + MD::LDS_BYTES);
+            PDS_MT(tw);
             while (!slot_free()) __builtin_amdgcn_s_sleep(1);
+            PDS_MADD(4, tw);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = fk + 4 * r;  // block (0, 0): G[i][fi], block (0, 1): G[i][16 + fi], block (1, 1): G[16 + i][16 + fi]
                 if (i <= fi) S[PK::tri_rt(i) - i + fi] = A[0][r];
-                if (16 + fi < SPPC) {
+                if (16 + fi < PK::QC) {
                     S[PK::tri_rt(i) - i + 16 + fi] = A[1][r];
                     if (i <= fi) S[PK::tri_rt(16 + i) - i + fi] = A[2][r];
                 }
             }
-            if (fk == 0) {
-                S[PK::XY + fi] = vx0;
-                S[PK::CS + fi] = vc0;
-                if (16 + fi < SPPC) {
-                    S[PK::XY + 16 + fi] = vx1;
-                    S[PK::CS + 16 + fi] = vc1;
+            if constexpr (!YC) {
+                if (fk == 0) {
+                    S[PK::XY + fi] = vx0;
+                    S[PK::CS + fi] = vc0;
+                    if (16 + fi < SPPC) {
+                        S[PK::XY + 16 + fi] = vx1;
+                        S[PK::CS + 16 + fi] = vc1;
+                    }
+                }
+                if (lane == 0) {
+                    S[PK::TAIL] = nn;
+                    S[PK::TAIL + 1] = vys;
                 }
             }
-            if (lane == 0) {
-                S[PK::TAIL] = nn;
-                S[PK::TAIL + 1] = vys;
-                S[PK::TAIL + 2] = __longlong_as_double((long long)gid);
-            }
+            if (lane == 0) S[PK::GID] = __longlong_as_double((long long)gid);
             PDS_WAVE_LDS_SYNC();
             ++pseq;
             FL[0] = pseq;
@@ -1013,11 +1085,13 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     auto hand_over = [&]() __attribute__((always_inline)) {
         if constexpr (PAIRED) {
             double vx0 = xy[0], vx1 = xy[1], vc0 = cs[0], vc1 = cs[1], vys = ys;
-            vx0 += __shfl_xor(vx0, 16); vx0 += __shfl_xor(vx0, 32);
-            vx1 += __shfl_xor(vx1, 16); vx1 += __shfl_xor(vx1, 32);
-            vc0 += __shfl_xor(vc0, 16); vc0 += __shfl_xor(vc0, 32);
-            vc1 += __shfl_xor(vc1, 16); vc1 += __shfl_xor(vc1, 32);
-            vys += __shfl_xor(vys, 16); vys += __shfl_xor(vys, 32);
+            if constexpr (!YC) {
+                vx0 += __shfl_xor(vx0, 16); vx0 += __shfl_xor(vx0, 32);
+                vx1 += __shfl_xor(vx1, 16); vx1 += __shfl_xor(vx1, 32);
+                vc0 += __shfl_xor(vc0, 16); vc0 += __shfl_xor(vc0, 32);
+                vc1 += __shfl_xor(vc1, 16); vc1 += __shfl_xor(vc1, 32);
+                vys += __shfl_xor(vys, 16); vys += __shfl_xor(vys, 32);
+            }
             flush_stash();
 #ifdef PDS_GMID_NO_STASH
             if (true) {
@@ -1074,18 +1148,26 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     fetch_tile(0, h0);
     for (int64_t h = h0; h < h1; ++h) {
         const int buf = (int)((h - h0) & 1);
+        PDS_MT(p0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // half-tile h has landed (and this wave's record stores are out)
         PDS_WAVE_LDS_SYNC();
+        PDS_MADD(0, p0);
+        PDS_MT(p1);
         if (h + 1 < h1) fetch_tile(buf ^ 1, h + 1);  // (the other image was consumed one iteration ago)
+        PDS_MADD(1, p1);
         const int64_t R0 = h * HR;
         const int64_t tile_end = R0 + HR < W1 ? R0 + HR : W1;
         while (pos < tile_end) {
             const int64_t seg_end = ge < tile_end ? ge : tile_end;
+            PDS_MT(p2);
             if (seg_end > pos && !(debug & 1)) consume(buf, (int)(pos - R0), (int)(seg_end - R0));
+            PDS_MADD(2, p2);
             if (debug & 1) rows_in_acc += seg_end - pos;
             pos = seg_end;
             if (pos == ge) {  // group complete (as far as this wave's rows go: `whole` decides how it is written)
+                PDS_MT(p3);
                 if (rows_in_acc > 0) flush();
+                PDS_MADD(3, p3);
                 do {  // (empty groups: their records stay zero)
                     ++g;
                     gs = ge;
@@ -1104,7 +1186,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
         while ((pseq & 3u) != 0u) {  // pad the last batch: the slot's contents once more (a valid system), marked as discarded
             typedef __attribute__((address_space(3))) double* lds_dp;
             while (!slot_free()) __builtin_amdgcn_s_sleep(1);
-            if (lane == 0) ((lds_dp)(sm + MD::LDS_BYTES))[MidPacked<SPPC>::TAIL + 2] = __longlong_as_double(-1ll);
+            if (lane == 0) ((lds_dp)(sm + MD::LDS_BYTES))[MidPacked<SPPC, YC>::GID] = __longlong_as_double(-1ll);
             PDS_WAVE_LDS_SYNC();
             ++pseq;
             FL[0] = pseq;
@@ -1114,6 +1196,10 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     } else {
         solve_pending();
     }
+#ifdef PDS_PROFILE_MID
+    PDS_MADD(7, t_kernel);
+    mprof_out();
+#endif
 #undef PDS_GM_LDSD
 }
 
@@ -1321,8 +1407,12 @@ int launch_grouped_mid_fused(pds_ctx* ctx, const DeviceCols<double>& dc, int n_f
                                debug, sa);
         };
         if (paired) {
-            if (p <= 24) launch_paired(grouped_mid_stream_kernel<2, 24, true>);
-            else launch_paired(grouped_mid_stream_kernel<2, 32, true>);
+            const char* yc_env = std::getenv("PDS_GROUPED_MID_YC");  // (development: '0' keeps the side sums of the 31 / 32-feature form)
+            const bool yc = !(yc_env && yc_env[0] == '0');
+            if (p <= 24 && yc) launch_paired(grouped_mid_stream_kernel<2, 24, true, true>);
+            else if (p <= 24) launch_paired(grouped_mid_stream_kernel<2, 24, true, false>);
+            else if (p <= 30 && yc) launch_paired(grouped_mid_stream_kernel<2, 32, true, true>);
+            else launch_paired(grouped_mid_stream_kernel<2, 32, true, false>);
         } else {
             if (p <= 24) launch(grouped_mid_stream_kernel<2, 24>);
             else launch(grouped_mid_stream_kernel<2, 32>);
@@ -1354,5 +1444,15 @@ int launch_grouped_mid_fused(pds_ctx* ctx, const DeviceCols<double>& dc, int n_f
     PDS_HIP_CHECK(hipGetLastError());
     return PDS_OK;
 }
+
+#ifdef PDS_PROFILE_MID
+extern "C" int pds_debug_mid_phase_cycles(unsigned long long* out, int reset) {
+    static const unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mid_phase), sizeof(z)) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_mid_phase), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
 
 }  // namespace pds
