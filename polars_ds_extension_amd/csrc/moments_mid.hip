@@ -1366,6 +1366,8 @@ int launch_grouped_mid_fused(pds_ctx* ctx, const DeviceCols<double>& dc, int n_f
     sa.sp.inv_tol = 1.0 / sp.gate_tol;
     const bool second_pass = sp.solver != PDS_SOLVER_CHOLESKEY;  // (as launch_solve_wave: "choleskey" IS the in-wave factorisation)
     sa.sp.sus_tol = second_pass ? std::sqrt(sa.sp.inv_tol) : 0.0;
+    sa.sp.sus_ratio = second_pass ? solve_suspect_ratio() : 0.0;
+    sa.sp.sus_band = 1e-5;
     sa.coeffs = d_coeffs;
     sa.flags = d_flags;
     unsigned* d_counts = reinterpret_cast<unsigned*>(take(256));  // [0] marked, [1] side groups
@@ -1382,6 +1384,9 @@ int launch_grouped_mid_fused(pds_ctx* ctx, const DeviceCols<double>& dc, int n_f
     double* co_c = reinterpret_cast<double*>(take(sysmax * pp * 8));
     uint8_t* fl_c = reinterpret_cast<uint8_t*>(take(sysmax));
     void* wave_ws = take(solve_wave_workspace(n_feat, bias, waves, 8));
+    // groups nobody answers (no rows) are null with NaN coefficients: the kernel writes a group's answer where it finishes it
+    PDS_HIP_CHECK(hipMemsetAsync(d_flags, 1, (size_t)n_groups, ctx->stream));
+    PDS_HIP_CHECK(hipMemsetAsync(d_coeffs, 0xFF, (size_t)n_groups * pp * sizeof(double), ctx->stream));
     PDS_HIP_CHECK(hipMemsetAsync(d_counts, 0, 256, ctx->stream));
     PDS_HIP_CHECK(hipMemsetAsync(sa.side_rec, 0, (size_t)waves * q * q * 8, ctx->stream));
     PDS_HIP_CHECK(hipMemsetAsync(sa.side_list, 0xFF, (size_t)waves * 4, ctx->stream));

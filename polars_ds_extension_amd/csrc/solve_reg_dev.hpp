@@ -1,6 +1,7 @@
 // solve_reg_dev.hpp -- device-side building blocks of the register-resident pivoted-QR solve (DPP
 // sub-wave groups), shared by solve_reg.hip and grouped_fused.hip.  See solve_reg.hip for the design notes.
 #pragma once
+#include <cstdlib>
 #include "common.hpp"
 
 namespace pds {
@@ -14,7 +15,25 @@ struct SolveRegDev {
     // is not answered by the Cholesky at all but marked for the pivoted-QR kernel, so that the null decision next to the
     // threshold and the coefficients of marginal systems come from the reference's own factorisation.  0 = off.
     double sus_tol = 0.0;
+    // The wave / row16 solvers (17 .. 64 features) mark less (round 4).  The reference's gate statistic, sum ln |R_ii| - sum ln G_ii of the
+    // pivoted QR, is ln det G - sum ln G_ii whatever the pivoting: MINUS the log of the pivot-ratio product these solvers form, so the
+    // null decision only needs the reference's own arithmetic where the two roundings could disagree -- a product within sus_band
+    // (relative) of 1 / tol -- and the coefficients only where a single pivot has lost sus_ratio of its diagonal (conditioning; a
+    // product of many moderate ratios, e.g. 64 random columns over 100 rows: 6.6e11 from ratios below 3, is no loss of accuracy).
+    // sus_ratio = 0: the product rule above.
+    double sus_ratio = 0.0, sus_band = 0.0;
 };
+// (host) the single-ratio bound: 1e5 unless PDS_SUSPECT_RATIO says otherwise, read per call (0: the product rule, for A/B)
+inline double solve_suspect_ratio() {
+    const char* e = std::getenv("PDS_SUSPECT_RATIO");
+    return e ? std::atof(e) : 1e5;
+}
+// suspect rule of the wave / row16 solvers (grow: product of the pivot ratios, rmax: the largest of them)
+__device__ __forceinline__ bool solve_suspect(const SolveRegDev& sp, bool ok, double grow, double rmax) {
+    if (!(sp.sus_tol > 0.0)) return false;
+    if (!(sp.sus_ratio > 0.0)) return !ok || !(grow < sp.sus_tol);
+    return !ok || !(rmax < sp.sus_ratio) || (grow >= sp.inv_tol * (1.0 - sp.sus_band) && grow <= sp.inv_tol * (1.0 + sp.sus_band));
+}
 
 // Cross-lane moves of a double.  The f64 overload of update_dpp matters: with row_newbcast it is ONE v_mov_b64_dpp
 // (the only DPP control the DP ALU takes), where moving the halves as two ints cost 2 x (v_mov_b32 to seed `old` +
@@ -320,6 +339,13 @@ struct CholBack<LPS, 0> {
     static __device__ __forceinline__ void run(const double (&)[LPS], double&) {}
 };
 
+__device__ __forceinline__ double grp_max16(double v) {
+    v = fmax(v, dpp_mov<kRor8>(0.0, v));
+    v = fmax(v, dpp_mov<kRor4>(0.0, v));
+    v = fmax(v, dpp_mov<kRor2>(0.0, v));
+    v = fmax(v, dpp_mov<kRor1>(0.0, v));
+    return v;
+}
 template <int LPS>
 __device__ __forceinline__ double grp_prod(double v);
 template <>

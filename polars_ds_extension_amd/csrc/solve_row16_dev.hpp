@@ -103,9 +103,10 @@ __device__ __forceinline__ void row16_ldl_solve(double (&a0)[PPC + 1], double (&
     bool ok = true;
     Row16Steps<PPC, PPC - 1, ALL>::run(a0, a1, t, p, i0, i1, ok);
     if (!ok) is_null = true;  // "Not positive-definite -> rank-deficient" (lr_solvers.rs:370-371)
-    const double grow = grp_prod<16>((c0v ? dj0 * i0 : 1.0) * (c1v ? dj1 * i1 : 1.0));  // prod G_kk / d_k
+    const double r0 = c0v ? dj0 * i0 : 1.0, r1 = c1v ? dj1 * i1 : 1.0;
+    const double grow = grp_prod<16>(r0 * r1);  // prod G_kk / d_k
     if (grow >= sp.inv_tol) is_null = true;
-    suspect = sp.sus_tol > 0.0 && (!ok || !(grow < sp.sus_tol)) && !few;
+    suspect = solve_suspect(sp, ok, grow, sp.sus_ratio > 0.0 ? grp_max16(fmax(r0, r1)) : 0.0) && !few;
     is_null = is_null || suspect;
     w0 = a0[PPC] * i0;
     w1 = a1[PPC] * i1;

@@ -144,6 +144,8 @@ int launch_solve_wave(pds_ctx* ctx, const T* d_moments, int64_t n_sys, const Sol
     sd.inv_tol = 1.0 / sp.gate_tol;
     const bool second_pass = sp.solver != PDS_SOLVER_CHOLESKEY;
     sd.sus_tol = second_pass ? std::sqrt(sd.inv_tol) : 0.0;
+    sd.sus_ratio = second_pass ? solve_suspect_ratio() : 0.0;
+    sd.sus_band = 1e-5;
     int32_t* d_list = nullptr;
     unsigned* d_count = nullptr;
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };

@@ -27,6 +27,11 @@ __device__ __forceinline__ double wave_prod64(double v) {
     for (int o = 32; o >= 1; o >>= 1) v *= __shfl_xor(v, o);
     return v;
 }
+__device__ __forceinline__ double wave_max64(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
 
 // PPC: compile-time bound of the feature count (a multiple of 8); p <= PPC features, rows / columns beyond p are exact zeros.
 // in : a (centred column j, rhs in a[PPC]), dj = uncentred diagonal (+ lambda) of column j (1 for lanes without a column),
@@ -59,9 +64,10 @@ __device__ __forceinline__ void wave_ldl_solve(double (&a)[PPC + 1], double dj, 
         }
     }
     if (!ok) is_null = true;  // "Not positive-definite -> rank-deficient" (lr_solvers.rs:370-371)
-    const double grow = wave_prod64(colv ? dj * invd : 1.0);  // prod G_kk / L_kk^2
+    const double ratio = colv ? dj * invd : 1.0;
+    const double grow = wave_prod64(ratio);  // prod G_kk / L_kk^2
     if (grow >= sp.inv_tol) is_null = true;
-    suspect = sp.sus_tol > 0.0 && (!ok || !(grow < sp.sus_tol)) && !few;
+    suspect = solve_suspect(sp, ok, grow, sp.sus_ratio > 0.0 ? wave_max64(ratio) : 0.0) && !few;
     is_null = is_null || suspect;
     // ---- back substitution: w <- w + bcast_M(w) (-a[M] / d_j), lane j final after step j + 1
     w = a[PPC] * invd;

@@ -1144,6 +1144,34 @@ def test_grouped_mid_width_wave_solver(pds, orc, p, bias, l2):
     assert np.median(np.linalg.norm(co_c[both] - co_o[both], axis=1) / np.linalg.norm(co_o[both], axis=1)) < 1e-10
 
 
+@pytest.mark.parametrize("p,rows,bias", [(64, 98, False), (63, 96, True), (48, 60, False), (32, 34, True)])
+def test_grouped_random_groups_at_the_gate(pds, orc, p, rows, bias):
+    """Random groups with few more rows than columns: the relative determinant of X'X is ~ 1e-12 by itself (64 columns over 100 rows: the product of
+    the pivot ratios n / (n - k) is 6.6e11), so every group sits AT the reference's 1e-12 gate, some on either side -- with no single
+    pivot small.  The null decision of the register factorisation must be the reference's (the statistic is the same number: ln det -
+    sum ln G_ii does not depend on the pivoting), and only groups within 1e-5 of the threshold may need the pivoted QR."""
+    rng = np.random.default_rng(6400 + p)
+    G = 3000
+    off = np.arange(0, G * rows + 1, rows, dtype=np.int64)
+    N = G * rows
+    X = rng.normal(size=(N, p))
+    y = X @ rng.normal(size=p) + (0.5 if bias else 0.0) + 0.3 * rng.normal(size=N)
+    co, nu = pds.lin_reg_by(*cols_of(X), target=dev(y), group_offsets=off, add_bias=bias)
+    co, nu = co.cpu().numpy(), nu.cpu().numpy().astype(bool)
+    co_o, nu_o = orc.grouped_lr([y] + [X[:, j] for j in range(p)], off, add_bias=bias, nthreads=4)
+    assert np.array_equal(nu, nu_o), (nu.sum(), nu_o.sum(), np.flatnonzero(nu != nu_o)[:10])
+    assert 0.02 * G < nu.sum() < 0.98 * G, nu.sum()   # (both sides of the gate are populated: the frame tests what it says)
+    ok = ~nu
+    err = np.linalg.norm(co[ok] - co_o[ok], axis=1) / np.linalg.norm(co_o[ok], axis=1)
+    worst = 0.0
+    for g in np.flatnonzero(ok)[np.argsort(err)[-6:]]:
+        Xg = X[off[g]: off[g + 1]]
+        Xb = np.c_[Xg, np.ones(len(Xg))] if bias else Xg
+        bound = max(F64_TOL, 64 * 2.2e-16 * np.linalg.cond(Xb.T @ Xb))
+        worst = max(worst, float(err[np.flatnonzero(ok) == g][0] / bound))
+    assert worst < 1.0, (worst, err.max())
+
+
 @pytest.mark.parametrize("p,bias,l2", [(17, True, 0.0), (22, False, 0.05), (28, True, 0.0), (32, False, 0.0)])
 def test_grouped_mid_fused_wave_boundaries(pds, orc, p, bias, l2):
     """17 .. 32 f64 features, round 4: ONE stream, a finished group solved in the streaming wave (moments_mid.hip SPPC), no moment
