@@ -93,10 +93,10 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
     // chunk the groups so one chunk's moment records (q*q values per group) stay inside the 256 MiB
     // Infinity Cache between the Gram kernel that writes them and the solve kernel that reads them
     const bool big = n_feat > kMaxFeatWide;  // > 64 features: one tiled-SYRK Gram build per group + solve_big
-    // (17 .. 64 features: 512 MiB of records per chunk -- every chunk ends in a host synchronisation for the solver's marked count, and
-    //  fourteen of those cost the 200 000 x 100 x 32 frame 0.6 of its 4.4 ms; PDS_GROUPED_CHUNK_MB overrides)
+    // (17 .. 64 features: 2 GiB of records per chunk -- every chunk ends in a host synchronisation for the solver's marked count:
+    //  100 000 groups x 100 rows x 64 features 7.4 ms in seven chunks of 512 MiB, 6.5 ms in two; PDS_GROUPED_CHUNK_MB overrides)
     static const int64_t chunk_env = [] { const char* e = std::getenv("PDS_GROUPED_CHUNK_MB"); return e ? std::max<int64_t>(1, std::atoll(e)) : 0; }();
-    const int64_t chunk_mb = chunk_env ? chunk_env : ((n_feat > 16 && n_feat <= kMaxFeatWide) ? 512 : 128);
+    const int64_t chunk_mb = chunk_env ? chunk_env : ((n_feat > 16 && n_feat <= kMaxFeatWide) ? 2048 : 128);
     int64_t chunk = std::max<int64_t>(big ? 64 : 4096, (int64_t)(chunk_mb << 20) / (int64_t)(sizeof(T) * q * q));
     chunk = std::min(chunk, n_groups);
     size_t need = 131072 + sizeof(T) * (size_t)chunk * q * q;
