@@ -451,6 +451,24 @@ struct MidSolveArgs {
     unsigned mark_cap = 0;
 };
 constexpr int kMidSolveScratch = 5120;  // bytes behind the tile images (4 x 40 KB per CU): 24 columns x 26 doubles in one trip, or 16 x 34 per trip
+// v summed lane-wise over the four 16-lane rows of the wave (every lane gets its column's total): v_permlane16_swap / v_permlane32_swap
+// of gfx950 -- with both operands the same value the swap leaves [r0 r0 r2 r2] and [r1 r1 r3 r3] (rows), then the two halves -- four
+// vector moves per stage instead of two trips through the LDS crossbar (__shfl_xor)
+__device__ __forceinline__ double rows_sum4(double v) {
+    {
+        const int lo = __double2loint(v), hi = __double2hiint(v);
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+    }
+    {
+        const int lo = __double2loint(v), hi = __double2hiint(v);
+        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+    }
+    return v;
+}
 // the slot between a streaming and a solving wave (PAIRED): the upper triangle of the SPPC x SPPC moment block row by row, U(r, c) at
 // tri(r) + c - r, then X'y, the column sums, and [rows, sum y, group] -- 4 760 bytes at 32 features
 // YC: the triangle is that of [X 1 y]' [X 1 y] (QC = columns incl. the two), only the group id follows it.
@@ -473,7 +491,12 @@ constexpr int kMidPairLds = MidDims<NBLK>::LDS_BYTES + kMidSolveScratch + 64;  /
 // YC (PAIRED, up to 30 features): the ones and the target are columns p and p + 1 of the second operand block -- the column sums, X'y, the
 // row count and sum y come out of the matrix instructions that run anyway (no side sums per step, no cross-row reductions per group),
 // and the accumulator blocks ARE the record [X 1 y]' [X 1 y].
-template <int NBLK, int SPPC = 0, bool PAIRED = false, bool YC = false>
+// NQ = 1 (YC, up to 18 features: the second operand block holds at most FOUR columns -- x16, x17, the ones, the target): its two
+// 16 x 16 x 4 matrix instructions per step (64 ticks each, a quarter of a block useful) become two v_mfma_f64_4x4x4_4b (20 ticks each; layout
+// and rate: tools/mfma_f64_4x4_probe.hip -- A[i][k] of block b in lane 16 k + 4 b + i, B[k][j] in lane 16 k + 4 b + j, D[i][j] in lane
+// 16 i + 4 b + j): block b of the first multiplies columns 4 b .. 4 b + 3 of the first operand block (its lanes ARE the 16 x 16 operand's)
+// with the quad, the second the quad with itself.
+template <int NBLK, int SPPC = 0, bool PAIRED = false, bool YC = false, int NQ = 0>
 __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(const double* const* __restrict__ cols, int p, int64_t n_frame,
                                                                 const int64_t* __restrict__ off, int64_t n_groups,
                                                                 double* __restrict__ records, int debug, MidSolveArgs sa) {
@@ -481,6 +504,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     static_assert(!PAIRED || SPPC > 0, "pairs exist for the in-kernel solve");
     static_assert(!PAIRED || MidPacked<SPPC ? SPPC : 1, YC>::COUNT * 8 <= kMidSolveScratch, "the slot holds one group");
     static_assert(!YC || PAIRED, "the ones / target columns are the paired form's");
+    static_assert(NQ == 0 || (NQ == 1 && YC && NBLK == 2), "the quad form: ones and target inside the quad");
     using MD = MidDims<NBLK>;
     constexpr int HR = MD::HR, GS = MD::GS, NPAIR = MD::NPAIR;
     extern __shared__ __attribute__((aligned(16))) char gmid_lds[];
@@ -658,18 +682,36 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
                 // one register each)
                 int tl = t, ul = u, rt = rowt, ru = rowu;
                 asm volatile("" : "+v"(tl), "+v"(ul), "+v"(rt), "+v"(ru));
+                // eight rows (sixteen reads) at a time, the next eight in flight while these are moved into the pending registers
+                constexpr int NB = SPPC / 8;
+                double va[2][8], vb[2][8];
+                auto fetch8 = [&](int b, double (&x0)[8], double (&x1)[8]) __attribute__((always_inline)) {
 #pragma unroll
-                for (int i = 0; i < SPPC; ++i) {
-                    // column t: rows beyond 15 are always below the diagonal
-                    const int e0 = (i < 16 && i <= t) ? PK::tri(i) - i + tl : rt + i;
-                    const double v0 = S[e0];
-                    const bool rowv = !YC || i < 16 || i < p;  // (YC: rows p, p + 1 of the slot are not the system's either)
-                    put(pa0[i], rowv ? v0 : 0.0);
-                    // column 16 + t: rows up to 15 are always above it
-                    const int e1 = (i < 16 || i <= u) ? PK::tri(i) - i + ul : ru + i;
-                    const double v1 = S[e1];
-                    put(pa1[i], (c1 && rowv) ? v1 : 0.0);
-                    if (i % 8 == 7) __builtin_amdgcn_sched_barrier(0);  // (sixteen reads in flight, not 2 SPPC: their temporaries count)
+                    for (int k = 0; k < 8; ++k) {
+                        const int i = 8 * b + k;
+                        // column t: rows beyond 15 are always below the diagonal; column 16 + t: rows up to 15 are always above it
+                        const int e0 = (i < 16 && i <= t) ? PK::tri(i) - i + tl : rt + i;
+                        const int e1 = (i < 16 || i <= u) ? PK::tri(i) - i + ul : ru + i;
+                        x0[k] = S[e0];
+                        x1[k] = S[e1];
+                    }
+                };
+                auto put8 = [&](int b, const double (&x0)[8], const double (&x1)[8]) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int i = 8 * b + k;
+                        const bool rowv = !YC || i < 16 || i < p;  // (YC: rows p, p + 1 of the slot are not the system's either)
+                        put(pa0[i], rowv ? x0[k] : 0.0);
+                        put(pa1[i], (c1 && rowv) ? x1[k] : 0.0);
+                    }
+                };
+                fetch8(0, va[0], vb[0]);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    if (b + 1 < NB) fetch8(b + 1, va[(b + 1) & 1], vb[(b + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    put8(b, va[b & 1], vb[b & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 // X'y, column sums, rows, sum y -- YC: entries (., p + 1), (., p), (p, p), (p, p + 1) of the triangle
                 const double x0 = YC ? S[rt + p + 1] : S[PK::XY + tl], x1 = YC ? S[ru + p + 1] : S[PK::XY + ul];
@@ -782,9 +824,11 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     int opo[NBLK];  // the lane's operand column of block b inside an image
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) opo[b] = fi * GS + b * HR * 8;
+    if constexpr (NQ == 1) opo[1] = (fi & 3) * GS + HR * 8;  // (the quad: column 16 + lane % 4)
     if constexpr (YC) {  // columns p and p + 1 of the second block: the ones image and the target's image
-        if (16 + fi == p) opo[1] = MD::W_OFF;
-        if (16 + fi == p + 1) opo[1] = MD::Y_OFF;
+        const int c1 = NQ == 1 ? 16 + (fi & 3) : 16 + fi;
+        if (c1 == p) opo[1] = MD::W_OFF;
+        if (c1 == p + 1) opo[1] = MD::Y_OFF;
     }
     // ---- the group that holds the wave's first row
     int64_t g = 0;
@@ -821,15 +865,21 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
             else yk = 0.0;
         };
         auto mult = [&](const double (&a)[NBLK], double yk) __attribute__((always_inline)) {
-            int t = 0;
+            if constexpr (NQ == 1) {
+                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], a[0], acc[0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[0], a[1], acc[1][0], 0, 0, 0);
+                acc[2][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[1], a[1], acc[2][0], 0, 0, 0);
+            } else {
+                int t = 0;
 #pragma unroll
-            for (int I = 0; I < NBLK; ++I)
+                for (int I = 0; I < NBLK; ++I)
 #pragma unroll
-                for (int J = I; J < NBLK; ++J) {
-                    if (t == 0 || !(debug & 8))  // (timing experiment: the first block only)
-                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], a[J], acc[t], 0, 0, 0);
-                    ++t;
-                }
+                    for (int J = I; J < NBLK; ++J) {
+                        if (t == 0 || !(debug & 8))  // (timing experiment: the first block only)
+                            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], a[J], acc[t], 0, 0, 0);
+                        ++t;
+                    }
+            }
             if constexpr (!YC) {
 #pragma unroll
                 for (int b = 0; b < NBLK; ++b) {
@@ -898,6 +948,20 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
         };
         int t = 0;
         const int pe = YC ? q : p;  // (YC: the blocks hold [X 1 y]' [X 1 y], which is the record)
+        if constexpr (NQ == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = fk + 4 * r, j = fi;
+                if (i < pe && j < pe) put(i + (int64_t)j * q, acc[0][r]);
+            }
+            const int qb = (lane >> 2) & 3, qj = lane & 3;  // quad lanes: D[i = fk][j = qj] of block qb
+            if (16 + qj < pe) {
+                put((4 * qb + fk) + (int64_t)(16 + qj) * q, acc[1][0]);
+                put((16 + qj) + (int64_t)(4 * qb + fk) * q, acc[1][0]);
+                if (qb == 0 && 16 + fk < pe) put((16 + fk) + (int64_t)(16 + qj) * q, acc[2][0]);
+            }
+            return;
+        }
 #pragma unroll
         for (int I = 0; I < NBLK; ++I)
 #pragma unroll
@@ -1045,13 +1109,24 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
             PDS_MT(tw);
             while (!slot_free()) __builtin_amdgcn_s_sleep(1);
             PDS_MADD(4, tw);
+            if constexpr (NQ == 1) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = fk + 4 * r;  // block (0, 0): G[i][fi], block (0, 1): G[i][16 + fi], block (1, 1): G[16 + i][16 + fi]
-                if (i <= fi) S[PK::tri_rt(i) - i + fi] = A[0][r];
-                if (16 + fi < PK::QC) {
-                    S[PK::tri_rt(i) - i + 16 + fi] = A[1][r];
-                    if (i <= fi) S[PK::tri_rt(16 + i) - i + fi] = A[2][r];
+                for (int r = 0; r < 4; ++r) {
+                    const int i = fk + 4 * r;
+                    if (i <= fi) S[PK::tri_rt(i) - i + fi] = A[0][r];
+                }
+                const int qb = (lane >> 2) & 3, qj = lane & 3, qr = 4 * qb + fk;  // quad lanes: D[i = fk][j = qj] of block qb
+                S[PK::tri_rt(qr) - qr + 16 + qj] = A[1][0];
+                if (qb == 0 && fk <= qj) S[PK::tri_rt(16 + fk) - fk + qj] = A[2][0];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = fk + 4 * r;  // block (0, 0): G[i][fi], block (0, 1): G[i][16 + fi], block (1, 1): G[16 + i][16 + fi]
+                    if (i <= fi) S[PK::tri_rt(i) - i + fi] = A[0][r];
+                    if (16 + fi < PK::QC) {
+                        S[PK::tri_rt(i) - i + 16 + fi] = A[1][r];
+                        if (i <= fi) S[PK::tri_rt(16 + i) - i + fi] = A[2][r];
+                    }
                 }
             }
             if constexpr (!YC) {
@@ -1086,11 +1161,11 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
         if constexpr (PAIRED) {
             double vx0 = xy[0], vx1 = xy[1], vc0 = cs[0], vc1 = cs[1], vys = ys;
             if constexpr (!YC) {
-                vx0 += __shfl_xor(vx0, 16); vx0 += __shfl_xor(vx0, 32);
-                vx1 += __shfl_xor(vx1, 16); vx1 += __shfl_xor(vx1, 32);
-                vc0 += __shfl_xor(vc0, 16); vc0 += __shfl_xor(vc0, 32);
-                vc1 += __shfl_xor(vc1, 16); vc1 += __shfl_xor(vc1, 32);
-                vys += __shfl_xor(vys, 16); vys += __shfl_xor(vys, 32);
+                vx0 = rows_sum4(vx0);
+                vx1 = rows_sum4(vx1);
+                vc0 = rows_sum4(vc0);
+                vc1 = rows_sum4(vc1);
+                vys = rows_sum4(vys);
             }
             flush_stash();
 #ifdef PDS_GMID_NO_STASH
@@ -1414,7 +1489,9 @@ int launch_grouped_mid_fused(pds_ctx* ctx, const DeviceCols<double>& dc, int n_f
         if (paired) {
             const char* yc_env = std::getenv("PDS_GROUPED_MID_YC");  // (development: '0' keeps the side sums of the 31 / 32-feature form)
             const bool yc = !(yc_env && yc_env[0] == '0');
-            if (p <= 24 && yc) launch_paired(grouped_mid_stream_kernel<2, 24, true, true>);
+            const char* nq_env = std::getenv("PDS_GROUPED_MID_QUAD");  // (development: '0' keeps the 16 x 16 x 4 form of the second block)
+            if (p <= 18 && yc && !(nq_env && nq_env[0] == '0')) launch_paired(grouped_mid_stream_kernel<2, 24, true, true, 1>);
+            else if (p <= 24 && yc) launch_paired(grouped_mid_stream_kernel<2, 24, true, true>);
             else if (p <= 24) launch_paired(grouped_mid_stream_kernel<2, 24, true, false>);
             else if (p <= 30 && yc) launch_paired(grouped_mid_stream_kernel<2, 32, true, true>);
             else launch_paired(grouped_mid_stream_kernel<2, 32, true, false>);
