@@ -504,7 +504,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     static_assert(!PAIRED || SPPC > 0, "pairs exist for the in-kernel solve");
     static_assert(!PAIRED || MidPacked<SPPC ? SPPC : 1, YC>::COUNT * 8 <= kMidSolveScratch, "the slot holds one group");
     static_assert(!YC || PAIRED, "the ones / target columns are the paired form's");
-    static_assert(NQ == 0 || (NQ == 1 && YC && NBLK == 2), "the quad form: ones and target inside the quad");
+    static_assert(NQ == 0 || ((NQ == 1 || NQ == 2) && YC && NBLK == 2), "the quad form: ones and target inside the quads");
     using MD = MidDims<NBLK>;
     constexpr int HR = MD::HR, GS = MD::GS, NPAIR = MD::NPAIR;
     extern __shared__ __attribute__((aligned(16))) char gmid_lds[];
@@ -821,15 +821,18 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     };
     zero_acc();
     const int fi = lane & 15, fk = lane >> 4;
-    int opo[NBLK];  // the lane's operand column of block b inside an image
+    constexpr int NOP = NQ ? 1 + NQ : NBLK;  // operand registers per step: the first block + NQ quads, or the NBLK blocks
+    int opo[NOP];  // the lane's operand column inside an image
 #pragma unroll
-    for (int b = 0; b < NBLK; ++b) opo[b] = fi * GS + b * HR * 8;
-    if constexpr (NQ == 1) opo[1] = (fi & 3) * GS + HR * 8;  // (the quad: column 16 + lane % 4)
-    if constexpr (YC) {  // columns p and p + 1 of the second block: the ones image and the target's image
-        const int c1 = NQ == 1 ? 16 + (fi & 3) : 16 + fi;
-        if (c1 == p) opo[1] = MD::W_OFF;
-        if (c1 == p + 1) opo[1] = MD::Y_OFF;
+    for (int b = 0; b < NOP; ++b) {
+        const int c = NQ ? (b == 0 ? fi : 12 + 4 * b + (fi & 3)) : 16 * b + fi;  // (quad b - 1: column 16 + 4 (b - 1) + lane % 4)
+        opo[b] = (c & 15) * GS + (c >> 4) * HR * 8;
+        if constexpr (YC) {  // columns p and p + 1: the ones image and the target's image
+            if (b > 0 && c == p) opo[b] = MD::W_OFF;
+            if (b > 0 && c == p + 1) opo[b] = MD::Y_OFF;
+        }
     }
+    const int qb = (lane >> 2) & 3, qj = lane & 3;  // quad lanes: D[i = fk][j = qj] of block qb
     // ---- the group that holds the wave's first row
     int64_t g = 0;
     {
@@ -857,18 +860,25 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     // multiplies (fetch -> wait -> multiply per step ran at half the stream rate: one wave per SIMD, nobody else hides the round trip)
     auto consume = [&](int buf, int lo, int hi) __attribute__((always_inline)) {
         const lds_c base = sm + buf * MD::HALF_BYTES;
-        auto fetch = [&](int s, double (&a)[NBLK], double& yk) __attribute__((always_inline)) {
+        auto fetch = [&](int s, double (&a)[NOP], double& yk) __attribute__((always_inline)) {
             const int roff = (4 * s + fk) * 8;
 #pragma unroll
-            for (int b = 0; b < NBLK; ++b) a[b] = PDS_GM_LDSD(base + opo[b] + roff);
+            for (int b = 0; b < NOP; ++b) a[b] = PDS_GM_LDSD(base + opo[b] + roff);
             if constexpr (!YC) yk = PDS_GM_LDSD(base + MD::Y_OFF + roff);
             else yk = 0.0;
         };
-        auto mult = [&](const double (&a)[NBLK], double yk) __attribute__((always_inline)) {
+        auto mult = [&](const double (&a)[NOP], double yk) __attribute__((always_inline)) {
             if constexpr (NQ == 1) {
                 acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], a[0], acc[0], 0, 0, 0);
                 acc[1][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[0], a[1], acc[1][0], 0, 0, 0);
                 acc[2][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[1], a[1], acc[2][0], 0, 0, 0);
+            } else if constexpr (NQ == 2) {
+                // the 8 x 8 corner in ONE instruction: block 0 = quad 0 with itself, 1 = quad 0 with quad 1, 2 (and 3) = quad 1 with itself
+                const double ca = qb < 2 ? a[1] : a[2], cb = qb == 0 ? a[1] : a[2];
+                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], a[0], acc[0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[0], a[1], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[0], a[2], acc[1][1], 0, 0, 0);
+                acc[2][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(ca, cb, acc[2][0], 0, 0, 0);
             } else {
                 int t = 0;
 #pragma unroll
@@ -893,25 +903,25 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
         auto masked = [&](int s) __attribute__((always_inline)) {
             const int rr = 4 * s + fk;
             const bool in = rr >= lo && rr < hi;
-            double a[NBLK], yk;
+            double a[NOP], yk;
             fetch(s, a, yk);
 #pragma unroll
-            for (int b = 0; b < NBLK; ++b) a[b] = in ? a[b] : 0.0;
+            for (int b = 0; b < NOP; ++b) a[b] = in ? a[b] : 0.0;
             yk = in ? yk : 0.0;
             mult(a, yk);
         };
         if (lo == 0 && hi == HR) {  // a whole half-tile of one group: the unrolled form of the single-regression kernel
-            double a[NBLK], yk;
+            double a[NOP], yk;
             fetch(0, a, yk);
 #pragma unroll
             for (int s = 0; s < MD::NS; ++s) {
-                double an[NBLK], ykn = 0.0;
+                double an[NOP], ykn = 0.0;
 #pragma unroll
-                for (int b = 0; b < NBLK; ++b) an[b] = 0.0;
+                for (int b = 0; b < NOP; ++b) an[b] = 0.0;
                 if (s + 1 < MD::NS) fetch(s + 1, an, ykn);
                 mult(a, yk);
 #pragma unroll
-                for (int b = 0; b < NBLK; ++b) a[b] = an[b];
+                for (int b = 0; b < NOP; ++b) a[b] = an[b];
                 yk = ykn;
             }
             rows_in_acc += HR;
@@ -927,14 +937,14 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
             masked(s1);
         }
         if (s0 < s1) {
-            double a[NBLK], yk;
+            double a[NOP], yk;
             fetch(s0, a, yk);
             for (int s = s0; s < s1; ++s) {
-                double an[NBLK], ykn;
+                double an[NOP], ykn;
                 fetch(s + 1 < s1 ? s + 1 : s, an, ykn);
                 mult(a, yk);
 #pragma unroll
-                for (int b = 0; b < NBLK; ++b) a[b] = an[b];
+                for (int b = 0; b < NOP; ++b) a[b] = an[b];
                 yk = ykn;
             }
         }
@@ -948,17 +958,26 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
         };
         int t = 0;
         const int pe = YC ? q : p;  // (YC: the blocks hold [X 1 y]' [X 1 y], which is the record)
-        if constexpr (NQ == 1) {
+        if constexpr (NQ != 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = fk + 4 * r, j = fi;
                 if (i < pe && j < pe) put(i + (int64_t)j * q, acc[0][r]);
             }
-            const int qb = (lane >> 2) & 3, qj = lane & 3;  // quad lanes: D[i = fk][j = qj] of block qb
-            if (16 + qj < pe) {
-                put((4 * qb + fk) + (int64_t)(16 + qj) * q, acc[1][0]);
-                put((16 + qj) + (int64_t)(4 * qb + fk) * q, acc[1][0]);
-                if (qb == 0 && 16 + fk < pe) put((16 + fk) + (int64_t)(16 + qj) * q, acc[2][0]);
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) {  // first block x quad u: G[4 qb + fk][16 + 4 u + qj]
+                const int c = 16 + 4 * u + qj;
+                if (c < pe) {
+                    put((4 * qb + fk) + (int64_t)c * q, acc[1][u]);
+                    put(c + (int64_t)(4 * qb + fk) * q, acc[1][u]);
+                }
+            }
+            {  // the corner: NQ = 1: block 0 = (quad 0, quad 0), both triangles in its lanes; NQ = 2: blocks (0, 0), (0, 1), (1, 1)
+                const int ri = 16 + (NQ == 2 && qb >= 2 ? 4 : 0) + fk, cj = 16 + (NQ == 2 && qb >= 1 ? 4 : 0) + qj;
+                if (qb < (NQ == 2 ? 3 : 1) && ri < pe && cj < pe) {
+                    put(ri + (int64_t)cj * q, acc[2][0]);
+                    if (NQ == 2 && qb == 1) put(cj + (int64_t)ri * q, acc[2][0]);
+                }
             }
             return;
         }
@@ -1109,15 +1128,19 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
             PDS_MT(tw);
             while (!slot_free()) __builtin_amdgcn_s_sleep(1);
             PDS_MADD(4, tw);
-            if constexpr (NQ == 1) {
+            if constexpr (NQ != 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int i = fk + 4 * r;
                     if (i <= fi) S[PK::tri_rt(i) - i + fi] = A[0][r];
                 }
-                const int qb = (lane >> 2) & 3, qj = lane & 3, qr = 4 * qb + fk;  // quad lanes: D[i = fk][j = qj] of block qb
-                S[PK::tri_rt(qr) - qr + 16 + qj] = A[1][0];
-                if (qb == 0 && fk <= qj) S[PK::tri_rt(16 + fk) - fk + qj] = A[2][0];
+                const int qr = 4 * qb + fk;  // quad lanes: D[i = fk][j = qj] of block qb
+#pragma unroll
+                for (int u = 0; u < NQ; ++u) S[PK::tri_rt(qr) - qr + 16 + 4 * u + qj] = A[1][u];
+                {   // the corner: (quad 0, quad 0) [, (quad 0, quad 1), (quad 1, quad 1)]: the upper triangle of it
+                    const int ri = 16 + (NQ == 2 && qb >= 2 ? 4 : 0) + fk, cj = 16 + (NQ == 2 && qb >= 1 ? 4 : 0) + qj;
+                    if (qb < (NQ == 2 ? 3 : 1) && ri <= cj) S[PK::tri_rt(ri) - ri + cj] = A[2][0];
+                }
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -1491,6 +1514,7 @@ int launch_grouped_mid_fused(pds_ctx* ctx, const DeviceCols<double>& dc, int n_f
             const bool yc = !(yc_env && yc_env[0] == '0');
             const char* nq_env = std::getenv("PDS_GROUPED_MID_QUAD");  // (development: '0' keeps the 16 x 16 x 4 form of the second block)
             if (p <= 18 && yc && !(nq_env && nq_env[0] == '0')) launch_paired(grouped_mid_stream_kernel<2, 24, true, true, 1>);
+            else if (p <= 22 && yc && !(nq_env && nq_env[0] == '0')) launch_paired(grouped_mid_stream_kernel<2, 24, true, true, 2>);
             else if (p <= 24 && yc) launch_paired(grouped_mid_stream_kernel<2, 24, true, true>);
             else if (p <= 24) launch_paired(grouped_mid_stream_kernel<2, 24, true, false>);
             else if (p <= 30 && yc) launch_paired(grouped_mid_stream_kernel<2, 32, true, true>);
