@@ -23,7 +23,7 @@ namespace {
 
 // PPC: compile-time bound of the feature count (a multiple of 8); p <= PPC features, rows / columns beyond p are exact zeros
 template <typename T, int PPC>
-__global__ __launch_bounds__(64) void solve_wave_kernel(const T* __restrict__ moments, int64_t n_sys, SolveRegDev sp, T* __restrict__ coeffs,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void solve_wave_kernel(const T* __restrict__ moments, int64_t n_sys, SolveRegDev sp, T* __restrict__ coeffs,
                                                         uint8_t* __restrict__ flags, const int64_t* __restrict__ rows_per_sys,
                                                         int32_t* __restrict__ mark_list, unsigned* __restrict__ mark_count) {
     const int j = threadIdx.x;
