@@ -503,4 +503,5 @@ int pds_gather_f32(pds_ctx* const* ctxs, int n_ctx, const float* const* src, con
     return pds::gather_impl<float>(ctxs, n_ctx, src, counts, dst);
 }
 int pds_debug_last_multi_route(void) { return pds::g_multi_route; }
+int pds_debug_last_grouped_route(void) { return pds::g_grouped_route; }
 }  // extern "C"

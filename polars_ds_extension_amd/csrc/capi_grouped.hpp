@@ -6,6 +6,9 @@
 // ---------------------------------------------------------------------------------------------
 // grouped
 // ---------------------------------------------------------------------------------------------
+// which way the last grouped call of this thread with 17 .. 32 f64 features went (tests): 0 neither, 1 the fused stream, 2 the record
+// pipeline after the fused form gave the call back (marked list overflow)
+static thread_local int g_grouped_route = 0;
 // Groups with more than 64 features (coverage path): every group's Gram matrix comes from the tiled matrix-core SYRK of the
 // single-regression path (moments_wide.hip) on that group's row range, the records of a chunk of groups are then solved
 // together (solve_big.hip: Cholesky on an L2-resident workspace, one workgroup per system; CD / NNLS: one wavefront each).
@@ -102,7 +105,7 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
     size_t need = 131072 + sizeof(T) * (size_t)chunk * q * q;
     need += (size_t)n_groups * 4 + (size_t)chunk * (pp * sizeof(T) + 1) + 4096;  // the fused path's pivoted-QR pass: list, results
     if (n_feat > 16 && n_feat <= 64) need += solve_wave_workspace(n_feat, bias, chunk, sizeof(T)) + 512;
-    if (n_feat > 16 && n_feat <= 32 && sizeof(T) == 8) need += grouped_mid_fused_workspace(ctx->num_cus, n_feat, bias) + 512;
+    if (n_feat > 16 && n_feat <= 32) need += grouped_mid_fused_workspace(ctx->num_cus, n_feat, bias) + 512;
     if (big) need += (size_t)n_groups * (n_feat + 1) * sizeof(T*) + moments_wide_workspace(ctx->num_cus, n_feat, n_rows) + 8192;
     if (space == PDS_HOST || !coeffs) need += (size_t)(n_groups + 1) * 8 + (size_t)n_groups * (pp * sizeof(T) + 1) + 4096;
     if (want_pred && space == PDS_HOST) need += 2 * ((size_t)n_rows * sizeof(T) + 256) + (size_t)n_rows + 256;
@@ -222,13 +225,15 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
         // (moments_mid.hip, SPPC); PDS_GROUPED_MID_FUSED=0: the record pipeline below (A/B); it also takes over when more systems sit
         // next to the gate than the fused form's marked list holds
         bool mid_done = false;
-        if constexpr (std::is_same<T, double>::value) {
+        g_grouped_route = 0;
+        {
             const char* mf = std::getenv("PDS_GROUPED_MID_FUSED");
             if (n_feat > 16 && n_feat <= 32 && !want_piv && !(mf && mf[0] == '0')) {
                 void* d_fws = ws_take(ctx, grouped_mid_fused_workspace(ctx->num_cus, n_feat, bias));
-                const int rcf = launch_grouped_mid_fused(ctx, dc, n_feat, n_rows, d_off, n_groups, sp, d_coeffs, d_null, d_fws);
+                const int rcf = launch_grouped_mid_fused<T>(ctx, dc, n_feat, n_rows, d_off, n_groups, sp, d_coeffs, d_null, d_fws);
                 if (rcf == PDS_OK) mid_done = true;
                 else if (rcf != PDS_ERR_UNSUPPORTED) return rcf;
+                g_grouped_route = mid_done ? 1 : 2;  // (development hook: pds_debug_last_grouped_route)
             }
         }
         void* d_wave_ws = (!mid_done && n_feat > 16 && n_feat <= 64 && !want_piv) ? ws_take(ctx, solve_wave_workspace(n_feat, bias, chunk, sizeof(T))) : nullptr;

@@ -272,8 +272,9 @@ int launch_grouped_pred_by_id(pds_ctx* ctx, const T* const* d_cols, int n_feat, 
 int launch_grouped_moments_stream(pds_ctx* ctx, const DeviceCols<double>& dc, int n_feat, int64_t n_frame, const int64_t* d_off, int64_t n_groups,
                                   double* d_records);  // moments_mid.hip: grouped Gram records, 17 .. 64 f64 features, one stream
 // moments_mid.hip: grouped OLS / ridge with 17 .. 32 f64 features as one stream, the solves in the streaming waves (no records)
-int launch_grouped_mid_fused(pds_ctx* ctx, const DeviceCols<double>& dc, int n_feat, int64_t n_frame, const int64_t* d_off, int64_t n_groups,
-                             const SolveParams& sp, double* d_coeffs, uint8_t* d_flags, void* d_ws);
+template <typename T>
+int launch_grouped_mid_fused(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_frame, const int64_t* d_off, int64_t n_groups,
+                             const SolveParams& sp, T* d_coeffs, uint8_t* d_flags, void* d_ws);
 size_t grouped_mid_fused_workspace(int num_cus, int n_feat, int add_bias);
 int leverage_operand(pds_ctx* ctx, const double* d_inv, int n_feat, int bias, const double** d_lop);
 int launch_report_mid(pds_ctx* ctx, const DeviceCols<double>& dc, int n_feat, int bias, int64_t n_rows, const double* d_beta, const double* d_inv,

@@ -439,9 +439,10 @@ int launch_mid(pds_ctx* ctx, const DeviceCols<T>& dc, int p, int64_t n, T* d_mom
 // boundary (atomics into the side table's slot of the wave it starts in: at most one per wave) and a system next to the gate
 // (appended to the marked list for the pivoted QR; its record is rebuilt from its rows).  The per-group dispatch
 // of pl_lr under group_by (linear_regression.rs:447-497) at 17 .. 32 features then moves input + coefficients only, as at <= 16.
-struct MidSolveArgs {
+template <typename T>
+struct MidSolveArgsT {
     SolveRegDev sp;
-    double* coeffs = nullptr;      // [n_groups][p + bias]
+    T* coeffs = nullptr;           // [n_groups][p + bias]
     uint8_t* flags = nullptr;      // [n_groups]: 1 = null
     double* side_rec = nullptr;    // [waves][q * q], zeroed: records of groups that straddle wave boundaries
     int32_t* side_list = nullptr;  // [waves], -1: slot w = the group that starts in wave w's rows and ends beyond them
@@ -450,6 +451,7 @@ struct MidSolveArgs {
     unsigned* mark_count = nullptr;  // appended count (beyond mark_cap: overflow, the caller falls back to the record pipeline)
     unsigned mark_cap = 0;
 };
+using MidSolveArgs = MidSolveArgsT<double>;
 constexpr int kMidSolveScratch = 5120;  // bytes behind the tile images (4 x 40 KB per CU): 24 columns x 26 doubles in one trip, or 16 x 34 per trip
 // v summed lane-wise over the four 16-lane rows of the wave (every lane gets its column's total): v_permlane16_swap / v_permlane32_swap
 // of gfx950 -- with both operands the same value the swap leaves [r0 r0 r2 r2] and [r1 r1 r3 r3] (rows), then the two halves -- four
@@ -496,16 +498,20 @@ constexpr int kMidPairLds = MidDims<NBLK>::LDS_BYTES + kMidSolveScratch + 64;  /
 // and rate: tools/mfma_f64_4x4_probe.hip -- A[i][k] of block b in lane 16 k + 4 b + i, B[k][j] in lane 16 k + 4 b + j, D[i][j] in lane
 // 16 i + 4 b + j): block b of the first multiplies columns 4 b .. 4 b + 3 of the first operand block (its lanes ARE the 16 x 16 operand's)
 // with the quad, the second the quad with itself.
-template <int NBLK, int SPPC = 0, bool PAIRED = false, bool YC = false, int NQ = 0>
-__global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(const double* const* __restrict__ cols, int p, int64_t n_frame,
+// T = float (PAIRED only): f32 frames -- 128-row half-tiles of the same 1 KiB instructions and the same LDS bytes, widened to f64 on their
+// way out of LDS; moments, slot, solve and side / marked records are f64 as for f64 frames, the coefficients are written as T.
+template <int NBLK, int SPPC = 0, bool PAIRED = false, bool YC = false, int NQ = 0, typename T = double>
+__global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(const T* const* __restrict__ cols, int p, int64_t n_frame,
                                                                 const int64_t* __restrict__ off, int64_t n_groups,
-                                                                double* __restrict__ records, int debug, MidSolveArgs sa) {
+                                                                double* __restrict__ records, int debug, MidSolveArgsT<T> sa) {
+    constexpr int ES = (int)sizeof(T), EPL = 16 / ES;  // element bytes; elements per 16-byte lane piece
+    static_assert(ES == 8 || PAIRED, "f32 frames: the paired form");
     static_assert(SPPC == 0 || NBLK == 2, "the in-wave solve serves two tile columns");
     static_assert(!PAIRED || SPPC > 0, "pairs exist for the in-kernel solve");
     static_assert(!PAIRED || MidPacked<SPPC ? SPPC : 1, YC>::COUNT * 8 <= kMidSolveScratch, "the slot holds one group");
     static_assert(!YC || PAIRED, "the ones / target columns are the paired form's");
     static_assert(NQ == 0 || ((NQ == 1 || NQ == 2) && YC && NBLK == 2), "the quad form: ones and target inside the quads");
-    using MD = MidDims<NBLK>;
+    using MD = MidDims<NBLK, ES>;
     constexpr int HR = MD::HR, GS = MD::GS, NPAIR = MD::NPAIR;
     extern __shared__ __attribute__((aligned(16))) char gmid_lds[];
     typedef __attribute__((address_space(3))) char* lds_c;
@@ -514,6 +520,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     typedef double mid_d2 __attribute__((ext_vector_type(2)));
     typedef volatile __attribute__((address_space(3))) unsigned* lds_flag;
 #define PDS_GM_LDSD(addr) (*(__attribute__((address_space(3))) double*)(addr))
+#define PDS_GM_LDST(addr) (*(__attribute__((address_space(3))) T*)(addr))
 #ifdef PDS_PROFILE_MID
     unsigned long long mprof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     auto mprof_out = [&]() __attribute__((always_inline)) {
@@ -540,8 +547,8 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
             if (lane < 4) FL[lane] = 0u;
         if constexpr (YC) {  // the ones column: the (otherwise unused) weight image of both half-tiles, written once
             PDS_WAVE_LDS_SYNC();
-            for (int b = 0; b < MD::NBUF; ++b) PDS_GM_LDSD(sm + b * MD::HALF_BYTES + MD::W_OFF + lane * 8) = 1.0;
-            static_assert(!YC || MD::HR == 64, "one lane per row of the ones image");
+            for (int b = 0; b < MD::NBUF; ++b)
+                for (int r = lane; r < HR; r += 64) PDS_GM_LDST(sm + b * MD::HALF_BYTES + MD::W_OFF + r * ES) = (T)1;
         }
         PDS_WAVE_LDS_SYNC();
     }
@@ -566,11 +573,11 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
         for (int e = lane; e < q * q; e += 64) {
             const int i = e % q, j = e / q;
             if (i > j) continue;
-            const gptr<double> ci = as_global(cols[i < p ? i : p]), cj = as_global(cols[j < p ? j : p]);  // (index p: the target column)
+            const gptr<T> ci = as_global(cols[i < p ? i : p]), cj = as_global(cols[j < p ? j : p]);  // (index p: the target column)
             double sacc = 0.0;
             for (int64_t r = r0; r < r1; ++r) {
-                const double zi = i < p ? ci[r] : (i == p ? 1.0 : ci[r]);
-                const double zj = j < p ? cj[r] : (j == p ? 1.0 : cj[r]);
+                const double zi = i < p ? (double)ci[r] : (i == p ? 1.0 : (double)ci[r]);
+                const double zj = j < p ? (double)cj[r] : (j == p ? 1.0 : (double)cj[r]);
                 sacc = fma(zi, zj, sacc);
             }
             M[i + (int64_t)j * q] = sacc;
@@ -614,12 +621,12 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
             row16_ldl_solve<SPPC, (PAIRED && SPPC > 24)>(pa0, pa1, pdj0, pdj1, t, p, pfew, sa.sp, w0, w1, is_null, suspect);
             const double nanv = __builtin_nan("");
             const int64_t gq = live ? pgid : 0;
-            double* co = sa.coeffs + gq * (int64_t)pout;
-            if (live && t < p) co[t] = is_null ? nanv : w0;
-            if (live && 16 + t < p) co[16 + t] = is_null ? nanv : w1;
+            T* co = sa.coeffs + gq * (int64_t)pout;
+            if (live && t < p) co[t] = (T)(is_null ? nanv : w0);
+            if (live && 16 + t < p) co[16 + t] = (T)(is_null ? nanv : w1);
             if (sa.sp.bias) {
                 const double sb = Grp<16>::sum((t < p ? psj0 * w0 : 0.0) + (16 + t < p ? psj1 * w1 : 0.0));
-                if (live && t == 0) co[p] = is_null ? nanv : (psy - sb) / pnn;
+                if (live && t == 0) co[p] = (T)(is_null ? nanv : (psy - sb) / pnn);
             }
             if (live && t == 0) sa.flags[gq] = is_null ? 1 : 0;
             // marked systems: one DPP row after the other (wave-uniform control flow)
@@ -782,28 +789,28 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
             return;
         }
     const int g_ = lane / MD::GL, piece = lane % MD::GL;
-    const double* cbase[16];
+    const T* cbase[16];
     unsigned valid = 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int c = 16 * g_ + i;
-        cbase[i] = cols[c < p ? c : p] + 2 * piece;
+        cbase[i] = cols[c < p ? c : p] + EPL * piece;
         if (c < p) valid |= 1u << i;
     }
-    const double* ybase = cols[p] + 2 * lane;
+    const T* ybase = cols[p] + EPL * lane;
     auto issue = [&](int buf, int64_t row0) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 16; ++i)
             if ((valid >> i) & 1u)
                 __builtin_amdgcn_global_load_lds((glb_ptr)(as_global(cbase[i]) + row0), (lds_ptr)(sm + buf * MD::HALF_BYTES + i * GS), 16, 0, 0);
-        if (lane < HR / 2)
+        if (lane < HR / EPL)
             __builtin_amdgcn_global_load_lds((glb_ptr)(as_global(ybase) + row0), (lds_ptr)(sm + buf * MD::HALF_BYTES + MD::Y_OFF), 16, 0, 0);
     };
     auto load_guarded = [&](int buf, int64_t row0) __attribute__((always_inline)) {  // the frame's last, partial half-tile
         for (int c = 0; c <= p; ++c) {
-            const int offb = c < p ? (c % 16) * GS + (c / 16) * HR * 8 : MD::Y_OFF;
-            const gptr<double> col = as_global(cols[c]);
-            for (int r = lane; r < HR; r += 64) PDS_GM_LDSD(sm + buf * MD::HALF_BYTES + offb + r * 8) = row0 + r < n_frame ? col[row0 + r] : 0.0;
+            const int offb = c < p ? (c % 16) * GS + (c / 16) * HR * ES : MD::Y_OFF;
+            const gptr<T> col = as_global(cols[c]);
+            for (int r = lane; r < HR; r += 64) PDS_GM_LDST(sm + buf * MD::HALF_BYTES + offb + r * ES) = row0 + r < n_frame ? col[row0 + r] : (T)0;
         }
     };
     auto fetch_tile = [&](int buf, int64_t h) __attribute__((always_inline)) {
@@ -826,7 +833,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
 #pragma unroll
     for (int b = 0; b < NOP; ++b) {
         const int c = NQ ? (b == 0 ? fi : 12 + 4 * b + (fi & 3)) : 16 * b + fi;  // (quad b - 1: column 16 + 4 (b - 1) + lane % 4)
-        opo[b] = (c & 15) * GS + (c >> 4) * HR * 8;
+        opo[b] = (c & 15) * GS + (c >> 4) * HR * ES;
         if constexpr (YC) {  // columns p and p + 1: the ones image and the target's image
             if (b > 0 && c == p) opo[b] = MD::W_OFF;
             if (b > 0 && c == p + 1) opo[b] = MD::Y_OFF;
@@ -861,10 +868,10 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     auto consume = [&](int buf, int lo, int hi) __attribute__((always_inline)) {
         const lds_c base = sm + buf * MD::HALF_BYTES;
         auto fetch = [&](int s, double (&a)[NOP], double& yk) __attribute__((always_inline)) {
-            const int roff = (4 * s + fk) * 8;
+            const int roff = (4 * s + fk) * ES;
 #pragma unroll
-            for (int b = 0; b < NOP; ++b) a[b] = PDS_GM_LDSD(base + opo[b] + roff);
-            if constexpr (!YC) yk = PDS_GM_LDSD(base + MD::Y_OFF + roff);
+            for (int b = 0; b < NOP; ++b) a[b] = (double)PDS_GM_LDST(base + opo[b] + roff);
+            if constexpr (!YC) yk = (double)PDS_GM_LDST(base + MD::Y_OFF + roff);
             else yk = 0.0;
         };
         auto mult = [&](const double (&a)[NOP], double yk) __attribute__((always_inline)) {
@@ -1299,6 +1306,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     mprof_out();
 #endif
 #undef PDS_GM_LDSD
+#undef PDS_GM_LDST
 }
 
 template <int NBLK>
@@ -1327,8 +1335,8 @@ int launch_grouped_stream(pds_ctx* ctx, const DeviceCols<double>& dc, int p, int
 
 // ---- the in-wave-solve form (SPPC): host side
 constexpr unsigned kMidMarkCap = 8192;  // records of marked systems kept for the pivoted QR; more than that: the record pipeline
-inline int64_t mid_fused_waves(const pds_ctx* ctx, int64_t n_frame) {
-    const int64_t w = std::min<int64_t>((int64_t)ctx->num_cus * kMidWavesPerCu, std::max<int64_t>(1, n_frame / (8 * MidDims<2>::HR)));
+inline int64_t mid_fused_waves(const pds_ctx* ctx, int64_t n_frame, int hr = MidDims<2>::HR) {
+    const int64_t w = std::min<int64_t>((int64_t)ctx->num_cus * kMidWavesPerCu, std::max<int64_t>(1, n_frame / (8 * hr)));
     return w >= 4 ? w / 4 * 4 : w;  // (whole workgroups of four pairs: the PAIRED form)
 }
 // side table -> compact: the groups that straddle wave boundaries (slot w used iff side_list[w] >= 0), their records, row counts as
@@ -1372,15 +1380,16 @@ __global__ __launch_bounds__(1024) void mid_side_compact_kernel(const double* __
         rec_c[e] = side_rec[(int64_t)s_slot[k] * qq + (e - (int64_t)k * qq)];
     }
 }
+template <typename T>
 __global__ __launch_bounds__(256) void mid_scatter_kernel(const double* __restrict__ co_c, const uint8_t* __restrict__ fl_c,
-                                                          const int32_t* __restrict__ list, int64_t n, int pp, double* __restrict__ coeffs,
+                                                          const int32_t* __restrict__ list, int64_t n, int pp, T* __restrict__ coeffs,
                                                           uint8_t* __restrict__ flags) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n * pp) return;
     const int64_t k = i / pp;
     const int c = (int)(i - k * pp);
     const int64_t g = list[k];
-    coeffs[g * pp + c] = co_c[i];
+    coeffs[g * pp + c] = (T)co_c[i];
     if (c == 0) flags[g] = fl_c[k] ? 1 : 0;
 }
 
@@ -1440,20 +1449,22 @@ size_t grouped_mid_fused_workspace(int num_cus, int n_feat, int add_bias) {
     return 4096 + 2 * up(waves * q * q * 8) + 2 * up(waves * 4) + up((waves + 1) * 8) + up((size_t)kMidMarkCap * q * q * 8) + up((size_t)kMidMarkCap * 4) +
            up(sysmax * pp * 8) + up(sysmax) + solve_wave_workspace(n_feat, add_bias, (int64_t)waves, 8) + 512;
 }
-int launch_grouped_mid_fused(pds_ctx* ctx, const DeviceCols<double>& dc, int n_feat, int64_t n_frame, const int64_t* d_off, int64_t n_groups,
-                             const SolveParams& sp, double* d_coeffs, uint8_t* d_flags, void* d_ws) {
+template <typename T>
+int launch_grouped_mid_fused(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_frame, const int64_t* d_off, int64_t n_groups,
+                             const SolveParams& sp, T* d_coeffs, uint8_t* d_flags, void* d_ws) {
     if (n_feat <= 16 || n_feat > 32 || !(sp.gate_tol > 0.0) || sp.lambda_on_bias || !d_flags || !d_ws || n_groups <= 0 ||
         n_groups >= (1ll << 31))
         return PDS_ERR_UNSUPPORTED;
-    using MD = MidDims<2>;
+    using MD = MidDims<2, (int)sizeof(T)>;
+    constexpr bool F64 = sizeof(T) == 8;
     const int p = n_feat, q = p + 2, bias = sp.add_bias ? 1 : 0, pp = p + bias;
-    const int64_t waves = mid_fused_waves(ctx, n_frame);
+    const int64_t waves = mid_fused_waves(ctx, n_frame, MD::HR);
     if (waves > 1024) return PDS_ERR_UNSUPPORTED;  // (mid_side_compact_kernel: one thread per wave)
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
     char* wsp = static_cast<char*>(d_ws);
     wsp += (256 - (reinterpret_cast<uintptr_t>(wsp) & 255)) & 255;
     auto take = [&](size_t b) { char* r = wsp; wsp += up(b); return r; };
-    MidSolveArgs sa;
+    MidSolveArgsT<T> sa;
     sa.sp.p = p;
     sa.sp.pp = p;
     sa.sp.bias = bias;
@@ -1484,13 +1495,16 @@ int launch_grouped_mid_fused(pds_ctx* ctx, const DeviceCols<double>& dc, int n_f
     void* wave_ws = take(solve_wave_workspace(n_feat, bias, waves, 8));
     // groups nobody answers (no rows) are null with NaN coefficients: the kernel writes a group's answer where it finishes it
     PDS_HIP_CHECK(hipMemsetAsync(d_flags, 1, (size_t)n_groups, ctx->stream));
-    PDS_HIP_CHECK(hipMemsetAsync(d_coeffs, 0xFF, (size_t)n_groups * pp * sizeof(double), ctx->stream));
+    PDS_HIP_CHECK(hipMemsetAsync(d_coeffs, 0xFF, (size_t)n_groups * pp * sizeof(T), ctx->stream));
     PDS_HIP_CHECK(hipMemsetAsync(d_counts, 0, 256, ctx->stream));
     PDS_HIP_CHECK(hipMemsetAsync(sa.side_rec, 0, (size_t)waves * q * q * 8, ctx->stream));
     PDS_HIP_CHECK(hipMemsetAsync(sa.side_list, 0xFF, (size_t)waves * 4, ctx->stream));
     constexpr int lds = MD::LDS_BYTES + kMidSolveScratch;
     const char* pair_env = std::getenv("PDS_GROUPED_MID_PAIRED");
     const bool paired = !(pair_env && pair_env[0] == '0') && waves % 4 == 0;
+    // (f32 frames: the paired form with the ones / target columns only -- at 31 / 32 features the side sums' registers push the streaming
+    //  wave's column pointers into scratch, which waits behind its own loads: the record pipeline is faster)
+    if (!F64 && (!paired || p > 30)) return PDS_ERR_UNSUPPORTED;
     {
         KernelTimer timer(ctx, kKindGroupedMoments);
 #ifdef PDS_DEV_SWITCHES  // timing experiments of development builds (EXTRA=-DPDS_DEV_SWITCHES): wrong results with it
@@ -1513,13 +1527,14 @@ int launch_grouped_mid_fused(pds_ctx* ctx, const DeviceCols<double>& dc, int n_f
             const char* yc_env = std::getenv("PDS_GROUPED_MID_YC");  // (development: '0' keeps the side sums of the 31 / 32-feature form)
             const bool yc = !(yc_env && yc_env[0] == '0');
             const char* nq_env = std::getenv("PDS_GROUPED_MID_QUAD");  // (development: '0' keeps the 16 x 16 x 4 form of the second block)
-            if (p <= 18 && yc && !(nq_env && nq_env[0] == '0')) launch_paired(grouped_mid_stream_kernel<2, 24, true, true, 1>);
-            else if (p <= 22 && yc && !(nq_env && nq_env[0] == '0')) launch_paired(grouped_mid_stream_kernel<2, 24, true, true, 2>);
-            else if (p <= 24 && yc) launch_paired(grouped_mid_stream_kernel<2, 24, true, true>);
-            else if (p <= 24) launch_paired(grouped_mid_stream_kernel<2, 24, true, false>);
-            else if (p <= 30 && yc) launch_paired(grouped_mid_stream_kernel<2, 32, true, true>);
-            else launch_paired(grouped_mid_stream_kernel<2, 32, true, false>);
-        } else {
+            if (p <= 18 && yc && !(nq_env && nq_env[0] == '0')) launch_paired(grouped_mid_stream_kernel<2, 24, true, true, 1, T>);
+            else if (p <= 22 && yc && !(nq_env && nq_env[0] == '0')) launch_paired(grouped_mid_stream_kernel<2, 24, true, true, 2, T>);
+            else if (p <= 24 && (yc || !F64)) launch_paired(grouped_mid_stream_kernel<2, 24, true, true, 0, T>);
+            else if (p <= 24) {
+                if constexpr (F64) launch_paired(grouped_mid_stream_kernel<2, 24, true, false>);
+            } else if (p <= 30 && yc) launch_paired(grouped_mid_stream_kernel<2, 32, true, true, 0, T>);
+            else if constexpr (F64) launch_paired(grouped_mid_stream_kernel<2, 32, true, false>);
+        } else if constexpr (F64) {
             if (p <= 24) launch(grouped_mid_stream_kernel<2, 24>);
             else launch(grouped_mid_stream_kernel<2, 32>);
         }
@@ -1538,18 +1553,22 @@ int launch_grouped_mid_fused(pds_ctx* ctx, const DeviceCols<double>& dc, int n_f
     if (h_counts[1] > 0) {
         const int64_t ns = h_counts[1];
         if (int rc = launch_solve_wave<double>(ctx, rec_c, ns, sp, co_c, fl_c, rows_c, wave_ws)) return rc;
-        hipLaunchKernelGGL(mid_scatter_kernel, dim3((unsigned)((ns * pp + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)co_c,
+        hipLaunchKernelGGL(mid_scatter_kernel<T>, dim3((unsigned)((ns * pp + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)co_c,
                            (const uint8_t*)fl_c, (const int32_t*)list_c, ns, pp, d_coeffs, d_flags);
     }
     if (h_counts[0] > 0) {  // systems next to the gate: the reference's default factorisation (pivoted QR, log-det gate)
         const int64_t nm = h_counts[0];
         if (int rc = launch_solve_marked<double>(ctx, sa.mark_rec, nm, sp, co_c, fl_c, nullptr)) return rc;
-        hipLaunchKernelGGL(mid_scatter_kernel, dim3((unsigned)((nm * pp + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)co_c,
+        hipLaunchKernelGGL(mid_scatter_kernel<T>, dim3((unsigned)((nm * pp + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)co_c,
                            (const uint8_t*)fl_c, (const int32_t*)sa.mark_list, nm, pp, d_coeffs, d_flags);
     }
     PDS_HIP_CHECK(hipGetLastError());
     return PDS_OK;
 }
+template int launch_grouped_mid_fused<double>(pds_ctx*, const DeviceCols<double>&, int, int64_t, const int64_t*, int64_t, const SolveParams&, double*, uint8_t*,
+                                              void*);
+template int launch_grouped_mid_fused<float>(pds_ctx*, const DeviceCols<float>&, int, int64_t, const int64_t*, int64_t, const SolveParams&, float*, uint8_t*,
+                                             void*);
 
 #ifdef PDS_PROFILE_MID
 extern "C" int pds_debug_mid_phase_cycles(unsigned long long* out, int reset) {
