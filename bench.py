@@ -497,7 +497,21 @@ def _mid_width(torch, np, pds, ctx, dev, wall):
     ms = wall(lambda: pds.lin_reg_by(*xs, target=y, group_offsets=off, ctx=ctx))
     out["grouped_200000x100_ms"] = round(ms, 3)
     out["grouped_regressions_per_s"] = round(G / ms * 1e3, 1)
-    del xs, y
+    # the 16 -> 17 feature step under group_by: the same 2e5 groups x 100 rows at 16 / 17 / 24 / 32 features, and the
+    # 64-feature frame whose random groups sit at the reference's rank gate (1e5 groups x 100 rows: the first half of the columns twice)
+    steps = {}
+    for q in (16, 17, 24, 32):
+        steps[str(q)] = round(wall(lambda: pds.lin_reg_by(*xs[:q], target=y, group_offsets=off, ctx=ctx)), 3)
+    out["grouped_200000x100_by_features_ms"] = steps
+    out["grouped_ratio_17_over_16"] = round(steps["17"] / steps["16"], 3)
+    out["grouped_ratio_32_over_16"] = round(steps["32"] / steps["16"], 3)
+    G2 = 100_000
+    off2 = np.arange(0, G2 * R + 1, R, dtype=np.int64)
+    xs2 = [x[: G2 * R] for x in xs] + [torch.randn(G2 * R, dtype=torch.float64, device=dev, generator=gen) for _ in range(32)]
+    co, nu = pds.lin_reg_by(*xs2, target=y[: G2 * R], group_offsets=off2, ctx=ctx)
+    out["grouped_100000x100x64_ms"] = round(wall(lambda: pds.lin_reg_by(*xs2, target=y[: G2 * R], group_offsets=off2, ctx=ctx)), 3)
+    out["grouped_100000x100x64_null_groups"] = int(nu.sum())
+    del xs, y, xs2
     torch.cuda.empty_cache()
     return out
 
@@ -553,6 +567,23 @@ def _other_configs(torch, pds, ctx, dev, xs, y, N, P, with_cpu=True):
         out["mid_width"] = _mid_width(torch, _np, pds, ctx, dev, wall)
     except Exception as e:
         out["mid_width"] = {"error": f"{type(e).__name__}: {e}"}
+    try:  # the headline frame with one column (and sixteen columns) more: the step VERDICT r3 item 2 measures
+        import numpy as _np
+
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(11)
+        more = [torch.randn(N, dtype=torch.float64, device=dev, generator=gen) for _ in range(16)]
+        off = torch.arange(0, N + 1, 100, dtype=torch.int64, device=dev)
+        cols = list(xs[:16]) + more
+        steps = {}
+        for q in (16, 17, 24, 32):
+            steps[str(q)] = round(wall(lambda: pds.lin_reg_by(*cols[:q], target=y, group_offsets=off, add_bias=False, ctx=ctx)), 3)
+        out["grouped_width_step"] = {"workload": f"{N // 100} groups x 100 rows, 16 / 17 / 24 / 32 f64 features (wall ms of lin_reg_by)", "ms": steps,
+                                     "ratio_17_over_16": round(steps["17"] / steps["16"], 3), "ratio_32_over_16": round(steps["32"] / steps["16"], 3)}
+        del more, cols
+        torch.cuda.empty_cache()
+    except Exception as e:
+        out["grouped_width_step"] = {"error": f"{type(e).__name__}: {e}"}
     if with_cpu:  # the reference's rolling driver is one sequential Woodbury chain: single thread, bounded sample of the same frame
         import numpy as np
 
