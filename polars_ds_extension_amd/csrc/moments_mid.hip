@@ -1538,7 +1538,7 @@ int launch_grouped_mid_fused(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, 
         };
         if (paired) {
             const char* yc_env = std::getenv("PDS_GROUPED_MID_YC");  // (development: '0' keeps the side sums of the 31 / 32-feature form)
-            const bool yc = !(yc_env && yc_env[0] == '0');
+            const bool yc = !F64 || !(yc_env && yc_env[0] == '0');  // (f32 frames have the ones / target column form only)
             const char* nq_env = std::getenv("PDS_GROUPED_MID_QUAD");  // (development: '0' keeps the 16 x 16 x 4 form of the second block)
             if (p <= 18 && yc && !(nq_env && nq_env[0] == '0')) launch_paired(grouped_mid_stream_kernel<2, 24, true, true, 1, T>);
             else if (p <= 22 && yc && !(nq_env && nq_env[0] == '0')) launch_paired(grouped_mid_stream_kernel<2, 24, true, true, 2, T>);
