@@ -1198,11 +1198,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
                 vys = rows_sum4(vys);
             }
             flush_stash();
-#ifdef PDS_GMID_NO_STASH
-            if (true) {
-#else
             if (slot_free()) {
-#endif
                 publish_group(acc, vx0, vx1, vc0, vc1, (double)rows_in_acc, vys, g);
             } else {
 #pragma unroll
