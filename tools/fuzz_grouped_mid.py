@@ -1,6 +1,6 @@
 """Development aid: randomised shapes with 17 .. 64 features through the grouped paths (paired stream + row16 solver up to 32, record
 stream + wave solver beyond) against the oracle: null decisions group by group, coefficients within 64 eps cond(X'X)."""
-import sys, time
+import os, sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import numpy as np, torch
@@ -18,7 +18,12 @@ while time.time() < t_end:
     off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     N = int(off[-1])
     if N == 0: continue
-    X = rng.normal(size=(N, p)) + rng.normal(size=p) * float(rng.choice([0.0, 0.3, 3.0]))
+    # (FUZZ_BIG_OFFSETS=1: a few columns with mean / sd of 30 .. 300 -- single pivot ratios of 1e3 .. 1e5 whose PRODUCT sits around the 1e12 gate)
+    if os.environ.get("FUZZ_BIG_OFFSETS") == "1":
+        X = rng.normal(size=(N, p))
+        for j in rng.choice(p, size=int(rng.integers(1, 5)), replace=False): X[:, j] += float(rng.choice([30.0, 100.0, 300.0]))
+    else:
+        X = rng.normal(size=(N, p)) + rng.normal(size=p) * float(rng.choice([0.0, 0.3, 3.0]))
     y = X @ rng.normal(size=p) + rng.normal(size=N) * 0.1 + 0.5
     for g in rng.integers(0, G, size=G // 50):  # collinear / nearly collinear groups
         a, b = off[g], off[g + 1]
