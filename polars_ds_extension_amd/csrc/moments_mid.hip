@@ -1187,8 +1187,56 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
             }
         }
     };
+    // STASH2 (up to 24 features, where the streaming wave has the registers): TWO spare sets -- a solve of four (17 600 ticks at 17 features)
+    // outlasts a group (10 800) and the slot + one set did not always absorb it: the streaming wave stood 9.6 % of its time in front of a
+    // full slot.  A two-deep FIFO in registers: set A / set B, `a_old` says which is the older; drained whenever the slot is free.
+    constexpr bool STASH2 = PAIRED && YC && SPPC == 24;
+    d4 st_b[STASH2 ? NPAIR : 1];
+    int64_t st_gb = 0;
+    int nst = 0;
+    bool a_old = true;
+    auto drain_one = [&]() __attribute__((always_inline)) {  // (the slot is free, nst > 0)
+        if constexpr (STASH2) {
+            if (a_old) publish_group(st_acc, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, st_g);
+            else publish_group(st_b, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, st_gb);
+            a_old = !a_old;
+            --nst;
+        }
+    };
+    auto drain_free = [&]() __attribute__((always_inline)) {
+        if constexpr (STASH2) {
+            while (nst > 0 && slot_free()) drain_one();
+        }
+    };
+    auto hand_over2 = [&]() __attribute__((always_inline)) {
+        if constexpr (STASH2) {
+            drain_free();
+            if (nst == 0 && slot_free()) {
+                publish_group(acc, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, g);
+                return;
+            }
+            if (nst == 2) drain_one();  // (both sets taken: this one waits for the slot inside publish_group)
+            if (nst == 0) {
+#pragma unroll
+                for (int b = 0; b < NPAIR; ++b) st_acc[b] = acc[b];
+                st_g = g;
+                a_old = true;
+            } else if (a_old) {
+#pragma unroll
+                for (int b = 0; b < NPAIR; ++b) st_b[b] = acc[b];
+                st_gb = g;
+            } else {
+#pragma unroll
+                for (int b = 0; b < NPAIR; ++b) st_acc[b] = acc[b];
+                st_g = g;
+            }
+            ++nst;
+        }
+    };
     auto hand_over = [&]() __attribute__((always_inline)) {
-        if constexpr (PAIRED) {
+        if constexpr (STASH2) {
+            hand_over2();
+        } else if constexpr (PAIRED) {
             double vx0 = xy[0], vx1 = xy[1], vc0 = cs[0], vc1 = cs[1], vys = ys;
             if constexpr (!YC) {
                 vx0 = rows_sum4(vx0);
@@ -1253,6 +1301,8 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // half-tile h has landed (and this wave's record stores are out)
         PDS_WAVE_LDS_SYNC();
         PDS_MADD(0, p0);
+        if constexpr (STASH2)
+            if (nst > 0) drain_free();
         PDS_MT(p1);
         if (h + 1 < h1) fetch_tile(buf ^ 1, h + 1);  // (the other image was consumed one iteration ago)
         PDS_MADD(1, p1);
@@ -1284,6 +1334,8 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     if (rows_in_acc > 0 && g < n_groups) flush();  // the group that continues in the next wave's rows
     if constexpr (PAIRED) {
         flush_stash();
+        if constexpr (STASH2)
+            while (nst > 0) drain_one();  // (publish_group waits for the slot)
         while ((pseq & 3u) != 0u) {  // pad the last batch: the slot's contents once more (a valid system), marked as discarded
             typedef __attribute__((address_space(3))) double* lds_dp;
             while (!slot_free()) __builtin_amdgcn_s_sleep(1);
