@@ -1301,8 +1301,13 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // half-tile h has landed (and this wave's record stores are out)
         PDS_WAVE_LDS_SYNC();
         PDS_MADD(0, p0);
-        if constexpr (STASH2)
+        // (a waiting group goes out as soon as the solving wave has emptied the slot, not only when the next group ends: without this look
+        // per half-tile the 17-feature kernel is 6 % slower)
+        if constexpr (STASH2) {
             if (nst > 0) drain_free();
+        } else if constexpr (PAIRED) {
+            if (stashed && slot_free()) flush_stash();
+        }
         PDS_MT(p1);
         if (h + 1 < h1) fetch_tile(buf ^ 1, h + 1);  // (the other image was consumed one iteration ago)
         PDS_MADD(1, p1);
