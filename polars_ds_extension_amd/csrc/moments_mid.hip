@@ -917,7 +917,9 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
             yk = in ? yk : 0.0;
             mult(a, yk);
         };
-        if (lo == 0 && hi == HR) {  // a whole half-tile of one group: the unrolled form of the single-regression kernel
+        // a whole half-tile of one group: the unrolled form of the single-regression kernel (not for f32 frames with the side sums: its 32
+        // steps cost that variant 65 spilled registers -- the column pointers, reloaded behind the loads in flight)
+        if ((ES == 8 || YC) && lo == 0 && hi == HR) {
             double a[NOP], yk;
             fetch(0, a, yk);
 #pragma unroll
@@ -1568,9 +1570,7 @@ int launch_grouped_mid_fused(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, 
     constexpr int lds = MD::LDS_BYTES + kMidSolveScratch;
     const char* pair_env = std::getenv("PDS_GROUPED_MID_PAIRED");
     const bool paired = !(pair_env && pair_env[0] == '0') && waves % 4 == 0;
-    // (f32 frames: the paired form with the ones / target columns only -- at 31 / 32 features the side sums' registers push the streaming
-    //  wave's column pointers into scratch, which waits behind its own loads: the record pipeline is faster)
-    if (!F64 && (!paired || p > 30)) return PDS_ERR_UNSUPPORTED;
+    if (!F64 && !paired) return PDS_ERR_UNSUPPORTED;  // (f32 frames: the paired form only)
     {
         KernelTimer timer(ctx, kKindGroupedMoments);
 #ifdef PDS_DEV_SWITCHES  // timing experiments of development builds (EXTRA=-DPDS_DEV_SWITCHES): wrong results with it
@@ -1599,7 +1599,7 @@ int launch_grouped_mid_fused(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, 
             else if (p <= 24) {
                 if constexpr (F64) launch_paired(grouped_mid_stream_kernel<2, 24, true, false>);
             } else if (p <= 30 && yc) launch_paired(grouped_mid_stream_kernel<2, 32, true, true, 0, T>);
-            else if constexpr (F64) launch_paired(grouped_mid_stream_kernel<2, 32, true, false>);
+            else launch_paired(grouped_mid_stream_kernel<2, 32, true, false, 0, T>);
         } else if constexpr (F64) {
             if (p <= 24) launch(grouped_mid_stream_kernel<2, 24>);
             else launch(grouped_mid_stream_kernel<2, 32>);

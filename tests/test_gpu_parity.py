@@ -1209,10 +1209,10 @@ def test_grouped_mid_fused_wave_boundaries(pds, orc, p, bias, l2):
     assert err[np.flatnonzero(ok) == 100][0] < F64_TOL and err[np.flatnonzero(ok) == 1500][0] < F64_TOL
 
 
-@pytest.mark.parametrize("p,bias", [(17, True), (20, False), (24, True), (30, True), (32, False)])
+@pytest.mark.parametrize("p,bias", [(17, True), (20, False), (24, True), (30, True), (31, True), (32, False)])
 def test_grouped_mid_fused_f32_frames(pds, orc, f32, p, bias):
-    """f32 frames with 17 .. 30 features take the paired stream too (128-row half-tiles, widened to f64 on their way out of LDS: f64
-    moments, f64 solve, f32 coefficients); 31 / 32 features stay on the record pipeline.  Wave boundaries, a group that spans many waves,
+    """f32 frames with 17 .. 32 features take the paired stream too (128-row half-tiles, widened to f64 on their way out of LDS: f64
+    moments, f64 solve, f32 coefficients).  Wave boundaries, a group that spans many waves,
     empty and too-small groups; against the f64 truth of the same f32 frame (the f32 contract, 1e-4 normwise)."""
     rng = np.random.default_rng(8100 + p)
     pp = p + int(bias)
@@ -1227,7 +1227,7 @@ def test_grouped_mid_fused_f32_frames(pds, orc, f32, p, bias):
     co, nu = pds.lin_reg_by(*cols_of(X), target=dev(y), group_offsets=off, add_bias=bias, singular_x_tol=1e-10)
     assert co.element_size() == 4
     from polars_ds_extension_amd import _lib
-    assert _lib.load().pds_debug_last_grouped_route() == (1 if p <= 30 else 2)
+    assert _lib.load().pds_debug_last_grouped_route() == 1
     co, nu = co.cpu().numpy().astype(np.float64), nu.cpu().numpy().astype(bool)
     X64, y64 = X.astype(np.float64), y.astype(np.float64)
     co_t, nu_t = orc.grouped_lr([y64] + [X64[:, j] for j in range(p)], off, add_bias=bias, tol=1e-10, nthreads=4)
