@@ -222,7 +222,7 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
         if (int rc = launch_grouped_fused<T>(ctx, dc, n_feat, n_rows, d_off, n_groups, sp, d_coeffs, d_null, d_mom, chunk)) return rc;
     } else {
         // 17 .. 32 f64 features, rank gate on (round 4): one stream, the solves in the streaming waves, no moment records
-        // (moments_mid.hip, SPPC); PDS_GROUPED_MID_FUSED=0: the record pipeline below (A/B); it also takes over when more systems sit
+        // (grouped_mid.hip); PDS_GROUPED_MID_FUSED=0: the record pipeline below (A/B); it also takes over when more systems sit
         // next to the gate than the fused form's marked list holds
         bool mid_done = false;
         g_grouped_route = 0;
@@ -241,7 +241,7 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
             const int64_t gc = std::min(chunk, n_groups - g0);
             bool streamed = false;
             if constexpr (std::is_same<T, double>::value) {
-                // 17 .. 64 f64 features: the chunk's records from ONE stream over its rows (moments_mid.hip); PDS_GROUPED_STREAM=0: A/B
+                // 17 .. 64 f64 features: the chunk's records from ONE stream over its rows (grouped_mid.hip); PDS_GROUPED_STREAM=0: A/B
                 static const bool stream_off = [] { const char* e = std::getenv("PDS_GROUPED_STREAM"); return e && e[0] == '0'; }();
                 // (below ~28 features the padded 32-wide stream costs more than the one-wave-per-group kernel saves: 2.7 against 2.5 ms at 20)
                 if (n_feat >= 28 && n_feat <= 64 && !stream_off) {

@@ -270,8 +270,8 @@ int launch_grouped_pred_by_id(pds_ctx* ctx, const T* const* d_cols, int n_feat, 
                               T* d_pred, T* d_resid, uint8_t* d_row_null);  // grouped_pred.hip
 // ---- leverage_mid.hip: HC2 / HC3 leverages of 17 .. 64 f64 features on the matrix cores (PDS_ERR_UNSUPPORTED: not applicable, nothing done)
 int launch_grouped_moments_stream(pds_ctx* ctx, const DeviceCols<double>& dc, int n_feat, int64_t n_frame, const int64_t* d_off, int64_t n_groups,
-                                  double* d_records);  // moments_mid.hip: grouped Gram records, 17 .. 64 f64 features, one stream
-// moments_mid.hip: grouped OLS / ridge with 17 .. 32 f64 features as one stream, the solves in the streaming waves (no records)
+                                  double* d_records);  // grouped_mid.hip: grouped Gram records, 17 .. 64 f64 features, one stream
+// grouped_mid.hip: grouped OLS / ridge with 17 .. 32 features as one stream, the solves in the streaming waves (no records)
 template <typename T>
 int launch_grouped_mid_fused(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_frame, const int64_t* d_off, int64_t n_groups,
                              const SolveParams& sp, T* d_coeffs, uint8_t* d_flags, void* d_ws);

@@ -1,0 +1,1216 @@
+// grouped_mid.hip -- grouped regressions with 17 .. 64 f64 features (17 .. 32 also f32) as ONE stream over the frame: the (p+2)^2 moment
+// records of contiguous groups (33 .. 64 features, and the fallback), or -- 17 .. 32 features -- no records at all: a streaming and a
+// solving wave per SIMD, the finished group crossing an LDS slot.  The half-tile layout is moments_mid.hip's
+// (moments_mid_dev.hpp).
+#include "common.hpp"
+#include "moments_dev.hpp"
+#include "moments_mid_dev.hpp"
+#include "solve_wave_dev.hpp"
+#include "solve_row16_dev.hpp"
+
+namespace pds {
+
+// -DPDS_PROFILE_MID: per-phase shader-clock sums of the paired grouped stream's waves (development; tools/grouped_mid_profile.py)
+#ifdef PDS_PROFILE_MID
+__device__ unsigned long long g_mid_phase[16];
+#define PDS_MT(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define PDS_MADD(k, t0) mprof[k] += __builtin_amdgcn_s_memtime() - (t0)
+#else
+#define PDS_MT(var) do {} while (0)
+#define PDS_MADD(k, t0) do {} while (0)
+#endif
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Grouped form: the (p+2)^2 moment records of CONTIGUOUS GROUPS (group g = rows [off[g], off[g+1])) from ONE stream over the frame --
+// `group_by(key).agg(pds.lin_reg(...))` with 17 .. 64 f64 features.  The one-wave-per-group kernel of moments.hip loads 32 rows at a
+// time with 8-byte loads and nothing in flight behind them (1.2 - 2.5 TB/s); here the rows are read exactly as above (waves own
+// contiguous, half-tile aligned row ranges; 1 KiB asynchronous loads into wave-private LDS images) and the accumulators are CUT at
+// group boundaries: a half-tile is walked as segments [lo, hi) of one group each, the first and last 4-row step of a segment with the
+// rows outside it zeroed in the operands, and a finished group's tiles go straight from the accumulator registers into its record.
+// Groups that lie inside one wave's rows are written with plain stores; a group cut by a wave boundary (two per wave, or a giant group
+// over many waves) is added to the zero-initialised record with atomics.
+// SPPC > 0 (NBLK = 2, up to 32 features, round 4): NO RECORDS -- a finished group is solved in the wave that streamed it.  Its
+// accumulator tiles go through a 4 KB LDS scratch (16 columns per trip) into one of four pending systems -- one per 16-lane DPP row,
+// lane t = columns t and 16 + t, centred -- and four pending systems are factored side by side (solve_row16_dev.hpp: L D L' with the
+// pivot-ratio gate) and their coefficients written; only what cannot be answered in place leaves as a record: a group cut by a wave
+// boundary (atomics into the side table's slot of the wave it starts in: at most one per wave) and a system next to the gate
+// (appended to the marked list for the pivoted QR; its record is rebuilt from its rows).  The per-group dispatch
+// of pl_lr under group_by (linear_regression.rs:447-497) at 17 .. 32 features then moves input + coefficients only, as at <= 16.
+template <typename T>
+struct MidSolveArgsT {
+    SolveRegDev sp;
+    T* coeffs = nullptr;           // [n_groups][p + bias]
+    uint8_t* flags = nullptr;      // [n_groups]: 1 = null
+    double* side_rec = nullptr;    // [waves][q * q], zeroed: records of groups that straddle wave boundaries
+    int32_t* side_list = nullptr;  // [waves], -1: slot w = the group that starts in wave w's rows and ends beyond them
+    double* mark_rec = nullptr;    // [mark_cap][q * q]: records of systems the in-wave solve marked
+    int32_t* mark_list = nullptr;  // [mark_cap]
+    unsigned* mark_count = nullptr;  // appended count (beyond mark_cap: overflow, the caller falls back to the record pipeline)
+    unsigned mark_cap = 0;
+};
+using MidSolveArgs = MidSolveArgsT<double>;
+constexpr int kMidSolveScratch = 5120;  // bytes behind the tile images (4 x 40 KB per CU): 24 columns x 26 doubles in one trip, or 16 x 34 per trip
+// v summed lane-wise over the four 16-lane rows of the wave (every lane gets its column's total): v_permlane16_swap / v_permlane32_swap
+// of gfx950 -- with both operands the same value the swap leaves [r0 r0 r2 r2] and [r1 r1 r3 r3] (rows), then the two halves -- four
+// vector moves per stage instead of two trips through the LDS crossbar (__shfl_xor)
+__device__ __forceinline__ double rows_sum4(double v) {
+    {
+        const int lo = __double2loint(v), hi = __double2hiint(v);
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+    }
+    {
+        const int lo = __double2loint(v), hi = __double2hiint(v);
+        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+    }
+    return v;
+}
+// the slot between a streaming and a solving wave (PAIRED): the upper triangle of the SPPC x SPPC moment block row by row, U(r, c) at
+// tri(r) + c - r, then X'y, the column sums, and [rows, sum y, group] -- 4 760 bytes at 32 features
+// YC: the triangle is that of [X 1 y]' [X 1 y] (QC = columns incl. the two), only the group id follows it.
+template <int SPPC, bool YC = false>
+struct MidPacked {
+    static constexpr int QC = YC ? (SPPC + 2 < 32 ? SPPC + 2 : 32) : SPPC;
+    static constexpr int tri(int r) { return r * QC - r * (r - 1) / 2; }
+    static __device__ __forceinline__ int tri_rt(int r) { return r * QC - ((r * (r - 1)) >> 1); }
+    static constexpr int XY = QC * (QC + 1) / 2, CS = XY + (YC ? 0 : SPPC), TAIL = CS + (YC ? 0 : SPPC), GID = TAIL + (YC ? 0 : 2), COUNT = GID + 1;
+};
+template <int NBLK>
+constexpr int kMidPairLds = MidDims<NBLK>::LDS_BYTES + kMidSolveScratch + 64;  // tile images + scratch + flag words of one pair of waves (PAIRED)
+
+// PAIRED (with SPPC): a workgroup is FOUR PAIRS of waves -- waves 0 .. 3 stream (loads, matrix steps, group walk: what a wave of the
+// unpaired form does up to the finished group), waves 4 .. 7 are their solvers: a finished group's moments cross the pair's LDS scratch
+// (a sequence-numbered slot: full / taken / done words behind it, polled with s_sleep -- no workgroup barrier after the first), the
+// solver wave keeps the four pending systems, factors them and writes coefficients, flags and marks.  Waves w and w + 4 of a workgroup
+// share a SIMD (tools/wave_placement.hip), so every SIMD runs one streaming and one solving wave: the hand-over and the solves of one
+// overlap the load waits and matrix instructions of the other (they ran one after the other in a single wave: 2.5 of 7.65 ms).
+// YC (PAIRED, up to 30 features): the ones and the target are columns p and p + 1 of the second operand block -- the column sums, X'y, the
+// row count and sum y come out of the matrix instructions that run anyway (no side sums per step, no cross-row reductions per group),
+// and the accumulator blocks ARE the record [X 1 y]' [X 1 y].
+// NQ = 1 (YC, up to 18 features: the second operand block holds at most FOUR columns -- x16, x17, the ones, the target): its two
+// 16 x 16 x 4 matrix instructions per step (64 ticks each, a quarter of a block useful) become two v_mfma_f64_4x4x4_4b (20 ticks each; layout
+// and rate: tools/mfma_f64_4x4_probe.hip -- A[i][k] of block b in lane 16 k + 4 b + i, B[k][j] in lane 16 k + 4 b + j, D[i][j] in lane
+// 16 i + 4 b + j): block b of the first multiplies columns 4 b .. 4 b + 3 of the first operand block (its lanes ARE the 16 x 16 operand's)
+// with the quad, the second the quad with itself.
+// T = float (PAIRED only): f32 frames -- 128-row half-tiles of the same 1 KiB instructions and the same LDS bytes, widened to f64 on their
+// way out of LDS; moments, slot, solve and side / marked records are f64 as for f64 frames, the coefficients are written as T.
+template <int NBLK, int SPPC = 0, bool PAIRED = false, bool YC = false, int NQ = 0, typename T = double>
+__global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(const T* const* __restrict__ cols, int p, int64_t n_frame,
+                                                                const int64_t* __restrict__ off, int64_t n_groups,
+                                                                double* __restrict__ records, int debug, MidSolveArgsT<T> sa) {
+    constexpr int ES = (int)sizeof(T), EPL = 16 / ES;  // element bytes; elements per 16-byte lane piece
+    static_assert(ES == 8 || PAIRED, "f32 frames: the paired form");
+    static_assert(SPPC == 0 || NBLK == 2, "the in-wave solve serves two tile columns");
+    static_assert(!PAIRED || SPPC > 0, "pairs exist for the in-kernel solve");
+    static_assert(!PAIRED || MidPacked<SPPC ? SPPC : 1, YC>::COUNT * 8 <= kMidSolveScratch, "the slot holds one group");
+    static_assert(!YC || PAIRED, "the ones / target columns are the paired form's");
+    static_assert(NQ == 0 || ((NQ == 1 || NQ == 2) && YC && NBLK == 2), "the quad form: ones and target inside the quads");
+    using MD = MidDims<NBLK, ES>;
+    constexpr int HR = MD::HR, GS = MD::GS, NPAIR = MD::NPAIR;
+    extern __shared__ __attribute__((aligned(16))) char gmid_lds[];
+    typedef __attribute__((address_space(3))) char* lds_c;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    typedef double mid_d2 __attribute__((ext_vector_type(2)));
+    typedef volatile __attribute__((address_space(3))) unsigned* lds_flag;
+#define PDS_GM_LDSD(addr) (*(__attribute__((address_space(3))) double*)(addr))
+#define PDS_GM_LDST(addr) (*(__attribute__((address_space(3))) T*)(addr))
+#ifdef PDS_PROFILE_MID
+    unsigned long long mprof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto mprof_out = [&]() __attribute__((always_inline)) {
+        if ((threadIdx.x & 63) == 0)
+            for (int k = 0; k < 16; ++k)
+                if (mprof[k]) atomicAdd(&g_mid_phase[k], mprof[k]);
+    };
+#endif
+    PDS_MT(t_kernel);
+    const int lane = threadIdx.x & 63;
+    const int wv = PAIRED ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0, pairi = wv & 3;
+    const bool consumer = PAIRED && wv >= 4;
+    lds_c sm = (lds_c)gmid_lds + (PAIRED ? pairi * kMidPairLds<NBLK> : 0);
+    const lds_flag FL = (lds_flag)(sm + MD::LDS_BYTES + kMidSolveScratch);  // [0] trips published, [1] trips taken, [2] stream finished
+    const int64_t wave = PAIRED ? (int64_t)blockIdx.x * 4 + pairi : (int64_t)blockIdx.x, nwaves = PAIRED ? (int64_t)gridDim.x * 4 : (int64_t)gridDim.x;
+    const int64_t row_begin = off[0], row_end = off[n_groups];
+    if (row_end <= row_begin) return;
+    // half-tiles [H0, H1) cover the chunk's rows; a wave takes a contiguous range of them
+    const int64_t H0 = row_begin / HR, H1 = (row_end + HR - 1) / HR;
+    const int64_t h0 = H0 + (H1 - H0) * wave / nwaves, h1 = H0 + (H1 - H0) * (wave + 1) / nwaves;
+    if (!consumer) {
+        for (int i = lane * 16; i < MD::LDS_BYTES; i += 64 * 16) *(__attribute__((address_space(3))) mid_d2*)(sm + i) = mid_d2{0.0, 0.0};
+        if constexpr (PAIRED)
+            if (lane < 4) FL[lane] = 0u;
+        if constexpr (YC) {  // the ones column: the (otherwise unused) weight image of both half-tiles, written once
+            PDS_WAVE_LDS_SYNC();
+            for (int b = 0; b < MD::NBUF; ++b)
+                for (int r = lane; r < HR; r += 64) PDS_GM_LDST(sm + b * MD::HALF_BYTES + MD::W_OFF + r * ES) = (T)1;
+        }
+        PDS_WAVE_LDS_SYNC();
+    }
+    if constexpr (PAIRED) __syncthreads();  // (the only workgroup barrier: the flag words are zero before a solver wave polls them)
+    if (h0 >= h1) return;
+    const int64_t W0 = h0 * HR > row_begin ? h0 * HR : row_begin, W1 = h1 * HR < row_end ? h1 * HR : row_end;  // the wave's rows
+    const int q = p + 2;
+    // SPPC: finished groups wait, up to four of them (one per 16-lane DPP row, two columns per lane: solve_row16_dev.hpp), and are
+    // solved side by side.  A system next to the gate is marked; its record is rebuilt from the group's rows (a rare, slow path: the
+    // accumulators it came from are gone by then).
+    // pending systems: RAW moments (the centring, lambda and the diagonal wait for the solve, where they cost once per four groups)
+    //   pa0 / pa1[i] = G[i][t] / G[i][16 + t], [SPPC] = X'y; psj0 / psj1 = column sums; pnn = rows; psy = sum y; pgid = group
+    double pa0[SPPC + 1], pa1[SPPC + 1], psj0 = 0.0, psj1 = 0.0, pnn = 1.0, psy = 0.0;
+    int64_t pgid = -1;
+    int npend = 0;
+    if constexpr (SPPC > 0) {
+#pragma unroll
+        for (int i = 0; i <= SPPC; ++i) pa0[i] = pa1[i] = 0.0;
+    }
+    auto record_from_rows = [&](int64_t gg, double* M) __attribute__((always_inline)) {
+        const int64_t r0 = off[gg], r1 = off[gg + 1];
+        for (int e = lane; e < q * q; e += 64) {
+            const int i = e % q, j = e / q;
+            if (i > j) continue;
+            const gptr<T> ci = as_global(cols[i < p ? i : p]), cj = as_global(cols[j < p ? j : p]);  // (index p: the target column)
+            double sacc = 0.0;
+            for (int64_t r = r0; r < r1; ++r) {
+                const double zi = i < p ? (double)ci[r] : (i == p ? 1.0 : (double)ci[r]);
+                const double zj = j < p ? (double)cj[r] : (j == p ? 1.0 : (double)cj[r]);
+                sacc = fma(zi, zj, sacc);
+            }
+            M[i + (int64_t)j * q] = sacc;
+            M[j + (int64_t)i * q] = sacc;
+        }
+    };
+    auto solve_pending = [&]() __attribute__((always_inline)) {
+        if constexpr (SPPC > 0) {
+            if (npend == 0) return;
+            const int t = lane & 15, R = lane >> 4, pout = p + sa.sp.bias;
+            const bool live = R < npend && pgid >= 0;  // (pgid < 0: padding of the paired form's last batch)
+            // ---- raw moments -> the centred system with lambda on the diagonal (all pending rows at once)
+            const bool c0v = t < p, c1v = 16 + t < p;
+            pa0[SPPC] = c0v ? pa0[SPPC] : 0.0;
+            pa1[SPPC] = c1v ? pa1[SPPC] : 0.0;
+            double pdj0 = 1.0, pdj1 = 1.0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {  // (selects, not a branch per i; a column beyond p gets a unit diagonal: its step changes nothing)
+                const bool at = i == t;
+                const double d0 = pa0[i] + sa.sp.lambda;
+                pdj0 = (at && c0v) ? d0 : pdj0;
+                pa0[i] = at ? (c0v ? d0 : 1.0) : pa0[i];
+                if (16 + i < SPPC) {
+                    const double d1 = pa1[16 + i] + sa.sp.lambda;
+                    pdj1 = (at && c1v) ? d1 : pdj1;
+                    pa1[16 + i] = at ? (c1v ? d1 : 1.0) : pa1[16 + i];
+                }
+            }
+            if (!sa.sp.bias) psj0 = psj1 = 0.0;
+            psj0 = c0v ? psj0 : 0.0;
+            psj1 = c1v ? psj1 : 0.0;
+            if (sa.sp.bias) {  // centre: G_ij - s_i s_j / n (the intercept never takes a lane)
+                const double m0 = psj0 / pnn, m1 = psj1 / pnn;
+                Row16Centre<SPPC, SPPC - 1>::run(pa0, pa1, psj0, psj1, m0, m1);
+                pa0[SPPC] = fma(-psy, m0, pa0[SPPC]);
+                pa1[SPPC] = fma(-psy, m1, pa1[SPPC]);
+            }
+            const bool pfew = pnn < (double)pout;  // "#Data < #features"
+            double w0, w1;
+            bool is_null, suspect;
+            row16_ldl_solve<SPPC, (PAIRED && SPPC > 24)>(pa0, pa1, pdj0, pdj1, t, p, pfew, sa.sp, w0, w1, is_null, suspect);
+            const double nanv = __builtin_nan("");
+            const int64_t gq = live ? pgid : 0;
+            T* co = sa.coeffs + gq * (int64_t)pout;
+            if (live && t < p) co[t] = (T)(is_null ? nanv : w0);
+            if (live && 16 + t < p) co[16 + t] = (T)(is_null ? nanv : w1);
+            if (sa.sp.bias) {
+                const double sb = Grp<16>::sum((t < p ? psj0 * w0 : 0.0) + (16 + t < p ? psj1 * w1 : 0.0));
+                if (live && t == 0) co[p] = (T)(is_null ? nanv : (psy - sb) / pnn);
+            }
+            if (live && t == 0) sa.flags[gq] = is_null ? 1 : 0;
+            // marked systems: one DPP row after the other (wave-uniform control flow)
+            const unsigned long long sus = __builtin_amdgcn_ballot_w64(live && suspect);
+            for (int r = 0; r < 4; ++r) {
+                if (!((sus >> (16 * r)) & 1ull)) continue;
+                const int glo = __builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)pgid, 16 * r);
+                const int ghi = __builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)pgid >> 32), 16 * r);
+                const int64_t gg = (int64_t)(((uint64_t)(uint32_t)ghi << 32) | (uint64_t)(uint32_t)glo);
+                unsigned slot = 0;
+                if (lane == 0) slot = atomicAdd(sa.mark_count, 1u);
+                slot = (unsigned)__builtin_amdgcn_readfirstlane((int)slot);
+                if (slot < sa.mark_cap) {
+                    if (lane == 0) sa.mark_list[slot] = (int32_t)gg;
+                    record_from_rows(gg, sa.mark_rec + (int64_t)slot * q * q);
+                }
+            }
+            npend = 0;
+        }
+    };
+    // PAIRED, solving wave: a published slot -> DPP row `npend` of the pending registers (row-masked moves, as route_pending), four
+    // pending -> solve.  The slot holds the UPPER TRIANGLE of G row by row (MidPacked: one trip at any width; the full columns of
+    // route_pending's layout took two from 25 features, and the streaming wave stood still between them while a solve ran): lane t
+    // reads row i of its column at U(i, t) for i <= t and at U(t, i) below the diagonal -- an immediate offset on one of two lane
+    // addresses, chosen per element only inside the two diagonal blocks.
+    auto solver_wave = [&]() __attribute__((always_inline)) {
+        if constexpr (PAIRED) {
+            typedef __attribute__((address_space(3))) double* lds_dp;
+            using PK = MidPacked<SPPC, YC>;
+            lds_dp S = (lds_dp)(sm + MD::LDS_BYTES);
+            const int t = lane & 15;
+            const bool c1 = YC ? 16 + t < p : 16 + t < SPPC;  // (YC: columns p, p + 1 of the slot are the ones and the target, not the system's)
+            const int u = c1 ? 16 + t : 16;  // (lanes without a second column read a valid address, their values are zeroed)
+            const int rowt = PK::tri_rt(t) - t, rowu = PK::tri_rt(u) - u;  // U(t, i) = S[rowt + i], U(u, i) = S[rowu + i]
+            unsigned cseq = 0;
+            // A batch is straight-line code: group 0 goes to EVERY row (plain reads: the registers are defined afresh, nothing of the last
+            // batch stays live), groups 1 .. 3 into their rows by row-masked DPP moves, then the solve.  With the row as a run-time
+            // value (a switch over four variants, or a branch on the lane's row) every pending register existed twice around the merge
+            // points -- copies, and a register file that spilled into the stream's memory queue: 15 000 clk per group.
+            auto wait_group = [&]() __attribute__((always_inline)) {  // false: the stream has finished and nothing is published
+                for (;;) {
+                    const unsigned d = FL[2], f = FL[0];  // (in this order: after `done` nothing is published)
+                    if (f != cseq) return true;
+                    if (d) return false;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            };
+            auto took = [&]() __attribute__((always_inline)) {
+                PDS_WAVE_LDS_SYNC();  // (the values are in registers)
+                ++cseq;
+                FL[1] = cseq;
+            };
+            auto take = [&](auto rm) __attribute__((always_inline)) {
+                constexpr int ROW = decltype(rm)::value;
+                auto put = [&](double& dst, double v) __attribute__((always_inline)) {
+                    if constexpr (ROW == 0) dst = v;
+                    else dst = __builtin_amdgcn_update_dpp(dst, v, 0xE4 /*quad_perm:[0,1,2,3]*/, 1 << ROW, 0xf, false);
+                };
+                // (the lane terms pass through an empty asm: per-lane addresses inside the diagonal blocks are loop invariants otherwise,
+                // one register each)
+                int tl = t, ul = u, rt = rowt, ru = rowu;
+                asm volatile("" : "+v"(tl), "+v"(ul), "+v"(rt), "+v"(ru));
+                // eight rows (sixteen reads) at a time, the next eight in flight while these are moved into the pending registers
+                constexpr int NB = SPPC / 8;
+                double va[2][8], vb[2][8];
+                auto fetch8 = [&](int b, double (&x0)[8], double (&x1)[8]) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int i = 8 * b + k;
+                        // column t: rows beyond 15 are always below the diagonal; column 16 + t: rows up to 15 are always above it
+                        const int e0 = (i < 16 && i <= t) ? PK::tri(i) - i + tl : rt + i;
+                        const int e1 = (i < 16 || i <= u) ? PK::tri(i) - i + ul : ru + i;
+                        x0[k] = S[e0];
+                        x1[k] = S[e1];
+                    }
+                };
+                auto put8 = [&](int b, const double (&x0)[8], const double (&x1)[8]) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int i = 8 * b + k;
+                        const bool rowv = !YC || i < 16 || i < p;  // (YC: rows p, p + 1 of the slot are not the system's either)
+                        put(pa0[i], rowv ? x0[k] : 0.0);
+                        put(pa1[i], (c1 && rowv) ? x1[k] : 0.0);
+                    }
+                };
+                fetch8(0, va[0], vb[0]);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    if (b + 1 < NB) fetch8(b + 1, va[(b + 1) & 1], vb[(b + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    put8(b, va[b & 1], vb[b & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // X'y, column sums, rows, sum y -- YC: entries (., p + 1), (., p), (p, p), (p, p + 1) of the triangle
+                const double x0 = YC ? S[rt + p + 1] : S[PK::XY + tl], x1 = YC ? S[ru + p + 1] : S[PK::XY + ul];
+                const double s0 = YC ? S[rt + p] : S[PK::CS + tl], s1 = YC ? S[ru + p] : S[PK::CS + ul];
+                put(pa0[SPPC], x0);
+                put(pa1[SPPC], c1 ? x1 : 0.0);
+                put(psj0, s0);
+                put(psj1, c1 ? s1 : 0.0);
+                put(pnn, YC ? S[PK::tri_rt(p)] : S[PK::TAIL]);
+                put(psy, YC ? S[PK::tri_rt(p) + 1] : S[PK::TAIL + 1]);
+                {
+                    const long long gv = __double_as_longlong(S[PK::GID]);
+                    if constexpr (ROW == 0) {
+                        pgid = (int64_t)gv;
+                    } else {
+                        int lo = (int)(uint32_t)(uint64_t)pgid, hi = (int)(uint32_t)((uint64_t)pgid >> 32);
+                        lo = __builtin_amdgcn_update_dpp(lo, (int)(uint32_t)(uint64_t)gv, 0xE4, 1 << ROW, 0xf, false);
+                        hi = __builtin_amdgcn_update_dpp(hi, (int)(uint32_t)((uint64_t)gv >> 32), 0xE4, 1 << ROW, 0xf, false);
+                        pgid = (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo);
+                    }
+                }
+                took();
+            };
+            // (the streaming wave pads its last batch with discarded groups -- gid < 0 -- so a batch is always four: the only way out of the
+            // loop is in front of a batch, with no pending register live)
+            auto next_group = [&]() __attribute__((always_inline)) {
+                while (FL[0] == cseq) __builtin_amdgcn_s_sleep(1);
+            };
+            for (;;) {
+                PDS_MT(c0);
+                if (!wait_group()) break;
+                PDS_MADD(8, c0);
+                PDS_MT(c1);
+                take(std::integral_constant<int, 0>{});
+                PDS_MADD(9, c1);
+                PDS_MT(c2);
+                next_group();
+                PDS_MADD(8, c2);
+                PDS_MT(c3);
+                take(std::integral_constant<int, 1>{});
+                PDS_MADD(9, c3);
+                PDS_MT(c4);
+                next_group();
+                PDS_MADD(8, c4);
+                PDS_MT(c5);
+                take(std::integral_constant<int, 2>{});
+                PDS_MADD(9, c5);
+                PDS_MT(c6);
+                next_group();
+                PDS_MADD(8, c6);
+                PDS_MT(c7);
+                take(std::integral_constant<int, 3>{});
+                PDS_MADD(9, c7);
+                npend = 4;
+                PDS_MT(c8);
+                if (!(debug & 4)) solve_pending();  // (bit 4, a timing experiment: routed, never solved)
+                PDS_MADD(10, c8);
+            }
+        }
+    };
+    if constexpr (PAIRED)
+        if (consumer) {  // (before the streaming wave's state exists: none of it is live in the solver's registers)
+            solver_wave();
+#ifdef PDS_PROFILE_MID
+            PDS_MADD(15, t_kernel);
+            mprof_out();
+#endif
+            return;
+        }
+    const int g_ = lane / MD::GL, piece = lane % MD::GL;
+    const T* cbase[16];
+    unsigned valid = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = 16 * g_ + i;
+        cbase[i] = cols[c < p ? c : p] + EPL * piece;
+        if (c < p) valid |= 1u << i;
+    }
+    const T* ybase = cols[p] + EPL * lane;
+    auto issue = [&](int buf, int64_t row0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if ((valid >> i) & 1u)
+                __builtin_amdgcn_global_load_lds((glb_ptr)(as_global(cbase[i]) + row0), (lds_ptr)(sm + buf * MD::HALF_BYTES + i * GS), 16, 0, 0);
+        if (lane < HR / EPL)
+            __builtin_amdgcn_global_load_lds((glb_ptr)(as_global(ybase) + row0), (lds_ptr)(sm + buf * MD::HALF_BYTES + MD::Y_OFF), 16, 0, 0);
+    };
+    auto load_guarded = [&](int buf, int64_t row0) __attribute__((always_inline)) {  // the frame's last, partial half-tile
+        for (int c = 0; c <= p; ++c) {
+            const int offb = c < p ? (c % 16) * GS + (c / 16) * HR * ES : MD::Y_OFF;
+            const gptr<T> col = as_global(cols[c]);
+            for (int r = lane; r < HR; r += 64) PDS_GM_LDST(sm + buf * MD::HALF_BYTES + offb + r * ES) = row0 + r < n_frame ? col[row0 + r] : (T)0;
+        }
+    };
+    auto fetch_tile = [&](int buf, int64_t h) __attribute__((always_inline)) {
+        if ((h + 1) * HR <= n_frame) issue(buf, h * HR);
+        else load_guarded(buf, h * HR);
+    };
+    d4 acc[NPAIR];
+    double xy[NBLK], cs[NBLK], yy = 0.0, ys = 0.0;
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < NPAIR; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) xy[b] = cs[b] = 0.0;
+        yy = ys = 0.0;
+    };
+    zero_acc();
+    const int fi = lane & 15, fk = lane >> 4;
+    constexpr int NOP = NQ ? 1 + NQ : NBLK;  // operand registers per step: the first block + NQ quads, or the NBLK blocks
+    int opo[NOP];  // the lane's operand column inside an image
+#pragma unroll
+    for (int b = 0; b < NOP; ++b) {
+        const int c = NQ ? (b == 0 ? fi : 12 + 4 * b + (fi & 3)) : 16 * b + fi;  // (quad b - 1: column 16 + 4 (b - 1) + lane % 4)
+        opo[b] = (c & 15) * GS + (c >> 4) * HR * ES;
+        if constexpr (YC) {  // columns p and p + 1: the ones image and the target's image
+            if (b > 0 && c == p) opo[b] = MD::W_OFF;
+            if (b > 0 && c == p + 1) opo[b] = MD::Y_OFF;
+        }
+    }
+    const int qb = (lane >> 2) & 3, qj = lane & 3;  // quad lanes: D[i = fk][j = qj] of block qb
+    // ---- the group that holds the wave's first row
+    int64_t g = 0;
+    {
+        int64_t lo = 0, hi = n_groups;  // last g with off[g] <= W0
+        while (hi - lo > 1) {
+            const int64_t mid = lo + ((hi - lo) >> 1);
+            if (off[mid] <= W0) lo = mid;
+            else hi = mid;
+        }
+        g = lo;
+    }
+    // the group walk is wave-uniform: with g known to be uniform the offsets come through the SCALAR cache (their own counter) --
+    // as vector loads every group end waited, through the in-order vmcnt, for the next half-tile's 17 loads as well (12 us per
+    // half-tile instead of 2); the end of the NEXT group is fetched one group ahead
+    auto uni64 = [](int64_t v) __attribute__((always_inline)) {
+        const int lo32 = __builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)v), hi32 = __builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
+        return (int64_t)(((uint64_t)(uint32_t)hi32 << 32) | (uint64_t)(uint32_t)lo32);
+    };
+    g = uni64(g);
+    int64_t gs = off[g], ge = off[g + 1];
+    int64_t ge_next = off[g + 2 <= n_groups ? g + 2 : n_groups];
+    int64_t rows_in_acc = 0;
+    // accumulate rows [lo, hi) (relative to the half-tile in `buf`) into acc: a masked step at either end where the segment does not
+    // start / end on a 4-row step, the steps in between unmasked with the next step's operands fetched from LDS before this step
+    // multiplies (fetch -> wait -> multiply per step ran at half the stream rate: one wave per SIMD, nobody else hides the round trip)
+    auto consume = [&](int buf, int lo, int hi) __attribute__((always_inline)) {
+        const lds_c base = sm + buf * MD::HALF_BYTES;
+        auto fetch = [&](int s, double (&a)[NOP], double& yk) __attribute__((always_inline)) {
+            const int roff = (4 * s + fk) * ES;
+#pragma unroll
+            for (int b = 0; b < NOP; ++b) a[b] = (double)PDS_GM_LDST(base + opo[b] + roff);
+            if constexpr (!YC) yk = (double)PDS_GM_LDST(base + MD::Y_OFF + roff);
+            else yk = 0.0;
+        };
+        auto mult = [&](const double (&a)[NOP], double yk) __attribute__((always_inline)) {
+            if constexpr (NQ == 1) {
+                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], a[0], acc[0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[0], a[1], acc[1][0], 0, 0, 0);
+                acc[2][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[1], a[1], acc[2][0], 0, 0, 0);
+            } else if constexpr (NQ == 2) {
+                // the 8 x 8 corner in ONE instruction: block 0 = quad 0 with itself, 1 = quad 0 with quad 1, 2 (and 3) = quad 1 with itself
+                const double ca = qb < 2 ? a[1] : a[2], cb = qb == 0 ? a[1] : a[2];
+                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], a[0], acc[0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[0], a[1], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[0], a[2], acc[1][1], 0, 0, 0);
+                acc[2][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(ca, cb, acc[2][0], 0, 0, 0);
+            } else {
+                int t = 0;
+#pragma unroll
+                for (int I = 0; I < NBLK; ++I)
+#pragma unroll
+                    for (int J = I; J < NBLK; ++J) {
+                        if (t == 0 || !(debug & 8))  // (timing experiment: the first block only)
+                            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], a[J], acc[t], 0, 0, 0);
+                        ++t;
+                    }
+            }
+            if constexpr (!YC) {
+#pragma unroll
+                for (int b = 0; b < NBLK; ++b) {
+                    xy[b] = fma(a[b], yk, xy[b]);
+                    cs[b] += a[b];
+                }
+                yy = fma(yk, yk, yy);
+                ys += yk;
+            }
+        };
+        auto masked = [&](int s) __attribute__((always_inline)) {
+            const int rr = 4 * s + fk;
+            const bool in = rr >= lo && rr < hi;
+            double a[NOP], yk;
+            fetch(s, a, yk);
+#pragma unroll
+            for (int b = 0; b < NOP; ++b) a[b] = in ? a[b] : 0.0;
+            yk = in ? yk : 0.0;
+            mult(a, yk);
+        };
+        // a whole half-tile of one group: the unrolled form of the single-regression kernel (not for f32 frames with the side sums: its 32
+        // steps cost that variant 65 spilled registers -- the column pointers, reloaded behind the loads in flight)
+        if ((ES == 8 || YC) && lo == 0 && hi == HR) {
+            double a[NOP], yk;
+            fetch(0, a, yk);
+#pragma unroll
+            for (int s = 0; s < MD::NS; ++s) {
+                double an[NOP], ykn = 0.0;
+#pragma unroll
+                for (int b = 0; b < NOP; ++b) an[b] = 0.0;
+                if (s + 1 < MD::NS) fetch(s + 1, an, ykn);
+                mult(a, yk);
+#pragma unroll
+                for (int b = 0; b < NOP; ++b) a[b] = an[b];
+                yk = ykn;
+            }
+            rows_in_acc += HR;
+            return;
+        }
+        int s0 = lo >> 2, s1 = (hi + 3) >> 2;  // steps [s0, s1)
+        if ((lo & 3) != 0 || s1 - s0 == 1) {    // (a segment inside one step: that step masked on both sides)
+            masked(s0);
+            ++s0;
+        }
+        if (s0 < s1 && (hi & 3) != 0) {
+            --s1;
+            masked(s1);
+        }
+        if (s0 < s1) {
+            double a[NOP], yk;
+            fetch(s0, a, yk);
+            for (int s = s0; s < s1; ++s) {
+                double an[NOP], ykn;
+                fetch(s + 1 < s1 ? s + 1 : s, an, ykn);
+                mult(a, yk);
+#pragma unroll
+                for (int b = 0; b < NOP; ++b) a[b] = an[b];
+                yk = ykn;
+            }
+        }
+        rows_in_acc += hi - lo;
+    };
+    // the accumulated rows of group g -> a record at M (plain stores, or atomics into a zeroed record that other waves add to)
+    auto put_record = [&](double* M, bool plain) __attribute__((always_inline)) {
+        auto put = [&](int64_t idx, double v) __attribute__((always_inline)) {
+            if (plain) M[idx] = v;
+            else if (v != 0.0) unsafeAtomicAdd(M + idx, v);
+        };
+        int t = 0;
+        const int pe = YC ? q : p;  // (YC: the blocks hold [X 1 y]' [X 1 y], which is the record)
+        if constexpr (NQ != 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = fk + 4 * r, j = fi;
+                if (i < pe && j < pe) put(i + (int64_t)j * q, acc[0][r]);
+            }
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) {  // first block x quad u: G[4 qb + fk][16 + 4 u + qj]
+                const int c = 16 + 4 * u + qj;
+                if (c < pe) {
+                    put((4 * qb + fk) + (int64_t)c * q, acc[1][u]);
+                    put(c + (int64_t)(4 * qb + fk) * q, acc[1][u]);
+                }
+            }
+            {  // the corner: NQ = 1: block 0 = (quad 0, quad 0), both triangles in its lanes; NQ = 2: blocks (0, 0), (0, 1), (1, 1)
+                const int ri = 16 + (NQ == 2 && qb >= 2 ? 4 : 0) + fk, cj = 16 + (NQ == 2 && qb >= 1 ? 4 : 0) + qj;
+                if (qb < (NQ == 2 ? 3 : 1) && ri < pe && cj < pe) {
+                    put(ri + (int64_t)cj * q, acc[2][0]);
+                    if (NQ == 2 && qb == 1) put(cj + (int64_t)ri * q, acc[2][0]);
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int I = 0; I < NBLK; ++I)
+#pragma unroll
+            for (int J = I; J < NBLK; ++J) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * I + fk + 4 * r, j = 16 * J + fi;
+                    if (i < pe && j < pe) {
+                        put(i + (int64_t)j * q, acc[t][r]);
+                        if (I != J) put(j + (int64_t)i * q, acc[t][r]);
+                    }
+                }
+                ++t;
+            }
+        if constexpr (YC) return;
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) {
+            double vx = xy[b], vc = cs[b];
+            vx += __shfl_xor(vx, 16);
+            vx += __shfl_xor(vx, 32);
+            vc += __shfl_xor(vc, 16);
+            vc += __shfl_xor(vc, 32);
+            const int f = 16 * b + fi;
+            if (fk == 0 && f < p) {
+                put(f + (int64_t)(p + 1) * q, vx);
+                put((p + 1) + (int64_t)f * q, vx);
+                put(f + (int64_t)p * q, vc);
+                put(p + (int64_t)f * q, vc);
+            }
+        }
+        double vyy = yy, vys = ys;
+        vyy += __shfl_xor(vyy, 16);
+        vyy += __shfl_xor(vyy, 32);
+        vys += __shfl_xor(vys, 16);
+        vys += __shfl_xor(vys, 32);
+        if (lane == 0) {
+            put(p + (int64_t)p * q, (double)rows_in_acc);
+            put(p + (int64_t)(p + 1) * q, vys);
+            put((p + 1) + (int64_t)p * q, vys);
+            put((p + 1) + (int64_t)(p + 1) * q, vyy);
+        }
+    };
+    // the finished group's accumulators -> DPP row `npend` of the pending registers, through the LDS scratch behind the tile images
+    // (every lane of every row reads column t / 16 + t; a ROW-MASKED DPP move -- identity permutation, row_mask = the pending row --
+    // drops the values into that row's lanes only: two instructions per value, no select against the old contents, no temporaries)
+    auto route_pending = [&]() __attribute__((always_inline)) {
+        if constexpr (SPPC > 0) {
+            typedef __attribute__((address_space(3))) double* lds_dp;
+            constexpr int SS = SPPC + 2;                                   // doubles per column of the scratch
+            constexpr bool ONE_TRIP = SPPC * SS * 8 <= kMidSolveScratch;   // all SPPC columns at once (up to 24 features)
+            lds_dp S = (lds_dp)(sm + MD::LDS_BYTES);
+            const int t = lane & 15;
+            double vx0 = xy[0], vx1 = xy[1], vc0 = cs[0], vc1 = cs[1], vys = ys;
+            vx0 += __shfl_xor(vx0, 16); vx0 += __shfl_xor(vx0, 32);
+            vx1 += __shfl_xor(vx1, 16); vx1 += __shfl_xor(vx1, 32);
+            vc0 += __shfl_xor(vc0, 16); vc0 += __shfl_xor(vc0, 32);
+            vc1 += __shfl_xor(vc1, 16); vc1 += __shfl_xor(vc1, 32);
+            vys += __shfl_xor(vys, 16); vys += __shfl_xor(vys, 32);
+            const double nn = (double)rows_in_acc;
+            auto into_row = [&](auto rm) __attribute__((always_inline)) {
+                constexpr int RM = 1 << decltype(rm)::value;
+                auto put = [&](double& dst, double v) __attribute__((always_inline)) {
+                    dst = __builtin_amdgcn_update_dpp(dst, v, 0xE4 /*quad_perm:[0,1,2,3]*/, RM, 0xf, false);
+                };
+                auto put64 = [&](int64_t& dst, int64_t v) __attribute__((always_inline)) {
+                    int lo = (int)(uint32_t)(uint64_t)dst, hi = (int)(uint32_t)((uint64_t)dst >> 32);
+                    lo = __builtin_amdgcn_update_dpp(lo, (int)(uint32_t)(uint64_t)v, 0xE4, RM, 0xf, false);
+                    hi = __builtin_amdgcn_update_dpp(hi, (int)(uint32_t)((uint64_t)v >> 32), 0xE4, RM, 0xf, false);
+                    dst = (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo);
+                };
+                PDS_WAVE_LDS_SYNC();
+                // columns 0 .. 15: rows 0 .. 15 from block (0, 0), rows 16 .. from block (0, 1) transposed (G is symmetric)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    S[fi * SS + fk + 4 * r] = acc[0][r];
+                    if (16 + fi < SPPC) S[(fk + 4 * r) * SS + 16 + fi] = acc[1][r];
+                }
+                if constexpr (ONE_TRIP) {
+                    // columns 16 .. SPPC - 1 behind them: rows 0 .. 15 from block (0, 1), rows 16 .. from block (1, 1)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (16 + fi < SPPC) {
+                            S[(16 + fi) * SS + fk + 4 * r] = acc[1][r];
+                            if (16 + fk + 4 * r < SPPC) S[(16 + fi) * SS + 16 + fk + 4 * r] = acc[2][r];
+                        }
+                    }
+                }
+                PDS_WAVE_LDS_SYNC();
+#pragma unroll
+                for (int i = 0; i < SPPC; ++i) put(pa0[i], S[t * SS + i]);
+                if constexpr (ONE_TRIP) {
+                    const int t1 = (16 + t < SPPC) ? 16 + t : 0;  // (lanes without a second column read a valid address, their values are zeroed)
+#pragma unroll
+                    for (int i = 0; i < SPPC; ++i) {
+                        const double v = S[t1 * SS + i];
+                        put(pa1[i], (16 + t < SPPC) ? v : 0.0);
+                    }
+                } else {
+                    PDS_WAVE_LDS_SYNC();
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        S[fi * SS + fk + 4 * r] = acc[1][r];
+                        S[fi * SS + 16 + fk + 4 * r] = acc[2][r];
+                    }
+                    PDS_WAVE_LDS_SYNC();
+#pragma unroll
+                    for (int i = 0; i < SPPC; ++i) put(pa1[i], S[t * SS + i]);
+                }
+                put(pa0[SPPC], vx0);
+                put(pa1[SPPC], vx1);
+                put(psj0, vc0);
+                put(psj1, vc1);
+                put(pnn, nn);
+                put(psy, vys);
+                put64(pgid, g);
+            };
+            switch (npend) {
+                case 0: into_row(std::integral_constant<int, 0>{}); break;
+                case 1: into_row(std::integral_constant<int, 1>{}); break;
+                case 2: into_row(std::integral_constant<int, 2>{}); break;
+                default: into_row(std::integral_constant<int, 3>{}); break;
+            }
+            ++npend;
+            if (npend == 4) {
+                if (debug & 4) npend = 0;  // (timing experiment: routed, never solved)
+                else solve_pending();
+            }
+        }
+    };
+    // PAIRED, streaming wave: the finished group's moments -> the pair's slot (MidPacked), published under a sequence number.  A slot
+    // the solving wave has not taken yet (it is in the middle of a solve) does not stop the stream: the group waits in a spare set of
+    // registers and goes out in front of the next one -- the stream stands still only when the solver is two groups behind.
+    unsigned pseq = 0;
+    d4 st_acc[NPAIR];
+    double st_x0 = 0.0, st_x1 = 0.0, st_c0 = 0.0, st_c1 = 0.0, st_nn = 0.0, st_ys = 0.0;
+    int64_t st_g = 0;
+    bool stashed = false;
+    auto slot_free = [&]() __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane((int)FL[1]) == (int)pseq; };
+    auto publish_group = [&](const d4 (&A)[NPAIR], double vx0, double vx1, double vc0, double vc1, double nn, double vys, int64_t gid)
+                             __attribute__((always_inline)) {
+        if constexpr (PAIRED) {
+            typedef __attribute__((address_space(3))) double* lds_dp;
+            using PK = MidPacked<SPPC, YC>;
+            lds_dp S = (lds_dp)(sm + MD::LDS_BYTES);
+            PDS_MT(tw);
+            while (!slot_free()) __builtin_amdgcn_s_sleep(1);
+            PDS_MADD(4, tw);
+            if constexpr (NQ != 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = fk + 4 * r;
+                    if (i <= fi) S[PK::tri_rt(i) - i + fi] = A[0][r];
+                }
+                const int qr = 4 * qb + fk;  // quad lanes: D[i = fk][j = qj] of block qb
+#pragma unroll
+                for (int u = 0; u < NQ; ++u) S[PK::tri_rt(qr) - qr + 16 + 4 * u + qj] = A[1][u];
+                {   // the corner: (quad 0, quad 0) [, (quad 0, quad 1), (quad 1, quad 1)]: the upper triangle of it
+                    const int ri = 16 + (NQ == 2 && qb >= 2 ? 4 : 0) + fk, cj = 16 + (NQ == 2 && qb >= 1 ? 4 : 0) + qj;
+                    if (qb < (NQ == 2 ? 3 : 1) && ri <= cj) S[PK::tri_rt(ri) - ri + cj] = A[2][0];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = fk + 4 * r;  // block (0, 0): G[i][fi], block (0, 1): G[i][16 + fi], block (1, 1): G[16 + i][16 + fi]
+                    if (i <= fi) S[PK::tri_rt(i) - i + fi] = A[0][r];
+                    if (16 + fi < PK::QC) {
+                        S[PK::tri_rt(i) - i + 16 + fi] = A[1][r];
+                        if (i <= fi) S[PK::tri_rt(16 + i) - i + fi] = A[2][r];
+                    }
+                }
+            }
+            if constexpr (!YC) {
+                if (fk == 0) {
+                    S[PK::XY + fi] = vx0;
+                    S[PK::CS + fi] = vc0;
+                    if (16 + fi < SPPC) {
+                        S[PK::XY + 16 + fi] = vx1;
+                        S[PK::CS + 16 + fi] = vc1;
+                    }
+                }
+                if (lane == 0) {
+                    S[PK::TAIL] = nn;
+                    S[PK::TAIL + 1] = vys;
+                }
+            }
+            if (lane == 0) S[PK::GID] = __longlong_as_double((long long)gid);
+            PDS_WAVE_LDS_SYNC();
+            ++pseq;
+            FL[0] = pseq;
+        }
+    };
+    auto flush_stash = [&]() __attribute__((always_inline)) {
+        if constexpr (PAIRED) {
+            if (stashed) {
+                publish_group(st_acc, st_x0, st_x1, st_c0, st_c1, st_nn, st_ys, st_g);
+                stashed = false;
+            }
+        }
+    };
+    // STASH2 (up to 24 features, where the streaming wave has the registers): TWO spare sets -- a solve of four (17 600 ticks at 17 features)
+    // outlasts a group (10 800) and the slot + one set did not always absorb it: the streaming wave stood 9.6 % of its time in front of a
+    // full slot.  A two-deep FIFO in registers: set A / set B, `a_old` says which is the older; drained whenever the slot is free.
+    constexpr bool STASH2 = PAIRED && YC && SPPC == 24;
+    d4 st_b[STASH2 ? NPAIR : 1];
+    int64_t st_gb = 0;
+    int nst = 0;
+    bool a_old = true;
+    auto drain_one = [&]() __attribute__((always_inline)) {  // (the slot is free, nst > 0)
+        if constexpr (STASH2) {
+            if (a_old) publish_group(st_acc, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, st_g);
+            else publish_group(st_b, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, st_gb);
+            a_old = !a_old;
+            --nst;
+        }
+    };
+    auto drain_free = [&]() __attribute__((always_inline)) {
+        if constexpr (STASH2) {
+            while (nst > 0 && slot_free()) drain_one();
+        }
+    };
+    auto hand_over2 = [&]() __attribute__((always_inline)) {
+        if constexpr (STASH2) {
+            drain_free();
+            if (nst == 0 && slot_free()) {
+                publish_group(acc, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, g);
+                return;
+            }
+            if (nst == 2) drain_one();  // (both sets taken: this one waits for the slot inside publish_group)
+            if (nst == 0) {
+#pragma unroll
+                for (int b = 0; b < NPAIR; ++b) st_acc[b] = acc[b];
+                st_g = g;
+                a_old = true;
+            } else if (a_old) {
+#pragma unroll
+                for (int b = 0; b < NPAIR; ++b) st_b[b] = acc[b];
+                st_gb = g;
+            } else {
+#pragma unroll
+                for (int b = 0; b < NPAIR; ++b) st_acc[b] = acc[b];
+                st_g = g;
+            }
+            ++nst;
+        }
+    };
+    auto hand_over = [&]() __attribute__((always_inline)) {
+        if constexpr (STASH2) {
+            hand_over2();
+        } else if constexpr (PAIRED) {
+            double vx0 = xy[0], vx1 = xy[1], vc0 = cs[0], vc1 = cs[1], vys = ys;
+            if constexpr (!YC) {
+                vx0 = rows_sum4(vx0);
+                vx1 = rows_sum4(vx1);
+                vc0 = rows_sum4(vc0);
+                vc1 = rows_sum4(vc1);
+                vys = rows_sum4(vys);
+            }
+            flush_stash();
+            if (slot_free()) {
+                publish_group(acc, vx0, vx1, vc0, vc1, (double)rows_in_acc, vys, g);
+            } else {
+#pragma unroll
+                for (int b = 0; b < NPAIR; ++b) st_acc[b] = acc[b];
+                st_x0 = vx0; st_x1 = vx1; st_c0 = vc0; st_c1 = vc1;
+                st_nn = (double)rows_in_acc; st_ys = vys; st_g = g;
+                stashed = true;
+            }
+        }
+    };
+    auto flush = [&]() __attribute__((always_inline)) {
+        const bool whole = gs >= W0 && ge <= W1;
+        if (debug & 2) {  // (timing experiment: no record stores)
+            zero_acc();
+            rows_in_acc = 0;
+            return;
+        }
+        if constexpr (SPPC > 0) {
+            if (whole) {
+                if constexpr (PAIRED) hand_over();
+                else route_pending();
+            } else {
+                // the wave the group starts in owns the side-table slot (largest w whose first row is <= gs)
+                int64_t slot = wave;
+                if (gs < W0) {
+                    int64_t lo = 0, hi = wave;
+                    while (hi - lo > 1) {
+                        const int64_t mid = lo + ((hi - lo) >> 1);
+                        const int64_t hm = H0 + (H1 - H0) * mid / nwaves;
+                        const int64_t wm = hm * HR > row_begin ? hm * HR : row_begin;
+                        if (wm <= gs) lo = mid;
+                        else hi = mid;
+                    }
+                    slot = lo;
+                } else if (lane == 0) {
+                    sa.side_list[wave] = (int32_t)g;
+                }
+                put_record(sa.side_rec + slot * (int64_t)q * q, false);
+            }
+        } else {
+            put_record(records + g * (int64_t)q * q, whole);
+        }
+        zero_acc();
+        rows_in_acc = 0;
+    };
+    // ---- stream the half-tiles
+    int64_t pos = W0;
+    fetch_tile(0, h0);
+    for (int64_t h = h0; h < h1; ++h) {
+        const int buf = (int)((h - h0) & 1);
+        PDS_MT(p0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // half-tile h has landed (and this wave's record stores are out)
+        PDS_WAVE_LDS_SYNC();
+        PDS_MADD(0, p0);
+        // (a waiting group goes out as soon as the solving wave has emptied the slot, not only when the next group ends: without this look
+        // per half-tile the 17-feature kernel is 6 % slower)
+        if constexpr (STASH2) {
+            if (nst > 0) drain_free();
+        } else if constexpr (PAIRED) {
+            if (stashed && slot_free()) flush_stash();
+        }
+        PDS_MT(p1);
+        if (h + 1 < h1) fetch_tile(buf ^ 1, h + 1);  // (the other image was consumed one iteration ago)
+        PDS_MADD(1, p1);
+        const int64_t R0 = h * HR;
+        const int64_t tile_end = R0 + HR < W1 ? R0 + HR : W1;
+        while (pos < tile_end) {
+            const int64_t seg_end = ge < tile_end ? ge : tile_end;
+            PDS_MT(p2);
+            if (seg_end > pos && !(debug & 1)) consume(buf, (int)(pos - R0), (int)(seg_end - R0));
+            PDS_MADD(2, p2);
+            if (debug & 1) rows_in_acc += seg_end - pos;
+            pos = seg_end;
+            if (pos == ge) {  // group complete (as far as this wave's rows go: `whole` decides how it is written)
+                PDS_MT(p3);
+                if (rows_in_acc > 0) flush();
+                PDS_MADD(3, p3);
+                do {  // (empty groups: their records stay zero)
+                    ++g;
+                    gs = ge;
+                    ge = ge_next;
+                    ge_next = off[g + 2 <= n_groups ? g + 2 : n_groups];
+                } while (g < n_groups && ge == pos);
+                if (g >= n_groups) break;
+            }
+        }
+        if (g >= n_groups) break;
+        PDS_WAVE_LDS_SYNC();
+    }
+    if (rows_in_acc > 0 && g < n_groups) flush();  // the group that continues in the next wave's rows
+    if constexpr (PAIRED) {
+        flush_stash();
+        if constexpr (STASH2)
+            while (nst > 0) drain_one();  // (publish_group waits for the slot)
+        while ((pseq & 3u) != 0u) {  // pad the last batch: the slot's contents once more (a valid system), marked as discarded
+            typedef __attribute__((address_space(3))) double* lds_dp;
+            while (!slot_free()) __builtin_amdgcn_s_sleep(1);
+            if (lane == 0) ((lds_dp)(sm + MD::LDS_BYTES))[MidPacked<SPPC, YC>::GID] = __longlong_as_double(-1ll);
+            PDS_WAVE_LDS_SYNC();
+            ++pseq;
+            FL[0] = pseq;
+        }
+        PDS_WAVE_LDS_SYNC();
+        FL[2] = 1u;
+    } else {
+        solve_pending();
+    }
+#ifdef PDS_PROFILE_MID
+    PDS_MADD(7, t_kernel);
+    mprof_out();
+#endif
+#undef PDS_GM_LDSD
+#undef PDS_GM_LDST
+}
+
+template <int NBLK>
+int launch_grouped_stream(pds_ctx* ctx, const DeviceCols<double>& dc, int p, int64_t n_frame, const int64_t* d_off, int64_t n_groups,
+                          double* d_records) {
+    using MD = MidDims<NBLK>;
+    const int q = p + 2;
+    PDS_HIP_CHECK(hipMemsetAsync(d_records, 0, (size_t)n_groups * q * q * sizeof(double), ctx->stream));
+    auto kern = grouped_mid_stream_kernel<NBLK>;
+    if (MD::LDS_BYTES > 64 * 1024)
+        PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, MD::LDS_BYTES));
+    // a wave takes at least eight half-tiles: a group then meets at most two waves unless it is longer than a wave's whole range, and
+    // the sum of two partial records does not depend on their order -- results are reproducible run to run but for such giant groups
+    // (the row count of the chunk is not known on the host: the frame's is an upper bound)
+    const int64_t waves = std::min<int64_t>((int64_t)ctx->num_cus * kMidWavesPerCu, std::max<int64_t>(1, n_frame / (8 * MD::HR)));
+#ifdef PDS_DEV_SWITCHES  // timing experiments of development builds (EXTRA=-DPDS_DEV_SWITCHES): wrong results with it
+    const char* dbg = std::getenv("PDS_GMID_DEBUG");
+#else
+    const char* dbg = nullptr;
+#endif
+    hipLaunchKernelGGL(kern, dim3((unsigned)waves), dim3(64), MD::LDS_BYTES, ctx->stream, dc.d_ptrs, p, n_frame, d_off, n_groups, d_records,
+                       dbg ? std::atoi(dbg) : 0, MidSolveArgs{});
+    PDS_HIP_CHECK(hipGetLastError());
+    return PDS_OK;
+}
+
+// ---- the in-wave-solve form (SPPC): host side
+constexpr unsigned kMidMarkCap = 8192;  // records of marked systems kept for the pivoted QR; more than that: the record pipeline
+inline int64_t mid_fused_waves(const pds_ctx* ctx, int64_t n_frame, int hr = MidDims<2>::HR) {
+    const int64_t w = std::min<int64_t>((int64_t)ctx->num_cus * kMidWavesPerCu, std::max<int64_t>(1, n_frame / (8 * hr)));
+    return w >= 4 ? w / 4 * 4 : w;  // (whole workgroups of four pairs: the PAIRED form)
+}
+// side table -> compact: the groups that straddle wave boundaries (slot w used iff side_list[w] >= 0), their records, row counts as
+// offsets, and the count (there are at most `waves` <= 1024 of them: every block repeats the scan, block 0 writes the lists, all blocks
+// share the copy of the records -- one block alone took 0.5 ms over the 9.5 MB of 1 024 records at 32 features)
+__global__ __launch_bounds__(1024) void mid_side_compact_kernel(const double* __restrict__ side_rec, const int32_t* __restrict__ side_list,
+                                                                int waves, int qq, const int64_t* __restrict__ off, double* __restrict__ rec_c,
+                                                                int32_t* __restrict__ list_c, int64_t* __restrict__ rows_c,
+                                                                unsigned* __restrict__ count_out) {
+    // thread w = slot w (waves <= 1024): inclusive scans of "used" and of the row counts through shared memory
+    __shared__ int s_cnt[1024];
+    __shared__ long long s_rows[1024];
+    __shared__ int s_slot[1024];
+    const int w = threadIdx.x;
+    const int32_t g = w < waves ? side_list[w] : -1;
+    const long long rows = g >= 0 ? (long long)(off[g + 1] - off[g]) : 0;
+    s_cnt[w] = g >= 0 ? 1 : 0;
+    s_rows[w] = rows;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int c = w >= d ? s_cnt[w - d] : 0;
+        const long long r = w >= d ? s_rows[w - d] : 0;
+        __syncthreads();
+        s_cnt[w] += c;
+        s_rows[w] += r;
+        __syncthreads();
+    }
+    const int n = s_cnt[1023];
+    if (g >= 0) {
+        const int k = s_cnt[w] - 1;
+        s_slot[k] = w;
+        if (blockIdx.x == 0) {
+            list_c[k] = g;
+            rows_c[k + 1] = s_rows[w];
+        }
+    }
+    if (w == 0 && blockIdx.x == 0) {
+        rows_c[0] = 0;
+        *count_out = (unsigned)n;
+    }
+    __syncthreads();
+    for (int64_t e = (int64_t)blockIdx.x * 1024 + w; e < (int64_t)n * qq; e += (int64_t)gridDim.x * 1024) {
+        const int k = (int)(e / qq);
+        rec_c[e] = side_rec[(int64_t)s_slot[k] * qq + (e - (int64_t)k * qq)];
+    }
+}
+// groups without rows: nobody finishes them, so nobody answers them -- null, NaN coefficients (the fill of the whole coefficient block
+// this replaces was 136 .. 264 MB of stores per call at 1e6 groups)
+template <typename T>
+__global__ __launch_bounds__(256) void mid_empty_groups_kernel(const int64_t* __restrict__ off, int64_t n_groups, int pp, T* __restrict__ coeffs,
+                                                               uint8_t* __restrict__ flags) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= n_groups || off[g + 1] != off[g]) return;
+    flags[g] = 1;
+    for (int c = 0; c < pp; ++c) coeffs[g * pp + c] = (T)__builtin_nan("");
+}
+template <typename T>
+__global__ __launch_bounds__(256) void mid_scatter_kernel(const double* __restrict__ co_c, const uint8_t* __restrict__ fl_c,
+                                                          const int32_t* __restrict__ list, int64_t n, int pp, T* __restrict__ coeffs,
+                                                          uint8_t* __restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * pp) return;
+    const int64_t k = i / pp;
+    const int c = (int)(i - k * pp);
+    const int64_t g = list[k];
+    coeffs[g * pp + c] = (T)co_c[i];
+    if (c == 0) flags[g] = fl_c[k] ? 1 : 0;
+}
+
+}  // namespace
+
+// Moment records ((p+2)^2 doubles each, column-major over [x_0 .. x_{p-1}, 1, y]) of n_groups contiguous groups (d_off: n_groups + 1
+// device offsets into the frame of n_frame rows) with 17 .. 64 f64 features, from one stream over the groups' rows.
+int launch_grouped_moments_stream(pds_ctx* ctx, const DeviceCols<double>& dc, int n_feat, int64_t n_frame, const int64_t* d_off, int64_t n_groups,
+                                  double* d_records) {
+    if (n_groups <= 0) return PDS_OK;
+    KernelTimer timer(ctx, kKindGroupedMoments);
+    if (n_feat <= 32) return launch_grouped_stream<2>(ctx, dc, n_feat, n_frame, d_off, n_groups, d_records);
+    if (n_feat <= 64) return launch_grouped_stream<4>(ctx, dc, n_feat, n_frame, d_off, n_groups, d_records);
+    return fail(PDS_ERR_UNSUPPORTED, "grouped_mid_stream: up to 64 features");
+}
+
+// OLS / ridge fits of n_groups contiguous groups with 17 .. 32 f64 features, rank gate on, as ONE stream with the solves in the
+// streaming waves (grouped_mid_stream_kernel, SPPC): coefficients [n_groups][p + bias] and null flags; no per-group records.
+// PDS_ERR_UNSUPPORTED (nothing usable written): not applicable, or more systems next to the gate than the marked list holds -- the
+// caller keeps the record pipeline.  d_ws: grouped_mid_fused_workspace() bytes.
+size_t grouped_mid_fused_workspace(int num_cus, int n_feat, int add_bias) {
+    const size_t q = (size_t)n_feat + 2, pp = (size_t)n_feat + (add_bias ? 1 : 0), waves = (size_t)num_cus * kMidWavesPerCu;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t sysmax = std::max<size_t>(waves, kMidMarkCap);
+    return 4096 + 2 * up(waves * q * q * 8) + 2 * up(waves * 4) + up((waves + 1) * 8) + up((size_t)kMidMarkCap * q * q * 8) + up((size_t)kMidMarkCap * 4) +
+           up(sysmax * pp * 8) + up(sysmax) + solve_wave_workspace(n_feat, add_bias, (int64_t)waves, 8) + 512;
+}
+template <typename T>
+int launch_grouped_mid_fused(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_frame, const int64_t* d_off, int64_t n_groups,
+                             const SolveParams& sp, T* d_coeffs, uint8_t* d_flags, void* d_ws) {
+    if (n_feat <= 16 || n_feat > 32 || !(sp.gate_tol > 0.0) || sp.lambda_on_bias || !d_flags || !d_ws || n_groups <= 0 ||
+        n_groups >= (1ll << 31))
+        return PDS_ERR_UNSUPPORTED;
+    using MD = MidDims<2, (int)sizeof(T)>;
+    constexpr bool F64 = sizeof(T) == 8;
+    const int p = n_feat, q = p + 2, bias = sp.add_bias ? 1 : 0, pp = p + bias;
+    const int64_t waves = mid_fused_waves(ctx, n_frame, MD::HR);
+    if (waves > 1024) return PDS_ERR_UNSUPPORTED;  // (mid_side_compact_kernel: one thread per wave)
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    char* wsp = static_cast<char*>(d_ws);
+    wsp += (256 - (reinterpret_cast<uintptr_t>(wsp) & 255)) & 255;
+    auto take = [&](size_t b) { char* r = wsp; wsp += up(b); return r; };
+    MidSolveArgsT<T> sa;
+    sa.sp.p = p;
+    sa.sp.pp = p;
+    sa.sp.bias = bias;
+    sa.sp.lambda_on_bias = 0;
+    sa.sp.lambda = sp.lambda;
+    sa.sp.gate_on = 1;
+    sa.sp.ln_tol = std::log(sp.gate_tol);
+    sa.sp.inv_tol = 1.0 / sp.gate_tol;
+    const bool second_pass = sp.solver != PDS_SOLVER_CHOLESKEY;  // (as launch_solve_wave: "choleskey" IS the in-wave factorisation)
+    sa.sp.sus_tol = second_pass ? std::sqrt(sa.sp.inv_tol) : 0.0;
+    sa.sp.sus_ratio = second_pass ? solve_suspect_ratio() : 0.0;
+    sa.sp.sus_band = 1e-5;
+    sa.coeffs = d_coeffs;
+    sa.flags = d_flags;
+    unsigned* d_counts = reinterpret_cast<unsigned*>(take(256));  // [0] marked, [1] side groups
+    sa.mark_count = d_counts;
+    sa.side_rec = reinterpret_cast<double*>(take((size_t)waves * q * q * 8));
+    sa.side_list = reinterpret_cast<int32_t*>(take((size_t)waves * 4));
+    sa.mark_rec = reinterpret_cast<double*>(take((size_t)kMidMarkCap * q * q * 8));
+    sa.mark_list = reinterpret_cast<int32_t*>(take((size_t)kMidMarkCap * 4));
+    sa.mark_cap = kMidMarkCap;
+    double* rec_c = reinterpret_cast<double*>(take((size_t)waves * q * q * 8));
+    int32_t* list_c = reinterpret_cast<int32_t*>(take((size_t)waves * 4));
+    int64_t* rows_c = reinterpret_cast<int64_t*>(take((size_t)(waves + 1) * 8));
+    const size_t sysmax = std::max<size_t>((size_t)waves, kMidMarkCap);
+    double* co_c = reinterpret_cast<double*>(take(sysmax * pp * 8));
+    uint8_t* fl_c = reinterpret_cast<uint8_t*>(take(sysmax));
+    void* wave_ws = take(solve_wave_workspace(n_feat, bias, waves, 8));
+    // groups nobody answers (no rows) are null with NaN coefficients: the kernel writes a group's answer where it finishes it
+    hipLaunchKernelGGL(mid_empty_groups_kernel<T>, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, ctx->stream, d_off, n_groups, pp, d_coeffs,
+                       d_flags);
+    PDS_HIP_CHECK(hipMemsetAsync(d_counts, 0, 256, ctx->stream));
+    PDS_HIP_CHECK(hipMemsetAsync(sa.side_rec, 0, (size_t)waves * q * q * 8, ctx->stream));
+    PDS_HIP_CHECK(hipMemsetAsync(sa.side_list, 0xFF, (size_t)waves * 4, ctx->stream));
+    constexpr int lds = MD::LDS_BYTES + kMidSolveScratch;
+    const char* pair_env = std::getenv("PDS_GROUPED_MID_PAIRED");
+    const bool paired = !(pair_env && pair_env[0] == '0') && waves % 4 == 0;
+    if (!F64 && !paired) return PDS_ERR_UNSUPPORTED;  // (f32 frames: the paired form only)
+    {
+        KernelTimer timer(ctx, kKindGroupedMoments);
+#ifdef PDS_DEV_SWITCHES  // timing experiments of development builds (EXTRA=-DPDS_DEV_SWITCHES): wrong results with it
+        const char* dbg = std::getenv("PDS_GMID_DEBUG");
+#else
+        const char* dbg = nullptr;
+#endif
+        const int debug = dbg ? std::atoi(dbg) : 0;
+        auto launch = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3((unsigned)waves), dim3(64), lds, ctx->stream, dc.d_ptrs, p, n_frame, d_off, n_groups, (double*)nullptr, debug, sa);
+        };
+        auto launch_paired = [&](auto kern) {
+            constexpr int plds = 4 * kMidPairLds<2>;
+            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, plds);
+            (void)attr;
+            hipLaunchKernelGGL(kern, dim3((unsigned)(waves / 4)), dim3(512), plds, ctx->stream, dc.d_ptrs, p, n_frame, d_off, n_groups, (double*)nullptr,
+                               debug, sa);
+        };
+        if (paired) {
+            const char* yc_env = std::getenv("PDS_GROUPED_MID_YC");  // (development: '0' keeps the side sums of the 31 / 32-feature form)
+            const bool yc = !F64 || !(yc_env && yc_env[0] == '0');  // (f32 frames have the ones / target column form only)
+            const char* nq_env = std::getenv("PDS_GROUPED_MID_QUAD");  // (development: '0' keeps the 16 x 16 x 4 form of the second block)
+            if (p <= 18 && yc && !(nq_env && nq_env[0] == '0')) launch_paired(grouped_mid_stream_kernel<2, 24, true, true, 1, T>);
+            else if (p <= 22 && yc && !(nq_env && nq_env[0] == '0')) launch_paired(grouped_mid_stream_kernel<2, 24, true, true, 2, T>);
+            else if (p <= 24 && (yc || !F64)) launch_paired(grouped_mid_stream_kernel<2, 24, true, true, 0, T>);
+            else if (p <= 24) {
+                if constexpr (F64) launch_paired(grouped_mid_stream_kernel<2, 24, true, false>);
+            } else if (p <= 30 && yc) launch_paired(grouped_mid_stream_kernel<2, 32, true, true, 0, T>);
+            else launch_paired(grouped_mid_stream_kernel<2, 32, true, false, 0, T>);
+        } else if constexpr (F64) {
+            if (p <= 24) launch(grouped_mid_stream_kernel<2, 24>);
+            else launch(grouped_mid_stream_kernel<2, 32>);
+        }
+        PDS_HIP_CHECK(hipGetLastError());
+    }
+    // the groups cut by wave boundaries: compacted, then the record solver
+    hipLaunchKernelGGL(mid_side_compact_kernel, dim3(64), dim3(1024), 0, ctx->stream, (const double*)sa.side_rec, (const int32_t*)sa.side_list,
+                       (int)waves, q * q, d_off, rec_c, list_c, rows_c, d_counts + 1);
+    unsigned h_counts[2] = {0, 0};
+    PDS_HIP_CHECK(hipMemcpyAsync(h_counts, d_counts, sizeof(h_counts), hipMemcpyDeviceToHost, ctx->stream));
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+#ifdef PDS_DEV_SWITCHES
+    if (std::getenv("PDS_GMID_VERBOSE")) std::fprintf(stderr, "grouped_mid_fused: waves %lld marked %u side %u\n", (long long)waves, h_counts[0], h_counts[1]);
+#endif
+    if (h_counts[0] > kMidMarkCap) return PDS_ERR_UNSUPPORTED;  // (every group will be answered by the record pipeline instead)
+    if (h_counts[1] > 0) {
+        const int64_t ns = h_counts[1];
+        if (int rc = launch_solve_wave<double>(ctx, rec_c, ns, sp, co_c, fl_c, rows_c, wave_ws)) return rc;
+        hipLaunchKernelGGL(mid_scatter_kernel<T>, dim3((unsigned)((ns * pp + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)co_c,
+                           (const uint8_t*)fl_c, (const int32_t*)list_c, ns, pp, d_coeffs, d_flags);
+    }
+    if (h_counts[0] > 0) {  // systems next to the gate: the reference's default factorisation (pivoted QR, log-det gate)
+        const int64_t nm = h_counts[0];
+        if (int rc = launch_solve_marked<double>(ctx, sa.mark_rec, nm, sp, co_c, fl_c, nullptr)) return rc;
+        hipLaunchKernelGGL(mid_scatter_kernel<T>, dim3((unsigned)((nm * pp + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)co_c,
+                           (const uint8_t*)fl_c, (const int32_t*)sa.mark_list, nm, pp, d_coeffs, d_flags);
+    }
+    PDS_HIP_CHECK(hipGetLastError());
+    return PDS_OK;
+}
+template int launch_grouped_mid_fused<double>(pds_ctx*, const DeviceCols<double>&, int, int64_t, const int64_t*, int64_t, const SolveParams&, double*, uint8_t*,
+                                              void*);
+template int launch_grouped_mid_fused<float>(pds_ctx*, const DeviceCols<float>&, int, int64_t, const int64_t*, int64_t, const SolveParams&, float*, uint8_t*,
+                                             void*);
+
+#ifdef PDS_PROFILE_MID
+extern "C" int pds_debug_mid_phase_cycles(unsigned long long* out, int reset) {
+    static const unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mid_phase), sizeof(z)) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_mid_phase), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
+
+}  // namespace pds

@@ -562,7 +562,7 @@ int launch_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_
 // v_mfma_f64_16x16x4_f64 (<= 15 accumulator tiles = 120 VGPRs), and the finished group writes its full symmetric
 // (p+2)^2 moment record.  Two-kernel pipeline (record -> solve_wave.hip's register solver): at these widths a group's record is as
 // large as its rows, so nothing is gained by fusing.  f64 frames with 28 .. 64 features take the streamed form instead
-// (moments_mid.hip, grouped_mid_stream_kernel); this kernel serves 17 .. 27 features and f32 frames.
+// (grouped_mid.hip, grouped_mid_stream_kernel); this kernel serves 17 .. 27 features and f32 frames.
 // ---------------------------------------------------------------------------------------------
 constexpr int kMidRows = 32;
 constexpr int kMidStride = 34;  // doubles per LDS column: 68 dwords = 4 mod 64 -> conflict-free b64 operand reads

@@ -1,5 +1,5 @@
 // solve_wave_dev.hpp -- ONE WAVE PER SYSTEM, the matrix in registers: the device-side core of solve_wave.hip, shared with the
-// fused grouped kernel of 17 .. 32 features (moments_mid.hip, which solves a finished group where its accumulators are).
+// fused grouped kernel of 17 .. 32 features (grouped_mid.hip, which solves a finished group where its accumulators are).
 //
 // lane j holds column j of the CENTRED p x p normal equations (a[i] = G_ij - s_i s_j / n, lambda already on the diagonal) and the
 // centred right-hand side in a[PPC]; step K broadcasts lane K's entries with v_readlane (compile-time lane: no LDS, no DPP row

@@ -1076,7 +1076,7 @@ def test_grouped_mid_width_f32(pds, orc, f32, p, bias):
 
 @pytest.mark.parametrize("p", [28, 40, 64])
 def test_grouped_stream_record_edges(pds, orc, p):
-    """The streamed Gram records of 28 .. 64 features (moments_mid.hip grouped_mid_stream_kernel): a group that spans many waves (its
+    """The streamed Gram records of 28 .. 64 features (grouped_mid.hip grouped_mid_stream_kernel): a group that spans many waves (its
     record is summed from partial records by atomics), groups that start / end inside a 4-row step, empty groups, one- and two-row
     groups, a last group that ends in a partial half-tile, and frames shorter than one half-tile -- coefficients and null flags
     against the oracle, group by group."""
@@ -1174,7 +1174,7 @@ def test_grouped_random_groups_at_the_gate(pds, orc, p, rows, bias):
 
 @pytest.mark.parametrize("p,bias,l2", [(17, True, 0.0), (22, False, 0.05), (28, True, 0.0), (32, False, 0.0)])
 def test_grouped_mid_fused_wave_boundaries(pds, orc, p, bias, l2):
-    """17 .. 32 f64 features, round 4: ONE stream, a finished group solved in the streaming wave (moments_mid.hip SPPC), no moment
+    """17 .. 32 f64 features, round 4: ONE stream, a finished group solved in the streaming wave (grouped_mid.hip), no moment
     records.  ~600 waves over this frame: groups cut by wave boundaries (side table + record solver), a group longer than many
     waves' ranges, empty and too-small groups, collinear / nearly collinear groups (marked -> pivoted QR).  Against the oracle."""
     rng = np.random.default_rng(5000 + p)

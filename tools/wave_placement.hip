@@ -1,5 +1,5 @@
 // Where do the waves of a 512-thread workgroup with the whole LDS of a CU land?  Prints (workgroup, wave in workgroup) -> XCC / SE / CU / SIMD
-// from HW_REG_HW_ID / HW_REG_XCC_ID.  The paired grouped stream (moments_mid.hip, PAIRED) relies on waves w and w + 4 sharing a SIMD.
+// from HW_REG_HW_ID / HW_REG_XCC_ID.  The paired grouped stream (grouped_mid.hip, PAIRED) relies on waves w and w + 4 sharing a SIMD.
 //   hipcc --offload-arch=gfx950 -O2 tools/wave_placement.hip -o /tmp/wave_placement && /tmp/wave_placement
 #include <hip/hip_runtime.h>
 #include <cstdio>
