@@ -1149,10 +1149,15 @@ int launch_grouped_mid_fused(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, 
         auto launch = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3((unsigned)waves), dim3(64), lds, ctx->stream, dc.d_ptrs, p, n_frame, d_off, n_groups, (double*)nullptr, debug, sa);
         };
+        bool paired_lds_ok = true;
         auto launch_paired = [&](auto kern) {
             constexpr int plds = 4 * kMidPairLds<2>;
-            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, plds);
-            (void)attr;
+            // (per call, not once per process: the attribute belongs to the function ON THE CURRENT DEVICE, and a process may drive several)
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, plds) != hipSuccess) {
+                (void)hipGetLastError();
+                paired_lds_ok = false;
+                return;
+            }
             hipLaunchKernelGGL(kern, dim3((unsigned)(waves / 4)), dim3(512), plds, ctx->stream, dc.d_ptrs, p, n_frame, d_off, n_groups, (double*)nullptr,
                                debug, sa);
         };
@@ -1171,6 +1176,7 @@ int launch_grouped_mid_fused(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, 
             if (p <= 24) launch(grouped_mid_stream_kernel<2, 24>);
             else launch(grouped_mid_stream_kernel<2, 32>);
         }
+        if (!paired_lds_ok) return PDS_ERR_UNSUPPORTED;  // (a device that does not grant a workgroup the whole LDS: the record pipeline)
         PDS_HIP_CHECK(hipGetLastError());
     }
     // the groups cut by wave boundaries: compacted, then the record solver
