@@ -102,7 +102,15 @@ constexpr int kMidPairLds = MidDims<NBLK>::LDS_BYTES + kMidSolveScratch + 64;  /
 template <int NBLK, int SPPC = 0, bool PAIRED = false, bool YC = false, int NQ = 0, typename T = double>
 __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(const T* const* __restrict__ cols, int p, int64_t n_frame,
                                                                 const int64_t* __restrict__ off, int64_t n_groups,
-                                                                double* __restrict__ records, int debug, MidSolveArgsT<T> sa) {
+                                                                double* __restrict__ records, int debug_arg, MidSolveArgsT<T> sa) {
+    // the timing switches (PDS_GMID_DEBUG) exist in development builds only: as a run-time value `debug & 8` put a scalar branch around
+    // every matrix instruction but the first of a step and copies of the accumulators behind the unrolled half-tile loop
+#ifdef PDS_DEV_SWITCHES
+    const int debug = debug_arg;
+#else
+    constexpr int debug = 0;
+    (void)debug_arg;
+#endif
     constexpr int ES = (int)sizeof(T), EPL = 16 / ES;  // element bytes; elements per 16-byte lane piece
     static_assert(ES == 8 || PAIRED, "f32 frames: the paired form");
     static_assert(SPPC == 0 || NBLK == 2, "the in-wave solve serves two tile columns");
