@@ -66,7 +66,7 @@ def main() -> int:
     ap.add_argument("--rows-per-group", type=int, default=100)
     ap.add_argument("--feats", type=int, default=16)
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
-    ap.add_argument("--gather-chunks", type=int, default=2, help="pieces per rank: results of a piece travel while the next is computed")
+    ap.add_argument("--gather-chunks", type=int, default=0, help="pieces per rank: results of a piece travel while the next is computed (0: parallel.auto_chunks)")
     ap.add_argument("--cpu-sample-groups", type=int, default=400_000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip end_to_end / grouped_c3spec / scatter (A/B runs)")
@@ -111,12 +111,8 @@ def main() -> int:
     off_host = np.arange(0, N + 1, R, dtype=np.int64)
     torch.cuda.synchronize(dev)
     gather = use_dist and strong
-    chunks = max(1, args.gather_chunks) if gather and world > 1 else 1
 
-    def grouped_fn(xs_c, y_c, off_c, **kw):
-        return pds.lin_reg_by(*xs_c, target=y_c, group_offsets=off_c, add_bias=False, ctx=ctx)
-
-    class _Off:  # device offsets for the kernels, host offsets for the piece bounds (no device read-back inside the step)
+    class _Off:  # device offsets for the kernels, host offsets for the piece bounds (no device read-back when the plan is built)
         def __init__(self, d, h):
             self.d, self.h = d, h
 
@@ -127,10 +123,14 @@ def main() -> int:
             return self.d[s]
 
     off_pair = _Off(offsets, torch.from_numpy(off_host))
+    # N-rank step: the prepared plan (persistent result buffers, the root's shard fitted in place, one grouped send per piece)
+    plan = par.GroupedShardPlan(xs, y, off_pair, parts, rank=rank, gather_to=0, chunks=args.gather_chunks or None, ctx=ctx,
+                                add_bias=False) if gather else None
+    chunks = plan.chunks if plan else 1
 
     def step():
         if gather:
-            res = par.lin_reg_by_group_local_shard(xs, y, off_pair, parts, rank=rank, gather_to=0, chunks=chunks, grouped_fn=grouped_fn)
+            res = plan.step()
             return (res[2], res[3]) if rank == 0 else (res[0], res[1])
         return pds.lin_reg_by(*xs, target=y, group_offsets=offsets, add_bias=False, ctx=ctx)
 
@@ -211,6 +211,16 @@ def main() -> int:
         #  the achievable read stream of this box is `read_stream_GBps` below, the single-OLS Gram kernel on the same frame)
         roofline["measured_copy_GBps"] = round(copy_gbps, 1)
         del a, b
+
+    # ---- fixed cost of the N-rank step, measured on this one GPU: the same frame through GroupedShardPlan over an RCCL process
+    # group of world size 1 (no peer: what is left is everything a step does beside its kernel -- Python, the prepared C call, the
+    # stream bookkeeping) against the plain call timed above.  At N ranks the kernel shrinks by N, this does not.
+    dist_overhead = None
+    if rank == 0 and world == 1:
+        try:
+            dist_overhead = _dist_step_overhead(torch, par, pds, ctx, dev, xs, y, off_pair, offsets, args, ms_per_step, use_dist)
+        except Exception as e:
+            dist_overhead = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- config 2 on the same frame: single OLS Gram build (pds_moments), HBM GB/s
     gram = None
@@ -309,13 +319,70 @@ def main() -> int:
                        "groups_total": G_total, "groups_per_gpu": G, "rows_per_group": R, "features": P,
                        "parallelism": f"group-sharded x{world}", "gather_chunks": chunks if gather else None},
             "roofline": roofline, "gram_build": gram, "grouped_p8": p8, "cpu_baseline": cpu, "parity_spot_check": parity,
-            "end_to_end": end_to_end, "other_configs": other, "grouped_c3spec": c3, "scatter": scatter,
+            "dist_step": dist_overhead, "end_to_end": end_to_end, "other_configs": other, "grouped_c3spec": c3, "scatter": scatter,
         }
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     return 0
+
+
+def _dist_step_overhead(torch, par, pds, ctx, dev, xs, y, off_pair, offsets, args, plain_ms, have_pg):
+    """World-1 RCCL process group + GroupedShardPlan (gather_to = 0) on the headline shard: wall per step beside the plain call's."""
+    import socket
+
+    import torch.distributed as dist
+
+    made = False
+    if not have_pg:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
+        made = True
+    try:
+        G = len(off_pair.h) - 1
+        plan = par.GroupedShardPlan(xs, y, off_pair, [(0, G)], rank=0, gather_to=0, ctx=ctx, add_bias=False)
+
+        def timed(fn, steps):
+            for _ in range(args.warmup):
+                fn()
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            return 1e3 * (time.perf_counter() - t0) / steps
+
+        steps = max(args.steps, 10)
+        # interleaved repeats: (plan, plain) pairs on the same box state; the medians are compared
+        pl, pn = [], []
+        for _ in range(3):
+            pl.append(timed(plan.step, steps))
+            pn.append(timed(lambda: pds.lin_reg_by(*xs, target=y, group_offsets=offsets, add_bias=False, ctx=ctx), steps))
+        pl_ms, pn_ms = sorted(pl)[1], sorted(pn)[1]
+        ctx.get_timing(reset=True)
+        ctx.set_timing(True)
+        for _ in range(steps):
+            plan.step()
+        ctx.set_timing(False)
+        k_ms, k_cnt = ctx.get_timing(reset=True)["grouped_moments"]
+        k_ms = k_ms / max(k_cnt, 1)
+        return {"what": "GroupedShardPlan.step over an RCCL group of world size 1 (gather_to = 0, no peer) on the headline shard, beside the "
+                        "plain lin_reg_by call; barrier + synchronize on both sides, median of 3 interleaved repeats",
+                "plan_step_ms": round(pl_ms, 4), "plain_call_ms": round(pn_ms, 4), "kernel_ms": round(k_ms, 4),
+                "dist_step_overhead_us": round(1e3 * (pl_ms - pn_ms), 1),
+                "step_minus_kernel_us": round(1e3 * (pl_ms - k_ms), 1), "plain_minus_kernel_us": round(1e3 * (pn_ms - k_ms), 1),
+                "chunks": plan.chunks}
+    finally:
+        if made:
+            dist.destroy_process_group()
 
 
 def _cpu_baseline(np, args, xs, y, coeffs, nulls, G, R, P):

@@ -619,6 +619,61 @@ def lin_reg_by(*x, target, group_offsets, add_bias: bool = False, l1_reg: float 
     return coeffs, nulls
 
 
+class GroupedFit:
+    """
+    A prepared `lin_reg_by` over DEVICE-resident columns with contiguous groups: the column pointer table, the parameter block, the
+    device offsets and the result buffers are set up once; `run()` is then one C call (`pds_lr_grouped_*`) and nothing else -- no
+    allocation, no dtype / contiguity checks, no Python per column.  What a host engine that evaluates the same expression over a
+    resident frame repeatedly (or one rank of the group-sharded step, parallel.GroupedShardPlan) holds on to.
+
+    `out` / `out_null`: where the coefficients ([n_groups, p'] of the config dtype, contiguous) and the null flags ([n_groups] uint8)
+    go -- e.g. rows of a larger gathered result, so that the fit writes them in place.  By default they are allocated here, once.
+    Every `run()` recomputes and overwrites them; it returns the same two tensors.
+    """
+
+    def __init__(self, *x, target, group_offsets, add_bias: bool = False, l1_reg: float = 0.0, l2_reg: float = 0.0, tol: float = 1e-5,
+                 solver: str = "qr", max_iter: int = 200, positive: bool = False, singular_x_tol: float | None = None, out=None,
+                 out_null=None, ctx: Context | None = None):
+        if max_iter <= 0:
+            raise ValueError("Input `max_iter` must be a positive.")  # expr_linear.py:231-232
+        import torch
+
+        self.ctx = ctx or default_context()
+        cols = _Cols(target, x)
+        if cols.space != _lib.PDS_DEVICE:
+            raise ValueError("GroupedFit prepares device-resident frames (host frames: lin_reg_by)")
+        self._cols = cols
+        self._prm = _params(add_bias, l1_reg, l2_reg, tol, solver, positive, max_iter, singular_x_tol)
+        self._off, off_p = _offsets_arg(cols, group_offsets)
+        ng = int(self._off.shape[0]) - 1
+        pp = cols.n_feat + int(bool(add_bias))
+        tdt = torch.float64 if config.LIN_REG_EXPR_F64 else torch.float32
+        dev = cols.keep[0].device
+        if out is None:
+            out = torch.empty((ng, pp), dtype=tdt, device=dev)
+        if out_null is None:
+            out_null = torch.empty((ng,), dtype=torch.uint8, device=dev)
+        if tuple(out.shape) != (ng, pp) or out.dtype != tdt or out.device != dev or not out.is_contiguous():
+            raise ValueError(f"`out` must be a contiguous [{ng}, {pp}] {tdt} tensor on {dev}")
+        if tuple(out_null.shape) != (ng,) or out_null.dtype != torch.uint8 or out_null.device != dev or not out_null.is_contiguous():
+            raise ValueError(f"`out_null` must be a contiguous [{ng}] uint8 tensor on {dev}")
+        self.coeffs, self.is_null = out, out_null
+        self.n_groups = ng
+        self._fn = self.ctx.fn("pds_lr_grouped")
+        self._args = (self.ctx._h, cols.cols, cols.n_feat, C.c_int64(cols.n_rows), off_p, C.c_int64(ng), cols.space, C.byref(self._prm),
+                      C.c_void_p(int(out.data_ptr())), C.c_void_p(int(out_null.data_ptr())))
+        self._dev = cols.torch_device
+
+    def run(self):
+        if self.n_groups <= 0:
+            return self.coeffs, self.is_null
+        self.ctx.follow_torch_stream(self._dev)
+        rc = self._fn(*self._args)
+        if rc:
+            _lib.check(rc)
+        return self.coeffs, self.is_null
+
+
 def lin_reg_by_key(*x, target, key, add_bias: bool = False, l1_reg: float = 0.0, l2_reg: float = 0.0, tol: float = 1e-5,
                    solver: str = "qr", max_iter: int = 200, positive: bool = False, singular_x_tol: float | None = None,
                    max_groups: int | None = None, ctx: Context | None = None):

@@ -110,91 +110,155 @@ def chunk_bounds(n_groups: int, chunks: int) -> list[tuple[int, int]]:
     return [shard_bounds(n_groups, chunks, c) for c in range(chunks)]
 
 
-def lin_reg_by_group_local_shard(xs_loc, y_loc, loc_off, parts, *, rank: int, gather_to: int | None = 0, chunks: int = 1,
-                                 grouped_fn: Callable | None = None, group=None, result_dtype=None, **lin_reg_kwargs):
+def auto_chunks(world: int, result_bytes_per_peer: int, shard_input_bytes: int, *, link_GBps: float = 45.0,
+                stream_GBps: float = 5500.0, launch_us: float = 25.0) -> int:
+    """
+    How many pieces a rank's shard is fitted in so that a finished piece's results travel while the next piece is computed.
+    With kernel time T_k = shard bytes / stream rate and transfer time T_x = result bytes / link rate (one xGMI link per peer into
+    the gathering rank), a c-piece pipeline takes max(T_k, T_x) + min(T_k, T_x) / c + c * (one more launch of each): the minimum is at
+    c = sqrt(min(T_k, T_x) / launch).  1e6 groups x 100 rows x 16 f64 features over 8 ranks: T_k = 0.31 ms, T_x = 0.36 ms -> 4 pieces;
+    a world of one has nothing to overlap -> 1.  The rates are defaults for the model, not measurements of the run.
+    """
+    if world <= 1 or result_bytes_per_peer <= 0 or shard_input_bytes <= 0:
+        return 1
+    t_x = result_bytes_per_peer / (link_GBps * 1e9)
+    t_k = shard_input_bytes / (stream_GBps * 1e9)
+    return int(max(1, min(8, round((min(t_x, t_k) / (launch_us * 1e-6)) ** 0.5))))
+
+
+class GroupedShardPlan:
     """
     The compute + gather leg of the group-sharded regression on a rank that already HOLDS its shard (rows of groups
-    parts[rank] = [g_lo, g_hi), `loc_off` rebased to the shard).  The shard is fitted in `chunks` pieces; a peer hands every
-    finished piece to the gathering rank at once (isend on RCCL's stream while the next piece is being computed), the
-    gathering rank posts all receives up front, straight into the rows of the assembled result -- no staging copy, and every
-    peer's traffic rides its own xGMI link into the root (results are n_groups x p' values + one flag byte per group:
-    16 MB per peer at 1e6 groups x 16 features on 8 GPUs).
-    Returns (coeffs_local, is_null_local) and, on the gathering rank, additionally the assembled (coeffs, is_null).
-    The dtype of the coefficients on the wire is `result_dtype`; by default what the library's grouped fit returns (the config
-    dtype: float64 under LIN_REG_EXPR_F64, whatever the inputs are) or, with an injected `grouped_fn`, the targets' dtype --
-    every rank casts to it before sending, so the receive buffers of the gathering rank always match the sends.
+    parts[rank] = [g_lo, g_hi), `loc_off` rebased to the shard), prepared ONCE and then run step after step with nothing but the
+    launches in a step:
+
+      * the result buffers are persistent: the gathering rank owns the assembled [n_groups, p'] coefficients + [n_groups] null flags,
+        its own shard is fitted IN PLACE into rows [g_lo, g_hi) of them (the kernel gets that address: no copy), and its local
+        results are views of those rows; a peer owns its shard's results;
+      * the shard is fitted in `chunks` pieces (default: auto_chunks); with the library's own fit every piece is a prepared call
+        (lstsq.GroupedFit: pointer table, offsets, parameters set up here) -- one C call per piece and step;
+      * a peer hands every finished piece to the gathering rank as ONE grouped point-to-point launch (coefficients + flags) on
+        RCCL's stream while its next piece is computed; the gathering rank posts, before its own fit, one grouped receive per piece
+        index straight into the rows of the assembled result -- every peer's traffic rides its own xGMI link, no staging copy.
+
+    `step()` returns (coeffs_local, is_null_local) and, on the gathering rank, additionally (coeffs, is_null) of all groups: views of
+    the persistent buffers, valid until the next step().  The dtype on the wire is `result_dtype`; by default what the library's
+    grouped fit returns (the config dtype) or, with an injected `grouped_fn`, the targets' dtype.
     """
-    import torch
 
-    dist = _dist()
-    default_fn = grouped_fn is None
-    grouped_fn = grouped_fn or _hip_grouped_out
-    world = len(parts)
-    g_lo, g_hi = parts[rank]
-    ng = g_hi - g_lo
-    pp = len(xs_loc) + int(bool(lin_reg_kwargs.get("add_bias", False)))
-    is_t = isinstance(y_loc, torch.Tensor)  # (NumPy 2 arrays have a .device too)
-    dev = y_loc.device if is_t else torch.device("cpu")
-    if result_dtype is not None:
-        cdt = result_dtype
-    elif default_fn:
-        from . import lstsq
+    def __init__(self, xs_loc, y_loc, loc_off, parts, *, rank: int, gather_to: int | None = 0, chunks: int | None = None,
+                 grouped_fn: Callable | None = None, group=None, result_dtype=None, ctx=None, **lin_reg_kwargs):
+        import torch
 
-        cdt = torch.float64 if lstsq._dtype() == np.float64 else torch.float32
-    else:
-        cdt = y_loc.dtype if is_t else torch.from_numpy(np.asarray(y_loc)[:0]).dtype
-    off = loc_off
-    off_h = np.asarray(loc_off.cpu() if hasattr(loc_off, "cpu") else loc_off, dtype=np.int64)  # (row bounds of the pieces: host)
-    root = gather_to
-    co_all = nu_all = None
-    reqs = []
-    if root is not None and rank == root:
-        total = parts[-1][1]
-        co_all = torch.empty((total, pp), dtype=cdt, device=dev)
-        nu_all = torch.empty((total,), dtype=torch.uint8, device=dev)
-        ops = []
-        for r in range(world):
-            if r == rank:
-                continue
-            for c_lo, c_hi in chunk_bounds(parts[r][1] - parts[r][0], chunks):
-                if c_hi > c_lo:
-                    lo, hi = parts[r][0] + c_lo, parts[r][0] + c_hi
-                    ops.append(dist.P2POp(dist.irecv, co_all[lo:hi], r, group))
-                    ops.append(dist.P2POp(dist.irecv, nu_all[lo:hi], r, group))
-        if ops:
-            reqs = dist.batch_isend_irecv(ops)
-    keep = []
-    co_parts, nu_parts = [], []
-    for c_lo, c_hi in chunk_bounds(ng, chunks) if ng > 0 else []:
-        if c_hi <= c_lo:
-            continue
-        r0, r1 = int(off_h[c_lo]), int(off_h[c_hi])
-        sub_off = off[c_lo: c_hi + 1] - r0
-        co, nu = grouped_fn([x[r0:r1] for x in xs_loc], y_loc[r0:r1], sub_off, **lin_reg_kwargs)
-        co = co if isinstance(co, torch.Tensor) else torch.as_tensor(np.asarray(co))
-        nu = (nu if isinstance(nu, torch.Tensor) else torch.as_tensor(np.asarray(nu))).to(torch.uint8)
-        if co.dtype != cdt or co.device != dev:
-            co = co.to(device=dev, dtype=cdt)  # (wire dtype / device: see the docstring)
-        nu = nu.to(dev)
-        co_parts.append(co)
-        nu_parts.append(nu)
-        if root is None:
-            continue
-        if rank == root:
-            co_all[g_lo + c_lo: g_lo + c_hi].copy_(co)
-            nu_all[g_lo + c_lo: g_lo + c_hi].copy_(nu)
+        self._dist = dist = _dist()
+        self.rank, self.parts, self.root, self.group = rank, parts, gather_to, group
+        world = len(parts)
+        g_lo, g_hi = parts[rank]
+        ng = g_hi - g_lo
+        pp = len(xs_loc) + int(bool(lin_reg_kwargs.get("add_bias", False)))
+        is_t = isinstance(y_loc, torch.Tensor)  # (NumPy 2 arrays have a .device too)
+        dev = y_loc.device if is_t else torch.device("cpu")
+        default_fn = grouped_fn is None
+        if result_dtype is not None:
+            cdt = result_dtype
+        elif default_fn:
+            from . import lstsq
+
+            cdt = torch.float64 if lstsq._dtype() == np.float64 else torch.float32
         else:
-            co, nu = co.contiguous(), nu.contiguous()
-            keep += [co, nu]
-            reqs.append(dist.isend(co, dst=root, group=group))
-            reqs.append(dist.isend(nu, dst=root, group=group))
-    for q in reqs:
-        q.wait()
-    co_loc = torch.cat(co_parts, 0) if co_parts else torch.empty((0, pp), dtype=cdt, device=dev)
-    nu_loc = torch.cat(nu_parts, 0) if nu_parts else torch.empty((0,), dtype=torch.uint8, device=dev)
-    if root is not None and rank == root:
-        return co_loc, nu_loc, co_all, nu_all
-    return co_loc, nu_loc
+            cdt = y_loc.dtype if is_t else torch.from_numpy(np.asarray(y_loc)[:0]).dtype
+        off_h = np.asarray(loc_off.cpu() if hasattr(loc_off, "cpu") else loc_off, dtype=np.int64)  # (row bounds of the pieces: host)
+        is_root = gather_to is not None and rank == gather_to
+        total = parts[-1][1]
+        if chunks is None:
+            esz = torch.empty((), dtype=cdt).element_size()
+            in_sz = y_loc.element_size() if is_t else np.asarray(y_loc).dtype.itemsize
+            peers = [hi - lo for r, (lo, hi) in enumerate(parts) if r != gather_to]
+            chunks = auto_chunks(world if gather_to is not None else 1, max(peers, default=0) * (pp * esz + 1),
+                                 int(off_h[-1] - off_h[0]) * (len(xs_loc) + 1) * in_sz)
+        self.chunks = chunks = max(1, int(chunks))
+        # ---- persistent results
+        if is_root:
+            self.co_all = torch.empty((total, pp), dtype=cdt, device=dev)
+            self.nu_all = torch.empty((total,), dtype=torch.uint8, device=dev)
+            self.co_loc, self.nu_loc = self.co_all[g_lo:g_hi], self.nu_all[g_lo:g_hi]
+        else:
+            self.co_all = self.nu_all = None
+            self.co_loc = torch.empty((ng, pp), dtype=cdt, device=dev)
+            self.nu_loc = torch.empty((ng,), dtype=torch.uint8, device=dev)
+        # ---- the receives of the gathering rank: one grouped launch per piece index (what the peers send, in the order they send it)
+        self._recv_batches = []
+        if is_root:
+            per_peer = {r: [b for b in chunk_bounds(parts[r][1] - parts[r][0], chunks) if b[1] > b[0]] for r in range(world) if r != rank}
+            for c in range(chunks):
+                ops = []
+                for r, bl in per_peer.items():
+                    if c < len(bl):
+                        lo, hi = parts[r][0] + bl[c][0], parts[r][0] + bl[c][1]
+                        ops.append(dist.P2POp(dist.irecv, self.co_all[lo:hi], r, group))
+                        ops.append(dist.P2POp(dist.irecv, self.nu_all[lo:hi], r, group))
+                if ops:
+                    self._recv_batches.append(ops)
+        # ---- this rank's pieces: a prepared fit (or the injected function + a copy into place) and, on a peer, its send
+        self._runs, self._send_batches = [], []
+        use_prepared = False
+        if default_fn and is_t and y_loc.is_cuda:  # (the wire dtype is the library's result dtype: the fit writes into place)
+            from . import lstsq
+
+            use_prepared = cdt == (torch.float64 if lstsq._dtype() == np.float64 else torch.float32)
+        for c_lo, c_hi in (b for b in chunk_bounds(ng, chunks) if ng > 0 and b[1] > b[0]):
+            r0, r1 = int(off_h[c_lo]), int(off_h[c_hi])
+            co_v, nu_v = self.co_loc[c_lo:c_hi], self.nu_loc[c_lo:c_hi]
+            xs_p, y_p = [x[r0:r1] for x in xs_loc], y_loc[r0:r1]
+            sub_off = loc_off[c_lo: c_hi + 1] - r0
+            if use_prepared:
+                fit = lstsq.GroupedFit(*xs_p, target=y_p, group_offsets=sub_off, out=co_v, out_null=nu_v, ctx=ctx, **lin_reg_kwargs)
+                self._runs.append(fit.run)
+            else:
+                self._runs.append(self._injected(grouped_fn or _hip_grouped_out, xs_p, y_p, sub_off, co_v, nu_v, lin_reg_kwargs))
+            if gather_to is not None and not is_root:
+                self._send_batches.append([dist.P2POp(dist.isend, co_v, gather_to, group), dist.P2POp(dist.isend, nu_v, gather_to, group)])
+
+    @staticmethod
+    def _injected(fn, xs_p, y_p, sub_off, co_v, nu_v, kw):
+        import torch
+
+        def run():
+            co, nu = fn(xs_p, y_p, sub_off, **kw)
+            co = co if isinstance(co, torch.Tensor) else torch.as_tensor(np.asarray(co))
+            nu = nu if isinstance(nu, torch.Tensor) else torch.as_tensor(np.asarray(nu))
+            co_v.copy_(co)  # (casts to the wire dtype / moves to the result's device)
+            nu_v.copy_(nu)
+
+        return run
+
+    def step(self):
+        batch = self._dist.batch_isend_irecv
+        reqs = []
+        for ops in self._recv_batches:
+            reqs += batch(ops)
+        if self._send_batches:
+            for run, ops in zip(self._runs, self._send_batches):
+                run()
+                reqs += batch(ops)
+        else:
+            for run in self._runs:
+                run()
+        for q in reqs:
+            q.wait()
+        if self.co_all is not None:
+            return self.co_loc, self.nu_loc, self.co_all, self.nu_all
+        return self.co_loc, self.nu_loc
+
+
+def lin_reg_by_group_local_shard(xs_loc, y_loc, loc_off, parts, *, rank: int, gather_to: int | None = 0, chunks: int | None = 1,
+                                 grouped_fn: Callable | None = None, group=None, result_dtype=None, **lin_reg_kwargs):
+    """
+    One step of a GroupedShardPlan built for this call (a caller that repeats the step keeps the plan instead).
+    Returns (coeffs_local, is_null_local) and, on the gathering rank, additionally the assembled (coeffs, is_null).
+    """
+    return GroupedShardPlan(xs_loc, y_loc, loc_off, parts, rank=rank, gather_to=gather_to, chunks=chunks, grouped_fn=grouped_fn,
+                            group=group, result_dtype=result_dtype, **lin_reg_kwargs).step()
 
 
 def scatter_frame_by_groups(xs, y, group_offsets, *, root: int = 0, group=None, device=None):

@@ -80,6 +80,38 @@ def _worker(rank, world, port, q):
 
         res = par.lin_reg_by_group_local_shard(xs_l, y_l, off_l, parts, rank=rank, gather_to=1, chunks=3, grouped_fn=grouped_fn_t,
                                                add_bias=True)
+        # ---- the prepared plan of the same leg: persistent result buffers, the gathering rank's shard fitted in place, one grouped
+        #      send per piece; two steps give the same (views of the same) results; then the orchestration alone is timed with a
+        #      compute step that does nothing (what a step costs beside the kernels: Python + the point-to-point launches)
+        plan = par.GroupedShardPlan(xs_l, y_l, off_l, parts, rank=rank, gather_to=1, chunks=3, grouped_fn=grouped_fn_t, add_bias=True)
+        st1 = plan.step()
+        first = [t.clone() for t in st1]
+        st2 = plan.step()
+        plan_ok = bool(all(a.data_ptr() == b.data_ptr() for a, b in zip(st1, st2)) and
+                       all(torch.equal(a, b) for a, b in zip(first, st2)) and
+                       all(torch.equal(a, b) for a, b in zip(first, res)))
+        if rank == 1:  # in place: the gathering rank's local results ARE rows of the assembled result
+            lo_g = parts[1][0]
+            plan_ok = plan_ok and st2[0].data_ptr() == st2[2][lo_g:].data_ptr() and st2[1].data_ptr() == st2[3][lo_g:].data_ptr()
+        pp_n = p + 1
+
+        def noop_fn(xs, yy, loc_off, add_bias=False, **kw):
+            k = len(loc_off) - 1
+            return torch.zeros((k, pp_n), dtype=torch.float64), torch.zeros(k, dtype=torch.uint8)
+
+        import time as _time
+
+        lean = par.GroupedShardPlan(xs_l, y_l, off_l, parts, rank=rank, gather_to=1, chunks=1, grouped_fn=noop_fn, add_bias=True)
+        for _ in range(5):
+            lean.step()
+        dist.barrier()
+        ts = []
+        for _ in range(30):
+            t0 = _time.perf_counter()
+            lean.step()
+            ts.append(_time.perf_counter() - t0)
+        plan_step_ms = 1e3 * sorted(ts)[len(ts) // 2]
+        auto_c = par.GroupedShardPlan(xs_l, y_l, off_l, parts, rank=rank, gather_to=1, grouped_fn=noop_fn, add_bias=True).chunks
         sc_rows_ok = bool(int(off_l[-1]) == len(y_l) and int(off_l[0]) == 0 and
                           np.array_equal(np.asarray(y_l), y[int(off[parts[rank][0]]): int(off[parts[rank][1]])]))
         # ---- lin_reg_report, row-sharded: two all-reduces (moment block; [sum e^2 | sum w e^2 | meat])
@@ -185,7 +217,8 @@ def _worker(rank, world, port, q):
         rec_valid_ok = bool(np.all(eva[first - e_lo :] == 1) and np.all(eva[: first - e_lo] == 0))
         out = {"rank": rank, "err_rows": err_rows, "range": (g_lo, g_hi), "err_roll": err_roll, "roll_valid_ok": roll_valid_ok,
                "err_rec": err_rec, "rec_valid_ok": rec_valid_ok, "sc_rows_ok": sc_rows_ok, "rep_err": rep_err,
-               "sc_local_groups": int(res[0].shape[0]), "parts": parts}
+               "sc_local_groups": int(res[0].shape[0]), "parts": parts, "plan_ok": plan_ok, "plan_step_ms": plan_step_ms,
+               "auto_chunks_small": auto_c}
         if rank == 1:
             ref_co_b, ref_nu_b = orc.grouped_lr([y[:n_used]] + [X[:n_used, j] for j in range(p)], off, add_bias=True)
             out["sc_gathered"] = tuple(res[2].shape)
@@ -215,6 +248,10 @@ def test_shard_helpers():
     assert parts[0][0] == 0 and parts[-1][1] == 1000 and all(parts[i][1] == parts[i + 1][0] for i in range(7))
     rows = [off[h] - off[l] for l, h in parts]
     assert max(rows) - min(rows) < 2 * 500  # balanced in rows up to one group
+    # pieces per shard: the headline frame over 8 ranks pipelines in 4 pieces, a world of one (or tiny results) in one
+    assert par.auto_chunks(8, 125_000 * (16 * 8 + 1), 12_500_000 * 17 * 8) == 4
+    assert par.auto_chunks(1, 10**9, 10**10) == 1 and par.auto_chunks(8, 4096, 10**6) == 1
+    assert par.chunk_bounds(10, 3) == [(0, 4), (4, 7), (7, 10)] and par.chunk_bounds(0, 4) == [(0, 0)]
 
 
 @pytest.mark.timeout(300)
@@ -244,6 +281,11 @@ def test_world2_gloo():
     parts = outs[0]["parts"]
     assert [o["sc_local_groups"] for o in outs] == [hi - lo for lo, hi in parts]
     assert outs[1]["sc_gathered"][0] == outs[0]["groups"] and outs[1]["sc_err"] < 1e-12 and outs[1]["sc_null_equal"]
+    # the prepared plan: same results step after step out of the same buffers, in place on the gathering rank; its orchestration
+    # (no compute) stays far below a millisecond even over gloo / TCP loopback (RCCL world 1 on the GPU: bench.py dist_step_overhead_us)
+    assert all(o["plan_ok"] for o in outs)
+    assert all(o["plan_step_ms"] < 5.0 for o in outs), [o["plan_step_ms"] for o in outs]
+    assert all(o["auto_chunks_small"] == 1 for o in outs)  # a few KB of results: nothing to overlap
     # row-sharded report == the single-frame report (both all-reduces), on every rank
     for o in outs:
         for kind, (e_se, e_beta, e_r2) in o["rep_err"].items():

@@ -69,6 +69,23 @@ def test_sharded_paths_on_rccl(world1):
     # (pieces start at other rows than the frame, so a group's rows meet the kernel's 128-row tiles differently: same sums in
     #  another order -- equal to rounding, not bitwise)
     assert parts == [(0, len(off) - 1)] and torch.allclose(co_g, ref_co, rtol=1e-12, atol=1e-14, equal_nan=True) and torch.equal(nu_g, ref_nu)
+    # the prepared plan (what bench.py's N-rank step runs): the library's fit as prepared calls writing IN PLACE into the rows of the
+    # persistent assembled result; step after step the same buffers, the same values
+    plan = par.GroupedShardPlan(xs_l, y_l, off_l, parts, rank=0, gather_to=0, chunks=3, add_bias=False)
+    s1 = plan.step()
+    keep = [t.clone() for t in s1]
+    s1[2].zero_()
+    s2 = plan.step()
+    assert all(a.data_ptr() == b.data_ptr() for a, b in zip(s1, s2)) and s2[0].data_ptr() == s2[2].data_ptr()
+    assert all(torch.equal(a, b) for a, b in zip(keep, s2))
+    assert torch.allclose(s2[2], ref_co, rtol=1e-12, atol=1e-14, equal_nan=True) and torch.equal(s2[3], ref_nu)
+    one = par.GroupedShardPlan(xs_l, y_l, off_l, parts, rank=0, gather_to=0, add_bias=False)  # (auto: one piece at world 1)
+    assert one.chunks == 1 and torch.equal(one.step()[2], ref_co)
+    fit = pds.GroupedFit(*xs, target=yt, group_offsets=off)
+    co_f, nu_f = fit.run()
+    assert torch.equal(co_f, ref_co) and torch.equal(nu_f, ref_nu) and fit.run()[0].data_ptr() == co_f.data_ptr()
+    with pytest.raises(ValueError):
+        pds.GroupedFit(*xs, target=yt, group_offsets=off, out=torch.empty((3, p), dtype=torch.float64, device="cuda"))
     # row-sharded report: moments -> all-reduce -> fit -> residual pass -> all-reduce -> epilogue == the single-frame report
     for kind in ("se", "hc0", "hc1", "hc2", "hc3"):
         rs = par.lin_reg_report_row_sharded(xs, yt, add_bias=True, std_err=kind)
