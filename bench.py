@@ -265,6 +265,15 @@ def main() -> int:
               "ms_per_step": round(t8 * 1e3, 4), "kernel_ms": round(k8, 4), "algorithmic_GBps": round(b8 / (k8 * 1e-3) / 1e9, 1),
               "frac_of_hbm_peak": round(b8 / (k8 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
 
+    # ---- the same step from the KEY COLUMN (sorted int64 keys, what group_by(key) starts from) instead of precomputed offsets: one pass
+    # over the keys (order check + run marks), a scan and a pass over the marks in front of the same fused kernel
+    by_key = None
+    if rank == 0:
+        try:
+            by_key = _by_key(torch, pds, ctx, dev, xs, y, offsets, G, R, P)
+        except Exception as e:
+            by_key = {"error": f"{type(e).__name__}: {e}"}
+
     # ---- CPU baseline + parity spot check on a bounded sample (rank 0, N = 1 only)
     cpu = None
     parity = None
@@ -314,11 +323,13 @@ def main() -> int:
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"group_by(key).agg(lin_reg): {args.groups} groups x {R} rows x {P} f64 feats {per} "
-                                   f"({args.groups * R:.0e} rows), OLS with rank gate (pl_lr default path), inputs resident in HBM"
+                                   f"({args.groups * R:.0e} rows), OLS with rank gate (pl_lr default path), inputs resident in HBM; `value`: the groups "
+                                   f"given as row offsets (pre-segmented, as Polars hands groups to pl_lr -- the cpu_baseline gets the same); "
+                                   f"the same step starting from a sorted int64 key column: grouped_by_key"
                                    + (", coefficients + null flags gathered to rank 0 inside the timed region" if gather else ""),
                        "groups_total": G_total, "groups_per_gpu": G, "rows_per_group": R, "features": P,
                        "parallelism": f"group-sharded x{world}", "gather_chunks": chunks if gather else None},
-            "roofline": roofline, "gram_build": gram, "grouped_p8": p8, "cpu_baseline": cpu, "parity_spot_check": parity,
+            "roofline": roofline, "gram_build": gram, "grouped_p8": p8, "grouped_by_key": by_key, "cpu_baseline": cpu, "parity_spot_check": parity,
             "dist_step": dist_overhead, "end_to_end": end_to_end, "other_configs": other, "grouped_c3spec": c3, "scatter": scatter,
         }
         print(json.dumps(line), flush=True)
@@ -326,6 +337,35 @@ def main() -> int:
         dist.barrier()
         dist.destroy_process_group()
     return 0
+
+
+def _by_key(torch, pds, ctx, dev, xs, y, offsets, G, R, P):
+    """lin_reg_by_key on sorted int64 keys against lin_reg_by on the offsets of the same groups, p = P and p = 8: wall ms (median of 7)."""
+    keys = torch.arange(G, dtype=torch.int64, device=dev).repeat_interleave(R)
+    out = {"workload": f"{G} groups x {R} rows, sorted int64 key column resident in HBM (0.8 GB per 1e8 rows) instead of group offsets"}
+
+    def wall(fn, reps=7):
+        fn()
+        ts = []
+        for _ in range(reps):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize(dev)
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)[len(ts) // 2]
+
+    for q in sorted({P, 8}, reverse=True):
+        if q > P:
+            continue
+        t_off = wall(lambda: pds.lin_reg_by(*xs[:q], target=y, group_offsets=offsets, add_bias=False, ctx=ctx))
+        t_key = wall(lambda: pds.lin_reg_by_key(*xs[:q], target=y, key=keys, max_groups=G, ctx=ctx))
+        alg = G * R * (q + 2) * 8 + G * (q * 8 + 1 + 8)  # features + target + keys in; coefficients + flags + distinct keys out
+        out[f"p{q}"] = {"by_key_wall_ms": round(t_key * 1e3, 4), "offsets_wall_ms": round(t_off * 1e3, 4), "ratio": round(t_key / t_off, 4),
+                        "regressions_per_s": round(G / t_key, 1), "algorithmic_bytes": int(alg),
+                        "frac_of_hbm_peak": round(alg / t_key / 1e9 / HBM_PEAK_GBPS, 4)}
+    del keys
+    return out
 
 
 def _dist_step_overhead(torch, par, pds, ctx, dev, xs, y, off_pair, offsets, args, plain_ms, have_pg):

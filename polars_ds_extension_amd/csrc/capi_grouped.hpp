@@ -483,13 +483,17 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
     // order flag + key range + the run counts of the order check (keyed.hip): they outlive the workspace sizing below
     const size_t run_slots = key_run_slots(n_rows);
     const size_t slot_bytes = (size_t)kKeySlots * 8 * sizeof(unsigned);
-    if (int rc = ensure_ws(ctx, ctx->solve_ws, 8192 + 2 * up((run_slots + 1) * sizeof(uint32_t)) + up(slot_bytes))) return rc;
+    const size_t mask_bytes = key_run_mask_bytes(n_rows);
+    if (int rc = ensure_ws(ctx, ctx->solve_ws, 8192 + 2 * up((run_slots + 1) * sizeof(uint32_t)) + up(slot_bytes) + mask_bytes)) return rc;
     bool sorted = false;
     int64_t mm[2] = {0, 0};
+    int64_t n_runs = 0;  // keys that differ from their successor: n_groups - 1 of an ordered column
     int64_t* d_state = reinterpret_cast<int64_t*>(static_cast<char*>(ctx->solve_ws.ptr) + 256);
     int64_t* d_minmax = d_state + 2;
     uint32_t* d_run_counts = reinterpret_cast<uint32_t*>(static_cast<char*>(ctx->solve_ws.ptr) + 4096);
     uint32_t* d_run_prefix = reinterpret_cast<uint32_t*>(static_cast<char*>(ctx->solve_ws.ptr) + 4096 + up((run_slots + 1) * sizeof(uint32_t)));
+    unsigned long long* d_run_masks = reinterpret_cast<unsigned long long*>(static_cast<char*>(ctx->solve_ws.ptr) + 4096 +
+                                                                            2 * up((run_slots + 1) * sizeof(uint32_t)) + up(slot_bytes));
     // dense-key candidates (unweighted, <= 16 features): the order check takes the partition route's bucket histogram along
     // PDS_KEYED_SORT=1 (read per call): the sorting route for every unordered frame -- the DETERMINISM switch: the partition route's
     // record order follows cursor atomics, so its sums are reproducible to rounding only.  solver = "svd" with the
@@ -500,8 +504,8 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
     const int part_shift = part_candidate ? keyed_partition_shift<T>(n_feat) : -1;
     unsigned* d_slots = reinterpret_cast<unsigned*>(static_cast<char*>(ctx->solve_ws.ptr) + 4096 + 2 * up((run_slots + 1) * sizeof(uint32_t)));
     bool hist_taken = false;
-    if (int rc = keys_order_minmax(ctx, d_keys, n_rows, d_state, &sorted, mm, d_run_counts, part_shift, part_candidate ? d_slots : nullptr,
-                                   &hist_taken))
+    if (int rc = keys_order_minmax(ctx, d_keys, n_rows, d_state, &sorted, mm, d_run_counts, d_run_masks, &n_runs, part_shift,
+                                   part_candidate ? d_slots : nullptr, &hist_taken))
         return rc;
     tr.mark("keys H2D + order check");
     if (place && !sorted) {
@@ -646,9 +650,11 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
     }
     tr.mark("sort + gather");
     int64_t ng = 0;
-    if (sorted) {  // keys in order: the order check has counted the run starts already -- a scan and one writing pass
-        if (int rc = keyed_runs_ordered(ctx, d_keys, n_rows, d_run_counts, d_run_prefix, run_cap, d_unique, d_offsets, d_temp, temp_bytes, &ng))
-            return rc;
+    if (sorted) {  // keys in order: the order check has counted and marked the run starts already -- a scan and one pass over the marks,
+        ng = n_runs + 1;  // left on the stream in front of the fit (the number of groups came back with the order flag)
+        if (ng <= max_groups)
+            if (int rc = keyed_runs_ordered(ctx, d_keys, n_rows, d_run_counts, d_run_prefix, d_run_masks, run_cap, d_unique, d_offsets, d_temp, temp_bytes))
+                return rc;
     } else if (int rc = keyed_runs(ctx, d_sorted_keys, n_rows, d_unique, d_counts, d_offsets, d_nruns, d_temp, temp_bytes, &ng)) {
         return rc;
     }

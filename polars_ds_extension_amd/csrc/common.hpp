@@ -330,12 +330,14 @@ size_t rolling_wide_workspace(int n_feat, int64_t n_rows, size_t elem);
 int keys_nondecreasing(pds_ctx* ctx, const int64_t* d_keys, int64_t n, unsigned* d_flag, bool* sorted);
 size_t keyed_temp_bytes(int64_t n);
 constexpr int kKeySlots = 8192;  // slots of the histogram the order check can take along (keyed.hip / keyed_partition.hip)
-int keys_order_minmax(pds_ctx* ctx, const int64_t* d_keys, int64_t n, int64_t* d_state, bool* sorted, int64_t* mm,
-                      uint32_t* d_run_counts = nullptr /* key_run_slots(n) entries: see keyed_runs_ordered */, int hist_shift = -1,
+int keys_order_minmax(pds_ctx* ctx, const int64_t* d_keys, int64_t n, int64_t* d_state /* 8 slots */, bool* sorted, int64_t* mm,
+                      uint32_t* d_run_counts = nullptr /* key_run_slots(n) entries: see keyed_runs_ordered */,
+                      unsigned long long* d_run_masks = nullptr /* key_run_mask_bytes(n) */, int64_t* n_runs = nullptr, int hist_shift = -1,
                       unsigned* d_slot_counts = nullptr /* kKeySlots x 8 */, bool* hist_taken = nullptr);
 size_t key_run_slots(int64_t n);
-int keyed_runs_ordered(pds_ctx* ctx, const int64_t* d_keys, int64_t n, uint32_t* d_counts, uint32_t* d_prefix, int64_t cap, int64_t* d_unique,
-                       int64_t* d_offsets, void* d_temp, size_t temp_bytes, int64_t* n_groups);
+size_t key_run_mask_bytes(int64_t n);
+int keyed_runs_ordered(pds_ctx* ctx, const int64_t* d_keys, int64_t n, uint32_t* d_counts, uint32_t* d_prefix, const unsigned long long* d_masks,
+                       int64_t cap, int64_t* d_unique, int64_t* d_offsets, void* d_temp, size_t temp_bytes);
 int keyed_minmax(pds_ctx* ctx, const int64_t* d_keys, int64_t n, void* d_temp, size_t temp_bytes, int64_t* d_minmax, int64_t* mm);
 int keyed_sort(pds_ctx* ctx, const int64_t* d_keys, int64_t n, uint32_t* d_idx_in, int64_t* d_sorted_keys, uint32_t* d_perm,
                void* d_temp, size_t temp_bytes, int64_t* d_scratch_keys, const int64_t* d_minmax, const int64_t* mm);

@@ -23,24 +23,35 @@ __global__ __launch_bounds__(256) void key_descent_kernel(const int64_t* __restr
     if (__any(found) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
 }
 
-// one pass over the keys: is any key smaller than its predecessor, and the smallest / largest key (state: [flag, -, min, max] as
-// four int64 slots; min / max start at INT64_MAX / INT64_MIN)
-// Every wave takes 128-key pieces (1 KiB per load instruction, 16 bytes per lane, four pieces in flight); a key's successor is the
+// one pass over the keys: is any key smaller than its predecessor, and the smallest / largest key (state: [flag, -, min, max, runs]
+// as int64 slots; min / max start at INT64_MAX / INT64_MIN, runs at 0)
+// Every wave takes 128-key pieces (1 KiB per load instruction, 16 bytes per lane, U pieces in flight); a key's successor is the
 // lane's own second key, the next lane's first (DPP shift) or -- lane 63 -- the first key of the next piece (one extra 8-byte load).
 // (The first version read every key twice with 8-byte loads: 0.40 ms for 1e8 keys = 2 TB/s, a quarter of every ordered by-key call.)
 // run_counts (nullable; npieces + 2 slots: [0] the unaligned first key, [1 + piece], [npieces + 1] the keys behind the last whole
 // piece): how many keys j of the slot differ from their successor j + 1 < n -- for keys that ARE in order, the number of groups that
-// start at j + 1.  An exclusive scan of the slots and a second pass (key_run_starts_kernel) then write the distinct keys and the
-// group offsets: the run-length encoding of an ordered key column without a library pass of its own (hipCUB's: 0.35 ms per 1e8 keys).
+// start at j + 1.  run_masks (with run_counts; two 64-bit words per piece): WHICH keys -- bit l of word 0: key 2l of the piece
+// differs from key 2l + 1, bit l of word 1: key 2l + 1 differs from key 2l + 2.  state[4] receives the sum of all counts, so the host
+// knows the number of groups with the order flag (one synchronisation).  An exclusive scan of the slots and a second pass over the
+// MASKS (key_run_starts_kernel: n / 8 bytes instead of the 8 n bytes of the keys; it fetches a key only where a group starts) then
+// write the distinct keys and the group offsets: the run-length encoding of an ordered key column with ONE pass over the keys and
+// no library pass of its own (hipCUB's: 0.35 ms per 1e8 keys; round 3/4 read the keys a second time: + 0.15 ms).
 // slot_counts (nullable; kKeySlots x 8 counters, zeroed by the caller; needs a 16-byte aligned key buffer and a grid that is a multiple
 // of 16): the histogram the partition route (keyed_partition.hip) starts from, taken in the same pass -- slot = (key >> hist_shift) mod
 // kKeySlots, stream = (row / 4096) mod 8 (a block's pieces all belong to one stream: (blockIdx / 2) mod 8).  Valid when the key range
 // turns out to span at most kKeySlots buckets; bucket b is then slot (b + (min >> hist_shift)) mod kKeySlots.  A wave whose 128 keys
 // share one slot -- ordered keys -- adds once.
+#ifndef PDS_KEY_ORDER_U
+#define PDS_KEY_ORDER_U 8
+#endif
+#ifndef PDS_KEY_ORDER_BPC
+#define PDS_KEY_ORDER_BPC 4
+#endif
 __global__ __launch_bounds__(256) void key_order_minmax_kernel(const int64_t* __restrict__ keys, int64_t n, long long* __restrict__ state,
-                                                               uint32_t* __restrict__ run_counts, int hist_shift,
-                                                               unsigned* __restrict__ slot_counts) {
+                                                               uint32_t* __restrict__ run_counts, unsigned long long* __restrict__ run_masks,
+                                                               int hist_shift, unsigned* __restrict__ slot_counts) {
     typedef long long ll2 __attribute__((ext_vector_type(2), aligned(16)));
+    typedef unsigned long long ull2 __attribute__((ext_vector_type(2), aligned(16)));
     __shared__ unsigned hist[kKeySlots];
     const bool do_hist = slot_counts != nullptr;
     if (do_hist) {
@@ -49,6 +60,7 @@ __global__ __launch_bounds__(256) void key_order_minmax_kernel(const int64_t* __
     }
     bool found = false;
     long long mn = 0x7fffffffffffffffll, mx = -0x7fffffffffffffffll - 1;
+    unsigned long long runs = 0;  // (wave-uniform)
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
     // 16-byte alignment of the buffer decides where the vector part starts
@@ -59,7 +71,7 @@ __global__ __launch_bounds__(256) void key_order_minmax_kernel(const int64_t* __
         mn = k < mn ? k : mn;
         mx = k > mx ? k : mx;
     };
-    constexpr int U = 4;
+    constexpr int U = PDS_KEY_ORDER_U;
     for (int64_t p0 = wave * U; p0 < npieces; p0 += nwaves * U) {
         ll2 v[U];
         long long edge[U];
@@ -68,19 +80,44 @@ __global__ __launch_bounds__(256) void key_order_minmax_kernel(const int64_t* __
             const int64_t pc = p0 + u < npieces ? p0 + u : npieces - 1;  // (clamped: unconditional loads)
             const int64_t base = head + pc * 128;
             v[u] = __builtin_nontemporal_load(reinterpret_cast<const ll2*>(keys + base) + lane);
-            const int64_t e = base + 128 < n ? base + 128 : n - 1;
-            edge[u] = keys[e];  // (wave-uniform address: one scalar-like broadcast load)
+        }
+        // a piece's successor key is the next piece's first key: inside the wave's U pieces it is already in a register
+        {
+            const int64_t pl = p0 + U - 1 < npieces ? p0 + U - 1 : npieces - 1;
+            const int64_t e = head + pl * 128 + 128 < n ? head + pl * 128 + 128 : n - 1;
+            edge[U - 1] = keys[e];  // (wave-uniform address: one scalar-like broadcast load)
+        }
+#pragma unroll
+        for (int u = 0; u + 1 < U; ++u) {
+            // (valid whenever piece p0 + u + 1 exists; a clamped duplicate otherwise -- then piece p0 + u is the last one or beyond,
+            //  and the last whole piece takes its successor from memory below)
+            edge[u] = __shfl(v[u + 1].x, 0);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (p0 + u < npieces) {
                 long long nxt = __shfl_down(v[u].x, 1);
-                if (lane == 63) nxt = edge[u];  // (the frame's last key is its own successor: the clamped index)
+                if (lane == 63) {
+                    long long ed = edge[u];
+                    if (u + 1 < U && p0 + u + 1 >= npieces) {  // the last whole piece inside an unrolled group
+                        const int64_t e = head + (p0 + u) * 128 + 128 < n ? head + (p0 + u) * 128 + 128 : n - 1;
+                        ed = keys[e];
+                    }
+                    nxt = ed;  // (the frame's last key is its own successor: the clamped index)
+                }
                 take(v[u].x, v[u].y);
                 take(v[u].y, nxt);
                 if (run_counts) {
-                    const unsigned c = (unsigned)__popcll(__ballot(v[u].x != v[u].y)) + (unsigned)__popcll(__ballot(v[u].y != nxt));
-                    if (lane == 0) run_counts[1 + p0 + u] = c;
+                    const unsigned long long bx = __ballot(v[u].x != v[u].y), by = __ballot(v[u].y != nxt);
+                    const unsigned c = (unsigned)__popcll(bx) + (unsigned)__popcll(by);
+                    runs += c;
+                    if (lane == 0) {
+                        run_counts[1 + p0 + u] = c;
+                        ull2 m;
+                        m.x = bx;
+                        m.y = by;
+                        *reinterpret_cast<ull2*>(run_masks + 2 * (p0 + u)) = m;
+                    }
                 }
                 if (do_hist) {
                     const unsigned sx = (unsigned)((v[u].x >> hist_shift) & (long long)(kKeySlots - 1));
@@ -109,9 +146,13 @@ __global__ __launch_bounds__(256) void key_order_minmax_kernel(const int64_t* __
             if (do_hist && in)  // (fewer than 128 keys: straight to the counters of their own chunk's stream)
                 atomicAdd(&slot_counts[(unsigned)((k >> hist_shift) & (long long)(kKeySlots - 1)) * 8u + (unsigned)((i >> 12) & 7)], 1u);
         }
-        if (run_counts && lane == 0) {
-            run_counts[0] = (head && n > 1 && keys[0] != keys[1]) ? 1u : 0u;
-            run_counts[1 + npieces] = ct;
+        if (run_counts) {
+            const unsigned c0 = (head && n > 1 && keys[0] != keys[1]) ? 1u : 0u;
+            runs += c0 + ct;
+            if (lane == 0) {
+                run_counts[0] = c0;
+                run_counts[1 + npieces] = ct;
+            }
         }
     }
     for (int o = 32; o > 0; o >>= 1) {
@@ -121,12 +162,14 @@ __global__ __launch_bounds__(256) void key_order_minmax_kernel(const int64_t* __
     }
     // one set of atomics per BLOCK (the 8192 waves of the first version queued 24 000 atomics on three addresses: most of its 0.4 ms)
     __shared__ long long red[2][4];
+    __shared__ unsigned long long red_runs[4];
     __shared__ int any_found[4];
     const int wv = threadIdx.x >> 6;
     const bool wf = __any(found);
     if (lane == 0) {
         red[0][wv] = mn;
         red[1][wv] = mx;
+        red_runs[wv] = runs;
         any_found[wv] = wf ? 1 : 0;
     }
     __syncthreads();
@@ -138,9 +181,11 @@ __global__ __launch_bounds__(256) void key_order_minmax_kernel(const int64_t* __
         if (any_found[0] | any_found[1] | any_found[2] | any_found[3]) atomicOr(reinterpret_cast<unsigned long long*>(state), 1ull);
         atomicMin(state + 2, mn);
         atomicMax(state + 3, mx);
+        const unsigned long long rs = red_runs[0] + red_runs[1] + red_runs[2] + red_runs[3];
+        if (rs) atomicAdd(reinterpret_cast<unsigned long long*>(state + 4), rs);
     }
     if (do_hist) {  // (the __syncthreads above also closed the histogram)
-        const unsigned stream = (blockIdx.x >> 1) & 7u;
+        const unsigned stream = (unsigned)(((int64_t)blockIdx.x * (PDS_KEY_ORDER_U * 512)) >> 12) & 7u;  // (rows of a block / 4096) mod 8
         for (int i = threadIdx.x; i < kKeySlots; i += 256) {
             const unsigned c = hist[i];
             if (c) atomicAdd(&slot_counts[(unsigned)i * 8u + stream], c);
@@ -245,13 +290,21 @@ int keys_nondecreasing(pds_ctx* ctx, const int64_t* d_keys, int64_t n, unsigned*
     return PDS_OK;
 }
 
-// order check + key range in ONE pass (d_state: 4 int64 slots on the device; d_state + 2 is the {min, max} pair keyed_sort and
-// the partition route read on the device)
+// order check + key range (+ run counts / masks / total of an ordered column) in ONE pass (d_state: 8 int64 slots on the device;
+// d_state + 2 is the {min, max} pair keyed_sort and the partition route read on the device; d_state[4] the number of keys that differ
+// from their successor = n_groups - 1 of an ordered column, returned through n_runs)
 int keys_order_minmax(pds_ctx* ctx, const int64_t* d_keys, int64_t n, int64_t* d_state, bool* sorted, int64_t* mm, uint32_t* d_run_counts,
-                      int hist_shift, unsigned* d_slot_counts, bool* hist_taken) {
-    const long long init[4] = {0, 0, 0x7fffffffffffffffll, -0x7fffffffffffffffll - 1};
-    PDS_HIP_CHECK(hipMemcpyAsync(d_state, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
-    int nb = (int)std::min<int64_t>(std::max<int64_t>((n + 2047) / 2048, 1), (int64_t)ctx->num_cus * 4);
+                      unsigned long long* d_run_masks, int64_t* n_runs, int hist_shift, unsigned* d_slot_counts, bool* hist_taken) {
+    if (int rc = ensure_pinned(ctx, 4096)) return rc;
+    long long* init = reinterpret_cast<long long*>(static_cast<char*>(ctx->pinned) + 2048);  // (pinned: the copies below are truly asynchronous)
+    init[0] = 0;
+    init[1] = 0;
+    init[2] = 0x7fffffffffffffffll;
+    init[3] = -0x7fffffffffffffffll - 1;
+    init[4] = 0;
+    PDS_HIP_CHECK(hipMemcpyAsync(d_state, init, 5 * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
+    constexpr int64_t per_block = 4 * 128 * PDS_KEY_ORDER_U;  // keys of one block and iteration
+    int nb = (int)std::min<int64_t>(std::max<int64_t>((n + per_block - 1) / per_block, 1), (int64_t)ctx->num_cus * PDS_KEY_ORDER_BPC);
     // the fused histogram: aligned keys, a grid in which a block's pieces all belong to one stream, enough keys to be worth it
     const bool hist = d_slot_counts && hist_shift >= 0 && ((uintptr_t)d_keys & 15) == 0 && nb >= 16;
     if (hist) {
@@ -259,61 +312,61 @@ int keys_order_minmax(pds_ctx* ctx, const int64_t* d_keys, int64_t n, int64_t* d
         PDS_HIP_CHECK(hipMemsetAsync(d_slot_counts, 0, (size_t)kKeySlots * 8 * sizeof(unsigned), ctx->stream));
     }
     if (hist_taken) *hist_taken = hist;
+    if (!d_run_masks) d_run_counts = nullptr;
     hipLaunchKernelGGL(key_order_minmax_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_keys, n, reinterpret_cast<long long*>(d_state), d_run_counts,
-                       hist ? hist_shift : 0, hist ? d_slot_counts : (unsigned*)nullptr);
-    long long h[4] = {0, 0, 0, 0};
-    PDS_HIP_CHECK(hipMemcpyAsync(h, d_state, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // (also makes `init` safe to leave scope)
+                       d_run_masks, hist ? hist_shift : 0, hist ? d_slot_counts : (unsigned*)nullptr);
+    long long* h = init + 8;
+    PDS_HIP_CHECK(hipMemcpyAsync(h, d_state, 5 * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     *sorted = h[0] == 0;
     mm[0] = h[2];
     mm[1] = h[3];
+    if (n_runs) *n_runs = h[4];
     return PDS_OK;
 }
 
-// second pass of the run-length encoding of an ORDERED key column: prefix = exclusive scan of key_order_minmax_kernel's slots.
-// Group r > 0 starts at j + 1 where key j differs from its successor, r = 1 + prefix[slot of j] + (such keys in front of j in the
-// slot); group 0 starts at row 0.  offsets[n_groups] = n is written by the thread that sees the last key.
+// second pass of the run-length encoding of an ORDERED key column: prefix = exclusive scan of key_order_minmax_kernel's slots,
+// masks = its change bits.  Group r > 0 starts at j + 1 where key j differs from its successor, r = 1 + prefix[slot of j] + (such keys
+// in front of j in the slot); group 0 starts at row 0.  A thread takes one 128-key piece: its two mask words (16 bytes, coalesced
+// across the wave) and, per set bit, one key fetch and two stores -- at a hundred rows per group about 1.3 per piece.  (Round 3 / 4
+// re-read the whole key column here: 0.8 GB per 1e8 keys against 12.5 MB of masks + 8 MB of fetched keys.)
 __global__ __launch_bounds__(256) void key_run_starts_kernel(const int64_t* __restrict__ keys, int64_t n, const uint32_t* __restrict__ prefix,
-                                                             int64_t* __restrict__ out_keys, int64_t* __restrict__ offsets, int64_t cap) {
-    typedef long long ll2 __attribute__((ext_vector_type(2), aligned(16)));
+                                                             const unsigned long long* __restrict__ masks, int64_t* __restrict__ out_keys,
+                                                             int64_t* __restrict__ offsets, int64_t cap) {
+    typedef unsigned long long ull2 __attribute__((ext_vector_type(2), aligned(16)));
     const int lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
     const int64_t head = (((uintptr_t)keys & 15) != 0 && n > 0) ? 1 : 0;
     const int64_t npieces = (n - head) / 128;
-    const unsigned long long lt = (1ull << lane) - 1ull;
     auto put = [&](int64_t r, long long k, int64_t start) __attribute__((always_inline)) {
         if (r < cap) {
             out_keys[r] = k;
             offsets[r] = start;
         }
     };
-    constexpr int U = 4;
-    for (int64_t p0 = wave * U; p0 < npieces; p0 += nwaves * U) {
-        ll2 v[U];
-        long long edge[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t pc = p0 + u < npieces ? p0 + u : npieces - 1;
-            const int64_t base = head + pc * 128;
-            v[u] = __builtin_nontemporal_load(reinterpret_cast<const ll2*>(keys + base) + lane);
-            const int64_t e = base + 128 < n ? base + 128 : n - 1;
-            edge[u] = keys[e];
+    for (int64_t pc = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pc < npieces; pc += (int64_t)gridDim.x * blockDim.x) {
+        const ull2 m = __builtin_nontemporal_load(reinterpret_cast<const ull2*>(masks) + pc);
+        unsigned long long bx = m.x, by = m.y;
+        if ((bx | by) == 0ull) continue;
+        const int64_t base = head + pc * 128;
+        const int64_t r0 = 1 + (int64_t)prefix[1 + pc];
+        unsigned long long rx = bx, ry = by;
+        while (rx) {  // key 2l differs from key 2l + 1: a group starts at 2l + 1
+            const int l = __builtin_ctzll(rx);
+            rx &= rx - 1;
+            const unsigned long long lt = (1ull << l) - 1ull;
+            const int64_t st = base + 2 * l + 1;
+            put(r0 + __popcll(bx & lt) + __popcll(by & lt), keys[st], st);
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (p0 + u < npieces) {
-                long long nxt = __shfl_down(v[u].x, 1);
-                if (lane == 63) nxt = edge[u];
-                const int64_t jx = head + (p0 + u) * 128 + 2 * lane;  // index of the lane's first key
-                const bool fx = v[u].x != v[u].y, fy = v[u].y != nxt;  // (the last key of the frame equals its clamped successor)
-                const unsigned long long bx = __ballot(fx), by = __ballot(fy);
-                const int64_t r0 = 1 + (int64_t)prefix[1 + p0 + u] + __popcll(bx & lt) + __popcll(by & lt);
-                if (fx) put(r0, v[u].y, jx + 1);
-                if (fy) put(r0 + (fx ? 1 : 0), nxt, jx + 2);
-            }
+        while (ry) {  // key 2l + 1 differs from key 2l + 2: a group starts at 2l + 2 (the x change of the same lane comes first)
+            const int l = __builtin_ctzll(ry);
+            ry &= ry - 1;
+            const unsigned long long lt = (1ull << l) - 1ull;
+            const int64_t st = base + 2 * l + 2;
+            put(r0 + __popcll(bx & (lt | (1ull << l))) + __popcll(by & lt), keys[st], st);
         }
     }
-    if (wave == 0) {
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        const unsigned long long ltl = (1ull << lane) - 1ull;
         if (lane == 0) {
             put(0, keys[0], 0);
             if (head && n > 1 && keys[0] != keys[1]) put(1 + (int64_t)prefix[0], keys[1], 1);
@@ -327,31 +380,29 @@ __global__ __launch_bounds__(256) void key_run_starts_kernel(const int64_t* __re
             const long long k = in ? keys[i] : 0, nx = (in && i + 1 < n) ? keys[i + 1] : k;
             const bool f = in && k != nx;
             const unsigned long long b = __ballot(f);
-            if (f) put(r + __popcll(b & lt), nx, i + 1);
+            if (f) put(r + __popcll(b & ltl), nx, i + 1);
             r += __popcll(b);
         }
     }
 }
 
 size_t key_run_slots(int64_t n) { return (size_t)(n / 128 + 3); }  // head, pieces, tail (+ one for the scan's total)
+size_t key_run_mask_bytes(int64_t n) { return ((size_t)(n / 128 + 1) * 16 + 255) & ~(size_t)255; }
 
-// distinct keys + offsets (n_groups + 1 entries) of an ORDERED key column from the counts key_order_minmax_kernel left in d_counts
-// (key_run_slots(n) entries; d_prefix: as many + 1).  cap: capacity of d_unique (d_offsets holds cap + 1).
-int keyed_runs_ordered(pds_ctx* ctx, const int64_t* d_keys, int64_t n, uint32_t* d_counts, uint32_t* d_prefix, int64_t cap, int64_t* d_unique,
-                       int64_t* d_offsets, void* d_temp, size_t temp_bytes, int64_t* n_groups) {
+// distinct keys + offsets (n_groups + 1 entries) of an ORDERED key column from the counts / masks key_order_minmax_kernel left
+// (d_counts: key_run_slots(n) entries; d_prefix: as many + 1; d_masks: key_run_mask_bytes(n)).  cap: capacity of d_unique (d_offsets
+// holds cap + 1).  Nothing is read back: the number of groups came with the order check (n_runs + 1); the launches are left on the stream.
+int keyed_runs_ordered(pds_ctx* ctx, const int64_t* d_keys, int64_t n, uint32_t* d_counts, uint32_t* d_prefix,
+                       const unsigned long long* d_masks, int64_t cap, int64_t* d_unique, int64_t* d_offsets, void* d_temp, size_t temp_bytes) {
     const int64_t head = (((uintptr_t)d_keys & 15) != 0 && n > 0) ? 1 : 0;
     const int64_t npieces = (n - head) / 128;
     const int slots = (int)(npieces + 2);
     // the slot behind the last one is zero: the exclusive scan over slots + 1 entries ends with the total
     PDS_HIP_CHECK(hipMemsetAsync(d_counts + slots, 0, sizeof(uint32_t), ctx->stream));
     PDS_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(d_temp, temp_bytes, (const uint32_t*)d_counts, d_prefix, slots + 1, ctx->stream));
-    uint32_t total = 0;
-    PDS_HIP_CHECK(hipMemcpyAsync(&total, d_prefix + slots, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    const int nb = (int)std::min<int64_t>(std::max<int64_t>((n + 2047) / 2048, 1), (int64_t)ctx->num_cus * 4);
-    hipLaunchKernelGGL(key_run_starts_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_keys, n, (const uint32_t*)d_prefix, d_unique, d_offsets, cap);
+    const int nb = (int)std::min<int64_t>(std::max<int64_t>((npieces + 255) / 256, 1), (int64_t)ctx->num_cus * 8);
+    hipLaunchKernelGGL(key_run_starts_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_keys, n, (const uint32_t*)d_prefix, d_masks, d_unique, d_offsets, cap);
     PDS_HIP_CHECK(hipGetLastError());
-    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    *n_groups = 1 + (int64_t)total;
     return PDS_OK;
 }
 
