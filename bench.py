@@ -554,10 +554,12 @@ def _end_to_end(torch, np, pds, dev, xs, y, G, R, P, cpu):
                        "frac_of_pcie_rate": round(gb_by / t_by / pcie, 3),
                        "route": f"sliced, {os.environ.get('PDS_BY_KEY_CONTEXTS', '2')} contexts per device, devices {os.environ.get('PDS_DEVICES', '0')}"}
     os.environ["PDS_BY_KEY_MULTI_MIN_ROWS"] = "0"
+    lib.pds_plugin_reload_settings()  # (the plugin layer reads its environment once)
     try:
         t_by1, _ = timed("pl_lr_by", [key] + host, reps=2)
     finally:
         del os.environ["PDS_BY_KEY_MULTI_MIN_ROWS"]
+        lib.pds_plugin_reload_settings()
     out["pl_lr_by"]["single_context_wall_ms"] = round(t_by1 * 1e3, 1)
     out["pl_lr_by"]["single_context_frac_of_pcie_rate"] = round(gb_by / t_by1 / pcie, 3)
     # `.over(key)` / group_by().agg(lin_reg(return_pred=True)) on the same host frame: pred + resid of every row come back
@@ -565,10 +567,12 @@ def _end_to_end(torch, np, pds, dev, xs, y, G, R, P, cpu):
     t_bp, resp = timed("pl_lr_by_pred", [key] + host, reps=3, warm=2)
     assert len(resp) == N
     os.environ["PDS_BY_KEY_MULTI_MIN_ROWS"] = "0"
+    lib.pds_plugin_reload_settings()
     try:
         t_bp1, _ = timed("pl_lr_by_pred", [key] + host, reps=3, warm=1)
     finally:
         del os.environ["PDS_BY_KEY_MULTI_MIN_ROWS"]
+        lib.pds_plugin_reload_settings()
     del resp
     out["pl_lr_by_pred"] = {"workload": "same host frame, per-row pred + resid of every group's fit (Struct{pred,resid}, frame order)",
                             "wall_ms": round(t_bp * 1e3, 1), "up_GB": round(N * (P + 2) * 8 / 1e9, 2), "down_GB": round(N * 17 / 1e9, 2),
@@ -727,7 +731,7 @@ def _c5(torch, pds, ctx, dev):
     pds.config.LIN_REG_EXPR_F64 = False
     try:
         for name, native in (("bf16x3_split_default", "0"), ("f32_mfma", "1")):
-            os.environ["PDS_WIDE_F32_NATIVE"] = native
+            ctx.set_option("wide_f32_native", int(native))
             fit = lambda: pds.lin_reg(*xs, target=y, l1_reg=0.01, l2_reg=0.01, tol=1e-5, ctx=ctx)
             fit()
             ctx.get_timing(reset=True)
@@ -753,7 +757,7 @@ def _c5(torch, pds, ctx, dev):
                 out[name]["frac_of_bf16_pipe_floor_12.3ms"] = round(12.3 / gram, 3)
                 out[name]["pipe"] = "bf16 matrix cores (three exact bf16 planes per f32 value); the f32-peak fraction above is a useful-flop rate, not a utilisation of that pipe"
     finally:
-        os.environ.pop("PDS_WIDE_F32_NATIVE", None)
+        ctx.set_option("wide_f32_native", 0)
         pds.config.LIN_REG_EXPR_F64 = True
     return out
 

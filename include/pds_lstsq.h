@@ -77,6 +77,13 @@ int pds_ctx_set_stream(pds_ctx* ctx, void* hip_stream);
 int pds_ctx_synchronize(pds_ctx* ctx);
 /* Number of compute units of the context's device (256 on MI355X). */
 int pds_ctx_num_cus(const pds_ctx* ctx);
+/* Behaviour switches of a context; the defaults are read from the environment ONCE, when the context is created:
+ *   "keyed_sort"      (PDS_KEYED_SORT=1)      pds_lr_by_key_*: unordered keys always take the sorting route -- the determinism switch: the
+ *                                             partition route appends records through cursor atomics, so its sums repeat to rounding only;
+ *   "wide_f32_native" (PDS_WIDE_F32_NATIVE=1) f32 Gram builds beyond 64 features on the f32 matrix instructions (v_mfma_f32_32x32x2_f32,
+ *                                             2.5e-7 from the f64 Gram) instead of three exact bf16 planes on the bf16 matrix cores (2e-6).
+ * value: 0 / 1.  Unknown names are PDS_ERR_INVALID. */
+int pds_ctx_set_option(pds_ctx* ctx, const char* name, long long value);
 /* Host-frame staging (process wide): chunk_mb = bytes of one row chunk of a PDS_HOST frame (default 256, env
  * PDS_HOST_CHUNK_MB); resident_max_mb = largest host frame that pds_lr_pred_* still stages whole (one PCIe trip; larger
  * frames make two chunked trips; default 98304, env PDS_HOST_RESIDENT_MAX_MB).  A value <= 0 leaves the setting as is.
@@ -395,7 +402,9 @@ int pds_lr_by_key_pred_multi_f32(pds_ctx* const* ctxs, int n_ctx, int n_slices, 
  *                           0 keeps reading the frame in place).
  *   pds_gather_f64          src[c]: counts[c] doubles on ctxs[c]'s device -> dst on ctxs[0]'s device, back to back in rank order
  *                           (row C3: the coefficient blocks of the ranks' groups).
- * f32 twins move floats (the all-reduce sums them in f64 on the way).
+ * f32 twins move floats.  Their all-reduce keeps the running sum as a float: every single addition is formed in f64 and rounded back,
+ * so n_ctx addends cost up to n_ctx - 1 float roundings -- not an f64 accumulation (moment blocks that need one travel as f64:
+ * pds_moments_* returns f64 records for both precisions).
  */
 int pds_allreduce_sum_f64(pds_ctx* const* ctxs, int n_ctx, double* const* bufs, int64_t count, int prefix);
 int pds_allreduce_sum_f32(pds_ctx* const* ctxs, int n_ctx, float* const* bufs, int64_t count, int prefix);

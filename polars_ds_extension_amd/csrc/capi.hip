@@ -55,6 +55,12 @@ int pds_ctx_create(int device, pds_ctx** out) {
         return fail(PDS_ERR_HIP, "hipStreamCreate failed");
     }
     c->own_stream = true;
+    {   // option defaults from the environment, once per context (pds_ctx_set_option changes them afterwards)
+        const char* ks = std::getenv("PDS_KEYED_SORT");
+        c->opt_keyed_sort = ks && ks[0] == '1';
+        const char* wn = std::getenv("PDS_WIDE_F32_NATIVE");
+        c->opt_wide_f32_native = wn && wn[0] == '1';
+    }
     const size_t pbytes = (size_t)c->num_cus * 8 * kPartStride * sizeof(double);
     if (hipMalloc(reinterpret_cast<void**>(&c->partials), pbytes) != hipSuccess) {
         (void)hipStreamDestroy(c->stream);
@@ -107,6 +113,15 @@ int pds_ctx_synchronize(pds_ctx* ctx) {
 }
 
 int pds_ctx_num_cus(const pds_ctx* ctx) { return ctx ? ctx->num_cus : 0; }
+
+int pds_ctx_set_option(pds_ctx* ctx, const char* name, long long value) {
+    if (!ctx || !name) return fail(PDS_ERR_INVALID, "null argument");
+    const std::string n(name);
+    if (n == "keyed_sort") ctx->opt_keyed_sort = value != 0;
+    else if (n == "wide_f32_native") ctx->opt_wide_f32_native = value != 0;
+    else return fail(PDS_ERR_INVALID, "unknown context option: " + n);
+    return PDS_OK;
+}
 
 int pds_glm_irls_f64(pds_ctx* ctx, const double* const* cols, int n_feat, int64_t n_rows, pds_space space, int add_bias, int link,
                      int variance, double tol, int max_iter, double* coeffs, int* n_iter) {

@@ -86,6 +86,7 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
                         // nullable; `coeffs` may then be null as well.  Not with the nullable form (its rows are compacted).
                         T* pred = nullptr, T* resid = nullptr, uint8_t* row_null = nullptr) {
     const bool want_pred = pred || resid || row_null;
+    g_grouped_route = 0;  // (the hook reports THIS call's route: the routes that do not set it leave 0, not the previous call's value)
     if (!ctx || !cols || !offsets || !prm || (!coeffs && !want_pred)) return fail(PDS_ERR_INVALID, "null argument");
     if (want_pred && nullable) return fail(PDS_ERR_UNSUPPORTED, "grouped pred: null-free frames only");
     if (n_feat < 1) return fail(PDS_ERR_INVALID, "need at least one feature column");
@@ -98,7 +99,7 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
     const bool big = n_feat > kMaxFeatWide;  // > 64 features: one tiled-SYRK Gram build per group + solve_big
     // (17 .. 64 features: 2 GiB of records per chunk -- every chunk ends in a host synchronisation for the solver's marked count:
     //  100 000 groups x 100 rows x 64 features 7.4 ms in seven chunks of 512 MiB, 6.5 ms in two; PDS_GROUPED_CHUNK_MB overrides)
-    static const int64_t chunk_env = [] { const char* e = std::getenv("PDS_GROUPED_CHUNK_MB"); return e ? std::max<int64_t>(1, std::atoll(e)) : 0; }();
+    static const int64_t chunk_env = [] { const char* e = dev_env("PDS_GROUPED_CHUNK_MB"); return e ? std::max<int64_t>(1, std::atoll(e)) : 0; }();
     const int64_t chunk_mb = chunk_env ? chunk_env : ((n_feat > 16 && n_feat <= kMaxFeatWide) ? 2048 : 128);
     int64_t chunk = std::max<int64_t>(big ? 64 : 4096, (int64_t)(chunk_mb << 20) / (int64_t)(sizeof(T) * q * q));
     chunk = std::min(chunk, n_groups);
@@ -190,15 +191,15 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
     // mark the ones next to the rank gate, which launch_solve_marked puts through the reference's SVD gate (lr_solvers.rs:358-366)
     SolveParams sp{n_feat, bias, prm->solver, prm->l2_reg, prm->singular_x_tol, 0};
     {
-        const char* piv0 = std::getenv("PDS_GROUPED_PIVOTED");
+        const char* piv0 = dev_env("PDS_GROUPED_PIVOTED");
         if (piv0 && piv0[0] == '1' && sp.solver == PDS_SOLVER_CHOLESKEY) sp.solver = PDS_SOLVER_QR;
     }
     // Default (rank gate on): ONE streaming kernel, Gram + in-register Cholesky, no moment records in HBM.
     // Gate off (singular_x_tol = 0) needs the pivoted QR to reproduce the reference's answers on rank-deficient
     // groups; that solver is register hungry and runs faster as its own kernel behind the grouped Gram build.
     // PDS_GROUPED_UNFUSED=1 / PDS_GROUPED_PIVOTED=1 force the two-kernel pipeline / the pivoted QR (development).
-    const char* unfused_env = std::getenv("PDS_GROUPED_UNFUSED");
-    const char* piv_env = std::getenv("PDS_GROUPED_PIVOTED");
+    const char* unfused_env = dev_env("PDS_GROUPED_UNFUSED");
+    const char* piv_env = dev_env("PDS_GROUPED_PIVOTED");
     const bool want_piv = !(sp.gate_tol > 0.0) || (piv_env && piv_env[0] == '1');
     if (big) {
         if (int rc = grouped_big<T>(ctx, dc, n_feat, d_off, n_groups, chunk, method, prm, sp, d_mom, d_coeffs, d_null)) return rc;
@@ -225,9 +226,8 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
         // (grouped_mid.hip); PDS_GROUPED_MID_FUSED=0: the record pipeline below (A/B); it also takes over when more systems sit
         // next to the gate than the fused form's marked list holds
         bool mid_done = false;
-        g_grouped_route = 0;
         {
-            const char* mf = std::getenv("PDS_GROUPED_MID_FUSED");
+            const char* mf = dev_env("PDS_GROUPED_MID_FUSED");
             if (n_feat > 16 && n_feat <= 32 && !want_piv && !(mf && mf[0] == '0')) {
                 void* d_fws = ws_take(ctx, grouped_mid_fused_workspace(ctx->num_cus, n_feat, bias));
                 const int rcf = launch_grouped_mid_fused<T>(ctx, dc, n_feat, n_rows, d_off, n_groups, sp, d_coeffs, d_null, d_fws);
@@ -242,7 +242,7 @@ static int grouped_impl(pds_ctx* ctx, const T* const* cols, int n_feat, int64_t 
             bool streamed = false;
             if constexpr (std::is_same<T, double>::value) {
                 // 17 .. 64 f64 features: the chunk's records from ONE stream over its rows (grouped_mid.hip); PDS_GROUPED_STREAM=0: A/B
-                static const bool stream_off = [] { const char* e = std::getenv("PDS_GROUPED_STREAM"); return e && e[0] == '0'; }();
+                static const bool stream_off = [] { const char* e = dev_env("PDS_GROUPED_STREAM"); return e && e[0] == '0'; }();
                 // (below ~28 features the padded 32-wide stream costs more than the one-wave-per-group kernel saves: 2.7 against 2.5 ms at 20)
                 if (n_feat >= 28 && n_feat <= 64 && !stream_off) {
                     if (int rc = launch_grouped_moments_stream(ctx, dc, n_feat, n_rows, d_off + g0, gc, d_mom)) return rc;
@@ -411,7 +411,7 @@ static int solve_partition_table(pds_ctx* ctx, const KeyedPartitionState& st, in
     const bool f32 = sizeof(T) == 4;
     // OLS / ridge with up to 16 coefficients: the register-resident solver reads the table's triangles itself (no expansion pass)
     if (method.kind == Method::OLS && pp <= 16 && (sp.solver != PDS_SOLVER_CHOLESKEY || sp.gate_tol > 0.0)) {
-        static const bool expand = [] { const char* e = std::getenv("PDS_PART_EXPAND"); return e && e[0] == '1'; }();  // (A/B)
+        static const bool expand = [] { const char* e = dev_env("PDS_PART_EXPAND"); return e && e[0] == '1'; }();  // (A/B)
         if (!expand) {
             TriSource tri;
             tri.table = st.table;
@@ -495,11 +495,10 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
     unsigned long long* d_run_masks = reinterpret_cast<unsigned long long*>(static_cast<char*>(ctx->solve_ws.ptr) + 4096 +
                                                                             2 * up((run_slots + 1) * sizeof(uint32_t)) + up(slot_bytes));
     // dense-key candidates (unweighted, <= 16 features): the order check takes the partition route's bucket histogram along
-    // PDS_KEYED_SORT=1 (read per call): the sorting route for every unordered frame -- the DETERMINISM switch: the partition route's
+    // context option "keyed_sort" (default from PDS_KEYED_SORT=1 at pds_ctx_create): the sorting route for every unordered frame -- the DETERMINISM switch: the partition route's
     // record order follows cursor atomics, so its sums are reproducible to rounding only.  solver = "svd" with the
     // rank gate on also sorts: the partition route solves every group with the pivoted QR and marks nothing for the SVD gate.
-    const char* ks_env = std::getenv("PDS_KEYED_SORT");
-    const bool force_sort = (ks_env && ks_env[0] == '1') || (prm->solver == PDS_SOLVER_SVD && prm->singular_x_tol > 0.0);
+    const bool force_sort = ctx->opt_keyed_sort || (prm->solver == PDS_SOLVER_SVD && prm->singular_x_tol > 0.0);
     const bool part_candidate = !force_sort && !weights && n_feat <= 16 && !place;
     const int part_shift = part_candidate ? keyed_partition_shift<T>(n_feat) : -1;
     unsigned* d_slots = reinterpret_cast<unsigned*>(static_cast<char*>(ctx->solve_ws.ptr) + 4096 + 2 * up((run_slots + 1) * sizeof(uint32_t)));
@@ -623,7 +622,7 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
         if (int rc = keyed_sort(ctx, d_keys, n_rows, idx_in, sk, perm, d_temp, temp_bytes, sk2, d_minmax, mm)) return rc;
         d_sorted_keys = sk;
         d_perm = perm;
-        static const bool by_column = [] { const char* e = std::getenv("PDS_KEYED_GATHER_BY_COLUMN"); return e && e[0] == '1'; }();
+        static const bool by_column = [] { const char* e = dev_env("PDS_KEYED_GATHER_BY_COLUMN"); return e && e[0] == '1'; }();
         // frames too wide for the 256-row transposition tile (32 f64 / 64 f32 columns and beyond) gather column by column
         if (by_column || !gather_frame_fits<T>(nc)) {  // (one random 8-byte read per element; the env switch is the A/B)
             for (int c = 0; c < nc; ++c) {

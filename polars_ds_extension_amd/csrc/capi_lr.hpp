@@ -126,37 +126,55 @@ static bool host_svd_gated(const std::vector<T>& M, int p, int bias, double l2, 
 
 // Grouped fits: the records of the systems the streaming kernels marked (next to the rank gate, gated, broken down) through the
 // reference's factorisation for `sp.solver` -- the pivoted QR with the log-det gate (solve.hip) for "qr", the SVD gate above for
-// "svd" (on the host: the marked systems are few; per-solver gate, tests/test_linear_exprs.py:1326-1340).  d_co [n][p'], d_fl [n].
+// "svd" (per-solver gate, tests/test_linear_exprs.py:1326-1340).  d_co [n][p'], d_fl [n].
+// The SVD runs on the host and only for SMALL marked sets (kHostSvdMax systems, a few host threads): a chunk in which most systems sit
+// next to the gate (groups with barely more rows than columns, duplicated columns, an overflowing marked list) arrives here whole --
+// 1e5+ systems -- and takes the device pivoted QR instead: its gate statistic ln det G - sum ln G_ii is the same number (|det| is the
+// product of the R diagonal as well as of the singular values), only the factorisation behind beta differs, to rounding.
+constexpr int64_t kHostSvdMax = 2048;
 template <typename T>
 int launch_solve_marked(pds_ctx* ctx, const T* d_rec, int64_t n, const SolveParams& sp, T* d_co, uint8_t* d_fl, const int64_t* d_rows_per_sys) {
     if (n <= 0) return PDS_OK;
     SolveParams sq = sp;
-    if (sp.solver != PDS_SOLVER_SVD || !(sp.gate_tol > 0.0)) {
+    if (sp.solver != PDS_SOLVER_SVD || !(sp.gate_tol > 0.0) || n > kHostSvdMax) {
         sq.solver = PDS_SOLVER_QR;
         return launch_solve<T>(ctx, d_rec, n, sq, d_co, d_fl, nullptr, d_rows_per_sys);
     }
     const int p = sp.p, bias = sp.add_bias ? 1 : 0, pp = p + bias, q = p + 2;
-    std::vector<T> rec((size_t)n * q * q), co((size_t)n * pp);
-    std::vector<uint8_t> fl((size_t)n, 0);
+    std::vector<T> rec, co;
+    std::vector<uint8_t> fl;
     std::vector<int64_t> rows;
-    PDS_HIP_CHECK(hipMemcpyAsync(rec.data(), d_rec, rec.size() * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
-    if (d_rows_per_sys) {
-        rows.resize((size_t)n + 1);
-        PDS_HIP_CHECK(hipMemcpyAsync(rows.data(), d_rows_per_sys, rows.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    try {
+        rec.resize((size_t)n * q * q);
+        co.resize((size_t)n * pp);
+        fl.assign((size_t)n, 0);
+        if (d_rows_per_sys) rows.resize((size_t)n + 1);
+    } catch (const std::bad_alloc&) {
+        return fail(PDS_ERR_HIP, "host staging of the marked systems: out of memory");
     }
+    PDS_HIP_CHECK(hipMemcpyAsync(rec.data(), d_rec, rec.size() * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+    if (d_rows_per_sys) PDS_HIP_CHECK(hipMemcpyAsync(rows.data(), d_rows_per_sys, rows.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
     PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    std::vector<T> M((size_t)q * q);
-    std::vector<int64_t> retry;
-    for (int64_t k = 0; k < n; ++k) {
-        std::copy(rec.begin() + k * q * q, rec.begin() + (k + 1) * q * q, M.begin());
+    auto work = [&](int64_t k0, int64_t k1) {
+        std::vector<T> M((size_t)q * q);
         std::vector<double> beta;
-        bool null = false;
-        bool ok = true;
-        if (!rows.empty() && rows[k + 1] - rows[k] < pp) null = true, beta.assign(pp, NAN);  // "#Data < #features"
-        else ok = host_svd_gated(M, p, bias, sp.lambda, sp.gate_tol, beta, null);
-        (void)ok;  // (gated: a failed iteration is "rank-deficient", never a retry)
-        fl[k] = null ? 1 : 0;
-        for (int r = 0; r < pp; ++r) co[(size_t)k * pp + r] = (T)beta[r];
+        for (int64_t k = k0; k < k1; ++k) {
+            std::copy(rec.begin() + k * q * q, rec.begin() + (k + 1) * q * q, M.begin());
+            bool null = false;
+            if (!rows.empty() && rows[k + 1] - rows[k] < pp) null = true, beta.assign(pp, NAN);  // "#Data < #features"
+            else (void)host_svd_gated(M, p, bias, sp.lambda, sp.gate_tol, beta, null);  // (gated: a failed iteration is "rank-deficient", never a retry)
+            fl[k] = null ? 1 : 0;
+            for (int r = 0; r < pp; ++r) co[(size_t)k * pp + r] = (T)beta[r];
+        }
+    };
+    // (a 65 x 65 Jacobi SVD is about a millisecond: beyond a few dozen systems the set is split over up to 16 host threads)
+    const int nt = (int)std::min<int64_t>(std::min<int64_t>(16, std::max(1u, std::thread::hardware_concurrency())), (n + 31) / 32);
+    if (nt <= 1) {
+        work(0, n);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t) th.emplace_back(work, n * t / nt, n * (t + 1) / nt);
+        for (auto& t : th) t.join();
     }
     PDS_HIP_CHECK(hipMemcpyAsync(d_co, co.data(), co.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
     PDS_HIP_CHECK(hipMemcpyAsync(d_fl, fl.data(), fl.size(), hipMemcpyHostToDevice, ctx->stream));

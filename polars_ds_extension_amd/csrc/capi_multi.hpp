@@ -121,8 +121,7 @@ template <typename T>
 static int lr_by_key_multi_unordered(pds_ctx* const* ctxs, int n_ctx, const T* const* cols, const int64_t* keys, int n_feat, int64_t n_rows,
                                      const pds_lr_params* prm, int64_t max_groups, int64_t* out_keys, T* coeffs, uint8_t* is_null,
                                      int64_t* n_groups) {
-    const char* ks_env = std::getenv("PDS_KEYED_SORT");
-    if ((ks_env && ks_env[0] == '1') || (prm->solver == PDS_SOLVER_SVD && prm->singular_x_tol > 0.0)) return PDS_ERR_UNSUPPORTED;
+    if (ctxs[0]->opt_keyed_sort || (prm->solver == PDS_SOLVER_SVD && prm->singular_x_tol > 0.0)) return PDS_ERR_UNSUPPORTED;
     if (n_ctx < 2 || n_feat > 16 || n_rows < ((int64_t)1 << 17) || n_rows >= ((int64_t)1 << 31)) return PDS_ERR_UNSUPPORTED;
     const int S = n_ctx, nc = n_feat + 1, pp = n_feat + (prm->add_bias ? 1 : 0);
     std::vector<int64_t> bounds(S + 1);
@@ -165,6 +164,8 @@ static int lr_by_key_multi_unordered(pds_ctx* const* ctxs, int n_ctx, const T* c
         std::string err;
     };
     std::vector<Slot> slot(S);
+    bool any_peer = false;
+    for (int c = 1; c < S; ++c) any_peer = any_peer || ctxs[c]->device != ctxs[0]->device;
     auto build = [&](int c) {
         Slot& me = slot[c];
         try {
@@ -174,10 +175,21 @@ static int lr_by_key_multi_unordered(pds_ctx* const* ctxs, int n_ctx, const T* c
                 const int64_t r0 = bounds[c], rows = bounds[c + 1] - r0;
                 size_t need = 4096 + up((size_t)rows * 8) + (size_t)nc * up((size_t)rows * sizeof(T)) + up(sizeof(T*) * 18) + 256 +
                               keyed_partition_workspace<T>(n_feat, rows, buckets);
-                // (first context: group list, results, and room for a peer's table -- bounded by the partition workspace of zero rows)
+                // (first context: group list, results, and -- only when some context sits on another device -- room for a peer's table,
+                //  bounded by the partition workspace of zero rows)
                 if (c == 0) need += 2 * up((size_t)(cap + 1) * 8) + up((size_t)cap * pp * sizeof(T)) + up((size_t)cap) +
-                                    keyed_partition_workspace<T>(n_feat, 0, buckets);
-                if (int rc = ensure_ws(ctx, ctx->keyed, need)) return rc;
+                                    (any_peer ? keyed_partition_workspace<T>(n_feat, 0, buckets) : 0);
+                // S id-indexed tables can be several times the frame: a context that cannot get its workspace hands the call back to the
+                // single-context route (which sorts or partitions the whole frame in one workspace) instead of failing it
+                if (ctx->keyed.bytes < need) {
+                    size_t free_b = 0, total_b = 0;
+                    PDS_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+                    if (need > free_b + ctx->keyed.bytes) return PDS_ERR_UNSUPPORTED;
+                }
+                if (ensure_ws(ctx, ctx->keyed, need) != PDS_OK) {
+                    (void)hipGetLastError();
+                    return PDS_ERR_UNSUPPORTED;
+                }
                 char* w = static_cast<char*>(ctx->keyed.ptr);
                 auto take = [&](size_t b) { char* r = w; w += up(b); return r; };
                 int64_t* d_keys = reinterpret_cast<int64_t*>(take((size_t)rows * 8));
@@ -215,6 +227,8 @@ static int lr_by_key_multi_unordered(pds_ctx* const* ctxs, int n_ctx, const T* c
         build(0);
         for (auto& t : th) t.join();
     }
+    for (int c = 0; c < S; ++c)
+        if (slot[c].rc == PDS_ERR_UNSUPPORTED) return PDS_ERR_UNSUPPORTED;  // (no room for a context's table: the single-context route)
     for (int c = 0; c < S; ++c)
         if (slot[c].rc) return fail(slot[c].rc, slot[c].err.empty() ? std::string("sliced fit failed") : slot[c].err);
     // ---- the exchange step: every other context's table into the first one's

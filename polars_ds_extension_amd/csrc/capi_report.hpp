@@ -16,7 +16,7 @@ static int report_second_pass(pds_ctx* ctx, const DeviceCols<T>& dc, int p, int6
     // residuals, sum e^2 and the meat in ONE pass over the frame (the report is two streams, not three, and the n-row
     // weight vector never exists).  HC2 / HC3 add the leverages (O(p'^2) per row, WM = 4).  Weighted frames and more than 16
     // features: pass2_kernel + a weighted Gram build.
-    static const bool no_fuse = [] { const char* e = std::getenv("PDS_REPORT_NO_FUSE"); return e && e[0] == '1'; }();
+    static const bool no_fuse = [] { const char* e = dev_env("PDS_REPORT_NO_FUSE"); return e && e[0] == '1'; }();
     if (hc == 1 && !weighted && p <= kMaxFeatSmall && !no_fuse)
         return launch_moments<T>(ctx, dc, p, n_rows, false, d_mom2, d_beta, bias, d_sums);
     if (hc >= 2 && !weighted && p <= kMaxFeatSmall && !no_fuse && d_inv) {  // ... and the leverages too: O(p'^2) per row in the same pass

@@ -109,12 +109,23 @@ struct pds_ctx {
     std::vector<hipEvent_t> ev_pool;
     struct EvPair { int kind; hipEvent_t a, b; };
     std::vector<EvPair> ev_pending;
+    // behaviour switches of the context (pds_ctx_set_option); their defaults come from the environment once, at pds_ctx_create
+    bool opt_keyed_sort = false;       // "keyed_sort" / PDS_KEYED_SORT=1: unordered keys always take the sorting route (determinism)
+    bool opt_wide_f32_native = false;  // "wide_f32_native" / PDS_WIDE_F32_NATIVE=1: f32 Gram beyond 64 features on the f32 matrix instructions
     double kind_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long kind_count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<float> kind_samples[8];  // the individual bracketed durations (ms), newest kept up to 4096 per class
 };
 
 namespace pds {
+
+// Development switches -- the A/B alternative of a default that won its measurement, timing experiments -- exist only in libraries
+// built with EXTRA=-DPDS_DEV_SWITCHES (tools/README.md).  A product build compiles the default in and never looks them up.
+#ifdef PDS_DEV_SWITCHES
+inline const char* dev_env(const char* name) { return std::getenv(name); }
+#else
+inline const char* dev_env(const char*) { return nullptr; }
+#endif
 
 // kernel classes for the timing hooks
 enum { kKindMoments = 0, kKindGroupedMoments = 1, kKindSolve = 2, kKindPass2 = 3, kKindRolling = 4, kKindIter = 5 };

@@ -638,7 +638,7 @@ int launch_grouped_fused(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int6
     sd.inv_tol = sd.gate_on ? 1.0 / sp.gate_tol : HUGE_VAL;
     if (n_groups <= 0) return PDS_OK;
     if (n_groups >= (1ll << 31)) return fail(PDS_ERR_INVALID, "internal: fused grouped kernel counts groups per wave in 32 bits");
-    const char* piv = std::getenv("PDS_GROUPED_PIVOTED");
+    const char* piv = dev_env("PDS_GROUPED_PIVOTED");
     const bool chol = sd.gate_on && !(piv && piv[0] == '1');
     // solver = "choleskey" IS this kernel's factorisation (llt + the 2 sum ln L_ii gate, lr_solvers.rs:369-380); for "qr"
     // (default) and "svd" the kernel answers the clear cases and leaves the rest to the pivoted QR below

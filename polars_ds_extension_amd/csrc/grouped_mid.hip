@@ -985,7 +985,7 @@ int launch_grouped_stream(pds_ctx* ctx, const DeviceCols<double>& dc, int p, int
     // (the row count of the chunk is not known on the host: the frame's is an upper bound)
     const int64_t waves = std::min<int64_t>((int64_t)ctx->num_cus * kMidWavesPerCu, std::max<int64_t>(1, n_frame / (8 * MD::HR)));
 #ifdef PDS_DEV_SWITCHES  // timing experiments of development builds (EXTRA=-DPDS_DEV_SWITCHES): wrong results with it
-    const char* dbg = std::getenv("PDS_GMID_DEBUG");
+    const char* dbg = dev_env("PDS_GMID_DEBUG");
 #else
     const char* dbg = nullptr;
 #endif
@@ -1143,13 +1143,13 @@ int launch_grouped_mid_fused(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, 
     PDS_HIP_CHECK(hipMemsetAsync(sa.side_rec, 0, (size_t)waves * q * q * 8, ctx->stream));
     PDS_HIP_CHECK(hipMemsetAsync(sa.side_list, 0xFF, (size_t)waves * 4, ctx->stream));
     constexpr int lds = MD::LDS_BYTES + kMidSolveScratch;
-    const char* pair_env = std::getenv("PDS_GROUPED_MID_PAIRED");
+    const char* pair_env = dev_env("PDS_GROUPED_MID_PAIRED");
     const bool paired = !(pair_env && pair_env[0] == '0') && waves % 4 == 0;
     if (!F64 && !paired) return PDS_ERR_UNSUPPORTED;  // (f32 frames: the paired form only)
     {
         KernelTimer timer(ctx, kKindGroupedMoments);
 #ifdef PDS_DEV_SWITCHES  // timing experiments of development builds (EXTRA=-DPDS_DEV_SWITCHES): wrong results with it
-        const char* dbg = std::getenv("PDS_GMID_DEBUG");
+        const char* dbg = dev_env("PDS_GMID_DEBUG");
 #else
         const char* dbg = nullptr;
 #endif
@@ -1170,9 +1170,9 @@ int launch_grouped_mid_fused(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, 
                                debug, sa);
         };
         if (paired) {
-            const char* yc_env = std::getenv("PDS_GROUPED_MID_YC");  // (development: '0' keeps the side sums of the 31 / 32-feature form)
+            const char* yc_env = dev_env("PDS_GROUPED_MID_YC");  // (development: '0' keeps the side sums of the 31 / 32-feature form)
             const bool yc = !F64 || !(yc_env && yc_env[0] == '0');  // (f32 frames have the ones / target column form only)
-            const char* nq_env = std::getenv("PDS_GROUPED_MID_QUAD");  // (development: '0' keeps the 16 x 16 x 4 form of the second block)
+            const char* nq_env = dev_env("PDS_GROUPED_MID_QUAD");  // (development: '0' keeps the 16 x 16 x 4 form of the second block)
             if (p <= 18 && yc && !(nq_env && nq_env[0] == '0')) launch_paired(grouped_mid_stream_kernel<2, 24, true, true, 1, T>);
             else if (p <= 22 && yc && !(nq_env && nq_env[0] == '0')) launch_paired(grouped_mid_stream_kernel<2, 24, true, true, 2, T>);
             else if (p <= 24 && (yc || !F64)) launch_paired(grouped_mid_stream_kernel<2, 24, true, true, 0, T>);
@@ -1194,7 +1194,7 @@ int launch_grouped_mid_fused(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, 
     PDS_HIP_CHECK(hipMemcpyAsync(h_counts, d_counts, sizeof(h_counts), hipMemcpyDeviceToHost, ctx->stream));
     PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
 #ifdef PDS_DEV_SWITCHES
-    if (std::getenv("PDS_GMID_VERBOSE")) std::fprintf(stderr, "grouped_mid_fused: waves %lld marked %u side %u\n", (long long)waves, h_counts[0], h_counts[1]);
+    if (dev_env("PDS_GMID_VERBOSE")) std::fprintf(stderr, "grouped_mid_fused: waves %lld marked %u side %u\n", (long long)waves, h_counts[0], h_counts[1]);
 #endif
     if (h_counts[0] > kMidMarkCap) return PDS_ERR_UNSUPPORTED;  // (every group will be answered by the record pipeline instead)
     if (h_counts[1] > 0) {

@@ -81,7 +81,7 @@ PartLayout make_layout(int p) {
     int shift = 0;
     while ((2 << shift) <= kAccumThreads / accum_tpi(L.nv)) ++shift;
 #ifdef PDS_DEV_SWITCHES  // (development builds only: EXTRA=-DPDS_DEV_SWITCHES; the accumulate launch refuses a foreign bucket width)
-    if (const char* e = std::getenv("PDS_PART_SHIFT")) shift = std::atoi(e);
+    if (const char* e = dev_env("PDS_PART_SHIFT")) shift = std::atoi(e);
 #endif
     L.shift = shift;
     return L;
@@ -496,7 +496,7 @@ int launch_accum(pds_ctx* ctx, unsigned grid, const PartLayout& L, const char* r
     auto kern = part_accum_kernel<T, PC, PPR>;
     if (lds > 64 * 1024) PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 #ifdef PDS_DEV_SWITCHES  // timing experiments of development builds (EXTRA=-DPDS_DEV_SWITCHES): the results are wrong with it
-    const char* dbg = std::getenv("PDS_PART_DEBUG");
+    const char* dbg = dev_env("PDS_PART_DEBUG");
 #else
     const char* dbg = nullptr;
 #endif
@@ -608,7 +608,7 @@ int keyed_partition_build(pds_ctx* ctx, const T* const* d_cols, const int64_t* d
     PDS_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(d_temp, temp_bytes, (const unsigned*)counts, starts, (int)ncnt, s));
     PDS_HIP_CHECK(hipMemcpyAsync(cursor, starts, ncnt * 4, hipMemcpyDeviceToDevice, s));
     // ---- 2. scatter
-    static const int scatter_bpc = [] { const char* e = std::getenv("PDS_PART_SCATTER_BPC"); return e ? std::max(1, std::atoi(e)) : 6; }();  // (2: 7.1 ms, 4: 4.76, 6: 4.59, 8: 5.52 on the C3 frame -- tools/gpu_scatter_bpc.sh)
+    static const int scatter_bpc = [] { const char* e = dev_env("PDS_PART_SCATTER_BPC"); return e ? std::max(1, std::atoi(e)) : 6; }();  // (2: 7.1 ms, 4: 4.76, 6: 4.59, 8: 5.52 on the C3 frame -- tools/gpu_scatter_bpc.sh)
     int sb = (int)std::min<int64_t>(nchunks, (int64_t)ctx->num_cus * scatter_bpc);
     sb = std::max(kPartStreams, sb / kPartStreams * kPartStreams);
     const int ppr = L.rs / 16;

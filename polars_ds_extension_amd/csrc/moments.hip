@@ -821,7 +821,7 @@ int launch_moments_rowmajor(pds_ctx* ctx, const T* d_X, int64_t ld, const T* d_y
     double* partials = ctx->partials;
     KernelTimer timer(ctx, kKindMoments);
     if constexpr (sizeof(T) == 8) {
-        static const bool narrow = [] { const char* e = std::getenv("PDS_ROWMAJOR_NARROW"); return e && e[0] == '1'; }();  // (A/B)
+        static const bool narrow = [] { const char* e = dev_env("PDS_ROWMAJOR_NARROW"); return e && e[0] == '1'; }();  // (A/B)
         if (!narrow)
             hipLaunchKernelGGL(moments_rowmajor_f64_kernel, dim3(nblocks), dim3(256), (size_t)kWaves * (kPartStride + 768) * sizeof(double),
                                ctx->stream, d_X, ld, d_y, n_feat, n_rows, partials);

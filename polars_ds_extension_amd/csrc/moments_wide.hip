@@ -885,7 +885,7 @@ static int launch_moments_wide_w(pds_ctx* ctx, const DeviceCols<T>& dc, int n_fe
     if constexpr (sizeof(T) == 4) {
         if (tail_narrow && nb_main > 0 && !done1) {
             fused = true;
-            const char* e128 = std::getenv("PDS_WIDE_TILE128");  // A/B: keep the 128 x 128 tile
+            const char* e128 = dev_env("PDS_WIDE_TILE128");  // A/B: keep the 128 x 128 tile
             if (SPLIT && nb_main >= 2 && nb_main % 2 == 0 && !(e128 && e128[0] == '1')) {
                 constexpr int lds256 = kS2Stage * (int)sizeof(unsigned);
                 PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_wide_split256_kernel<WEIGHTED>),
@@ -942,14 +942,13 @@ template <typename T>
 int launch_moments_wide(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, bool weighted, T* d_moments) {
     {
         // 17 .. 64 features: the streaming kernel of moments_mid.hip, both precisions (PDS_MID_GRAM=0 keeps the compact tile forms: A/B)
-        const char* e = std::getenv("PDS_MID_GRAM");
+        const char* e = dev_env("PDS_MID_GRAM");
         if (n_feat <= 64 && !(e && e[0] == '0')) return launch_moments_mid<T>(ctx, dc, n_feat, n_rows, weighted, d_moments);
     }
     if constexpr (sizeof(T) == 4) {
         // f32: products on the bf16 matrix cores as three-plane splits (2.7x the f32 matrix-core rate at f32 accuracy);
-        // PDS_WIDE_F32_NATIVE=1 keeps v_mfma_f32_32x32x2_f32 (A/B, and the exact-fmaf-chain arithmetic)
-        const char* e = std::getenv("PDS_WIDE_F32_NATIVE");  // read per call: the parity tests run both arithmetics
-        if (!(e && e[0] == '1'))
+        // the context option "wide_f32_native" keeps v_mfma_f32_32x32x2_f32 (A/B, and the exact-fmaf-chain arithmetic)
+        if (!ctx->opt_wide_f32_native)  // (context option "wide_f32_native"; default from PDS_WIDE_F32_NATIVE at pds_ctx_create)
             return weighted ? launch_moments_wide_w<T, true, true>(ctx, dc, n_feat, n_rows, d_moments)
                             : launch_moments_wide_w<T, false, true>(ctx, dc, n_feat, n_rows, d_moments);
     }

@@ -386,7 +386,7 @@ int launch_pass2(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_ro
         if constexpr (std::is_same<T, double>::value) {
             // 17 .. 64 f64 features: the leverages as an n x p' x p' product on the matrix cores (leverage_mid.hip);
             // PDS_LEVERAGE_VALU=1 keeps the per-row vector-ALU form below (A/B)
-            const char* e = std::getenv("PDS_LEVERAGE_VALU");
+            const char* e = dev_env("PDS_LEVERAGE_VALU");
             if (hc_mode >= 2 && n_feat <= 64 && !(e && e[0] == '1')) {
                 PDS_HIP_CHECK(hipGetLastError());
                 const int rc = launch_leverage_mid(ctx, dc, n_feat, add_bias ? 1 : 0, n_rows, d_inv, hc_mode, s_rows);

@@ -50,13 +50,7 @@ struct PinnedPool {
     // the per-row results of the headline frame are two 0.8 GB blocks: with 1 GiB one of them was pinned afresh on every call, +40 ms).
     // Pinned pages are taken from every other process on the host, so the cache is bounded, evicts its largest blocks first when a
     // returning block would exceed the bound, and serves a request from any cached block up to twice its size.
-    static size_t cache_cap() {
-        static const size_t cap = [] {
-            const char* e = std::getenv("PDS_PLUGIN_PINNED_CACHE_MB");
-            return e ? (size_t)std::max<long long>(0, std::atoll(e)) << 20 : (size_t)4 << 30;
-        }();
-        return cap;
-    }
+    static size_t cache_cap() { return settings().pinned_cache_bytes; }
     std::mutex m;
     std::multimap<size_t, void*> free_blocks;   // size -> block
     std::map<void*, size_t> live;               // blocks handed out (size)
@@ -71,8 +65,7 @@ struct PinnedPool {
         return (bytes + q - 1) / q * q;
     }
     void* take(size_t bytes) {
-        static const bool off = [] { const char* e = std::getenv("PDS_PLUGIN_PINNED_RESULTS"); return e && e[0] == '0'; }();
-        if (off || bytes < kMinBytes || bytes > kMaxBytes) return nullptr;
+        if (!settings().pinned_results || bytes < kMinBytes || bytes > kMaxBytes) return nullptr;
         const size_t sz = size_class(bytes);
         {
             std::lock_guard<std::mutex> g(m);

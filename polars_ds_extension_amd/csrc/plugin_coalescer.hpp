@@ -251,10 +251,4 @@ class LrCoalescer {
     }
 };
 
-inline bool coalescing_enabled() {
-    static const bool on = [] {
-        const char* e = std::getenv("PDS_PLUGIN_COALESCE");
-        return !(e && e[0] == '0');
-    }();
-    return on;
-}
+inline bool coalescing_enabled() { return settings().coalesce != 0; }

@@ -7,8 +7,7 @@ pds_ctx* thread_ctx() {
     // Polars calls plugin symbols from many rayon threads: one context (stream + workspace) per thread
     thread_local pds_ctx* ctx = nullptr;
     if (!ctx) {
-        const char* dev = std::getenv("PDS_DEVICE");
-        if (pds_ctx_create(dev ? std::atoi(dev) : 0, &ctx) != PDS_OK) raise(pds_last_error());
+        if (pds_ctx_create(settings().device, &ctx) != PDS_OK) raise(pds_last_error());
     }
     return ctx;
 }
@@ -33,12 +32,13 @@ struct MultiContexts {
         if (tried) return ctxs;
         tried = true;
         std::vector<int> devs;
-        const char* e = std::getenv("PDS_DEVICES");
-        if (e && std::string(e) == "all") {
+        const std::string devices = settings().devices;
+        const char* e = devices.c_str();
+        if (devices == "all") {
             int n = 0;
             if (pds_device_count(&n) == PDS_OK)
                 for (int d = 0; d < n; ++d) devs.push_back(d);
-        } else if (e && *e) {
+        } else if (*e) {
             std::string tok;
             for (const char* c = e;; ++c) {
                 if (*c == ',' || *c == 0) {
@@ -50,12 +50,8 @@ struct MultiContexts {
                 }
             }
         }
-        if (devs.empty()) {
-            const char* d = std::getenv("PDS_DEVICE");
-            devs.push_back(d ? std::atoi(d) : 0);
-        }
-        const char* pc = std::getenv("PDS_BY_KEY_CONTEXTS");
-        const int per = pc ? std::max(1, std::atoi(pc)) : 2;
+        if (devs.empty()) devs.push_back(settings().device);
+        const int per = settings().by_key_contexts;
         for (int k = 0; k < per; ++k)      // (device-major interleave: slice s goes to device s mod n_dev first)
             for (int d : devs) {
                 pds_ctx* c = nullptr;
@@ -64,16 +60,13 @@ struct MultiContexts {
         return ctxs;
     }
 };
-// PDS_REFERENCE_QUIRKS=1 (read per call): answer the two places where the reference's outputs are accidents of its
+// PDS_REFERENCE_QUIRKS=1 (plugin_settings.hpp): answer the two places where the reference's outputs are accidents of its
 // result assembly exactly as it does instead of the way DESIGN.md section 7 argues for --
 //   pl_lr_pred, null_policy "ignore", nulls present: ONE row {pred: null, resid: null} (the dummy mask of
 //     series_to_mat_for_lr has length 1 and is false, linear_regression.rs:194-197, and :790-806 builds from the mask);
 //   pl_recursive_lr, skip / fill, nulls present: pred of the j-th fitted row is formed from compacted row j, not from the
 //     row the coefficients belong to (:1158-1166 reads x.get(i..i+1) where the null-free branch reads row m + i).
-bool reference_quirks() {
-    const char* e = std::getenv("PDS_REFERENCE_QUIRKS");
-    return e && e[0] == '1';
-}
+bool reference_quirks() { return settings().reference_quirks; }
 
 template <typename T> struct Api;
 template <> struct Api<double> {

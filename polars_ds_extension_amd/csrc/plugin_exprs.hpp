@@ -74,8 +74,7 @@ void do_pl_lr(SeriesExport* in, size_t n_in, const Kwargs& kw, SeriesExport* out
             req.resid = as<T>(resid_b);
             valid.assign(n, 1);
         }
-        static const bool bypass = [] { const char* e = std::getenv("PDS_PLUGIN_COALESCE"); return e && e[0] == '2'; }();
-        if (bypass) LrCoalescer<T>::run_one(&req);
+        if (settings().coalesce == 2) LrCoalescer<T>::run_one(&req);
         else LrCoalescer<T>::instance().submit(&req);
         if (!req.error.empty()) raise(req.error);
         is_null = req.is_null;
@@ -441,13 +440,11 @@ void do_lr_by(SeriesExport* in, size_t n_in, const Kwargs& kw, SeriesExport* out
             resid_b = raw_buffer<T>((size_t)n);
             row_null.resize(n);
             // large frames: the sliced route (as for the coefficient fit below), slices independent
-            const char* e_min = std::getenv("PDS_BY_KEY_MULTI_MIN_ROWS");
-            const int64_t multi_min = e_min ? (int64_t)std::atoll(e_min) : (int64_t)1 << 22;
-            const char* e_sl = std::getenv("PDS_BY_KEY_SLICES");
+            const int64_t multi_min = settings().by_key_multi_min_rows;
             std::unique_lock<std::mutex> multi(MultiContexts::get().busy, std::defer_lock);
             if (n >= multi_min && multi_min > 0 && multi.try_lock() && MultiContexts::get().contexts().size() > 1) {
                 const auto& cx = MultiContexts::get().contexts();
-                check(Api<T>::by_key_pred_multi(cx.data(), (int)cx.size(), e_sl ? std::atoi(e_sl) : 0, ptrs.data(), wts, ikey, n_feat, n, &prm,
+                check(Api<T>::by_key_pred_multi(cx.data(), (int)cx.size(), settings().by_key_slices, ptrs.data(), wts, ikey, n_feat, n, &prm,
                                                 as<T>(pred_b), as<T>(resid_b), row_null.data()));
             } else {
                 check(Api<T>::by_key_pred(thread_ctx(), ptrs.data(), wts, ikey, n_feat, n, PDS_HOST, &prm, n, nullptr, nullptr, nullptr,
@@ -465,11 +462,9 @@ void do_lr_by(SeriesExport* in, size_t n_in, const Kwargs& kw, SeriesExport* out
                 // large unweighted frames: the sliced route -- several contexts (devices: PDS_DEVICES; per device:
                 // PDS_BY_KEY_CONTEXTS), every slice over its context's stream / its device's PCIe link (capi_multi.hpp); it
                 // falls back to the single-context entry point by itself when the keys are not in order
-                // (read per call: PDS_BY_KEY_MULTI_MIN_ROWS=0 switches the route off, PDS_BY_KEY_SLICES sets the slice count)
-                const char* e_min = std::getenv("PDS_BY_KEY_MULTI_MIN_ROWS");
-                const int64_t multi_min = e_min ? (int64_t)std::atoll(e_min) : (int64_t)1 << 22;
-                const char* e_sl = std::getenv("PDS_BY_KEY_SLICES");
-                const int slices = e_sl ? std::atoi(e_sl) : 0;
+                // (plugin_settings.hpp: PDS_BY_KEY_MULTI_MIN_ROWS=0 switches the route off, PDS_BY_KEY_SLICES sets the slice count)
+                const int64_t multi_min = settings().by_key_multi_min_rows;
+                const int slices = settings().by_key_slices;
                 std::unique_lock<std::mutex> multi(MultiContexts::get().busy, std::defer_lock);
                 if (weighted) {
                     rc = Api<T>::by_key_pred(thread_ctx(), ptrs.data(), wts, ikey, n_feat, n, PDS_HOST, &prm, cap, keys.data(), as<T>(cobuf),

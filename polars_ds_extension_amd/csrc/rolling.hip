@@ -69,7 +69,6 @@ struct RollArgs {
 
 }  // namespace pds
 #include "rolling_seg_dev.hpp"  // (needs RollArgs)
-#include "rolling_pair_dev.hpp"
 namespace pds {
 
 // fetch_row: raw z (PP entries, padding = 0, bias entry = 1) and y of row r (zeros when r is out of range) -- only
@@ -435,7 +434,7 @@ static int launch_pp_f(pds_ctx* ctx, const DeviceCols<T>& dc, RollArgs ra, bool 
     const int64_t ntiles = (ra.n + ra.tile_rows - 1) / ra.tile_rows;
     int64_t nb = (ntiles + kRollWaves - 1) / kRollWaves;
     int per_cu = 2 * PDS_ROLL_WPE;  // blocks of kRollWaves waves: PDS_ROLL_WPE waves per SIMD
-    if (const char* e = std::getenv("PDS_ROLL_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e));
+    if (const char* e = dev_env("PDS_ROLL_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e));
     nb = std::min<int64_t>(std::max<int64_t>(nb, 1), (int64_t)ctx->num_cus * per_cu);
     auto kern0 = roll_kernel_ptr<T, PP, 0, FULLP>();
     auto kern1 = roll_kernel_ptr<T, PP, 1, FULLP>();
@@ -445,35 +444,18 @@ static int launch_pp_f(pds_ctx* ctx, const DeviceCols<T>& dc, RollArgs ra, bool 
             PDS_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // up to 8 coefficients: lane = 4 consecutive rows, running moments in registers (rolling_seg_dev.hpp); PDS_ROLLING_V1=1
     // keeps the lane = row kernel (development A/B).  The totals pass of the expanding fit stays with the first kernel.
-    static const bool v1 = [] { const char* e = std::getenv("PDS_ROLLING_V1"); return e && e[0] == '1'; }();
+    static const bool v1 = [] { const char* e = dev_env("PDS_ROLLING_V1"); return e && e[0] == '1'; }();
     bool seg = false;
     if constexpr (PP <= 8) seg = !v1;
     [[maybe_unused]] auto launch_seg = [&](auto mode_c, const double* tot) {
         if constexpr (PP <= 8) {
             constexpr int M = decltype(mode_c)::value;
-            // f64 frames whose p' is the even template width: two lanes per chain of rows, two waves per SIMD
-            // (rolling_pair_dev.hpp).  OPT-IN (PDS_ROLL_PAIR=1, read per call): parity-green, but measured SLOWER than the lane = 4
-            // rows kernel below at C4 -- rolling 6.0 vs 3.9 ms, expanding main pass 3.7 vs 3.7 ms (profiles/r04_rolling_pair_ab.txt)
-            if constexpr (std::is_same<T, double>::value && PP % 2 == 0 && FULLP != 0) {
-                const char* pe = std::getenv("PDS_ROLL_PAIR");
-                const bool pair_off = !(pe && pe[0] == '1');
-                if (!pair_off) {
-                    using PD = PairDims<PP>;
-                    const int64_t ptiles = (ra.n + kPairTile - 1) / kPairTile;
-                    int per_cu_p = 8;
-                    if (const char* e = std::getenv("PDS_ROLL_PAIR_PER_CU")) per_cu_p = std::max(1, atoi(e));
-                    const int64_t pb = std::min<int64_t>(std::max<int64_t>((ptiles + 3) / 4, 1), (int64_t)ctx->num_cus * per_cu_p);
-                    hipLaunchKernelGGL((rolling_pair_kernel<PP, M, FULLP>), dim3((unsigned)pb), dim3(64), (size_t)PD::LDS_BYTES,
-                                       ctx->stream, dc.d_ptrs, ra, tot, d_coeffs, d_pred, d_valid);
-                    return;
-                }
-            }
             constexpr int64_t tile = M == 0 ? kSegTileRoll : kSegTile;
             const int64_t seg_tiles = (ra.n + tile - 1) / tile;
             const int64_t sb = std::min<int64_t>(std::max<int64_t>(seg_tiles, 1), (int64_t)ctx->num_cus * 4);
             // window == one stage: the rows leaving the window are the previous stage's rows, kept in registers (no second read
             // stream); PDS_ROLL_OLD_STREAM=1 keeps the two-stream form for that window too (A/B)
-            static const bool old_stream = [] { const char* e = std::getenv("PDS_ROLL_OLD_STREAM"); return e && e[0] == '1'; }();
+            static const bool old_stream = [] { const char* e = dev_env("PDS_ROLL_OLD_STREAM"); return e && e[0] == '1'; }();
             if (M == 0 && ra.window == kSegStage && !old_stream) {
                 if constexpr (M == 0) {
                     using SD = SegDims<T, PP, 1>;

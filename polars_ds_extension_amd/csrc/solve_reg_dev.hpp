@@ -25,7 +25,7 @@ struct SolveRegDev {
 };
 // (host) the single-ratio bound: 1e5 unless PDS_SUSPECT_RATIO says otherwise, read per call (0: the product rule, for A/B)
 inline double solve_suspect_ratio() {
-    const char* e = std::getenv("PDS_SUSPECT_RATIO");
+    const char* e = dev_env("PDS_SUSPECT_RATIO");
     return e ? std::atof(e) : 1e5;
 }
 // suspect rule of the wave / row16 solvers (grow: product of the pivot ratios, rmax: the largest of them)

@@ -130,7 +130,7 @@ template <typename T>
 int launch_solve_wave(pds_ctx* ctx, const T* d_moments, int64_t n_sys, const SolveParams& sp, T* d_coeffs, uint8_t* d_flags,
                       const int64_t* d_rows_per_sys, void* d_ws /* solve_wave_workspace(...) bytes, reusable across calls */) {
     if (sp.p <= 16 || sp.p > 64 || !(sp.gate_tol > 0.0) || sp.lambda_on_bias || !d_flags || !d_ws) return PDS_ERR_UNSUPPORTED;
-    static const bool off = [] { const char* e = std::getenv("PDS_SOLVE_WAVE"); return e && e[0] == '0'; }();  // (A/B)
+    static const bool off = [] { const char* e = dev_env("PDS_SOLVE_WAVE"); return e && e[0] == '0'; }();  // (A/B)
     if (off) return PDS_ERR_UNSUPPORTED;
     if (n_sys <= 0) return PDS_OK;
     SolveRegDev sd;

@@ -107,6 +107,11 @@ class Context:
     def synchronize(self) -> None:
         _lib.check(self._lib.pds_ctx_synchronize(self._h))
 
+    def set_option(self, name: str, value) -> None:
+        """Behaviour switches of the context (include/pds_lstsq.h, pds_ctx_set_option): "keyed_sort", "wide_f32_native"; the
+        defaults came from PDS_KEYED_SORT / PDS_WIDE_F32_NATIVE when the context was created."""
+        _lib.check(self._lib.pds_ctx_set_option(self._h, str(name).encode(), C.c_longlong(int(value))))
+
     @property
     def num_cus(self) -> int:
         return int(self._lib.pds_ctx_num_cus(self._h))

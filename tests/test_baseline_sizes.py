@@ -208,18 +208,18 @@ def test_c5_one_million_rows_against_oracle_f32_and_f64(pds, orc):
     import os
 
     # two arithmetics for the f32 Gram beyond 16 features (moments_wide.hip): the default runs the products on the bf16 matrix
-    # cores as exact three-plane splits (1.3x faster, Gram error ~3 ulp of f32), PDS_WIDE_F32_NATIVE=1 keeps
+    # cores as exact three-plane splits (1.3x faster, Gram error ~3 ulp of f32), the context option "wide_f32_native" keeps
     # v_mfma_f32_32x32x2_f32 (the fmaf chain, ~1 ulp).  Both are held to the contract; the native one also to the
     # reference's own f32 distance.
     fits = {}
     pds.config.LIN_REG_EXPR_F64 = False
     try:
         for native in ("0", "1"):
-            os.environ["PDS_WIDE_F32_NATIVE"] = native
+            pds.default_context().set_option("wide_f32_native", int(native))
             fits[native] = pds.lin_reg(*[X[j] for j in range(p)], target=y, l1_reg=0.01, l2_reg=0.01, tol=1e-5)
     finally:
         pds.config.LIN_REG_EXPR_F64 = True
-        del os.environ["PDS_WIDE_F32_NATIVE"]
+        pds.default_context().set_option("wide_f32_native", 0)
     b = fits["0"]
     assert b.dtype == np.float32
     Xh = np.asfortranarray(X.cpu().numpy().T)
@@ -285,7 +285,7 @@ def test_c5_configured_size_gram_and_descent(pds, orc, n):
     pds.config.LIN_REG_EXPR_F64 = False
     try:
         for native in ("0", "1"):
-            os.environ["PDS_WIDE_F32_NATIVE"] = native
+            pds.default_context().set_option("wide_f32_native", int(native))
             name = "f32 matrix cores" if native == "1" else "bf16 x 3 split"
             M = np.asarray(pds.gram_moments(*cols, target=y), dtype=np.float64)  # Z'Z, Z = [X | 1 | y]
             assert M.shape == (p + 2, p + 2)
@@ -312,4 +312,4 @@ def test_c5_configured_size_gram_and_descent(pds, orc, n):
             assert np.array_equal(np.abs(b) > 1e-6, np.abs(truth) > 1e-6)
     finally:
         pds.config.LIN_REG_EXPR_F64 = True
-        os.environ.pop("PDS_WIDE_F32_NATIVE", None)
+        pds.default_context().set_option("wide_f32_native", 0)

@@ -664,6 +664,51 @@ def test_exchange_steps_compose_the_multi_device_paths_through_the_c_abi(pds, or
         cx.close()
 
 
+def test_exchange_steps_and_unordered_by_key_across_two_devices(pds, orc):
+    """The CROSS-DEVICE legs (hipMemcpyPeerAsync in pds_allreduce_sum_* / pds_scatter_rows_* / pds_gather_* and the peer table copy of the
+    unordered multi-context by-key route, capi_multi.hpp): contexts on two different devices of one process.  Skipped on a one-GPU box --
+    which is every box this repository has been run on so far: until this test runs somewhere, those legs are unverified on hardware
+    (INTEGRATION.md "what has never been run")."""
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two devices in one process")
+    rng = np.random.default_rng(4242)
+    ctxs = [pds.Context(0), pds.Context(1)]
+    n, p = 400_000, 5
+    X = rng.normal(size=(n, p))
+    y = X @ rng.normal(size=p) + 0.3 + 0.1 * rng.normal(size=n)
+    cols_dev = [dev(y)] + cols_of(X)
+    bounds = [0, n // 2 + 3, n]
+    shards = pds.scatter_rows(ctxs, cols_dev, bounds)
+    assert all(t.device.index == 1 for t in shards[1])
+    for c in range(2):
+        assert all(torch.equal(s.cpu(), full[bounds[c]:bounds[c + 1]].cpu()) for s, full in zip(shards[c], cols_dev))
+    moms = [pds.gram_moments(*sh[1:], target=sh[0], ctx=ctxs[c], out_device=True).contiguous() for c, sh in enumerate(shards)]
+    want = moms[0].cpu() + moms[1].cpu()
+    pds.allreduce_sum(ctxs, moms)
+    assert all(torch.allclose(m.cpu(), want, rtol=1e-14, atol=0.0) for m in moms)
+    b = pds.lin_reg_from_moments(moms[1], add_bias=True, ctx=ctxs[1])
+    b = b.cpu().numpy() if hasattr(b, "cpu") else np.asarray(b)
+    assert nrel(b.ravel(), orc.pl_lr(X, y, add_bias=True)) < F64_TOL
+    blocks = [torch.arange(64 * (c + 1), dtype=torch.float64, device=f"cuda:{c}") + 1000.0 * c for c in range(2)]
+    assert torch.equal(pds.gather(ctxs, blocks).cpu(), torch.cat([b_.cpu() for b_ in blocks]))
+    # unordered keys over the two devices: per-context moment tables, the peer's table copied across and added, one solve
+    G = 3000
+    sizes = rng.integers(40, 160, size=G)
+    key = np.repeat(np.arange(G, dtype=np.int64) * 2 + 11, sizes)
+    N = len(key)
+    Xg = rng.normal(size=(N, 4))
+    yg = Xg @ rng.normal(size=4) + 1e-3 * key + 0.1 * rng.normal(size=N)
+    perm = rng.permutation(N)
+    k2, c2, n2 = pds.lin_reg_by_key_multi(*[np.ascontiguousarray(Xg[perm, j]) for j in range(4)], target=yg[perm], key=key[perm], contexts=ctxs)
+    k1, c1, n1 = pds.lin_reg_by_key(*[np.ascontiguousarray(Xg[perm, j]) for j in range(4)], target=yg[perm], key=key[perm], ctx=ctxs[0])
+    assert np.array_equal(np.asarray(k2), np.asarray(k1)) and np.array_equal(np.asarray(n2), np.asarray(n1))
+    assert np.max(np.abs(np.asarray(c2) - np.asarray(c1))) < 1e-9
+    for cx in ctxs:
+        cx.close()
+
+
 @pytest.mark.parametrize("n_ctx,n_slices", [(1, 3), (2, 0), (3, 7), (4, 4)])
 def test_by_key_multi_context_equals_single_context(pds, orc, n_ctx, n_slices):
     """One host frame through several contexts of ONE process (pds_lr_by_key_multi_*: the route by which a Polars plugin can
@@ -1620,12 +1665,13 @@ def test_rolling_skip_non_finite(pds, orc):
 
 @pytest.mark.parametrize("pp,bias", [(2, False), (2, True), (4, True), (6, False), (8, False), (8, True)])
 @pytest.mark.parametrize("n,w", [(33, 5), (4099, 31), (4096 * 4 + 5, 32), (40_013, 256), (70_001, 1000)])
-def test_rolling_pair_kernel_shapes(pds, monkeypatch, pp, bias, n, w):
-    """rolling_pair_dev.hpp (f64, even p'; opt-in PDS_ROLL_PAIR=1): two lanes per chain of rows, four tiles per wave.  Frame lengths off every
-    granule (2-row pieces, 4-row chains, 32-row stages, 4096-row tiles, 4-tile rounds), windows shorter / longer than a stage and a tile."""
+def test_rolling_even_widths_frame_granules(pds, pp, bias, n, w):
+    """Rolling + expanding fits at even p' with ridge: frame lengths off every granule of the kernels (2-row pieces, 4-row chains, 32- and
+    256-row stages, 4096- / 16384-row tiles), windows shorter / longer than a stage and a tile, direct window solves at the granule edges.
+    (Written for round 4's two-lanes-per-chain kernel -- tools/experiments/rolling_pair_dev.hpp.txt, measured slower and parked --; the
+    shapes now run against the product kernel.)"""
     if w < pp:
         pytest.skip("window shorter than the coefficient count")
-    monkeypatch.setenv("PDS_ROLL_PAIR", "1")
     rng = np.random.default_rng(1000 * pp + w)
     p = pp - (1 if bias else 0)
     X = rng.random((n, p))
@@ -1655,9 +1701,8 @@ def test_rolling_pair_kernel_shapes(pds, monkeypatch, pp, bias, n, w):
 
 
 @pytest.mark.parametrize("pp,bias,w,m", [(2, False, 10, 6), (4, True, 40, 20), (8, False, 256, 200)])
-def test_rolling_pair_kernel_non_finite_rows(pds, orc, monkeypatch, pp, bias, w, m):
-    """Non-finite rows in the pair kernel: left out of the sums, counted out of the window, NaN pred (lr_online_solvers.rs:85-89, 218-301)."""
-    monkeypatch.setenv("PDS_ROLL_PAIR", "1")
+def test_rolling_even_widths_non_finite_rows(pds, orc, pp, bias, w, m):
+    """Non-finite rows at even p': left out of the sums, counted out of the window, NaN pred (lr_online_solvers.rs:85-89, 218-301)."""
     rng = np.random.default_rng(17 + pp)
     n = 9000
     p = pp - (1 if bias else 0)
@@ -1921,8 +1966,8 @@ def test_wide_moments_f32_split_k(pds, f32, n, p):
 @pytest.mark.parametrize("n,p,weighted", [(20_011, 515, False), (9_001, 260, True), (40_000, 768, False), (16_390, 512, True)])
 def test_wide_moments_f32_256_tile(pds, f32, n, p, weighted):
     """Even block grids (p = 255..286, 511..542, 767..798) take the 256 x 256 tile of the bf16-split arithmetic: diagonal and
-    off-diagonal workgroups, the fused [1 | y] tail, ragged last stage, the weight column -- against an f64 Gram and against
-    the 128 x 128 tile and the f32 instructions on the same frame."""
+    off-diagonal workgroups, the fused [1 | y] tail, ragged last stage, the weight column -- against an f64 Gram, with both f32
+    arithmetics on the same frame."""
     import os
 
     rng = np.random.default_rng(n + p)
@@ -1933,18 +1978,17 @@ def test_wide_moments_f32_256_tile(pds, f32, n, p, weighted):
     G = Z.T @ (Z if w is None else w.astype(np.float64)[:, None] * Z)
     sc = np.sqrt(np.outer(np.diag(G), np.diag(G)))
     got = {}
-    for name, env in (("tile256", {}), ("tile128", {"PDS_WIDE_TILE128": "1"}), ("f32", {"PDS_WIDE_F32_NATIVE": "1"})):
-        os.environ.update(env)
+    for name, native in (("tile256", 0), ("f32", 1)):
+        pds.default_context().set_option("wide_f32_native", native)
         try:
             M = pds.gram_moments(*cols_of(X), target=dev(y), weights=None if w is None else dev(w))
         finally:
-            for k in env:
-                del os.environ[k]
+            pds.default_context().set_option("wide_f32_native", 0)
         assert M.dtype == np.float32 and M.shape == G.shape and np.array_equal(M, M.T)
         assert np.max(np.abs(M - G) / sc) < 3e-6, name
         got[name] = M
-    # the two tiles of the split arithmetic add the same products in the same order: bit for bit the same Gram
-    assert np.array_equal(got["tile256"], got["tile128"])
+    # (the 128 x 128 tile of the split arithmetic serves the odd block grids -- test_wide_moments_* -- and adds the same products in
+    #  the same order; forcing it onto these grids is a development switch, PDS_WIDE_TILE128 with EXTRA=-DPDS_DEV_SWITCHES)
 
 
 def test_config5_elastic_net_f32_wide(pds, orc, f32):
@@ -1964,13 +2008,13 @@ def test_config5_elastic_net_f32_wide(pds, orc, f32):
     Z = np.c_[X.astype(np.float64), np.ones(n), y.astype(np.float64)]
     G = Z.T @ Z
     # the f32 Gram beyond 16 features has two arithmetics (moments_wide.hip): products on the bf16 matrix cores as exact
-    # three-plane splits (default; measured 5.1e-7 here) or v_mfma_f32_32x32x2_f32 (PDS_WIDE_F32_NATIVE=1; 1.3e-7)
+    # three-plane splits (default; measured 5.1e-7 here) or v_mfma_f32_32x32x2_f32 (context option "wide_f32_native"; 1.3e-7)
     for native, bar in (("1", 3e-7), ("0", 1e-6)):
-        os.environ["PDS_WIDE_F32_NATIVE"] = native
+        pds.default_context().set_option("wide_f32_native", int(native))
         try:
             M = pds.gram_moments(*cols_of(X), target=dev(y))
         finally:
-            del os.environ["PDS_WIDE_F32_NATIVE"]
+            pds.default_context().set_option("wide_f32_native", 0)
         assert nrel(M, G) < bar, (native, nrel(M, G))
         assert np.array_equal(M, M.T)
     b = pds.lin_reg(*cols_of(X), target=dev(y), l1_reg=0.01, l2_reg=0.01, tol=1e-5)

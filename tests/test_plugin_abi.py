@@ -408,6 +408,7 @@ def test_reference_quirks_switch(so, orc):
     _, pred_plain = ph.call_plugin(so, "pl_lr_pred", ins, dict(LR, bias=True, null_policy="ignore"))
     assert len(pred_plain) == n
     os.environ["PDS_REFERENCE_QUIRKS"] = "1"
+    so.pds_plugin_reload_settings()  # (the plugin layer reads its environment once: plugin_settings.hpp)
     try:
         _, pred_q = ph.call_plugin(so, "pl_lr_pred", ins, dict(LR, bias=True, null_policy="ignore"))
         _, rec_q = ph.call_plugin(so, "pl_recursive_lr", ins, kw_rec)
@@ -416,6 +417,7 @@ def test_reference_quirks_switch(so, orc):
         _, pred_clean = ph.call_plugin(so, "pl_lr_pred", clean, dict(LR, bias=True, null_policy="ignore"))
     finally:
         del os.environ["PDS_REFERENCE_QUIRKS"]
+        so.pds_plugin_reload_settings()
     assert pred_q.to_pylist() == [{"pred": None, "resid": None}]
     assert len(pred_clean) == n and pred_clean.null_count == 0
     plain, rec_q = plain.to_pylist(), rec_q.to_pylist()
@@ -596,10 +598,12 @@ def test_pl_lr_by_pred_large_host_frame_takes_the_sliced_route(so, orc):
     import os
 
     os.environ["PDS_BY_KEY_MULTI_MIN_ROWS"] = "0"
+    so.pds_plugin_reload_settings()
     try:
         _, out1 = ph.call_plugin(so, "pl_lr_by_pred", ins, dict(LR, bias=True))
     finally:
         del os.environ["PDS_BY_KEY_MULTI_MIN_ROWS"]
+        so.pds_plugin_reload_settings()
     pred1 = out1.field("pred").to_numpy(zero_copy_only=False)
     assert out.field("pred").null_count == 0 and len(pred) == n
     assert np.max(np.abs(pred - pred1) / (np.abs(pred1) + 1.0)) < 1e-10
