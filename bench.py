@@ -340,26 +340,29 @@ def main() -> int:
 
 
 def _by_key(torch, pds, ctx, dev, xs, y, offsets, G, R, P):
-    """lin_reg_by_key on sorted int64 keys against lin_reg_by on the offsets of the same groups, p = P and p = 8: wall ms (median of 7)."""
+    """lin_reg_by_key on sorted int64 keys against lin_reg_by on the offsets of the same groups, p = P and p = 8: wall ms (medians of 9 alternating calls)."""
     keys = torch.arange(G, dtype=torch.int64, device=dev).repeat_interleave(R)
     out = {"workload": f"{G} groups x {R} rows, sorted int64 key column resident in HBM (0.8 GB per 1e8 rows) instead of group offsets"}
 
-    def wall(fn, reps=7):
-        fn()
-        ts = []
+    def wall_pair(fa, fb, reps=9):  # (alternating calls: a box's clocks drift over a process's first seconds)
+        for _ in range(2):
+            fa()
+            fb()
+        ta, tb = [], []
         for _ in range(reps):
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            fn()
-            torch.cuda.synchronize(dev)
-            ts.append(time.perf_counter() - t0)
-        return sorted(ts)[len(ts) // 2]
+            for f, ts in ((fa, ta), (fb, tb)):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                f()
+                torch.cuda.synchronize(dev)
+                ts.append(time.perf_counter() - t0)
+        return sorted(ta)[len(ta) // 2], sorted(tb)[len(tb) // 2]
 
     for q in sorted({P, 8}, reverse=True):
         if q > P:
             continue
-        t_off = wall(lambda: pds.lin_reg_by(*xs[:q], target=y, group_offsets=offsets, add_bias=False, ctx=ctx))
-        t_key = wall(lambda: pds.lin_reg_by_key(*xs[:q], target=y, key=keys, max_groups=G, ctx=ctx))
+        t_off, t_key = wall_pair(lambda: pds.lin_reg_by(*xs[:q], target=y, group_offsets=offsets, add_bias=False, ctx=ctx),
+                                 lambda: pds.lin_reg_by_key(*xs[:q], target=y, key=keys, max_groups=G, ctx=ctx))
         alg = G * R * (q + 2) * 8 + G * (q * 8 + 1 + 8)  # features + target + keys in; coefficients + flags + distinct keys out
         out[f"p{q}"] = {"by_key_wall_ms": round(t_key * 1e3, 4), "offsets_wall_ms": round(t_off * 1e3, 4), "ratio": round(t_key / t_off, 4),
                         "regressions_per_s": round(G / t_key, 1), "algorithmic_bytes": int(alg),

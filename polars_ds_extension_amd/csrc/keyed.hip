@@ -327,46 +327,75 @@ int keys_order_minmax(pds_ctx* ctx, const int64_t* d_keys, int64_t n, int64_t* d
 
 // second pass of the run-length encoding of an ORDERED key column: prefix = exclusive scan of key_order_minmax_kernel's slots,
 // masks = its change bits.  Group r > 0 starts at j + 1 where key j differs from its successor, r = 1 + prefix[slot of j] + (such keys
-// in front of j in the slot); group 0 starts at row 0.  A thread takes one 128-key piece: its two mask words (16 bytes, coalesced
-// across the wave) and, per set bit, one key fetch and two stores -- at a hundred rows per group about 1.3 per piece.  (Round 3 / 4
-// re-read the whole key column here: 0.8 GB per 1e8 keys against 12.5 MB of masks + 8 MB of fetched keys.)
+// in front of j in the slot); group 0 starts at row 0.  A WAVE takes 64 consecutive 128-key pieces: lane = piece reads the piece's two
+// mask words (16 bytes, coalesced) and lists its run starts in the wave's LDS list -- the ranks of a wave's starts are consecutive, so
+// entry e of the list is group 1 + prefix[first piece] + e -- and then the lanes walk the LIST: one key fetch and two coalesced stores
+// per entry, all of a wave's fetches in flight together.  (Round 3 / 4 re-read the whole key column here: 0.8 GB per 1e8 keys against
+// 12.5 MB of masks + the fetched keys; the first mask version looped over a lane's set bits with one dependent fetch per trip: 31 us.)
+constexpr int kRunListCap = 1024;  // list entries per round; a wave whose 64 pieces start more groups than that goes round again
 __global__ __launch_bounds__(256) void key_run_starts_kernel(const int64_t* __restrict__ keys, int64_t n, const uint32_t* __restrict__ prefix,
                                                              const unsigned long long* __restrict__ masks, int64_t* __restrict__ out_keys,
                                                              int64_t* __restrict__ offsets, int64_t cap) {
     typedef unsigned long long ull2 __attribute__((ext_vector_type(2), aligned(16)));
-    const int lane = threadIdx.x & 63;
+    __shared__ uint16_t list[4][kRunListCap];  // offset of a run start inside the wave's 8192 keys, minus 1 (fits 13 bits)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t head = (((uintptr_t)keys & 15) != 0 && n > 0) ? 1 : 0;
     const int64_t npieces = (n - head) / 128;
+    const unsigned long long ltl = (1ull << lane) - 1ull;
     auto put = [&](int64_t r, long long k, int64_t start) __attribute__((always_inline)) {
         if (r < cap) {
             out_keys[r] = k;
             offsets[r] = start;
         }
     };
-    for (int64_t pc = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pc < npieces; pc += (int64_t)gridDim.x * blockDim.x) {
-        const ull2 m = __builtin_nontemporal_load(reinterpret_cast<const ull2*>(masks) + pc);
-        unsigned long long bx = m.x, by = m.y;
-        if ((bx | by) == 0ull) continue;
-        const int64_t base = head + pc * 128;
-        const int64_t r0 = 1 + (int64_t)prefix[1 + pc];
-        unsigned long long rx = bx, ry = by;
-        while (rx) {  // key 2l differs from key 2l + 1: a group starts at 2l + 1
-            const int l = __builtin_ctzll(rx);
-            rx &= rx - 1;
-            const unsigned long long lt = (1ull << l) - 1ull;
-            const int64_t st = base + 2 * l + 1;
-            put(r0 + __popcll(bx & lt) + __popcll(by & lt), keys[st], st);
+    const int64_t nwt = (npieces + 63) / 64;  // wave tiles (one per wave when the grid allows: the pass is a chain of latencies,
+                                              // mask -> list -> key -> store, so it wants every tile in flight at once)
+    for (int64_t wt = (int64_t)blockIdx.x * 4 + wv; wt < nwt; wt += (int64_t)gridDim.x * 4) {
+        const int64_t pc = wt * 64 + lane;
+        ull2 m;
+        m.x = 0ull;
+        m.y = 0ull;
+        if (pc < npieces) m = __builtin_nontemporal_load(reinterpret_cast<const ull2*>(masks) + pc);
+        const unsigned long long bx = m.x, by = m.y;
+        const int c = __popcll(bx) + __popcll(by);
+        // exclusive scan of the counts over the lanes (the wave's starts in key order: piece by piece, inside a piece x before y per lane)
+        int inc = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
         }
-        while (ry) {  // key 2l + 1 differs from key 2l + 2: a group starts at 2l + 2 (the x change of the same lane comes first)
-            const int l = __builtin_ctzll(ry);
-            ry &= ry - 1;
-            const unsigned long long lt = (1ull << l) - 1ull;
-            const int64_t st = base + 2 * l + 2;
-            put(r0 + __popcll(bx & (lt | (1ull << l))) + __popcll(by & lt), keys[st], st);
+        const int total = __shfl(inc, 63), exc = inc - c;
+        if (total == 0) continue;
+        const int64_t r0 = 1 + (int64_t)prefix[1 + wt * 64];
+        uint16_t* const li = list[wv];
+        const int64_t base = head + wt * 64 * 128 + 1;
+        for (int e0 = 0; e0 < total; e0 += kRunListCap) {  // (one round unless more than 1024 groups start inside 8192 keys)
+            unsigned long long rx = bx, ry = by;
+            while (rx) {  // key 2l differs from key 2l + 1: a group starts at 2l + 1
+                const int l = __builtin_ctzll(rx);
+                rx &= rx - 1;
+                const unsigned long long lt = (1ull << l) - 1ull;
+                const int e = exc + __popcll(bx & lt) + __popcll(by & lt) - e0;
+                if (e >= 0 && e < kRunListCap) li[e] = (uint16_t)(lane * 128 + 2 * l);
+            }
+            while (ry) {  // key 2l + 1 differs from key 2l + 2: a group starts at 2l + 2 (the x change of the same lane comes first)
+                const int l = __builtin_ctzll(ry);
+                ry &= ry - 1;
+                const unsigned long long lt = (1ull << l) - 1ull;
+                const int e = exc + __popcll(bx & (lt | (1ull << l))) + __popcll(by & lt) - e0;
+                if (e >= 0 && e < kRunListCap) li[e] = (uint16_t)(lane * 128 + 2 * l + 1);
+            }
+            PDS_WAVE_LDS_SYNC();
+            const int cnt = total - e0 < kRunListCap ? total - e0 : kRunListCap;
+            for (int e = lane; e < cnt; e += 64) {
+                const int64_t st = base + (int64_t)li[e];
+                put(r0 + e0 + e, keys[st], st);
+            }
+            PDS_WAVE_LDS_SYNC();
         }
     }
     if (blockIdx.x == 0 && threadIdx.x < 64) {
-        const unsigned long long ltl = (1ull << lane) - 1ull;
         if (lane == 0) {
             put(0, keys[0], 0);
             if (head && n > 1 && keys[0] != keys[1]) put(1 + (int64_t)prefix[0], keys[1], 1);

@@ -98,8 +98,29 @@ __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* _
     // slot i / 64.  Every row needs all of its upper triangle with wave-uniform indices; v_readlane hands an entry to the
     // scalar side in one instruction -- as scalar LOADS from memory the 289 entries cost 10 ms per pass at 1e8 x 16 (what
     // pass2_kernel's HC2 / HC3 path still pays), as LDS broadcasts 50 ms.  Off-diagonal entries are stored doubled.
+    // LEVM (WM == 4, more than 8 features): the leverages on the MATRIX CORES instead.  h_i = z_i' P z_i with P = (X'X)^-1 =
+    // x_i' (P_xx x_i + 2 p_xb) + p_bb (the intercept's 1 handled in closed form, so 16 features + intercept need no 17th operand row):
+    // U = P_xx X' for 16 rows of the tile is FOUR matrix instructions (contraction over the 16 features, four at a time) whose result
+    // layout -- lane (row j, quad q), register v holds U[feature drow(lane, v)][row j] -- is exactly the layout of their own B
+    // operands, so the lane multiplies U by the x values it has just fed in, adds 2 p_xb, and the four quads are summed by two lane
+    // swaps.  32 more matrix instructions per 128-row tile (as many as the Gram itself) replace 153 FMAs + 306 v_readlane PER ROW:
+    // the HC2 / HC3 pass was bound by that vector work (report_c2_hc3 0.55 of the HBM peak against 0.73 for SE / HC1).
+    constexpr bool LEVM = WM == 4 && P2 == 0;
+    T lev_a[4] = {T(0), T(0), T(0), T(0)}, lev_pb[4] = {T(0), T(0), T(0), T(0)};
+    T lev_pbb = T(0);
+    if constexpr (LEVM) {
+        const T* const inv_g = static_cast<const T*>(ia.inv);
+        const int pp = p + bias, i = lane & 15;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int fm = Tile<T>::drow(lane, m);  // the feature this lane's quad carries in matrix step m (operand A and B alike)
+            lev_a[m] = (i < p && fm < p) ? inv_g[i + fm * pp] : T(0);
+            lev_pb[m] = (bias && fm < p) ? T(2) * inv_g[fm + p * pp] : T(0);
+        }
+        lev_pbb = bias ? inv_g[p + p * pp] : T(0);
+    }
     unsigned hc_lo[5], hc_hi[5];
-    if constexpr (WM == 4) {
+    if constexpr (WM == 4 && !LEVM) {
         const T* const inv_g = static_cast<const T*>(ia.inv);
         const int pp = p + bias;
 #pragma unroll
@@ -158,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* _
                 regs.w[e] = (row + e < n_lim) ? r * r : T(0);
             }
         }
-        if constexpr (WM == 4) {
+        if constexpr (WM == 4 && !LEVM) {
             // HC2 / HC3: the weight of a row is e_i^2 / (1 - h_i)^k with the leverage h_i = z_i' (X'X)^-1 z_i (the arithmetic of
             // pass2_kernel, operation by operation).  The y slot of the tile takes (1 - h_i)^k, so that the moment entry
             // (ones, y) = sum w_i y'_i is the plain residual sum of squares the report needs beside the meat.
@@ -227,19 +248,109 @@ __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* _
     int64_t t = (int64_t)(((__int128)nfull * wid) / nw);
     const int64_t t_end = (int64_t)(((__int128)nfull * (wid + 1)) / nw), t_step = 1;
 #endif
+    // LEVM, first half (while the tile is still in registers): squared residuals of the lane's rows, the features to LDS
+    T lev_r2[RPL], lev_y[RPL];
+    auto lev_stage = [&]() __attribute__((always_inline)) {
+        using V = typename Tile<T>::vec;
+#pragma unroll
+        for (int e = 0; e < RPL; ++e) {
+            T acc1 = b0;  // same order as pass2_kernel: bias first, then the features in column order
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                if (c < p) acc1 += regs.x[c][e] * bx[c];
+            const T r = regs.y[e] - acc1;
+            lev_r2[e] = r * r;
+            lev_y[e] = regs.y[e];
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (c < p) *reinterpret_cast<V*>(wl + c * kColStride + lane * 16) = regs.x[c];
+    };
+    // LEVM, second half (the next tile may already be on its way into `regs`): leverages of the tile's rows from LDS on the matrix
+    // cores, then the weight column w = e^2 / (1 - h)^k and the y slot (1 - h)^k of the lane's own rows
+    auto lev_weights = [&](int64_t row, int64_t n_lim) __attribute__((always_inline)) {
+        using V = typename Tile<T>::vec;
+        using Acc = typename Tile<T>::acc;
+        const int j = lane & 15;
+        T* const hcol = reinterpret_cast<T*>(wl + kSlotW * kColStride);
+        const T* xq[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) xq[m] = reinterpret_cast<const T*>(wl + Tile<T>::drow(lane, m) * kColStride) + j;
+        // four 16-row blocks at a time, their matrix steps interleaved (block-inner order): consecutive instructions are independent,
+        // a block's own chain comes round every fourth issue -- left to the compiler the blocks ran one after the other, every step
+        // waiting out the previous one's 16 passes (s_nop 15 in front of each reduction: ~400 clk per block with the pipe idle)
+        constexpr int NB = 4;
+#pragma unroll
+        for (int b0 = 0; b0 < TR / 16; b0 += NB) {
+            T xb[NB][4];
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) xb[bb][m] = xq[m][16 * (b0 + bb)];
+            Acc u[NB];
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) u[bb] = Acc{0, 0, 0, 0};
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                // (f64 operand layout: step m carries features 4 m .. 4 m + 3 -- narrower frames stop early; f32: every step
+                //  carries features m, 4 + m, 8 + m, 12 + m)
+                if (sizeof(T) == 8 && 4 * m >= p) continue;
+#pragma unroll
+                for (int bb = 0; bb < NB; ++bb) u[bb] = Tile<T>::mfma(lev_a[m], xb[bb][m], u[bb]);
+            }
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) {
+                T hl = T(0);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) hl = fma(xb[bb][m], (T)u[bb][m] + lev_pb[m], hl);
+                if constexpr (sizeof(T) == 8) {
+                    hl = xor_sum_q(hl);
+                } else {
+                    hl += __shfl_xor(hl, 16);
+                    hl += __shfl_xor(hl, 32);
+                }
+                if (lane < 16) hcol[16 * (b0 + bb) + j] = hl + lev_pbb;
+            }
+        }
+        const V hv = *reinterpret_cast<const V*>(wl + kSlotW * kColStride + lane * 16);
+        V wv, yv;
+#pragma unroll
+        for (int e = 0; e < RPL; ++e) {
+            const T om = T(1) - hv[e];
+            const T s2 = lev_r2[e];
+            const T wgt = (ia.hc_pow == 1) ? s2 * (T(1) / om) : s2 * (T(1) / (om * om));
+            const bool in = row + e < n_lim;
+            wv[e] = in ? wgt : T(0);
+            yv[e] = in ? ((ia.hc_pow == 1) ? om : om * om) : T(0);
+        }
+        *reinterpret_cast<V*>(wl + kSlotW * kColStride + lane * 16) = wv;
+        *reinterpret_cast<V*>(wl + kSlotY * kColStride + lane * 16) = yv;
+        (void)lev_y;
+    };
     if (t < t_end) load_full_tile<T, LOADW>(cp, p, t * TR + lane * RPL, regs);
     for (; t < t_end; t += t_step) {
-        resid_weights(0, 1 << 30);  // (full tiles: every row counts)
-        store_tile_lds<T, WEIGHTED>(wl, p, lane, regs);
         const int64_t tn = t + t_step;
-        if (tn < t_end) load_full_tile<T, LOADW>(cp, p, tn * TR + lane * RPL, regs);
+        if constexpr (LEVM) {
+            lev_stage();
+            if (tn < t_end) load_full_tile<T, LOADW>(cp, p, tn * TR + lane * RPL, regs);
+            lev_weights(0, 1 << 30);
+        } else {
+            resid_weights(0, 1 << 30);  // (full tiles: every row counts)
+            store_tile_lds<T, WEIGHTED>(wl, p, lane, regs);
+            if (tn < t_end) load_full_tile<T, LOADW>(cp, p, tn * TR + lane * RPL, regs);
+        }
         if constexpr (P2 != 0) consume_tile_pack<T, WEIGHTED, P2>(wl, lane, acc);
         else consume_tile<T, WEIGHTED>(wl, lane, TR / 4, acc);
     }
     if (nfull * TR < n && wid == nw - 1) {  // ragged tail: exactly one wave
         load_tail_tile<T, LOADW>(cp, p, nfull * TR + lane * RPL, n, regs);
-        resid_weights(nfull * TR + lane * RPL, n);
-        store_tile_lds<T, WEIGHTED>(wl, p, lane, regs);
+        if constexpr (LEVM) {
+            lev_stage();
+            lev_weights(nfull * TR + lane * RPL, n);
+        } else {
+            resid_weights(nfull * TR + lane * RPL, n);
+            store_tile_lds<T, WEIGHTED>(wl, p, lane, regs);
+        }
         if constexpr (P2 != 0) consume_tile_pack<T, WEIGHTED, P2>(wl, lane, acc);
         else consume_tile<T, WEIGHTED>(wl, lane, TR / 4, acc);
     }
@@ -522,7 +633,10 @@ int launch_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_
     double* partials = ctx->partials;  // sized for 8 blocks per CU at context creation
     KernelTimer timer(ctx, kKindMoments);
     size_t lds = (size_t)kWaves * kWaveLds + 64;  // + slack: the pipelined operand fetch reads two steps ahead
-    const int p2 = n_feat > 8 ? 0 : (n_feat > 4 ? 8 : (n_feat > 2 ? 4 : (n_feat > 1 ? 2 : 1)));
+    const bool hc23 = irls && irls->hc_pow > 0;  // residual weights scaled by the leverages (HC2 / HC3)
+    // (HC2 / HC3 at any width: the unpacked tile, whose leverages run on the matrix cores -- the packed kernels' vector form of the
+    //  leverages cost more than the packing saves: 1e8 x 8, hc3 5.2 ms against 4.8 at 9 features)
+    const int p2 = (n_feat > 8 || hc23) ? 0 : (n_feat > 4 ? 8 : (n_feat > 2 ? 4 : (n_feat > 1 ? 2 : 1)));
     auto launch = [&](auto w_c, auto p16_c, auto p2_c) {
         hipLaunchKernelGGL((moments_small_kernel<T, decltype(w_c)::value, decltype(p16_c)::value, decltype(p2_c)::value>), dim3(nblocks),
                            dim3(256), lds, ctx->stream, dc.d_ptrs, n_feat, n_rows, partials, d_beta_resid, bias_resid, ia);
@@ -537,7 +651,6 @@ int launch_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_
         else if (p2 == 1) launch(w_c, false_type{}, integral_constant<int, 1>{});
         else launch(w_c, false_type{}, integral_constant<int, 0>{});
     };
-    const bool hc23 = irls && irls->hc_pow > 0;  // residual weights scaled by the leverages (HC2 / HC3)
     if (hc23) by_p2(std::integral_constant<int, 4>{});
     else if (irls) by_p2(std::integral_constant<int, 3>{});
     else if (d_beta_resid) by_p2(std::integral_constant<int, 2>{});

@@ -1059,7 +1059,9 @@ def test_by_key_ordered_keys_run_lengths(pds, shift):
 
     rng = np.random.default_rng(60 + shift)
     cases = [rng.integers(1, 6, size=700), rng.integers(100, 300, size=40), np.array([1] * 300), np.array([5000]), np.array([3]),
-             np.array([1, 1]), np.array([127, 1, 128, 129, 2, 255, 1, 1, 64, 64]), rng.integers(1, 400, size=900)]
+             np.array([1, 1]), np.array([127, 1, 128, 129, 2, 255, 1, 1, 64, 64]), rng.integers(1, 400, size=900),
+             # more than 1024 group starts inside one wave's 8192 keys: the writing pass goes round its list several times
+             np.array([1] * 20_000), rng.integers(1, 4, size=15_000), np.r_[np.array([1] * 9000), rng.integers(50, 200, size=300)]]
     for sizes in cases:
         keys_g = np.cumsum(rng.integers(1, 9, size=len(sizes))) - 40
         key = np.repeat(keys_g, sizes).astype(np.int64)

@@ -22,25 +22,30 @@ off = torch.arange(0, G * R + 1, R, dtype=torch.int64, device=dev)
 key = torch.arange(7, 7 + G, dtype=torch.int64, device=dev).repeat_interleave(R)
 
 
-def wall(fn, reps=9):
-    fn()
-    fn()
-    ts = []
+def wall_pair(fa, fb, reps=15):
+    """The two calls alternate (the clocks of a box drift over the first seconds of a process: timing one after the other
+    compares a cold kernel with a warm one); medians and minima of each."""
+    for _ in range(3):
+        fa()
+        fb()
+    ta, tb = [], []
     for _ in range(reps):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        fn()
-        torch.cuda.synchronize()
-        ts.append(1e3 * (time.perf_counter() - t0))
-    ts.sort()
-    return ts[len(ts) // 2], ts[0]
+        for f, ts in ((fa, ta), (fb, tb)):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            f()
+            torch.cuda.synchronize()
+            ts.append(1e3 * (time.perf_counter() - t0))
+    ta.sort()
+    tb.sort()
+    return ta[len(ta) // 2], ta[0], tb[len(tb) // 2], tb[0]
 
 
 for p in (16, 8):
-    t_off, t_off_min = wall(lambda: pds.lin_reg_by(*xs[:p], target=y, group_offsets=off, ctx=ctx))
-    t_key, t_key_min = wall(lambda: pds.lin_reg_by_key(*xs[:p], target=y, key=key, max_groups=G, ctx=ctx))
+    t_off, t_off_min, t_key, t_key_min = wall_pair(lambda: pds.lin_reg_by(*xs[:p], target=y, group_offsets=off, ctx=ctx),
+                                                   lambda: pds.lin_reg_by_key(*xs[:p], target=y, key=key, max_groups=G, ctx=ctx))
     co0, nu0 = pds.lin_reg_by(*xs[:p], target=y, group_offsets=off, ctx=ctx)
     k1, co1, nu1 = pds.lin_reg_by_key(*xs[:p], target=y, key=key, max_groups=G, ctx=ctx)
     same = bool(torch.equal(co0, co1) and torch.equal(nu0, nu1) and torch.equal(k1, torch.arange(7, 7 + G, dtype=torch.int64, device=dev)))
     print(f"p = {p:2d}: offsets {t_off:.3f} (min {t_off_min:.3f}) ms, ordered keys {t_key:.3f} (min {t_key_min:.3f}) ms, "
-          f"ratio {t_key / t_off:.3f}, keys cost {1e3 * (t_key - t_off):.0f} us, identical results {same}", flush=True)
+          f"ratio {t_key / t_off:.3f} (of minima {t_key_min / t_off_min:.3f}), keys cost {1e3 * (t_key - t_off):.0f} us, identical results {same}", flush=True)
