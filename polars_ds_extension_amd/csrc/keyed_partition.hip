@@ -120,6 +120,11 @@ __global__ __launch_bounds__(256) void part_counts_from_slots_kernel(const unsig
 }
 
 // ---- 2. scatter.  PPR = 16-byte pieces per record.
+// (Round 5, measured and parked -- tools/experiments/keyed_partition_scatter_block_reserve.hip.txt: a block counts its 16 384 rows per
+//  bucket in LDS, reserves each bucket's space with ONE global atomic and places its rows through LDS atomics, so a bucket's ~4
+//  records per block land side by side.  It does cut the write amplification -- 12.15 -> 10.4 GB written for 8.0 GB of records -- and is
+//  SLOWER: 6.7 against 4.6 ms.  Two passes over a block's rows between block-wide barriers expose the latency that 24 independent waves
+//  per CU hide here; the scatter is not bound by the bytes it writes.  profiles/r05_scatter_block_reserve_ab.txt.)
 template <typename T, int PPR>
 __global__ __launch_bounds__(256) void part_scatter_kernel(const T* const* __restrict__ cols /*x_0..x_{p-1}, y*/, int p, int pc,
                                                            const int64_t* __restrict__ keys, int64_t n,
