@@ -124,7 +124,10 @@ __global__ __launch_bounds__(256) void part_counts_from_slots_kernel(const unsig
 //  bucket in LDS, reserves each bucket's space with ONE global atomic and places its rows through LDS atomics, so a bucket's ~4
 //  records per block land side by side.  It does cut the write amplification -- 12.15 -> 10.4 GB written for 8.0 GB of records -- and is
 //  SLOWER: 6.7 against 4.6 ms.  Two passes over a block's rows between block-wide barriers expose the latency that 24 independent waves
-//  per CU hide here; the scatter is not bound by the bytes it writes.  profiles/r05_scatter_block_reserve_ab.txt.)
+//  per CU hide here; the scatter is not bound by the bytes it writes.  The other direction -- no LDS stage at all, every lane writes
+//  its own record's pieces, 32 / 48 / 64 waves per CU -- costs 7.2 ms whatever the occupancy: 5e8 lane-private 16-byte stores are the
+//  slower way into the L2, the piece-cooperative write (a record's pieces side by side in adjacent lanes) stays.
+//  profiles/r05_scatter_block_reserve_ab.txt.)
 template <typename T, int PPR>
 __global__ __launch_bounds__(256) void part_scatter_kernel(const T* const* __restrict__ cols /*x_0..x_{p-1}, y*/, int p, int pc,
                                                            const int64_t* __restrict__ keys, int64_t n,
