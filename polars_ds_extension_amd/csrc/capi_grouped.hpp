@@ -537,6 +537,12 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
     if (space == PDS_HOST || !coeffs) need += up((size_t)cap * pp * sizeof(T));
     if (space == PDS_HOST || !is_null) need += up((size_t)cap);
     if (partition) need += keyed_partition_workspace<T>(n_feat, n_rows, part_buckets) + up(sizeof(T*) * (size_t)std::max(nc, 18));
+    // per-row predictions on the partition route: an id-indexed copy of the coefficient block (one randomly read object per row) when
+    // the id space is small enough to live in the memory-side cache like the block itself -- up to 2^25 ids and 1 GiB
+    const int64_t part_ids = partition ? keyed_partition_table_ids<T>(n_feat, part_buckets) : 0;
+    const size_t cbi_bytes = (size_t)part_ids * grouped_pred_table_stride<T>(pp) * sizeof(T);
+    const bool pred_table = partition && want_pred && part_ids <= ((int64_t)1 << 25) && cbi_bytes <= ((size_t)1 << 30);
+    if (pred_table) need += up(cbi_bytes);
     else if (!sorted) need += 2 * key_bytes + 2 * idx_bytes + col_bytes * nc + up((size_t)n_rows * nc * sizeof(T)) + up(2 * (size_t)nc * sizeof(T*)) + 1024;
     if (want_pred) need += up(sizeof(T*) * (size_t)std::max(nc, 18)) + (space == PDS_HOST ? 2 * col_bytes + up((size_t)n_rows) : 0);
     if (int rc = ensure_ws(ctx, ctx->keyed, need)) return rc;
@@ -591,9 +597,15 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
                 if (resid) d_resid = reinterpret_cast<T*>(take((size_t)n_rows * sizeof(T)));
                 if (row_null) d_rn = reinterpret_cast<uint8_t*>(take((size_t)n_rows));
             }
-            if (int rc = launch_grouped_pred_by_id<T>(ctx, d_tbl, n_feat, prm->add_bias ? 1 : 0, n_rows, d_keys, d_part_base, st.rank, ng, d_co, d_nu,
-                                                      d_pred, d_resid, d_rn))
+            if (pred_table) {
+                T* d_cbi = reinterpret_cast<T*>(take(cbi_bytes));
+                if (int rc = launch_grouped_pred_by_id_table<T>(ctx, d_tbl, n_feat, prm->add_bias ? 1 : 0, n_rows, d_keys, d_part_base, st.ids, ng, d_co,
+                                                                d_nu, d_cbi, d_pred, d_resid, d_rn))
+                    return rc;
+            } else if (int rc = launch_grouped_pred_by_id<T>(ctx, d_tbl, n_feat, prm->add_bias ? 1 : 0, n_rows, d_keys, d_part_base, st.rank, ng, d_co,
+                                                             d_nu, d_pred, d_resid, d_rn)) {
                 return rc;
+            }
             if (space == PDS_HOST) {
                 if (pred) PDS_HIP_CHECK(hipMemcpyAsync(pred, d_pred, (size_t)n_rows * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
                 if (resid) PDS_HIP_CHECK(hipMemcpyAsync(resid, d_resid, (size_t)n_rows * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));

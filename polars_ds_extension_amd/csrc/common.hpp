@@ -278,7 +278,17 @@ int launch_grouped_pred(pds_ctx* ctx, const T* const* d_cols, int n_feat, int bi
 template <typename T>
 int launch_grouped_pred_by_id(pds_ctx* ctx, const T* const* d_cols, int n_feat, int bias, int64_t n_rows, const int64_t* d_keys,
                               const int64_t* d_kmin, const uint32_t* d_rank, int64_t n_groups, const T* d_coeffs, const uint8_t* d_flags,
-                              T* d_pred, T* d_resid, uint8_t* d_row_null);  // grouped_pred.hip
+                              T* d_pred, T* d_resid, uint8_t* d_row_null);
+// elements per row of the id-indexed coefficient table: rows padded to whole 64- or 128-byte lines (wider rows: as they are)
+template <typename T>
+inline int grouped_pred_table_stride(int pp) {
+    const int b = pp * (int)sizeof(T);
+    return b <= 64 ? 64 / (int)sizeof(T) : (b <= 128 ? 128 / (int)sizeof(T) : pp);
+}
+template <typename T>
+int launch_grouped_pred_by_id_table(pds_ctx* ctx, const T* const* d_cols, int n_feat, int bias, int64_t n_rows, const int64_t* d_keys,
+                                    const int64_t* d_kmin, const uint32_t* d_ids /* dense id of group g */, int64_t n_groups, const T* d_coeffs,
+                                    const uint8_t* d_flags, T* d_table /* n_ids x grouped_pred_table_stride(p') workspace */, T* d_pred, T* d_resid, uint8_t* d_row_null);  // grouped_pred.hip
 // ---- leverage_mid.hip: HC2 / HC3 leverages of 17 .. 64 f64 features on the matrix cores (PDS_ERR_UNSUPPORTED: not applicable, nothing done)
 int launch_grouped_moments_stream(pds_ctx* ctx, const DeviceCols<double>& dc, int n_feat, int64_t n_frame, const int64_t* d_off, int64_t n_groups,
                                   double* d_records);  // grouped_mid.hip: grouped Gram records, 17 .. 64 f64 features, one stream

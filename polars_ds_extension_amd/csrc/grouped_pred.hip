@@ -54,6 +54,30 @@ __device__ __forceinline__ int64_t group_of_row(const int64_t* __restrict__ off,
 // up from its key (dense ids: group = rank[key - *kmin], keyed_partition.hip) -- the frame is read where it lies, nothing is
 // permuted, and the n_groups x p' coefficient block is the only randomly read object (72 MB at 1e6 groups x 8 features: it lives
 // in the L2s / the memory-side cache)
+// MODE 3 (round 5): as MODE 2, but `coeffs` is an ID-indexed copy of the coefficient block (row id = key - *kmin; a null group's row
+// starts with a NaN of payload 1; fill_coef_by_id_kernel below) -- the row's id IS its coefficient row, so rank[] and flags[] are not
+// read: ONE randomly read object per row instead of three.
+template <typename T> struct GpNullMark;
+template <> struct GpNullMark<double> {
+    static __device__ __forceinline__ double value() { return __builtin_bit_cast(double, 0x7ff8000000000001ull); }
+    static __device__ __forceinline__ bool is(double v) { return __builtin_bit_cast(unsigned long long, v) == 0x7ff8000000000001ull; }
+};
+template <> struct GpNullMark<float> {
+    static __device__ __forceinline__ float value() { return __builtin_bit_cast(float, 0x7fc00001u); }
+    static __device__ __forceinline__ bool is(float v) { return __builtin_bit_cast(unsigned, v) == 0x7fc00001u; }
+};
+template <typename T>
+__global__ __launch_bounds__(256) void fill_coef_by_id_kernel(const T* __restrict__ coeffs, const uint8_t* __restrict__ flags,
+                                                              const unsigned* __restrict__ ids, int64_t n_groups, int pp, int stride,
+                                                              T* __restrict__ table) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_groups * pp; i += (int64_t)gridDim.x * 256) {
+        const int64_t g = i / pp;
+        const int c = (int)(i - g * pp);
+        T v = coeffs[i];
+        if (c == 0 && flags && flags[g]) v = GpNullMark<T>::value();
+        table[(size_t)ids[g] * stride + c] = v;
+    }
+}
 template <typename T, int PC, int MODE>
 __global__ __launch_bounds__(kGpThreads) void grouped_pred_kernel(const T* const* __restrict__ cols, int p_arg, int bias, int64_t n,
                                                                   const int64_t* __restrict__ off, int64_t n_groups,
@@ -81,7 +105,7 @@ __global__ __launch_bounds__(kGpThreads) void grouped_pred_kernel(const T* const
     const bool rn_vec = (reinterpret_cast<uintptr_t>(row_null) & (RPL - 1)) == 0;
     int64_t g[RPL];
     uint64_t kbase = 0;
-    if constexpr (MODE == 2) {
+    if constexpr (MODE >= 2) {
         kbase = (uint64_t)*kmin;
     } else {
         const int64_t r = c0 * 64 * RPL + (int64_t)lane * RPL;
@@ -101,6 +125,13 @@ __global__ __launch_bounds__(kGpThreads) void grouped_pred_kernel(const T* const
                 const int64_t r = (r0 + e < n) ? r0 + e : n - 1;
                 g[e] = (int64_t)perm[(uint64_t)__builtin_nontemporal_load(keys + r) - kbase];
             }
+        } else if constexpr (MODE == 3) {
+            // ---- the lane's rows' ids: the coefficient table is indexed by them
+#pragma unroll
+            for (int e = 0; e < RPL; ++e) {
+                const int64_t r = (r0 + e < n) ? r0 + e : n - 1;
+                g[e] = (int64_t)((uint64_t)__builtin_nontemporal_load(keys + r) - kbase);
+            }
         } else {
             // ---- the groups of the lane's rows (monotone in r: forward steps only)
 #pragma unroll
@@ -114,7 +145,7 @@ __global__ __launch_bounds__(kGpThreads) void grouped_pred_kernel(const T* const
         double acc[RPL];
         const T* brow[RPL];
         bool staged = false;
-        if constexpr (MODE != 2) {
+        if constexpr (MODE < 2) {
             const int64_t g_lo = __shfl(g[0], 0), g_hi = __shfl(g[RPL - 1], 63);
             const int64_t cnt = (g_hi - g_lo + 1) * pp;
             staged = cnt <= kGpStage;  // (wave-uniform)
@@ -128,11 +159,19 @@ __global__ __launch_bounds__(kGpThreads) void grouped_pred_kernel(const T* const
             }
         }
         if (!staged) {
+            // (MODE 3: rows of the id-indexed table are padded to whole 64 / 128-byte lines -- one line per row instead of a 72-byte row
+            //  straddling two; the stride travels in the n_groups argument, which this mode has no other use for)
+            const int64_t cstride = (MODE == 3) ? n_groups : (int64_t)pp;
 #pragma unroll
-            for (int e = 0; e < RPL; ++e) brow[e] = coeffs + g[e] * pp;
+            for (int e = 0; e < RPL; ++e) brow[e] = coeffs + g[e] * cstride;
         }
 #pragma unroll
         for (int e = 0; e < RPL; ++e) acc[e] = bias ? (double)brow[e][p] : 0.0;
+        bool nl3[RPL];
+        if constexpr (MODE == 3) {
+#pragma unroll
+            for (int e = 0; e < RPL; ++e) nl3[e] = GpNullMark<T>::is(brow[e][0]);
+        }
         auto col_step = [&](int c) __attribute__((always_inline)) {
             const gptr<T> col = as_global(cols[c]);
             V v;
@@ -163,7 +202,8 @@ __global__ __launch_bounds__(kGpThreads) void grouped_pred_kernel(const T* const
         uint8_t nl[RPL];
 #pragma unroll
         for (int e = 0; e < RPL; ++e) {
-            nl[e] = flags ? flags[g[e]] : (uint8_t)0;
+            if constexpr (MODE == 3) nl[e] = nl3[e] ? (uint8_t)1 : (uint8_t)0;
+            else nl[e] = flags ? flags[g[e]] : (uint8_t)0;
             const T pr = nl[e] ? nanv : (T)acc[e];
             pv[e] = pr;
             rv[e] = nl[e] ? nanv : (T)((double)yv[e] - (double)pr);
@@ -271,6 +311,30 @@ int launch_grouped_pred_by_id(pds_ctx* ctx, const T* const* d_cols, int n_feat, 
     PDS_HIP_CHECK(hipGetLastError());
     return PDS_OK;
 }
+// the same with an id-indexed coefficient table (d_table: n_ids x p' values of workspace, filled here from the compact block through
+// d_ids = dense id of group g): one randomly read object per row
+template <typename T>
+int launch_grouped_pred_by_id_table(pds_ctx* ctx, const T* const* d_cols, int n_feat, int bias, int64_t n_rows, const int64_t* d_keys,
+                                    const int64_t* d_kmin, const uint32_t* d_ids, int64_t n_groups, const T* d_coeffs, const uint8_t* d_flags,
+                                    T* d_table, T* d_pred, T* d_resid, uint8_t* d_row_null) {
+    if (n_rows <= 0 || n_groups <= 0) return PDS_OK;
+    KernelTimer timer(ctx, kKindPass2);
+    const int pp = n_feat + bias;
+    const int fb = (int)std::min<int64_t>((n_groups * pp + 255) / 256, (int64_t)ctx->num_cus * 16);
+    const int stride = grouped_pred_table_stride<T>(pp);
+    hipLaunchKernelGGL((fill_coef_by_id_kernel<T>), dim3(fb), dim3(256), 0, ctx->stream, d_coeffs, d_flags, d_ids, n_groups, pp, stride, d_table);
+    constexpr int RPL = GP16<T>::RPL;
+    const int64_t nchunk = (n_rows + 64 * RPL - 1) / (64 * RPL);
+    const int nb = (int)std::min<int64_t>(std::max<int64_t>((nchunk + 3) / 4, 1), (int64_t)ctx->num_cus * 8);
+    launch_pc<T, 3>(n_feat, dim3(nb), ctx->stream, d_cols, bias, n_rows, nullptr, (int64_t)stride, (const T*)d_table, nullptr, nullptr, d_pred, d_resid,
+                    d_row_null, d_keys, d_kmin);
+    PDS_HIP_CHECK(hipGetLastError());
+    return PDS_OK;
+}
+template int launch_grouped_pred_by_id_table<double>(pds_ctx*, const double* const*, int, int, int64_t, const int64_t*, const int64_t*,
+                                                     const uint32_t*, int64_t, const double*, const uint8_t*, double*, double*, double*, uint8_t*);
+template int launch_grouped_pred_by_id_table<float>(pds_ctx*, const float* const*, int, int, int64_t, const int64_t*, const int64_t*,
+                                                    const uint32_t*, int64_t, const float*, const uint8_t*, float*, float*, float*, uint8_t*);
 template int launch_grouped_pred_by_id<double>(pds_ctx*, const double* const*, int, int, int64_t, const int64_t*, const int64_t*,
                                                const uint32_t*, int64_t, const double*, const uint8_t*, double*, double*, uint8_t*);
 template int launch_grouped_pred_by_id<float>(pds_ctx*, const float* const*, int, int, int64_t, const int64_t*, const int64_t*,

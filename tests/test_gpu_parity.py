@@ -613,6 +613,59 @@ def test_grouped_pred_by_key_shuffled_weighted_f32(pds, orc):
     assert np.max(np.abs(p32.cpu().numpy().astype(np.float64) - po[back]) / scale) < F32_TOL
 
 
+@pytest.mark.parametrize("p,bias,f32", [(1, False, False), (4, True, False), (8, False, False), (8, True, True), (11, True, False), (16, False, False)])
+def test_by_key_pred_partition_route(pds, orc, p, bias, f32):
+    """Shuffled rows, dense integer keys, >= 2^17 rows: per-row predictions of the PARTITION route (grouped_pred.hip MODE 3, round 5: the
+    frame read where it lies, the row's dense id indexing an id-indexed copy of the coefficient block) -- every row's prediction lands
+    where the row is; collinear and too-small groups give null rows (NaN + flag); sparse key values; both precisions; against the oracle's per-group
+    fits and against the call on the same frame in key order (the fused kernel + grouped_pred's offsets form)."""
+    rng = np.random.default_rng(4100 + 10 * p + bias)
+    G = 3000
+    sizes = rng.integers(p + bias + 6, 110, size=G)
+    sizes[::97] = rng.integers(1, p + bias, size=len(sizes[::97])) if p + bias > 1 else 1  # fewer rows than coefficients -> null (p' > 1)
+    key_of_group = (rng.permutation(G) * 3 - 500).astype(np.int64)
+    key = np.repeat(key_of_group, sizes)
+    N = len(key)
+    assert N >= 1 << 17
+    X = rng.normal(size=(N, p))
+    y = X @ rng.normal(size=p) + 1e-3 * key + 0.1 * rng.normal(size=N) + (0.4 if bias else 0.0)
+    off0 = np.concatenate([[0], np.cumsum(sizes)])
+    if p >= 2:
+        for g in range(11, G, 211):
+            X[off0[g]: off0[g + 1], 1] = 2.0 * X[off0[g]: off0[g + 1], 0]
+    perm = rng.permutation(N)
+    kp, Xp, yp = key[perm], X[perm], y[perm]
+    dt = np.float32 if f32 else np.float64
+    pds.config.LIN_REG_EXPR_F64 = not f32
+    try:
+        pred, resid, rn = pds.lin_reg_by_key_pred(*cols_of(Xp.astype(dt)), target=dev(yp.astype(dt)), key=dev(kp), add_bias=bias)
+        order = np.argsort(kp, kind="stable")
+        ps, rs, ns = pds.lin_reg_by_key_pred(*cols_of(Xp[order].astype(dt)), target=dev(yp[order].astype(dt)), key=dev(kp[order]), add_bias=bias)
+    finally:
+        pds.config.LIN_REG_EXPR_F64 = True
+    pred, resid, rn = pred.cpu().numpy().astype(np.float64), resid.cpu().numpy().astype(np.float64), rn.cpu().numpy().astype(bool)
+    ps, ns = ps.cpu().numpy().astype(np.float64), ns.cpu().numpy().astype(bool)
+    uk, cnt = np.unique(kp, return_counts=True)
+    off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+    po, ro, rno = _grouped_pred_oracle(orc, Xp[order], yp[order], off, bias)
+    back = np.empty(N, dtype=np.int64)
+    back[order] = np.arange(N)
+    assert np.array_equal(rn, rno[back]) and (p + bias == 1 or rn.sum() > 20)
+    assert np.isnan(pred[rn]).all() and np.isnan(resid[rn]).all()
+    # the same null rows and -- to the two routes' different summation orders -- the same predictions as the ordered call
+    assert np.array_equal(ns, rno)
+    gid = np.repeat(np.arange(len(uk)), cnt)
+    well = ((cnt >= 2 * (p + bias) + 8)[gid] & ~rno)[back]
+    scale = (np.linalg.norm(np.c_[Xp, np.ones(N)], axis=1) * 3.0)
+    tol = F32_TOL if f32 else F64_TOL
+    assert np.max(np.abs(pred[well] - po[back][well]) / scale[well]) < tol
+    assert np.max(np.abs(resid[well] - ro[back][well]) / np.maximum(scale[well], np.abs(yp[well]))) < tol
+    assert np.max(np.abs(pred[well] - ps[back][well]) / scale[well]) < tol
+    # resid = y - pred on every fitted row
+    okr = ~rn
+    np.testing.assert_allclose(resid[okr], yp.astype(dt).astype(np.float64)[okr] - pred[okr], rtol=0, atol=(1e-5 if f32 else 1e-12) * (1 + np.abs(yp[okr]).max()))
+
+
 @pytest.mark.parametrize("n_ctx", [2, 3])
 def test_exchange_steps_compose_the_multi_device_paths_through_the_c_abi(pds, orc, n_ctx):
     """pds_allreduce_sum_* / pds_scatter_rows_* / pds_gather_* (include/pds_lstsq.h, round 4): the three exchange steps of SURVEY.md
