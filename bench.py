@@ -45,7 +45,7 @@ sys.path.insert(0, str(ROOT))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-PROFILE_TAG = "r04"     # profiles/<tag>_traffic.json: HBM bytes per launch from the rocprofv3 PMC passes
+PROFILE_TAG = "r05"     # profiles/<tag>_traffic.json: HBM bytes per launch from the rocprofv3 PMC passes
 
 
 def _gen_frame(torch, dev, seed, G, R, P):
@@ -176,7 +176,7 @@ def main() -> int:
     # HBM bytes per launch measured offline with rocprofv3 PMC passes (profiles/<tag>_traffic.json, committed)
     traffic = None
     traffic_source = None
-    for tag in (PROFILE_TAG, "r03", "r02", "r01"):
+    for tag in (PROFILE_TAG, "r04", "r03", "r02", "r01"):
         try:
             tj = json.loads((ROOT / "profiles" / f"{tag}_traffic.json").read_text())["kernels"]
             want = "pds::grouped_stream_kernel<double, 16," if fused else "pds::grouped_moments_kernel<double>"

@@ -13,7 +13,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "SQ_
   rm -rf /tmp/pg; timeout -k 5 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pg -o g -- python -u $ROOT/tools/wide_split_ab.py time > $OUT/run_$k.log 2>&1
   f=$(find /tmp/pg -name "*counter_collection.csv" | head -1)
   [ -z "$f" ] && { echo "no counters for: $set"; tail -5 $OUT/run_$k.log; continue; }
-  cp $f $OUT/pmc_$k.csv
+  head -1 $f > $OUT/pmc_$k.csv; grep "moments_wide" $f >> $OUT/pmc_$k.csv
 done
 rm -rf /tmp/pg; timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pg -o g -- python -u $ROOT/tools/wide_split_ab.py time > $OUT/run_stats.log 2>&1
 cp $(find /tmp/pg -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
@@ -33,5 +33,5 @@ st={}
 for r in csv.DictReader(open(root+"/kernel_stats.csv")):
     if "moments_wide" in r["Name"]: st[r["Name"].split("(")[0][-60:]]={"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"])/1e3}
 json.dump({"counters": out, "kernel_stats": st}, open(root+"/r05_pmc_wide.json","w"), indent=1)
-print(json.dumps({"counters": out, "kernel_stats": st}, indent=1)[:6000])
+print(json.dumps({"counters": out, "kernel_stats": st}, indent=1)[:1500])
 PY

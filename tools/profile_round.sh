@@ -8,7 +8,10 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 5 400 python -u $ROOT/bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
+# counter / trace CSVs carry every torch kernel of the frame generators: keep the header and the library's kernels only (gpurun merges
+# at most 64 MiB back; round 5 lost a whole call's output to that limit)
+slim() { for f in "$@"; do [ -f "$f" ] && { head -1 "$f" > "$f.tmp"; grep "pds::" "$f" >> "$f.tmp"; mv "$f.tmp" "$f"; }; done; }
+timeout -k 5 600 python -u $ROOT/bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
 # same flags as the bench line's timed region (warm-ups excluded from the averages by summarize_profiles.py: it drops the
 # first `warmup` launches of each kernel using the kernel trace, not the --stats table)
 rm -rf /tmp/p1 && timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -o b -- python -u $ROOT/bench.py --steps 10 --warmup 3 --no-cpu --no-extras > $OUT/stats_run.log 2>&1
@@ -54,4 +57,13 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_AC
   rm -rf /tmp/p11 && timeout -k 5 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/p11 -o s -- python -u $ROOT/bench.py --steps 3 --warmup 1 --no-cpu --no-extras > $OUT/pmc_sq_$k.log 2>&1
   f=$(find /tmp/p11 -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp $f $OUT/pmc_sq_$k.csv
 done
+# round 5: the partition route's id-indexed prediction pass (grouped_pred MODE 3), the C5 wide Gram's counters (FETCH / WRITE, L2 hit rate,
+# matrix-pipe busy cycles), the ordered-keys call's kernels, the HC2 / HC3 report widths
+bash $ROOT/tools/pmc_wide_r05.sh > $OUT/pmc_wide_r05.log 2>&1; cp $ROOT/gpurun_out/pmc_wide/r05_pmc_wide.json $OUT/ 2>/dev/null; rm -rf $ROOT/gpurun_out/pmc_wide
+cd /tmp
+rm -rf /tmp/p12 && timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p12 -o k -- python -u $ROOT/tools/sorted_keys_ab.py > $OUT/sorted_keys_run.log 2>&1
+cp $(find /tmp/p12 -name "*kernel_stats.csv" | head -1) $OUT/sorted_keys_kernel_stats.csv
+timeout -k 5 300 python -u $ROOT/tools/report_hc_quick.py > $OUT/report_hc.log 2>&1
+slim $OUT/pmc_*.csv $OUT/bench_kernel_trace.csv
+du -sh $OUT
 ls -la $OUT
