@@ -568,6 +568,10 @@ __global__ __launch_bounds__(kWThreads, (SPLIT && kSplitKC == 16) ? 3 : 2) void 
 //   * diagonal workgroups compute the 10 of their 16 wave tiles that the upper triangle needs; their two idle waves multiply
 //     all 256 rows with the [1 | y] tail tile, parked in the unused J half (as MODE 2 does).
 // Used when the block grid is even (p = 512, 768, ...) and the tail fits one MFMA tile; everything else stays with the kernel above.
+// (Round 5, measured and parked -- tools/experiments/moments_wide_split256_pipelined.hip.txt: the stage as two 16-row halves, a wave
+//  converting-and-storing one half of the NEXT stage while it multiplies the other half of the current one, the two waves of a SIMD in
+//  complementary order (convert-then-multiply / multiply-then-convert) so that its vector and matrix pipes work at the same time instead of
+//  taking turns between the barriers.  Same results, 21.4 against 19.7 ms -- see DESIGN.md 4.6 for the counters and the cut-out variants.)
 constexpr int kS2B = 256;                    // tile edge
 constexpr int kS2KC = 32;                    // rows per stage
 constexpr int kS2CSD = kS2KC / 2 + 4;        // dwords per column and plane (64 B of bf16 + 16 pad: conflict-free 16-byte reads)
@@ -888,10 +892,10 @@ static int launch_moments_wide_w(pds_ctx* ctx, const DeviceCols<T>& dc, int n_fe
             const char* e128 = dev_env("PDS_WIDE_TILE128");  // A/B: keep the 128 x 128 tile
             if (SPLIT && nb_main >= 2 && nb_main % 2 == 0 && !(e128 && e128[0] == '1')) {
                 constexpr int lds256 = kS2Stage * (int)sizeof(unsigned);
-                PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&moments_wide_split256_kernel<WEIGHTED>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds256));
+                auto kern256 = &moments_wide_split256_kernel<WEIGHTED>;
+                PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern256), hipFuncAttributeMaxDynamicSharedMemorySize, lds256));
                 const int nbs = nb_main / 2;
-                hipLaunchKernelGGL((moments_wide_split256_kernel<WEIGHTED>), dim3(nbs * (nbs + 1) / 2, nsplit), dim3(kS2Threads), lds256,
+                hipLaunchKernelGGL(kern256, dim3(nbs * (nbs + 1) / 2, nsplit), dim3(kS2Threads), lds256,
                                    ctx->stream, dc.d_ptrs, n_feat, n_rows, nb, nb_main, rows_per_split, d_sw, partials);
             } else {
                 hipLaunchKernelGGL((moments_wide_kernel<T, 2, WEIGHTED, SPLIT>), grid_main, dim3(kWThreads), lds, ctx->stream, dc.d_ptrs,
