@@ -173,7 +173,16 @@ int launch_solve_marked(pds_ctx* ctx, const T* d_rec, int64_t n, const SolvePara
         work(0, n);
     } else {
         std::vector<std::thread> th;
-        for (int t = 0; t < nt; ++t) th.emplace_back(work, n * t / nt, n * (t + 1) / nt);
+        int64_t done = 0;  // (a host that refuses more threads: the calling thread takes what is left)
+        try {
+            th.reserve((size_t)nt);
+            for (int t = 0; t < nt; ++t) {
+                th.emplace_back(work, n * t / nt, n * (t + 1) / nt);
+                done = n * (t + 1) / nt;
+            }
+        } catch (const std::exception&) {
+        }
+        if (done < n) work(done, n);
         for (auto& t : th) t.join();
     }
     PDS_HIP_CHECK(hipMemcpyAsync(d_co, co.data(), co.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));

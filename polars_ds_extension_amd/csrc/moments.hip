@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* _
     const int64_t t_end = (int64_t)(((__int128)nfull * (wid + 1)) / nw), t_step = 1;
 #endif
     // LEVM, first half (while the tile is still in registers): squared residuals of the lane's rows, the features to LDS
-    T lev_r2[RPL], lev_y[RPL];
+    T lev_r2[RPL];
     auto lev_stage = [&]() __attribute__((always_inline)) {
         using V = typename Tile<T>::vec;
 #pragma unroll
@@ -260,7 +260,6 @@ __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* _
                 if (c < p) acc1 += regs.x[c][e] * bx[c];
             const T r = regs.y[e] - acc1;
             lev_r2[e] = r * r;
-            lev_y[e] = regs.y[e];
         }
 #pragma unroll
         for (int c = 0; c < 16; ++c)
@@ -325,7 +324,6 @@ __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* _
         }
         *reinterpret_cast<V*>(wl + kSlotW * kColStride + lane * 16) = wv;
         *reinterpret_cast<V*>(wl + kSlotY * kColStride + lane * 16) = yv;
-        (void)lev_y;
     };
     if (t < t_end) load_full_tile<T, LOADW>(cp, p, t * TR + lane * RPL, regs);
     for (; t < t_end; t += t_step) {
