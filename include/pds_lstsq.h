@@ -363,7 +363,7 @@ int pds_lr_by_key_f32(pds_ctx* ctx, const float* const* cols, const int64_t* key
  * whatever the order; every context builds the id-indexed moment table of its rows (dense integer keys, <= 16 features: the
  * partition route of pds_lr_by_key_*), the tables are summed on ctxs[0] (same device: in place; another device: hipMemcpyPeer),
  * which lists the groups and solves them -- one exchange of (key range) x (p+2)(p+3)/2 doubles per extra context.  Frames the
- * partition route does not take (sparse keys, wider frames, PDS_KEYED_SORT=1) and n_ctx == 1 take pds_lr_by_key_* on ctxs[0].
+ * partition route does not take (sparse keys, wider frames, the "keyed_sort" option of ctxs[0]) and n_ctx == 1 take pds_lr_by_key_* on ctxs[0].
  * Arguments as pds_lr_by_key_* (space = PDS_HOST).
  */
 int pds_lr_by_key_multi_f64(pds_ctx* const* ctxs, int n_ctx, int n_slices, const double* const* cols, const int64_t* keys, int n_feat,
