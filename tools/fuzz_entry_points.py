@@ -74,7 +74,10 @@ while time.time() < t_end:
         Z = np.c_[X.astype(np.float64), np.ones(n), y.astype(np.float64)]
         note("f32/gram", nrel(M, Z.T @ Z))
         note("f32/lin_reg", nrel(b, orc.pl_lr(X.astype(np.float64), y.astype(np.float64), add_bias=bias, singular_x_tol=0.0)))
-        assert worst["f32/gram"] < 1e-6 and worst["f32/lin_reg"] < 1e-4, (p, n, bias, worst["f32/gram"], worst["f32/lin_reg"])
+        # (Gram bar: the bf16 three-plane split of frames beyond 64 features is 2e-6 from the f64 Gram by construction -- DESIGN 4.6, the
+        #  parity tests hold it to 3e-6 --; up to 64 features the f32 matrix instructions stay below 1e-6.  Contract: 1e-4 on coefficients.)
+        bar = 3e-6 if p > 64 else 1e-6
+        assert nrel(M, Z.T @ Z) < bar and worst["f32/lin_reg"] < 1e-4, (p, n, bias, nrel(M, Z.T @ Z), worst["f32/lin_reg"])
     elif kind == "grouped":
         # contiguous groups, 1 .. 64 features (17 .. 64: one wave per system in registers + the pivoted-QR pass over what it marks)
         p = int(rng.choice([2, 9, 16, 17, 20, 31, 32, 33, 47, 48, 63, 64]))
