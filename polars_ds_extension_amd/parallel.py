@@ -141,6 +141,8 @@ class GroupedShardPlan:
         RCCL's stream while its next piece is computed; the gathering rank posts, before its own fit, one grouped receive per piece
         index straight into the rows of the assembled result -- every peer's traffic rides its own xGMI link, no staging copy.
 
+    Building a plan is COLLECTIVE when `chunks` is left to the model (every rank of the group builds its plan at the same point: one
+    all-reduce agrees on the piece count); with an explicit `chunks` every rank must pass the same value.
     `step()` returns (coeffs_local, is_null_local) and, on the gathering rank, additionally (coeffs, is_null) of all groups: views of
     the persistent buffers, valid until the next step().  The dtype on the wire is `result_dtype`; by default what the library's
     grouped fit returns (the config dtype) or, with an injected `grouped_fn`, the targets' dtype.
@@ -176,6 +178,12 @@ class GroupedShardPlan:
             peers = [hi - lo for r, (lo, hi) in enumerate(parts) if r != gather_to]
             chunks = auto_chunks(world if gather_to is not None else 1, max(peers, default=0) * (pp * esz + 1),
                                  int(off_h[-1] - off_h[0]) * (len(xs_loc) + 1) * in_sz)
+            if world > 1 and gather_to is not None:
+                # the piece count decides how the gathering rank cuts every peer's rows: ranks whose shards differ by a group must not
+                # round the model to different counts -- one tiny all-reduce(MAX) when the plan is built (building a plan is collective)
+                agree = torch.tensor([int(chunks)], dtype=torch.int64, device=dev)
+                dist.all_reduce(agree, op=dist.ReduceOp.MAX, group=group)
+                chunks = int(agree.item())
         self.chunks = chunks = max(1, int(chunks))
         # ---- persistent results
         if is_root:
