@@ -68,6 +68,19 @@ def test_headline_config_against_oracle(pds, orc):
         checked += g1 - g0
     print(f"headline 1e6 x 100 x 16: {checked} groups vs oracle, max normwise rel {worst:.2e}")
     assert checked == 200_000 and worst < F64_TOL
+    # the same step from the KEY COLUMN (bench.py `grouped_by_key`): sorted int64 keys with gaps -- the one-pass order check + run marks,
+    # the scan and the mask pass must reproduce the 1e6 offsets exactly, so the fused kernel gives the same bits; and a frame whose LAST
+    # two keys are swapped (an inversion only the final piece sees) must still come back with every key in order
+    keys = (torch.arange(G, dtype=torch.int64, device="cuda") * 3 - 17).repeat_interleave(R)
+    k1, co1, nu1 = pds.lin_reg_by_key(*xs, target=y, key=keys, max_groups=G)
+    assert torch.equal(k1, torch.arange(G, dtype=torch.int64, device="cuda") * 3 - 17)
+    assert torch.equal(co1, co) and torch.equal(nu1, nu)
+    del k1, co1, nu1
+    keys[-1], keys[-R - 1] = keys[-R - 1].clone(), keys[-1].clone()  # one row of the last group moves into the one before: not ordered
+    k2, co2, nu2 = pds.lin_reg_by_key(*xs, target=y, key=keys, max_groups=G)
+    assert torch.equal(k2, torch.arange(G, dtype=torch.int64, device="cuda") * 3 - 17) and int(nu2.sum().item()) == 0
+    assert torch.equal(co2[: G - 2], co[: G - 2]) or float((co2[: G - 2] - co[: G - 2]).abs().max().item()) < 1e-9
+    del keys, k2, co2, nu2
     # the same frame as ONE regression (configs[1]'s Gram build): moment matrix of a 1e7-row prefix against the oracle's
     # blocked Gram, and of the whole frame against an f64 torch reduction of sampled entries
     n_s = 10_000_000
@@ -192,6 +205,16 @@ def test_c2_prefix_against_oracle(pds, orc):
     ci_bound = F64_TOL * (np.linalg.norm(ro["beta"]) + t_crit * ro["std_err"])
     assert np.all(np.abs(r["0.025"] - ro["ci_lo"]) <= ci_bound) and np.all(np.abs(r["0.975"] - ro["ci_hi"]) <= ci_bound)
     assert abs(np.ravel(r["r2"])[0] - ro["r2"]) < 1e-12
+    # robust errors on the same prefix: HC1 (meat fused into the residual pass) and HC2 / HC3 (round 5: the leverages on the matrix
+    # cores) against the oracle's per-row arithmetic -- and on the first 9 and 12 features, the widths whose matrix steps stop early
+    for cols_n in (p, 12, 9):
+        Xb = np.c_[Xh[:, :cols_n], np.ones(n)]
+        for kind in ("hc1", "hc2", "hc3"):
+            rk = pds.lin_reg_report(*fr["xs"][:cols_n], target=fr["y"], add_bias=True, std_err=kind)
+            rok = orc.lin_reg_report(Xb, yh, std_err=kind)
+            e_se = float(np.max(np.abs(rk[f"{kind}_se"] - rok["std_err"]) / rok["std_err"]))
+            assert e_se < F64_TOL, (cols_n, kind, e_se)
+            assert np.linalg.norm(rk["beta"] - rok["beta"]) / np.linalg.norm(rok["beta"]) < F64_TOL
 
 
 # ------------------------------------------------------------------------------------------ configs[4]: elastic net, f32, p = 512
