@@ -613,6 +613,38 @@ def test_grouped_pred_by_key_shuffled_weighted_f32(pds, orc):
     assert np.max(np.abs(p32.cpu().numpy().astype(np.float64) - po[back]) / scale) < F32_TOL
 
 
+def test_context_options(pds):
+    """pds_ctx_set_option (include/pds_lstsq.h): unknown names are refused; "keyed_sort" sends a shuffled frame through the stable sort +
+    gather route -- two runs give the same BITS (the partition route's sums follow cursor atomics: equal to rounding only) -- and agrees
+    with the default route to rounding."""
+    import torch
+
+    from polars_ds_extension_amd import _lib
+
+    ctx = pds.Context(0)
+    with pytest.raises(_lib.PdsError):
+        ctx.set_option("no_such_option", 1)
+    rng = np.random.default_rng(12)
+    G, p = 2000, 5
+    sizes = rng.integers(20, 120, size=G)
+    key = np.repeat(np.arange(G, dtype=np.int64) * 2 + 3, sizes)
+    N = len(key)
+    assert N >= 1 << 16
+    X = rng.normal(size=(N, p))
+    y = X @ rng.normal(size=p) + 1e-3 * key + 0.1 * rng.normal(size=N)
+    perm = rng.permutation(N)
+    cols, yt, kt = cols_of(X[perm]), dev(y[perm]), dev(key[perm])
+    k0, c0, n0 = pds.lin_reg_by_key(*cols, target=yt, key=kt, ctx=ctx)           # partition route
+    ctx.set_option("keyed_sort", 1)
+    k1, c1, n1 = pds.lin_reg_by_key(*cols, target=yt, key=kt, ctx=ctx)
+    k2, c2, n2 = pds.lin_reg_by_key(*cols, target=yt, key=kt, ctx=ctx)
+    ctx.set_option("keyed_sort", 0)
+    assert torch.equal(c1, c2) and torch.equal(n1, n2) and torch.equal(k1, k2)
+    assert torch.equal(k0, k1) and torch.equal(n0, n1)
+    assert float((c0 - c1).abs().max().item()) < 1e-9
+    ctx.close()
+
+
 @pytest.mark.parametrize("p,bias,f32", [(1, False, False), (4, True, False), (8, False, False), (8, True, True), (11, True, False), (16, False, False)])
 def test_by_key_pred_partition_route(pds, orc, p, bias, f32):
     """Shuffled rows, dense integer keys, >= 2^17 rows: per-row predictions of the PARTITION route (grouped_pred.hip MODE 3, round 5: the
