@@ -251,6 +251,37 @@ def test_rcond(pds, orc):
 
 
 # ------------------------------------------------------------------------------------------ report
+@pytest.mark.parametrize("p", list(range(1, 17)))
+def test_report_hc_leverages_every_width(pds, orc, p):
+    """HC2 / HC3 at every width of the small-frame kernel, with and without intercept, on a frame whose length is off the 128-row tile
+    (ragged last tile) and below it: the leverages come from the matrix cores (moments.hip LEVM: the four 16 x 16 x 4 steps stop early for
+    narrow f64 frames, the intercept is handled in closed form) -- robust errors against the oracle's per-row arithmetic, f64 and f32."""
+    rng = np.random.default_rng(900 + p)
+    for n in (100, 5_003, 70_001):
+        if n <= 2 * p + 4:
+            continue
+        X = rng.normal(size=(n, p)) + 0.3
+        y = X @ rng.normal(size=p) + 0.5 + (0.2 + np.abs(X[:, 0])) * rng.normal(size=n)  # heteroskedastic
+        for bias in (False, True):
+            Xb = np.c_[X, np.ones(n)] if bias else X
+            for se in ("hc2", "hc3"):
+                r = pds.lin_reg_report(*cols_of(X), target=dev(y), add_bias=bias, std_err=se)
+                ro = orc.lin_reg_report(Xb, y, std_err=se)
+                assert nrel(r["beta"], ro["beta"]) < F64_TOL, (n, bias, se)
+                assert frel(r[f"{se}_se"], ro["std_err"], 1e-12) < 1e-9, (n, bias, se, frel(r[f"{se}_se"], ro["std_err"], 1e-12))
+    # f32 frames (the f32 matrix instruction's operand layout differs: every step carries four strided features)
+    n = 20_011
+    X = (rng.normal(size=(n, p)) + 0.3).astype(np.float32)
+    y = (X.astype(np.float64) @ rng.normal(size=p) + 0.5 + (0.2 + np.abs(X[:, 0])) * rng.normal(size=n)).astype(np.float32)
+    pds.config.LIN_REG_EXPR_F64 = False
+    try:
+        r32 = pds.lin_reg_report(*cols_of(X), target=dev(y), add_bias=True, std_err="hc3")
+    finally:
+        pds.config.LIN_REG_EXPR_F64 = True
+    ro = orc.lin_reg_report(np.c_[X.astype(np.float64), np.ones(n)], y.astype(np.float64), std_err="hc3")
+    assert np.max(np.abs(np.asarray(r32["hc3_se"], np.float64) - ro["std_err"]) / ro["std_err"]) < F32_TOL
+
+
 @pytest.mark.parametrize("se", ["se", "hc0", "hc1", "hc2", "hc3"])
 @pytest.mark.parametrize("bias", [False, True])
 def test_lin_reg_report(pds, orc, se, bias):
