@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void key_descent_kernel(const int64_t* __restr
 // no library pass of its own (hipCUB's: 0.35 ms per 1e8 keys; round 3/4 read the keys a second time: + 0.15 ms).
 // slot_counts (nullable; kKeySlots x 8 counters, zeroed by the caller; needs a 16-byte aligned key buffer and a grid that is a multiple
 // of 16): the histogram the partition route (keyed_partition.hip) starts from, taken in the same pass -- slot = (key >> hist_shift) mod
-// kKeySlots, stream = (row / 4096) mod 8 (a block's pieces all belong to one stream: (blockIdx / 2) mod 8).  Valid when the key range
+// kKeySlots, stream = (row / 4096) mod 8 (a block takes 4 x U x 128 = 4096 keys per round with U = 8: all of one stream, blockIdx mod 8).  Valid when the key range
 // turns out to span at most kKeySlots buckets; bucket b is then slot (b + (min >> hist_shift)) mod kKeySlots.  A wave whose 128 keys
 // share one slot -- ordered keys -- adds once.
 #ifndef PDS_KEY_ORDER_U
@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256) void key_order_minmax_kernel(const int64_t* __
         mx = k > mx ? k : mx;
     };
     constexpr int U = PDS_KEY_ORDER_U;
+    static_assert(U == 4 || U == 8, "the histogram's stream of a block: 4 x U x 128 keys per round must divide or equal a 4096-row chunk");
     for (int64_t p0 = wave * U; p0 < npieces; p0 += nwaves * U) {
         ll2 v[U];
         long long edge[U];
