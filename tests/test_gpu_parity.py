@@ -1193,6 +1193,21 @@ def test_by_key_ordered_keys_run_lengths(pds, shift):
         assert torch.equal(nu, nu2) and torch.equal(torch.nan_to_num(co), torch.nan_to_num(co2))
 
 
+def test_by_key_more_groups_than_the_first_guess(pds):
+    """Without `max_groups` the outputs are sized for max(2^20, n / 16) groups; an ordered column with more distinct keys than that comes
+    back with the count (the order check's run total, before anything is written) and the call repeats with the exact capacity."""
+    import torch
+
+    n = 3_000_000
+    key = torch.arange(n, dtype=torch.int64, device="cuda") // 2  # 1.5e6 groups of two rows
+    x = torch.linspace(0.0, 1.0, n, dtype=torch.float64, device="cuda") + (torch.arange(n, device="cuda") % 2).double()
+    y = 2.0 * x + 1.0
+    k, co, nu = pds.lin_reg_by_key(x, target=y, key=key, add_bias=True)
+    assert k.shape[0] == n // 2 and torch.equal(k, torch.arange(n // 2, dtype=torch.int64, device="cuda"))
+    assert int(nu.sum().item()) == 0
+    assert float((co[:, 0] - 2.0).abs().max().item()) < 1e-6 and float((co[:, 1] - 1.0).abs().max().item()) < 1e-6
+
+
 def test_by_key_order_check_sees_every_inversion(pds):
     """keyed.hip's one-pass order check (16-byte loads, the successor of a key from the lane itself, the next lane or the next
     128-key piece): ONE adjacent inversion anywhere -- inside a lane's pair, between lanes, between pieces, in the unaligned head,
