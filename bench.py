@@ -648,6 +648,15 @@ def _other_configs(torch, pds, ctx, dev, xs, y, N, P, with_cpu=True):
         streams = 2  # Gram + one more pass (residual pass, or the fused residual + meat pass)
         out[f"report_c2_{se}"] = {"wall_ms": round(ms, 3), "streams_over_the_frame": streams,
                                   "frac_of_hbm_peak": round(streams * gb / ms * 1e3 / HBM_PEAK_GBPS, 4)}
+    if with_cpu:
+        try:
+            _report_cpu(out, xs, y, N, P)
+        except Exception as e:
+            out["report_c2_se"]["cpu"] = {"error": f"{type(e).__name__}: {e}"}
+        try:
+            out["config1"] = _config1(torch, pds, ctx, dev)
+        except Exception as e:
+            out["config1"] = {"error": f"{type(e).__name__}: {e}"}
     n, p, w = 100_000_000, 8, 256
     gen = torch.Generator(device=dev)
     gen.manual_seed(3)
@@ -672,7 +681,7 @@ def _other_configs(torch, pds, ctx, dev, xs, y, N, P, with_cpu=True):
     del rx, ry
     torch.cuda.empty_cache()
     try:
-        out["elastic_net_c5"] = _c5(torch, pds, ctx, dev)
+        out["elastic_net_c5"] = _c5(torch, pds, ctx, dev, with_cpu=with_cpu)
     except Exception as e:
         out["elastic_net_c5"] = {"error": f"{type(e).__name__}: {e}"}
     try:
@@ -713,7 +722,92 @@ def _other_configs(torch, pds, ctx, dev, xs, y, N, P, with_cpu=True):
     return out
 
 
-def _c5(torch, pds, ctx, dev):
+def _report_cpu(out, xs, y, N, P, ns=2_000_000):
+    """pl_lin_reg_report on the host beside C2's report (linear_regression.rs:822-980): the oracle's restatement -- X'X, explicit inverse,
+    beta = (inv X') y, residual pass (+ the leverage / meat sums of HC3) -- on a row PREFIX of the same frame with the ones column, one
+    thread (the port is sequential; the reference's products run on faer's rayon pool), scaled by rows to the frame."""
+    import numpy as np
+
+    from oracle import oracle as orc
+
+    ns = min(ns, N)
+    X = np.empty((ns, P + 1), dtype=np.float64, order="F")
+    for j in range(P):
+        X[:, j] = xs[j][:ns].cpu().numpy()
+    X[:, P] = 1.0
+    yh = y[:ns].cpu().numpy()
+    for se in ("se", "hc3"):
+        t0 = time.perf_counter()
+        rep = orc.lin_reg_report(X, yh, std_err=se)
+        t = time.perf_counter() - t0
+        gpu_s = out[f"report_c2_{se}"]["wall_ms"] / 1e3
+        out[f"report_c2_{se}"]["cpu"] = {
+            "kind": "port", "unit": "s/fit", "cores": 1, "value": round(t * N / ns, 2), "sample_s": round(t, 3),
+            "sample": f"first {ns} rows of the same frame x {P} f64 features + ones column, std_err = {se}, 1 thread = {t:.2f} s; "
+                      f"every pass is linear in rows: scaled by {N / ns:.0f} to the frame",
+            "gpu_fit_s": round(gpu_s, 5), "gpu_over_cpu": round(t * N / ns / gpu_s, 1), "r2_of_sample": float(rep["r2"])}
+
+
+def _config1(torch, pds, ctx, dev, calls=200):
+    """configs[0] (benchmarks/test_linear_regression.py:9-31): pds.lin_reg(x1..x4, target=y, add_bias=False) on a 100 000-row f64 frame,
+    seed 208 -- the reference's own CPU-runnable case.  Here: host Arrow buffers -> `_polars_plugin_pl_lr` -> Arrow list, through the
+    plugin-ABI harness (PCIe both ways inside every call), the same columns resident in HBM through the C ABI, and the oracle's `pl_lr`
+    (gated col-piv QR on X'X) on the host, 1 thread and all threads."""
+    import numpy as np
+    import pyarrow as pa
+
+    sys.path.insert(0, str(ROOT / "tests"))
+    import plugin_harness as ph
+    from oracle import oracle as orc
+    from polars_ds_extension_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(208)
+    n = 100_000
+    X = rng.random((n, 4))
+    yh = X @ np.array([0.5, 0.25, -0.15, 0.2]) + 1e-4 * rng.random(n)
+    host = [("y", pa.array(yh))] + [(f"x{j + 1}", pa.array(np.ascontiguousarray(X[:, j]))) for j in range(4)]
+    kw = {"bias": False, "null_policy": "raise", "l1_reg": 0.0, "l2_reg": 0.0, "solver": "qr", "tol": 1e-5, "max_iter": 200,
+          "weighted": False, "positive": False, "singular_x_tol": 1e-12}
+
+    def per_call(fn, k):
+        for _ in range(5):
+            r = fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(k):
+            r = fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / k * 1e6, r
+
+    us_plugin, res = per_call(lambda: ph.call_plugin(lib, "pl_lr", host, kw)[1], calls)
+    b_gpu = np.asarray(res[0].as_py(), dtype=np.float64)
+    dcols = [torch.from_numpy(np.ascontiguousarray(X[:, j])).to(dev) for j in range(4)]
+    dy = torch.from_numpy(yh).to(dev)
+    us_dev, _ = per_call(lambda: pds.lin_reg(*dcols, target=dy, ctx=ctx), calls)
+    Xf = np.asfortranarray(X)
+    nthreads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    nt = min(nthreads, orc.max_threads()) if orc.max_threads() > 0 else nthreads
+    cpu = {}
+    for t in sorted({1, min(nt, 8)}):
+        for _ in range(3):
+            b_cpu = orc.solve_lr_gated(Xf, yh, 0.0, False, "qr", 1e-12, nthreads=t)
+        t0 = time.perf_counter()
+        for _ in range(50):
+            b_cpu = orc.solve_lr_gated(Xf, yh, 0.0, False, "qr", 1e-12, nthreads=t)
+        cpu[t] = (time.perf_counter() - t0) / 50 * 1e6
+    best = min(cpu, key=cpu.get)
+    return {"workload": "pds.lin_reg(x1..x4, target=y, add_bias=False), 100 000 rows f64, seed 208 (the reference's CPU-runnable benchmark case)",
+            "plugin_abi_host_arrow_us_per_call": round(us_plugin, 1), "c_abi_hbm_resident_us_per_call": round(us_dev, 1),
+            "bytes_per_call": n * 5 * 8, "hbm_resident_frac_of_hbm_peak": round(n * 5 * 8 / (us_dev * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+            "note": "4 MB per call: launch + synchronisation latency, not bandwidth, on both GPU routes",
+            "max_rel_err_vs_cpu": float(np.max(np.abs(b_gpu - b_cpu) / np.abs(b_cpu))),
+            "cpu": {"kind": "port", "unit": "us/call", "cores": int(best), "value": round(cpu[best], 1),
+                    "us_per_call_by_threads": {str(k): round(v, 1) for k, v in cpu.items()},
+                    "sample": "the whole workload (100 000 rows x 4), 50 calls per thread count after 3 warm-up calls: X'X + X'y + rank gate + col-piv QR (pl_lr default path)"}}
+
+
+def _c5(torch, pds, ctx, dev, with_cpu=True):
     """configs[4]: elastic net (l1 = l2 = 0.01, tol 1e-5) on 1e7 rows x 512 f32 features, AR(0.5) columns, 32 true coefficients --
     one Gram build (MFMA bound) + coordinate-descent sweeps on the 514 x 514 moment matrix.  Both f32 Gram arithmetics."""
     n, p = 10_000_000, 512
@@ -749,7 +843,8 @@ def _c5(torch, pds, ctx, dev):
             t = ctx.get_timing(reset=True)
             gram = t["moments"][0] / max(t["moments"][1], 1)
             useful = n * (p + 2) * (p + 3)  # flops of the upper triangle incl. the diagonal, 2 per multiply-add
-            out[name] = {"wall_ms": round(wall, 2), "gram_ms": round(gram, 3), "gram_useful_TFLOPs": round(useful / gram / 1e9, 1),
+            out[name] = {"wall_ms": round(wall, 2), "gram_ms": round(gram, 3), "cd_ms": round(t["iterative"][0] / max(t["iterative"][1], 1), 3),
+                         "gram_useful_TFLOPs": round(useful / gram / 1e9, 1),
                          "frac_of_f32_mfma_peak_157TF": round(useful / gram / 1e9 / 157.3, 3), "nonzero": int((abs(b) > 1e-6).sum())}
             if native == "0":
                 # the split path does NOT execute on the f32 pipe: every product is six v_mfma_f32_32x32x16_bf16 (hh, hm, mh, hl,
@@ -762,7 +857,51 @@ def _c5(torch, pds, ctx, dev):
     finally:
         ctx.set_option("wide_f32_native", 0)
         pds.config.LIN_REG_EXPR_F64 = True
+    if with_cpu:
+        try:
+            out["cpu"] = _c5_cpu(xs, y, n, p, out.get("bf16x3_split_default", {}).get("wall_ms"))
+        except Exception as e:
+            out["cpu"] = {"error": f"{type(e).__name__}: {e}"}
     return out
+
+
+def _c5_cpu(xs, y, n, p, gpu_wall_ms, ns=200_000):
+    """The reference's elastic net on the host beside C5 (benchmarks/test_linear_regression.py:119-179 times the same fit through sklearn
+    and pds): the oracle's f32 `faer_coordinate_descent` (lr_solvers.rs:426-538) in its two parts -- X'X + X'y of a bounded ROW SAMPLE of
+    the same frame on all host threads (the reference: faer matmul, Par::rayon(0)), scaled by rows to the frame; the covariance-update
+    sweeps on the 512 x 512 block, one thread (sequential Gauss-Seidel, as the reference) -- they do not depend on the row count."""
+    import numpy as np
+
+    from oracle import oracle as orc
+
+    orc.build()
+    nthreads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    nt = min(nthreads, orc.max_threads()) if orc.max_threads() > 0 else nthreads
+    X = np.empty((ns, p), dtype=np.float32, order="F")
+    for j in range(p):
+        X[:, j] = xs[j][:ns].cpu().numpy()
+    yh = y[:ns].cpu().numpy()
+    orc.gram(X[:4096], nthreads=nt)  # (warm the thread pool)
+    t0 = time.perf_counter()
+    G = orc.gram(X, nthreads=nt)
+    c = orc.xty(X, yh, nthreads=nt)
+    t_gram = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    beta, sweeps, conv = orc.cd_from_gram(G, c, np.zeros(p, dtype=np.float32), 0.0, float(ns), 0.01, 0.01, False, 1e-5, 2000)
+    t_cd = time.perf_counter() - t0
+    gram_scaled = t_gram * (n / ns)
+    res = {"kind": "port", "unit": "s/fit", "cores": nt, "nproc": os.cpu_count(),
+           "sample": f"first {ns} rows of the same frame x {p} f32 features: X'X + X'y on {nt} threads = {t_gram:.2f} s (scaled by rows to {n:.0e}: "
+                     f"{gram_scaled:.1f} s); {sweeps} covariance-update sweeps on the {p} x {p} block, 1 thread = {t_cd:.3f} s "
+                     f"(f32 twin: tol 1e-5, at most 2000 sweeps, linear_regression_f32.rs:362)",
+           "gram_sample_s": round(t_gram, 3), "gram_s_scaled_to_frame": round(gram_scaled, 2),
+           "gram_GFLOPs_upper_triangle": round(ns * p * (p + 1) / t_gram / 1e9, 1),
+           "sweeps": int(sweeps), "converged": bool(conv), "us_per_sweep": round(t_cd / max(sweeps, 1) * 1e6, 1), "cd_s": round(t_cd, 4),
+           "value": round(gram_scaled + t_cd, 2), "nonzero": int((np.abs(beta) > 1e-6).sum())}
+    if gpu_wall_ms:
+        res["gpu_fit_s"] = round(gpu_wall_ms / 1e3, 4)
+        res["gpu_over_cpu"] = round((gram_scaled + t_cd) / (gpu_wall_ms / 1e3), 1)
+    return res
 
 
 def _c3_spec(torch, pds, ctx, dev):

@@ -93,6 +93,11 @@ int pds_set_host_staging(double chunk_mb, double resident_max_mb);
 /* Diagnostics: how many call-local workspace slices had to be allocated outside the per-call reservation since the context
  * was created (0 unless an entry point under-estimated its bound; the slices are still valid, never out of bounds). */
 long long pds_ctx_workspace_spills(const pds_ctx* ctx);
+/* Bytes the context currently holds in one of its grow-only HBM workspaces: which = 0 call-local scratch, 1 host-frame staging,
+ * 2 solver / key-order scratch, 3 the keyed-grouping workspace (pds_lr_by_key_*), 4 the weighted grouped frame.  -1 on a bad argument.
+ * Lets a host size its frames against what a route reserves (the partition route of unordered keys must not reserve the sort
+ * route's buffers: tests/test_gpu_parity.py). */
+long long pds_ctx_workspace_bytes(const pds_ctx* ctx, int which);
 /*
  * Measurement hooks (bench.py): with timing enabled every kernel class is bracketed by a HIP event
  * pair recorded on the context's stream.  pds_ctx_get_timing synchronises and returns, per class,
@@ -111,7 +116,10 @@ typedef struct {
     double l1_reg;         /* kwargs.l1_reg */
     double l2_reg;         /* kwargs.l2_reg */
     double tol;            /* kwargs.tol (CD / NNLS convergence; rcond for pds_lr_rcond) */
-    int solver;            /* pds_solver, from kwargs.solver */
+    int solver;            /* pds_solver, from kwargs.solver.  Grouped fits with PDS_SOLVER_SVD and the rank gate on: the systems a
+                            * chunk marks next to the gate go through a host SVD (the reference's thin_svd gate, lr_solvers.rs:358-366)
+                            * while the marked set costs no more than 2048 systems of 66 x 66 (5.6e5 systems at 8 features); a larger
+                            * set takes the device pivoted QR -- same gate statistic, beta from QR instead of the SVD. */
     int positive;          /* kwargs.positive */
     int max_iter;          /* kwargs.max_iter (the f32 twin ignores it: 2000 CD; NNLS 200 in pl_lr_f32, 2000 in pl_lr_pred_f32) */
     double singular_x_tol; /* kwargs.singular_x_tol: > 0 enables the log-det rank gate */

@@ -20,7 +20,7 @@ PDS_REPORT_DERIVE_YVAR = 0x100  # include/pds_lstsq.h
 
 EXPORTS = [
     "pds_last_error", "pds_version", "pds_ctx_create", "pds_ctx_destroy", "pds_ctx_set_stream",
-    "pds_ctx_synchronize", "pds_ctx_num_cus", "pds_ctx_set_option", "pds_set_host_staging", "pds_rows_to_cols_f64", "pds_rows_to_cols_f32", "pds_glm_irls_f64", "pds_glm_irls_f32", "pds_lr_rowmajor_f64", "pds_lr_rowmajor_f32", "pds_ctx_workspace_spills", "pds_ctx_set_timing", "pds_ctx_get_timing", "pds_ctx_get_timing_samples",
+    "pds_ctx_synchronize", "pds_ctx_num_cus", "pds_ctx_set_option", "pds_set_host_staging", "pds_rows_to_cols_f64", "pds_rows_to_cols_f32", "pds_glm_irls_f64", "pds_glm_irls_f32", "pds_lr_rowmajor_f64", "pds_lr_rowmajor_f32", "pds_ctx_workspace_spills", "pds_ctx_workspace_bytes", "pds_ctx_set_timing", "pds_ctx_get_timing", "pds_ctx_get_timing_samples",
     "pds_lr_f64", "pds_lr_f32", "pds_lr_pred_f64", "pds_lr_pred_f32", "pds_lr_rcond_f64", "pds_lr_rcond_f32", "pds_elastic_net_f64", "pds_elastic_net_f32", "pds_lr_nullable_f64", "pds_lr_nullable_f32", "pds_lr_multi_f64", "pds_lr_multi_f32",
     "pds_lin_reg_report_f64", "pds_lin_reg_report_f32",
     "pds_report_fit_from_moments_f64", "pds_report_fit_from_moments_f32", "pds_report_partials_f64", "pds_report_partials_f32",
@@ -113,6 +113,9 @@ def load() -> C.CDLL:
         if hasattr(lib, "pds_ctx_workspace_spills"):  # (absent from older builds used in A/B runs)
             lib.pds_ctx_workspace_spills.argtypes = [C.c_void_p]
             lib.pds_ctx_workspace_spills.restype = C.c_longlong
+        if hasattr(lib, "pds_ctx_workspace_bytes"):
+            lib.pds_ctx_workspace_bytes.argtypes = [C.c_void_p, C.c_int]
+            lib.pds_ctx_workspace_bytes.restype = C.c_longlong
         _lib = lib
     return _lib
 

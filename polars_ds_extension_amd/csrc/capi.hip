@@ -158,6 +158,12 @@ int pds_set_host_staging(double chunk_mb, double resident_max_mb) {
 
 long long pds_ctx_workspace_spills(const pds_ctx* ctx) { return ctx ? ctx->ws_spill_count : -1; }
 
+long long pds_ctx_workspace_bytes(const pds_ctx* ctx, int which) {
+    if (!ctx) return -1;
+    const pds::Workspace* w[5] = {&ctx->ws, &ctx->stage, &ctx->solve_ws, &ctx->keyed, &ctx->wkeyed};
+    return which >= 0 && which < 5 ? (long long)w[which]->bytes : -1;
+}
+
 int pds_ctx_set_timing(pds_ctx* ctx, int enable) {
     if (!ctx) return fail(PDS_ERR_INVALID, "null ctx");
     ctx->timing = enable != 0;

@@ -543,7 +543,8 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
     const size_t cbi_bytes = (size_t)part_ids * grouped_pred_table_stride<T>(pp) * sizeof(T);
     const bool pred_table = partition && want_pred && part_ids <= ((int64_t)1 << 25) && cbi_bytes <= ((size_t)1 << 30);
     if (pred_table) need += up(cbi_bytes);
-    else if (!sorted) need += 2 * key_bytes + 2 * idx_bytes + col_bytes * nc + up((size_t)n_rows * nc * sizeof(T)) + up(2 * (size_t)nc * sizeof(T*)) + 1024;
+    // the sort + gather route's buffers: only when neither the order check nor the partition route serves the frame
+    if (!partition && !sorted) need += 2 * key_bytes + 2 * idx_bytes + col_bytes * nc + up((size_t)n_rows * nc * sizeof(T)) + up(2 * (size_t)nc * sizeof(T*)) + 1024;
     if (want_pred) need += up(sizeof(T*) * (size_t)std::max(nc, 18)) + (space == PDS_HOST ? 2 * col_bytes + up((size_t)n_rows) : 0);
     if (int rc = ensure_ws(ctx, ctx->keyed, need)) return rc;
     tr.mark("workspace");

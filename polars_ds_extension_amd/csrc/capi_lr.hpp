@@ -131,12 +131,20 @@ static bool host_svd_gated(const std::vector<T>& M, int p, int bias, double l2, 
 // next to the gate (groups with barely more rows than columns, duplicated columns, an overflowing marked list) arrives here whole --
 // 1e5+ systems -- and takes the device pivoted QR instead: its gate statistic ln det G - sum ln G_ii is the same number (|det| is the
 // product of the R diagonal as well as of the singular values), only the factorisation behind beta differs, to rounding.
-constexpr int64_t kHostSvdMax = 2048;
+// The bound is a COST bound (a Jacobi SVD of a q x q block is O(q^3) per sweep; 2048 systems of 65 x 65 are about two seconds of one
+// host thread): narrow systems come in much larger sets -- 5.6e5 at 8 features -- before the route changes.  Beyond it the result
+// depends on how many systems a chunk marked (documented: include/pds_lstsq.h "solver").
+constexpr int64_t kHostSvdMax = 2048;  // ... systems of the widest LDS-solved block (q = 66)
+static inline int64_t host_svd_max_systems(int q) {
+    const double unit = 66.0 * 66.0 * 66.0 * (double)kHostSvdMax;
+    const double n = unit / ((double)q * q * q);
+    return (int64_t)std::min<double>(std::max<double>(n, (double)kHostSvdMax), (double)((int64_t)1 << 20));
+}
 template <typename T>
 int launch_solve_marked(pds_ctx* ctx, const T* d_rec, int64_t n, const SolveParams& sp, T* d_co, uint8_t* d_fl, const int64_t* d_rows_per_sys) {
     if (n <= 0) return PDS_OK;
     SolveParams sq = sp;
-    if (sp.solver != PDS_SOLVER_SVD || !(sp.gate_tol > 0.0) || n > kHostSvdMax) {
+    if (sp.solver != PDS_SOLVER_SVD || !(sp.gate_tol > 0.0) || n > host_svd_max_systems(sp.p + 2)) {
         sq.solver = PDS_SOLVER_QR;
         return launch_solve<T>(ctx, d_rec, n, sq, d_co, d_fl, nullptr, d_rows_per_sys);
     }

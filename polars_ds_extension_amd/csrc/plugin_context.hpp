@@ -3,11 +3,21 @@
 #pragma once
 
 // ------------------------------------------------------------------------------------------------- context
+void apply_context_options(pds_ctx* c) {
+    (void)pds_ctx_set_option(c, "keyed_sort", settings().keyed_sort ? 1 : 0);
+    (void)pds_ctx_set_option(c, "wide_f32_native", settings().wide_f32_native ? 1 : 0);
+}
 pds_ctx* thread_ctx() {
     // Polars calls plugin symbols from many rayon threads: one context (stream + workspace) per thread
     thread_local pds_ctx* ctx = nullptr;
+    thread_local int epoch = 0;  // the settings generation this context's options were taken from
     if (!ctx) {
         if (pds_ctx_create(settings().device, &ctx) != PDS_OK) raise(pds_last_error());
+    }
+    const int now = g_settings_epoch.load(std::memory_order_acquire);
+    if (epoch != now) {
+        apply_context_options(ctx);
+        epoch = now;
     }
     return ctx;
 }
@@ -23,14 +33,22 @@ struct MultiContexts {
     std::mutex busy;
     std::vector<pds_ctx*> ctxs;
     bool tried = false;
+    int epoch = 0;
     static MultiContexts& get() {
         static MultiContexts* m = new MultiContexts();
         return *m;
     }
     // call with `busy` held
     const std::vector<pds_ctx*>& contexts() {
-        if (tried) return ctxs;
+        const int now = g_settings_epoch.load(std::memory_order_acquire);
+        if (tried) {
+            if (epoch != now)
+                for (pds_ctx* c : ctxs) apply_context_options(c);
+            epoch = now;
+            return ctxs;
+        }
         tried = true;
+        epoch = now;
         std::vector<int> devs;
         const std::string devices = settings().devices;
         const char* e = devices.c_str();
@@ -55,7 +73,10 @@ struct MultiContexts {
         for (int k = 0; k < per; ++k)      // (device-major interleave: slice s goes to device s mod n_dev first)
             for (int d : devs) {
                 pds_ctx* c = nullptr;
-                if (pds_ctx_create(d, &c) == PDS_OK && c) ctxs.push_back(c);
+                if (pds_ctx_create(d, &c) == PDS_OK && c) {
+                    apply_context_options(c);
+                    ctxs.push_back(c);
+                }
             }
         return ctxs;
     }

@@ -13,6 +13,10 @@ struct PluginSettings {
     bool reference_quirks = false;                // PDS_REFERENCE_QUIRKS=1: the reference's two result-assembly accidents, as it has them
     size_t pinned_cache_bytes = (size_t)4 << 30;  // PDS_PLUGIN_PINNED_CACHE_MB: page-locked result blocks kept between calls
     bool pinned_results = true;                   // PDS_PLUGIN_PINNED_RESULTS=0: pageable result storage
+    // the two CONTEXT options (pds_ctx_set_option) as the plugin layer's contexts get them: a context latches the environment when it
+    // is created, the plugin's contexts live for the process -- so a reload re-applies these to every context at its next use
+    bool keyed_sort = false;                      // PDS_KEYED_SORT=1: the determinism switch of the keyed route
+    bool wide_f32_native = false;                 // PDS_WIDE_F32_NATIVE=1
 
     static PluginSettings from_env() {
         PluginSettings s;
@@ -26,9 +30,12 @@ struct PluginSettings {
         if (const char* e = env("PDS_REFERENCE_QUIRKS")) s.reference_quirks = e[0] == '1';
         if (const char* e = env("PDS_PLUGIN_PINNED_CACHE_MB")) s.pinned_cache_bytes = (size_t)std::max<long long>(0, std::atoll(e)) << 20;
         if (const char* e = env("PDS_PLUGIN_PINNED_RESULTS")) s.pinned_results = e[0] != '0';
+        if (const char* e = env("PDS_KEYED_SORT")) s.keyed_sort = e[0] == '1';
+        if (const char* e = env("PDS_WIDE_F32_NATIVE")) s.wide_f32_native = e[0] == '1';
         return s;
     }
 };
+std::atomic<int> g_settings_epoch{1};  // bumped by pds_plugin_reload_settings: contexts re-apply the context options when they see a new one
 PluginSettings& settings() {
     static PluginSettings* s = new PluginSettings(PluginSettings::from_env());  // (never destroyed: results may outlive static destruction)
     return *s;

@@ -116,6 +116,12 @@ class Context:
     def num_cus(self) -> int:
         return int(self._lib.pds_ctx_num_cus(self._h))
 
+    WORKSPACES = ("scratch", "stage", "solve", "keyed", "wkeyed")
+
+    def workspace_bytes(self, which: str = "keyed") -> int:
+        """Bytes held in one of the context's grow-only HBM workspaces (pds_ctx_workspace_bytes)."""
+        return int(self._lib.pds_ctx_workspace_bytes(self._h, self.WORKSPACES.index(which)))
+
     KINDS = ("moments", "grouped_moments", "solve", "pass2", "rolling", "iterative")
 
     def set_timing(self, enable: bool) -> None:

@@ -61,6 +61,19 @@ def _dist():
     return dist
 
 
+def _collective_device(dist, group, fallback):
+    """Where a small control tensor of a collective must live: the current GPU under the nccl (= RCCL) backend, else `fallback`."""
+    import torch
+
+    try:
+        backend = str(dist.get_backend(group))
+    except Exception:
+        backend = ""
+    if "nccl" in backend and torch.cuda.is_available():
+        return torch.device("cuda", torch.cuda.current_device())
+    return fallback
+
+
 def _hip_moments(xs, y, weights=None):
     from . import lstsq
 
@@ -181,7 +194,8 @@ class GroupedShardPlan:
             if world > 1 and gather_to is not None:
                 # the piece count decides how the gathering rank cuts every peer's rows: ranks whose shards differ by a group must not
                 # round the model to different counts -- one tiny all-reduce(MAX) when the plan is built (building a plan is collective)
-                agree = torch.tensor([int(chunks)], dtype=torch.int64, device=dev)
+                # (on the backend's device: RCCL reduces device tensors only, whatever space the shard's columns live in)
+                agree = torch.tensor([int(chunks)], dtype=torch.int64, device=_collective_device(dist, group, dev))
                 dist.all_reduce(agree, op=dist.ReduceOp.MAX, group=group)
                 chunks = int(agree.item())
         self.chunks = chunks = max(1, int(chunks))
@@ -211,9 +225,15 @@ class GroupedShardPlan:
         self._runs, self._send_batches = [], []
         use_prepared = False
         if default_fn and is_t and y_loc.is_cuda:  # (the wire dtype is the library's result dtype: the fit writes into place)
+            import inspect
+
             from . import lstsq
 
-            use_prepared = cdt == (torch.float64 if lstsq._dtype() == np.float64 else torch.float32)
+            # kwargs that only lin_reg_by takes (null_policy, weights): the unprepared call, as before the plan existed
+            prepared_kw = set(inspect.signature(lstsq.GroupedFit.__init__).parameters)
+            use_prepared = cdt == (torch.float64 if lstsq._dtype() == np.float64 else torch.float32) and set(lin_reg_kwargs) <= prepared_kw
+        # the library's own fit runs on the caller's context on either path; an injected function gets exactly the caller's kwargs
+        call_kw = dict(lin_reg_kwargs, ctx=ctx) if (default_fn and ctx is not None) else lin_reg_kwargs
         for c_lo, c_hi in (b for b in chunk_bounds(ng, chunks) if ng > 0 and b[1] > b[0]):
             r0, r1 = int(off_h[c_lo]), int(off_h[c_hi])
             co_v, nu_v = self.co_loc[c_lo:c_hi], self.nu_loc[c_lo:c_hi]
@@ -223,7 +243,7 @@ class GroupedShardPlan:
                 fit = lstsq.GroupedFit(*xs_p, target=y_p, group_offsets=sub_off, out=co_v, out_null=nu_v, ctx=ctx, **lin_reg_kwargs)
                 self._runs.append(fit.run)
             else:
-                self._runs.append(self._injected(grouped_fn or _hip_grouped_out, xs_p, y_p, sub_off, co_v, nu_v, lin_reg_kwargs))
+                self._runs.append(self._injected(grouped_fn or _hip_grouped_out, xs_p, y_p, sub_off, co_v, nu_v, call_kw))
             if gather_to is not None and not is_root:
                 self._send_batches.append([dist.P2POp(dist.isend, co_v, gather_to, group), dist.P2POp(dist.isend, nu_v, gather_to, group)])
 

@@ -676,6 +676,34 @@ def test_context_options(pds):
     ctx.close()
 
 
+def test_partition_route_does_not_reserve_the_sort_routes_workspace(pds):
+    """The workspace a shuffled dense-key fit reserves (`pds_ctx_workspace_bytes`, capi_grouped.hpp `need`): the partition route holds
+    its record buffers -- not ALSO the sorted keys, ranks and gathered copy of the frame the sort route needs (a round-5 regression:
+    a dangling else tied that reservation to the per-row prediction table).  The same frame through "keyed_sort" reserves more."""
+    rng = np.random.default_rng(77)
+    G, p = 4000, 8
+    key = np.repeat(np.arange(G, dtype=np.int64), 64)
+    N = len(key)
+    X = rng.normal(size=(N, p))
+    y = X @ rng.normal(size=p) + 0.1 * rng.normal(size=N)
+    perm = rng.permutation(N)
+    cols, yt, kt = cols_of(X[perm]), dev(y[perm]), dev(key[perm])
+    frame_bytes = N * (p + 1) * 8
+    ctx = pds.Context(0)
+    pds.lin_reg_by_key(*cols, target=yt, key=kt, ctx=ctx, max_groups=G)
+    part = ctx.workspace_bytes("keyed")
+    ctx.close()
+    ctx = pds.Context(0)
+    ctx.set_option("keyed_sort", 1)
+    pds.lin_reg_by_key(*cols, target=yt, key=kt, ctx=ctx, max_groups=G)
+    srt = ctx.workspace_bytes("keyed")
+    ctx.close()
+    # sort route: 2 key copies + 2 rank arrays + a gathered copy of the frame twice over (columns + packed rows) > 2 frames;
+    # partition route: one record per row (frame + ids) + bucket tables
+    assert srt > 2 * frame_bytes
+    assert 0 < part < 2 * frame_bytes and part < srt - frame_bytes, (part, srt, frame_bytes)
+
+
 @pytest.mark.parametrize("p,bias,f32", [(1, False, False), (4, True, False), (8, False, False), (8, True, True), (11, True, False), (16, False, False)])
 def test_by_key_pred_partition_route(pds, orc, p, bias, f32):
     """Shuffled rows, dense integer keys, >= 2^17 rows: per-row predictions of the PARTITION route (grouped_pred.hip MODE 3, round 5: the

@@ -97,10 +97,9 @@ if "en" in which:
                              "gram_TFLOPs_upper_triangle": round(flops / 2 / (gms * 1e-3) / 1e12, 1),
                              "cd_ms": round(t.get("iterative", (0, 0))[0], 3), "nonzero": int((abs(b) > 1e-6).sum()),
                              "arithmetic": "f32 products as three-plane bf16 splits on the bf16 matrix cores (default)"}
-    import os
-    os.environ["PDS_WIDE_F32_NATIVE"] = "1"
+    ctx.set_option("wide_f32_native", 1)  # (a context option since round 5: the environment is only its default at pds_ctx_create)
     wall2, t2, _ = timed(lambda: pds.lin_reg(*xs, target=y, l1_reg=0.01, l2_reg=0.01, tol=1e-5, ctx=ctx), reps=3, warm=1)
-    del os.environ["PDS_WIDE_F32_NATIVE"]
+    ctx.set_option("wide_f32_native", 0)
     out["elastic_net_c5"]["native_f32_mfma"] = {"wall_ms": round(wall2 * 1e3, 2), "gram_ms": round(t2["moments"][0], 3)}
     pds.config.LIN_REG_EXPR_F64 = True
 if "c1" in which:

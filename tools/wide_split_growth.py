@@ -1,5 +1,5 @@
 """The f32 wide Gram's distance to an f64 Gram of the same f32 data against the frame length, both arithmetics (bf16 x 3 split =
-default; PDS_WIDE_F32_NATIVE=1 = v_mfma_f32_32x32x2_f32; the switch is read per call): does the split's error stay bounded?
+default; context option "wide_f32_native" = v_mfma_f32_32x32x2_f32, set per run through Context.set_option): does the split's error stay bounded?
 The reference is summed over 1e6-row chunks (torch f64 matmul), so the frame never exists in f64.
    python tools/wide_split_growth.py [p=512] [n=1e6,1e7,3e7] [offset=3.0]"""
 import os, sys, time
@@ -31,12 +31,12 @@ for n in ns:
     T = T.cpu().numpy()
     sc = np.sqrt(np.outer(np.diag(T), np.diag(T)))
     for native in ("0", "1"):
-        os.environ["PDS_WIDE_F32_NATIVE"] = native
+        ctx.set_option("wide_f32_native", int(native))
         A = np.asarray(pds.gram_moments(*xs, target=y, ctx=ctx)).astype(np.float64)
         d = np.abs(A - T)
         print(f"n={n:.0e} p={p} offset={off} {'native f32 mfma' if native == '1' else 'bf16 x3 split  '}: fro_rel {np.linalg.norm(d) / np.linalg.norm(T):.3e}  "
               f"max |d| / sqrt(G_ii G_jj) {(d / sc).max():.3e}  diag rel {np.max(np.diag(d) / np.diag(T)):.3e}  "
               f"signed mean (A-T)/sc {np.mean((A - T) / sc):.3e}", flush=True)
-    os.environ.pop("PDS_WIDE_F32_NATIVE", None)
+    ctx.set_option("wide_f32_native", 0)
     del xs, y
     torch.cuda.empty_cache()
