@@ -429,6 +429,23 @@ int pds_host_alloc(size_t bytes, void** out);
 int pds_host_free(void* p);
 /* number of visible devices (the plugin layer's PDS_DEVICES=all) */
 int pds_device_count(int* n);
+/*
+ * Result storage another PROCESS's kernels can write (one process per device, SURVEY.md 8(e) row C3 "results: gather of n_groups_r x p'
+ * f64 + validity to rank 0"): the gathering rank allocates the assembled [n_groups][p'] block with pds_device_alloc (hipMalloc on
+ * `device`: an IPC handle names a whole allocation), exports it, hands the 64 handle bytes to its peers (any side channel: the
+ * launcher's store, a broadcast), every peer maps it with pds_ipc_open on ITS device (peer access over xGMI is enabled by the
+ * mapping) and passes `mapped + its groups' offset` as the `coeffs` / `is_null` arguments of pds_lr_grouped_*: the fit's stores
+ * cross the link while the kernel runs -- no staging buffer, no send / receive launches, no separate gather step.  The gathering rank
+ * may read the rows once the peer's stream has passed the call (the host's completion signal: a barrier, an all-reduce of a flag).
+ * pds_ipc_close unmaps (the allocation stays the exporter's, freed with pds_device_free after every peer has closed).
+ * python: polars_ds_extension_amd/parallel.py, GroupedShardPlan(direct=True).
+ */
+#define PDS_IPC_HANDLE_BYTES 64
+int pds_device_alloc(int device, size_t bytes, void** out);
+int pds_device_free(int device, void* p);
+int pds_ipc_export(int device, void* p, unsigned char handle[PDS_IPC_HANDLE_BYTES]);
+int pds_ipc_open(int device, const unsigned char handle[PDS_IPC_HANDLE_BYTES], void** mapped);
+int pds_ipc_close(int device, void* mapped);
 
 /*
  * pds_lr_grouped_pred_* / pds_lr_by_key_pred_*: the grouped form of `pl_lr_pred` (linear_regression.rs:704-820) -- what

@@ -9,6 +9,7 @@ from . import config  # noqa: F401
 from . import linear_models  # noqa: F401  (LR / ElasticNet / OnlineLR over NumPy or CUDA tensors)
 from .lstsq import (  # noqa: F401
     Context,
+    DeviceBlock,
     GroupedFit,
     allreduce_sum,
     default_context,

@@ -409,6 +409,44 @@ int pds_device_count(int* n) {
     PDS_HIP_CHECK(hipGetDeviceCount(n));
     return PDS_OK;
 }
+// result storage a peer PROCESS's kernels write into (the direct gather of the group-sharded step: include/pds_lstsq.h)
+static_assert(sizeof(hipIpcMemHandle_t) == PDS_IPC_HANDLE_BYTES, "the handle travels as 64 opaque bytes");
+int pds_device_alloc(int device, size_t bytes, void** out) {
+    if (!out) return pds::fail(PDS_ERR_INVALID, "null argument");
+    *out = nullptr;
+    PDS_HIP_CHECK(hipSetDevice(device));
+    PDS_HIP_CHECK(hipMalloc(out, bytes ? bytes : 1));
+    return PDS_OK;
+}
+int pds_device_free(int device, void* p) {
+    if (!p) return PDS_OK;
+    PDS_HIP_CHECK(hipSetDevice(device));
+    PDS_HIP_CHECK(hipFree(p));
+    return PDS_OK;
+}
+int pds_ipc_export(int device, void* p, unsigned char handle[PDS_IPC_HANDLE_BYTES]) {
+    if (!p || !handle) return pds::fail(PDS_ERR_INVALID, "null argument");
+    PDS_HIP_CHECK(hipSetDevice(device));
+    hipIpcMemHandle_t h;
+    PDS_HIP_CHECK(hipIpcGetMemHandle(&h, p));
+    std::memcpy(handle, &h, sizeof(h));
+    return PDS_OK;
+}
+int pds_ipc_open(int device, const unsigned char handle[PDS_IPC_HANDLE_BYTES], void** mapped) {
+    if (!handle || !mapped) return pds::fail(PDS_ERR_INVALID, "null argument");
+    *mapped = nullptr;
+    PDS_HIP_CHECK(hipSetDevice(device));
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handle, sizeof(h));
+    PDS_HIP_CHECK(hipIpcOpenMemHandle(mapped, h, hipIpcMemLazyEnablePeerAccess));
+    return PDS_OK;
+}
+int pds_ipc_close(int device, void* mapped) {
+    if (!mapped) return PDS_OK;
+    PDS_HIP_CHECK(hipSetDevice(device));
+    PDS_HIP_CHECK(hipIpcCloseMemHandle(mapped));
+    return PDS_OK;
+}
 
 int pds_lr_grouped_pred_f64(pds_ctx* ctx, const double* const* cols, const double* weights, int n_feat, int64_t n_rows,
                             const int64_t* group_offsets, int64_t n_groups, pds_space space, const pds_lr_params* prm, double* coeffs,

@@ -468,7 +468,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     g = uni64(g);
     int64_t gs = off[g], ge = off[g + 1];
     int64_t ge_next = off[g + 2 <= n_groups ? g + 2 : n_groups];
-    int64_t rows_in_acc = 0;
+    int rows_in_acc = 0;  // (rows of the open group in THIS wave's accumulators: a wave's range is far below 2^31 rows)
     // accumulate rows [lo, hi) (relative to the half-tile in `buf`) into acc: a masked step at either end where the segment does not
     // start / end on a 4-row step, the steps in between unmasked with the next step's operands fetched from LDS before this step
     // multiplies (fetch -> wait -> multiply per step ran at half the stream rate: one wave per SIMD, nobody else hides the round trip)
@@ -744,6 +744,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
             PDS_MT(tw);
             while (!slot_free()) __builtin_amdgcn_s_sleep(1);
             PDS_MADD(4, tw);
+            PDS_MT(tpb);
             if constexpr (NQ != 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -786,6 +787,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
             PDS_WAVE_LDS_SYNC();
             ++pseq;
             FL[0] = pseq;
+            PDS_MADD(5, tpb);
         }
     };
     auto flush_stash = [&]() __attribute__((always_inline)) {
@@ -866,8 +868,11 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
             }
         }
     };
-    auto flush = [&]() __attribute__((always_inline)) {
-        const bool whole = gs >= W0 && ge <= W1;
+    // `whole`: the group's rows all lie in this wave's range.  The walk knows without comparing 64-bit offsets (vector compares: the
+    // scalar unit has none): a group that ENDS inside the range (the in-loop call) is whole iff it also started here -- every group but
+    // the wave's first does --, the group left open behind the loop is not.
+    bool started_here = gs >= W0;
+    auto flush = [&](bool whole) __attribute__((always_inline)) {
         if (debug & 2) {  // (timing experiment: no record stores)
             zero_acc();
             rows_in_acc = 0;
@@ -880,7 +885,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
             } else {
                 // the wave the group starts in owns the side-table slot (largest w whose first row is <= gs)
                 int64_t slot = wave;
-                if (gs < W0) {
+                if (!started_here) {
                     int64_t lo = 0, hi = wave;
                     while (hi - lo > 1) {
                         const int64_t mid = lo + ((hi - lo) >> 1);
@@ -912,40 +917,57 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
         PDS_MADD(0, p0);
         // (a waiting group goes out as soon as the solving wave has emptied the slot, not only when the next group ends: without this look
         // per half-tile the 17-feature kernel is 6 % slower)
+        PDS_MT(p11);
         if constexpr (STASH2) {
             if (nst > 0) drain_free();
         } else if constexpr (PAIRED) {
             if (stashed && slot_free()) flush_stash();
         }
+        PDS_MADD(11, p11);
         PDS_MT(p1);
         if (h + 1 < h1) fetch_tile(buf ^ 1, h + 1);  // (the other image was consumed one iteration ago)
         PDS_MADD(1, p1);
         const int64_t R0 = h * HR;
         const int64_t tile_end = R0 + HR < W1 ? R0 + HR : W1;
-        while (pos < tile_end) {
-            const int64_t seg_end = ge < tile_end ? ge : tile_end;
+        // the walk inside a half-tile runs on 32-bit offsets relative to its first row (scalar compares; as int64 every `pos < tile_end`,
+        // `ge < tile_end`, `pos == ge` was a vector compare + a branch on its result): the open group's end is clamped to HR + 1
+        auto rel_end = [&](int64_t e) __attribute__((always_inline)) {  // e > R0
+            const uint64_t d = (uint64_t)(e - R0);
+            const uint32_t dh = (uint32_t)(d >> 32), dl = (uint32_t)d;
+            return (dh != 0u || dl > (uint32_t)HR) ? HR + 1 : (int)dl;
+        };
+        const int tile_n = (int)(tile_end - R0);
+        int posr = (int)(pos - R0);
+        int ger = rel_end(ge);
+        while (posr < tile_n) {
+            const int seg = ger < tile_n ? ger : tile_n;
             PDS_MT(p2);
-            if (seg_end > pos && !(debug & 1)) consume(buf, (int)(pos - R0), (int)(seg_end - R0));
+            if (seg > posr && !(debug & 1)) consume(buf, posr, seg);
             PDS_MADD(2, p2);
-            if (debug & 1) rows_in_acc += seg_end - pos;
-            pos = seg_end;
-            if (pos == ge) {  // group complete (as far as this wave's rows go: `whole` decides how it is written)
+            if (debug & 1) rows_in_acc += seg - posr;
+            posr = seg;
+            if (posr == ger) {  // group complete (as far as this wave's rows go: `started_here` decides how it is written)
                 PDS_MT(p3);
-                if (rows_in_acc > 0) flush();
+                if (rows_in_acc != 0) flush(started_here);
                 PDS_MADD(3, p3);
+                PDS_MT(p6);
                 do {  // (empty groups: their records stay zero)
                     ++g;
                     gs = ge;
                     ge = ge_next;
                     ge_next = off[g + 2 <= n_groups ? g + 2 : n_groups];
-                } while (g < n_groups && ge == pos);
+                } while (g < n_groups && ge == gs);
+                started_here = true;
+                PDS_MADD(6, p6);
                 if (g >= n_groups) break;
+                ger = rel_end(ge);
             }
         }
+        pos = R0 + posr;
         if (g >= n_groups) break;
         PDS_WAVE_LDS_SYNC();
     }
-    if (rows_in_acc > 0 && g < n_groups) flush();  // the group that continues in the next wave's rows
+    if (rows_in_acc != 0 && g < n_groups) flush(false);  // the group that continues in the next wave's rows
     if constexpr (PAIRED) {
         flush_stash();
         if constexpr (STASH2)

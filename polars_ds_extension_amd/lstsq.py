@@ -630,6 +630,65 @@ def lin_reg_by(*x, target, group_offsets, add_bias: bool = False, l1_reg: float 
     return coeffs, nulls
 
 
+class DeviceBlock:
+    """
+    `bytes` of device memory that kernels of ANOTHER process can write (include/pds_lstsq.h: pds_device_alloc / pds_ipc_export /
+    pds_ipc_open): the owner allocates and exports 64 opaque handle bytes; a peer maps them with `DeviceBlock.open(handle, device)`
+    and uses `.addr` (+ byte offsets) as a raw output address.  `tensor(dtype, shape, byte_offset)` views the OWNER's block as a torch
+    tensor (`__cuda_array_interface__`).  Freed / unmapped by `close()` (or at garbage collection).
+    """
+
+    def __init__(self, nbytes: int, device: int):
+        self._lib = _lib.load()
+        self.device, self.nbytes, self.owner = int(device), int(nbytes), True
+        p = C.c_void_p()
+        _lib.check(self._lib.pds_device_alloc(self.device, C.c_size_t(self.nbytes), C.byref(p)))
+        self.addr = int(p.value)
+
+    @classmethod
+    def open(cls, handle: bytes, device: int, nbytes: int = 0):
+        self = cls.__new__(cls)
+        self._lib = _lib.load()
+        self.device, self.nbytes, self.owner = int(device), int(nbytes), False
+        p = C.c_void_p()
+        hb = (C.c_ubyte * 64).from_buffer_copy(bytes(handle))
+        _lib.check(self._lib.pds_ipc_open(self.device, hb, C.byref(p)))
+        self.addr = int(p.value)
+        return self
+
+    def handle(self) -> bytes:
+        hb = (C.c_ubyte * 64)()
+        _lib.check(self._lib.pds_ipc_export(self.device, C.c_void_p(self.addr), hb))
+        return bytes(hb)
+
+    def tensor(self, dtype, shape, byte_offset: int = 0):
+        import torch
+
+        class _View:  # (torch keeps the object alive as the tensor's base)
+            pass
+
+        v = _View()
+        v.block = self
+        typestr = {torch.float64: "<f8", torch.float32: "<f4", torch.uint8: "|u1", torch.int64: "<i8"}[dtype]
+        v.__cuda_array_interface__ = {"shape": tuple(int(d) for d in shape), "typestr": typestr, "data": (self.addr + int(byte_offset), False),
+                                      "version": 2, "strides": None}
+        return torch.as_tensor(v, device=torch.device("cuda", self.device))
+
+    def close(self) -> None:
+        if getattr(self, "addr", 0):
+            if self.owner:
+                self._lib.pds_device_free(self.device, C.c_void_p(self.addr))
+            else:
+                self._lib.pds_ipc_close(self.device, C.c_void_p(self.addr))
+            self.addr = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class GroupedFit:
     """
     A prepared `lin_reg_by` over DEVICE-resident columns with contiguous groups: the column pointer table, the parameter block, the
@@ -640,11 +699,14 @@ class GroupedFit:
     `out` / `out_null`: where the coefficients ([n_groups, p'] of the config dtype, contiguous) and the null flags ([n_groups] uint8)
     go -- e.g. rows of a larger gathered result, so that the fit writes them in place.  By default they are allocated here, once.
     Every `run()` recomputes and overwrites them; it returns the same two tensors.
+    `out_addr` / `out_null_addr` (both or neither; instead of `out` / `out_null`): raw device addresses of such rows in memory that
+    is not a torch tensor of this process -- the assembled result of ANOTHER rank, mapped with `DeviceBlock.open` (the direct gather of
+    parallel.GroupedShardPlan): the kernel's stores cross the link.  `run()` then returns (None, None).
     """
 
     def __init__(self, *x, target, group_offsets, add_bias: bool = False, l1_reg: float = 0.0, l2_reg: float = 0.0, tol: float = 1e-5,
                  solver: str = "qr", max_iter: int = 200, positive: bool = False, singular_x_tol: float | None = None, out=None,
-                 out_null=None, ctx: Context | None = None):
+                 out_null=None, out_addr: int | None = None, out_null_addr: int | None = None, ctx: Context | None = None):
         if max_iter <= 0:
             raise ValueError("Input `max_iter` must be a positive.")  # expr_linear.py:231-232
         import torch
@@ -660,6 +722,16 @@ class GroupedFit:
         pp = cols.n_feat + int(bool(add_bias))
         tdt = torch.float64 if config.LIN_REG_EXPR_F64 else torch.float32
         dev = cols.keep[0].device
+        if (out_addr is None) != (out_null_addr is None) or (out_addr is not None and (out is not None or out_null is not None)):
+            raise ValueError("`out_addr` and `out_null_addr` come together, instead of `out` / `out_null`")
+        if out_addr is not None:
+            self.coeffs = self.is_null = None
+            self.n_groups = ng
+            self._fn = self.ctx.fn("pds_lr_grouped")
+            self._args = (self.ctx._h, cols.cols, cols.n_feat, C.c_int64(cols.n_rows), off_p, C.c_int64(ng), cols.space, C.byref(self._prm),
+                          C.c_void_p(int(out_addr)), C.c_void_p(int(out_null_addr)))
+            self._dev = cols.torch_device
+            return
         if out is None:
             out = torch.empty((ng, pp), dtype=tdt, device=dev)
         if out_null is None:
@@ -682,7 +754,7 @@ class GroupedFit:
         rc = self._fn(*self._args)
         if rc:
             _lib.check(rc)
-        return self.coeffs, self.is_null
+        return self.coeffs, self.is_null  # ((None, None) with raw output addresses)
 
 
 def lin_reg_by_key(*x, target, key, add_bias: bool = False, l1_reg: float = 0.0, l2_reg: float = 0.0, tol: float = 1e-5,

@@ -16,7 +16,7 @@ off = np.arange(0, N + 1, R, dtype=np.int64)
 so = _lib.load()
 buf = (C.c_ulonglong * 16)()
 names = {0: "stream: waiting for the half-tile", 1: "stream: next half-tile's loads issued", 2: "stream: matrix steps (consume)", 3: "stream: finished group (hand-over, side records)",
-         4: "   of it: waiting for the slot", 7: "stream wave total", 8: "solver: waiting for a group", 9: "solver: slot -> pending registers", 10: "solver: solve of four", 15: "solver wave total"}
+         4: "   of it: waiting for the slot", 5: "   publish body (all call sites)", 6: "stream: group advance (offsets)", 11: "stream: per-half-tile look at the stash", 7: "stream wave total", 8: "solver: waiting for a group", 9: "solver: slot -> pending registers", 10: "solver: solve of four", 15: "solver wave total"}
 for P in (17, 24, 32):
     f = lambda: pds.lin_reg_by(*xs[:P], target=y, group_offsets=off, ctx=ctx)
     for _ in range(2): f()
