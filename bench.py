@@ -67,6 +67,9 @@ def main() -> int:
     ap.add_argument("--feats", type=int, default=16)
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--gather-chunks", type=int, default=0, help="pieces per rank: results of a piece travel while the next is computed (0: parallel.auto_chunks)")
+    ap.add_argument("--gather", choices=["p2p", "direct"], default="p2p",
+                    help="N > 1, strong scaling: how the coefficients reach rank 0 -- RCCL point-to-point per piece (default), or the peers' kernels "
+                         "storing straight into rank 0's IPC-mapped result block (opt-in until it has run across two devices)")
     ap.add_argument("--cpu-sample-groups", type=int, default=400_000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip end_to_end / grouped_c3spec / scatter (A/B runs)")
@@ -80,8 +83,14 @@ def main() -> int:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # PDS_BENCH_DRYRUN=1: a REHEARSAL of the N > 1 control flow on a box without GPUs (tests/test_bench_dryrun.py) -- gloo instead of
+    # RCCL, CPU tensors, the per-group compute injected (numpy normal equations: test infrastructure, never a measurement; the line it
+    # prints says so in `data`).  Every branch the driver's `--gpus N` run takes -- plan construction, the piece-count agreement, the
+    # peer sends, the MAX all-reduce of the elapsed time, the scatter leg -- runs as written; only the kernels are absent.
+    dry = os.environ.get("PDS_BENCH_DRYRUN") == "1"
+    if not dry:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cpu") if dry else torch.device("cuda", local_rank)
     # PDS_BENCH_FORCE_DIST=1 runs the RCCL init / barrier / gather code path at world_size 1 (single-GPU smoke of the N > 1 path)
     use_dist = world > 1 or os.environ.get("PDS_BENCH_FORCE_DIST") == "1"
     if use_dist:
@@ -89,7 +98,10 @@ def main() -> int:
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     import polars_ds_extension_amd as pds
     from polars_ds_extension_amd import parallel as par
@@ -102,14 +114,27 @@ def main() -> int:
     g_lo, g_hi = parts[rank]
     G = g_hi - g_lo
     N = G * R
-    ctx = pds.Context(local_rank)
-    ctx.set_stream(torch.cuda.current_stream(dev))
+    ctx = None
+    if not dry:
+        ctx = pds.Context(local_rank)
+        ctx.set_stream(torch.cuda.current_stream(dev))
+
+    def _dry_grouped(xs_, y_, off_, add_bias=False, **kw):  # (rehearsal only: per-group normal equations in numpy)
+        o = np.asarray(off_.cpu() if hasattr(off_, "cpu") else off_, dtype=np.int64)
+        X = np.stack([np.asarray(x) for x in xs_], axis=1)
+        yy = np.asarray(y_)
+        co = np.empty((len(o) - 1, X.shape[1]))
+        for k in range(len(o) - 1):
+            Xg = X[o[k]:o[k + 1]]
+            co[k] = np.linalg.solve(Xg.T @ Xg, Xg.T @ yy[o[k]:o[k + 1]])
+        return torch.from_numpy(co), torch.zeros(len(o) - 1, dtype=torch.uint8)
 
     # ---- this rank's shard of the synthetic frame, generated in HBM (seeded per rank)
     xs, y = _gen_frame(torch, dev, 1234 + rank, G, R, P)
     offsets = torch.arange(0, N + 1, R, dtype=torch.int64, device=dev)
     off_host = np.arange(0, N + 1, R, dtype=np.int64)
-    torch.cuda.synchronize(dev)
+    if not dry:
+        torch.cuda.synchronize(dev)
     gather = use_dist and strong
 
     class _Off:  # device offsets for the kernels, host offsets for the piece bounds (no device read-back when the plan is built)
@@ -124,7 +149,9 @@ def main() -> int:
 
     off_pair = _Off(offsets, torch.from_numpy(off_host))
     # N-rank step: the prepared plan (persistent result buffers, the root's shard fitted in place, one grouped send per piece)
+    # --gather direct (opt-in): the peers' kernels store straight into rank 0's result block; default: RCCL point-to-point
     plan = par.GroupedShardPlan(xs, y, off_pair, parts, rank=rank, gather_to=0, chunks=args.gather_chunks or None, ctx=ctx,
+                                grouped_fn=_dry_grouped if dry else None, direct=(args.gather == "direct" and not dry),
                                 add_bias=False) if gather else None
     chunks = plan.chunks if plan else 1
 
@@ -132,27 +159,35 @@ def main() -> int:
         if gather:
             res = plan.step()
             return (res[2], res[3]) if rank == 0 else (res[0], res[1])
+        if dry:
+            return _dry_grouped(xs, y, off_host)
         return pds.lin_reg_by(*xs, target=y, group_offsets=offsets, add_bias=False, ctx=ctx)
 
     def barrier():
-        torch.cuda.synchronize(dev)
+        if not dry:
+            torch.cuda.synchronize(dev)
         if use_dist:
             dist.barrier()
 
     for _ in range(args.warmup):
         step()
-    ctx.get_timing(reset=True)
-    ctx.get_timing_samples("grouped_moments", reset=True)
-    ctx.set_timing(True)
+    if not dry:
+        ctx.get_timing(reset=True)
+        ctx.get_timing_samples("grouped_moments", reset=True)
+        ctx.set_timing(True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         coeffs, nulls = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    ctx.set_timing(False)
-    timing = ctx.get_timing(reset=True)
-    launch_ms = sorted(ctx.get_timing_samples("grouped_moments", reset=True))
+    if dry:
+        timing = {"grouped_moments": (0.0, 0), "solve": (0.0, 0)}
+        launch_ms = []
+    else:
+        ctx.set_timing(False)
+        timing = ctx.get_timing(reset=True)
+        launch_ms = sorted(ctx.get_timing_samples("grouped_moments", reset=True))
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -197,7 +232,7 @@ def main() -> int:
     }
 
     # ---- what this box's HBM delivers to a plain streaming copy (quote the spec peak AND a measured figure)
-    if rank == 0:
+    if rank == 0 and not dry:
         a = torch.empty(1 << 27, dtype=torch.float64, device=dev)  # 1 GiB
         b = torch.empty_like(a)
         b.copy_(a)
@@ -224,7 +259,7 @@ def main() -> int:
 
     # ---- config 2 on the same frame: single OLS Gram build (pds_moments), HBM GB/s
     gram = None
-    if rank == 0:
+    if rank == 0 and not dry:
         for _ in range(2):
             pds.gram_moments(*xs, target=y, ctx=ctx)
         ctx.get_timing(reset=True)
@@ -245,7 +280,7 @@ def main() -> int:
     # ---- BASELINE.json configs[2] as written (8 features; the headline metric is quoted on 16 -- SURVEY.md 8d asks for
     # both): the same groups on the first 8 feature columns
     p8 = None
-    if rank == 0 and P >= 8:
+    if rank == 0 and P >= 8 and not dry:
         for _ in range(2):
             pds.lin_reg_by(*xs[:8], target=y, group_offsets=offsets, add_bias=False, ctx=ctx)
         torch.cuda.synchronize(dev)
@@ -268,7 +303,7 @@ def main() -> int:
     # ---- the same step from the KEY COLUMN (sorted int64 keys, what group_by(key) starts from) instead of precomputed offsets: one pass
     # over the keys (order check + run marks), a scan and a pass over the marks in front of the same fused kernel
     by_key = None
-    if rank == 0:
+    if rank == 0 and not dry:
         try:
             by_key = _by_key(torch, pds, ctx, dev, xs, y, offsets, G, R, P)
         except Exception as e:
@@ -278,12 +313,12 @@ def main() -> int:
     cpu = None
     parity = None
     host_cols = None
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu and not dry:
         cpu, parity = _cpu_baseline(np, args, xs, y, coeffs, nulls, G, R, P)
 
     # ---- the same workload from HOST Arrow buffers through the plugin boundary (rank 0, N = 1): the rate a Polars user sees
     end_to_end = None
-    if rank == 0 and world == 1 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras and not dry:
         try:
             end_to_end = _end_to_end(torch, np, pds, dev, xs, y, G, R, P, cpu)
         except Exception as e:  # pyarrow / harness trouble must not cost the headline line
@@ -291,7 +326,7 @@ def main() -> int:
 
     # ---- the other BASELINE configs, on the headline frame where they share it (C2) and on a C4 frame
     other = None
-    if rank == 0 and world == 1 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras and not dry:
         try:
             other = _other_configs(torch, pds, ctx, dev, xs, y, N, P, with_cpu=not args.no_cpu)
         except Exception as e:
@@ -299,7 +334,7 @@ def main() -> int:
 
     # ---- SURVEY.md 8(d) C3 data: Poisson sizes, collinear groups (the gate fires inside the timed run), sorted and shuffled keys
     c3 = None
-    if rank == 0 and world == 1 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras and not dry:
         try:
             del xs, y
             torch.cuda.empty_cache()
@@ -321,14 +356,15 @@ def main() -> int:
             "metric": "grouped lstsq regressions/sec (1e8 rows x 16 f64 feats; Gram-build GB/s under gram_build)",
             "value": round(value, 1), "unit": "regressions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic" if not dry else "synthetic -- DRY RUN on CPU (gloo, injected numpy compute): control-flow rehearsal, not a measurement",
             "config": {"workload": f"group_by(key).agg(lin_reg): {args.groups} groups x {R} rows x {P} f64 feats {per} "
                                    f"({args.groups * R:.0e} rows), OLS with rank gate (pl_lr default path), inputs resident in HBM; `value`: the groups "
                                    f"given as row offsets (pre-segmented, as Polars hands groups to pl_lr -- the cpu_baseline gets the same); "
                                    f"the same step starting from a sorted int64 key column: grouped_by_key"
                                    + (", coefficients + null flags gathered to rank 0 inside the timed region" if gather else ""),
                        "groups_total": G_total, "groups_per_gpu": G, "rows_per_group": R, "features": P,
-                       "parallelism": f"group-sharded x{world}", "gather_chunks": chunks if gather else None},
+                       "parallelism": f"group-sharded x{world}", "gather_chunks": chunks if gather else None,
+                       "gather": (args.gather if gather else None)},
             "roofline": roofline, "gram_build": gram, "grouped_p8": p8, "grouped_by_key": by_key, "cpu_baseline": cpu, "parity_spot_check": parity,
             "dist_step": dist_overhead, "end_to_end": end_to_end, "other_configs": other, "grouped_c3spec": c3, "scatter": scatter,
         }
@@ -948,12 +984,13 @@ def _scatter_leg(torch, dist, par, dev, rank, world, G_total, R, P):
     else:
         args = (None, None, None)
     ts = []
+    sync = (lambda: torch.cuda.synchronize(dev)) if dev.type == "cuda" else (lambda: None)
     for _ in range(2):
-        torch.cuda.synchronize(dev)
+        sync()
         dist.barrier()
         t0 = time.perf_counter()
         got = par.scatter_frame_by_groups(*args, root=0, device=dev)
-        torch.cuda.synchronize(dev)
+        sync()
         dist.barrier()
         ts.append(time.perf_counter() - t0)
         del got

@@ -436,15 +436,28 @@ int pds_device_count(int* n);
  * launcher's store, a broadcast), every peer maps it with pds_ipc_open on ITS device (peer access over xGMI is enabled by the
  * mapping) and passes `mapped + its groups' offset` as the `coeffs` / `is_null` arguments of pds_lr_grouped_*: the fit's stores
  * cross the link while the kernel runs -- no staging buffer, no send / receive launches, no separate gather step.  The gathering rank
- * may read the rows once the peer's stream has passed the call (the host's completion signal: a barrier, an all-reduce of a flag).
+ * may read the rows once the peer's stream has passed the call (completion: below).
  * pds_ipc_close unmaps (the allocation stays the exporter's, freed with pds_device_free after every peer has closed).
  * python: polars_ds_extension_amd/parallel.py, GroupedShardPlan(direct=True).
+ *
+ * Completion without a collective: a SIGNAL block (pds_device_alloc with fine_grained = 1: device memory that is coherent across
+ * devices, as RCCL's own flag words are) shared the same way holds one 32-bit word per rank.  A peer calls
+ * pds_signal_post(ctx, mapped_word, seq) behind its fit -- a one-lane kernel on the context's stream: the fit's stores are complete and
+ * visible at the kernel boundary before it, the word is stored with system scope --; the gathering rank calls
+ * pds_signal_wait(ctx, words, n, seq) on ITS stream: a one-wave kernel that polls the n words (system-scope loads) until each is
+ * >= seq.  Both are stream ordered: no host synchronisation, no collective launch; a step is the fit + one tiny kernel on every rank.
+ * The wait gives up after `timeout_ms` (a peer that died must not hang the device): the call then fails at the next synchronisation
+ * point through pds_signal_wait_status (0 = every wait so far was satisfied).  fine_grained = 1 also for the RESULT block of a direct
+ * gather: the gathering device's L2 must not keep lines of rows another device writes.
  */
 #define PDS_IPC_HANDLE_BYTES 64
-int pds_device_alloc(int device, size_t bytes, void** out);
+int pds_device_alloc(int device, size_t bytes, int fine_grained, void** out);
+int pds_signal_post(pds_ctx* ctx, unsigned* word, unsigned value);
+int pds_signal_wait(pds_ctx* ctx, const unsigned* words, int n_words, unsigned value, int timeout_ms);
+int pds_signal_wait_status(pds_ctx* ctx, int* timed_out);
 int pds_device_free(int device, void* p);
-int pds_ipc_export(int device, void* p, unsigned char handle[PDS_IPC_HANDLE_BYTES]);
-int pds_ipc_open(int device, const unsigned char handle[PDS_IPC_HANDLE_BYTES], void** mapped);
+int pds_ipc_export(int device, void* p, unsigned char* handle);             /* handle: PDS_IPC_HANDLE_BYTES bytes, written */
+int pds_ipc_open(int device, const unsigned char* handle, void** mapped);  /* handle: PDS_IPC_HANDLE_BYTES bytes */
 int pds_ipc_close(int device, void* mapped);
 
 /*

@@ -30,7 +30,7 @@ EXPORTS = [
     "pds_recursive_lr_seeded_f64", "pds_recursive_lr_seeded_f32",
     "pds_lin_reg_report_nullable_f64", "pds_lin_reg_report_nullable_f32",
     "pds_lr_grouped_nullable_f64", "pds_lr_grouped_nullable_f32",
-    "pds_lr_by_key_f64", "pds_lr_by_key_f32", "pds_lr_by_key_multi_f64", "pds_lr_by_key_multi_f32", "pds_lr_by_key_pred_multi_f64", "pds_lr_by_key_pred_multi_f32", "pds_host_alloc", "pds_host_free", "pds_device_count", "pds_device_alloc", "pds_device_free", "pds_ipc_export", "pds_ipc_open", "pds_ipc_close", "pds_lr_grouped_pred_f64", "pds_lr_grouped_pred_f32", "pds_lr_by_key_pred_f64", "pds_lr_by_key_pred_f32", "pds_lr_grouped_weighted_f64", "pds_lr_grouped_weighted_f32",
+    "pds_lr_by_key_f64", "pds_lr_by_key_f32", "pds_lr_by_key_multi_f64", "pds_lr_by_key_multi_f32", "pds_lr_by_key_pred_multi_f64", "pds_lr_by_key_pred_multi_f32", "pds_host_alloc", "pds_host_free", "pds_device_count", "pds_device_alloc", "pds_device_free", "pds_ipc_export", "pds_ipc_open", "pds_ipc_close", "pds_signal_post", "pds_signal_wait", "pds_signal_wait_status", "pds_lr_grouped_pred_f64", "pds_lr_grouped_pred_f32", "pds_lr_by_key_pred_f64", "pds_lr_by_key_pred_f32", "pds_lr_grouped_weighted_f64", "pds_lr_grouped_weighted_f32",
     "pds_lr_with_inv_f64", "pds_lr_with_inv_f32",
     "pds_moments_f64", "pds_moments_f32", "pds_lr_from_moments_f64", "pds_lr_from_moments_f32",
     "pds_student_t_sf", "pds_student_t_ppf",

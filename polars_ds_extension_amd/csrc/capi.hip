@@ -83,6 +83,7 @@ void pds_ctx_destroy(pds_ctx* ctx) {
     if (ctx->keyed.ptr) (void)hipFree(ctx->keyed.ptr);
     if (ctx->wkeyed.ptr) (void)hipFree(ctx->wkeyed.ptr);
     if (ctx->mark_count) (void)hipFree(ctx->mark_count);
+    if (ctx->wait_timeouts) (void)hipFree(ctx->wait_timeouts);
     if (ctx->mark_host) (void)hipHostFree(ctx->mark_host);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pinned_in) (void)hipHostFree(ctx->pinned_in);
@@ -411,11 +412,63 @@ int pds_device_count(int* n) {
 }
 // result storage a peer PROCESS's kernels write into (the direct gather of the group-sharded step: include/pds_lstsq.h)
 static_assert(sizeof(hipIpcMemHandle_t) == PDS_IPC_HANDLE_BYTES, "the handle travels as 64 opaque bytes");
-int pds_device_alloc(int device, size_t bytes, void** out) {
+int pds_device_alloc(int device, size_t bytes, int fine_grained, void** out) {
     if (!out) return pds::fail(PDS_ERR_INVALID, "null argument");
     *out = nullptr;
     PDS_HIP_CHECK(hipSetDevice(device));
-    PDS_HIP_CHECK(hipMalloc(out, bytes ? bytes : 1));
+    if (fine_grained) PDS_HIP_CHECK(hipExtMallocWithFlags(out, bytes ? bytes : 1, hipDeviceMallocFinegrained));
+    else PDS_HIP_CHECK(hipMalloc(out, bytes ? bytes : 1));
+    return PDS_OK;
+}
+// stream-ordered completion words of the direct gather (include/pds_lstsq.h)
+namespace pds {
+__global__ void signal_post_kernel(unsigned* word, unsigned value) {
+    __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ __launch_bounds__(64) void signal_wait_kernel(const unsigned* words, int n, unsigned value, long long budget_ticks, int* timed_out) {
+    const int lane = threadIdx.x;
+    const long long t0 = wall_clock64();
+    bool ok = lane >= n;
+    while (!__all(ok)) {
+        if (!ok) ok = (int)(__hip_atomic_load(words + lane, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - value) >= 0;  // (wrap-safe >=)
+        if (wall_clock64() - t0 > budget_ticks) {
+            if (lane == 0) atomicAdd(timed_out, 1);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+}  // namespace pds
+int pds_signal_post(pds_ctx* ctx, unsigned* word, unsigned value) {
+    if (!ctx || !word) return pds::fail(PDS_ERR_INVALID, "null argument");
+    PDS_HIP_CHECK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(pds::signal_post_kernel, dim3(1), dim3(1), 0, ctx->stream, word, value);
+    PDS_HIP_CHECK(hipGetLastError());
+    return PDS_OK;
+}
+int pds_signal_wait(pds_ctx* ctx, const unsigned* words, int n_words, unsigned value, int timeout_ms) {
+    if (!ctx || !words || n_words < 0 || n_words > 64) return pds::fail(PDS_ERR_INVALID, "pds_signal_wait: up to 64 words");
+    if (n_words == 0) return PDS_OK;
+    PDS_HIP_CHECK(hipSetDevice(ctx->device));
+    if (!ctx->wait_timeouts) {
+        PDS_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ctx->wait_timeouts), 64));
+        PDS_HIP_CHECK(hipMemsetAsync(ctx->wait_timeouts, 0, 64, ctx->stream));
+    }
+    int rate_khz = 100000;  // wall_clock64 ticks per ms
+    (void)hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, ctx->device);
+    const long long budget = (long long)(timeout_ms > 0 ? timeout_ms : 2000) * (long long)rate_khz;
+    hipLaunchKernelGGL(pds::signal_wait_kernel, dim3(1), dim3(64), 0, ctx->stream, words, n_words, value, budget,
+                       ctx->wait_timeouts);
+    PDS_HIP_CHECK(hipGetLastError());
+    return PDS_OK;
+}
+int pds_signal_wait_status(pds_ctx* ctx, int* timed_out) {
+    if (!ctx || !timed_out) return pds::fail(PDS_ERR_INVALID, "null argument");
+    *timed_out = 0;
+    if (!ctx->wait_timeouts) return PDS_OK;
+    PDS_HIP_CHECK(hipSetDevice(ctx->device));
+    PDS_HIP_CHECK(hipMemcpyAsync(timed_out, ctx->wait_timeouts, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return PDS_OK;
 }
 int pds_device_free(int device, void* p) {
@@ -424,7 +477,7 @@ int pds_device_free(int device, void* p) {
     PDS_HIP_CHECK(hipFree(p));
     return PDS_OK;
 }
-int pds_ipc_export(int device, void* p, unsigned char handle[PDS_IPC_HANDLE_BYTES]) {
+int pds_ipc_export(int device, void* p, unsigned char* handle) {
     if (!p || !handle) return pds::fail(PDS_ERR_INVALID, "null argument");
     PDS_HIP_CHECK(hipSetDevice(device));
     hipIpcMemHandle_t h;
@@ -432,7 +485,7 @@ int pds_ipc_export(int device, void* p, unsigned char handle[PDS_IPC_HANDLE_BYTE
     std::memcpy(handle, &h, sizeof(h));
     return PDS_OK;
 }
-int pds_ipc_open(int device, const unsigned char handle[PDS_IPC_HANDLE_BYTES], void** mapped) {
+int pds_ipc_open(int device, const unsigned char* handle, void** mapped) {
     if (!handle || !mapped) return pds::fail(PDS_ERR_INVALID, "null argument");
     *mapped = nullptr;
     PDS_HIP_CHECK(hipSetDevice(device));

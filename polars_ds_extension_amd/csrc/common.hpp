@@ -99,6 +99,7 @@ struct pds_ctx {
     unsigned* mark_count = nullptr;
     unsigned* mark_host = nullptr;      // host address
     unsigned* mark_host_dev = nullptr;  // the same word as the device sees it
+    int* wait_timeouts = nullptr;       // device counter of pds_signal_wait kernels that gave up (pds_signal_wait_status)
     bool mark_dirty = false;            // a launch went out and mark_count has not been seen back at zero since (an error path)
     void* pinned = nullptr;  // pinned host scratch (small results, pointer arrays)
     size_t pinned_bytes = 0;

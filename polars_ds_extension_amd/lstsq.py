@@ -116,6 +116,19 @@ class Context:
     def num_cus(self) -> int:
         return int(self._lib.pds_ctx_num_cus(self._h))
 
+    def signal_post(self, word_addr: int, value: int) -> None:
+        """Stream ordered: store `value` (system scope) into the 32-bit word at `word_addr` behind everything queued so far."""
+        _lib.check(self._lib.pds_signal_post(self._h, C.c_void_p(int(word_addr)), C.c_uint(int(value) & 0xFFFFFFFF)))
+
+    def signal_wait(self, words_addr: int, n_words: int, value: int, timeout_ms: int = 2000) -> None:
+        """Stream ordered: what follows on the stream runs once the `n_words` words at `words_addr` are all >= `value`."""
+        _lib.check(self._lib.pds_signal_wait(self._h, C.c_void_p(int(words_addr)), int(n_words), C.c_uint(int(value) & 0xFFFFFFFF), int(timeout_ms)))
+
+    def signal_wait_timeouts(self) -> int:
+        n = C.c_int(0)
+        _lib.check(self._lib.pds_signal_wait_status(self._h, C.byref(n)))
+        return int(n.value)
+
     WORKSPACES = ("scratch", "stage", "solve", "keyed", "wkeyed")
 
     def workspace_bytes(self, which: str = "keyed") -> int:
@@ -638,11 +651,12 @@ class DeviceBlock:
     tensor (`__cuda_array_interface__`).  Freed / unmapped by `close()` (or at garbage collection).
     """
 
-    def __init__(self, nbytes: int, device: int):
+    def __init__(self, nbytes: int, device: int, fine_grained: bool = True):
         self._lib = _lib.load()
         self.device, self.nbytes, self.owner = int(device), int(nbytes), True
         p = C.c_void_p()
-        _lib.check(self._lib.pds_device_alloc(self.device, C.c_size_t(self.nbytes), C.byref(p)))
+        # (fine grained: coherent across devices -- rows another device's kernel writes must not sit stale in this device's L2)
+        _lib.check(self._lib.pds_device_alloc(self.device, C.c_size_t(self.nbytes), int(bool(fine_grained)), C.byref(p)))
         self.addr = int(p.value)
 
     @classmethod

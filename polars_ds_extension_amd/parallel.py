@@ -159,10 +159,23 @@ class GroupedShardPlan:
     `step()` returns (coeffs_local, is_null_local) and, on the gathering rank, additionally (coeffs, is_null) of all groups: views of
     the persistent buffers, valid until the next step().  The dtype on the wire is `result_dtype`; by default what the library's
     grouped fit returns (the config dtype) or, with an injected `grouped_fn`, the targets' dtype.
+
+    `direct=True` (device-resident shards, the library's own fit; opt-in until it has run across two devices): NO gather step at all.
+    The gathering rank allocates the assembled result as an exportable block (lstsq.DeviceBlock), every peer maps it (IPC handle,
+    exchanged once when the plan is built) and its prepared fit gets `mapped + its rows' offset` as output address: the kernel's
+    coefficient / flag stores cross the peer's xGMI link while it runs (16 MB per peer inside a 0.31 ms kernel on the headline frame
+    over 8 ranks = 52 GB/s per link), one piece per rank, no send / receive launches.  Completion is a word per rank in a second
+    shared block: a peer posts the step number behind its fit (`Context.signal_post`: a one-lane kernel, stream ordered), the
+    gathering rank's stream waits for all of them (`Context.signal_wait`: a one-wave polling kernel) -- no collective, no host
+    synchronisation; consecutive steps queue back to back.  Peers return (None, None) from step() (their results live on the
+    gathering rank only); `chunks` / `chunk_model` do not apply.  `close()` (collective) unmaps the blocks before the owner frees them.
+
+    `chunk_model`: overrides of auto_chunks' rates ({"link_GBps", "stream_GBps", "launch_us"}) when `chunks` is left to the model.
     """
 
     def __init__(self, xs_loc, y_loc, loc_off, parts, *, rank: int, gather_to: int | None = 0, chunks: int | None = None,
-                 grouped_fn: Callable | None = None, group=None, result_dtype=None, ctx=None, **lin_reg_kwargs):
+                 grouped_fn: Callable | None = None, group=None, result_dtype=None, ctx=None, direct: bool = False,
+                 chunk_model: dict | None = None, **lin_reg_kwargs):
         import torch
 
         self._dist = dist = _dist()
@@ -185,12 +198,18 @@ class GroupedShardPlan:
         off_h = np.asarray(loc_off.cpu() if hasattr(loc_off, "cpu") else loc_off, dtype=np.int64)  # (row bounds of the pieces: host)
         is_root = gather_to is not None and rank == gather_to
         total = parts[-1][1]
+        self.direct = bool(direct) and gather_to is not None
+        if self.direct:
+            if not (default_fn and is_t and y_loc.is_cuda):
+                raise ValueError("direct=True: device-resident shards fitted by the library (no injected grouped_fn)")
+            self._init_direct(xs_loc, y_loc, loc_off, ng, pp, cdt, dev, is_root, g_lo, total, world, ctx, lin_reg_kwargs)
+            return
         if chunks is None:
             esz = torch.empty((), dtype=cdt).element_size()
             in_sz = y_loc.element_size() if is_t else np.asarray(y_loc).dtype.itemsize
             peers = [hi - lo for r, (lo, hi) in enumerate(parts) if r != gather_to]
             chunks = auto_chunks(world if gather_to is not None else 1, max(peers, default=0) * (pp * esz + 1),
-                                 int(off_h[-1] - off_h[0]) * (len(xs_loc) + 1) * in_sz)
+                                 int(off_h[-1] - off_h[0]) * (len(xs_loc) + 1) * in_sz, **(chunk_model or {}))
             if world > 1 and gather_to is not None:
                 # the piece count decides how the gathering rank cuts every peer's rows: ranks whose shards differ by a group must not
                 # round the model to different counts -- one tiny all-reduce(MAX) when the plan is built (building a plan is collective)
@@ -247,6 +266,67 @@ class GroupedShardPlan:
             if gather_to is not None and not is_root:
                 self._send_batches.append([dist.P2POp(dist.isend, co_v, gather_to, group), dist.P2POp(dist.isend, nu_v, gather_to, group)])
 
+    def _init_direct(self, xs_loc, y_loc, loc_off, ng, pp, cdt, dev, is_root, g_lo, total, world, ctx, lin_reg_kwargs):
+        """The direct gather: one exportable result block on the gathering rank, mapped by every peer; one prepared fit per rank."""
+        import torch
+
+        from . import lstsq
+
+        dist = self._dist
+        if cdt != (torch.float64 if lstsq._dtype() == np.float64 else torch.float32):
+            raise ValueError("direct=True writes the library's result dtype")
+        esz = torch.empty((), dtype=cdt).element_size()
+        co_bytes = (total * pp * esz + 255) & ~255  # [coefficients | flags] in ONE allocation: one handle
+        self.chunks = 1
+        dev_i = dev.index if dev.index is not None else torch.cuda.current_device()
+        self._ctx = ctx or lstsq.default_context()
+        meta = [None]
+        if is_root:
+            self._block = lstsq.DeviceBlock(co_bytes + total, dev_i)
+            self._sig = lstsq.DeviceBlock(4096, dev_i)
+            self._sig.tensor(torch.uint8, (4096,)).zero_()
+            torch.cuda.synchronize(dev)
+            self.co_all = self._block.tensor(cdt, (total, pp))
+            self.nu_all = self._block.tensor(torch.uint8, (total,), co_bytes)
+            meta = [(self._block.handle(), self._sig.handle())]
+        dist.broadcast_object_list(meta, src=self.root, group=self.group)  # (collective: every rank builds its plan at the same point)
+        if is_root:
+            self.co_loc, self.nu_loc = self.co_all[g_lo:g_lo + ng], self.nu_all[g_lo:g_lo + ng]
+        else:
+            self._block = lstsq.DeviceBlock.open(meta[0][0], dev_i, co_bytes + total)
+            self._sig = lstsq.DeviceBlock.open(meta[0][1], dev_i, 4096)
+            self.co_all = self.nu_all = self.co_loc = self.nu_loc = None
+        base = self._block.addr
+        self._runs, self._send_batches, self._recv_batches = [], [], []
+        if ng > 0:
+            fit = lstsq.GroupedFit(*xs_loc, target=y_loc, group_offsets=loc_off[0: ng + 1], out_addr=base + g_lo * pp * esz,
+                                   out_null_addr=base + co_bytes + g_lo, ctx=self._ctx, **lin_reg_kwargs)
+            self._runs.append(fit.run)
+        # completion words: slot k of the signal block belongs to the k-th peer (ranks other than the gathering one, in rank order)
+        peers = [r for r in range(world) if r != self.root]
+        self._n_peers = len(peers)
+        self._my_word = None if is_root else self._sig.addr + 4 * peers.index(self.rank)
+        self._seq = 0
+        self._torch_dev = dev
+
+    def close(self) -> None:
+        """Direct plans: peers unmap the shared blocks, then the owner frees them (collective).  Other plans: nothing to do."""
+        if not self.direct or getattr(self, "_block", None) is None:
+            return
+        import torch
+
+        torch.cuda.synchronize(self._torch_dev)
+        self._runs = []
+        if self.co_all is None:
+            self._block.close()
+            self._sig.close()
+        self._dist.barrier(group=self.group)
+        if self.co_all is not None:
+            self.co_all = self.nu_all = self.co_loc = self.nu_loc = None  # (views of the block)
+            self._block.close()
+            self._sig.close()
+        self._block = self._sig = None
+
     @staticmethod
     def _injected(fn, xs_p, y_p, sub_off, co_v, nu_v, kw):
         import torch
@@ -260,7 +340,22 @@ class GroupedShardPlan:
 
         return run
 
+    def _step_direct(self):
+        self._seq += 1
+        if not self._runs:  # (an empty shard still follows the stream its words are posted on)
+            self._ctx.follow_torch_stream(self._torch_dev)
+        for run in self._runs:
+            run()
+        if self.co_all is not None:
+            if self._n_peers:
+                self._ctx.signal_wait(self._sig.addr, self._n_peers, self._seq)
+            return self.co_loc, self.nu_loc, self.co_all, self.nu_all
+        self._ctx.signal_post(self._my_word, self._seq)
+        return None, None
+
     def step(self):
+        if self.direct:
+            return self._step_direct()
         batch = self._dist.batch_isend_irecv
         reqs = []
         for ops in self._recv_batches:
