@@ -15,6 +15,10 @@
 
 #include "moments_dev.hpp"
 
+#ifndef PDS_LEV_NB
+#define PDS_LEV_NB 2  // (4: same speed, 6 spilled VGPRs + 28 B of scratch at 256 registers; round 6 A/B) 16-row blocks of a tile whose leverage matrix steps are interleaved (moments_small_kernel, LEVM)
+#endif
+
 namespace pds {
 
 // link / variance functions of the GLM (link_functions.rs:5-77): 0 identity / gaussian, 1 log / poisson, 2 logit / binomial,
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* _
         // four 16-row blocks at a time, their matrix steps interleaved (block-inner order): consecutive instructions are independent,
         // a block's own chain comes round every fourth issue -- left to the compiler the blocks ran one after the other, every step
         // waiting out the previous one's 16 passes (s_nop 15 in front of each reduction: ~400 clk per block with the pipe idle)
-        constexpr int NB = 4;
+        constexpr int NB = PDS_LEV_NB;
 #pragma unroll
         for (int b0 = 0; b0 < TR / 16; b0 += NB) {
             T xb[NB][4];

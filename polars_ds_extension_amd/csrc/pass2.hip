@@ -43,6 +43,14 @@ __global__ __launch_bounds__(kP2Threads, PDS_P2_BLOCKS) void pass2_kernel(const 
     const int p = PC ? PC : p_arg;
     const int pp = p + bias;
     double sse = 0.0, wsse = 0.0;
+    __shared__ T s_inv[HC >= 2 ? 17 * 17 : 1];  // (X'X)^-1 padded to 17 x 17, off-diagonal entries doubled (HC2 / HC3 leverages)
+    if constexpr (HC >= 2) {
+        for (int i = threadIdx.x; i < 17 * 17; i += blockDim.x) {
+            const int a = i % 17, b = i / 17;
+            s_inv[i] = (a < pp && b < pp) ? inv[a + b * pp] * (a == b ? T(1) : T(2)) : T(0);
+        }
+        __syncthreads();
+    }
     // loop-invariant, wave-uniform: column pointers and coefficients live in SGPRs
     gptr<T> cx[16];
     T bx[16];
@@ -74,6 +82,42 @@ __global__ __launch_bounds__(kP2Threads, PDS_P2_BLOCKS) void pass2_kernel(const 
     };
     auto compute = [&](int64_t row, const V (&x)[16], const V& yv, const V& wv, bool full) __attribute__((always_inline)) {
         V pr, rs, sv;
+        T om_of[RPL];
+        if constexpr (HC >= 2) {
+            // leverage h = z' A z, z = [x_0 .. x_{p-1}, 1 (bias)], over the upper triangle of A = (X'X)^-1 (off-diagonal entries stored
+            // doubled): every entry is ONE broadcast read from the block's LDS copy, used for all of the lane's rows.  (As scalar loads
+            // the compiler kept all 17 x 17 entries in scalar registers: 1 310 spilled SGPRs + scratch in the 16-feature variant.)
+            T hh[RPL];
+#pragma unroll
+            for (int e = 0; e < RPL; ++e) hh[e] = T(0);
+            // up to 8 features the 45 entries stay in registers across the chunks (the compiler hoists the reads); beyond, they are read
+            // again for every chunk -- the 153 entries of 16 features + intercept do not fit beside two register sets of the frame
+            // (hoisted: 390 spilled VGPRs).  An empty asm makes the base a per-chunk value.
+            int zo = 0;
+            if constexpr (PC == 0 || PC > 8) asm volatile("" : "+v"(zo));
+            const T* const sinv = s_inv + zo;
+#pragma unroll
+            for (int a = 0; a < 17; ++a) {
+                if (a < p || (bias && a == p)) {
+                    T tt[RPL];
+                    const T daa = sinv[a + 17 * a];
+#pragma unroll
+                    for (int e = 0; e < RPL; ++e) tt[e] = daa * (a < p ? x[a < 16 ? a : 0][e] : T(1));
+#pragma unroll
+                    for (int b = a + 1; b < 17; ++b)
+                        if (b < p || (bias && b == p)) {
+                            const T dab = sinv[a + 17 * b];
+#pragma unroll
+                            for (int e = 0; e < RPL; ++e) tt[e] = fma(dab, (b < p ? x[b < 16 ? b : 0][e] : T(1)), tt[e]);
+                        }
+#pragma unroll
+                    for (int e = 0; e < RPL; ++e) hh[e] = fma(a < p ? x[a < 16 ? a : 0][e] : T(1), tt[e], hh[e]);
+                    if constexpr (PC == 0 || PC > 8) __builtin_amdgcn_sched_barrier(0);  // (one row of A at a time: the reads of all 17 rows ahead of their use filled the register file)
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < RPL; ++e) om_of[e] = T(1) - hh[e];
+        }
 #pragma unroll
         for (int e = 0; e < RPL; ++e) {
             T acc = b0;
@@ -89,27 +133,7 @@ __global__ __launch_bounds__(kP2Threads, PDS_P2_BLOCKS) void pass2_kernel(const 
             if (WEIGHTED) wsse = fma((double)wv[e], rd * rd, wsse);
             if (HC) {
                 T s = r * r;
-                if (HC >= 2) {  // leverage h = x' inv x (inv is pp x pp column-major, symmetric)
-                    T h = T(0);
-#pragma unroll
-                    for (int a = 0; a < 16; ++a)
-                        if (a < p) {
-                            T tt = bias ? inv[a + p * pp] : T(0);
-#pragma unroll
-                            for (int b = 0; b < 16; ++b)
-                                if (b < p) tt += inv[a + b * pp] * x[b][e];
-                            h += x[a][e] * tt;
-                        }
-                    if (bias) {
-                        T tt = inv[p + p * pp];
-#pragma unroll
-                        for (int b = 0; b < 16; ++b)
-                            if (b < p) tt += inv[p + b * pp] * x[b][e];
-                        h += tt;
-                    }
-                    const T om = T(1) - h;
-                    s = (HC == 2) ? s * (T(1) / om) : s * (T(1) / (om * om));
-                }
+                if (HC >= 2) s = (HC == 2) ? s * (T(1) / om_of[e]) : s * (T(1) / (om_of[e] * om_of[e]));
                 sv[e] = in ? s : T(0);
             }
         }
@@ -128,15 +152,23 @@ __global__ __launch_bounds__(kP2Threads, PDS_P2_BLOCKS) void pass2_kernel(const 
         }
     };
     // (one register set at four waves per SIMD instead -- 98 VGPRs -- measured 2.12 vs 2.08 ms: the double buffer stays)
-    if (t < t_end) load_full(t * CH + lane * RPL, xa, ya, wa);
+    // (the HC2 / HC3 form at 9+ features computes ~350 f64 operations per row: one register set -- with the second one the
+    //  16-feature variant spilled 13 registers to scratch; its loads are covered by the other waves of the SIMD)
+    constexpr bool DOUBLE_SET = !(HC >= 2 && (PC == 0 || PC > 8));
+    if (DOUBLE_SET && t < t_end) load_full(t * CH + lane * RPL, xa, ya, wa);
     for (; t < t_end; ++t) {
-        V xb[16], yb, wb;
+        if constexpr (DOUBLE_SET) {
+            V xb[16], yb, wb;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) xb[c] = xa[c];
-        yb = ya;
-        wb = wa;
-        if (t + 1 < t_end) load_full((t + 1) * CH + lane * RPL, xa, ya, wa);
-        compute(t * CH + lane * RPL, xb, yb, wb, true);
+            for (int c = 0; c < 16; ++c) xb[c] = xa[c];
+            yb = ya;
+            wb = wa;
+            if (t + 1 < t_end) load_full((t + 1) * CH + lane * RPL, xa, ya, wa);
+            compute(t * CH + lane * RPL, xb, yb, wb, true);
+        } else {
+            load_full(t * CH + lane * RPL, xa, ya, wa);
+            compute(t * CH + lane * RPL, xa, ya, wa, true);
+        }
     }
     if (nfull * CH < n && wid == nw - 1) {  // ragged tail: exactly one wave
         const int64_t row = nfull * CH + lane * RPL;
