@@ -464,7 +464,6 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
     if (want_coef && !place && (!out_keys || !coeffs)) return fail(PDS_ERR_INVALID, "out_keys and coeffs come together");
     if (n_feat < 1) return fail(PDS_ERR_INVALID, "need at least one feature column");
     if (n_rows <= 0) return fail(PDS_ERR_EMPTY, "Empty data");
-    if (n_rows >= (1ll << 31)) return fail(PDS_ERR_UNSUPPORTED, "keyed grouping: fewer than 2^31 rows per call");
     if (!want_coef) max_groups = n_rows;
     if (max_groups < 1) return fail(PDS_ERR_INVALID, "max_groups must be positive");
     PDS_HIP_CHECK(hipSetDevice(ctx->device));
@@ -507,6 +506,10 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
                                    part_candidate ? d_slots : nullptr, &hist_taken))
         return rc;
     tr.mark("keys H2D + order check");
+    // ORDERED keys have no row bound of their own (the order check, the run marks and the fits index rows with 64 bits; 2^31 + rows x 8
+    // f64 features fit this device's HBM, and the reference's series_to_mat_for_lr has no bound either, linear_regression.rs:151-267);
+    // the routes for keys in ANY order carry 32-bit row ranks through the sort / the partition
+    if (!sorted && n_rows >= (1ll << 31)) return fail(PDS_ERR_UNSUPPORTED, "keyed grouping of unordered keys: fewer than 2^31 rows per call");
     if (place && !sorted) {
         place->unsorted();
         return fail(PDS_ERR_UNSUPPORTED, "sliced fit: the slice's keys are not in order");
@@ -529,8 +532,9 @@ static int lr_by_key_impl(pds_ctx* ctx, const T* const* cols, const int64_t* key
     if (partition) PDS_HIP_CHECK(hipMemcpyAsync(d_part_base, &part_base, sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
     // ---- workspace: [raw columns (host frames)] [sorted keys, index in/out, gathered columns (unsorted frames)] runs, temp
     const int64_t cap = std::min<int64_t>(max_groups, n_rows);
-    const size_t temp_bytes = keyed_temp_bytes(n_rows);
-    const int64_t run_cap = partition ? cap : n_rows;  // unique keys, counts, offsets: at most one per row / per group
+    const size_t temp_bytes = sorted ? keyed_ordered_temp_bytes(n_rows) : keyed_temp_bytes(n_rows);
+    // unique keys, counts, offsets: at most one per group (the partition route; ordered keys: the order check has counted them) / per row
+    const int64_t run_cap = partition ? cap : (sorted ? std::min<int64_t>(n_runs + 1, cap) : n_rows);
     size_t need = temp_bytes + 3 * up((size_t)(run_cap + 1) * 8) + 8192;
     if (space == PDS_HOST) need += col_bytes * nc;
     // (the same predicates as the take() sites below: a device frame with coeffs but no is_null still takes its flags here)

@@ -351,6 +351,7 @@ size_t rolling_wide_workspace(int n_feat, int64_t n_rows, size_t elem);
 // ---- keyed.hip: int64 keys in any row order -> sorted keys, permutation, distinct keys, group offsets
 int keys_nondecreasing(pds_ctx* ctx, const int64_t* d_keys, int64_t n, unsigned* d_flag, bool* sorted);
 size_t keyed_temp_bytes(int64_t n);
+size_t keyed_ordered_temp_bytes(int64_t n);
 constexpr int kKeySlots = 8192;  // slots of the histogram the order check can take along (keyed.hip / keyed_partition.hip)
 int keys_order_minmax(pds_ctx* ctx, const int64_t* d_keys, int64_t n, int64_t* d_state /* 8 slots */, bool* sorted, int64_t* mm,
                       uint32_t* d_run_counts = nullptr /* key_run_slots(n) entries: see keyed_runs_ordered */,

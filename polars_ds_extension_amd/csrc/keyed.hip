@@ -436,6 +436,14 @@ int keyed_runs_ordered(pds_ctx* ctx, const int64_t* d_keys, int64_t n, uint32_t*
     return PDS_OK;
 }
 
+// temp bytes of the ordered route alone (the scan of the order check's run counts): what a frame whose keys are already in order
+// needs -- the sort's temp storage is 12 bytes per row
+size_t keyed_ordered_temp_bytes(int64_t n) {
+    size_t c = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, c, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)std::min<int64_t>(n / 128 + 4, INT32_MAX));
+    return ((c + 255) & ~(size_t)255) + 256;
+}
+
 // temp bytes of the sort + run-length + scan stages for n rows
 size_t keyed_temp_bytes(int64_t n) {
     size_t a = 0, b = 0, c = 0;

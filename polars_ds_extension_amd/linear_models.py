@@ -41,8 +41,8 @@ def _columns(X) -> list:
     The p contiguous columns of an n x p matrix.  With a GPU the row-major matrix is transposed ONCE on the device
     (`pds_rows_to_cols_*`, csrc/layout.hip): a NumPy matrix crosses PCIe as contiguous row chunks -- one copy, not p strided
     host gathers -- and a row-major CUDA tensor never leaves HBM.  The reference reads the NumPy buffer through a strided
-    faer MatRef (src/pymodels/numpy_faer.rs:10-66).  Without a device (the CPU test-suite on the mock library) the columns
-    are cut on the host.
+    faer MatRef (src/pymodels/numpy_faer.rs:10-66).  Without a visible device the columns are cut on the host (the fit that
+    follows then fails in the library: there is no CPU path).
     """
     try:
         import torch
@@ -50,8 +50,6 @@ def _columns(X) -> list:
         have_gpu = torch.cuda.is_available()
     except ImportError:
         have_gpu = False
-    if have_gpu and str(getattr(_lib.load(), "_name", "")) != str(_lib.LIB_PATH):
-        have_gpu = False  # (the CPU test-suite's mock library stands in for the product library: columns are cut on the host)
     if have_gpu:
         f64 = bool(config.LIN_REG_EXPR_F64)
         tdt, ndt = (torch.float64, np.float64) if f64 else (torch.float32, np.float32)
@@ -83,13 +81,12 @@ def _fit_rowmajor(X, y, prm, mode: int, pp: int):
     """
     LR / ElasticNet / OnlineLR fits straight from the row-major matrix (`pds_lr_rowmajor_*`): up to 16 features the matrix
     core reads the rows as they lie -- one pass over X, nothing transposed, a NumPy matrix crossing PCIe as contiguous row
-    chunks.  Returns (coeffs, is_null, inv) or None when this route does not apply (no GPU / the CPU suite's mock library),
-    in which case the caller cuts columns.
+    chunks.  Returns (coeffs, is_null, inv) or None when no device is visible, in which case the caller cuts columns.
     """
     try:
         import torch
 
-        if not torch.cuda.is_available() or str(getattr(_lib.load(), "_name", "")) != str(_lib.LIB_PATH):
+        if not torch.cuda.is_available():
             return None
     except ImportError:
         return None

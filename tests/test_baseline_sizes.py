@@ -336,3 +336,46 @@ def test_c5_configured_size_gram_and_descent(pds, orc, n):
     finally:
         pds.config.LIN_REG_EXPR_F64 = True
         pds.default_context().set_option("wide_f32_native", 0)
+
+
+def test_ordered_keys_beyond_2_31_rows(pds):
+    """`lin_reg_by_key` on an ORDERED int64 key column of 2^31 + 4096 rows x 1 feature (51.5 GB resident: keys, target, feature): the
+    order check, the run marks and the fused fit index rows with 64 bits -- only the routes for unordered keys carry 32-bit row ranks
+    (capi_grouped.hpp).  The reference's marshalling has no row bound (linear_regression.rs:151-267).  Checked: the group list, and the
+    fits of groups at the front, across the 2^31 boundary and at the end against an f64 closed form on the same rows."""
+    import torch
+
+    free, _ = torch.cuda.mem_get_info()
+    n = (1 << 31) + 4096
+    if free < 64 * (1 << 30):
+        pytest.skip("needs 64 GB of free HBM")
+    dev_ = torch.device("cuda", 0)
+    R = 4096
+    G = n // R
+    assert G * R == n
+    gen = torch.Generator(device=dev_)
+    gen.manual_seed(2031)
+    x = torch.rand(n, dtype=torch.float64, device=dev_, generator=gen)
+    y = torch.empty(n, dtype=torch.float64, device=dev_)
+    step = 1 << 27
+    for a in range(0, n, step):  # y = (1 + g mod 7) x + noise, group g = row // R; built in pieces (no 17 GB temporaries)
+        b = min(n, a + step)
+        g_of = torch.arange(a, b, device=dev_, dtype=torch.int64) // R
+        y[a:b] = x[a:b] * (1.0 + (g_of % 7).double()) + 1e-3 * torch.randn(b - a, dtype=torch.float64, device=dev_, generator=gen)
+        del g_of
+    key = torch.empty(n, dtype=torch.int64, device=dev_)
+    for a in range(0, n, step):
+        b = min(n, a + step)
+        key[a:b] = torch.arange(a, b, device=dev_, dtype=torch.int64) // R * 3 - 11  # ordered, sparse key values
+    keys_out, co, nu = pds.lin_reg_by_key(x, target=y, key=key, max_groups=G + 8)
+    torch.cuda.synchronize()
+    assert keys_out.shape[0] == G and co.shape == (G, 1) and not bool(nu.any().item())
+    assert int(keys_out[0].item()) == -11 and int(keys_out[-1].item()) == (G - 1) * 3 - 11
+    assert bool((keys_out[1:] - keys_out[:-1] == 3).all().item())
+    g_cut = (1 << 31) // R
+    assert g_cut == G - 1  # (the last group lies entirely beyond row 2^31)
+    for g in (0, 1, G // 2, g_cut - 2, g_cut - 1, g_cut):
+        xs_, ys_ = x[g * R:(g + 1) * R], y[g * R:(g + 1) * R]
+        ref = float((xs_ @ ys_) / (xs_ @ xs_))
+        assert abs(float(co[g, 0].item()) - ref) <= 1e-12 * abs(ref), (g, float(co[g, 0].item()), ref)
+        assert abs(ref - (1.0 + g % 7)) < 1e-3

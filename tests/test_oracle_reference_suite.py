@@ -32,11 +32,18 @@ def oracle_backed_package(orc):
 
     saved_lib, saved_tls = _lib._lib, lstsq._tls if hasattr(lstsq, "_tls") else None
     _lib._lib = device.load_for_package()
+    # the mock answers HOST pointers only: while it stands in, the package must see no device (on a GPU box its model classes would
+    # otherwise hand it device buffers) -- the test double adapts the environment, the product does not know about the double
+    import torch
+
+    saved_avail = torch.cuda.is_available
+    torch.cuda.is_available = lambda: False
     if saved_tls is not None:
         lstsq._tls = threading.local()
     try:
         yield m
     finally:
+        torch.cuda.is_available = saved_avail
         _lib._lib = saved_lib
         if saved_tls is not None:
             lstsq._tls = saved_tls
