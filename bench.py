@@ -45,7 +45,7 @@ sys.path.insert(0, str(ROOT))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-PROFILE_TAG = "r05"     # profiles/<tag>_traffic.json: HBM bytes per launch from the rocprofv3 PMC passes
+PROFILE_TAG = "r06"     # profiles/<tag>_traffic.json: HBM bytes per launch from the rocprofv3 PMC passes
 
 
 def _gen_frame(torch, dev, seed, G, R, P):

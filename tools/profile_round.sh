@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (via gpurun): collects everything profiles/rNN_* is built from into gpurun_out/prof/.
-#   bash tools/profile_round.sh        then, back in the repo:  python tools/summarize_profiles.py r04
+#   bash tools/profile_round.sh        then, back in the repo:  python tools/summarize_profiles.py r06
 # PMC passes are separate runs with --kernel-trace only (never combined with sys/hip/hsa traces).
 # Every profiler run is under `timeout` and writes to a file (tools/README.md, GPU-box hygiene).
 set -u
@@ -59,11 +59,19 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_AC
 done
 # round 5: the partition route's id-indexed prediction pass (grouped_pred MODE 3), the C5 wide Gram's counters (FETCH / WRITE, L2 hit rate,
 # matrix-pipe busy cycles), the ordered-keys call's kernels, the HC2 / HC3 report widths
-bash $ROOT/tools/pmc_wide_r05.sh > $OUT/pmc_wide_r05.log 2>&1; cp $ROOT/gpurun_out/pmc_wide/r05_pmc_wide.json $OUT/ 2>/dev/null; rm -rf $ROOT/gpurun_out/pmc_wide
+bash $ROOT/tools/pmc_wide_r05.sh > $OUT/pmc_wide_r05.log 2>&1; cp $ROOT/gpurun_out/pmc_wide/r05_pmc_wide.json $OUT/pmc_wide.json 2>/dev/null; rm -rf $ROOT/gpurun_out/pmc_wide
 cd /tmp
 rm -rf /tmp/p12 && timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p12 -o k -- python -u $ROOT/tools/sorted_keys_ab.py > $OUT/sorted_keys_run.log 2>&1
 cp $(find /tmp/p12 -name "*kernel_stats.csv" | head -1) $OUT/sorted_keys_kernel_stats.csv
 timeout -k 5 300 python -u $ROOT/tools/report_hc_quick.py > $OUT/report_hc.log 2>&1
+# round 6: the HC2 / HC3 report route at C2 (1e8 x 16 / 12 / 9 / 8 f64 + intercept): kernel stats and HBM counters of its kernels
+# (moments_small_kernel<double, 4, ...>: residuals + leverages + meat fused), the two-process direct gather smoke
+rm -rf /tmp/p13 && timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p13 -o h -- python -u $ROOT/tools/report_hc_quick.py > $OUT/report_hc_run.log 2>&1
+cp $(find /tmp/p13 -name "*kernel_stats.csv" | head -1) $OUT/hc_kernel_stats.csv
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/p14 && timeout -k 5 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/p14 -o h -- python -u $ROOT/tools/report_hc_quick.py > $OUT/pmc_hc_$c.log 2>&1
+  cp $(find /tmp/p14 -name "*counter_collection.csv" | head -1) $OUT/pmc_hc_$c.csv
+done
 slim $OUT/pmc_*.csv $OUT/bench_kernel_trace.csv
 du -sh $OUT
 ls -la $OUT

@@ -18,7 +18,7 @@ gen.manual_seed(1)
 n, P = 100_000_000, 16
 xs = [torch.rand(n, dtype=torch.float64, device=dev, generator=gen) for _ in range(P)]
 y = sum(xs[j] * ((-1) ** j * (0.05 + 0.03 * j)) for j in range(P)) + 1e-2 * torch.randn(n, dtype=torch.float64, device=dev, generator=gen)
-for p in (16, 12):
+for p in (16, 12, 9, 8):
     out = []
     for se in ("se", "hc1", "hc2", "hc3"):
         f = lambda: pds.lin_reg_report(*xs[:p], target=y, add_bias=True, std_err=se, ctx=ctx)

@@ -179,5 +179,34 @@ if sq:
     for c in names:
         md.append(f"| {c} | " + " | ".join(f"{table[k].get(c, float('nan')):.4g}" for k in table) + " |")
     md.append("")
+# ---- round 6: the HC2 / HC3 report route at C2, kernel resources of the product build, the wide Gram's counters
+hs = SRC / "hc_kernel_stats.csv"
+if hs.exists():
+    (OUT / f"{rnd}_hc_kernel_stats.csv").write_text(hs.read_text())
+    hf, hw = SRC / "pmc_hc_FETCH_SIZE.csv", SRC / "pmc_hc_WRITE_SIZE.csv"
+    f2, w2 = (pmc(hf), pmc(hw)) if hf.exists() and hw.exists() else ({}, {})
+    md += ["## HC2 / HC3 reports at C2 (`rocprofv3 --kernel-trace --stats -- python tools/report_hc_quick.py`: 1e8 rows x 16 / 12 / 9 / 8 f64 + intercept, "
+           "every std_err type; HBM bytes per launch from separate `--pmc FETCH_SIZE` / `WRITE_SIZE` passes, averaged over the launches of a kernel)", "",
+           "| kernel | calls | avg us | read MB | write MB |", "|---|---|---|---|---|"]
+    for n, c, us, pct in stats(hs):
+        if us * c < 500.0:
+            continue
+        rd = 2.0 * f2[n][0] * 1024 / 1e6 if n in f2 else float("nan")
+        wr = w2.get(n, (0.0, 0))[0] * 1024 / 1e6 if n in w2 else float("nan")
+        md.append(f"| `{n}` | {c} | {us:.1f} | {rd:.1f} | {wr:.1f} |")
+    log = SRC / "report_hc_run.log"
+    if log.exists():
+        md += ["", "```", *[l for l in log.read_text().splitlines() if l.startswith("p =")], "```", ""]
+pw = SRC / "pmc_wide.json"
+if pw.exists():
+    (OUT / f"{rnd}_pmc_wide_raw.json").write_text(pw.read_text())
+import subprocess
+kr = subprocess.run([sys.executable, str(ROOT / "tools" / "kernel_resources.py")], capture_output=True, text=True).stdout
+if kr.strip():
+    (OUT / f"{rnd}_kernel_resources.txt").write_text("# python tools/kernel_resources.py: registers / spills / scratch of every kernel of the product build (code-object notes)\n" + kr)
+    rows = [l for l in kr.splitlines()[1:] if l.split() and (int(l.split()[4]) > 0 or int(l.split()[6]) > 0)]
+    md += [f"## Kernel resources (`{rnd}_kernel_resources.txt`): kernels with spilled VGPRs or scratch: {len(rows)}", "", "```", kr.splitlines()[0], *rows, "```", ""]
+    sg = sorted((l for l in kr.splitlines()[1:] if l.split()), key=lambda l: -int(l.split()[5]))[:12]
+    md += ["Largest spilled-SGPR counts (v_writelane / v_readlane into spare VGPR lanes, no memory traffic):", "", "```", kr.splitlines()[0], *sg, "```", ""]
 (OUT / f"{rnd}_summary.md").write_text("\n".join(md))
 print("wrote", sorted(p.name for p in OUT.glob(f"{rnd}_*")))
