@@ -98,18 +98,15 @@ __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* _
         for (int c = p; c < 16; ++c) *reinterpret_cast<typename Tile<T>::vec*>(wl + c * kColStride + lane * 16) = z;
     }
 
-    // WM == 4: (X'X)^-1, padded to 17 x 17 (unused rows / columns zero), spread over the lanes: entry i lives in lane i % 64,
-    // slot i / 64.  Every row needs all of its upper triangle with wave-uniform indices; v_readlane hands an entry to the
-    // scalar side in one instruction -- as scalar LOADS from memory the 289 entries cost 10 ms per pass at 1e8 x 16 (what
-    // pass2_kernel's HC2 / HC3 path still pays), as LDS broadcasts 50 ms.  Off-diagonal entries are stored doubled.
-    // LEVM (WM == 4, more than 8 features): the leverages on the MATRIX CORES instead.  h_i = z_i' P z_i with P = (X'X)^-1 =
+    // LEVM (WM == 4): the leverages on the MATRIX CORES.  h_i = z_i' P z_i with P = (X'X)^-1 =
     // x_i' (P_xx x_i + 2 p_xb) + p_bb (the intercept's 1 handled in closed form, so 16 features + intercept need no 17th operand row):
     // U = P_xx X' for 16 rows of the tile is FOUR matrix instructions (contraction over the 16 features, four at a time) whose result
     // layout -- lane (row j, quad q), register v holds U[feature drow(lane, v)][row j] -- is exactly the layout of their own B
     // operands, so the lane multiplies U by the x values it has just fed in, adds 2 p_xb, and the four quads are summed by two lane
     // swaps.  32 more matrix instructions per 128-row tile (as many as the Gram itself) replace 153 FMAs + 306 v_readlane PER ROW:
     // the HC2 / HC3 pass was bound by that vector work (report_c2_hc3 0.55 of the HBM peak against 0.73 for SE / HC1).
-    constexpr bool LEVM = WM == 4 && P2 == 0;
+    static_assert(!(WM == 4 && P2 != 0), "HC2 / HC3 run on the unpacked tile (the packed kernels' vector form of the leverages -- 153 FMAs + 306 v_readlane per row, 744 spilled SGPRs -- lost to it at every width and left the product in round 6)");
+    constexpr bool LEVM = WM == 4;
     T lev_a[4] = {T(0), T(0), T(0), T(0)}, lev_pb[4] = {T(0), T(0), T(0), T(0)};
     T lev_pbb = T(0);
     if constexpr (LEVM) {
@@ -123,34 +120,6 @@ __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* _
         }
         lev_pbb = bias ? inv_g[p + p * pp] : T(0);
     }
-    unsigned hc_lo[5], hc_hi[5];
-    if constexpr (WM == 4 && !LEVM) {
-        const T* const inv_g = static_cast<const T*>(ia.inv);
-        const int pp = p + bias;
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const int i = lane + 64 * j, a = i % 17, b = i / 17;
-            T v = T(0);
-            if (i < 289 && a < pp && b < pp) v = inv_g[a + b * pp] * (a == b ? T(1) : T(2));
-            if constexpr (sizeof(T) == 8) {
-                const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-                hc_lo[j] = (unsigned)u;
-                hc_hi[j] = (unsigned)(u >> 32);
-            } else {
-                hc_lo[j] = __builtin_bit_cast(unsigned, v);
-                hc_hi[j] = 0;
-            }
-        }
-    }
-    auto hc_entry = [&](int i) __attribute__((always_inline)) -> T {  // i = a + 17 b, compile-time after unrolling
-        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)hc_lo[i / 64], i % 64);
-        if constexpr (sizeof(T) == 8) {
-            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)hc_hi[i / 64], i % 64);
-            return __builtin_bit_cast(T, ((unsigned long long)hi << 32) | lo);
-        } else {
-            return __builtin_bit_cast(T, lo);
-        }
-    };
     WaveAcc acc;
     zero_acc(acc);
     const int64_t nfull = n / TR;
@@ -181,39 +150,6 @@ __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* _
                     if (c < p) acc1 += regs.x[c][e] * bx[c];
                 const T r = regs.y[e] - acc1;
                 regs.w[e] = (row + e < n_lim) ? r * r : T(0);
-            }
-        }
-        if constexpr (WM == 4 && !LEVM) {
-            // HC2 / HC3: the weight of a row is e_i^2 / (1 - h_i)^k with the leverage h_i = z_i' (X'X)^-1 z_i (the arithmetic of
-            // pass2_kernel, operation by operation).  The y slot of the tile takes (1 - h_i)^k, so that the moment entry
-            // (ones, y) = sum w_i y'_i is the plain residual sum of squares the report needs beside the meat.
-#pragma unroll
-            for (int e = 0; e < RPL; ++e) {
-                T acc1 = b0;
-#pragma unroll
-                for (int c = 0; c < 16; ++c)
-                    if (c < p) acc1 += regs.x[c][e] * bx[c];
-                const T r = regs.y[e] - acc1;
-                // leverage h = z' A z over the upper triangle, z = [x_0 .. x_{p-1}, 1 (bias), 0 ..]: the padded entries of A are
-                // zero, so all 17 x 18 / 2 terms run without a test (slots c >= p of the tile registers are not zeros in the
-                // packed layouts: they are masked here)
-                T z[17];
-#pragma unroll
-                for (int c = 0; c < 17; ++c) z[c] = (c < 16 && c < p) ? regs.x[c < 16 ? c : 0][e] : ((bias && c == p) ? T(1) : T(0));
-                T h = T(0);
-#pragma unroll
-                for (int a = 0; a < 17; ++a) {
-                    T tt = hc_entry(a + 17 * a) * z[a];
-#pragma unroll
-                    for (int b = a + 1; b < 17; ++b) tt += hc_entry(a + 17 * b) * z[b];
-                    h += z[a] * tt;
-                }
-                const T om = T(1) - h;
-                const T s2 = r * r;
-                const T wv = (ia.hc_pow == 1) ? s2 * (T(1) / om) : s2 * (T(1) / (om * om));
-                const bool in = row + e < n_lim;
-                regs.w[e] = in ? wv : T(0);
-                regs.y[e] = in ? ((ia.hc_pow == 1) ? om : om * om) : T(0);
             }
         }
         if constexpr (WM == 3) {
@@ -647,6 +583,7 @@ int launch_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_
         using std::integral_constant;
         using std::false_type;
         if (n_feat == 16) launch(w_c, std::true_type{}, integral_constant<int, 0>{});
+        else if constexpr (decltype(w_c)::value == 4) launch(w_c, false_type{}, integral_constant<int, 0>{});  // (p2 = 0 above: HC2 / HC3 never pack)
         else if (p2 == 8) launch(w_c, false_type{}, integral_constant<int, 8>{});
         else if (p2 == 4) launch(w_c, false_type{}, integral_constant<int, 4>{});
         else if (p2 == 2) launch(w_c, false_type{}, integral_constant<int, 2>{});
