@@ -119,8 +119,8 @@ while time.time() < t_end:
         p = int(rng.choice([1, 2, 4, 7, 8, 10, 12, 14, 30]))
         bias = bool(rng.integers(0, 2))
         pp = p + bias
-        n = int(rng.integers(4 * pp + 300, 40_000))
         w = int(rng.integers(max(2 * pp + 5, 20), 400))
+        n = int(rng.integers(max(4 * pp + 300, w + 50), 40_000))  # (a window longer than the frame is an argument error, not a case)
         X = rng.random((n, p))
         y = X @ rng.normal(size=p) + 0.2 + 0.01 * rng.normal(size=n)
         lam = float(rng.choice([0.0, 0.1]))
