@@ -122,6 +122,7 @@ __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* _
     }
     WaveAcc acc;
     zero_acc(acc);
+    double hc_sw = 0.0, hc_ys = 0.0;  // HC passes on the unpacked tile: sum w / sum w y' of the lane's OWN rows, added to the record at the end
     const int64_t nfull = n / TR;
     const int64_t wid = (int64_t)blockIdx.x * kWaves + wave, nw = (int64_t)gridDim.x * kWaves;
     TileRegs<T> regs;
@@ -150,6 +151,7 @@ __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* _
                     if (c < p) acc1 += regs.x[c][e] * bx[c];
                 const T r = regs.y[e] - acc1;
                 regs.w[e] = (row + e < n_lim) ? r * r : T(0);
+                if constexpr (P2 == 0) hc_sw += (double)regs.w[e];  // (the unpacked tile's consume leaves sum w to the lane that owns the row)
             }
         }
         if constexpr (WM == 3) {
@@ -228,7 +230,10 @@ __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* _
                 for (int m = 0; m < 4; ++m) xb[bb][m] = xq[m][16 * (b0 + bb)];
             Acc u[NB];
 #pragma unroll
-            for (int bb = 0; bb < NB; ++bb) u[bb] = Acc{0, 0, 0, 0};
+            for (int bb = 0; bb < NB; ++bb) {  // (the accumulator starts at 2 p_xb in its own layout: the matrix steps add P_xx x to it for nothing)
+                if constexpr (sizeof(T) == 8) u[bb] = Acc{lev_pb[0], lev_pb[1], lev_pb[2], lev_pb[3]};
+                else u[bb] = Acc{0, 0, 0, 0};
+            }
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 // (f64 operand layout: step m carries features 4 m .. 4 m + 3 -- narrower frames stop early; f32: every step
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* _
             for (int bb = 0; bb < NB; ++bb) {
                 T hl = T(0);
 #pragma unroll
-                for (int m = 0; m < 4; ++m) hl = fma(xb[bb][m], (T)u[bb][m] + lev_pb[m], hl);
+                for (int m = 0; m < 4; ++m) hl = fma(xb[bb][m], sizeof(T) == 8 ? (T)u[bb][m] : (T)u[bb][m] + lev_pb[m], hl);
                 if constexpr (sizeof(T) == 8) {
                     hl = xor_sum_q(hl);
                 } else {
@@ -261,6 +266,8 @@ __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* _
             const bool in = row + e < n_lim;
             wv[e] = in ? wgt : T(0);
             yv[e] = in ? ((ia.hc_pow == 1) ? om : om * om) : T(0);
+            hc_sw += (double)wv[e];
+            hc_ys = fma((double)wv[e], (double)yv[e], hc_ys);
         }
         *reinterpret_cast<V*>(wl + kSlotW * kColStride + lane * 16) = wv;
         *reinterpret_cast<V*>(wl + kSlotY * kColStride + lane * 16) = yv;
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* _
             if (tn < t_end) load_full_tile<T, LOADW>(cp, p, tn * TR + lane * RPL, regs);
         }
         if constexpr (P2 != 0) consume_tile_pack<T, WEIGHTED, P2>(wl, lane, acc);
-        else consume_tile<T, WEIGHTED>(wl, lane, TR / 4, acc);
+        else consume_tile<T, WEIGHTED, (WM == 2 || WM == 4) ? 2 : 0>(wl, lane, TR / 4, acc);  // (HC passes: a meat block; sum w / sum w y' per tile below)
     }
     if (nfull * TR < n && wid == nw - 1) {  // ragged tail: exactly one wave
         load_tail_tile<T, LOADW>(cp, p, nfull * TR + lane * RPL, n, regs);
@@ -290,9 +297,19 @@ __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* _
             store_tile_lds<T, WEIGHTED>(wl, p, lane, regs);
         }
         if constexpr (P2 != 0) consume_tile_pack<T, WEIGHTED, P2>(wl, lane, acc);
-        else consume_tile<T, WEIGHTED>(wl, lane, TR / 4, acc);
+        else consume_tile<T, WEIGHTED, (WM == 2 || WM == 4) ? 2 : 0>(wl, lane, TR / 4, acc);  // (HC passes: a meat block; sum w / sum w y' per tile below)
     }
 
+    if constexpr ((WM == 2 || WM == 4) && P2 == 0) {
+        // the per-lane sums of the lane's own rows -> the record's convention (lane 0 of the four row-slot lanes carries the wave's total)
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            hc_sw += __shfl_xor(hc_sw, o);
+            hc_ys += __shfl_xor(hc_ys, o);
+        }
+        acc.sw = lane == 0 ? hc_sw : 0.0;
+        acc.ys = lane == 0 ? hc_ys : 0.0;
+    }
     // block reduction through LDS (tile storage is dead now)
     __syncthreads();
     double* recs = reinterpret_cast<double*>(smem);

@@ -123,7 +123,11 @@ __device__ __forceinline__ void store_tile_lds(char* wl, int p, int lane, const 
 }
 
 // ---- consume `steps` groups of 4 rows from the wave's LDS tile
-template <typename T, bool WEIGHTED>
+// LEAN (weighted builds whose record is only read as a MEAT block: the HC passes of lin_reg_report): 1 = X'y and y'y are not formed,
+// 2 = sum w and sum w y are not formed either (the caller adds them once per TILE from the lane's own rows) -- three / five of the
+// eight f64 vector operations per step.  They are not free beside the matrix instructions: a v_fma_f64 takes the SIMD's FP64 unit
+// for 8.6 clk, a v_mfma_f64_16x16x4 for 65, and the two take turns (tools/fp64_share_probe.hip, profiles/r06_fp64_share_probe.txt).
+template <typename T, bool WEIGHTED, int LEAN = 0>
 __device__ __forceinline__ void consume_tile(const char* wl, int lane, int steps, WaveAcc& a) {
     const int f = lane & 15, q = lane >> 4;
     const T* xcol = reinterpret_cast<const T*>(wl + f * kColStride) + q;
@@ -148,15 +152,17 @@ __device__ __forceinline__ void consume_tile(const char* wl, int lane, int steps
             if (WEIGHTED) {
                 double wv = wv0;
                 xa = x * wv;
-                yy = fma(wv * yv, yv, yy);
-                ys = fma(wv, yv, ys);
-                sw += wv;
+                if (LEAN == 0) yy = fma(wv * yv, yv, yy);
+                if (LEAN < 2) {
+                    ys = fma(wv, yv, ys);
+                    sw += wv;
+                }
             } else {
                 yy = fma(yv, yv, yy);
                 ys += yv;
             }
             acc = Tile<double>::mfma(xa, x, acc);
-            xy = fma(xa, yv, xy);
+            if (LEAN == 0) xy = fma(xa, yv, xy);
             cs += xa;
         }
         a.d[0] = acc[0]; a.d[1] = acc[1]; a.d[2] = acc[2]; a.d[3] = acc[3];
@@ -172,15 +178,17 @@ __device__ __forceinline__ void consume_tile(const char* wl, int lane, int steps
             if (WEIGHTED) {
                 float wv = wcol[4 * s];
                 xa = x * wv;
-                yy = fmaf(wv * yv, yv, yy);
-                ys = fmaf(wv, yv, ys);
-                sw += wv;
+                if (LEAN == 0) yy = fmaf(wv * yv, yv, yy);
+                if (LEAN < 2) {
+                    ys = fmaf(wv, yv, ys);
+                    sw += wv;
+                }
             } else {
                 yy = fmaf(yv, yv, yy);
                 ys += yv;
             }
             acc = Tile<float>::mfma(xa, x, acc);
-            xy = fmaf(xa, yv, xy);
+            if (LEAN == 0) xy = fmaf(xa, yv, xy);
             cs += xa;
         }
         a.d[0] += (double)acc[0]; a.d[1] += (double)acc[1]; a.d[2] += (double)acc[2]; a.d[3] += (double)acc[3];
