@@ -209,7 +209,9 @@ __global__ __launch_bounds__(FUSE ? 256 : 64) void moments_mid_kernel(const T* c
             double aw[NBLK];
 #pragma unroll
             for (int b = 0; b < NBLK; ++b) aw[b] = WT ? a[b] * wk : a[b];
-            const double ywk = WT ? yk * wk : yk;
+            // (FUSE: the record is read as a MEAT block -- X'WX, its column sums and sum w; X'y, y'y and sum y are not formed: f64 vector
+            //  instructions take the SIMD's FP64 unit from the matrix instructions)
+            const double ywk = FUSE ? 0.0 : (WT ? yk * wk : yk);
             int q = 0;
 #pragma unroll
             for (int I = 0; I < NBLK; ++I)
@@ -220,11 +222,13 @@ __global__ __launch_bounds__(FUSE ? 256 : 64) void moments_mid_kernel(const T* c
                 }
 #pragma unroll
             for (int b = 0; b < NBLK; ++b) {
-                xy[b] = fma(aw[b], yk, xy[b]);
+                if constexpr (FUSE == 0) xy[b] = fma(aw[b], yk, xy[b]);
                 cs[b] += aw[b];
             }
-            yy = fma(ywk, yk, yy);
-            ys += ywk;
+            if constexpr (FUSE == 0) {
+                yy = fma(ywk, yk, yy);
+                ys += ywk;
+            }
             if constexpr (WT) sw += wk;
 #pragma unroll
             for (int b = 0; b < NBLK; ++b) a[b] = an[b];
