@@ -10,20 +10,27 @@
 // one more *weighted* Gram build = the meat X' diag(s) X (d_mom2: (p+2)^2 moment layout; untouched for plain standard errors)
 template <typename T>
 static int report_second_pass(pds_ctx* ctx, const DeviceCols<T>& dc, int p, int64_t n_rows, int bias, bool weighted, int se_type,
-                              const T* d_beta, const T* d_inv, double* d_sums, T* d_mom2) {
+                              const T* d_beta, const T* d_inv, double* d_sums, T* d_mom2,
+                              // PDS_REPORT_DERIVE_YVAR: the pass also sums y - y[0] and its square where it can (<= 16 features) -- d_ysums[0..1],
+                              // *ysums_done says whether it did (otherwise the caller runs the separate pass over y)
+                              double* d_ysums = nullptr, bool* ysums_done = nullptr) {
+    if (ysums_done) *ysums_done = false;
     const int hc = (se_type == PDS_SE) ? 0 : (se_type == PDS_HC2 ? 2 : (se_type == PDS_HC3 ? 3 : 1));
     // HC0 / HC1, p <= 16: the row weights are e_i^2, which the Gram kernel can form itself from the row it has just loaded --
     // residuals, sum e^2 and the meat in ONE pass over the frame (the report is two streams, not three, and the n-row
     // weight vector never exists).  HC2 / HC3 add the leverages (O(p'^2) per row, WM = 4).  Weighted frames and more than 16
     // features: pass2_kernel + a weighted Gram build.
     static const bool no_fuse = [] { const char* e = dev_env("PDS_REPORT_NO_FUSE"); return e && e[0] == '1'; }();
-    if (hc == 1 && !weighted && p <= kMaxFeatSmall && !no_fuse)
-        return launch_moments<T>(ctx, dc, p, n_rows, false, d_mom2, d_beta, bias, d_sums);
+    if (hc == 1 && !weighted && p <= kMaxFeatSmall && !no_fuse) {
+        if (ysums_done) *ysums_done = d_ysums != nullptr;
+        return launch_moments<T>(ctx, dc, p, n_rows, false, d_mom2, d_beta, bias, d_sums, nullptr, nullptr, d_ysums);
+    }
     if (hc >= 2 && !weighted && p <= kMaxFeatSmall && !no_fuse && d_inv) {  // ... and the leverages too: O(p'^2) per row in the same pass
         IrlsArgs ha;
         ha.inv = d_inv;
         ha.hc_pow = hc - 1;
-        return launch_moments<T>(ctx, dc, p, n_rows, false, d_mom2, d_beta, bias, d_sums, nullptr, &ha);
+        if (ysums_done) *ysums_done = d_ysums != nullptr;
+        return launch_moments<T>(ctx, dc, p, n_rows, false, d_mom2, d_beta, bias, d_sums, nullptr, &ha, d_ysums);
     }
     if constexpr (std::is_same<T, double>::value) {
         // 17 .. 64 f64 features: the same fusion on the streaming multi-tile-column kernel (moments_mid.hip, FUSE)
@@ -33,9 +40,11 @@ static int report_second_pass(pds_ctx* ctx, const DeviceCols<T>& dc, int p, int6
         }
     }
     T* d_s = hc ? reinterpret_cast<T*>(ws_take(ctx, (size_t)n_rows * sizeof(T))) : nullptr;
+    const bool ys_here = d_ysums && p <= kMaxFeatSmall;  // (the 17+ feature form of the pass does not carry them)
     if (int rc = launch_pass2<T>(ctx, dc, p, n_rows, bias, weighted, d_beta, d_inv, hc, nullptr, nullptr, d_sums,
-                                 reinterpret_cast<double*>(d_s)))
+                                 reinterpret_cast<double*>(d_s), ys_here ? d_ysums : nullptr))
         return rc;
+    if (ysums_done) *ysums_done = ys_here;
     if (hc) {
         // meat = X' diag(s) X : one more weighted Gram build with w = s
         DeviceCols<T> dc2;
@@ -170,7 +179,11 @@ static int report_impl(pds_ctx* ctx, const T* const* cols, const T* weights, int
     // xtx.col_piv_qr() -> inverse() and the solve (:855-858, 1028-1030)
     SolveParams sp{p, bias, PDS_SOLVER_QR, 0.0, 0.0, 0};
     if (int rc = launch_solve<T>(ctx, d_mom, 1, sp, d_beta, d_flag, d_inv, nullptr)) return rc;
-    if (int rc = report_second_pass<T>(ctx, dc, p, n_rows, bias, weighted, se_type, d_beta, d_inv, d_sums, d_mom2)) return rc;
+    // PDS_REPORT_DERIVE_YVAR: sums of y - y[0] for var(y) -- from the second pass itself where it reads y anyway (<= 16 features), one
+    // more pass over the target column otherwise
+    double* d_ys = derive_var ? reinterpret_cast<double*>(ws_take(ctx, 64)) : nullptr;
+    bool ys_done = false;
+    if (int rc = report_second_pass<T>(ctx, dc, p, n_rows, bias, weighted, se_type, d_beta, d_inv, d_sums, d_mom2, d_ys, &ys_done)) return rc;
     const bool hc = se_type != PDS_SE;
     std::vector<T> beta(pp), inv((size_t)pp * pp), meat((size_t)q * q);
     double sums[2] = {0, 0};
@@ -185,8 +198,8 @@ static int report_impl(pds_ctx* ctx, const T* const* cols, const T* weights, int
     if (derive_var) {
         // var(y) as Polars' `target.var()` delivers it to the reference (numerically stable): from the sums of y - y[0], one more
         // pass over the target column -- the raw moments of the Gram record (sum y, sum y^2) cancel when |mean| >> std
-        double* d_ys = reinterpret_cast<double*>(ws_take(ctx, 64));
-        if (int rc = launch_y_sums<T>(ctx, dc.h_ptrs[p], n_rows, d_ys, true)) return rc;
+        if (!ys_done)
+            if (int rc = launch_y_sums<T>(ctx, dc.h_ptrs[p], n_rows, d_ys, true)) return rc;
         PDS_HIP_CHECK(hipMemcpyAsync(mom_y, d_ys, sizeof(mom_y), hipMemcpyDeviceToHost, ctx->stream));
     }
     PDS_HIP_CHECK(hipStreamSynchronize(ctx->stream));

@@ -71,6 +71,7 @@ constexpr int kTileBytesPerLane = 16;
 // per-block partial record of the small-p moment kernel (doubles):
 //   [0,256)  D[i + 16*j]   X'X tile     [256,272) xy[f]   [272,288) cs[f]   288 yy  289 ys  290 sw
 constexpr int kPartD = 0, kPartXY = 256, kPartCS = 272, kPartYY = 288, kPartYS = 289, kPartSW = 290;
+constexpr int kPartY1 = 291, kPartY2 = 292;  // spare slots: sum (y - y[0]), sum (y - y[0])^2 (IrlsArgs::y_sums)
 constexpr int kPartStride = 296;
 
 struct Workspace {
@@ -169,6 +170,9 @@ struct IrlsArgs {
     // 1 / (1 - h_i) that scales the squared residual (1: HC2, 2: HC3)
     const void* inv = nullptr;
     int hc_pow = 0;
+    // residual-weighted passes of lin_reg_report (WM = 2 / 4): also sum (y - y[0]) and sum (y - y[0])^2 of the rows the pass reads anyway --
+    // the target's variance (PDS_REPORT_DERIVE_YVAR) without one more pass over y; they travel in two spare slots of the partial records
+    int y_sums = 0;
 };
 
 // ---- kernels' host launchers (moments.hip) ----
@@ -181,7 +185,9 @@ int launch_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_
                    // p <= 16: write the record as f64 into this slot instead of d_moments (row chunks of a host frame)
                    double* d_moments_f64 = nullptr,
                    // p <= 16: weights and working response of one IRLS step from d_beta_resid (moments = X'WX | X'Wz)
-                   const IrlsArgs* irls = nullptr);
+                   const IrlsArgs* irls = nullptr,
+                   // p <= 16, residual-weighted passes (d_beta_resid): sum (y - y[0]), sum (y - y[0])^2 -> d_ysums[0..1] (see IrlsArgs::y_sums)
+                   double* d_ysums = nullptr);
 // moments.hip: weights and working response of one IRLS step for frames of more than 16 features (the wide Gram build reads them)
 template <typename T>
 int launch_irls_working_wide(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, int bias, const T* d_beta,
@@ -313,7 +319,9 @@ int launch_y_sums(pds_ctx* ctx, const T* d_y, int64_t n_rows, double* d_out, boo
 template <typename T>
 int launch_pass2(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, int add_bias,
                  bool weighted, const T* d_beta, const T* d_inv /*nullable, for HC2/3*/, int hc_mode,
-                 T* d_pred, T* d_resid, double* d_sums /*[2]*/, double* d_meat /*p'*p' or null*/);
+                 T* d_pred, T* d_resid, double* d_sums /*[2]*/, double* d_meat /*p'*p' or null*/,
+                 // p <= 16: also sum (y - y[0]), sum (y - y[0])^2 -> d_ysums[0..1] (the report's derived var(y), from the rows this pass reads anyway)
+                 double* d_ysums = nullptr);
 
 // ---- nulls.hip ----
 template <typename T>

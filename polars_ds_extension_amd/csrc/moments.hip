@@ -123,11 +123,13 @@ __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* _
     WaveAcc acc;
     zero_acc(acc);
     double hc_sw = 0.0, hc_ys = 0.0;  // HC passes on the unpacked tile: sum w / sum w y' of the lane's OWN rows, added to the record at the end
+    double hy1 = 0.0, hy2 = 0.0;      // ia.y_sums: sum (y - y[0]), sum (y - y[0])^2 of the lane's own rows (the report's derived var(y))
     const int64_t nfull = n / TR;
     const int64_t wid = (int64_t)blockIdx.x * kWaves + wave, nw = (int64_t)gridDim.x * kWaves;
     TileRegs<T> regs;
     ColPtrs<T> cp;
     fetch_col_ptrs<T, LOADW>(cols, p, cp);
+    const double yc = (ia.y_sums && n > 0) ? (double)cp.y[0] : 0.0;
     // WM == 2: coefficients are wave uniform (scalar registers); rows at or beyond n_lim get weight 0
     T bx[16];
     T b0 = T(0);
@@ -152,6 +154,11 @@ __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* _
                 const T r = regs.y[e] - acc1;
                 regs.w[e] = (row + e < n_lim) ? r * r : T(0);
                 if constexpr (P2 == 0) hc_sw += (double)regs.w[e];  // (the unpacked tile's consume leaves sum w to the lane that owns the row)
+                if (ia.y_sums) {
+                    const double dy = (row + e < n_lim) ? (double)regs.y[e] - yc : 0.0;
+                    hy1 += dy;
+                    hy2 = fma(dy, dy, hy2);
+                }
             }
         }
         if constexpr (WM == 3) {
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* _
 #endif
     // LEVM, first half (while the tile is still in registers): squared residuals of the lane's rows, the features to LDS
     T lev_r2[RPL];
-    auto lev_stage = [&]() __attribute__((always_inline)) {
+    auto lev_stage = [&](int64_t row, int64_t n_lim) __attribute__((always_inline)) {
         using V = typename Tile<T>::vec;
 #pragma unroll
         for (int e = 0; e < RPL; ++e) {
@@ -202,6 +209,11 @@ __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* _
                 if (c < p) acc1 += regs.x[c][e] * bx[c];
             const T r = regs.y[e] - acc1;
             lev_r2[e] = r * r;
+            if (ia.y_sums) {
+                const double dy = (row + e < n_lim) ? (double)regs.y[e] - yc : 0.0;
+                hy1 += dy;
+                hy2 = fma(dy, dy, hy2);
+            }
         }
 #pragma unroll
         for (int c = 0; c < 16; ++c)
@@ -276,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* _
     for (; t < t_end; t += t_step) {
         const int64_t tn = t + t_step;
         if constexpr (LEVM) {
-            lev_stage();
+            lev_stage(0, 1 << 30);
             if (tn < t_end) load_full_tile<T, LOADW>(cp, p, tn * TR + lane * RPL, regs);
             lev_weights(0, 1 << 30);
         } else {
@@ -290,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* _
     if (nfull * TR < n && wid == nw - 1) {  // ragged tail: exactly one wave
         load_tail_tile<T, LOADW>(cp, p, nfull * TR + lane * RPL, n, regs);
         if constexpr (LEVM) {
-            lev_stage();
+            lev_stage(nfull * TR + lane * RPL, n);
             lev_weights(nfull * TR + lane * RPL, n);
         } else {
             resid_weights(nfull * TR + lane * RPL, n);
@@ -315,10 +327,21 @@ __global__ __launch_bounds__(256, 2) void moments_small_kernel(const T* const* _
     double* recs = reinterpret_cast<double*>(smem);
     if constexpr (P2 != 0) wave_record_pack<T, P2>(acc, lane, recs + wave * kPartStride);
     else wave_record<T>(acc, lane, recs + wave * kPartStride);
+    {   // the two spare slots behind sum w: the wave's sums of y - y[0] and its square (zeros unless ia.y_sums)
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            hy1 += __shfl_xor(hy1, o);
+            hy2 += __shfl_xor(hy2, o);
+        }
+        if (lane == 0) {
+            recs[wave * kPartStride + kPartY1] = hy1;
+            recs[wave * kPartStride + kPartY2] = hy2;
+        }
+    }
     __syncthreads();
     for (int e = threadIdx.x; e < kPartStride; e += blockDim.x) {
         double s = 0.0;
-        if (e <= kPartSW) {
+        if (e <= kPartY2) {
 #pragma unroll
             for (int w = 0; w < kWaves; ++w) s += recs[w * kPartStride + e];
         }
@@ -419,6 +442,24 @@ __global__ __launch_bounds__(256, 2) void moments_rowmajor_kernel(const T* __res
             for (int w = 0; w < kWaves; ++w) sum += recs[w * kPartStride + e];
         }
         partials[(int64_t)blockIdx.x * kPartStride + e] = sum;
+    }
+}
+
+// the blocks' y sums (slots kPartY1 / kPartY2 of the partial records) in block order -> out[0..1]
+__global__ __launch_bounds__(64) void moments_ysums_kernel(const double* __restrict__ partials, int nblocks, double* __restrict__ out) {
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 64) {
+        a += partials[(int64_t)i * kPartStride + kPartY1];
+        b += partials[(int64_t)i * kPartStride + kPartY2];
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        a += __shfl_xor(a, o);
+        b += __shfl_xor(b, o);
+    }
+    if (threadIdx.x == 0) {
+        out[0] = a;
+        out[1] = b;
     }
 }
 
@@ -571,7 +612,7 @@ __global__ __launch_bounds__(256, 2) void grouped_moments_kernel(const T* const*
 template <typename T>
 int launch_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, bool weighted,
                    T* d_moments, const T* d_beta_resid, int bias_resid, double* d_sums_resid, double* d_moments_f64,
-                   const IrlsArgs* irls) {
+                   const IrlsArgs* irls, double* d_ysums) {
     if (n_feat > kMaxFeatSmall) {
         if (d_moments_f64) return fail(PDS_ERR_INVALID, "internal: f64 moment slots are the p <= 16 kernel's");
         if (d_beta_resid) return fail(PDS_ERR_INVALID, "internal: the residual-weighted Gram build is the p <= 16 kernel's");
@@ -579,7 +620,9 @@ int launch_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_
     }
     if ((d_beta_resid || irls) && weighted) return fail(PDS_ERR_INVALID, "internal: residual / IRLS weights replace the weight column");
     if (irls && n_feat > kMaxFeatSmall) return fail(PDS_ERR_UNSUPPORTED, "GLM (IRLS): up to 16 feature columns");
-    const IrlsArgs ia = irls ? *irls : IrlsArgs{};
+    IrlsArgs ia = irls ? *irls : IrlsArgs{};
+    if (d_ysums && d_beta_resid && (!irls || irls->hc_pow > 0)) ia.y_sums = 1;  // (the residual-weighted passes of the report)
+    else d_ysums = nullptr;
     if (n_feat < 1) return fail(PDS_ERR_INVALID, "need at least one feature column");
     constexpr int TR = 64 * Tile<T>::RPL;
     int64_t ntiles = (n_rows + TR - 1) / TR;
@@ -619,6 +662,7 @@ int launch_moments(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_
         hipLaunchKernelGGL((moments_finalize_kernel<T>), dim3(kPartSW + 1), dim3(64), 0, ctx->stream, partials, nblocks, n_feat,
                            (double)n_rows, (weighted || d_beta_resid || irls) ? 1 : 0, p2, d_moments,
                            (d_beta_resid && (!irls || hc23)) ? d_sums_resid : nullptr, hc23 ? 1 : 0);
+    if (d_ysums) hipLaunchKernelGGL(moments_ysums_kernel, dim3(1), dim3(64), 0, ctx->stream, (const double*)partials, nblocks, d_ysums);
     PDS_HIP_CHECK(hipGetLastError());
     return PDS_OK;
 }
@@ -973,9 +1017,9 @@ template int launch_sum_moment_slots<double>(pds_ctx*, const double*, int, int, 
 template int launch_sum_moment_slots<float>(pds_ctx*, const double*, int, int, float*);
 
 template int launch_moments<double>(pds_ctx*, const DeviceCols<double>&, int, int64_t, bool, double*, const double*, int, double*, double*,
-                                    const IrlsArgs*);
+                                    const IrlsArgs*, double*);
 template int launch_moments<float>(pds_ctx*, const DeviceCols<float>&, int, int64_t, bool, float*, const float*, int, double*, double*,
-                                   const IrlsArgs*);
+                                   const IrlsArgs*, double*);
 template int launch_grouped_moments<double>(pds_ctx*, const DeviceCols<double>&, int, const int64_t*, int64_t,
                                             double*, const int32_t*);
 template int launch_grouped_moments<float>(pds_ctx*, const DeviceCols<float>&, int, const int64_t*, int64_t,

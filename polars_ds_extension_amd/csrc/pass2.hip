@@ -37,7 +37,7 @@ __global__ __launch_bounds__(kP2Threads, PDS_P2_BLOCKS) void pass2_kernel(const 
                                                            int64_t n, const T* __restrict__ beta,
                                                            const T* __restrict__ inv, T* __restrict__ pred_out,
                                                            T* __restrict__ resid_out, T* __restrict__ s_out,
-                                                           double* __restrict__ partials) {
+                                                           double* __restrict__ partials, double* __restrict__ ypart) {
     using V = typename V16<T>::type;
     constexpr int RPL = V16<T>::RPL;
     const int p = PC ? PC : p_arg;
@@ -62,6 +62,9 @@ __global__ __launch_bounds__(kP2Threads, PDS_P2_BLOCKS) void pass2_kernel(const 
     const gptr<T> cy = as_global(cols[p]);
     const gptr<T> cw = as_global(WEIGHTED ? cols[p + 1] : cols[p]);
     const T b0 = bias ? beta[p] : T(0);
+    // ypart (the report's derived var(y), PDS_REPORT_DERIVE_YVAR): sums of y - y[0] and its square over the rows this pass reads anyway
+    const double yc = ypart ? (double)cy[0] : 0.0;
+    double sy = 0.0, syy = 0.0;
     // Wave w owns the CONTIGUOUS chunk range [nchunk w / W, nchunk (w+1) / W) (a chunk = 64 RPL rows = 1 KiB of every column):
     // consecutive pieces of a column stay with one wave, the loads are non-temporal (every element is read once) and the next
     // chunk is in flight in a second register set while this one is computed -- the recipe of the Gram kernel (moments.hip),
@@ -130,6 +133,11 @@ __global__ __launch_bounds__(kP2Threads, PDS_P2_BLOCKS) void pass2_kernel(const 
             const bool in = full || row + e < n;
             const double rd = in ? (double)r : 0.0;
             sse = fma(rd, rd, sse);
+            if (ypart) {
+                const double dy = in ? (double)yv[e] - yc : 0.0;
+                sy += dy;
+                syy = fma(dy, dy, syy);
+            }
             if (WEIGHTED) wsse = fma((double)wv[e], rd * rd, wsse);
             if (HC) {
                 T s = r * r;
@@ -187,26 +195,36 @@ __global__ __launch_bounds__(kP2Threads, PDS_P2_BLOCKS) void pass2_kernel(const 
         compute(row, xa, ya, wa, false);
     }
     // block reduction (fixed order) -> one partial pair per block
-    __shared__ double red[2][kP2Threads / 64];
+    __shared__ double red[4][kP2Threads / 64];
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
         sse += __shfl_xor(sse, o);
         wsse += __shfl_xor(wsse, o);
+        sy += __shfl_xor(sy, o);
+        syy += __shfl_xor(syy, o);
     }
     const int wave = threadIdx.x >> 6;
     if (lane == 0) {
         red[0][wave] = sse;
         red[1][wave] = wsse;
+        red[2][wave] = sy;
+        red[3][wave] = syy;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double a = 0.0, b = 0.0;
+        double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
         for (int w = 0; w < kP2Threads / 64; ++w) {
             a += red[0][w];
             b += red[1][w];
+            c += red[2][w];
+            d += red[3][w];
         }
         partials[2 * blockIdx.x] = a;
         partials[2 * blockIdx.x + 1] = b;
+        if (ypart) {
+            ypart[2 * blockIdx.x] = c;
+            ypart[2 * blockIdx.x + 1] = d;
+        }
     }
 }
 
@@ -374,24 +392,24 @@ __global__ __launch_bounds__(kP2Threads) void leverage_scale_wide_kernel(const T
 
 template <typename T, bool W, int P16>
 static void launch_p2_w(int hc, dim3 g, hipStream_t st, const T* const* cols, int p, int bias, int64_t n, const T* beta,
-                        const T* inv, T* pred, T* resid, T* s, double* partials) {
+                        const T* inv, T* pred, T* resid, T* s, double* partials, double* ypart) {
     switch (hc) {
-        case 0: hipLaunchKernelGGL((pass2_kernel<T, W, 0, P16>), g, dim3(kP2Threads), 0, st, cols, p, bias, n, beta, inv, pred, resid, s, partials); break;
-        case 1: hipLaunchKernelGGL((pass2_kernel<T, W, 1, P16>), g, dim3(kP2Threads), 0, st, cols, p, bias, n, beta, inv, pred, resid, s, partials); break;
-        case 2: hipLaunchKernelGGL((pass2_kernel<T, W, 2, P16>), g, dim3(kP2Threads), 0, st, cols, p, bias, n, beta, inv, pred, resid, s, partials); break;
-        default: hipLaunchKernelGGL((pass2_kernel<T, W, 3, P16>), g, dim3(kP2Threads), 0, st, cols, p, bias, n, beta, inv, pred, resid, s, partials); break;
+        case 0: hipLaunchKernelGGL((pass2_kernel<T, W, 0, P16>), g, dim3(kP2Threads), 0, st, cols, p, bias, n, beta, inv, pred, resid, s, partials, ypart); break;
+        case 1: hipLaunchKernelGGL((pass2_kernel<T, W, 1, P16>), g, dim3(kP2Threads), 0, st, cols, p, bias, n, beta, inv, pred, resid, s, partials, ypart); break;
+        case 2: hipLaunchKernelGGL((pass2_kernel<T, W, 2, P16>), g, dim3(kP2Threads), 0, st, cols, p, bias, n, beta, inv, pred, resid, s, partials, ypart); break;
+        default: hipLaunchKernelGGL((pass2_kernel<T, W, 3, P16>), g, dim3(kP2Threads), 0, st, cols, p, bias, n, beta, inv, pred, resid, s, partials, ypart); break;
     }
 }
 template <typename T, bool W>
 static void launch_p2(int hc, dim3 g, hipStream_t st, const T* const* cols, int p, int bias, int64_t n, const T* beta,
-                      const T* inv, T* pred, T* resid, T* s, double* partials) {
+                      const T* inv, T* pred, T* resid, T* s, double* partials, double* ypart) {
     switch (p) {
-        case 16: launch_p2_w<T, W, 16>(hc, g, st, cols, p, bias, n, beta, inv, pred, resid, s, partials); break;
-        case 8: launch_p2_w<T, W, 8>(hc, g, st, cols, p, bias, n, beta, inv, pred, resid, s, partials); break;
-        case 4: launch_p2_w<T, W, 4>(hc, g, st, cols, p, bias, n, beta, inv, pred, resid, s, partials); break;
-        case 2: launch_p2_w<T, W, 2>(hc, g, st, cols, p, bias, n, beta, inv, pred, resid, s, partials); break;
-        case 1: launch_p2_w<T, W, 1>(hc, g, st, cols, p, bias, n, beta, inv, pred, resid, s, partials); break;
-        default: launch_p2_w<T, W, 0>(hc, g, st, cols, p, bias, n, beta, inv, pred, resid, s, partials); break;
+        case 16: launch_p2_w<T, W, 16>(hc, g, st, cols, p, bias, n, beta, inv, pred, resid, s, partials, ypart); break;
+        case 8: launch_p2_w<T, W, 8>(hc, g, st, cols, p, bias, n, beta, inv, pred, resid, s, partials, ypart); break;
+        case 4: launch_p2_w<T, W, 4>(hc, g, st, cols, p, bias, n, beta, inv, pred, resid, s, partials, ypart); break;
+        case 2: launch_p2_w<T, W, 2>(hc, g, st, cols, p, bias, n, beta, inv, pred, resid, s, partials, ypart); break;
+        case 1: launch_p2_w<T, W, 1>(hc, g, st, cols, p, bias, n, beta, inv, pred, resid, s, partials, ypart); break;
+        default: launch_p2_w<T, W, 0>(hc, g, st, cols, p, bias, n, beta, inv, pred, resid, s, partials, ypart); break;
     }
 }
 
@@ -400,7 +418,7 @@ static void launch_p2(int hc, dim3 g, hipStream_t st, const T* const* cols, int 
 template <typename T>
 int launch_pass2(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_rows, int add_bias, bool weighted,
                  const T* d_beta, const T* d_inv, int hc_mode, T* d_pred, T* d_resid, double* d_sums,
-                 double* d_s_rows) {
+                 double* d_s_rows, double* d_ysums) {
     if (n_feat < 1) return fail(PDS_ERR_INVALID, "need at least one feature column");
     if (n_feat > kMaxFeatSmall) {
         if (hc_mode >= 2 && !d_inv) return fail(PDS_ERR_INVALID, "HC2 / HC3 need the inverse of X'X");
@@ -462,15 +480,17 @@ int launch_pass2(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, int64_t n_ro
     // two resident blocks per CU (8 waves, like the Gram kernel): every wave streams one contiguous range, all of them at once
     const int nblocks = (int)std::min<int64_t>(std::max<int64_t>(want, 1), (int64_t)ctx->num_cus * PDS_P2_BLOCKS);
     double* partials = ctx->partials;
+    double* ypart = d_ysums ? ctx->partials + 4096 : nullptr;  // (2 nblocks <= 1024 doubles each; the context's block is num_cus x 8 records)
     T* s_rows = reinterpret_cast<T*>(d_s_rows);
     KernelTimer timer(ctx, kKindPass2);
     if (weighted)
         launch_p2<T, true>(hc_mode, dim3(nblocks), ctx->stream, dc.d_ptrs, n_feat, add_bias ? 1 : 0, n_rows, d_beta,
-                           d_inv, d_pred, d_resid, s_rows, partials);
+                           d_inv, d_pred, d_resid, s_rows, partials, ypart);
     else
         launch_p2<T, false>(hc_mode, dim3(nblocks), ctx->stream, dc.d_ptrs, n_feat, add_bias ? 1 : 0, n_rows, d_beta,
-                            d_inv, d_pred, d_resid, s_rows, partials);
+                            d_inv, d_pred, d_resid, s_rows, partials, ypart);
     hipLaunchKernelGGL(pass2_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream, partials, nblocks, d_sums);
+    if (ypart) hipLaunchKernelGGL(pass2_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream, (const double*)ypart, nblocks, d_ysums);
     PDS_HIP_CHECK(hipGetLastError());
     return PDS_OK;
 }
@@ -527,8 +547,8 @@ template int launch_y_sums<double>(pds_ctx*, const double*, int64_t, double*, bo
 template int launch_y_sums<float>(pds_ctx*, const float*, int64_t, double*, bool);
 
 template int launch_pass2<double>(pds_ctx*, const DeviceCols<double>&, int, int64_t, int, bool, const double*,
-                                  const double*, int, double*, double*, double*, double*);
+                                  const double*, int, double*, double*, double*, double*, double*);
 template int launch_pass2<float>(pds_ctx*, const DeviceCols<float>&, int, int64_t, int, bool, const float*,
-                                 const float*, int, float*, float*, double*, double*);
+                                 const float*, int, float*, float*, double*, double*, double*);
 
 }  // namespace pds
