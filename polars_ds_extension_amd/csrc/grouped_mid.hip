@@ -8,6 +8,22 @@
 #include "solve_wave_dev.hpp"
 #include "solve_row16_dev.hpp"
 
+#ifndef PDS_MID_DIRECT
+#define PDS_MID_DIRECT 1
+#endif
+// the direct form's loads: two consecutive instructions read the two halves of the same sixteen 128-byte lines
+#ifndef PDS_MID_DIRECT_DYNIDX
+#define PDS_MID_DIRECT_DYNIDX 0
+#endif
+#ifndef PDS_MID_DIRECT_ACC2
+#define PDS_MID_DIRECT_ACC2 0
+#endif
+#ifdef PDS_MID_DIRECT_NT
+#define PDS_MID_DIRECT_LOAD(q) __builtin_nontemporal_load(q)
+#else
+#define PDS_MID_DIRECT_LOAD(q) (*(q))
+#endif
+
 namespace pds {
 
 // -DPDS_PROFILE_MID: per-phase shader-clock sums of the paired grouped stream's waves (development; tools/grouped_mid_profile.py)
@@ -80,8 +96,17 @@ struct MidPacked {
     static __device__ __forceinline__ int tri_rt(int r) { return r * QC - ((r * (r - 1)) >> 1); }
     static constexpr int XY = QC * (QC + 1) / 2, CS = XY + (YC ? 0 : SPPC), TAIL = CS + (YC ? 0 : SPPC), GID = TAIL + (YC ? 0 : 2), COUNT = GID + 1;
 };
-template <int NBLK>
-constexpr int kMidPairLds = MidDims<NBLK>::LDS_BYTES + kMidSolveScratch + 64;  // tile images + scratch + flag words of one pair of waves (PAIRED)
+// DIRECT: the LDS the tile images no longer take holds a RING of slots between the streaming and the solving wave -- a finished group waits
+// there, not in a spare register set of the streaming wave (which has none left beside its two operand sets)
+constexpr int kMidDirectSlots = 4;
+template <int NBLK, bool DIRECT = false>
+constexpr int kMidPairLds = DIRECT ? kMidDirectSlots * kMidSolveScratch + 64  // the direct form: a ring of slots + flag words
+                                      : MidDims<NBLK>::LDS_BYTES + kMidSolveScratch + 64;  // tile images + scratch + flag words of one pair of waves (PAIRED)
+// DIRECT: the ones column and the padding columns of the second operand block are loaded like every other column -- from 64 ones and
+// 64 zeros, with a lane stride of nothing per half-tile (no selects, no partially active load instructions)
+#define PDS_R8(v) v, v, v, v, v, v, v, v
+__device__ const double g_mid_direct_const[128] = {PDS_R8(1.0), PDS_R8(1.0), PDS_R8(1.0), PDS_R8(1.0), PDS_R8(1.0), PDS_R8(1.0), PDS_R8(1.0), PDS_R8(1.0)};
+#undef PDS_R8
 
 // PAIRED (with SPPC): a workgroup is FOUR PAIRS of waves -- waves 0 .. 3 stream (loads, matrix steps, group walk: what a wave of the
 // unpaired form does up to the finished group), waves 4 .. 7 are their solvers: a finished group's moments cross the pair's LDS scratch
@@ -99,7 +124,12 @@ constexpr int kMidPairLds = MidDims<NBLK>::LDS_BYTES + kMidSolveScratch + 64;  /
 // with the quad, the second the quad with itself.
 // T = float (PAIRED only): f32 frames -- 128-row half-tiles of the same 1 KiB instructions and the same LDS bytes, widened to f64 on their
 // way out of LDS; moments, slot, solve and side / marked records are f64 as for f64 frames, the coefficients are written as T.
-template <int NBLK, int SPPC = 0, bool PAIRED = false, bool YC = false, int NQ = 0, typename T = double>
+// DIRECT (PAIRED, YC, f64 frames; round 6): NO tile images.  The streaming wave loads the half-tile straight into the matrix instructions'
+// operand layout -- lane (feature = lane % 16, slot = lane / 16) reads 16 bytes = rows 8 k + 2 slot, + 1 of its own column for block k of
+// eight rows: sixteen columns x 64 contiguous bytes per 1 KiB load instruction, the order of the rows inside a block does not matter to a
+// sum over rows -- into one of two register sets (the half-tile being walked, the next one in flight); a 4-row step multiplies rows
+// {8 k + 2 slot + j}.  No asynchronous LDS pieces (95 clk of the wave's time each), no operand reads from LDS in front of every step.
+template <int NBLK, int SPPC = 0, bool PAIRED = false, bool YC = false, int NQ = 0, typename T = double, bool DIRECT = false>
 __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(const T* const* __restrict__ cols, int p, int64_t n_frame,
                                                                 const int64_t* __restrict__ off, int64_t n_groups,
                                                                 double* __restrict__ records, int debug_arg, MidSolveArgsT<T> sa) {
@@ -118,7 +148,9 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     static_assert(!PAIRED || MidPacked<SPPC ? SPPC : 1, YC>::COUNT * 8 <= kMidSolveScratch, "the slot holds one group");
     static_assert(!YC || PAIRED, "the ones / target columns are the paired form's");
     static_assert(NQ == 0 || ((NQ == 1 || NQ == 2) && YC && NBLK == 2), "the quad form: ones and target inside the quads");
+    static_assert(!DIRECT || (PAIRED && YC && ES == 8 && NBLK == 2 && NQ <= 1), "the direct form: f64 frames, ones / target as columns, two operand pieces");
     using MD = MidDims<NBLK, ES>;
+    constexpr int IMG = DIRECT ? 0 : MD::LDS_BYTES;  // bytes of tile images in front of the pair's slot
     constexpr int HR = MD::HR, GS = MD::GS, NPAIR = MD::NPAIR;
     extern __shared__ __attribute__((aligned(16))) char gmid_lds[];
     typedef __attribute__((address_space(3))) char* lds_c;
@@ -140,8 +172,9 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     const int lane = threadIdx.x & 63;
     const int wv = PAIRED ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0, pairi = wv & 3;
     const bool consumer = PAIRED && wv >= 4;
-    lds_c sm = (lds_c)gmid_lds + (PAIRED ? pairi * kMidPairLds<NBLK> : 0);
-    const lds_flag FL = (lds_flag)(sm + MD::LDS_BYTES + kMidSolveScratch);  // [0] trips published, [1] trips taken, [2] stream finished
+    lds_c sm = (lds_c)gmid_lds + (PAIRED ? pairi * kMidPairLds<NBLK, DIRECT> : 0);
+    constexpr int NSLOT = DIRECT ? kMidDirectSlots : 1;
+    const lds_flag FL = (lds_flag)(sm + IMG + NSLOT * kMidSolveScratch);  // [0] trips published, [1] trips taken, [2] stream finished
     const int64_t wave = PAIRED ? (int64_t)blockIdx.x * 4 + pairi : (int64_t)blockIdx.x, nwaves = PAIRED ? (int64_t)gridDim.x * 4 : (int64_t)gridDim.x;
     const int64_t row_begin = off[0], row_end = off[n_groups];
     if (row_end <= row_begin) return;
@@ -149,10 +182,10 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     const int64_t H0 = row_begin / HR, H1 = (row_end + HR - 1) / HR;
     const int64_t h0 = H0 + (H1 - H0) * wave / nwaves, h1 = H0 + (H1 - H0) * (wave + 1) / nwaves;
     if (!consumer) {
-        for (int i = lane * 16; i < MD::LDS_BYTES; i += 64 * 16) *(__attribute__((address_space(3))) mid_d2*)(sm + i) = mid_d2{0.0, 0.0};
+        for (int i = lane * 16; i < IMG; i += 64 * 16) *(__attribute__((address_space(3))) mid_d2*)(sm + i) = mid_d2{0.0, 0.0};
         if constexpr (PAIRED)
             if (lane < 4) FL[lane] = 0u;
-        if constexpr (YC) {  // the ones column: the (otherwise unused) weight image of both half-tiles, written once
+        if constexpr (YC && !DIRECT) {  // the ones column: the (otherwise unused) weight image of both half-tiles, written once
             PDS_WAVE_LDS_SYNC();
             for (int b = 0; b < MD::NBUF; ++b)
                 for (int r = lane; r < HR; r += 64) PDS_GM_LDST(sm + b * MD::HALF_BYTES + MD::W_OFF + r * ES) = (T)1;
@@ -263,7 +296,6 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
         if constexpr (PAIRED) {
             typedef __attribute__((address_space(3))) double* lds_dp;
             using PK = MidPacked<SPPC, YC>;
-            lds_dp S = (lds_dp)(sm + MD::LDS_BYTES);
             const int t = lane & 15;
             const bool c1 = YC ? 16 + t < p : 16 + t < SPPC;  // (YC: columns p, p + 1 of the slot are the ones and the target, not the system's)
             const int u = c1 ? 16 + t : 16;  // (lanes without a second column read a valid address, their values are zeroed)
@@ -288,6 +320,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
             };
             auto take = [&](auto rm) __attribute__((always_inline)) {
                 constexpr int ROW = decltype(rm)::value;
+                const lds_dp S = (lds_dp)(sm + IMG + (DIRECT ? (int)(cseq % NSLOT) * kMidSolveScratch : 0));  // (DIRECT: the ring's slot of this sequence number)
                 auto put = [&](double& dst, double v) __attribute__((always_inline)) {
                     if constexpr (ROW == 0) dst = v;
                     else dst = __builtin_amdgcn_update_dpp(dst, v, 0xE4 /*quad_perm:[0,1,2,3]*/, 1 << ROW, 0xf, false);
@@ -388,6 +421,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     };
     if constexpr (PAIRED)
         if (consumer) {  // (before the streaming wave's state exists: none of it is live in the solver's registers)
+            if (debug & 16) return;  // (timing experiment: no solving wave at all, nothing published)
             solver_wave();
 #ifdef PDS_PROFILE_MID
             PDS_MADD(15, t_kernel);
@@ -395,6 +429,11 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
 #endif
             return;
         }
+#ifdef PDS_MID_STREAM_PRIO
+    // the streaming wave goes first where both waves of the SIMD want the FP64 unit (its matrix instructions against the solving wave's
+    // vector instructions: DESIGN 4.0) -- the solving wave has the slack
+    if constexpr (PAIRED) __builtin_amdgcn_s_setprio(PDS_MID_STREAM_PRIO);
+#endif
     const int g_ = lane / MD::GL, piece = lane % MD::GL;
     const T* cbase[16];
     unsigned valid = 0;
@@ -425,8 +464,16 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
         else load_guarded(buf, h * HR);
     };
     d4 acc[NPAIR];
+    // DIRECT: a second accumulator set for the second step of every block -- two chains of dependent matrix instructions instead of one
+    // (folded into the first when the group is finished)
+    constexpr bool ACC2 = PAIRED && YC && PDS_MID_DIRECT_ACC2;
+    d4 accB[ACC2 ? NPAIR : 1];
     double xy[NBLK], cs[NBLK], yy = 0.0, ys = 0.0;
     auto zero_acc = [&]() __attribute__((always_inline)) {
+        if constexpr (ACC2) {
+#pragma unroll
+            for (int t = 0; t < NPAIR; ++t) accB[t] = d4{0.0, 0.0, 0.0, 0.0};
+        }
 #pragma unroll
         for (int t = 0; t < NPAIR; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -447,6 +494,47 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
         }
     }
     const int qb = (lane >> 2) & 3, qj = lane & 3;  // quad lanes: D[i = fk][j = qj] of block qb
+    // ---- DIRECT: two register sets of NB8 blocks x NOP pieces x 16 bytes; the lane's address per piece moves on by one half-tile per issue
+    constexpr int NB8 = HR / 8;
+    d2u CUR[DIRECT ? NB8 : 1][NOP], NXT[DIRECT ? NB8 : 1][NOP];
+    gptr<char> dcp[NOP];
+    bool dreal[NOP];
+    if constexpr (DIRECT) {
+#pragma unroll
+        for (int b = 0; b < NOP; ++b) {
+            const int c = NQ ? (b == 0 ? fi : 12 + 4 * b + (fi & 3)) : 16 * b + fi;  // (as opo: the piece's column in this lane)
+            const bool real = c < p || c == p + 1;                                   // a frame column (p + 1: the target); p: ones; beyond: zeros
+            const char* base = real ? reinterpret_cast<const char*>(cols[c < p ? c : p]) + h0 * (int64_t)(HR * 8)
+                                    : reinterpret_cast<const char*>(g_mid_direct_const + (c == p ? 0 : 64));
+            dcp[b] = (gptr<char>)(base + 16 * fk);
+            dreal[b] = real;
+        }
+    }
+    auto issue_direct = [&](int64_t h) __attribute__((always_inline)) {
+        if constexpr (DIRECT) {
+            if ((h + 1) * HR <= n_frame) {
+#pragma unroll
+                for (int k = 0; k < NB8; ++k)
+#pragma unroll
+                    for (int b = 0; b < NOP; ++b) NXT[k][b] = PDS_MID_DIRECT_LOAD(reinterpret_cast<gptr<d2u>>(dcp[b] + 64 * k));
+            } else {  // the frame's last, partial half-tile: row by row, rows beyond the frame are zeros (nobody multiplies them)
+#pragma unroll
+                for (int k = 0; k < NB8; ++k)
+#pragma unroll
+                    for (int b = 0; b < NOP; ++b)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int64_t row = h * HR + 8 * k + 2 * fk + j;
+                            double v = 0.0;
+                            if (!dreal[b] || row < n_frame) v = *reinterpret_cast<gptr<double>>(dcp[b] + 64 * k + 8 * j);
+                            NXT[k][b][j] = v;
+                        }
+            }
+#pragma unroll
+            for (int b = 0; b < NOP; ++b)
+                if (b == 0 || dreal[b]) dcp[b] += HR * 8;  // (the first block's columns are all frame columns)
+        }
+    };
     // ---- the group that holds the wave's first row
     int64_t g = 0;
     {
@@ -481,7 +569,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
             if constexpr (!YC) yk = (double)PDS_GM_LDST(base + MD::Y_OFF + roff);
             else yk = 0.0;
         };
-        auto mult = [&](const double (&a)[NOP], double yk) __attribute__((always_inline)) {
+        auto mult_into = [&](d4 (&acc)[NPAIR], const double (&a)[NOP], double yk) __attribute__((always_inline)) {
             if constexpr (NQ == 1) {
                 acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], a[0], acc[0], 0, 0, 0);
                 acc[1][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[0], a[1], acc[1][0], 0, 0, 0);
@@ -514,6 +602,73 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
                 ys += yk;
             }
         };
+        auto mult = [&](const double (&a)[NOP], double yk) __attribute__((always_inline)) { mult_into(acc, a, yk); };
+        if constexpr (DIRECT) {
+            // Blocks of eight rows.  The blocks the segment covers as a whole, [f0, f1), are multiplied straight from their registers: ONE
+            // jump into a run of NB8 copies of the two steps and one out of it (a loop over blocks with a switch inside cost six taken
+            // branches per block -- twice the matrix instructions' own time).  A block covered in part (at most one at either end) is
+            // copied out and multiplied with the rows outside zeroed (both of its steps: a lane's rows are 8 kb + 2 fk + j).
+            auto two_steps = [&](const d2u (&c)[NOP]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    double a[NOP];
+#pragma unroll
+                    for (int b = 0; b < NOP; ++b) a[b] = c[b][j];
+                    if constexpr (ACC2) {
+                        if (j == 1) mult_into(accB, a, 0.0);
+                        else mult(a, 0.0);
+                    } else {
+                        mult(a, 0.0);
+                    }
+                }
+            };
+            // A block the segment covers in part (at most one at either end) is copied out -- a switch over the block index: moves of
+            // operand registers only --, the rows outside the segment zeroed, and multiplied: ONE copy of that code in a loop of two.  The
+            // blocks it covers as a whole, [f0, f1), are multiplied straight from their registers by NB8 predicated copies of the two steps
+            // (if-then without else: the accumulators stay where they are on either path.  A run of the same copies entered by a switch
+            // and left by `break`s came back from the compiler with every accumulator moved between two register sets at each block
+            // boundary, behind an s_nop that drains the matrix pipe: 170 instead of 100 clk per step.)
+            auto partial = [&](int kb) __attribute__((always_inline)) {
+                d2u c8[NOP];
+#define PDS_GM_CASE(K)                                                                       \
+    case K:                                                                                  \
+        _Pragma("unroll") for (int b = 0; b < NOP; ++b) c8[b] = CUR[K < NB8 ? K : 0][b];    \
+        break;
+                switch (kb) {
+                    PDS_GM_CASE(0) PDS_GM_CASE(1) PDS_GM_CASE(2) PDS_GM_CASE(3) PDS_GM_CASE(4) PDS_GM_CASE(5) PDS_GM_CASE(6)
+                    default:
+#pragma unroll
+                        for (int b = 0; b < NOP; ++b) c8[b] = CUR[NB8 - 1][b];
+                        break;
+                }
+#undef PDS_GM_CASE
+                const int rr = 8 * kb + 2 * fk;
+                const bool in0 = rr >= lo && rr < hi, in1 = rr + 1 >= lo && rr + 1 < hi;
+#pragma unroll
+                for (int b = 0; b < NOP; ++b) {
+                    c8[b][0] = in0 ? c8[b][0] : 0.0;
+                    c8[b][1] = in1 ? c8[b][1] : 0.0;
+                }
+                two_steps(c8);
+            };
+            const int f0 = (lo + 7) >> 3, f1 = hi >> 3;
+            const int pk0 = (f0 > f1 || (lo & 7)) ? lo >> 3 : ((hi & 7) ? hi >> 3 : -1);
+            const int pk1 = (f0 <= f1 && (lo & 7) && (hi & 7)) ? hi >> 3 : -1;
+            PDS_MT(tp13);
+            for (int t = 0; t < 2; ++t) {
+                const int kb = t == 0 ? pk0 : pk1;
+                if (kb < 0) break;
+                partial(kb);
+            }
+            PDS_MADD(13, tp13);
+            PDS_MT(tp12);
+#pragma unroll
+            for (int K = 0; K < NB8; ++K)
+                if (K >= f0 && K < f1) two_steps(CUR[K]);
+            PDS_MADD(12, tp12);
+            rows_in_acc += hi - lo;
+            return;
+        }
         auto masked = [&](int s) __attribute__((always_inline)) {
             const int rr = 4 * s + fk;
             const bool in = rr >= lo && rr < hi;
@@ -535,7 +690,12 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
 #pragma unroll
                 for (int b = 0; b < NOP; ++b) an[b] = 0.0;
                 if (s + 1 < MD::NS) fetch(s + 1, an, ykn);
-                mult(a, yk);
+                if constexpr (ACC2) {
+                    if (s & 1) mult_into(accB, a, yk);
+                    else mult(a, yk);
+                } else {
+                    mult(a, yk);
+                }
 #pragma unroll
                 for (int b = 0; b < NOP; ++b) a[b] = an[b];
                 yk = ykn;
@@ -567,7 +727,13 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
         rows_in_acc += hi - lo;
     };
     // the accumulated rows of group g -> a record at M (plain stores, or atomics into a zeroed record that other waves add to)
+    // (DIRECT: the lane terms of the record / slot addresses pass through an empty asm -- as loop invariants every one of them held a
+    // register for the whole stream, and the streaming wave's two operand sets leave none: spilled, they were reloaded in front of
+    // `s_waitcnt vmcnt(0)` behind the next half-tile's loads)
     auto put_record = [&](double* M, bool plain) __attribute__((always_inline)) {
+        int l0 = fi, l1 = fk, l2 = qb, l3 = qj;
+        if constexpr (DIRECT) asm volatile("" : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3));
+        const int fi = l0, fk = l1, qb = l2, qj = l3;
         auto put = [&](int64_t idx, double v) __attribute__((always_inline)) {
             if (plain) M[idx] = v;
             else if (v != 0.0) unsafeAtomicAdd(M + idx, v);
@@ -647,7 +813,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
             typedef __attribute__((address_space(3))) double* lds_dp;
             constexpr int SS = SPPC + 2;                                   // doubles per column of the scratch
             constexpr bool ONE_TRIP = SPPC * SS * 8 <= kMidSolveScratch;   // all SPPC columns at once (up to 24 features)
-            lds_dp S = (lds_dp)(sm + MD::LDS_BYTES);
+            lds_dp S = (lds_dp)(sm + IMG);
             const int t = lane & 15;
             double vx0 = xy[0], vx1 = xy[1], vc0 = cs[0], vc1 = cs[1], vys = ys;
             vx0 += __shfl_xor(vx0, 16); vx0 += __shfl_xor(vx0, 32);
@@ -734,17 +900,23 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     double st_x0 = 0.0, st_x1 = 0.0, st_c0 = 0.0, st_c1 = 0.0, st_nn = 0.0, st_ys = 0.0;
     int64_t st_g = 0;
     bool stashed = false;
-    auto slot_free = [&]() __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane((int)FL[1]) == (int)pseq; };
+    auto slot_free = [&]() __attribute__((always_inline)) {
+        return (unsigned)((int)pseq - __builtin_amdgcn_readfirstlane((int)FL[1])) < (unsigned)NSLOT;
+    };
     auto publish_group = [&](const d4 (&A)[NPAIR], double vx0, double vx1, double vc0, double vc1, double nn, double vys, int64_t gid)
                              __attribute__((always_inline)) {
         if constexpr (PAIRED) {
             typedef __attribute__((address_space(3))) double* lds_dp;
             using PK = MidPacked<SPPC, YC>;
-            lds_dp S = (lds_dp)(sm + MD::LDS_BYTES);
+            const lds_dp S = (lds_dp)(sm + IMG + (DIRECT ? (int)(pseq % NSLOT) * kMidSolveScratch : 0));
+            if (debug & 16) return;
             PDS_MT(tw);
             while (!slot_free()) __builtin_amdgcn_s_sleep(1);
             PDS_MADD(4, tw);
             PDS_MT(tpb);
+            int l0 = fi, l1 = fk, l2 = qb, l3 = qj;
+            if constexpr (DIRECT) asm volatile("" : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3));
+            const int fi = l0, fk = l1, qb = l2, qj = l3;
             if constexpr (NQ != 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -801,7 +973,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     // STASH2 (up to 24 features, where the streaming wave has the registers): TWO spare sets -- a solve of four (17 600 ticks at 17 features)
     // outlasts a group (10 800) and the slot + one set did not always absorb it: the streaming wave stood 9.6 % of its time in front of a
     // full slot.  A two-deep FIFO in registers: set A / set B, `a_old` says which is the older; drained whenever the slot is free.
-    constexpr bool STASH2 = PAIRED && YC && SPPC == 24;
+    constexpr bool STASH2 = PAIRED && YC && SPPC == 24 && !DIRECT;  // (the direct form has the registers for one spare set)
     d4 st_b[STASH2 ? NPAIR : 1];
     int64_t st_gb = 0;
     int nst = 0;
@@ -847,6 +1019,8 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     auto hand_over = [&]() __attribute__((always_inline)) {
         if constexpr (STASH2) {
             hand_over2();
+        } else if constexpr (DIRECT) {  // (the ring is the queue: the stream stands still only in front of NSLOT unsolved groups)
+            publish_group(acc, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, g);
         } else if constexpr (PAIRED) {
             double vx0 = xy[0], vx1 = xy[1], vc0 = cs[0], vc1 = cs[1], vys = ys;
             if constexpr (!YC) {
@@ -873,6 +1047,10 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     // the wave's first does --, the group left open behind the loop is not.
     bool started_here = gs >= W0;
     auto flush = [&](bool whole) __attribute__((always_inline)) {
+        if constexpr (ACC2) {
+#pragma unroll
+            for (int t = 0; t < NPAIR; ++t) acc[t] += accB[t];
+        }
         if (debug & 2) {  // (timing experiment: no record stores)
             zero_acc();
             rows_in_acc = 0;
@@ -908,24 +1086,40 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     };
     // ---- stream the half-tiles
     int64_t pos = W0;
-    fetch_tile(0, h0);
+    if constexpr (DIRECT) issue_direct(h0);
+    else fetch_tile(0, h0);
     for (int64_t h = h0; h < h1; ++h) {
         const int buf = (int)((h - h0) & 1);
         PDS_MT(p0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // half-tile h has landed (and this wave's record stores are out)
-        PDS_WAVE_LDS_SYNC();
+        if constexpr (DIRECT) {  // half-tile h has landed: it becomes the set the walk reads (the compiler's own wait sits in front of the moves)
+#pragma unroll
+            for (int k = 0; k < NB8; ++k)
+#pragma unroll
+                for (int b = 0; b < NOP; ++b) {
+                    CUR[k][b] = NXT[k][b];
+                    // (a definition the compiler cannot see through: without it the first half-tile is loaded into CUR directly, CUR counts as
+                    // "maybe in flight" in the whole loop, and every step of the walk waits for the NEXT half-tile's loads)
+                    asm volatile("" : "+v"(CUR[k][b]));
+                }
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // half-tile h has landed (and this wave's record stores are out)
+            PDS_WAVE_LDS_SYNC();
+        }
         PDS_MADD(0, p0);
         // (a waiting group goes out as soon as the solving wave has emptied the slot, not only when the next group ends: without this look
         // per half-tile the 17-feature kernel is 6 % slower)
         PDS_MT(p11);
         if constexpr (STASH2) {
             if (nst > 0) drain_free();
-        } else if constexpr (PAIRED) {
+        } else if constexpr (PAIRED && !DIRECT) {
             if (stashed && slot_free()) flush_stash();
         }
         PDS_MADD(11, p11);
         PDS_MT(p1);
-        if (h + 1 < h1) fetch_tile(buf ^ 1, h + 1);  // (the other image was consumed one iteration ago)
+        if (h + 1 < h1) {
+            if constexpr (DIRECT) issue_direct(h + 1);
+            else fetch_tile(buf ^ 1, h + 1);  // (the other image was consumed one iteration ago)
+        }
         PDS_MADD(1, p1);
         const int64_t R0 = h * HR;
         const int64_t tile_end = R0 + HR < W1 ? R0 + HR : W1;
@@ -972,10 +1166,10 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
         flush_stash();
         if constexpr (STASH2)
             while (nst > 0) drain_one();  // (publish_group waits for the slot)
-        while ((pseq & 3u) != 0u) {  // pad the last batch: the slot's contents once more (a valid system), marked as discarded
+        while ((pseq & 3u) != 0u && !(debug & 16)) {  // pad the last batch: the slot's contents once more (a valid system), marked as discarded
             typedef __attribute__((address_space(3))) double* lds_dp;
             while (!slot_free()) __builtin_amdgcn_s_sleep(1);
-            if (lane == 0) ((lds_dp)(sm + MD::LDS_BYTES))[MidPacked<SPPC, YC>::GID] = __longlong_as_double(-1ll);
+            if (lane == 0) ((lds_dp)(sm + IMG + (DIRECT ? (int)(pseq % NSLOT) * kMidSolveScratch : 0)))[MidPacked<SPPC, YC>::GID] = __longlong_as_double(-1ll);
             PDS_WAVE_LDS_SYNC();
             ++pseq;
             FL[0] = pseq;
@@ -1180,8 +1374,8 @@ int launch_grouped_mid_fused(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, 
             hipLaunchKernelGGL(kern, dim3((unsigned)waves), dim3(64), lds, ctx->stream, dc.d_ptrs, p, n_frame, d_off, n_groups, (double*)nullptr, debug, sa);
         };
         bool paired_lds_ok = true;
-        auto launch_paired = [&](auto kern) {
-            constexpr int plds = 4 * kMidPairLds<2>;
+        auto launch_paired_c = [&](auto kern, auto direct_c) {
+            constexpr int plds = 4 * kMidPairLds<2, decltype(direct_c)::value>;
             // (per call, not once per process: the attribute belongs to the function ON THE CURRENT DEVICE, and a process may drive several)
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, plds) != hipSuccess) {
                 (void)hipGetLastError();
@@ -1191,10 +1385,23 @@ int launch_grouped_mid_fused(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, 
             hipLaunchKernelGGL(kern, dim3((unsigned)(waves / 4)), dim3(512), plds, ctx->stream, dc.d_ptrs, p, n_frame, d_off, n_groups, (double*)nullptr,
                                debug, sa);
         };
+        auto launch_paired = [&](auto kern) { launch_paired_c(kern, std::false_type{}); };
         if (paired) {
             const char* yc_env = dev_env("PDS_GROUPED_MID_YC");  // (development: '0' keeps the side sums of the 31 / 32-feature form)
             const bool yc = !F64 || !(yc_env && yc_env[0] == '0');  // (f32 frames have the ones / target column form only)
             const char* nq_env = dev_env("PDS_GROUPED_MID_QUAD");  // (development: '0' keeps the 16 x 16 x 4 form of the second block)
+            // the direct form (f64 frames, up to 30 features: PDS_MID_DIRECT, on by default; PDS_GROUPED_MID_DIRECT=0 in development builds)
+            const char* dir_env = dev_env("PDS_GROUPED_MID_DIRECT");
+            const bool direct = F64 && PDS_MID_DIRECT && yc && p <= 30 && !(dir_env && dir_env[0] == '0');
+            if constexpr (F64) {
+                if (direct) {
+                    if (p <= 18) launch_paired_c(grouped_mid_stream_kernel<2, 24, true, true, 1, T, true>, std::true_type{});
+                    else if (p <= 24) launch_paired_c(grouped_mid_stream_kernel<2, 24, true, true, 0, T, true>, std::true_type{});
+                    else launch_paired_c(grouped_mid_stream_kernel<2, 32, true, true, 0, T, true>, std::true_type{});
+                }
+            }
+            if (direct) {
+            } else
             if (p <= 18 && yc && !(nq_env && nq_env[0] == '0')) launch_paired(grouped_mid_stream_kernel<2, 24, true, true, 1, T>);
             else if (p <= 22 && yc && !(nq_env && nq_env[0] == '0')) launch_paired(grouped_mid_stream_kernel<2, 24, true, true, 2, T>);
             else if (p <= 24 && (yc || !F64)) launch_paired(grouped_mid_stream_kernel<2, 24, true, true, 0, T>);

@@ -15,9 +15,9 @@ y = torch.randn(N, dtype=torch.float64, device=dev, generator=gen)
 off = np.arange(0, N + 1, R, dtype=np.int64)
 so = _lib.load()
 buf = (C.c_ulonglong * 16)()
-names = {0: "stream: waiting for the half-tile", 1: "stream: next half-tile's loads issued", 2: "stream: matrix steps (consume)", 3: "stream: finished group (hand-over, side records)",
+names = {0: "stream: waiting for the half-tile", 1: "stream: next half-tile's loads issued", 2: "stream: matrix steps (consume)", 13: "   direct: partial blocks", 12: "   direct: run of whole blocks", 3: "stream: finished group (hand-over, side records)",
          4: "   of it: waiting for the slot", 5: "   publish body (all call sites)", 6: "stream: group advance (offsets)", 11: "stream: per-half-tile look at the stash", 7: "stream wave total", 8: "solver: waiting for a group", 9: "solver: slot -> pending registers", 10: "solver: solve of four", 15: "solver wave total"}
-for P in (17, 24, 32):
+for P in [int(v) for v in os.environ.get("P", "17,24,32").split(",")]:
     f = lambda: pds.lin_reg_by(*xs[:P], target=y, group_offsets=off, ctx=ctx)
     for _ in range(2): f()
     torch.cuda.synchronize(); so.pds_debug_mid_phase_cycles(buf, 1)
