@@ -98,9 +98,10 @@ struct MidPacked {
 };
 // DIRECT: the LDS the tile images no longer take holds a RING of slots between the streaming and the solving wave -- a finished group waits
 // there, not in a spare register set of the streaming wave (which has none left beside its two operand sets)
-constexpr int kMidDirectSlots = 4;
+constexpr int kMidDirectSlots = 8;       // two batches of four: the solving wave takes FOUR groups at once (one per 16-lane row, one read per value)
+constexpr int kMidDirectSlotBytes = 4240;  // the upper triangle of 32 columns + the group id, rounded up to 16 bytes
 template <int NBLK, bool DIRECT = false>
-constexpr int kMidPairLds = DIRECT ? kMidDirectSlots * kMidSolveScratch + 64  // the direct form: a ring of slots + flag words
+constexpr int kMidPairLds = DIRECT ? kMidDirectSlots * kMidDirectSlotBytes + 64  // the direct form: a ring of slots + flag words
                                       : MidDims<NBLK>::LDS_BYTES + kMidSolveScratch + 64;  // tile images + scratch + flag words of one pair of waves (PAIRED)
 // DIRECT: the ones column and the padding columns of the second operand block are loaded like every other column -- from 64 ones and
 // 64 zeros, with a lane stride of nothing per half-tile (no selects, no partially active load instructions)
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     static_assert(ES == 8 || PAIRED, "f32 frames: the paired form");
     static_assert(SPPC == 0 || NBLK == 2, "the in-wave solve serves two tile columns");
     static_assert(!PAIRED || SPPC > 0, "pairs exist for the in-kernel solve");
-    static_assert(!PAIRED || MidPacked<SPPC ? SPPC : 1, YC>::COUNT * 8 <= kMidSolveScratch, "the slot holds one group");
+    static_assert(!PAIRED || MidPacked<SPPC ? SPPC : 1, YC>::COUNT * 8 <= (DIRECT ? kMidDirectSlotBytes : kMidSolveScratch), "the slot holds one group");
     static_assert(!YC || PAIRED, "the ones / target columns are the paired form's");
     static_assert(NQ == 0 || ((NQ == 1 || NQ == 2) && YC && NBLK == 2), "the quad form: ones and target inside the quads");
     static_assert(!DIRECT || (PAIRED && YC && ES == 8 && NBLK == 2 && NQ <= 1), "the direct form: f64 frames, ones / target as columns, two operand pieces");
@@ -173,8 +174,8 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     const int wv = PAIRED ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0, pairi = wv & 3;
     const bool consumer = PAIRED && wv >= 4;
     lds_c sm = (lds_c)gmid_lds + (PAIRED ? pairi * kMidPairLds<NBLK, DIRECT> : 0);
-    constexpr int NSLOT = DIRECT ? kMidDirectSlots : 1;
-    const lds_flag FL = (lds_flag)(sm + IMG + NSLOT * kMidSolveScratch);  // [0] trips published, [1] trips taken, [2] stream finished
+    constexpr int NSLOT = DIRECT ? kMidDirectSlots : 1, SLOTB = DIRECT ? kMidDirectSlotBytes : kMidSolveScratch;
+    const lds_flag FL = (lds_flag)(sm + IMG + NSLOT * SLOTB);  // [0] trips published, [1] trips taken, [2] stream finished
     const int64_t wave = PAIRED ? (int64_t)blockIdx.x * 4 + pairi : (int64_t)blockIdx.x, nwaves = PAIRED ? (int64_t)gridDim.x * 4 : (int64_t)gridDim.x;
     const int64_t row_begin = off[0], row_end = off[n_groups];
     if (row_end <= row_begin) return;
@@ -315,12 +316,14 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
             };
             auto took = [&]() __attribute__((always_inline)) {
                 PDS_WAVE_LDS_SYNC();  // (the values are in registers)
-                ++cseq;
+                cseq += DIRECT ? 4 : 1;
                 FL[1] = cseq;
             };
             auto take = [&](auto rm) __attribute__((always_inline)) {
                 constexpr int ROW = decltype(rm)::value;
-                const lds_dp S = (lds_dp)(sm + IMG + (DIRECT ? (int)(cseq % NSLOT) * kMidSolveScratch : 0));  // (DIRECT: the ring's slot of this sequence number)
+                // DIRECT: FOUR groups at once -- row R of the wave reads slot (cseq + R) mod NSLOT (cseq is a multiple of four there), every
+                // lane's read lands in its own row: no row-masked moves, a quarter of the reads per group
+                const lds_dp S = (lds_dp)(sm + IMG + (DIRECT ? ((int)(cseq & (NSLOT - 1)) + (lane >> 4)) * SLOTB : 0));
                 auto put = [&](double& dst, double v) __attribute__((always_inline)) {
                     if constexpr (ROW == 0) dst = v;
                     else dst = __builtin_amdgcn_update_dpp(dst, v, 0xE4 /*quad_perm:[0,1,2,3]*/, 1 << ROW, 0xf, false);
@@ -387,6 +390,31 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
             auto next_group = [&]() __attribute__((always_inline)) {
                 while (FL[0] == cseq) __builtin_amdgcn_s_sleep(1);
             };
+            if constexpr (DIRECT) {
+                for (;;) {
+                    PDS_MT(c0);
+                    bool more = true;
+                    for (;;) {  // four groups published (the streaming wave pads its last batch), or the stream finished with nothing left
+                        const unsigned d = FL[2], f = FL[0];  // (in this order: after `done` nothing is published)
+                        if ((unsigned)(f - cseq) >= 4u) break;
+                        if (d) {
+                            more = false;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    PDS_MADD(8, c0);
+                    if (!more) break;
+                    PDS_MT(c1);
+                    take(std::integral_constant<int, 0>{});
+                    PDS_MADD(9, c1);
+                    npend = 4;
+                    PDS_MT(c8);
+                    if (!(debug & 4)) solve_pending();
+                    PDS_MADD(10, c8);
+                }
+                return;
+            }
             for (;;) {
                 PDS_MT(c0);
                 if (!wait_group()) break;
@@ -908,7 +936,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
         if constexpr (PAIRED) {
             typedef __attribute__((address_space(3))) double* lds_dp;
             using PK = MidPacked<SPPC, YC>;
-            const lds_dp S = (lds_dp)(sm + IMG + (DIRECT ? (int)(pseq % NSLOT) * kMidSolveScratch : 0));
+            const lds_dp S = (lds_dp)(sm + IMG + (DIRECT ? (int)(pseq % NSLOT) * SLOTB : 0));
             if (debug & 16) return;
             PDS_MT(tw);
             while (!slot_free()) __builtin_amdgcn_s_sleep(1);
@@ -1169,7 +1197,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
         while ((pseq & 3u) != 0u && !(debug & 16)) {  // pad the last batch: the slot's contents once more (a valid system), marked as discarded
             typedef __attribute__((address_space(3))) double* lds_dp;
             while (!slot_free()) __builtin_amdgcn_s_sleep(1);
-            if (lane == 0) ((lds_dp)(sm + IMG + (DIRECT ? (int)(pseq % NSLOT) * kMidSolveScratch : 0)))[MidPacked<SPPC, YC>::GID] = __longlong_as_double(-1ll);
+            if (lane == 0) ((lds_dp)(sm + IMG + (DIRECT ? (int)(pseq % NSLOT) * SLOTB : 0)))[MidPacked<SPPC, YC>::GID] = __longlong_as_double(-1ll);
             PDS_WAVE_LDS_SYNC();
             ++pseq;
             FL[0] = pseq;
