@@ -11,20 +11,8 @@
 #ifndef PDS_MID_DIRECT
 #define PDS_MID_DIRECT 1
 #endif
-// the direct form's loads: two consecutive instructions read the two halves of the same sixteen 128-byte lines
-// the next half-tile's loads dealt out between the blocks of the one being walked (inline asm: see PDS_GM_ISSUE_BLOCK).  Built, bit-equal,
-// SLOWER (17 features 3.42 -> 4.25 ms, 30: 5.5 -> 6.35): block K's load is issued when block K has been multiplied and waited for at the top of
-// the next half-tile -- the last blocks' loads have no time to land.  Off; what it would take is one register set with the wait in front of
-// every block (profiles/r06_grouped_mid_direct.txt).
-#ifndef PDS_MID_DIRECT_INTER
-#define PDS_MID_DIRECT_INTER 0
-#endif
-#ifndef PDS_MID_DIRECT_DYNIDX
-#define PDS_MID_DIRECT_DYNIDX 0
-#endif
-#ifndef PDS_MID_DIRECT_ACC2
-#define PDS_MID_DIRECT_ACC2 0
-#endif
+// the direct form's loads: two consecutive instructions read the two halves of the same sixteen 128-byte lines -- as non-temporal loads
+// (-DPDS_MID_DIRECT_NT) the second one misses again: 30 features 6.4 -> 7.5 ms (profiles/r06_grouped_mid_direct.txt)
 #ifdef PDS_MID_DIRECT_NT
 #define PDS_MID_DIRECT_LOAD(q) __builtin_nontemporal_load(q)
 #else
@@ -464,11 +452,6 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
 #endif
             return;
         }
-#ifdef PDS_MID_STREAM_PRIO
-    // the streaming wave goes first where both waves of the SIMD want the FP64 unit (its matrix instructions against the solving wave's
-    // vector instructions: DESIGN 4.0) -- the solving wave has the slack
-    if constexpr (PAIRED) __builtin_amdgcn_s_setprio(PDS_MID_STREAM_PRIO);
-#endif
     const int g_ = lane / MD::GL, piece = lane % MD::GL;
     const T* cbase[16];
     unsigned valid = 0;
@@ -499,16 +482,8 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
         else load_guarded(buf, h * HR);
     };
     d4 acc[NPAIR];
-    // DIRECT: a second accumulator set for the second step of every block -- two chains of dependent matrix instructions instead of one
-    // (folded into the first when the group is finished)
-    constexpr bool ACC2 = PAIRED && YC && PDS_MID_DIRECT_ACC2;
-    d4 accB[ACC2 ? NPAIR : 1];
     double xy[NBLK], cs[NBLK], yy = 0.0, ys = 0.0;
     auto zero_acc = [&]() __attribute__((always_inline)) {
-        if constexpr (ACC2) {
-#pragma unroll
-            for (int t = 0; t < NPAIR; ++t) accB[t] = d4{0.0, 0.0, 0.0, 0.0};
-        }
 #pragma unroll
         for (int t = 0; t < NPAIR; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -545,20 +520,10 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
             dreal[b] = real;
         }
     }
-    // INTER: block K of the NEXT half-tile is requested as soon as block K of this one has been multiplied to its end -- the load
-    // instructions (50 - 90 clk of the wave's time each) sit between matrix instructions that run meanwhile instead of in one burst in front
-    // of the walk.  The compiler's own bookkeeping of loads in flight cannot follow loads issued under data-dependent control flow (it would
-    // wait for all of them at the next use of ANY register it thinks may be in flight), so these are inline asm it does not see; the wait is
-    // ours: `s_waitcnt vmcnt(0)` at the top of the half-tile loop, with every register of the set passing through that statement so that no
-    // use can move in front of it.  (Nothing reads or moves NXT between the loads and that wait: tools/isa_blocks.py on the listing.)
-    constexpr bool INTER = DIRECT && PDS_MID_DIRECT_INTER;
-    bool inter = false;  // this half-tile's walk issues the next one's loads
-    // (a macro, not a lambda over the block index: inline asm operands that name captured arrays do not compile inside a generic lambda)
-#define PDS_GM_ISSUE_BLOCK(K)                                                                                                       \
-    do {                                                                                                                            \
-        _Pragma("unroll") for (int b_ = 0; b_ < NOP; ++b_)                                                                          \
-            asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(NXT[K][b_]) : "v"(dcp[b_]), "n"(64 * (K)));            \
-    } while (0)
+    // (Measured and not kept, profiles/r06_grouped_mid_direct.txt: the next half-tile's loads dealt out between the blocks of this one --
+    // inline asm loads, the wait at the top of the next half-tile: the last blocks' loads have no time to land, 17 features 3.42 -> 4.25 ms;
+    // ONE register set refilled in place with a wait in front of every block: the compiler keeps such a set in two places and moves it
+    // between them wherever it likes -- a move of a register whose load is in flight reads what was there before.)
     auto advance_direct = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int b = 0; b < NOP; ++b)
@@ -567,15 +532,10 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     auto issue_direct = [&](int64_t h) __attribute__((always_inline)) {
         if constexpr (DIRECT) {
             if ((h + 1) * HR <= n_frame) {
-                if constexpr (INTER) {  // (the compiler must never count a register of the set as in flight: see PDS_GM_ISSUE_BLOCK)
-                    PDS_GM_ISSUE_BLOCK(0); PDS_GM_ISSUE_BLOCK(1); PDS_GM_ISSUE_BLOCK(2); PDS_GM_ISSUE_BLOCK(3);
-                    PDS_GM_ISSUE_BLOCK(4); PDS_GM_ISSUE_BLOCK(5); PDS_GM_ISSUE_BLOCK(6); PDS_GM_ISSUE_BLOCK(7);
-                } else {
 #pragma unroll
-                    for (int k = 0; k < NB8; ++k)
+                for (int k = 0; k < NB8; ++k)
 #pragma unroll
-                        for (int b = 0; b < NOP; ++b) NXT[k][b] = PDS_MID_DIRECT_LOAD(reinterpret_cast<gptr<d2u>>(dcp[b] + 64 * k));
-                }
+                    for (int b = 0; b < NOP; ++b) NXT[k][b] = PDS_MID_DIRECT_LOAD(reinterpret_cast<gptr<d2u>>(dcp[b] + 64 * k));
             } else {  // the frame's last, partial half-tile: row by row, rows beyond the frame are zeros (nobody multiplies them)
 #pragma unroll
                 for (int k = 0; k < NB8; ++k)
@@ -588,12 +548,6 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
                             if (!dreal[b] || row < n_frame) v = *reinterpret_cast<gptr<double>>(dcp[b] + 64 * k + 8 * j);
                             NXT[k][b][j] = v;
                         }
-                if constexpr (INTER) {  // (waited for on the spot, once per frame: these loads the compiler sees)
-#pragma unroll
-                    for (int k = 0; k < NB8; ++k)
-#pragma unroll
-                        for (int b = 0; b < NOP; ++b) asm volatile("" : "+v"(NXT[k][b]));
-                }
             }
             advance_direct();
         }
@@ -632,7 +586,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
             if constexpr (!YC) yk = (double)PDS_GM_LDST(base + MD::Y_OFF + roff);
             else yk = 0.0;
         };
-        auto mult_into = [&](d4 (&acc)[NPAIR], const double (&a)[NOP], double yk) __attribute__((always_inline)) {
+        auto mult = [&](const double (&a)[NOP], double yk) __attribute__((always_inline)) {
             if constexpr (NQ == 1) {
                 acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], a[0], acc[0], 0, 0, 0);
                 acc[1][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[0], a[1], acc[1][0], 0, 0, 0);
@@ -665,24 +619,15 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
                 ys += yk;
             }
         };
-        auto mult = [&](const double (&a)[NOP], double yk) __attribute__((always_inline)) { mult_into(acc, a, yk); };
         if constexpr (DIRECT) {
-            // Blocks of eight rows.  The blocks the segment covers as a whole, [f0, f1), are multiplied straight from their registers: ONE
-            // jump into a run of NB8 copies of the two steps and one out of it (a loop over blocks with a switch inside cost six taken
-            // branches per block -- twice the matrix instructions' own time).  A block covered in part (at most one at either end) is
-            // copied out and multiplied with the rows outside zeroed (both of its steps: a lane's rows are 8 kb + 2 fk + j).
+            // Blocks of eight rows; a lane's rows in block kb are 8 kb + 2 fk + j, step j of the block multiplies row j of every lane.
             auto two_steps = [&](const d2u (&c)[NOP]) __attribute__((always_inline)) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     double a[NOP];
 #pragma unroll
                     for (int b = 0; b < NOP; ++b) a[b] = c[b][j];
-                    if constexpr (ACC2) {
-                        if (j == 1) mult_into(accB, a, 0.0);
-                        else mult(a, 0.0);
-                    } else {
-                        mult(a, 0.0);
-                    }
+                    mult(a, 0.0);
                 }
             };
             // A block the segment covers in part (at most one at either end) is copied out -- a switch over the block index: moves of
@@ -725,18 +670,9 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
             }
             PDS_MADD(13, tp13);
             PDS_MT(tp12);
-            const int i0 = lo >> 3, i1 = hi >> 3;  // the blocks this segment reaches the end of
-#define PDS_GM_BLOCK(K)                                          \
-    do {                                                         \
-        if (K >= f0 && K < f1) two_steps(CUR[K]);                \
-        if constexpr (INTER) {                                   \
-            if (inter && K >= i0 && K < i1) PDS_GM_ISSUE_BLOCK(K); \
-        }                                                        \
-    } while (0)
-            static_assert(NB8 == 8, "the blocks are written out for eight");
-            PDS_GM_BLOCK(0); PDS_GM_BLOCK(1); PDS_GM_BLOCK(2); PDS_GM_BLOCK(3);
-            PDS_GM_BLOCK(4); PDS_GM_BLOCK(5); PDS_GM_BLOCK(6); PDS_GM_BLOCK(7);
-#undef PDS_GM_BLOCK
+#pragma unroll
+            for (int K = 0; K < NB8; ++K)
+                if (K >= f0 && K < f1) two_steps(CUR[K]);
             PDS_MADD(12, tp12);
             rows_in_acc += hi - lo;
             return;
@@ -762,12 +698,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
 #pragma unroll
                 for (int b = 0; b < NOP; ++b) an[b] = 0.0;
                 if (s + 1 < MD::NS) fetch(s + 1, an, ykn);
-                if constexpr (ACC2) {
-                    if (s & 1) mult_into(accB, a, yk);
-                    else mult(a, yk);
-                } else {
-                    mult(a, yk);
-                }
+                mult(a, yk);
 #pragma unroll
                 for (int b = 0; b < NOP; ++b) a[b] = an[b];
                 yk = ykn;
@@ -1119,10 +1050,6 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     // the wave's first does --, the group left open behind the loop is not.
     bool started_here = gs >= W0;
     auto flush = [&](bool whole) __attribute__((always_inline)) {
-        if constexpr (ACC2) {
-#pragma unroll
-            for (int t = 0; t < NPAIR; ++t) acc[t] += accB[t];
-        }
         if (debug & 2) {  // (timing experiment: no record stores)
             zero_acc();
             rows_in_acc = 0;
@@ -1164,12 +1091,6 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
         const int buf = (int)((h - h0) & 1);
         PDS_MT(p0);
         if constexpr (DIRECT) {  // half-tile h has landed: it becomes the set the walk reads (the compiler's own wait sits in front of the moves)
-            if constexpr (INTER) {
-                static_assert(NOP == 2, "the wait below names the sixteen registers of a set");
-#define PDS_N2(k) "+v"(NXT[k][0]), "+v"(NXT[k][1])
-                asm volatile("s_waitcnt vmcnt(0)" : PDS_N2(0), PDS_N2(1), PDS_N2(2), PDS_N2(3), PDS_N2(4), PDS_N2(5), PDS_N2(6), PDS_N2(7));
-#undef PDS_N2
-            }
 #pragma unroll
             for (int k = 0; k < NB8; ++k)
 #pragma unroll
@@ -1194,11 +1115,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
         }
         PDS_MADD(11, p11);
         PDS_MT(p1);
-        if constexpr (INTER) {
-            if (inter) advance_direct();  // (the last walk's requests were made from the old addresses)
-            inter = h + 1 < h1 && (h + 2) * HR <= n_frame;
-        }
-        if (h + 1 < h1 && !inter) {
+        if (h + 1 < h1) {
             if constexpr (DIRECT) issue_direct(h + 1);
             else fetch_tile(buf ^ 1, h + 1);  // (the other image was consumed one iteration ago)
         }
@@ -1215,15 +1132,6 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
         const int tile_n = (int)(tile_end - R0);
         int posr = (int)(pos - R0);
         int ger = rel_end(ge);
-        if constexpr (INTER) {
-            if (inter && posr >= 8) {  // (the wave's first half-tile: the blocks in front of its first row are never walked)
-                const int nb = posr >> 3;
-#define PDS_GM_EARLY(K) \
-    if (K < nb) PDS_GM_ISSUE_BLOCK(K)
-                PDS_GM_EARLY(0); PDS_GM_EARLY(1); PDS_GM_EARLY(2); PDS_GM_EARLY(3); PDS_GM_EARLY(4); PDS_GM_EARLY(5); PDS_GM_EARLY(6);
-#undef PDS_GM_EARLY
-            }
-        }
         while (posr < tile_n) {
             const int seg = ger < tile_n ? ger : tile_n;
             PDS_MT(p2);
