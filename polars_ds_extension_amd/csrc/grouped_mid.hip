@@ -94,9 +94,10 @@ struct MidPacked {
 // DIRECT: the LDS the tile images no longer take holds a RING of slots between the streaming and the solving wave -- a finished group waits
 // there, not in a spare register set of the streaming wave (which has none left beside its two operand sets)
 constexpr int kMidDirectSlots = 8;       // two batches of four: the solving wave takes FOUR groups at once (one per 16-lane row, one read per value)
-constexpr int kMidDirectSlotBytes = 4240;  // the upper triangle of 32 columns + the group id, rounded up to 16 bytes
+constexpr int kMidDirectSlotBytes = 4768;  // the upper triangle of 32 columns, X'y, the column sums, [rows, sum y], the group id: to 16 bytes
+constexpr int kMidDirectYBytes = 64 * 8 + 16;  // one image of the target's half-tile (31 / 32 features: the target does not fit the operand blocks)
 template <int NBLK, bool DIRECT = false>
-constexpr int kMidPairLds = DIRECT ? kMidDirectSlots * kMidDirectSlotBytes + 64  // the direct form: a ring of slots + flag words
+constexpr int kMidPairLds = DIRECT ? kMidDirectSlots * kMidDirectSlotBytes + 2 * kMidDirectYBytes + 64  // the direct form: a ring of slots, two target images, flag words
                                       : MidDims<NBLK>::LDS_BYTES + kMidSolveScratch + 64;  // tile images + scratch + flag words of one pair of waves (PAIRED)
 // DIRECT: the ones column and the padding columns of the second operand block are loaded like every other column -- from 64 ones and
 // 64 zeros, with a lane stride of nothing per half-tile (no selects, no partially active load instructions)
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     static_assert(!PAIRED || MidPacked<SPPC ? SPPC : 1, YC>::COUNT * 8 <= (DIRECT ? kMidDirectSlotBytes : kMidSolveScratch), "the slot holds one group");
     static_assert(!YC || PAIRED, "the ones / target columns are the paired form's");
     static_assert(NQ == 0 || ((NQ == 1 || NQ == 2) && YC && NBLK == 2), "the quad form: ones and target inside the quads");
-    static_assert(!DIRECT || (PAIRED && YC && ES == 8 && NBLK == 2 && NQ <= 1), "the direct form: f64 frames, ones / target as columns, two operand pieces");
+    static_assert(!DIRECT || (PAIRED && ES == 8 && NBLK == 2 && NQ <= 1 && (YC || SPPC == 32)), "the direct form: f64 frames, two operand pieces");
     using MD = MidDims<NBLK, ES>;
     constexpr int IMG = DIRECT ? 0 : MD::LDS_BYTES;  // bytes of tile images in front of the pair's slot
     constexpr int HR = MD::HR, GS = MD::GS, NPAIR = MD::NPAIR;
@@ -170,7 +171,8 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     const bool consumer = PAIRED && wv >= 4;
     lds_c sm = (lds_c)gmid_lds + (PAIRED ? pairi * kMidPairLds<NBLK, DIRECT> : 0);
     constexpr int NSLOT = DIRECT ? kMidDirectSlots : 1, SLOTB = DIRECT ? kMidDirectSlotBytes : kMidSolveScratch;
-    const lds_flag FL = (lds_flag)(sm + IMG + NSLOT * SLOTB);  // [0] trips published, [1] trips taken, [2] stream finished
+    constexpr int DY_OFF = IMG + NSLOT * SLOTB;  // (DIRECT without YC: the target's two images behind the ring)
+    const lds_flag FL = (lds_flag)(sm + DY_OFF + (DIRECT ? 2 * kMidDirectYBytes : 0));  // [0] trips published, [1] trips taken, [2] stream finished
     const int64_t wave = PAIRED ? (int64_t)blockIdx.x * 4 + pairi : (int64_t)blockIdx.x, nwaves = PAIRED ? (int64_t)gridDim.x * 4 : (int64_t)gridDim.x;
     const int64_t row_begin = off[0], row_end = off[n_groups];
     if (row_end <= row_begin) return;
@@ -513,9 +515,9 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
 #pragma unroll
         for (int b = 0; b < NOP; ++b) {
             const int c = NQ ? (b == 0 ? fi : 12 + 4 * b + (fi & 3)) : 16 * b + fi;  // (as opo: the piece's column in this lane)
-            const bool real = c < p || c == p + 1;                                   // a frame column (p + 1: the target); p: ones; beyond: zeros
+            const bool real = c < p || (YC && c == p + 1);                           // a frame column (YC: p + 1 = the target, p = ones); beyond: zeros
             const char* base = real ? reinterpret_cast<const char*>(cols[c < p ? c : p]) + h0 * (int64_t)(HR * 8)
-                                    : reinterpret_cast<const char*>(g_mid_direct_const + (c == p ? 0 : 64));
+                                    : reinterpret_cast<const char*>(g_mid_direct_const + ((YC && c == p) ? 0 : 64));
             dcp[b] = (gptr<char>)(base + 16 * fk);
             dreal[b] = real;
         }
@@ -548,6 +550,15 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
                             if (!dreal[b] || row < n_frame) v = *reinterpret_cast<gptr<double>>(dcp[b] + 64 * k + 8 * j);
                             NXT[k][b][j] = v;
                         }
+            }
+            if constexpr (!YC) {  // 31 / 32 features: the target rides beside the blocks -- its image of this half-tile in LDS, read per step
+                const lds_c yimg = sm + DY_OFF + (int)((h - h0) & 1) * kMidDirectYBytes;
+                if ((h + 1) * HR <= n_frame) {
+                    if (lane < HR / EPL) __builtin_amdgcn_global_load_lds((glb_ptr)(as_global(ybase) + h * HR), (lds_ptr)yimg, 16, 0, 0);
+                } else {
+                    const gptr<T> col = as_global(cols[p]);
+                    for (int r = lane; r < HR; r += 64) PDS_GM_LDST(yimg + r * ES) = h * HR + r < n_frame ? col[h * HR + r] : (T)0;
+                }
             }
             advance_direct();
         }
@@ -621,14 +632,19 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
         };
         if constexpr (DIRECT) {
             // Blocks of eight rows; a lane's rows in block kb are 8 kb + 2 fk + j, step j of the block multiplies row j of every lane.
-            auto two_steps = [&](const d2u (&c)[NOP]) __attribute__((always_inline)) {
+            const lds_c yrow = sm + DY_OFF + buf * kMidDirectYBytes + 16 * fk;  // (without YC: the lane's two target values of block kb at + 64 kb)
+            auto two_steps = [&](const d2u (&c)[NOP], mid_d2 yv) __attribute__((always_inline)) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     double a[NOP];
 #pragma unroll
                     for (int b = 0; b < NOP; ++b) a[b] = c[b][j];
-                    mult(a, 0.0);
+                    mult(a, YC ? 0.0 : yv[j]);
                 }
+            };
+            auto y_of = [&](int kb) __attribute__((always_inline)) {
+                if constexpr (YC) return mid_d2{0.0, 0.0};
+                else return *(__attribute__((address_space(3))) mid_d2*)(yrow + 64 * kb);
             };
             // A block the segment covers in part (at most one at either end) is copied out -- a switch over the block index: moves of
             // operand registers only --, the rows outside the segment zeroed, and multiplied: ONE copy of that code in a loop of two.  The
@@ -657,7 +673,10 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
                     c8[b][0] = in0 ? c8[b][0] : 0.0;
                     c8[b][1] = in1 ? c8[b][1] : 0.0;
                 }
-                two_steps(c8);
+                mid_d2 yv = y_of(kb);
+                yv[0] = in0 ? yv[0] : 0.0;
+                yv[1] = in1 ? yv[1] : 0.0;
+                two_steps(c8, yv);
             };
             const int f0 = (lo + 7) >> 3, f1 = hi >> 3;
             const int pk0 = (f0 > f1 || (lo & 7)) ? lo >> 3 : ((hi & 7) ? hi >> 3 : -1);
@@ -672,7 +691,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
             PDS_MT(tp12);
 #pragma unroll
             for (int K = 0; K < NB8; ++K)
-                if (K >= f0 && K < f1) two_steps(CUR[K]);
+                if (K >= f0 && K < f1) two_steps(CUR[K], y_of(K));
             PDS_MADD(12, tp12);
             rows_in_acc += hi - lo;
             return;
@@ -1023,7 +1042,8 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
         if constexpr (STASH2) {
             hand_over2();
         } else if constexpr (DIRECT) {  // (the ring is the queue: the stream stands still only in front of NSLOT unsolved groups)
-            publish_group(acc, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, g);
+            if constexpr (YC) publish_group(acc, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, g);
+            else publish_group(acc, rows_sum4(xy[0]), rows_sum4(xy[1]), rows_sum4(cs[0]), rows_sum4(cs[1]), (double)rows_in_acc, rows_sum4(ys), g);
         } else if constexpr (PAIRED) {
             double vx0 = xy[0], vx1 = xy[1], vc0 = cs[0], vc1 = cs[1], vys = ys;
             if constexpr (!YC) {
@@ -1091,6 +1111,10 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
         const int buf = (int)((h - h0) & 1);
         PDS_MT(p0);
         if constexpr (DIRECT) {  // half-tile h has landed: it becomes the set the walk reads (the compiler's own wait sits in front of the moves)
+            if constexpr (!YC) {  // (and the target's image, which the compiler does not follow into LDS)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                PDS_WAVE_LDS_SYNC();
+            }
 #pragma unroll
             for (int k = 0; k < NB8; ++k)
 #pragma unroll
@@ -1391,12 +1415,13 @@ int launch_grouped_mid_fused(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, 
             const char* nq_env = dev_env("PDS_GROUPED_MID_QUAD");  // (development: '0' keeps the 16 x 16 x 4 form of the second block)
             // the direct form (f64 frames, up to 30 features: PDS_MID_DIRECT, on by default; PDS_GROUPED_MID_DIRECT=0 in development builds)
             const char* dir_env = dev_env("PDS_GROUPED_MID_DIRECT");
-            const bool direct = F64 && PDS_MID_DIRECT && yc && p <= 30 && !(dir_env && dir_env[0] == '0');
+            const bool direct = F64 && PDS_MID_DIRECT && yc && !(dir_env && dir_env[0] == '0');
             if constexpr (F64) {
                 if (direct) {
                     if (p <= 18) launch_paired_c(grouped_mid_stream_kernel<2, 24, true, true, 1, T, true>, std::true_type{});
                     else if (p <= 24) launch_paired_c(grouped_mid_stream_kernel<2, 24, true, true, 0, T, true>, std::true_type{});
-                    else launch_paired_c(grouped_mid_stream_kernel<2, 32, true, true, 0, T, true>, std::true_type{});
+                    else if (p <= 30) launch_paired_c(grouped_mid_stream_kernel<2, 32, true, true, 0, T, true>, std::true_type{});
+                    else launch_paired_c(grouped_mid_stream_kernel<2, 32, true, false, 0, T, true>, std::true_type{});
                 }
             }
             if (direct) {
