@@ -533,6 +533,16 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     };
     auto issue_direct = [&](int64_t h) __attribute__((always_inline)) {
         if constexpr (DIRECT) {
+            if constexpr (!YC) {  // 31 / 32 features: the target rides beside the blocks -- its image of this half-tile in LDS, read per step
+                                  // (requested FIRST: behind the sixteen register loads the one asynchronous piece cost the wave 600 clk)
+                const lds_c yimg = sm + DY_OFF + (int)((h - h0) & 1) * kMidDirectYBytes;
+                if ((h + 1) * HR <= n_frame) {
+                    if (lane < HR / EPL) __builtin_amdgcn_global_load_lds((glb_ptr)(as_global(ybase) + h * HR), (lds_ptr)yimg, 16, 0, 0);
+                } else {
+                    const gptr<T> col = as_global(cols[p]);
+                    for (int r = lane; r < HR; r += 64) PDS_GM_LDST(yimg + r * ES) = h * HR + r < n_frame ? col[h * HR + r] : (T)0;
+                }
+            }
             if ((h + 1) * HR <= n_frame) {
 #pragma unroll
                 for (int k = 0; k < NB8; ++k)
@@ -550,15 +560,6 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
                             if (!dreal[b] || row < n_frame) v = *reinterpret_cast<gptr<double>>(dcp[b] + 64 * k + 8 * j);
                             NXT[k][b][j] = v;
                         }
-            }
-            if constexpr (!YC) {  // 31 / 32 features: the target rides beside the blocks -- its image of this half-tile in LDS, read per step
-                const lds_c yimg = sm + DY_OFF + (int)((h - h0) & 1) * kMidDirectYBytes;
-                if ((h + 1) * HR <= n_frame) {
-                    if (lane < HR / EPL) __builtin_amdgcn_global_load_lds((glb_ptr)(as_global(ybase) + h * HR), (lds_ptr)yimg, 16, 0, 0);
-                } else {
-                    const gptr<T> col = as_global(cols[p]);
-                    for (int r = lane; r < HR; r += 64) PDS_GM_LDST(yimg + r * ES) = h * HR + r < n_frame ? col[h * HR + r] : (T)0;
-                }
             }
             advance_direct();
         }
