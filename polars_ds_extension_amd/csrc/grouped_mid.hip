@@ -103,6 +103,8 @@ constexpr int kMidPairLds = DIRECT ? kMidDirectSlots * kMidDirectSlotBytes + 2 *
 // 64 zeros, with a lane stride of nothing per half-tile (no selects, no partially active load instructions)
 #define PDS_R8(v) v, v, v, v, v, v, v, v
 __device__ const double g_mid_direct_const[128] = {PDS_R8(1.0), PDS_R8(1.0), PDS_R8(1.0), PDS_R8(1.0), PDS_R8(1.0), PDS_R8(1.0), PDS_R8(1.0), PDS_R8(1.0)};
+__device__ const float g_mid_direct_const_f32[256] = {PDS_R8(1.0f), PDS_R8(1.0f), PDS_R8(1.0f), PDS_R8(1.0f), PDS_R8(1.0f), PDS_R8(1.0f), PDS_R8(1.0f), PDS_R8(1.0f),
+                                                      PDS_R8(1.0f), PDS_R8(1.0f), PDS_R8(1.0f), PDS_R8(1.0f), PDS_R8(1.0f), PDS_R8(1.0f), PDS_R8(1.0f), PDS_R8(1.0f)};
 #undef PDS_R8
 
 // PAIRED (with SPPC): a workgroup is FOUR PAIRS of waves -- waves 0 .. 3 stream (loads, matrix steps, group walk: what a wave of the
@@ -121,7 +123,7 @@ __device__ const double g_mid_direct_const[128] = {PDS_R8(1.0), PDS_R8(1.0), PDS
 // with the quad, the second the quad with itself.
 // T = float (PAIRED only): f32 frames -- 128-row half-tiles of the same 1 KiB instructions and the same LDS bytes, widened to f64 on their
 // way out of LDS; moments, slot, solve and side / marked records are f64 as for f64 frames, the coefficients are written as T.
-// DIRECT (PAIRED, YC, f64 frames; round 6): NO tile images.  The streaming wave loads the half-tile straight into the matrix instructions'
+// DIRECT (PAIRED; f64 frames of 17 .. 32 features, f32 frames of 17 .. 30; round 6): NO tile images.  The streaming wave loads the half-tile straight into the matrix instructions'
 // operand layout -- lane (feature = lane % 16, slot = lane / 16) reads 16 bytes = rows 8 k + 2 slot, + 1 of its own column for block k of
 // eight rows: sixteen columns x 64 contiguous bytes per 1 KiB load instruction, the order of the rows inside a block does not matter to a
 // sum over rows -- into one of two register sets (the half-tile being walked, the next one in flight); a 4-row step multiplies rows
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     static_assert(!PAIRED || MidPacked<SPPC ? SPPC : 1, YC>::COUNT * 8 <= (DIRECT ? kMidDirectSlotBytes : kMidSolveScratch), "the slot holds one group");
     static_assert(!YC || PAIRED, "the ones / target columns are the paired form's");
     static_assert(NQ == 0 || ((NQ == 1 || NQ == 2) && YC && NBLK == 2), "the quad form: ones and target inside the quads");
-    static_assert(!DIRECT || (PAIRED && ES == 8 && NBLK == 2 && NQ <= 1 && (YC || SPPC == 32)), "the direct form: f64 frames, two operand pieces");
+    static_assert(!DIRECT || (PAIRED && NBLK == 2 && NQ <= 1 && (YC || (SPPC == 32 && ES == 8))), "the direct form: two operand pieces; the target beside the blocks: f64 frames");
     using MD = MidDims<NBLK, ES>;
     constexpr int IMG = DIRECT ? 0 : MD::LDS_BYTES;  // bytes of tile images in front of the pair's slot
     constexpr int HR = MD::HR, GS = MD::GS, NPAIR = MD::NPAIR;
@@ -507,8 +509,11 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     }
     const int qb = (lane >> 2) & 3, qj = lane & 3;  // quad lanes: D[i = fk][j = qj] of block qb
     // ---- DIRECT: two register sets of NB8 blocks x NOP pieces x 16 bytes; the lane's address per piece moves on by one half-tile per issue
-    constexpr int NB8 = HR / 8;
-    d2u CUR[DIRECT ? NB8 : 1][NOP], NXT[DIRECT ? NB8 : 1][NOP];
+    // (f32 frames: the same 16 bytes per lane are FOUR rows -- blocks of 16 rows, four steps each, the operands widened as they are multiplied)
+    constexpr int RPL = EPL, BR = 4 * RPL, BSH = ES == 8 ? 3 : 4, NB8 = HR / BR;
+    static_assert(!DIRECT || NB8 == 8, "eight blocks per half-tile");
+    using VT = typename Tile<T>::vec;
+    VT CUR[DIRECT ? NB8 : 1][NOP], NXT[DIRECT ? NB8 : 1][NOP];
     gptr<char> dcp[NOP];
     bool dreal[NOP];
     if constexpr (DIRECT) {
@@ -516,8 +521,8 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
         for (int b = 0; b < NOP; ++b) {
             const int c = NQ ? (b == 0 ? fi : 12 + 4 * b + (fi & 3)) : 16 * b + fi;  // (as opo: the piece's column in this lane)
             const bool real = c < p || (YC && c == p + 1);                           // a frame column (YC: p + 1 = the target, p = ones); beyond: zeros
-            const char* base = real ? reinterpret_cast<const char*>(cols[c < p ? c : p]) + h0 * (int64_t)(HR * 8)
-                                    : reinterpret_cast<const char*>(g_mid_direct_const + ((YC && c == p) ? 0 : 64));
+            const char* cst = ES == 8 ? reinterpret_cast<const char*>(g_mid_direct_const) : reinterpret_cast<const char*>(g_mid_direct_const_f32);
+            const char* base = real ? reinterpret_cast<const char*>(cols[c < p ? c : p]) + h0 * (int64_t)(HR * ES) : cst + ((YC && c == p) ? 0 : HR * ES);
             dcp[b] = (gptr<char>)(base + 16 * fk);
             dreal[b] = real;
         }
@@ -529,7 +534,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     auto advance_direct = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int b = 0; b < NOP; ++b)
-            if (b == 0 || dreal[b]) dcp[b] += HR * 8;  // (the first block's columns are all frame columns)
+            if (b == 0 || dreal[b]) dcp[b] += HR * ES;  // (the first block's columns are all frame columns)
     };
     auto issue_direct = [&](int64_t h) __attribute__((always_inline)) {
         if constexpr (DIRECT) {
@@ -547,17 +552,17 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
 #pragma unroll
                 for (int k = 0; k < NB8; ++k)
 #pragma unroll
-                    for (int b = 0; b < NOP; ++b) NXT[k][b] = PDS_MID_DIRECT_LOAD(reinterpret_cast<gptr<d2u>>(dcp[b] + 64 * k));
+                    for (int b = 0; b < NOP; ++b) NXT[k][b] = PDS_MID_DIRECT_LOAD(reinterpret_cast<gptr<VT>>(dcp[b] + 64 * k));
             } else {  // the frame's last, partial half-tile: row by row, rows beyond the frame are zeros (nobody multiplies them)
 #pragma unroll
                 for (int k = 0; k < NB8; ++k)
 #pragma unroll
                     for (int b = 0; b < NOP; ++b)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            const int64_t row = h * HR + 8 * k + 2 * fk + j;
-                            double v = 0.0;
-                            if (!dreal[b] || row < n_frame) v = *reinterpret_cast<gptr<double>>(dcp[b] + 64 * k + 8 * j);
+                        for (int j = 0; j < RPL; ++j) {
+                            const int64_t row = h * HR + BR * k + RPL * fk + j;
+                            T v = (T)0;
+                            if (!dreal[b] || row < n_frame) v = *reinterpret_cast<gptr<T>>(dcp[b] + 64 * k + ES * j);
                             NXT[k][b][j] = v;
                         }
             }
@@ -634,13 +639,13 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
         if constexpr (DIRECT) {
             // Blocks of eight rows; a lane's rows in block kb are 8 kb + 2 fk + j, step j of the block multiplies row j of every lane.
             const lds_c yrow = sm + DY_OFF + buf * kMidDirectYBytes + 16 * fk;  // (without YC: the lane's two target values of block kb at + 64 kb)
-            auto two_steps = [&](const d2u (&c)[NOP], mid_d2 yv) __attribute__((always_inline)) {
+            auto two_steps = [&](const VT (&c)[NOP], mid_d2 yv) __attribute__((always_inline)) {  // (f32 frames: four)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < RPL; ++j) {
                     double a[NOP];
 #pragma unroll
-                    for (int b = 0; b < NOP; ++b) a[b] = c[b][j];
-                    mult(a, YC ? 0.0 : yv[j]);
+                    for (int b = 0; b < NOP; ++b) a[b] = (double)c[b][j];
+                    mult(a, YC ? 0.0 : yv[j & 1]);
                 }
             };
             auto y_of = [&](int kb) __attribute__((always_inline)) {
@@ -654,7 +659,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
             // and left by `break`s came back from the compiler with every accumulator moved between two register sets at each block
             // boundary, behind an s_nop that drains the matrix pipe: 170 instead of 100 clk per step.)
             auto partial = [&](int kb) __attribute__((always_inline)) {
-                d2u c8[NOP];
+                VT c8[NOP];
 #define PDS_GM_CASE(K)                                                                       \
     case K:                                                                                  \
         _Pragma("unroll") for (int b = 0; b < NOP; ++b) c8[b] = CUR[K < NB8 ? K : 0][b];    \
@@ -667,21 +672,22 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
                         break;
                 }
 #undef PDS_GM_CASE
-                const int rr = 8 * kb + 2 * fk;
+                const int rr = BR * kb + RPL * fk;
                 const bool in0 = rr >= lo && rr < hi, in1 = rr + 1 >= lo && rr + 1 < hi;
 #pragma unroll
-                for (int b = 0; b < NOP; ++b) {
-                    c8[b][0] = in0 ? c8[b][0] : 0.0;
-                    c8[b][1] = in1 ? c8[b][1] : 0.0;
+                for (int j = 0; j < RPL; ++j) {
+                    const bool in = rr + j >= lo && rr + j < hi;
+#pragma unroll
+                    for (int b = 0; b < NOP; ++b) c8[b][j] = in ? c8[b][j] : (T)0;
                 }
                 mid_d2 yv = y_of(kb);
                 yv[0] = in0 ? yv[0] : 0.0;
                 yv[1] = in1 ? yv[1] : 0.0;
                 two_steps(c8, yv);
             };
-            const int f0 = (lo + 7) >> 3, f1 = hi >> 3;
-            const int pk0 = (f0 > f1 || (lo & 7)) ? lo >> 3 : ((hi & 7) ? hi >> 3 : -1);
-            const int pk1 = (f0 <= f1 && (lo & 7) && (hi & 7)) ? hi >> 3 : -1;
+            const int f0 = (lo + BR - 1) >> BSH, f1 = hi >> BSH;
+            const int pk0 = (f0 > f1 || (lo & (BR - 1))) ? lo >> BSH : ((hi & (BR - 1)) ? hi >> BSH : -1);
+            const int pk1 = (f0 <= f1 && (lo & (BR - 1)) && (hi & (BR - 1))) ? hi >> BSH : -1;
             PDS_MT(tp13);
             for (int t = 0; t < 2; ++t) {
                 const int kb = t == 0 ? pk0 : pk1;
@@ -1416,14 +1422,12 @@ int launch_grouped_mid_fused(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, 
             const char* nq_env = dev_env("PDS_GROUPED_MID_QUAD");  // (development: '0' keeps the 16 x 16 x 4 form of the second block)
             // the direct form (f64 frames, up to 30 features: PDS_MID_DIRECT, on by default; PDS_GROUPED_MID_DIRECT=0 in development builds)
             const char* dir_env = dev_env("PDS_GROUPED_MID_DIRECT");
-            const bool direct = F64 && PDS_MID_DIRECT && yc && !(dir_env && dir_env[0] == '0');
-            if constexpr (F64) {
-                if (direct) {
-                    if (p <= 18) launch_paired_c(grouped_mid_stream_kernel<2, 24, true, true, 1, T, true>, std::true_type{});
-                    else if (p <= 24) launch_paired_c(grouped_mid_stream_kernel<2, 24, true, true, 0, T, true>, std::true_type{});
-                    else if (p <= 30) launch_paired_c(grouped_mid_stream_kernel<2, 32, true, true, 0, T, true>, std::true_type{});
-                    else launch_paired_c(grouped_mid_stream_kernel<2, 32, true, false, 0, T, true>, std::true_type{});
-                }
+            const bool direct = PDS_MID_DIRECT && yc && (F64 || p <= 30) && !(dir_env && dir_env[0] == '0');  // (f32 frames of 31 / 32 features: the LDS form)
+            if (direct) {
+                if (p <= 18) launch_paired_c(grouped_mid_stream_kernel<2, 24, true, true, 1, T, true>, std::true_type{});
+                else if (p <= 24) launch_paired_c(grouped_mid_stream_kernel<2, 24, true, true, 0, T, true>, std::true_type{});
+                else if (p <= 30) launch_paired_c(grouped_mid_stream_kernel<2, 32, true, true, 0, T, true>, std::true_type{});
+                else if constexpr (F64) launch_paired_c(grouped_mid_stream_kernel<2, 32, true, false, 0, T, true>, std::true_type{});
             }
             if (direct) {
             } else
