@@ -13,6 +13,10 @@
 #endif
 // the direct form's loads: two consecutive instructions read the two halves of the same sixteen 128-byte lines -- as non-temporal loads
 // (-DPDS_MID_DIRECT_NT) the second one misses again: 30 features 6.4 -> 7.5 ms (profiles/r06_grouped_mid_direct.txt)
+// a group that crosses a wave boundary is finished by the wave it starts in (0: summed by both waves into a side record, rounds 4 / 5)
+#ifndef PDS_MID_OWNER
+#define PDS_MID_OWNER 1
+#endif
 #ifdef PDS_MID_DIRECT_NT
 #define PDS_MID_DIRECT_LOAD(q) __builtin_nontemporal_load(q)
 #else
@@ -1111,10 +1115,18 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
         rows_in_acc = 0;
     };
     // ---- stream the half-tiles
+    // OWNER (the forms that solve in the kernel): a group belongs to the wave in whose rows it STARTS.  That wave follows it beyond the end of
+    // its own range -- at most `own_limit` rows, less than the next wave's whole range --, the wave it runs into skips it: no partial sums, no
+    // atomics, no side record, the same bits every run.  Only a group LONGER than `own_limit` (both waves judge by its offsets alone) is
+    // summed by every wave that meets it, into the side table's slot of the wave it starts in, as before.
+    constexpr bool OWNER = SPPC > 0 && PDS_MID_OWNER;
+    const int64_t own_limit = ((H1 - H0) / nwaves) * HR;
+    bool skip = OWNER && !started_here && ge - gs <= own_limit;  // the wave's first group, begun (and finished) by the wave in front
+    int64_t wend = W1, hend = h1;                                 // the rows this wave walks, the half-tiles it streams: grow with a followed group
     int64_t pos = W0;
     if constexpr (DIRECT) issue_direct(h0);
     else fetch_tile(0, h0);
-    for (int64_t h = h0; h < h1; ++h) {
+    for (int64_t h = h0; h < hend; ++h) {
         const int buf = (int)((h - h0) & 1);
         PDS_MT(p0);
         if constexpr (DIRECT) {  // half-tile h has landed: it becomes the set the walk reads (the compiler's own wait sits in front of the moves)
@@ -1146,13 +1158,13 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
         }
         PDS_MADD(11, p11);
         PDS_MT(p1);
-        if (h + 1 < h1) {
+        if (h + 1 < (OWNER ? H1 : h1)) {  // (OWNER: also the half-tile behind the wave's own range -- a group may have to be followed into it)
             if constexpr (DIRECT) issue_direct(h + 1);
             else fetch_tile(buf ^ 1, h + 1);  // (the other image was consumed one iteration ago)
         }
         PDS_MADD(1, p1);
         const int64_t R0 = h * HR;
-        const int64_t tile_end = R0 + HR < W1 ? R0 + HR : W1;
+        const int64_t tile_end = R0 + HR < wend ? R0 + HR : wend;
         // the walk inside a half-tile runs on 32-bit offsets relative to its first row (scalar compares; as int64 every `pos < tile_end`,
         // `ge < tile_end`, `pos == ge` was a vector compare + a branch on its result): the open group's end is clamped to HR + 1
         auto rel_end = [&](int64_t e) __attribute__((always_inline)) {  // e > R0
@@ -1166,7 +1178,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
         while (posr < tile_n) {
             const int seg = ger < tile_n ? ger : tile_n;
             PDS_MT(p2);
-            if (seg > posr && !(debug & 1)) consume(buf, posr, seg);
+            if (seg > posr && !(debug & 1) && !skip) consume(buf, posr, seg);
             PDS_MADD(2, p2);
             if (debug & 1) rows_in_acc += seg - posr;
             posr = seg;
@@ -1182,6 +1194,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
                     ge_next = off[g + 2 <= n_groups ? g + 2 : n_groups];
                 } while (g < n_groups && ge == gs);
                 started_here = true;
+                skip = false;
                 PDS_MADD(6, p6);
                 if (g >= n_groups) break;
                 ger = rel_end(ge);
@@ -1189,6 +1202,13 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
         }
         pos = R0 + posr;
         if (g >= n_groups) break;
+        if constexpr (OWNER) {
+            // the open group at the end of the wave's (possibly extended) rows: its own and not longer than the limit -> one more half-tile
+            if (h + 1 == hend && rows_in_acc != 0 && started_here && ge - gs <= own_limit && h + 1 < H1) {
+                wend = ge < row_end ? ge : row_end;
+                hend = h + 2;
+            }
+        }
         PDS_WAVE_LDS_SYNC();
     }
     if (rows_in_acc != 0 && g < n_groups) flush(false);  // the group that continues in the next wave's rows
