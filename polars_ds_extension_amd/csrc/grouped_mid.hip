@@ -13,6 +13,9 @@
 #endif
 // the direct form's loads: two consecutive instructions read the two halves of the same sixteen 128-byte lines -- as non-temporal loads
 // (-DPDS_MID_DIRECT_NT) the second one misses again: 30 features 6.4 -> 7.5 ms (profiles/r06_grouped_mid_direct.txt)
+#ifndef PDS_MID_DIRECT_OCTET
+#define PDS_MID_DIRECT_OCTET 1
+#endif
 // a group that crosses a wave boundary is finished by the wave it starts in (0: summed by both waves into a side record, rounds 4 / 5)
 #ifndef PDS_MID_OWNER
 #define PDS_MID_OWNER 1
@@ -150,8 +153,9 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     static_assert(!PAIRED || SPPC > 0, "pairs exist for the in-kernel solve");
     static_assert(!PAIRED || MidPacked<SPPC ? SPPC : 1, YC>::COUNT * 8 <= (DIRECT ? kMidDirectSlotBytes : kMidSolveScratch), "the slot holds one group");
     static_assert(!YC || PAIRED, "the ones / target columns are the paired form's");
-    static_assert(NQ == 0 || ((NQ == 1 || NQ == 2) && YC && NBLK == 2), "the quad form: ones and target inside the quads");
-    static_assert(!DIRECT || (PAIRED && NBLK == 2 && NQ <= 1 && (YC || (SPPC == 32 && ES == 8))), "the direct form: two operand pieces; the target beside the blocks: f64 frames");
+    static_assert(NQ == 0 || ((NQ == 1 || NQ == 2 || NQ == 3) && YC && NBLK == 2), "the quad form: ones and target inside the quads");
+    static_assert(NQ != 3 || DIRECT, "the octet is the direct form's");
+    static_assert(!DIRECT || (PAIRED && NBLK == 2 && NQ != 2 && (YC || (SPPC == 32 && ES == 8))), "the direct form: two operand pieces; the target beside the blocks: f64 frames");
     using MD = MidDims<NBLK, ES>;
     constexpr int IMG = DIRECT ? 0 : MD::LDS_BYTES;  // bytes of tile images in front of the pair's slot
     constexpr int HR = MD::HR, GS = MD::GS, NPAIR = MD::NPAIR;
@@ -500,11 +504,15 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     };
     zero_acc();
     const int fi = lane & 15, fk = lane >> 4;
-    constexpr int NOP = NQ ? 1 + NQ : NBLK;  // operand registers per step: the first block + NQ quads, or the NBLK blocks
+    // NQ = 3 (direct form, 19 .. 22 features): the second piece is an OCTET -- columns 16 .. 23 (x16 .., the ones, the target), lane fi holds
+    // column 16 + fi % 8, so the four lanes of block b hold quad b % 2 of it; rotated by four lanes inside the row (one DPP move per half)
+    // they hold the other quad.  Four v_mfma_f64_4x4x4_4b per step -- first block x octet as it is and rotated, octet x octet likewise -- give
+    // the first block's products with all eight columns and the 8 x 8 corner: 64 ticks of the matrix pipe where two 16 x 16 x 4 took 128.
+    constexpr int NOP = NQ == 3 ? 2 : (NQ ? 1 + NQ : NBLK);  // operand registers per step: the first block + NQ quads (or the octet), or the NBLK blocks
     int opo[NOP];  // the lane's operand column inside an image
 #pragma unroll
     for (int b = 0; b < NOP; ++b) {
-        const int c = NQ ? (b == 0 ? fi : 12 + 4 * b + (fi & 3)) : 16 * b + fi;  // (quad b - 1: column 16 + 4 (b - 1) + lane % 4)
+        const int c = NQ == 3 ? (b == 0 ? fi : 16 + (fi & 7)) : NQ ? (b == 0 ? fi : 12 + 4 * b + (fi & 3)) : 16 * b + fi;  // (quad b - 1: column 16 + 4 (b - 1) + lane % 4)
         opo[b] = (c & 15) * GS + (c >> 4) * HR * ES;
         if constexpr (YC) {  // columns p and p + 1: the ones image and the target's image
             if (b > 0 && c == p) opo[b] = MD::W_OFF;
@@ -523,7 +531,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     if constexpr (DIRECT) {
 #pragma unroll
         for (int b = 0; b < NOP; ++b) {
-            const int c = NQ ? (b == 0 ? fi : 12 + 4 * b + (fi & 3)) : 16 * b + fi;  // (as opo: the piece's column in this lane)
+            const int c = NQ == 3 ? (b == 0 ? fi : 16 + (fi & 7)) : NQ ? (b == 0 ? fi : 12 + 4 * b + (fi & 3)) : 16 * b + fi;  // (as opo: the piece's column in this lane)
             const bool real = c < p || (YC && c == p + 1);                           // a frame column (YC: p + 1 = the target, p = ones); beyond: zeros
             const char* cst = ES == 8 ? reinterpret_cast<const char*>(g_mid_direct_const) : reinterpret_cast<const char*>(g_mid_direct_const_f32);
             const char* base = real ? reinterpret_cast<const char*>(cols[c < p ? c : p]) + h0 * (int64_t)(HR * ES) : cst + ((YC && c == p) ? 0 : HR * ES);
@@ -612,6 +620,15 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
                 acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], a[0], acc[0], 0, 0, 0);
                 acc[1][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[0], a[1], acc[1][0], 0, 0, 0);
                 acc[2][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[1], a[1], acc[2][0], 0, 0, 0);
+            } else if constexpr (NQ == 3) {
+                const int lo32 = __double2loint(a[1]), hi32 = __double2hiint(a[1]);  // the octet, rotated by four lanes inside its row
+                const double ar = __hiloint2double(__builtin_amdgcn_update_dpp(0, hi32, 0x124 /*row_ror:4*/, 0xf, 0xf, true),
+                                                   __builtin_amdgcn_update_dpp(0, lo32, 0x124, 0xf, 0xf, true));
+                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], a[0], acc[0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[0], a[1], acc[1][0], 0, 0, 0);  // G[4 qb + fk][16 + 4 (qb % 2) + qj]
+                acc[1][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[0], ar, acc[1][1], 0, 0, 0);    // G[4 qb + fk][16 + 4 (1 - qb % 2) + qj]
+                acc[1][2] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[1], a[1], acc[1][2], 0, 0, 0);  // G[16 + 4 (qb % 2) + fk][16 + 4 (qb % 2) + qj]
+                acc[1][3] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[1], ar, acc[1][3], 0, 0, 0);    // G[16 + 4 (qb % 2) + fk][16 + 4 (1 - qb % 2) + qj]
             } else if constexpr (NQ == 2) {
                 // the 8 x 8 corner in ONE instruction: block 0 = quad 0 with itself, 1 = quad 0 with quad 1, 2 (and 3) = quad 1 with itself
                 const double ca = qb < 2 ? a[1] : a[2], cb = qb == 0 ? a[1] : a[2];
@@ -773,6 +790,28 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
         };
         int t = 0;
         const int pe = YC ? q : p;  // (YC: the blocks hold [X 1 y]' [X 1 y], which is the record)
+        if constexpr (NQ == 3) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = fk + 4 * r, j = fi;
+                if (i < pe && j < pe) put(i + (int64_t)j * q, acc[0][r]);
+            }
+            const int par = qb & 1, ri = 4 * qb + fk, c0 = 16 + 4 * par + qj, c1 = 16 + 4 * (par ^ 1) + qj;
+            if (c0 < pe) {
+                put(ri + (int64_t)c0 * q, acc[1][0]);
+                put(c0 + (int64_t)ri * q, acc[1][0]);
+            }
+            if (c1 < pe) {
+                put(ri + (int64_t)c1 * q, acc[1][1]);
+                put(c1 + (int64_t)ri * q, acc[1][1]);
+            }
+            const int rr = 16 + 4 * par + fk;
+            if (qb < 2 && rr < pe) {  // (blocks 2, 3 repeat blocks 0, 1)
+                if (c0 < pe) put(rr + (int64_t)c0 * q, acc[1][2]);  // the diagonal 4 x 4 blocks: both triangles in these lanes
+                if (c1 < pe) put(rr + (int64_t)c1 * q, acc[1][3]);  // block 0: rows 16 .., columns 20 ..; block 1: its transpose
+            }
+            return;
+        }
         if constexpr (NQ != 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -950,7 +989,19 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
             int l0 = fi, l1 = fk, l2 = qb, l3 = qj;
             if constexpr (DIRECT) asm volatile("" : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3));
             const int fi = l0, fk = l1, qb = l2, qj = l3;
-            if constexpr (NQ != 0) {
+            if constexpr (NQ == 3) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = fk + 4 * r;
+                    if (i <= fi) S[PK::tri_rt(i) - i + fi] = A[0][r];
+                }
+                const int par = qb & 1, qr = 4 * qb + fk, c0 = 16 + 4 * par + qj, c1 = 16 + 4 * (par ^ 1) + qj;
+                S[PK::tri_rt(qr) - qr + c0] = A[1][0];  // rows 0 .. 15 against the octet: all above the diagonal
+                S[PK::tri_rt(qr) - qr + c1] = A[1][1];
+                const int rr = 16 + 4 * par + fk;
+                if (qb < 2 && rr <= c0) S[PK::tri_rt(rr) - rr + c0] = A[1][2];  // the diagonal 4 x 4 blocks of the corner
+                if (qb == 0) S[PK::tri_rt(rr) - rr + c1] = A[1][3];             // rows 16 .. 19 against columns 20 .. 23
+            } else if constexpr (NQ != 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int i = fk + 4 * r;
@@ -1445,6 +1496,7 @@ int launch_grouped_mid_fused(pds_ctx* ctx, const DeviceCols<T>& dc, int n_feat, 
             const bool direct = PDS_MID_DIRECT && yc && (F64 || p <= 30) && !(dir_env && dir_env[0] == '0');  // (f32 frames of 31 / 32 features: the LDS form)
             if (direct) {
                 if (p <= 18) launch_paired_c(grouped_mid_stream_kernel<2, 24, true, true, 1, T, true>, std::true_type{});
+                else if (p <= 22 && PDS_MID_DIRECT_OCTET) launch_paired_c(grouped_mid_stream_kernel<2, 24, true, true, 3, T, true>, std::true_type{});
                 else if (p <= 24) launch_paired_c(grouped_mid_stream_kernel<2, 24, true, true, 0, T, true>, std::true_type{});
                 else if (p <= 30) launch_paired_c(grouped_mid_stream_kernel<2, 32, true, true, 0, T, true>, std::true_type{});
                 else if constexpr (F64) launch_paired_c(grouped_mid_stream_kernel<2, 32, true, false, 0, T, true>, std::true_type{});
