@@ -13,6 +13,10 @@
 #endif
 // the direct form's loads: two consecutive instructions read the two halves of the same sixteen 128-byte lines -- as non-temporal loads
 // (-DPDS_MID_DIRECT_NT) the second one misses again: 30 features 6.4 -> 7.5 ms (profiles/r06_grouped_mid_direct.txt)
+// (A/B: 1 = the lane terms of the slot / record addresses pass through an empty asm in every direct kernel, not only where registers are short)
+#ifndef PDS_MID_LAUNDER_ALL
+#define PDS_MID_LAUNDER_ALL 0
+#endif
 #ifndef PDS_MID_DIRECT_OCTET
 #define PDS_MID_DIRECT_OCTET 1
 #endif
@@ -779,10 +783,11 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     // the accumulated rows of group g -> a record at M (plain stores, or atomics into a zeroed record that other waves add to)
     // (DIRECT: the lane terms of the record / slot addresses pass through an empty asm -- as loop invariants every one of them held a
     // register for the whole stream, and the streaming wave's two operand sets leave none: spilled, they were reloaded in front of
-    // `s_waitcnt vmcnt(0)` behind the next half-tile's loads)
+    // `s_waitcnt vmcnt(0)` behind the next half-tile's loads.  The 17 / 18-feature f64 kernel has the registers: hoisted there, 3.40 -> 3.32 ms;
+    // the octet kernel has them too and is 3 % SLOWER with the addresses hoisted)
     auto put_record = [&](double* M, bool plain) __attribute__((always_inline)) {
         int l0 = fi, l1 = fk, l2 = qb, l3 = qj;
-        if constexpr (DIRECT) asm volatile("" : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3));
+        if constexpr (DIRECT && (SPPC == 32 || ES == 4 || NQ != 1 || PDS_MID_LAUNDER_ALL)) asm volatile("" : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3));
         const int fi = l0, fk = l1, qb = l2, qj = l3;
         auto put = [&](int64_t idx, double v) __attribute__((always_inline)) {
             if (plain) M[idx] = v;
@@ -987,7 +992,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
             PDS_MADD(4, tw);
             PDS_MT(tpb);
             int l0 = fi, l1 = fk, l2 = qb, l3 = qj;
-            if constexpr (DIRECT) asm volatile("" : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3));
+            if constexpr (DIRECT && (SPPC == 32 || ES == 4 || NQ != 1 || PDS_MID_LAUNDER_ALL)) asm volatile("" : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3));
             const int fi = l0, fk = l1, qb = l2, qj = l3;
             if constexpr (NQ == 3) {
 #pragma unroll
