@@ -1415,6 +1415,41 @@ def test_grouped_mid_fused_wave_boundaries(pds, orc, p, bias, l2):
     assert err[np.flatnonzero(ok) == 100][0] < F64_TOL and err[np.flatnonzero(ok) == 1500][0] < F64_TOL
 
 
+@pytest.mark.parametrize("p,dtype", [(17, np.float64), (20, np.float64), (26, np.float64), (32, np.float64), (22, np.float32)])
+def test_grouped_mid_groups_across_wave_boundaries_repeat_bit_for_bit(pds, p, dtype):
+    """Round 6: a group that crosses a wave boundary of the 17 .. 32-feature stream is finished by the wave it starts in (no partial sums
+    added by two waves in either order).  ~1000 waves over this frame, nearly every one of them with a group across its end: two calls
+    give the same bits, and every group -- the crossing ones included -- equals a plain f64 solve of its rows."""
+    rng = np.random.default_rng(6100 + p)
+    G = 40_000
+    sizes = rng.integers(p + 8, 3 * p, size=G)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    N = int(off[-1])
+    X = (rng.normal(size=(N, p)) + 0.2).astype(dtype)
+    y = (X.astype(np.float64) @ rng.normal(size=p) + 0.1 * rng.normal(size=N) + 0.3).astype(dtype)
+    if dtype == np.float32:
+        pds.config.LIN_REG_EXPR_F64 = False
+    try:
+        a, na = pds.lin_reg_by(*cols_of(X), target=dev(y), group_offsets=off, add_bias=True)
+        b, nb = pds.lin_reg_by(*cols_of(X), target=dev(y), group_offsets=off, add_bias=True)
+    finally:
+        pds.config.LIN_REG_EXPR_F64 = True
+    import torch
+    bits = torch.int64 if dtype == np.float64 else torch.int32  # (null groups carry NaN coefficients: compare the bits)
+    assert torch.equal(a.view(bits), b.view(bits)) and torch.equal(na, nb)
+    null = na.cpu().numpy().astype(bool)
+    assert null.sum() == 0 or dtype == np.float32  # (the f32 default gate is the f32 twin's own)
+    a = a.cpu().numpy().astype(np.float64)
+    worst = 0.0
+    for g in rng.integers(0, G, size=200):
+        if null[g]:
+            continue
+        Xg = np.c_[X[off[g]: off[g + 1]].astype(np.float64), np.ones(int(sizes[g]))]
+        beta = np.linalg.lstsq(Xg, y[off[g]: off[g + 1]].astype(np.float64), rcond=None)[0]
+        worst = max(worst, float(np.linalg.norm(a[g] - beta) / np.linalg.norm(beta)))
+    assert worst < (1e-4 if dtype == np.float32 else 1e-9), worst
+
+
 @pytest.mark.parametrize("p,bias", [(17, True), (20, False), (24, True), (30, True), (31, True), (32, False)])
 def test_grouped_mid_fused_f32_frames(pds, orc, f32, p, bias):
     """f32 frames with 17 .. 32 features take the paired stream too (128-row half-tiles, widened to f64 on their way out of LDS: f64
