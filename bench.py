@@ -738,7 +738,22 @@ def _other_configs(torch, pds, ctx, dev, xs, y, N, P, with_cpu=True):
         for q in (16, 17, 24, 32):
             steps[str(q)] = round(wall(lambda: pds.lin_reg_by(*cols[:q], target=y, group_offsets=off, add_bias=False, ctx=ctx)), 3)
         out["grouped_width_step"] = {"workload": f"{N // 100} groups x 100 rows, 16 / 17 / 24 / 32 f64 features (wall ms of lin_reg_by)", "ms": steps,
-                                     "ratio_17_over_16": round(steps["17"] / steps["16"], 3), "ratio_32_over_16": round(steps["32"] / steps["16"], 3)}
+                                     "ratio_17_over_16": round(steps["17"] / steps["16"], 3), "ratio_32_over_16": round(steps["32"] / steps["16"], 3),
+                                     "frac_of_hbm_peak": {k: round(N * (int(k) + 1) * 8 / (v * 1e-3) / 8e12, 3) for k, v in steps.items()}}
+        # the widths in between, and f32 frames of the same shape (the reference's f32 twins, pl_lr_f32: linear_regression_f32.rs)
+        more_steps = {}
+        for q in (20, 28, 30):
+            more_steps[str(q)] = round(wall(lambda: pds.lin_reg_by(*cols[:q], target=y, group_offsets=off, add_bias=False, ctx=ctx)), 3)
+        out["grouped_width_step"]["ms_more"] = more_steps
+        try:
+            f32_cols = [c.float() for c in cols[:30]]
+            y32 = y.float()
+            pds.config.LIN_REG_EXPR_F64 = False
+            out["grouped_width_step"]["ms_f32"] = {
+                str(q): round(wall(lambda: pds.lin_reg_by(*f32_cols[:q], target=y32, group_offsets=off, add_bias=False, ctx=ctx)), 3) for q in (17, 24, 30)}
+            del f32_cols, y32
+        finally:
+            pds.config.LIN_REG_EXPR_F64 = True
         del more, cols
         torch.cuda.empty_cache()
     except Exception as e:
