@@ -1321,7 +1321,10 @@ int launch_grouped_stream(pds_ctx* ctx, const DeviceCols<double>& dc, int p, int
 constexpr unsigned kMidMarkCap = 8192;  // records of marked systems kept for the pivoted QR; more than that: the record pipeline
 inline int64_t mid_fused_waves(const pds_ctx* ctx, int64_t n_frame, int hr = MidDims<2>::HR) {
     const int64_t w = std::min<int64_t>((int64_t)ctx->num_cus * kMidWavesPerCu, std::max<int64_t>(1, n_frame / (8 * hr)));
-    return w >= 4 ? w / 4 * 4 : w;  // (whole workgroups of four pairs: the PAIRED form)
+    // (whole workgroups of four pairs: the PAIRED form -- also for frames of fewer than four waves' worth of rows, where some pairs find no
+    // half-tile and leave at once: small f32 frames used to fall through to f32 moment RECORDS, whose 6e-8 moments cannot see a pivot
+    // of 1e-11 under a diagonal of 300 -- tools/experiments/f32_gate_case.py)
+    return w >= 4 ? w / 4 * 4 : 4;
 }
 // side table -> compact: the groups that straddle wave boundaries (slot w used iff side_list[w] >= 0), their records, row counts as
 // offsets, and the count (there are at most `waves` <= 1024 of them: every block repeats the scan, block 0 writes the lists, all blocks

@@ -46,7 +46,8 @@ while time.time() < t_end:
             Xg = X[off[g]: off[g + 1]]
             Xb = np.c_[Xg, np.ones(len(Xg))] if bias else Xg
             cnd = np.linalg.cond(Xb.T @ Xb + lam * np.eye(Xb.shape[1]))
-            # (f32 frames too small for the paired stream go through f32 moment records: the solve sees moments rounded to 6e-8)
+            # (until round 6 f32 frames too small for the paired stream went through f32 moment records -- moments rounded to 6e-8; they take the
+            #  paired stream now, the bound is kept)
             bound = max(1e-4, 2 * 6e-8 * cnd) if F32 else max(1e-10, 64 * 2.2e-16 * cnd)
             r = float(err[np.flatnonzero(ok) == g][0] / bound)
             worst = max(worst, r)
