@@ -1171,11 +1171,11 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
         rows_in_acc = 0;
     };
     // ---- stream the half-tiles
-    // OWNER (the forms that solve in the kernel): a group belongs to the wave in whose rows it STARTS.  That wave follows it beyond the end of
+    // OWNER: a group belongs to the wave in whose rows it STARTS.  That wave follows it beyond the end of
     // its own range -- at most `own_limit` rows, less than the next wave's whole range --, the wave it runs into skips it: no partial sums, no
     // atomics, no side record, the same bits every run.  Only a group LONGER than `own_limit` (both waves judge by its offsets alone) is
     // summed by every wave that meets it, into the side table's slot of the wave it starts in, as before.
-    constexpr bool OWNER = SPPC > 0 && PDS_MID_OWNER;
+    constexpr bool OWNER = PDS_MID_OWNER;  // (the record form too: whole records by plain stores, the caller zeroes only giant and empty groups' records)
     const int64_t own_limit = ((H1 - H0) / nwaves) * HR;
     bool skip = OWNER && !started_here && ge - gs <= own_limit;  // the wave's first group, begun (and finished) by the wave in front
     int64_t wend = W1, hend = h1;                                 // the rows this wave walks, the half-tiles it streams: grow with a followed group
@@ -1293,12 +1293,27 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
 #undef PDS_GM_LDST
 }
 
+// the records the stream ADDS to (a group longer than a wave's range: summed by every wave it meets) or never writes (groups without rows):
+// zeroed here, sixty-four groups per block; every other record is written once, whole, by plain stores -- the memset of all records this
+// replaces was 3.5 GB per call at 100 000 groups x 64 features.  `limit` is the kernel's own_limit, from the same numbers.
+__global__ __launch_bounds__(256) void mid_zero_records_kernel(const int64_t* __restrict__ off, int64_t n_groups, int qq, double* __restrict__ records,
+                                                               int hr, int64_t nwaves) {
+    const int64_t row_begin = off[0], row_end = off[n_groups];
+    const int64_t H0 = row_begin / hr, H1 = (row_end + hr - 1) / hr;
+    const int64_t limit = row_end > row_begin ? ((H1 - H0) / nwaves) * hr : -1;
+    for (int k = 0; k < 64; ++k) {
+        const int64_t g = (int64_t)blockIdx.x * 64 + k;
+        if (g >= n_groups) return;
+        const int64_t len = off[g + 1] - off[g];
+        if (len != 0 && len <= limit) continue;
+        for (int e = threadIdx.x; e < qq; e += 256) records[g * (int64_t)qq + e] = 0.0;
+    }
+}
 template <int NBLK>
 int launch_grouped_stream(pds_ctx* ctx, const DeviceCols<double>& dc, int p, int64_t n_frame, const int64_t* d_off, int64_t n_groups,
                           double* d_records) {
     using MD = MidDims<NBLK>;
     const int q = p + 2;
-    PDS_HIP_CHECK(hipMemsetAsync(d_records, 0, (size_t)n_groups * q * q * sizeof(double), ctx->stream));
     auto kern = grouped_mid_stream_kernel<NBLK>;
     if (MD::LDS_BYTES > 64 * 1024)
         PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, MD::LDS_BYTES));
@@ -1306,6 +1321,11 @@ int launch_grouped_stream(pds_ctx* ctx, const DeviceCols<double>& dc, int p, int
     // the sum of two partial records does not depend on their order -- results are reproducible run to run but for such giant groups
     // (the row count of the chunk is not known on the host: the frame's is an upper bound)
     const int64_t waves = std::min<int64_t>((int64_t)ctx->num_cus * kMidWavesPerCu, std::max<int64_t>(1, n_frame / (8 * MD::HR)));
+    if (PDS_MID_OWNER)
+        hipLaunchKernelGGL(mid_zero_records_kernel, dim3((unsigned)((n_groups + 63) / 64)), dim3(256), 0, ctx->stream, d_off, n_groups, q * q, d_records, MD::HR,
+                           waves);
+    else
+        PDS_HIP_CHECK(hipMemsetAsync(d_records, 0, (size_t)n_groups * q * q * sizeof(double), ctx->stream));
 #ifdef PDS_DEV_SWITCHES  // timing experiments of development builds (EXTRA=-DPDS_DEV_SWITCHES): wrong results with it
     const char* dbg = dev_env("PDS_GMID_DEBUG");
 #else
