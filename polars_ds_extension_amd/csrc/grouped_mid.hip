@@ -17,6 +17,10 @@
 #ifndef PDS_MID_LAUNDER_ALL
 #define PDS_MID_LAUNDER_ALL 0
 #endif
+// the record stream of 33 .. 64 features in the direct form (0: the LDS form of rounds 3 - 5)
+#ifndef PDS_MID_DIRECT_RECORDS
+#define PDS_MID_DIRECT_RECORDS 1
+#endif
 #ifndef PDS_MID_DIRECT_OCTET
 #define PDS_MID_DIRECT_OCTET 1
 #endif
@@ -106,6 +110,8 @@ struct MidPacked {
 // there, not in a spare register set of the streaming wave (which has none left beside its two operand sets)
 constexpr int kMidDirectSlots = 8;       // two batches of four: the solving wave takes FOUR groups at once (one per 16-lane row, one read per value)
 constexpr int kMidDirectSlotBytes = 4768;  // the upper triangle of 32 columns, X'y, the column sums, [rows, sum y], the group id: to 16 bytes
+template <int ES>
+constexpr int kMidDirectRows = ES == 8 ? 64 : 128;  // rows per half-tile of the direct form: eight blocks of 16 bytes per lane and slot
 constexpr int kMidDirectYBytes = 64 * 8 + 16;  // one image of the target's half-tile (31 / 32 features: the target does not fit the operand blocks)
 template <int NBLK, bool DIRECT = false>
 constexpr int kMidPairLds = DIRECT ? kMidDirectSlots * kMidDirectSlotBytes + 2 * kMidDirectYBytes + 64  // the direct form: a ring of slots, two target images, flag words
@@ -159,10 +165,12 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     static_assert(!YC || PAIRED, "the ones / target columns are the paired form's");
     static_assert(NQ == 0 || ((NQ == 1 || NQ == 2 || NQ == 3) && YC && NBLK == 2), "the quad form: ones and target inside the quads");
     static_assert(NQ != 3 || DIRECT, "the octet is the direct form's");
-    static_assert(!DIRECT || (PAIRED && NBLK == 2 && NQ != 2 && (YC || (SPPC == 32 && ES == 8))), "the direct form: two operand pieces; the target beside the blocks: f64 frames");
+    static_assert(!DIRECT || (PAIRED && NBLK == 2 && NQ != 2 && (YC || (SPPC == 32 && ES == 8))) || (!PAIRED && NBLK == 4 && SPPC == 0 && !YC && NQ == 0 && ES == 8),
+                  "the direct form: the paired kernels of 17 .. 32 features (the target beside the blocks: f64 frames), or the record stream of 33 .. 64");
     using MD = MidDims<NBLK, ES>;
     constexpr int IMG = DIRECT ? 0 : MD::LDS_BYTES;  // bytes of tile images in front of the pair's slot
-    constexpr int HR = MD::HR, GS = MD::GS, NPAIR = MD::NPAIR;
+    // (the direct form walks eight blocks of eight rows -- sixteen of f32 -- whatever the LDS form's half-tile of this NBLK is)
+    constexpr int HR = DIRECT ? kMidDirectRows<ES> : MD::HR, GS = MD::GS, NPAIR = MD::NPAIR;
     extern __shared__ __attribute__((aligned(16))) char gmid_lds[];
     typedef __attribute__((address_space(3))) char* lds_c;
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
     const int wv = PAIRED ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0, pairi = wv & 3;
     const bool consumer = PAIRED && wv >= 4;
     lds_c sm = (lds_c)gmid_lds + (PAIRED ? pairi * kMidPairLds<NBLK, DIRECT> : 0);
-    constexpr int NSLOT = DIRECT ? kMidDirectSlots : 1, SLOTB = DIRECT ? kMidDirectSlotBytes : kMidSolveScratch;
+    constexpr int NSLOT = DIRECT ? (PAIRED ? kMidDirectSlots : 0) : 1, SLOTB = DIRECT ? kMidDirectSlotBytes : kMidSolveScratch;
     constexpr int DY_OFF = IMG + NSLOT * SLOTB;  // (DIRECT without YC: the target's two images behind the ring)
     const lds_flag FL = (lds_flag)(sm + DY_OFF + (DIRECT ? 2 * kMidDirectYBytes : 0));  // [0] trips published, [1] trips taken, [2] stream finished
     const int64_t wave = PAIRED ? (int64_t)blockIdx.x * 4 + pairi : (int64_t)blockIdx.x, nwaves = PAIRED ? (int64_t)gridDim.x * 4 : (int64_t)gridDim.x;
@@ -847,9 +855,9 @@ __global__ __launch_bounds__(PAIRED ? 512 : 64) void grouped_mid_stream_kernel(c
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int i = 16 * I + fk + 4 * r, j = 16 * J + fi;
-                    if (i < pe && j < pe) {
-                        put(i + (int64_t)j * q, acc[t][r]);
-                        if (I != J) put(j + (int64_t)i * q, acc[t][r]);
+                    if (i < pe && j < pe) {  // (j runs with the lane: G[j][i] first -- sixteen lanes, one line; the tile's own position is the strided one)
+                        put(j + (int64_t)i * q, acc[t][r]);
+                        if (I != J) put(i + (int64_t)j * q, acc[t][r]);
                     }
                 }
                 ++t;
@@ -1314,15 +1322,19 @@ int launch_grouped_stream(pds_ctx* ctx, const DeviceCols<double>& dc, int p, int
                           double* d_records) {
     using MD = MidDims<NBLK>;
     const int q = p + 2;
-    auto kern = grouped_mid_stream_kernel<NBLK>;
-    if (MD::LDS_BYTES > 64 * 1024)
-        PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, MD::LDS_BYTES));
+    // 33 .. 64 features: the direct form too (round 6) -- a wave alone on its SIMD has the registers for two operand sets of four pieces
+    // beside ten accumulator blocks, and no tile images at all (the target's image: 1 KB)
+    constexpr bool kDirect = NBLK == 4 && PDS_MID_DIRECT_RECORDS;
+    constexpr int hr = kDirect ? kMidDirectRows<8> : MD::HR, lds_bytes = kDirect ? 2 * kMidDirectYBytes + 64 : MD::LDS_BYTES;
+    auto kern = grouped_mid_stream_kernel<NBLK, 0, false, false, 0, double, kDirect>;
+    if (lds_bytes > 64 * 1024)
+        PDS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     // a wave takes at least eight half-tiles: a group then meets at most two waves unless it is longer than a wave's whole range, and
     // the sum of two partial records does not depend on their order -- results are reproducible run to run but for such giant groups
     // (the row count of the chunk is not known on the host: the frame's is an upper bound)
-    const int64_t waves = std::min<int64_t>((int64_t)ctx->num_cus * kMidWavesPerCu, std::max<int64_t>(1, n_frame / (8 * MD::HR)));
+    const int64_t waves = std::min<int64_t>((int64_t)ctx->num_cus * kMidWavesPerCu, std::max<int64_t>(1, n_frame / (8 * hr)));
     if (PDS_MID_OWNER)
-        hipLaunchKernelGGL(mid_zero_records_kernel, dim3((unsigned)((n_groups + 63) / 64)), dim3(256), 0, ctx->stream, d_off, n_groups, q * q, d_records, MD::HR,
+        hipLaunchKernelGGL(mid_zero_records_kernel, dim3((unsigned)((n_groups + 63) / 64)), dim3(256), 0, ctx->stream, d_off, n_groups, q * q, d_records, hr,
                            waves);
     else
         PDS_HIP_CHECK(hipMemsetAsync(d_records, 0, (size_t)n_groups * q * q * sizeof(double), ctx->stream));
@@ -1331,7 +1343,7 @@ int launch_grouped_stream(pds_ctx* ctx, const DeviceCols<double>& dc, int p, int
 #else
     const char* dbg = nullptr;
 #endif
-    hipLaunchKernelGGL(kern, dim3((unsigned)waves), dim3(64), MD::LDS_BYTES, ctx->stream, dc.d_ptrs, p, n_frame, d_off, n_groups, d_records,
+    hipLaunchKernelGGL(kern, dim3((unsigned)waves), dim3(64), lds_bytes, ctx->stream, dc.d_ptrs, p, n_frame, d_off, n_groups, d_records,
                        dbg ? std::atoi(dbg) : 0, MidSolveArgs{});
     PDS_HIP_CHECK(hipGetLastError());
     return PDS_OK;
